@@ -1,0 +1,143 @@
+/*
+ * klt_gpu.h -- C ABI of libkltgpu.so, the MI355X (gfx950) backend for the PyFeatureTrack KLT
+ * hot path: pyramid build -> min-eigenvalue corner selection -> per-feature Newton tracking.
+ *
+ * The reference (TimSC/PyFeatureTrack) has no FFI of its own; its only native boundary is the
+ * Cython `def` layer (setup.py:8-9).  Each entry point below names the reference interface it
+ * replaces (file:line relative to the reference root).  Host code stays Python and binds this
+ * header with ctypes (pyfeaturetrack_amd/_abi.py; INTEGRATION.md shows the stub a reference
+ * maintainer would add).
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types cross the boundary;
+ *   - every function returns 0 on success or a negative klt_status; the message is available
+ *     from klt_last_error(); nothing exits the process or throws across the ABI
+ *     (the reference's KLTError prints and calls exit(1), error.py:12-14);
+ *   - per-feature failures are data (klt_feat.val < 0, klt.py:23-29), not errors;
+ *   - host buffers are caller-owned and only borrowed for the duration of the call;
+ *   - device buffers are owned by the context: frames live in numbered *slots* (u8/f32 image +
+ *     the three pyramids), feature lists in numbered *feature buffers*;
+ *   - a context owns one HIP stream; *_async entry points only enqueue, everything else has
+ *     completed on return.  One context per host thread / device; no shared mutable globals;
+ *   - there is NO CPU path: klt_create fails if the device cannot be opened.
+ */
+#ifndef KLT_GPU_H
+#define KLT_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KLT_ABI_VERSION 1
+#define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
+#define KLT_MAX_LEVELS 8
+
+typedef enum {
+    KLT_OK = 0,
+    KLT_ERR_ARG = -1,        /* bad argument / unsupported parameter combination */
+    KLT_ERR_DEVICE = -2,     /* HIP runtime error */
+    KLT_ERR_STATE = -3,      /* call order (e.g. tracking a slot whose pyramids were never built) */
+    KLT_ERR_NOMEM = -4
+} klt_status;
+
+/* feature status codes, klt.py:23-29 (kltState) */
+enum { KLT_TRACKED = 0, KLT_NOT_FOUND = -1, KLT_SMALL_DET = -2, KLT_MAX_ITERATIONS = -3,
+       KLT_OOB = -4, KLT_LARGE_RESIDUE = -5 };
+
+/* selection modes, selectGoodFeatures.py:11-13 */
+enum { KLT_SELECTING_ALL = 1, KLT_REPLACING_SOME = 2 };
+
+/* 16-byte feature record; replaces the KLT_Feature attribute bag (klt.py:249-263).
+ * x, y hold the reference's Python floats (integers after selection, f32-valued after tracking,
+ * -1 when lost); val is the status / int(eigenvalue). */
+typedef struct { float x, y; int32_t val; int32_t aux; } klt_feat;
+
+/* POD mirror of KLT_TrackingContext (klt.py:45-73) plus the values the reference derives from it.
+ * borderx/bordery are Python floats in the reference (e.g. 30.0, klt.py:186-189). */
+typedef struct {
+    int32_t mindist, window_width, window_height;
+    int32_t smoothBeforeSelecting, retainTrackers, nSkippedPixels;
+    int32_t max_iterations, nPyramidLevels, subsampling, use_max_residue;
+    float   min_determinant, min_displacement, step_factor, max_residue;
+    double  min_eigenvalue;
+    double  grad_sigma, smooth_sigma, pyramid_sigma;
+    double  borderx, bordery;
+} klt_params;
+
+typedef struct klt_ctx klt_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int         klt_abi_version(void);
+int         klt_device_count(void);
+int         klt_create(int device, klt_ctx **out);          /* replaces KLT_TrackingContext() device state, klt.py:43-81 */
+void        klt_destroy(klt_ctx *ctx);
+const char *klt_last_error(klt_ctx *ctx);                   /* ctx may be NULL: error of the last failed klt_create */
+int         klt_sync(klt_ctx *ctx);                         /* wait for everything enqueued on the context's stream */
+
+/* ---- parameters and taps ------------------------------------------------------------------- */
+int klt_set_params(klt_ctx *ctx, const klt_params *p);      /* klt.py:45-73, :84-128, :137-189 */
+/* FP64 taps computed on the host exactly as convolve.py:27-93 (_computeKernels).
+ * which: 0 = smoothing (sigma = smooth_sigma_fact*max(w,h)), 1 = pyramid (pyramid_sigma_fact*ss), 2 = gradient (grad_sigma) */
+int klt_set_kernels(klt_ctx *ctx, int which, const double *gauss, int ng, const double *deriv, int nd);
+
+/* ---- frames (slots) ------------------------------------------------------------------------ */
+/* replaces `np.array(img.convert("F"))`, trackFeatures.py:165,176 / selectGoodFeatures.py:190.
+ * pitch is in elements.  The upload is enqueued; the host buffer may be reused on return. */
+int klt_upload_u8(klt_ctx *ctx, int slot, const uint8_t *px, int ncols, int nrows, int pitch);
+int klt_upload_f32(klt_ctx *ctx, int slot, const float *px, int ncols, int nrows, int pitch);
+/* smooth -> pyramid -> gradients of every level: ComputeImagePyramids for one image,
+ * trackFeatures.py:165-172 + pyramid.py:37-77 + convolve.py:208-264 */
+int klt_build_pyramids_async(klt_ctx *ctx, int slot);
+int klt_build_pyramids(klt_ctx *ctx, int slot);
+/* sequentialMode: the frame-2 pyramids become frame 1 (trackFeatures.py:152-161, :401-404) */
+int klt_swap_slots(klt_ctx *ctx, int a, int b);
+
+/* ---- feature buffers ----------------------------------------------------------------------- */
+int   klt_featbuf_upload(klt_ctx *ctx, int fb, const klt_feat *src, int n);
+int   klt_featbuf_download(klt_ctx *ctx, int fb, klt_feat *dst, int n);
+void *klt_featbuf_devptr(klt_ctx *ctx, int fb);             /* device address (for RCCL gathers); NULL if unset */
+
+/* ---- selection: _KLTSelectGoodFeatures, selectGoodFeatures.py:141-261 ---------------------- */
+/* ScanImageForGoodFeatures (goodFeaturesUtils.pyx:35-73) + sort (:234-236) + _enforceMinimumDistance
+ * (:45-135).  mode KLT_REPLACING_SOME keeps features with val >= 0.  If use_pyramid != 0 the
+ * level-0 image/gradients of the slot's pyramids are reused (selectGoodFeatures.py:176-181),
+ * otherwise the slot's raw frame is smoothed/differentiated afresh (:183-197). */
+int klt_select_async(klt_ctx *ctx, int slot, int mode, int use_pyramid, int fb, int n);
+int klt_select(klt_ctx *ctx, int slot, int mode, int use_pyramid, klt_feat *inout, int n, int *n_placed);
+
+/* ---- tracking: KLTTrackFeatures, trackFeatures.py:205-409 (translation model) -------------- */
+/* _trackFeature (:67-136) + trackFeatureIterateCKLT (trackFeaturesUtils.pyx:393-459) for every
+ * live feature, coarse to fine, one wavefront per feature.  Pyramids of both slots must be built. */
+int klt_track_async(klt_ctx *ctx, int slot1, int slot2, int fb_in, int fb_out, int n);
+int klt_track(klt_ctx *ctx, int slot1, int slot2, klt_feat *inout, int n, int *n_tracked);
+
+typedef struct {
+    uint64_t features;                       /* live features entering the kernel */
+    uint64_t level_visits[KLT_MAX_LEVELS];   /* _trackFeature calls per pyramid level */
+    uint64_t iterations[KLT_MAX_LEVELS];     /* Newton iterations per pyramid level */
+} klt_track_stats;
+int klt_track_stats_reset(klt_ctx *ctx);
+int klt_track_stats_read(klt_ctx *ctx, klt_track_stats *out);
+
+/* ---- test / inspection hooks --------------------------------------------------------------- */
+/* pyramid: 0 = image, 1 = gradx, 2 = grady; dst holds level_ncols*level_nrows floats */
+int klt_level_dims(klt_ctx *ctx, int slot, int level, int *ncols, int *nrows);
+int klt_download_f32(klt_ctx *ctx, int slot, int pyramid, int level, float *dst);
+/* selection intermediates of the last klt_select*: 0 = smoothed image, 1 = gradx, 2 = grady (full frame),
+ * 3 = eigenvalue map [ny][nx] (scan order, goodFeaturesUtils.pyx:53-54).  dims via klt_select_dims. */
+int klt_select_dims(klt_ctx *ctx, int what, int *ncols, int *nrows);
+int klt_download_select_f32(klt_ctx *ctx, int what, float *dst);
+/* first `n` sorted candidates of the last klt_select* as (val, x, y), selectGoodFeatures.py:234-236 */
+int klt_download_sorted_candidates(klt_ctx *ctx, float *val, int32_t *x, int32_t *y, int n, int *n_valid);
+
+/* ---- per-kernel timing (HIP events on the context's stream) -------------------------------- */
+typedef struct { char name[32]; uint32_t launches; float total_ms; double bytes; } klt_kernel_time;
+int klt_timing_enable(klt_ctx *ctx, int on);                /* resets the accumulated figures */
+int klt_timing_read(klt_ctx *ctx, klt_kernel_time *out, int max_entries);   /* returns the entry count */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KLT_GPU_H */

@@ -1,0 +1,196 @@
+"""ctypes wrapper of oracle/libkltoracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (pyfeaturetrack_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pyfeaturetrack_amd._abi import KltFeat, KltParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libkltoracle.so")
+_lib = None
+
+FEAT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("val", np.int32), ("aux", np.int32)])
+
+
+class KoCand(C.Structure):
+    _fields_ = [("val", C.c_float), ("x", C.c_int32), ("y", C.c_int32)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "klt_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libkltoracle.so"], check=True, stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.ko_abs_sum_f32.restype = C.c_float
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def compute_kernels(sigma):
+    g = np.zeros(71, np.float64)
+    d = np.zeros(71, np.float64)
+    ng = C.c_int()
+    nd = C.c_int()
+    rc = lib().ko_compute_kernels(C.c_double(sigma), _fp(g), C.byref(ng), _fp(d), C.byref(nd))
+    if rc:
+        raise ValueError("sigma %r needs more than 71 taps" % sigma)
+    return g[:ng.value].copy(), d[:nd.value].copy()
+
+
+def convolve_separate(img, hk, vk):
+    img = np.ascontiguousarray(img, np.float32)
+    hk = np.ascontiguousarray(hk, np.float64)
+    vk = np.ascontiguousarray(vk, np.float64)
+    out = np.empty_like(img)
+    lib().ko_convolve_separate(_fp(img), img.shape[1], img.shape[0], _fp(hk), len(hk), _fp(vk), len(vk), _fp(out))
+    return out
+
+
+def smooth(img, sigma):
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.empty_like(img)
+    assert lib().ko_smooth(_fp(img), img.shape[1], img.shape[0], C.c_double(sigma), _fp(out)) == 0
+    return out
+
+
+def gradients(img, sigma):
+    img = np.ascontiguousarray(img, np.float32)
+    gx = np.empty_like(img)
+    gy = np.empty_like(img)
+    assert lib().ko_gradients(_fp(img), img.shape[1], img.shape[0], C.c_double(sigma), _fp(gx), _fp(gy)) == 0
+    return gx, gy
+
+
+def level_dims(ncols, nrows, ss, nlevels):
+    dims = []
+    for _ in range(nlevels):
+        dims.append((ncols, nrows))
+        ncols //= ss
+        nrows //= ss
+    return dims
+
+
+class Pyramids:
+    """img / gradx / grady pyramids of one frame (level-concatenated f32 buffers)."""
+    def __init__(self, params, img_f32):
+        img = np.ascontiguousarray(img_f32, np.float32)
+        self.nrows, self.ncols = img.shape
+        self.dims = level_dims(self.ncols, self.nrows, params.subsampling, params.nPyramidLevels)
+        total = sum(c * r for c, r in self.dims)
+        self.img = np.empty(total, np.float32)
+        self.gx = np.empty(total, np.float32)
+        self.gy = np.empty(total, np.float32)
+        rc = lib().ko_build_pyramid(C.byref(params), _fp(img), self.ncols, self.nrows,
+                                    _fp(self.img), _fp(self.gx), _fp(self.gy))
+        if rc:
+            raise RuntimeError("ko_build_pyramid failed: %d" % rc)
+
+    def level(self, which, l):
+        buf = {"img": self.img, "gx": self.gx, "gy": self.gy, 0: self.img, 1: self.gx, 2: self.gy}[which]
+        off = sum(c * r for c, r in self.dims[:l])
+        c, r = self.dims[l]
+        return buf[off:off + c * r].reshape(r, c)
+
+
+def scan_borders(params):
+    """(bx, by, hw, hh) as the C ints ScanImageForGoodFeatures receives (selectGoodFeatures.py:168-231)."""
+    bx = max(params.borderx, params.window_width / 2.0)
+    by = max(params.bordery, params.window_height / 2.0)
+    return int(bx), int(by), params.window_width // 2, params.window_height // 2
+
+
+def scan_good_features(gx, gy, bx, by, hw, hh, skip):
+    gx = np.ascontiguousarray(gx, np.float32)
+    gy = np.ascontiguousarray(gy, np.float32)
+    nrows, ncols = gx.shape
+    nx = C.c_int()
+    ny = C.c_int()
+    lib().ko_scan_dims(ncols, nrows, bx, by, skip, C.byref(nx), C.byref(ny))
+    val = np.empty((ny.value, nx.value), np.float32)
+    rc = lib().ko_scan_good_features(_fp(gx), _fp(gy), ncols, nrows, bx, by, hw, hh, skip, _fp(val))
+    if rc < 0:
+        raise ValueError("border smaller than window half-size + 1")
+    return val
+
+
+def sorted_candidates(val, ncols, nrows, bx, by, skip):
+    val = np.ascontiguousarray(val, np.float32)
+    cand = (KoCand * max(val.size, 1))()
+    n = lib().ko_sorted_candidates(_fp(val), ncols, nrows, bx, by, skip, cand)
+    arr = np.frombuffer(cand, dtype=np.dtype([("val", np.float32), ("x", np.int32), ("y", np.int32)]), count=n)
+    return arr.copy()
+
+
+def make_featurelist(n):
+    fl = np.zeros(n, FEAT_DTYPE)
+    fl["val"] = -1
+    fl["x"] = -1
+    fl["y"] = -1
+    return fl
+
+
+def enforce_min_distance(cand, fl, ncols, nrows, mindist, min_eigenvalue, overwrite_all):
+    cand = np.ascontiguousarray(cand)
+    return lib().ko_enforce_min_distance(_fp(cand), len(cand), _fp(fl), len(fl), ncols, nrows,
+                                         int(mindist), C.c_double(min_eigenvalue), int(bool(overwrite_all)))
+
+
+def select_good_features(params, img_f32, n, mode=1, fl=None, want_val=False):
+    img = np.ascontiguousarray(img_f32, np.float32)
+    nrows, ncols = img.shape
+    if fl is None:
+        fl = make_featurelist(n)
+    val = None
+    if want_val:
+        bx, by, _, _ = scan_borders(params)
+        nx = C.c_int()
+        ny = C.c_int()
+        lib().ko_scan_dims(ncols, nrows, bx, by, params.nSkippedPixels, C.byref(nx), C.byref(ny))
+        val = np.empty((ny.value, nx.value), np.float32)
+    rc = lib().ko_select_good_features(C.byref(params), _fp(img), ncols, nrows, mode, _fp(fl), len(fl),
+                                       _fp(val) if val is not None else None)
+    if rc < 0:
+        raise RuntimeError("ko_select_good_features failed: %d" % rc)
+    return (fl, val) if want_val else fl
+
+
+def extract_patch(img, x, y, w, h):
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.empty((h, w), np.float32)
+    rc = lib().ko_extract_patch(_fp(img), img.shape[1], img.shape[0], C.c_float(x), C.c_float(y), w, h, _fp(out))
+    if rc:
+        raise AssertionError("patch leaves the image")
+    return out
+
+
+def abs_sum_f32(a):
+    a = np.ascontiguousarray(a, np.float32)
+    return np.float32(lib().ko_abs_sum_f32(_fp(a), a.size))
+
+
+def track_features(params, pyr1, pyr2, fl, want_iters=False):
+    """In-place KLTTrackFeatures on the structured array `fl`; returns the tracked count."""
+    it = np.full((len(fl), params.nPyramidLevels), -1, np.int32) if want_iters else None
+    rc = lib().ko_track_features(C.byref(params), pyr1.ncols, pyr1.nrows,
+                                 _fp(pyr1.img), _fp(pyr1.gx), _fp(pyr1.gy),
+                                 _fp(pyr2.img), _fp(pyr2.gx), _fp(pyr2.gy),
+                                 _fp(fl), len(fl), _fp(it) if it is not None else None)
+    if rc < 0:
+        raise RuntimeError("ko_track_features failed: %d" % rc)
+    return (rc, it) if want_iters else rc

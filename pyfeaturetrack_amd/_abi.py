@@ -1,0 +1,102 @@
+"""ctypes binding of include/klt_gpu.h (libkltgpu.so).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this
+module raises -- the product path must fail loudly rather than silently compute
+somewhere else.
+"""
+import ctypes as C
+import os
+
+KLT_MAX_LEVELS = 8
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkltgpu.so")
+
+
+class KltFeat(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("val", C.c_int32), ("aux", C.c_int32)]
+
+
+class KltParams(C.Structure):
+    _fields_ = [
+        ("mindist", C.c_int32), ("window_width", C.c_int32), ("window_height", C.c_int32),
+        ("smoothBeforeSelecting", C.c_int32), ("retainTrackers", C.c_int32), ("nSkippedPixels", C.c_int32),
+        ("max_iterations", C.c_int32), ("nPyramidLevels", C.c_int32), ("subsampling", C.c_int32),
+        ("use_max_residue", C.c_int32),
+        ("min_determinant", C.c_float), ("min_displacement", C.c_float), ("step_factor", C.c_float),
+        ("max_residue", C.c_float),
+        ("min_eigenvalue", C.c_double),
+        ("grad_sigma", C.c_double), ("smooth_sigma", C.c_double), ("pyramid_sigma", C.c_double),
+        ("borderx", C.c_double), ("bordery", C.c_double),
+    ]
+
+
+class KltTrackStats(C.Structure):
+    _fields_ = [("features", C.c_uint64), ("level_visits", C.c_uint64 * KLT_MAX_LEVELS),
+                ("iterations", C.c_uint64 * KLT_MAX_LEVELS)]
+
+
+class KltKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_float), ("bytes", C.c_double)]
+
+
+# every symbol include/klt_gpu.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_I = C.c_int
+_PI = C.POINTER(C.c_int)
+SYMBOLS = {
+    "klt_abi_version": (_I, []),
+    "klt_device_count": (_I, []),
+    "klt_create": (_I, [_I, C.POINTER(_P)]),
+    "klt_destroy": (None, [_P]),
+    "klt_last_error": (C.c_char_p, [_P]),
+    "klt_sync": (_I, [_P]),
+    "klt_set_params": (_I, [_P, C.POINTER(KltParams)]),
+    "klt_set_kernels": (_I, [_P, _I, C.POINTER(C.c_double), _I, C.POINTER(C.c_double), _I]),
+    "klt_upload_u8": (_I, [_P, _I, _P, _I, _I, _I]),
+    "klt_upload_f32": (_I, [_P, _I, _P, _I, _I, _I]),
+    "klt_build_pyramids_async": (_I, [_P, _I]),
+    "klt_build_pyramids": (_I, [_P, _I]),
+    "klt_swap_slots": (_I, [_P, _I, _I]),
+    "klt_featbuf_upload": (_I, [_P, _I, _P, _I]),
+    "klt_featbuf_download": (_I, [_P, _I, _P, _I]),
+    "klt_featbuf_devptr": (_P, [_P, _I]),
+    "klt_select_async": (_I, [_P, _I, _I, _I, _I, _I]),
+    "klt_select": (_I, [_P, _I, _I, _I, _P, _I, _PI]),
+    "klt_track_async": (_I, [_P, _I, _I, _I, _I, _I]),
+    "klt_track": (_I, [_P, _I, _I, _P, _I, _PI]),
+    "klt_track_stats_reset": (_I, [_P]),
+    "klt_track_stats_read": (_I, [_P, C.POINTER(KltTrackStats)]),
+    "klt_level_dims": (_I, [_P, _I, _I, _PI, _PI]),
+    "klt_download_f32": (_I, [_P, _I, _I, _I, _P]),
+    "klt_select_dims": (_I, [_P, _I, _PI, _PI]),
+    "klt_download_select_f32": (_I, [_P, _I, _P]),
+    "klt_download_sorted_candidates": (_I, [_P, _P, _P, _P, _I, _PI]),
+    "klt_timing_enable": (_I, [_P, _I]),
+    "klt_timing_read": (_I, [_P, C.POINTER(KltKernelTime), _I]),
+}
+
+_lib = None
+
+
+class KltBackendError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load libkltgpu.so and type every entry point.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("KLT_GPU_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise KltBackendError(
+            "HIP backend %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib

@@ -1,0 +1,73 @@
+"""Deterministic synthetic frames for the benchmark configs and the parity tests.
+
+The reference ships only img0.pgm / img1.pgm (320x240).  The larger
+BASELINE.json configs (1080p, 720p batches, 2160p sequences) use a seeded
+texture with a known per-frame translation so that tracking has a known answer
+(SURVEY.md section 8(d)).
+
+The generator is numpy-only and bit-reproducible across machines:
+  * `numpy.random.default_rng(seed).random` (PCG64) is platform independent;
+  * the blur is a *circular* separable Gaussian built from `np.roll` and
+    elementwise multiply/add (no reductions, no FMA fusion);
+  * the sub-pixel shift is a bilinear blend of four rolled copies.
+Because the texture is periodic, frame k of any length sequence is defined:
+    frame_k(x, y) = base((x - k*sx) mod W, (y - k*sy) mod H)
+so every feature moves by exactly (+sx, +sy) pixels per frame.
+"""
+import math
+
+import numpy as np
+
+DEFAULT_SHIFT = (3.3, -2.1)
+
+
+def _circular_blur(a, sigma):
+    r = int(math.ceil(3.0 * sigma))
+    taps = [math.exp(-(i * i) / (2.0 * sigma * sigma)) for i in range(-r, r + 1)]
+    s = sum(taps)
+    taps = [t / s for t in taps]
+    for axis in (1, 0):
+        acc = np.zeros_like(a)
+        for i, t in zip(range(-r, r + 1), taps):
+            acc = acc + np.roll(a, i, axis=axis) * t
+        a = acc
+    return a
+
+
+def synth_base(width, height, seed, sigma=2.0):
+    """Periodic float64 texture in [0, 255] of shape (height, width)."""
+    rng = np.random.default_rng(seed)
+    a = rng.random((height, width))
+    a = _circular_blur(a, sigma)
+    lo = a.min()
+    hi = a.max()
+    return (a - lo) * (255.0 / (hi - lo))
+
+
+def shift_frame(base, dx, dy):
+    """uint8 frame whose content is `base` moved by (+dx, +dy) pixels (periodic)."""
+    # frame(x, y) = base(x - dx, y - dy); split the shift into integer + fraction
+    fx = math.floor(-dx)
+    ax = (-dx) - fx
+    fy = math.floor(-dy)
+    ay = (-dy) - fy
+    # b00(x, y) = base(x + fx, y + fy)
+    b00 = np.roll(base, (-fy, -fx), axis=(0, 1))
+    b01 = np.roll(b00, -1, axis=1)
+    b10 = np.roll(b00, -1, axis=0)
+    b11 = np.roll(b10, -1, axis=1)
+    out = (b00 * ((1.0 - ax) * (1.0 - ay)) + b01 * (ax * (1.0 - ay))
+           + b10 * ((1.0 - ax) * ay) + b11 * (ax * ay))
+    return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+
+
+def synth_frame(width, height, seed, k, shift=DEFAULT_SHIFT, base=None):
+    """Frame k of the sequence for (width, height, seed); uint8 [height, width]."""
+    if base is None:
+        base = synth_base(width, height, seed)
+    return shift_frame(base, k * shift[0], k * shift[1])
+
+
+def synth_pair(width, height, seed, shift=DEFAULT_SHIFT):
+    base = synth_base(width, height, seed)
+    return shift_frame(base, 0.0, 0.0), shift_frame(base, shift[0], shift[1])

@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the *reference itself*.
+
+Runs ONLY in the development container, where the reference lives read-only at
+/root/reference.  It copies the reference to a temp dir, builds its two Cython
+extensions there, imports it, runs it on fixed inputs and
+writes inputs + expected outputs as .npz / .json data files.  Nothing of the
+reference's source travels: the fixtures are data only.
+
+    python tests/golden/gen_golden.py            # regenerates everything
+
+Versions the vectors were produced with are recorded in golden_meta.json.
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("KLT_REFERENCE", "/root/reference")
+
+sys.path.insert(0, REPO)
+from pyfeaturetrack_amd import synth  # noqa: E402
+
+
+def build_reference():
+    d = tempfile.mkdtemp(prefix="klt_ref_")
+    for f in os.listdir(REF):
+        shutil.copy(os.path.join(REF, f), os.path.join(d, f))
+    for f in os.listdir(d):
+        os.chmod(os.path.join(d, f), 0o644)
+    subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=d, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return d
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def feats_to_arrays(fl):
+    x = np.array([float(f.x) for f in fl], np.float64)
+    y = np.array([float(f.y) for f in fl], np.float64)
+    v = np.array([int(f.val) for f in fl], np.int64)
+    return x, y, v
+
+
+def main():
+    refdir = build_reference()
+    sys.path.insert(0, refdir)
+    os.chdir(refdir)
+    warnings.simplefilter("ignore")
+    import scipy
+    import PIL
+    from PIL import Image
+    import Cython
+    import klt
+    import convolve
+    import pyramid as pyramid_mod
+    import selectGoodFeatures as sgf
+    import trackFeatures as tf
+    import trackFeaturesUtils as tfu
+    import goodFeaturesUtils as gfu
+
+    sgf.KLT_verbose = 0
+    tf.KLT_verbose = 0
+
+    meta = {
+        "python": sys.version.split()[0], "numpy": np.__version__, "scipy": scipy.__version__,
+        "pillow": PIL.__version__, "cython": Cython.__version__,
+        "reference": "TimSC/PyFeatureTrack @ /root/reference",
+    }
+
+    # ------------------------------------------------------------------ kernels
+    ker = {}
+    for sigma in (0.7, 1.0, 1.5, 1.8, 3.6, 7.2):
+        g, gd = convolve._computeKernels(sigma)
+        ker["gauss_%s" % sigma] = np.array(g, np.float64)
+        ker["deriv_%s" % sigma] = np.array(gd, np.float64)
+    np.savez(os.path.join(HERE, "kernels.npz"), **ker)
+
+    # ------------------------------------------------- tracking-context table
+    rows = []
+    for (w, how, a, b) in [(7, "search", 15, None), (7, "set", 3, 2), (7, "set", 3, 4), (7, "set", 3, 8),
+                           (15, "set", 4, 2), (15, "set", 4, 4), (7, "set", 2, 2), (7, "set", 1, 2),
+                           (5, "search", 3, None), (9, "search", 40, None), (7, "search", 100, None),
+                           (11, "search", 2, None), (15, "set", 2, 2), (7, "set", 2, 4)]:
+        tc = klt.KLT_TrackingContext()
+        tc.window_width = w
+        tc.window_height = w
+        if how == "search":
+            tc.KLTChangeTCPyramid(a)
+        else:
+            tc.nPyramidLevels = a
+            tc.subsampling = b
+        tc.KLTUpdateTCBorder()
+        rows.append({"window": w, "how": how, "a": a, "b": b, "nPyramidLevels": tc.nPyramidLevels,
+                     "subsampling": tc.subsampling, "borderx": tc.borderx, "bordery": tc.bordery,
+                     "borderx_type": type(tc.borderx).__name__})
+    with open(os.path.join(HERE, "context_table.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+
+    # ------------------------------------------------- numpy pairwise f32 sum pins
+    rng = np.random.default_rng(7)
+    pw = {}
+    for n in (1, 7, 8, 9, 49, 81, 127, 128, 129, 225, 961):
+        a = (rng.random(n) * 20).astype(np.float32)
+        pw["a_%d" % n] = a
+        pw["s_%d" % n] = np.array([np.abs(a).sum()], np.float32)
+    np.savez(os.path.join(HERE, "pairwise_sum.npz"), **pw)
+
+    # ---------------------------------------------------------------- helpers
+    class IterRecorder:
+        """Proxy for trackFeaturesUtils that records every Newton-loop call."""
+        def __init__(self):
+            self.rows = []
+
+        def __getattr__(self, name):
+            return getattr(tfu, name)
+
+        def trackFeatureIterateCKLT(self, x2, y2, gxp, gyp, ip, img2, gx2, gy2, tc):
+            r = tfu.trackFeatureIterateCKLT(x2, y2, gxp, gyp, ip, img2, gx2, gy2, tc)
+            self.rows.append((float(x2), float(y2), img2.shape[1], float(r[0]), float(r[1]), int(r[2]), int(r[3])))
+            return r
+
+    def run_track(tc, im1, im2, fl, record=None):
+        if record is not None:
+            rec = IterRecorder()
+            tf.trackFeaturesUtils = rec
+        tf.KLTTrackFeatures(tc, im1, im2, fl)
+        if record is not None:
+            tf.trackFeaturesUtils = tfu
+            record.extend(rec.rows)
+
+    def selection_internals(tc, pil_img):
+        """The arrays _KLTSelectGoodFeatures computes on the way (selectGoodFeatures.py:187-236)."""
+        tmp = np.array(pil_img.convert("F"))
+        if tc.smoothBeforeSelecting:
+            fimg = convolve.KLTComputeSmoothedImage(tmp, klt.KLTComputeSmoothSigma(tc))
+        else:
+            fimg = tmp
+        gx, gy = convolve.KLTComputeGradients(fimg, tc.grad_sigma)
+        bx, by = tc.borderx, tc.bordery
+        hw, hh = tc.window_width / 2, tc.window_height / 2
+        if bx < hw:
+            bx = hw
+        if by < hh:
+            by = hh
+        px, py, pv = gfu.ScanImageForGoodFeatures(gx, gy, bx, by, hw, hh, tc.nSkippedPixels)
+        pl = list(zip(pv, px, py))
+        pl.sort()
+        pl.reverse()
+        return fimg, gx, gy, px, py, pv, pl
+
+    def pyramids_of(tc, pil_img):
+        """img / gradx / grady pyramids exactly as ComputeImagePyramids builds them (trackFeatures.py:165-172)."""
+        ncols, nrows = pil_img.size
+        tmp = np.array(pil_img.convert("F"))
+        f = convolve.KLTComputeSmoothedImage(tmp, klt.KLTComputeSmoothSigma(tc))
+        p = pyramid_mod.KLTPyramid(ncols, nrows, int(tc.subsampling), tc.nPyramidLevels)
+        p.Compute(f, tc.pyramid_sigma_fact)
+        gxs, gys = [], []
+        for i in range(tc.nPyramidLevels):
+            gx, gy = convolve.KLTComputeGradients(p.img[i], tc.grad_sigma)
+            gxs.append(gx)
+            gys.append(gy)
+        return p.img, gxs, gys
+
+    # ------------------------------------------------------- cfg-1: img0/img1
+    shutil.copy(os.path.join(REF, "img0.pgm"), os.path.join(HERE, "img0.pgm"))
+    shutil.copy(os.path.join(REF, "img1.pgm"), os.path.join(HERE, "img1.pgm"))
+    img0 = Image.open(os.path.join(REF, "img0.pgm"))
+    img1 = Image.open(os.path.join(REF, "img1.pgm"))
+
+    out = {}
+    tc = klt.KLT_TrackingContext()
+    fimg, gx, gy, px, py, pv, pl = selection_internals(tc, img0)
+    out["sel_smooth"] = fimg
+    out["sel_gx"] = gx
+    out["sel_gy"] = gy
+    nx = len(range(int(tc.borderx), 320 - int(tc.borderx)))
+    out["sel_val"] = np.array(pv, np.float32).reshape(-1, nx)
+    # descending candidate order (prefix) as (val, x, y)
+    out["sel_sorted_val"] = np.array([p[0] for p in pl[:20000]], np.float32)
+    out["sel_sorted_x"] = np.array([p[1] for p in pl[:20000]], np.int32)
+    out["sel_sorted_y"] = np.array([p[2] for p in pl[:20000]], np.int32)
+    for n in (50, 100, 300):
+        fl = sgf.KLTSelectGoodFeatures(tc, img0, n)
+        x, y, v = feats_to_arrays(fl)
+        out["sel%d_x" % n], out["sel%d_y" % n], out["sel%d_val" % n] = x, y, v
+    for name, im in (("p0", img0), ("p1", img1)):
+        imgs, gxs, gys = pyramids_of(tc, im)
+        for l in range(tc.nPyramidLevels):
+            out["%s_img_%d" % (name, l)] = imgs[l]
+            out["%s_gx_%d" % (name, l)] = gxs[l]
+            out["%s_gy_%d" % (name, l)] = gys[l]
+    # track 100 features img0 -> img1, with and without the residue test
+    for tag, mr in (("r10", 10.0), ("rnone", None)):
+        tc = klt.KLT_TrackingContext()
+        tc.max_residue = mr
+        fl = sgf.KLTSelectGoodFeatures(tc, img0, 100)
+        rec = []
+        run_track(tc, img0, img1, fl, rec)
+        x, y, v = feats_to_arrays(fl)
+        out["trk100_%s_x" % tag], out["trk100_%s_y" % tag], out["trk100_%s_val" % tag] = x, y, v
+        out["trk100_%s_iter" % tag] = np.array(rec, np.float64)
+    # retainTrackers
+    tc = klt.KLT_TrackingContext()
+    tc.max_residue = 10.0
+    tc.retainTrackers = True
+    fl = sgf.KLTSelectGoodFeatures(tc, img0, 100)
+    run_track(tc, img0, img1, fl)
+    out["trk100_retain_x"], out["trk100_retain_y"], out["trk100_retain_val"] = feats_to_arrays(fl)
+    # example1-style ping-pong, state after each of the first 6 calls (n=50, max_residue=10)
+    tc = klt.KLT_TrackingContext()
+    tc.max_residue = 10.0
+    fl = sgf.KLTSelectGoodFeatures(tc, img0, 50)
+    for k in range(6):
+        if k % 2 == 0:
+            run_track(tc, img0, img1, fl)
+        else:
+            run_track(tc, img1, img0, fl)
+        x, y, v = feats_to_arrays(fl)
+        out["pp50_%d_x" % k], out["pp50_%d_y" % k], out["pp50_%d_val" % k] = x, y, v
+    # sequential mode: track(img0,img1) then track(<ignored>,img0) reusing pyramid_last
+    tc = klt.KLT_TrackingContext()
+    tc.max_residue = 10.0
+    tc.sequentialMode = True
+    fl = sgf.KLTSelectGoodFeatures(tc, img0, 50)
+    run_track(tc, img0, img1, fl)
+    out["seq50_0_x"], out["seq50_0_y"], out["seq50_0_val"] = feats_to_arrays(fl)
+    run_track(tc, img0, img0, fl)   # img1 argument content is ignored in sequential mode
+    out["seq50_1_x"], out["seq50_1_y"], out["seq50_1_val"] = feats_to_arrays(fl)
+    # REPLACING_SOME pinned at the _enforceMinimumDistance level (SURVEY a-23):
+    # take the list after a track (some lost), candidates from img1, overwriteAllFeatures=False
+    tc = klt.KLT_TrackingContext()
+    tc.max_residue = 10.0
+    fl = sgf.KLTSelectGoodFeatures(tc, img0, 100)
+    run_track(tc, img0, img1, fl)
+    out["repl_in_x"], out["repl_in_y"], out["repl_in_val"] = feats_to_arrays(fl)
+    _, _, _, _, _, _, pl1 = selection_internals(tc, img1)
+    sgf._enforceMinimumDistance(pl1, fl, 320, 240, tc.mindist, tc.min_eigenvalue, False)
+    out["repl_out_x"], out["repl_out_y"], out["repl_out_val"] = feats_to_arrays(fl)
+    # nSkippedPixels = 2, mindist 15, no pre-smoothing
+    tc = klt.KLT_TrackingContext()
+    tc.nSkippedPixels = 2
+    tc.mindist = 15
+    tc.smoothBeforeSelecting = False
+    fl = sgf.KLTSelectGoodFeatures(tc, img0, 60)
+    out["selskip_x"], out["selskip_y"], out["selskip_val"] = feats_to_arrays(fl)
+    np.savez_compressed(os.path.join(HERE, "cfg1.npz"), **out)
+
+    # ------------------------------------ synthetic odd-sized sequence 251x187
+    W, H, SEED = 251, 187, 11
+    base = synth.synth_base(W, H, SEED)
+    frames = [synth.synth_frame(W, H, SEED, k, shift=(1.3, -0.8), base=base) for k in range(3)]
+    pil = [Image.fromarray(f, "L") for f in frames]
+    out = {"frame0_sha": np.frombuffer(bytes.fromhex(sha(frames[0])), np.uint8),
+           "frame1_sha": np.frombuffer(bytes.fromhex(sha(frames[1])), np.uint8),
+           "frame2_sha": np.frombuffer(bytes.fromhex(sha(frames[2])), np.uint8)}
+    tc = klt.KLT_TrackingContext()
+    tc.nPyramidLevels = 3
+    tc.subsampling = 2
+    tc.KLTUpdateTCBorder()
+    tc.max_residue = 10.0
+    fimg, gx, gy, px, py, pv, pl = selection_internals(tc, pil[0])
+    nx = len(range(int(tc.borderx), W - int(tc.borderx)))
+    out["sel_val"] = np.array(pv, np.float32).reshape(-1, nx)
+    out["sel_gx_sha"] = np.frombuffer(bytes.fromhex(sha(gx)), np.uint8)
+    out["sel_gy_sha"] = np.frombuffer(bytes.fromhex(sha(gy)), np.uint8)
+    fl = sgf.KLTSelectGoodFeatures(tc, pil[0], 60)
+    out["sel60_x"], out["sel60_y"], out["sel60_val"] = feats_to_arrays(fl)
+    for name, im in (("p0", pil[0]), ("p1", pil[1])):
+        imgs, gxs, gys = pyramids_of(tc, im)
+        for l in range(tc.nPyramidLevels):
+            for nm, arr in (("img", imgs[l]), ("gx", gxs[l]), ("gy", gys[l])):
+                out["%s_%s_%d_sha" % (name, nm, l)] = np.frombuffer(bytes.fromhex(sha(arr)), np.uint8)
+                if l == tc.nPyramidLevels - 1:
+                    out["%s_%s_%d" % (name, nm, l)] = arr
+    tc.sequentialMode = True
+    rec = []
+    run_track(tc, pil[0], pil[1], fl, rec)
+    out["trk_0_x"], out["trk_0_y"], out["trk_0_val"] = feats_to_arrays(fl)
+    out["trk_0_iter"] = np.array(rec, np.float64)
+    run_track(tc, pil[1], pil[2], fl)
+    out["trk_1_x"], out["trk_1_y"], out["trk_1_val"] = feats_to_arrays(fl)
+    # 15x15 window, 2 levels / ss 2, translation only, no residue test
+    tc = klt.KLT_TrackingContext()
+    tc.window_width = 15
+    tc.window_height = 15
+    tc.nPyramidLevels = 2
+    tc.subsampling = 2
+    tc.KLTUpdateTCBorder()
+    out["w15_border"] = np.array([tc.borderx], np.float64)
+    fl = sgf.KLTSelectGoodFeatures(tc, pil[0], 25)
+    out["w15_sel_x"], out["w15_sel_y"], out["w15_sel_val"] = feats_to_arrays(fl)
+    tc.max_residue = 12.0
+    run_track(tc, pil[0], pil[1], fl)
+    out["w15_trk_x"], out["w15_trk_y"], out["w15_trk_val"] = feats_to_arrays(fl)
+    np.savez_compressed(os.path.join(HERE, "synth251.npz"), **out)
+
+    with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    shutil.rmtree(refdir, ignore_errors=True)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
