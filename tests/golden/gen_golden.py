@@ -116,6 +116,20 @@ def main():
         pw["s_%d" % n] = np.array([np.abs(a).sum()], np.float32)
     np.savez(os.path.join(HERE, "pairwise_sum.npz"), **pw)
 
+    # ------------------------------------------- bilinear patch extraction pins
+    rng = np.random.default_rng(3)
+    pimg = (rng.random((50, 64)) * 255).astype(np.float32)
+    pt = {"img": pimg}
+    for w, cnt in ((7, 300), (15, 100)):
+        xs = (10 + rng.random(cnt) * 40).astype(np.float32)
+        ys = (10 + rng.random(cnt) * 28).astype(np.float32)
+        xs[:5] = np.floor(xs[:5])          # integer positions (ax = 0)
+        pt["x_%d" % w] = xs
+        pt["y_%d" % w] = ys
+        pt["patch_%d" % w] = np.stack([tfu.extractImagePatchSlow(pimg, float(x), float(y), w, w)
+                                       for x, y in zip(xs, ys)])
+    np.savez_compressed(os.path.join(HERE, "patches.npz"), **pt)
+
     # ---------------------------------------------------------------- helpers
     class IterRecorder:
         """Proxy for trackFeaturesUtils that records every Newton-loop call."""

@@ -1,0 +1,163 @@
+"""The oracle (oracle/klt_oracle.c) against golden vectors produced by the reference itself.
+
+Everything here is bit-exact: the oracle is only trusted as the checker for the HIP path
+because it reproduces the reference's outputs on these fixtures.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import klt_oracle as ko
+from helpers import make_tc, params_from_tc, synth251_frames, sha_bytes, feats_equal
+
+
+def test_kernels(golden_dir):
+    k = np.load(os.path.join(golden_dir, "kernels.npz"))
+    for s in (0.7, 1.0, 1.5, 1.8, 3.6, 7.2):
+        g, d = ko.compute_kernels(s)
+        assert np.array_equal(g, k["gauss_%s" % s])
+        assert np.array_equal(d, k["deriv_%s" % s])
+
+
+def test_pairwise_abs_sum(golden_dir):
+    p = np.load(os.path.join(golden_dir, "pairwise_sum.npz"))
+    for n in (1, 7, 8, 9, 49, 81, 127, 128, 129, 225, 961):
+        assert ko.abs_sum_f32(p["a_%d" % n]) == p["s_%d" % n][0], n
+
+
+def test_patch_extraction(golden_dir):
+    p = np.load(os.path.join(golden_dir, "patches.npz"))
+    for w in (7, 15):
+        for x, y, ref in zip(p["x_%d" % w], p["y_%d" % w], p["patch_%d" % w]):
+            assert np.array_equal(ko.extract_patch(p["img"], x, y, w, w), ref)
+
+
+def test_selection_internals_cfg1(cfg1, img0):
+    p = params_from_tc(make_tc())
+    sm = ko.smooth(img0.astype(np.float32), p.smooth_sigma)
+    assert np.array_equal(sm, cfg1["sel_smooth"])
+    gx, gy = ko.gradients(sm, p.grad_sigma)
+    assert np.array_equal(gx, cfg1["sel_gx"]) and np.array_equal(gy, cfg1["sel_gy"])
+    bx, by, hw, hh = ko.scan_borders(p)
+    assert (bx, by, hw, hh) == (30, 30, 3, 3)
+    val = ko.scan_good_features(gx, gy, bx, by, hw, hh, 0)
+    assert np.array_equal(val, cfg1["sel_val"])
+    c = ko.sorted_candidates(val, 320, 240, bx, by, 0)
+    assert np.array_equal(c["val"][:20000], cfg1["sel_sorted_val"])
+    assert np.array_equal(c["x"][:20000], cfg1["sel_sorted_x"])
+    assert np.array_equal(c["y"][:20000], cfg1["sel_sorted_y"])
+
+
+@pytest.mark.parametrize("n", [50, 100, 300])
+def test_select_cfg1(cfg1, img0, n):
+    fl = ko.select_good_features(params_from_tc(make_tc()), img0.astype(np.float32), n)
+    assert feats_equal(fl, cfg1["sel%d_x" % n], cfg1["sel%d_y" % n], cfg1["sel%d_val" % n])
+
+
+def test_select_skip_mindist_nosmooth(cfg1, img0):
+    tc = make_tc(nSkippedPixels=2, mindist=15, smoothBeforeSelecting=False)
+    fl = ko.select_good_features(params_from_tc(tc), img0.astype(np.float32), 60)
+    assert feats_equal(fl, cfg1["selskip_x"], cfg1["selskip_y"], cfg1["selskip_val"])
+
+
+def test_pyramids_cfg1(cfg1, img0, img1):
+    p = params_from_tc(make_tc())
+    for name, im in (("p0", img0), ("p1", img1)):
+        P = ko.Pyramids(p, im.astype(np.float32))
+        for l in range(2):
+            for w in ("img", "gx", "gy"):
+                assert np.array_equal(P.level(w, l), cfg1["%s_%s_%d" % (name, w, l)]), (name, w, l)
+
+
+@pytest.mark.parametrize("tag,mr", [("r10", 10.0), ("rnone", None)])
+def test_track_cfg1(cfg1, img0, img1, tag, mr):
+    p = params_from_tc(make_tc(max_residue=mr))
+    fl = ko.select_good_features(p, img0.astype(np.float32), 100)
+    P0, P1 = ko.Pyramids(p, img0.astype(np.float32)), ko.Pyramids(p, img1.astype(np.float32))
+    _, it = ko.track_features(p, P0, P1, fl, want_iters=True)
+    assert feats_equal(fl, cfg1["trk100_%s_x" % tag], cfg1["trk100_%s_y" % tag], cfg1["trk100_%s_val" % tag])
+    # Newton iterations recorded per trackFeatureIterateCKLT call (coarse level first per feature)
+    rec = cfg1["trk100_%s_iter" % tag]
+    mine = [int(v) for row in it for v in row[::-1] if v >= 0]
+    assert mine == [int(v) for v in rec[:, 6]]
+
+
+def test_track_retain(cfg1, img0, img1):
+    p = params_from_tc(make_tc(max_residue=10.0, retainTrackers=True))
+    fl = ko.select_good_features(p, img0.astype(np.float32), 100)
+    ko.track_features(p, ko.Pyramids(p, img0.astype(np.float32)), ko.Pyramids(p, img1.astype(np.float32)), fl)
+    assert feats_equal(fl, cfg1["trk100_retain_x"], cfg1["trk100_retain_y"], cfg1["trk100_retain_val"])
+
+
+def test_pingpong_cfg1(cfg1, img0, img1):
+    p = params_from_tc(make_tc(max_residue=10.0))
+    P = [ko.Pyramids(p, img0.astype(np.float32)), ko.Pyramids(p, img1.astype(np.float32))]
+    fl = ko.select_good_features(p, img0.astype(np.float32), 50)
+    for k in range(6):
+        ko.track_features(p, P[k % 2], P[(k + 1) % 2], fl)
+        assert feats_equal(fl, cfg1["pp50_%d_x" % k], cfg1["pp50_%d_y" % k], cfg1["pp50_%d_val" % k]), k
+
+
+def test_replacing_some_cfg1(cfg1, img1):
+    """_enforceMinimumDistance(overwriteAllFeatures=False) on a list with lost features (SURVEY a-23)."""
+    p = params_from_tc(make_tc(max_residue=10.0))
+    fl = ko.make_featurelist(100)
+    fl["x"], fl["y"], fl["val"] = cfg1["repl_in_x"], cfg1["repl_in_y"], cfg1["repl_in_val"]
+    fl = ko.select_good_features(p, img1.astype(np.float32), 100, mode=2, fl=fl)
+    assert feats_equal(fl, cfg1["repl_out_x"], cfg1["repl_out_y"], cfg1["repl_out_val"])
+
+
+def test_synth_frames_reproducible(synth251):
+    fr = synth251_frames()
+    for k in range(3):
+        assert np.array_equal(sha_bytes(fr[k]), synth251["frame%d_sha" % k])
+
+
+def test_synth251_select_pyramids_track(synth251):
+    fr = [f.astype(np.float32) for f in synth251_frames()]
+    tc = make_tc(levels=3, ss=2, max_residue=10.0)
+    assert tc.borderx == 34.0
+    p = params_from_tc(tc)
+    fl, val = ko.select_good_features(p, fr[0], 60, want_val=True)
+    assert np.array_equal(val, synth251["sel_val"])
+    assert feats_equal(fl, synth251["sel60_x"], synth251["sel60_y"], synth251["sel60_val"])
+    P = [ko.Pyramids(p, f) for f in fr]
+    for name, pyr in (("p0", P[0]), ("p1", P[1])):
+        for l in range(3):
+            for w in ("img", "gx", "gy"):
+                assert np.array_equal(sha_bytes(pyr.level(w, l)), synth251["%s_%s_%d_sha" % (name, w, l)]), (name, w, l)
+    assert P[0].dims == [(251, 187), (125, 93), (62, 46)]
+    ko.track_features(p, P[0], P[1], fl)
+    assert feats_equal(fl, synth251["trk_0_x"], synth251["trk_0_y"], synth251["trk_0_val"])
+    ko.track_features(p, P[1], P[2], fl)            # sequential mode: frame-2 pyramids become frame 1
+    assert feats_equal(fl, synth251["trk_1_x"], synth251["trk_1_y"], synth251["trk_1_val"])
+
+
+def test_synth251_window15(synth251):
+    fr = [f.astype(np.float32) for f in synth251_frames()]
+    tc = make_tc(levels=2, ss=2, window=15)
+    assert tc.borderx == synth251["w15_border"][0]
+    p = params_from_tc(tc)
+    fl = ko.select_good_features(p, fr[0], 25)
+    assert feats_equal(fl, synth251["w15_sel_x"], synth251["w15_sel_y"], synth251["w15_sel_val"])
+    tc.max_residue = 12.0
+    p = params_from_tc(tc)
+    ko.track_features(p, ko.Pyramids(p, fr[0]), ko.Pyramids(p, fr[1]), fl)
+    assert feats_equal(fl, synth251["w15_trk_x"], synth251["w15_trk_y"], synth251["w15_trk_val"])
+
+
+def test_context_table(golden_dir):
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    for row in json.load(open(os.path.join(golden_dir, "context_table.json"))):
+        tc = KLT_TrackingContext()
+        tc.window_width = tc.window_height = row["window"]
+        if row["how"] == "search":
+            tc.KLTChangeTCPyramid(row["a"])
+        else:
+            tc.nPyramidLevels, tc.subsampling = row["a"], row["b"]
+        tc.KLTUpdateTCBorder()
+        assert (tc.nPyramidLevels, tc.subsampling) == (row["nPyramidLevels"], row["subsampling"])
+        assert tc.borderx == row["borderx"] and tc.bordery == row["bordery"]
+        assert type(tc.borderx).__name__ == row["borderx_type"]
