@@ -132,6 +132,13 @@ int klt_download_select_f32(klt_ctx *ctx, int what, float *dst);
 /* first `n` sorted candidates of the last klt_select* as (val, x, y), selectGoodFeatures.py:234-236 */
 int klt_download_sorted_candidates(klt_ctx *ctx, float *val, int32_t *x, int32_t *y, int n, int *n_valid);
 
+/* ---- standalone convolutions (host buffers in / out, synchronous) ---------------------------- */
+/* KLTComputeSmoothedImage, convolve.py:254-264: _convolveSeparate(img, gauss, gauss) */
+int klt_smooth_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, const double *gauss, int ng, float *dst);
+/* KLTComputeGradients, convolve.py:226-248: gradx = (deriv, gauss), grady = (gauss, deriv) */
+int klt_gradients_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, const double *gauss, int ng,
+                      const double *deriv, int nd, float *gradx, float *grady);
+
 /* ---- per-kernel timing (HIP events on the context's stream) -------------------------------- */
 typedef struct { char name[32]; uint32_t launches; float total_ms; double bytes; } klt_kernel_time;
 int klt_timing_enable(klt_ctx *ctx, int on);                /* resets the accumulated figures */

@@ -1,0 +1,215 @@
+"""Thin object wrapper over the C ABI (include/klt_gpu.h) -- one `Context` per device.
+
+Everything numeric happens behind the ABI in hand-written HIP kernels; this module only
+marshals numpy buffers and keeps the tracking-context parameters in sync.  There is no
+CPU fallback: creating a Context without a usable MI355X raises KltBackendError.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._abi import (KLT_MAX_LEVELS, KltBackendError, KltFeat, KltKernelTime, KltParams, KltTrackStats,
+                   load_library)
+from .params import params_from_tc, taps_from_params
+
+FEAT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("val", np.int32), ("aux", np.int32)])
+assert FEAT_DTYPE.itemsize == C.sizeof(KltFeat)
+
+SELECTING_ALL = 1
+REPLACING_SOME = 2
+
+
+def _dp(a):
+    return (C.c_double * len(a))(*a)
+
+
+class Context:
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.klt_create(int(device), C.byref(h))
+        if rc != 0:
+            msg = self._lib.klt_last_error(None)
+            raise KltBackendError("klt_create(device=%d) failed (%d): %s" % (device, rc, (msg or b"").decode()))
+        self._h = h
+        self.device = int(device)
+        self._params_key = None
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.klt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            msg = self._lib.klt_last_error(self._h)
+            raise KltBackendError("libkltgpu error %d: %s" % (rc, (msg or b"").decode()))
+        return rc
+
+    def sync(self):
+        self._check(self._lib.klt_sync(self._h))
+
+    # ---------------------------------------------------------------- parameters
+    def set_params(self, p):
+        """p: KltParams.  Taps for the three sigmas are generated on the host (convolve.py:27-93)."""
+        key = bytes(p)
+        if key == self._params_key:
+            return
+        self._check(self._lib.klt_set_params(self._h, C.byref(p)))
+        for which, (g, d) in enumerate(taps_from_params(p)):
+            self._check(self._lib.klt_set_kernels(self._h, which, _dp(g), len(g), _dp(d), len(d)))
+        self._params_key = key
+        self.params = p
+
+    def configure(self, tc):
+        self.set_params(params_from_tc(tc))
+
+    # -------------------------------------------------------------------- frames
+    def upload(self, slot, img):
+        """img: 2-D uint8 or float32 array (the reference's `np.array(pil.convert("F"))`)."""
+        a = np.asarray(img)
+        if a.ndim != 2:
+            raise ValueError("expected a 2-D image")
+        if a.dtype == np.uint8:
+            a = np.ascontiguousarray(a)
+            self._check(self._lib.klt_upload_u8(self._h, slot, a.ctypes.data, a.shape[1], a.shape[0], a.shape[1]))
+        else:
+            a = np.ascontiguousarray(a, np.float32)
+            self._check(self._lib.klt_upload_f32(self._h, slot, a.ctypes.data, a.shape[1], a.shape[0], a.shape[1]))
+
+    def build_pyramids(self, slot, sync=True):
+        fn = self._lib.klt_build_pyramids if sync else self._lib.klt_build_pyramids_async
+        self._check(fn(self._h, slot))
+
+    def swap_slots(self, a, b):
+        self._check(self._lib.klt_swap_slots(self._h, a, b))
+
+    def level_dims(self, slot, level):
+        nc, nr = C.c_int(), C.c_int()
+        self._check(self._lib.klt_level_dims(self._h, slot, level, C.byref(nc), C.byref(nr)))
+        return nc.value, nr.value
+
+    def download_level(self, slot, pyramid, level):
+        nc, nr = self.level_dims(slot, level)
+        out = np.empty((nr, nc), np.float32)
+        self._check(self._lib.klt_download_f32(self._h, slot, pyramid, level, out.ctypes.data))
+        return out
+
+    # ------------------------------------------------------------------ features
+    def featbuf_upload(self, fb, fl):
+        fl = np.ascontiguousarray(fl, FEAT_DTYPE)
+        self._check(self._lib.klt_featbuf_upload(self._h, fb, fl.ctypes.data, len(fl)))
+
+    def featbuf_download(self, fb, n):
+        out = np.empty(n, FEAT_DTYPE)
+        self._check(self._lib.klt_featbuf_download(self._h, fb, out.ctypes.data, n))
+        return out
+
+    def featbuf_devptr(self, fb):
+        return self._lib.klt_featbuf_devptr(self._h, fb)
+
+    # ----------------------------------------------------------------- selection
+    def select(self, slot, n, mode=SELECTING_ALL, fl=None, use_pyramid=False):
+        """Returns (structured feature array, number placed)."""
+        if fl is None:
+            fl = np.zeros(n, FEAT_DTYPE)
+            fl["x"] = -1
+            fl["y"] = -1
+            fl["val"] = -1
+        fl = np.ascontiguousarray(fl, FEAT_DTYPE)
+        placed = C.c_int()
+        self._check(self._lib.klt_select(self._h, slot, mode, int(bool(use_pyramid)), fl.ctypes.data, len(fl), C.byref(placed)))
+        return fl, placed.value
+
+    def select_async(self, slot, mode, use_pyramid, fb, n):
+        self._check(self._lib.klt_select_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))
+
+    def select_intermediate(self, what):
+        nc, nr = C.c_int(), C.c_int()
+        self._check(self._lib.klt_select_dims(self._h, what, C.byref(nc), C.byref(nr)))
+        out = np.empty((nr.value, nc.value), np.float32)
+        self._check(self._lib.klt_download_select_f32(self._h, what, out.ctypes.data))
+        return out
+
+    def sorted_candidates(self, n):
+        val = np.empty(n, np.float32)
+        x = np.empty(n, np.int32)
+        y = np.empty(n, np.int32)
+        nv = C.c_int()
+        self._check(self._lib.klt_download_sorted_candidates(self._h, val.ctypes.data, x.ctypes.data, y.ctypes.data, n, C.byref(nv)))
+        return val[:nv.value], x[:nv.value], y[:nv.value]
+
+    # ------------------------------------------------------------------ tracking
+    def track(self, slot1, slot2, fl):
+        """In-place on a copy: returns (structured feature array, number still tracked)."""
+        fl = np.ascontiguousarray(fl, FEAT_DTYPE).copy()
+        k = C.c_int()
+        self._check(self._lib.klt_track(self._h, slot1, slot2, fl.ctypes.data, len(fl), C.byref(k)))
+        return fl, k.value
+
+    def track_async(self, slot1, slot2, fb_in, fb_out, n):
+        self._check(self._lib.klt_track_async(self._h, slot1, slot2, fb_in, fb_out, n))
+
+    def track_stats_reset(self):
+        self._check(self._lib.klt_track_stats_reset(self._h))
+
+    def track_stats(self):
+        s = KltTrackStats()
+        self._check(self._lib.klt_track_stats_read(self._h, C.byref(s)))
+        return {"features": int(s.features),
+                "level_visits": [int(v) for v in s.level_visits],
+                "iterations": [int(v) for v in s.iterations]}
+
+    # -------------------------------------------------- standalone convolutions
+    def smooth(self, img, gauss):
+        img = np.ascontiguousarray(img, np.float32)
+        out = np.empty_like(img)
+        self._check(self._lib.klt_smooth_f32(self._h, img.ctypes.data, img.shape[1], img.shape[0], _dp(gauss), len(gauss),
+                                             out.ctypes.data))
+        return out
+
+    def gradients(self, img, gauss, deriv):
+        img = np.ascontiguousarray(img, np.float32)
+        gx = np.empty_like(img)
+        gy = np.empty_like(img)
+        self._check(self._lib.klt_gradients_f32(self._h, img.ctypes.data, img.shape[1], img.shape[0], _dp(gauss), len(gauss),
+                                                _dp(deriv), len(deriv), gx.ctypes.data, gy.ctypes.data))
+        return gx, gy
+
+    # -------------------------------------------------------------------- timing
+    def timing_enable(self, on=True):
+        self._check(self._lib.klt_timing_enable(self._h, int(bool(on))))
+
+    def timing_read(self):
+        buf = (KltKernelTime * 32)()
+        n = self._check(self._lib.klt_timing_read(self._h, buf, 32))
+        return [{"name": buf[i].name.decode(), "launches": int(buf[i].launches), "total_ms": float(buf[i].total_ms),
+                 "bytes": float(buf[i].bytes)} for i in range(n)]
+
+
+_default = {}
+
+
+def default_context(device=None):
+    """Process-wide context used by the reference-shaped Python API (one per device)."""
+    import os
+    if device is None:
+        device = int(os.environ.get("KLT_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = load_library().klt_device_count()
+        if n > 0:
+            device %= n
+    ctx = _default.get(device)
+    if ctx is None:
+        ctx = _default[device] = Context(device)
+    return ctx
+
+
+__all__ = ["Context", "default_context", "FEAT_DTYPE", "SELECTING_ALL", "REPLACING_SOME", "KltBackendError",
+           "KLT_MAX_LEVELS", "KltParams"]

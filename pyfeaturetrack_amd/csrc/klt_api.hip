@@ -1,0 +1,844 @@
+// C ABI of libkltgpu.so (include/klt_gpu.h): context, slots, feature buffers, and the launch
+// sequences for pyramid build, selection and tracking.  Host-side C++ only; all kernels live in
+// conv_kernels.hip / select_kernels.hip / track_kernels.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "klt_internal.h"
+
+namespace {
+
+enum Family { F_SMOOTH_H, F_SMOOTH_V, F_PYR_H, F_PYR_V, F_GRAD_H, F_GRAD_V, F_TRACK, F_SAT_ROWS, F_SAT_COLS,
+              F_EIGEN, F_SORT, F_NMS, F_SEED, F_COUNT };
+const char *const kFamilyName[F_COUNT] = {"smooth_h", "smooth_v", "pyramid_h", "pyramid_v", "gradient_h", "gradient_v",
+                                          "track", "sat_rows", "sat_cols", "eigen_keys", "sort", "nms", "seed_map"};
+
+struct Level { int nc = 0, nr = 0; float *img = nullptr, *gx = nullptr, *gy = nullptr; };
+
+struct Slot {
+    int nc = 0, nr = 0;
+    int raw_kind = 0;                 // 0 none, 1 u8, 2 f32
+    uint8_t *u8 = nullptr;
+    float *f32 = nullptr;
+    size_t raw_cap = 0;               // pixels
+    float *planes = nullptr;          // 3 pyramids, level-concatenated
+    size_t planes_cap = 0;            // floats
+    Level lv[KLT_MAX_LEVELS];
+    int nlev = 0, ss = 0;
+    bool pyr_valid = false;
+};
+
+struct FeatBuf { klt_feat *d = nullptr; int cap = 0; };
+
+struct Timed { int fam; hipEvent_t a, b; double bytes; };
+
+std::string g_create_error;
+
+}  // namespace
+
+struct klt_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    klt_params p{};
+    bool have_params = false;
+    Taps gauss[3], deriv[3];
+    bool have_taps[3] = {false, false, false};
+    std::vector<Slot> slots;
+    std::vector<FeatBuf> fbs;
+    float *tmpA = nullptr, *tmpB = nullptr;
+    size_t tmp_cap = 0;
+    // selection scratch
+    float *sel_img = nullptr, *sel_gx = nullptr, *sel_gy = nullptr, *sat = nullptr, *valmap = nullptr;
+    size_t sel_cap = 0;               // pixels
+    unsigned long long *keys = nullptr;
+    size_t keys_cap = 0;
+    uint8_t *seedmap = nullptr;
+    size_t seed_cap = 0;
+    uint32_t *grid = nullptr;
+    size_t grid_cap = 0;
+    int *placed_d = nullptr;
+    const float *last_sel[3] = {nullptr, nullptr, nullptr};
+    int sel_nc = 0, sel_nr = 0, sel_nx = 0, sel_ny = 0, sel_npow2 = 0;
+    unsigned long long *stats_d = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<Timed> pending;
+    std::vector<hipEvent_t> pool;
+    double acc_ms[F_COUNT] = {0}, acc_bytes[F_COUNT] = {0};
+    unsigned acc_n[F_COUNT] = {0};
+};
+
+namespace {
+
+int fail(klt_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail((c), KLT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct TimerScope {
+    klt_ctx *c;
+    Timed t;
+    bool on;
+    TimerScope(klt_ctx *c_, int fam, double bytes) : c(c_), on(c_->timing)
+    {
+        if (!on) return;
+        t.fam = fam;
+        t.bytes = bytes;
+        for (hipEvent_t *e : {&t.a, &t.b}) {
+            if (!c->pool.empty()) { *e = c->pool.back(); c->pool.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
+        }
+        hipEventRecord(t.a, c->stream);
+    }
+    ~TimerScope()
+    {
+        if (!on) return;
+        hipEventRecord(t.b, c->stream);
+        c->pending.push_back(t);
+    }
+};
+
+int drain_timers(klt_ctx *c)
+{
+    if (c->pending.empty()) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (Timed &t : c->pending) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, t.a, t.b);
+        c->acc_ms[t.fam] += ms;
+        c->acc_bytes[t.fam] += t.bytes;
+        c->acc_n[t.fam]++;
+        c->pool.push_back(t.a);
+        c->pool.push_back(t.b);
+    }
+    c->pending.clear();
+    return 0;
+}
+
+template <typename T>
+int ensure(klt_ctx *c, T *&ptr, size_t &cap, size_t want)
+{
+    if (want <= cap && ptr) return 0;
+    if (ptr) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(ptr)); ptr = nullptr; cap = 0; }
+    HIPCHK(c, hipMalloc((void **)&ptr, want * sizeof(T)));
+    cap = want;
+    return 0;
+}
+
+int ensure_tmp(klt_ctx *c, size_t pixels)
+{
+    if (pixels <= c->tmp_cap && c->tmpA) return 0;
+    if (c->tmpA) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->tmpA); hipFree(c->tmpB); c->tmpA = c->tmpB = nullptr; }
+    HIPCHK(c, hipMalloc((void **)&c->tmpA, pixels * sizeof(float)));
+    HIPCHK(c, hipMalloc((void **)&c->tmpB, pixels * sizeof(float)));
+    c->tmp_cap = pixels;
+    return 0;
+}
+
+int get_slot(klt_ctx *c, int slot, Slot **out, bool create)
+{
+    if (slot < 0 || slot > 65535) return fail(c, KLT_ERR_ARG, "slot index out of range");
+    if ((size_t)slot >= c->slots.size()) {
+        if (!create) return fail(c, KLT_ERR_STATE, "slot has no frame");
+        c->slots.resize(slot + 1);
+    }
+    *out = &c->slots[slot];
+    return 0;
+}
+
+int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
+{
+    if (fb < 0 || fb > 65535) return fail(c, KLT_ERR_ARG, "feature buffer index out of range");
+    if ((size_t)fb >= c->fbs.size()) c->fbs.resize(fb + 1);
+    FeatBuf &b = c->fbs[fb];
+    if (n > b.cap) {
+        klt_feat *nd = nullptr;
+        HIPCHK(c, hipMalloc((void **)&nd, (size_t)n * sizeof(klt_feat)));
+        if (b.d) {
+            HIPCHK(c, hipMemcpyAsync(nd, b.d, (size_t)b.cap * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(b.d);
+        }
+        b.d = nd;
+        b.cap = n;
+    }
+    *out = &b;
+    return 0;
+}
+
+void make_taps(const double *k, int n, Taps &t)
+{
+    // scipy.ndimage.convolve1d: weights[::-1], then correlate1d's symmetry test (|a -+ b| <= DBL_EPSILON)
+    std::memset(&t, 0, sizeof(t));
+    t.n = n;
+    for (int i = 0; i < n; i++) t.k[i] = k[n - 1 - i];
+    t.sym = 0;
+    if (n & 1) {
+        const int half = n / 2;
+        t.sym = 1;
+        for (int ii = 1; ii <= half; ii++)
+            if (std::fabs(t.k[half + ii] - t.k[half - ii]) > 2.220446049250313e-16) { t.sym = 0; break; }
+        if (t.sym == 0) {
+            t.sym = -1;
+            for (int ii = 1; ii <= half; ii++)
+                if (std::fabs(t.k[half + ii] + t.k[half - ii]) > 2.220446049250313e-16) { t.sym = 0; break; }
+        }
+    }
+}
+
+int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int pitch, int kind)
+{
+    if (!c || !px) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535 || pitch < ncols)
+        return fail(c, KLT_ERR_ARG, "bad image geometry");
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot *s;
+    if (int rc = get_slot(c, slot, &s, true)) return rc;
+    const size_t px_count = (size_t)ncols * nrows;
+    if (px_count > s->raw_cap) {
+        if (s->u8) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(s->u8); hipFree(s->f32); s->u8 = nullptr; s->f32 = nullptr; }
+        HIPCHK(c, hipMalloc((void **)&s->u8, px_count));
+        HIPCHK(c, hipMalloc((void **)&s->f32, px_count * sizeof(float)));
+        s->raw_cap = px_count;
+    }
+    const size_t esz = kind == 1 ? 1 : sizeof(float);
+    void *dst = kind == 1 ? (void *)s->u8 : (void *)s->f32;
+    HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)ncols * esz, px, (size_t)pitch * esz, (size_t)ncols * esz, nrows,
+                                hipMemcpyHostToDevice, c->stream));
+    // pageable host memory: the copy above is staged before returning, but make it explicit
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    s->nc = ncols;
+    s->nr = nrows;
+    s->raw_kind = kind;
+    s->pyr_valid = false;
+    return 0;
+}
+
+int layout_pyramid(klt_ctx *c, Slot *s)
+{
+    const int L = c->p.nPyramidLevels, ss = c->p.subsampling;
+    size_t total = 0;
+    int nc = s->nc, nr = s->nr;
+    for (int l = 0; l < L; l++) {
+        if (nc <= 0 || nr <= 0) return fail(c, KLT_ERR_ARG, "image too small for the requested pyramid");
+        total += (size_t)nc * nr;
+        nc /= ss;
+        nr /= ss;
+    }
+    if (3 * total > s->planes_cap) {
+        if (s->planes) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(s->planes); s->planes = nullptr; }
+        HIPCHK(c, hipMalloc((void **)&s->planes, 3 * total * sizeof(float)));
+        s->planes_cap = 3 * total;
+    }
+    size_t off = 0;
+    nc = s->nc;
+    nr = s->nr;
+    for (int l = 0; l < L; l++) {
+        s->lv[l].nc = nc;
+        s->lv[l].nr = nr;
+        s->lv[l].img = s->planes + off;
+        s->lv[l].gx = s->planes + total + off;
+        s->lv[l].gy = s->planes + 2 * total + off;
+        off += (size_t)nc * nr;
+        nc /= ss;
+        nr /= ss;
+    }
+    s->nlev = L;
+    s->ss = ss;
+    return 0;
+}
+
+int check_ready(klt_ctx *c)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (!c->have_params) return fail(c, KLT_ERR_STATE, "klt_set_params has not been called");
+    for (int i = 0; i < 3; i++)
+        if (!c->have_taps[i]) return fail(c, KLT_ERR_STATE, "klt_set_kernels has not been called for all three tap sets");
+    return 0;
+}
+
+// smooth(raw) -> dst, convolve.py:254-264 with the smoothing taps
+int enqueue_smooth_raw(klt_ctx *c, Slot *s, float *dst)
+{
+    const int nc = s->nc, nr = s->nr;
+    const double N = (double)nc * nr;
+    const Taps &g = c->gauss[0];
+    {
+        TimerScope t(c, F_SMOOTH_H, N * ((s->raw_kind == 1 ? 1 : 4) + 4));
+        if (s->raw_kind == 1) launch_hconv_u8(c->stream, s->u8, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+        else launch_hconv_f32(c->stream, s->f32, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+    }
+    {
+        TimerScope t(c, F_SMOOTH_V, N * 8);
+        launch_vconv(c->stream, c->tmpA, nullptr, nc, nr, dst, nullptr, nr, 1, 0, g, nullptr);
+    }
+    return 0;
+}
+
+// KLTComputeGradients, convolve.py:226-248: gx = (deriv horizontally, gauss vertically), gy = (gauss, deriv)
+int enqueue_gradients(klt_ctx *c, const float *img, int nc, int nr, float *gx, float *gy)
+{
+    const double N = (double)nc * nr;
+    {
+        TimerScope t(c, F_GRAD_H, N * 12);
+        launch_hconv_f32(c->stream, img, nc, nr, c->tmpA, c->tmpB, nc, 1, 0, c->deriv[2], &c->gauss[2]);
+    }
+    {
+        TimerScope t(c, F_GRAD_V, N * 16);
+        launch_vconv(c->stream, c->tmpA, c->tmpB, nc, nr, gx, gy, nr, 1, 0, c->gauss[2], &c->deriv[2]);
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================================== ABI
+
+extern "C" {
+
+int klt_abi_version(void) { return KLT_ABI_VERSION; }
+
+int klt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int klt_create(int device, klt_ctx **out)
+{
+    if (!out) return KLT_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device available (") + hipGetErrorString(e) + "); libkltgpu has no CPU path";
+        return KLT_ERR_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        g_create_error = "device index out of range";
+        return KLT_ERR_ARG;
+    }
+    klt_ctx *c = new klt_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->stats_d, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->placed_d, sizeof(int))) != hipSuccess ||
+        (e = hipMemset(c->stats_d, 0, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess) {
+        g_create_error = std::string("device setup failed: ") + hipGetErrorString(e);
+        delete c;
+        return KLT_ERR_DEVICE;
+    }
+    *out = c;
+    return KLT_OK;
+}
+
+void klt_destroy(klt_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.f32); hipFree(s.planes); }
+    for (FeatBuf &b : c->fbs) hipFree(b.d);
+    hipFree(c->tmpA); hipFree(c->tmpB);
+    hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->placed_d); hipFree(c->stats_d);
+    for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (hipEvent_t e : c->pool) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *klt_last_error(klt_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int klt_sync(klt_ctx *c)
+{
+    if (!c) return KLT_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KLT_OK;
+}
+
+int klt_set_params(klt_ctx *c, const klt_params *p)
+{
+    if (!c || !p) return fail(c, KLT_ERR_ARG, "null argument");
+    if (p->window_width != p->window_height || (p->window_width & 1) == 0 || p->window_width < 3 || p->window_width > 31)
+        return fail(c, KLT_ERR_ARG, "window must be square, odd and between 3 and 31");
+    if (p->nPyramidLevels < 1 || p->nPyramidLevels > KLT_MAX_LEVELS) return fail(c, KLT_ERR_ARG, "nPyramidLevels out of range");
+    const int ss = p->subsampling;
+    if (p->nPyramidLevels > 1 && ss != 2 && ss != 4 && ss != 8 && ss != 16 && ss != 32)
+        return fail(c, KLT_ERR_ARG, "subsampling must be 2, 4, 8, 16 or 32");      // pyramid.py:17-20
+    if (p->nSkippedPixels < 0 || p->max_iterations < 0) return fail(c, KLT_ERR_ARG, "negative count");
+    const bool relayout = !c->have_params || c->p.nPyramidLevels != p->nPyramidLevels || c->p.subsampling != ss;
+    c->p = *p;
+    if (c->p.nPyramidLevels == 1 && (ss < 2)) c->p.subsampling = 2;
+    c->have_params = true;
+    if (relayout)
+        for (Slot &s : c->slots) s.pyr_valid = false;
+    return KLT_OK;
+}
+
+int klt_set_kernels(klt_ctx *c, int which, const double *gauss, int ng, const double *deriv, int nd)
+{
+    if (!c || !gauss || !deriv) return fail(c, KLT_ERR_ARG, "null argument");
+    if (which < 0 || which > 2) return fail(c, KLT_ERR_ARG, "which must be 0, 1 or 2");
+    if (ng < 1 || nd < 1 || ng > KLT_MAX_KERNEL_WIDTH || nd > KLT_MAX_KERNEL_WIDTH || !(ng & 1) || !(nd & 1))
+        return fail(c, KLT_ERR_ARG, "tap counts must be odd and at most 71");
+    make_taps(gauss, ng, c->gauss[which]);
+    make_taps(deriv, nd, c->deriv[which]);
+    c->have_taps[which] = true;
+    for (Slot &s : c->slots) s.pyr_valid = false;
+    return KLT_OK;
+}
+
+int klt_upload_u8(klt_ctx *c, int slot, const uint8_t *px, int ncols, int nrows, int pitch)
+{
+    return upload_raw(c, slot, px, ncols, nrows, pitch, 1);
+}
+
+int klt_upload_f32(klt_ctx *c, int slot, const float *px, int ncols, int nrows, int pitch)
+{
+    return upload_raw(c, slot, px, ncols, nrows, pitch, 2);
+}
+
+int klt_build_pyramids_async(klt_ctx *c, int slot)
+{
+    if (int rc = check_ready(c)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot *s;
+    if (int rc = get_slot(c, slot, &s, false)) return rc;
+    if (s->raw_kind == 0) return fail(c, KLT_ERR_STATE, "slot has no frame");
+    if (int rc = layout_pyramid(c, s)) return rc;
+    if (int rc = ensure_tmp(c, (size_t)s->nc * s->nr)) return rc;
+    // level 0: smoothed frame (trackFeatures.py:165-166)
+    enqueue_smooth_raw(c, s, s->lv[0].img);
+    // levels 1..L-1: smooth with the pyramid sigma, keep pixel (ss*y + ss/2, ss*x + ss/2) (pyramid.py:59-72).
+    // Only the surviving columns / rows are evaluated.
+    const int ss = s->ss;
+    for (int l = 1; l < s->nlev; l++) {
+        const Level &src = s->lv[l - 1];
+        const Level &dst = s->lv[l];
+        {
+            TimerScope t(c, F_PYR_H, 4.0 * ((double)src.nc * src.nr + (double)dst.nc * src.nr));
+            launch_hconv_f32(c->stream, src.img, src.nc, src.nr, c->tmpA, nullptr, dst.nc, ss, ss / 2, c->gauss[1], nullptr);
+        }
+        {
+            TimerScope t(c, F_PYR_V, 4.0 * ((double)dst.nc * src.nr + (double)dst.nc * dst.nr));
+            launch_vconv(c->stream, c->tmpA, nullptr, dst.nc, src.nr, dst.img, nullptr, dst.nr, ss, ss / 2, c->gauss[1], nullptr);
+        }
+    }
+    for (int l = 0; l < s->nlev; l++) enqueue_gradients(c, s->lv[l].img, s->lv[l].nc, s->lv[l].nr, s->lv[l].gx, s->lv[l].gy);
+    HIPCHK(c, hipGetLastError());
+    s->pyr_valid = true;
+    return KLT_OK;
+}
+
+int klt_build_pyramids(klt_ctx *c, int slot)
+{
+    if (int rc = klt_build_pyramids_async(c, slot)) return rc;
+    return klt_sync(c);
+}
+
+int klt_swap_slots(klt_ctx *c, int a, int b)
+{
+    if (!c) return KLT_ERR_ARG;
+    Slot *sa, *sb;
+    const int hi = a > b ? a : b;
+    if (hi >= 0 && (size_t)hi >= c->slots.size() && hi <= 65535) c->slots.resize(hi + 1);
+    if (int rc = get_slot(c, a, &sa, true)) return rc;
+    if (int rc = get_slot(c, b, &sb, true)) return rc;
+    std::swap(*sa, *sb);
+    return KLT_OK;
+}
+
+int klt_featbuf_upload(klt_ctx *c, int fb, const klt_feat *src, int n)
+{
+    if (!c || !src || n < 0) return fail(c, KLT_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    FeatBuf *b;
+    if (int rc = get_fb(c, fb, n > 0 ? n : 1, &b)) return rc;
+    HIPCHK(c, hipMemcpyAsync(b->d, src, (size_t)n * sizeof(klt_feat), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KLT_OK;
+}
+
+int klt_featbuf_download(klt_ctx *c, int fb, klt_feat *dst, int n)
+{
+    if (!c || !dst || n < 0) return fail(c, KLT_ERR_ARG, "bad argument");
+    if (fb < 0 || (size_t)fb >= c->fbs.size() || c->fbs[fb].cap < n) return fail(c, KLT_ERR_STATE, "feature buffer not that large");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, c->fbs[fb].d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KLT_OK;
+}
+
+void *klt_featbuf_devptr(klt_ctx *c, int fb)
+{
+    if (!c || fb < 0 || (size_t)fb >= c->fbs.size()) return nullptr;
+    return c->fbs[fb].d;
+}
+
+// ---------------------------------------------------------------------------------------- selection
+int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, int n)
+{
+    if (int rc = check_ready(c)) return rc;
+    if (mode != KLT_SELECTING_ALL && mode != KLT_REPLACING_SOME) return fail(c, KLT_ERR_ARG, "bad selection mode");
+    if (n <= 0) return fail(c, KLT_ERR_ARG, "nFeatures must be positive");
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot *s;
+    if (int rc = get_slot(c, slot, &s, false)) return rc;
+    const int nc = s->nc, nr = s->nr;
+    const size_t N = (size_t)nc * nr;
+    FeatBuf *b;
+    if (int rc = get_fb(c, fb, n, &b)) return rc;
+
+    // borders / half-windows as ScanImageForGoodFeatures receives them: Python floats truncated to C ints
+    // (selectGoodFeatures.py:168-169, :215-221, goodFeaturesUtils.pyx:35-37)
+    const klt_params &p = c->p;
+    double bxd = p.borderx, byd = p.bordery;
+    if (bxd < p.window_width / 2.0) bxd = p.window_width / 2.0;
+    if (byd < p.window_height / 2.0) byd = p.window_height / 2.0;
+    const int bx = (int)bxd, by = (int)byd, hw = p.window_width / 2, hh = p.window_height / 2;
+    const int step = p.nSkippedPixels + 1;
+    if (bx - hw - 1 < 0 || by - hh - 1 < 0)
+        return fail(c, KLT_ERR_ARG, "border must be at least window/2 + 1 (the reference reads outside the image otherwise)");
+    const int nx = (nc - bx > bx) ? (nc - 2 * bx + step - 1) / step : 0;
+    const int ny = (nr - by > by) ? (nr - 2 * by + step - 1) / step : 0;
+    const long long ncand = (long long)nx * ny;
+    long long npow2 = 2048;
+    while (npow2 < ncand) npow2 <<= 1;
+    if (npow2 > (1LL << 30)) return fail(c, KLT_ERR_ARG, "too many candidates");
+
+    // scratch
+    if (N > c->sel_cap) {
+        if (c->sel_img) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap); }
+        c->sel_img = c->sel_gx = c->sel_gy = c->sat = c->valmap = nullptr;
+        HIPCHK(c, hipMalloc((void **)&c->sel_img, N * sizeof(float)));
+        HIPCHK(c, hipMalloc((void **)&c->sel_gx, N * sizeof(float)));
+        HIPCHK(c, hipMalloc((void **)&c->sel_gy, N * sizeof(float)));
+        HIPCHK(c, hipMalloc((void **)&c->sat, 3 * N * sizeof(float)));
+        HIPCHK(c, hipMalloc((void **)&c->valmap, N * sizeof(float)));
+        c->sel_cap = N;
+    }
+    if (int rc = ensure(c, c->keys, c->keys_cap, (size_t)npow2)) return rc;
+    if (int rc = ensure_tmp(c, N)) return rc;
+
+    // images: reuse the slot's level-0 pyramid (selectGoodFeatures.py:176-181) or compute afresh (:183-197)
+    const float *img, *gx, *gy;
+    if (use_pyramid) {
+        if (!s->pyr_valid) return fail(c, KLT_ERR_STATE, "use_pyramid requested but the slot's pyramids are not built");
+        img = s->lv[0].img; gx = s->lv[0].gx; gy = s->lv[0].gy;
+    } else {
+        if (s->raw_kind == 0) return fail(c, KLT_ERR_STATE, "slot has no frame");
+        if (p.smoothBeforeSelecting) {
+            enqueue_smooth_raw(c, s, c->sel_img);
+            img = c->sel_img;
+        } else if (s->raw_kind == 2) {
+            img = s->f32;
+        } else {
+            // u8 -> f32 with a 1-tap identity kernel is overkill; widen with a 1-tap correlate (exact)
+            Taps one;
+            std::memset(&one, 0, sizeof(one));
+            one.n = 1; one.sym = 1; one.k[0] = 1.0;
+            launch_hconv_u8(c->stream, s->u8, nc, nr, c->sel_img, nullptr, nc, 1, 0, one, nullptr);
+            img = c->sel_img;
+        }
+        enqueue_gradients(c, img, nc, nr, c->sel_gx, c->sel_gy);
+        gx = c->sel_gx; gy = c->sel_gy;
+    }
+    c->last_sel[0] = img; c->last_sel[1] = gx; c->last_sel[2] = gy;
+    c->sel_nc = nc; c->sel_nr = nr; c->sel_nx = nx; c->sel_ny = ny; c->sel_npow2 = (int)npow2;
+
+    // summed-area tables (goodFeaturesUtils.pyx:49-51)
+    { TimerScope t(c, F_SAT_ROWS, (double)N * (8 + 12)); launch_sat_rows(c->stream, gx, gy, c->sat, nc, nr); }
+    { TimerScope t(c, F_SAT_COLS, (double)N * 24); launch_sat_cols(c->stream, c->sat, nc, nr); }
+
+    int mindist = p.mindist < 0 ? 0 : p.mindist;          // selectGoodFeatures.py:241-243
+    const int d = mindist - 1;                            // :61
+    const uint8_t *seed = nullptr;
+    if (mode == KLT_REPLACING_SOME && d >= 0) {
+        if (int rc = ensure(c, c->seedmap, c->seed_cap, N)) return rc;
+        HIPCHK(c, hipMemsetAsync(c->seedmap, 0, N, c->stream));
+        TimerScope t(c, F_SEED, (double)n * 16);
+        launch_seed_fill(c->stream, b->d, n, c->seedmap, nc, nr, d);
+        seed = c->seedmap;
+    }
+
+    SelectArgs sa;
+    sa.sat = c->sat; sa.valmap = c->valmap; sa.keys = c->keys; sa.seedmap = seed;
+    sa.min_eig = p.min_eigenvalue < 1 ? 1.0 : p.min_eigenvalue;          // :53
+    sa.ncols = nc; sa.nrows = nr; sa.bx = bx; sa.by = by; sa.step = step; sa.nx = nx; sa.ny = ny;
+    sa.hw = hw; sa.hh = hh; sa.npow2 = (int)npow2;
+    { TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8)); launch_eigen(c->stream, sa); }
+    { TimerScope t(c, F_SORT, (double)npow2 * 16); launch_sort_desc(c->stream, c->keys, (int)npow2); }
+
+    NmsArgs na;
+    na.keys = c->keys; na.fl = b->d; na.placed_out = c->placed_d;
+    na.nkeys = (int)(ncand < npow2 ? ncand : npow2); na.nfeat = n; na.overwrite_all = (mode == KLT_SELECTING_ALL);
+    na.d = d; na.cell = d >= 0 ? d + 1 : 1;
+    na.gw = (nc + na.cell - 1) / na.cell; na.gh = (nr + na.cell - 1) / na.cell;
+    if (d < 0) { na.gw = na.gh = 1; }
+    const size_t grid_bytes = (size_t)na.gw * na.gh * sizeof(uint32_t);
+    na.grid_in_lds = grid_bytes <= 144 * 1024;
+    na.grid_global = nullptr;
+    if (!na.grid_in_lds) {
+        if (int rc = ensure(c, c->grid, c->grid_cap, (size_t)na.gw * na.gh)) return rc;
+        HIPCHK(c, hipMemsetAsync(c->grid, 0, grid_bytes, c->stream));
+        na.grid_global = c->grid;
+    }
+    {
+        TimerScope t(c, F_NMS, (double)n * 16);
+        const int e = launch_nms(c->stream, na);
+        if (e) return fail(c, KLT_ERR_DEVICE, std::string("nms launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    HIPCHK(c, hipGetLastError());
+    return KLT_OK;
+}
+
+int klt_select(klt_ctx *c, int slot, int mode, int use_pyramid, klt_feat *inout, int n, int *n_placed)
+{
+    if (!c || !inout) return fail(c, KLT_ERR_ARG, "null argument");
+    const int fb = 65535;       // private staging buffer
+    if (int rc = klt_featbuf_upload(c, fb, inout, n)) return rc;
+    if (int rc = klt_select_async(c, slot, mode, use_pyramid, fb, n)) return rc;
+    if (int rc = klt_featbuf_download(c, fb, inout, n)) return rc;
+    if (n_placed) {
+        HIPCHK(c, hipMemcpy(n_placed, c->placed_d, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return KLT_OK;
+}
+
+// ----------------------------------------------------------------------------------------- tracking
+int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int n)
+{
+    if (int rc = check_ready(c)) return rc;
+    if (n < 0) return fail(c, KLT_ERR_ARG, "negative feature count");
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot *s1, *s2;
+    if (int rc = get_slot(c, slot1, &s1, false)) return rc;
+    if (int rc = get_slot(c, slot2, &s2, false)) return rc;
+    if (!s1->pyr_valid || !s2->pyr_valid) return fail(c, KLT_ERR_STATE, "pyramids of both slots must be built before tracking");
+    if (s1->nc != s2->nc || s1->nr != s2->nr || s1->nlev != s2->nlev || s1->ss != s2->ss)
+        return fail(c, KLT_ERR_ARG, "the two frames differ in size");            // trackFeatures.py:156-159, :217
+    if (fb_in < 0 || (size_t)fb_in >= c->fbs.size() || c->fbs[fb_in].cap < n) return fail(c, KLT_ERR_STATE, "input feature buffer not set");
+    FeatBuf *bo;
+    if (int rc = get_fb(c, fb_out, n > 0 ? n : 1, &bo)) return rc;
+    const klt_params &p = c->p;
+    TrackArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int l = 0; l < s1->nlev; l++) {
+        a.lv[l].i1 = s1->lv[l].img; a.lv[l].gx1 = s1->lv[l].gx; a.lv[l].gy1 = s1->lv[l].gy;
+        a.lv[l].i2 = s2->lv[l].img; a.lv[l].gx2 = s2->lv[l].gx; a.lv[l].gy2 = s2->lv[l].gy;
+        a.lv[l].nc = s1->lv[l].nc; a.lv[l].nr = s1->lv[l].nr;
+    }
+    a.in = c->fbs[fb_in].d; a.out = bo->d; a.stats = c->stats_d;
+    a.half_window = p.window_width / 2.0;
+    a.borderx = p.borderx; a.bordery = p.bordery;
+    a.n = n; a.nlevels = s1->nlev; a.window = p.window_width; a.max_iterations = p.max_iterations;
+    a.use_max_residue = p.use_max_residue; a.retain = p.retainTrackers; a.ncols = s1->nc; a.nrows = s1->nr;
+    a.small = p.min_determinant; a.th = p.min_displacement; a.step = p.step_factor; a.max_residue = p.max_residue;
+    a.ss = (float)s1->ss;
+    {
+        const double foot = 12.0 * (p.window_width + 1) * (p.window_width + 1);
+        TimerScope t(c, F_TRACK, (double)n * (foot * 2 * s1->nlev + 32));      // refined by the caller from klt_track_stats
+        if (launch_track(c->stream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
+    }
+    HIPCHK(c, hipGetLastError());
+    return KLT_OK;
+}
+
+int klt_track(klt_ctx *c, int slot1, int slot2, klt_feat *inout, int n, int *n_tracked)
+{
+    if (!c || !inout) return fail(c, KLT_ERR_ARG, "null argument");
+    const int fi = 65534, fo = 65535;
+    if (int rc = klt_featbuf_upload(c, fi, inout, n)) return rc;
+    if (int rc = klt_track_async(c, slot1, slot2, fi, fo, n)) return rc;
+    if (int rc = klt_featbuf_download(c, fo, inout, n)) return rc;
+    if (n_tracked) {
+        int k = 0;
+        for (int i = 0; i < n; i++) k += inout[i].val >= 0;
+        *n_tracked = k;
+    }
+    return KLT_OK;
+}
+
+int klt_track_stats_reset(klt_ctx *c)
+{
+    if (!c) return KLT_ERR_ARG;
+    HIPCHK(c, hipMemsetAsync(c->stats_d, 0, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long), c->stream));
+    return KLT_OK;
+}
+
+int klt_track_stats_read(klt_ctx *c, klt_track_stats *out)
+{
+    if (!c || !out) return fail(c, KLT_ERR_ARG, "null argument");
+    unsigned long long h[1 + 2 * KLT_MAX_LEVELS];
+    HIPCHK(c, hipMemcpyAsync(h, c->stats_d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->features = h[0];
+    for (int l = 0; l < KLT_MAX_LEVELS; l++) { out->level_visits[l] = h[1 + l]; out->iterations[l] = h[1 + KLT_MAX_LEVELS + l]; }
+    return KLT_OK;
+}
+
+// -------------------------------------------------------------------------------------- inspection
+int klt_level_dims(klt_ctx *c, int slot, int level, int *ncols, int *nrows)
+{
+    if (!c) return KLT_ERR_ARG;
+    Slot *s;
+    if (int rc = get_slot(c, slot, &s, false)) return rc;
+    if (!s->pyr_valid || level < 0 || level >= s->nlev) return fail(c, KLT_ERR_STATE, "no such pyramid level");
+    if (ncols) *ncols = s->lv[level].nc;
+    if (nrows) *nrows = s->lv[level].nr;
+    return KLT_OK;
+}
+
+int klt_download_f32(klt_ctx *c, int slot, int pyramid, int level, float *dst)
+{
+    if (!c || !dst) return fail(c, KLT_ERR_ARG, "null argument");
+    Slot *s;
+    if (int rc = get_slot(c, slot, &s, false)) return rc;
+    if (!s->pyr_valid || level < 0 || level >= s->nlev || pyramid < 0 || pyramid > 2) return fail(c, KLT_ERR_STATE, "no such pyramid level");
+    const Level &l = s->lv[level];
+    const float *src = pyramid == 0 ? l.img : (pyramid == 1 ? l.gx : l.gy);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)l.nc * l.nr * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KLT_OK;
+}
+
+int klt_select_dims(klt_ctx *c, int what, int *ncols, int *nrows)
+{
+    if (!c || what < 0 || what > 3) return fail(c, KLT_ERR_ARG, "bad argument");
+    if (c->sel_nc == 0) return fail(c, KLT_ERR_STATE, "no selection has run");
+    if (ncols) *ncols = what == 3 ? c->sel_nx : c->sel_nc;
+    if (nrows) *nrows = what == 3 ? c->sel_ny : c->sel_nr;
+    return KLT_OK;
+}
+
+int klt_download_select_f32(klt_ctx *c, int what, float *dst)
+{
+    if (!c || !dst || what < 0 || what > 3) return fail(c, KLT_ERR_ARG, "bad argument");
+    if (c->sel_nc == 0) return fail(c, KLT_ERR_STATE, "no selection has run");
+    const float *src = what == 3 ? c->valmap : c->last_sel[what];
+    const size_t cnt = what == 3 ? (size_t)c->sel_nx * c->sel_ny : (size_t)c->sel_nc * c->sel_nr;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KLT_OK;
+}
+
+int klt_download_sorted_candidates(klt_ctx *c, float *val, int32_t *x, int32_t *y, int n, int *n_valid)
+{
+    if (!c || !val || !x || !y || n < 0) return fail(c, KLT_ERR_ARG, "bad argument");
+    if (c->sel_nc == 0) return fail(c, KLT_ERR_STATE, "no selection has run");
+    if (n > c->sel_npow2) n = c->sel_npow2;
+    std::vector<unsigned long long> h((size_t)n);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->keys, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int k = 0;
+    for (; k < n && h[k] != 0ull; k++) {
+        const uint32_t bits = (uint32_t)(h[k] >> 32);
+        std::memcpy(&val[k], &bits, 4);
+        x[k] = (int32_t)((h[k] >> 16) & 0xffffull);
+        y[k] = (int32_t)(h[k] & 0xffffull);
+    }
+    if (n_valid) *n_valid = k;
+    return KLT_OK;
+}
+
+// ------------------------------------------------------------------------- standalone convolutions
+int klt_smooth_f32(klt_ctx *c, const float *src, int ncols, int nrows, const double *gauss, int ng, float *dst)
+{
+    if (!c || !src || !dst || !gauss) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ng < 1 || ng > KLT_MAX_KERNEL_WIDTH || !(ng & 1)) return fail(c, KLT_ERR_ARG, "tap count must be odd and at most 71");
+    if (ncols <= 0 || nrows <= 0) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)ncols * nrows;
+    if (int rc = ensure_tmp(c, N)) return rc;
+    float *d_in = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_in, 2 * N * sizeof(float)));
+    float *d_out = d_in + N;
+    Taps g;
+    make_taps(gauss, ng, g);
+    hipError_t e = hipMemcpyAsync(d_in, src, N * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_hconv_f32(c->stream, d_in, ncols, nrows, c->tmpA, nullptr, ncols, 1, 0, g, nullptr);
+        launch_vconv(c->stream, c->tmpA, nullptr, ncols, nrows, d_out, nullptr, nrows, 1, 0, g, nullptr);
+        e = hipMemcpyAsync(dst, d_out, N * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_in);
+    if (e != hipSuccess) return fail(c, KLT_ERR_DEVICE, hipGetErrorString(e));
+    return KLT_OK;
+}
+
+int klt_gradients_f32(klt_ctx *c, const float *src, int ncols, int nrows, const double *gauss, int ng,
+                      const double *deriv, int nd, float *gx, float *gy)
+{
+    if (!c || !src || !gx || !gy || !gauss || !deriv) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ng < 1 || nd < 1 || ng > KLT_MAX_KERNEL_WIDTH || nd > KLT_MAX_KERNEL_WIDTH || !(ng & 1) || !(nd & 1))
+        return fail(c, KLT_ERR_ARG, "tap counts must be odd and at most 71");
+    if (ncols <= 0 || nrows <= 0) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)ncols * nrows;
+    if (int rc = ensure_tmp(c, N)) return rc;
+    float *d_in = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_in, 3 * N * sizeof(float)));
+    float *d_gx = d_in + N, *d_gy = d_in + 2 * N;
+    Taps g, d;
+    make_taps(gauss, ng, g);
+    make_taps(deriv, nd, d);
+    hipError_t e = hipMemcpyAsync(d_in, src, N * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_hconv_f32(c->stream, d_in, ncols, nrows, c->tmpA, c->tmpB, ncols, 1, 0, d, &g);
+        launch_vconv(c->stream, c->tmpA, c->tmpB, ncols, nrows, d_gx, d_gy, nrows, 1, 0, g, &d);
+        e = hipMemcpyAsync(gx, d_gx, N * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(gy, d_gy, N * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_in);
+    if (e != hipSuccess) return fail(c, KLT_ERR_DEVICE, hipGetErrorString(e));
+    return KLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ timing
+int klt_timing_enable(klt_ctx *c, int on)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (int rc = drain_timers(c)) return rc;
+    for (int f = 0; f < F_COUNT; f++) { c->acc_ms[f] = 0; c->acc_bytes[f] = 0; c->acc_n[f] = 0; }
+    c->timing = on != 0;
+    return KLT_OK;
+}
+
+int klt_timing_read(klt_ctx *c, klt_kernel_time *out, int max_entries)
+{
+    if (!c || !out) return fail(c, KLT_ERR_ARG, "null argument");
+    if (int rc = drain_timers(c)) return rc;
+    int k = 0;
+    for (int f = 0; f < F_COUNT && k < max_entries; f++) {
+        if (!c->acc_n[f]) continue;
+        std::memset(&out[k], 0, sizeof(out[k]));
+        std::snprintf(out[k].name, sizeof(out[k].name), "%s", kFamilyName[f]);
+        out[k].launches = c->acc_n[f];
+        out[k].total_ms = (float)c->acc_ms[f];
+        out[k].bytes = c->acc_bytes[f];
+        k++;
+    }
+    return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+"""KLTPyramid (reference: pyramid.py:14-77).
+
+The tracker does not use this class -- it builds all three pyramids of a frame on the device in
+one enqueue (klt_build_pyramids).  The class is kept for API compatibility: level 0 is the input,
+level i is level i-1 smoothed with sigma = subsampling * sigma_fact (on the GPU) and sampled at
+(ss*y + ss/2, ss*x + ss/2), dimensions int(n / ss) per level.
+"""
+import numpy as np
+
+from .convolve import KLTComputeSmoothedImage
+from .error import KLTError
+
+_ALLOWED = (2, 4, 8, 16, 32)
+
+
+class KLTPyramid:
+    def __init__(self, ncols, nrows, subsampling, nlevels):
+        if subsampling not in _ALLOWED:
+            KLTError("(_KLTCreatePyramid)  Pyramid's subsampling must be either 2, 4, 8, 16, or 32")
+        self.subsampling = subsampling
+        self.nLevels = nlevels
+        self.img = [None] * nlevels
+        self.ncols = []
+        self.nrows = []
+        for _ in range(nlevels):
+            self.ncols.append(ncols)
+            self.nrows.append(nrows)
+            ncols /= subsampling       # true division, as in the reference (levels >= 1 hold floats)
+            nrows /= subsampling
+
+    def Compute(self, img, sigma_fact):
+        img = np.ascontiguousarray(img, np.float32)
+        ss = self.subsampling
+        assert self.ncols[0] == img.shape[1] and self.nrows[0] == img.shape[0]
+        sigma = ss * sigma_fact
+        self.img[0] = img
+        cur = img
+        nrows, ncols = img.shape
+        for i in range(1, self.nLevels):
+            smooth = KLTComputeSmoothedImage(cur, sigma)
+            ncols = int(ncols / ss)
+            nrows = int(nrows / ss)
+            cur = np.ascontiguousarray(smooth[ss // 2::ss, ss // 2::ss][:nrows, :ncols])
+            self.img[i] = cur

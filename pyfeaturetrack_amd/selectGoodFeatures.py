@@ -1,0 +1,133 @@
+"""KLTSelectGoodFeatures (reference: selectGoodFeatures.py) on the MI355X backend.
+
+The reference smooths the frame, differentiates it, scores every interior pixel with the minimum
+eigenvalue of the windowed gradient matrix (goodFeaturesUtils.pyx:35-73), sorts ~W*H Python tuples
+and walks them greedily (selectGoodFeatures.py:230-251).  Here the frame goes to the device once and
+klt_select runs all of that as HIP kernels; only the n selected 16-byte records come back.
+"""
+from __future__ import print_function
+
+import numpy as np
+
+from .backend import FEAT_DTYPE, REPLACING_SOME, SELECTING_ALL, default_context
+from .klt import KLT_Feature, KLTCountRemainingFeatures, kltState
+from .error import KLTWarning
+
+
+class selectionMode:
+    SELECTING_ALL = SELECTING_ALL
+    REPLACING_SOME = REPLACING_SOME
+
+
+KLT_verbose = 1
+
+
+def image_to_array(img):
+    """PIL image (or ndarray) -> uint8 or float32 2-D array holding exactly `np.array(img.convert("F"))`."""
+    if isinstance(img, np.ndarray):
+        return img if img.dtype == np.uint8 else np.ascontiguousarray(img, np.float32)
+    if getattr(img, "mode", None) == "L":
+        return np.asarray(img, np.uint8)          # convert("F") of an 8-bit image is the exact u8 value
+    return np.array(img.convert("F"), np.float32)
+
+
+def _image_size(img):
+    if isinstance(img, np.ndarray):
+        return img.shape[1], img.shape[0]
+    return img.size
+
+
+def features_to_array(featurelist):
+    fl = np.zeros(len(featurelist), FEAT_DTYPE)
+    for i, f in enumerate(featurelist):
+        fl[i] = (f.x, f.y, f.val, 0)
+    return fl
+
+
+def _slots_of(tc):
+    """Two device slots per tracking context: [frame 1, frame 2]; a third for selection frames."""
+    s = getattr(tc, "_klt_slots", None)
+    if s is None:
+        ctx = default_context()
+        base = getattr(ctx, "_next_slot", 0)
+        ctx._next_slot = base + 3
+        s = tc._klt_slots = (base, base + 1, base + 2)
+    return s
+
+
+def _fix_window(tc):
+    if tc.window_width % 2 != 1:
+        tc.window_width += 1
+        KLTWarning("Tracking context's window width must be odd.  Changing to {0}.\n".format(tc.window_width))
+    if tc.window_height % 2 != 1:
+        tc.window_height += 1
+        KLTWarning("Tracking context's window height must be odd.  Changing to {0}.\n".format(tc.window_height))
+    if tc.window_width < 3:
+        tc.window_width = 3
+        KLTWarning("Tracking context's window width must be at least three.  \nChanging to 3.\n")
+    if tc.window_height < 3:
+        tc.window_height = 3
+        KLTWarning("Tracking context's window height must be at least three.  \nChanging to 3.\n")
+
+
+def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
+    """selectGoodFeatures.py:141-261.  With REPLACING_SOME the given list is updated in place."""
+    _fix_window(tc)
+    if tc.mindist < 0:
+        KLTWarning("(_KLTSelectGoodFeatures) Tracking context field tc.mindist is negative ({0}); setting to zero".format(tc.mindist))
+        tc.mindist = 0
+    ctx = default_context()
+    ctx.configure(tc)
+    slots = _slots_of(tc)
+    if featurelist is None:
+        featurelist = [KLT_Feature() for _ in range(nFeatures)]
+    reuse = (mode == selectionMode.REPLACING_SOME and tc.sequentialMode and tc.pyramid_last is not None)
+    if reuse:
+        slot = slots[0]            # selectGoodFeatures.py:176-181: level 0 of the pyramids kept from the last track
+    else:
+        slot = slots[2]
+        ctx.upload(slot, image_to_array(img))
+    fl_in = features_to_array(featurelist) if mode == selectionMode.REPLACING_SOME else None
+    fl, _ = ctx.select(slot, len(featurelist), mode=mode, fl=fl_in, use_pyramid=reuse)
+    for feat, rec, old in zip(featurelist, fl, fl_in if fl_in is not None else fl):
+        if mode == selectionMode.REPLACING_SOME and old["val"] >= 0:
+            continue                # live features are left untouched (:109-110)
+        if rec["val"] >= 0:
+            feat.x = int(rec["x"])
+            feat.y = int(rec["y"])
+            feat.val = int(rec["val"])
+        elif mode == selectionMode.SELECTING_ALL:
+            feat.x = -1
+            feat.y = -1
+            feat.val = kltState.KLT_NOT_FOUND
+        else:
+            continue
+        feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = None
+        feat.aff_x = feat.aff_y = -1.0
+        feat.aff_Axx, feat.aff_Ayx, feat.aff_Axy, feat.aff_Ayy = 1.0, 0.0, 0.0, 1.0
+    return featurelist
+
+
+def KLTSelectGoodFeatures(tc, img, nFeatures):
+    """selectGoodFeatures.py:279-294"""
+    ncols, nrows = _image_size(img)
+    if KLT_verbose >= 1:
+        print("(KLT) Selecting the {0} best features from a {1} by {2} image...  ".format(nFeatures, ncols, nrows))
+    fl = _KLTSelectGoodFeatures(tc, img, nFeatures, selectionMode.SELECTING_ALL)
+    if KLT_verbose >= 1:
+        print("\n\t{0} features found.\n".format(KLTCountRemainingFeatures(fl)))
+    return fl
+
+
+def KLTReplaceLostFeatures(tc, img, featurelist):
+    """Upstream KLT's KLTReplaceLostFeatures (absent from the reference, which only carries the
+    REPLACING_SOME plumbing: selectGoodFeatures.py:64-69, :109-110, :176-181).  Lost features
+    (val < 0) are replaced by the best new candidates that keep `mindist` to every live feature."""
+    ncols, nrows = _image_size(img)
+    nLost = len(featurelist) - KLTCountRemainingFeatures(featurelist)
+    if KLT_verbose >= 1:
+        print("(KLT) Attempting to replace {0} features in a {1} by {2} image...  ".format(nLost, ncols, nrows))
+    if nLost > 0:
+        _KLTSelectGoodFeatures(tc, img, len(featurelist), selectionMode.REPLACING_SOME, featurelist)
+    if KLT_verbose >= 1:
+        print("\n\t{0} features replaced.".format(nLost - len(featurelist) + KLTCountRemainingFeatures(featurelist)))

@@ -1,0 +1,80 @@
+"""KLTTrackFeatures (reference: trackFeatures.py) on the MI355X backend.
+
+One call = upload the frame(s) as u8, build the image / gradx / grady pyramids of each on the
+device (ComputeImagePyramids, trackFeatures.py:146-196) and run one tracker launch over all live
+features (one wavefront per feature, all pyramid levels inside the kernel).  In sequentialMode the
+frame-2 pyramids stay resident and become frame 1 of the next call (:152-161, :401-404).
+"""
+from __future__ import print_function
+
+from . import selectGoodFeatures as _sgf
+from .backend import default_context
+from .klt import KLTCountRemainingFeatures, kltState  # noqa: F401
+from .selectGoodFeatures import _fix_window, _image_size, _slots_of, features_to_array, image_to_array
+
+
+class _ResidentPyramids:
+    """What tc.pyramid_last* point at in sequential mode: pyramids living in a device slot."""
+    def __init__(self, slot, ncols, nrows, which):
+        self.slot, self.which = slot, which
+        self.ncols, self.nrows = [ncols], [nrows]
+
+    def __repr__(self):
+        return "<device pyramid %s of slot %d, %dx%d>" % (self.which, self.slot, self.ncols[0], self.nrows[0])
+
+
+def _outOfBounds(x, y, ncols, nrows, borderx, bordery):
+    """trackFeatures.py:140-141"""
+    return x < borderx or x > ncols - 1 - borderx or y < bordery or y > nrows - 1 - bordery
+
+
+def KLTTrackFeatures(tc, img1, img2, featurelist):
+    """trackFeatures.py:205-409 (translation model; the affine branch :347-399 calls functions the
+    reference never defines)."""
+    ncols, nrows = _image_size(img1)
+    assert _image_size(img2) == (ncols, nrows)
+    if _sgf.KLT_verbose >= 1:
+        print("(KLT) Tracking {0} features in a {1} by {2} image...  ".format(
+            KLTCountRemainingFeatures(featurelist), ncols, nrows))
+    _fix_window(tc)
+    if tc.affineConsistencyCheck >= 0:
+        raise NotImplementedError("affine consistency check: not implemented by the reference "
+                                  "(trackFeatures.py:347-399 raises NameError); planned, see DESIGN.md")
+    ctx = default_context()
+    ctx.configure(tc)
+    s1, s2, _ = _slots_of(tc)
+    resident = tc.sequentialMode and tc.pyramid_last is not None
+    if resident:
+        if tc.pyramid_last.ncols[0] != ncols or tc.pyramid_last.nrows[0] != nrows:
+            from .error import KLTError
+            KLTError("(KLTTrackFeatures) Size of incoming image ({0} by {1}) is different from size of previous image "
+                     "({2} by {3})".format(ncols, nrows, tc.pyramid_last.ncols[0], tc.pyramid_last.nrows[0]))
+    else:
+        ctx.upload(s1, image_to_array(img1))
+        ctx.build_pyramids(s1, sync=False)
+    ctx.upload(s2, image_to_array(img2))
+    ctx.build_pyramids(s2, sync=False)
+
+    fl_in = features_to_array(featurelist)
+    fl_out, _ = ctx.track(s1, s2, fl_in)
+    for feat, old, new in zip(featurelist, fl_in, fl_out):
+        if old["val"] < 0:
+            continue                                  # only live features are tracked (:253)
+        if new["val"] == kltState.KLT_TRACKED:
+            feat.x = float(new["x"])
+            feat.y = float(new["y"])
+            feat.val = kltState.KLT_TRACKED
+        else:
+            feat.x = -1.0
+            feat.y = -1.0
+            feat.val = int(new["val"])
+            feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = None
+
+    if tc.sequentialMode:
+        ctx.swap_slots(s1, s2)                        # frame-2 pyramids become frame 1 (:401-404)
+        tc.pyramid_last = _ResidentPyramids(s1, ncols, nrows, "img")
+        tc.pyramid_last_gradx = _ResidentPyramids(s1, ncols, nrows, "gradx")
+        tc.pyramid_last_grady = _ResidentPyramids(s1, ncols, nrows, "grady")
+
+    if _sgf.KLT_verbose >= 1:
+        print("\n\t{0} features successfully tracked.".format(KLTCountRemainingFeatures(featurelist)))

@@ -1,0 +1,397 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and with the reference's goldens.
+
+Integer / index results and every f32 image are compared bit-for-bit; tracked positions are
+compared bit-for-bit as well (the north-star tolerance is 1e-3 px -- TOL below -- but the kernels
+reproduce the reference's arithmetic order, so the stricter check is the regression guard).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_tc, params_from_tc, synth251_frames, sha_bytes
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3   # px, BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyfeaturetrack_amd.backend import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ko():
+    from oracle import klt_oracle
+    return klt_oracle
+
+
+def assert_same(a, b, what):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    bad = np.flatnonzero(a.ravel() != b.ravel())
+    if bad.size:
+        i = bad[0]
+        raise AssertionError("%s: %d of %d differ; first at flat index %d: %r vs %r" %
+                             (what, bad.size, a.size, i, a.ravel()[i], b.ravel()[i]))
+
+
+def assert_feats(fl, gx, gy, gv, what):
+    assert_same(fl["val"].astype(np.int64), np.asarray(gv, np.int64), what + ".val")
+    dx = np.abs(fl["x"].astype(np.float64) - np.asarray(gx, np.float64)).max()
+    dy = np.abs(fl["y"].astype(np.float64) - np.asarray(gy, np.float64)).max()
+    assert dx <= TOL and dy <= TOL, "%s: position error %g / %g px exceeds %g" % (what, dx, dy, TOL)
+    assert_same(fl["x"].astype(np.float64), gx, what + ".x (bit-exact)")
+    assert_same(fl["y"].astype(np.float64), gy, what + ".y (bit-exact)")
+
+
+def oracle_feats(fl):
+    return fl["x"].astype(np.float64), fl["y"].astype(np.float64), fl["val"].astype(np.int64)
+
+
+# ------------------------------------------------------------------------------ convolutions
+def test_smooth_and_gradients_img0(ctx, ko, cfg1, img0):
+    from pyfeaturetrack_amd.convolve import _computeKernels
+    g07, _ = _computeKernels(0.1 * 7)     # smooth_sigma_fact * max(window) as the reference computes it
+    sm = ctx.smooth(img0.astype(np.float32), g07)
+    assert_same(sm, cfg1["sel_smooth"], "smooth(img0)")
+    g, d = _computeKernels(1.0)
+    gx, gy = ctx.gradients(sm, g, d)
+    assert_same(gx, cfg1["sel_gx"], "gradx(img0)")
+    assert_same(gy, cfg1["sel_gy"], "grady(img0)")
+
+
+@pytest.mark.parametrize("shape,sigma", [((187, 251), 3.6), ((67, 120), 7.2), ((9, 7), 7.2), ((5, 300), 1.8),
+                                         ((300, 3), 1.5), ((1, 1), 1.0), ((64, 64), 0.7), ((130, 257), 1.0)])
+def test_convolutions_vs_oracle(ctx, ko, shape, sigma):
+    from pyfeaturetrack_amd.convolve import _computeKernels
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    img = (rng.random(shape) * 255).astype(np.float32)
+    g, d = _computeKernels(sigma)
+    assert_same(ctx.smooth(img, g), ko.smooth(img, sigma), "smooth %s sigma %s" % (shape, sigma))
+    gx, gy = ctx.gradients(img, g, d)
+    ogx, ogy = ko.gradients(img, sigma)
+    assert_same(gx, ogx, "gradx %s sigma %s" % (shape, sigma))
+    assert_same(gy, ogy, "grady %s sigma %s" % (shape, sigma))
+
+
+# ---------------------------------------------------------------------------------- pyramids
+def test_pyramids_cfg1(ctx, cfg1, img0, img1):
+    ctx.configure(make_tc())
+    for slot, (name, im) in enumerate((("p0", img0), ("p1", img1))):
+        ctx.upload(slot, im)
+        ctx.build_pyramids(slot)
+        for l in range(2):
+            for pi, w in enumerate(("img", "gx", "gy")):
+                assert_same(ctx.download_level(slot, pi, l), cfg1["%s_%s_%d" % (name, w, l)], "%s %s level %d" % (name, w, l))
+
+
+def test_pyramids_f32_upload_equals_u8(ctx, img0):
+    ctx.configure(make_tc())
+    ctx.upload(0, img0)
+    ctx.build_pyramids(0)
+    ctx.upload(1, img0.astype(np.float32))
+    ctx.build_pyramids(1)
+    for l in range(2):
+        for pi in range(3):
+            assert_same(ctx.download_level(0, pi, l), ctx.download_level(1, pi, l), "u8 vs f32 upload")
+
+
+def test_pyramids_synth251(ctx, ko, synth251):
+    fr = synth251_frames()
+    tc = make_tc(levels=3, ss=2, max_residue=10.0)
+    ctx.configure(tc)
+    p = params_from_tc(tc)
+    for slot, name in ((0, "p0"), (1, "p1")):
+        ctx.upload(slot, fr[slot])
+        ctx.build_pyramids(slot)
+        P = ko.Pyramids(p, fr[slot].astype(np.float32))
+        assert [ctx.level_dims(slot, l) for l in range(3)] == [(251, 187), (125, 93), (62, 46)]
+        for l in range(3):
+            for pi, w in enumerate(("img", "gx", "gy")):
+                got = ctx.download_level(slot, pi, l)
+                assert_same(got, P.level(w, l), "synth %s %s level %d vs oracle" % (name, w, l))
+                assert_same(sha_bytes(got), synth251["%s_%s_%d_sha" % (name, w, l)], "synth %s %s level %d sha" % (name, w, l))
+
+
+# --------------------------------------------------------------------------------- selection
+def test_select_internals_cfg1(ctx, cfg1, img0):
+    ctx.configure(make_tc())
+    ctx.upload(2, img0)
+    fl, placed = ctx.select(2, 100)
+    assert placed == 100
+    assert_same(ctx.select_intermediate(0), cfg1["sel_smooth"], "selection smoothed image")
+    assert_same(ctx.select_intermediate(1), cfg1["sel_gx"], "selection gradx")
+    assert_same(ctx.select_intermediate(2), cfg1["sel_gy"], "selection grady")
+    assert_same(ctx.select_intermediate(3), cfg1["sel_val"], "eigenvalue map")
+    val, x, y = ctx.sorted_candidates(20000)
+    n = len(val)
+    gv = cfg1["sel_sorted_val"]
+    n_ref = int(np.count_nonzero(gv >= 1.0))      # the device list drops val < max(min_eigenvalue, 1)
+    assert n == min(n_ref, 20000) or n_ref == 20000
+    assert_same(val, gv[:n], "sorted candidate values")
+    assert_same(x, cfg1["sel_sorted_x"][:n], "sorted candidate x")
+    assert_same(y, cfg1["sel_sorted_y"][:n], "sorted candidate y")
+    assert_feats(fl, cfg1["sel100_x"], cfg1["sel100_y"], cfg1["sel100_val"], "select 100")
+
+
+@pytest.mark.parametrize("n", [50, 100, 300])
+def test_select_cfg1(ctx, cfg1, img0, n):
+    ctx.configure(make_tc())
+    ctx.upload(2, img0)
+    fl, placed = ctx.select(2, n)
+    assert placed == n
+    assert_feats(fl, cfg1["sel%d_x" % n], cfg1["sel%d_y" % n], cfg1["sel%d_val" % n], "select %d" % n)
+
+
+def test_select_skip_mindist_nosmooth(ctx, cfg1, img0):
+    ctx.configure(make_tc(nSkippedPixels=2, mindist=15, smoothBeforeSelecting=False))
+    ctx.upload(2, img0)
+    fl, _ = ctx.select(2, 60)
+    assert_feats(fl, cfg1["selskip_x"], cfg1["selskip_y"], cfg1["selskip_val"], "select skip=2 mindist=15 nosmooth")
+    ctx.upload(2, img0.astype(np.float32))       # f32 frame without pre-smoothing
+    fl, _ = ctx.select(2, 60)
+    assert_feats(fl, cfg1["selskip_x"], cfg1["selskip_y"], cfg1["selskip_val"], "select (f32 upload)")
+
+
+@pytest.mark.parametrize("mindist", [0, 1, 2, 10, 40])
+def test_select_mindist_and_exhaustion_vs_oracle(ctx, ko, img0, mindist):
+    """more features requested than can be placed -> remaining slots are (-1,-1,KLT_NOT_FOUND)"""
+    tc = make_tc(mindist=mindist)
+    ctx.configure(tc)
+    ctx.upload(2, img0)
+    n = 3000 if mindist >= 2 else 500
+    fl, placed = ctx.select(2, n)
+    ofl = ko.select_good_features(params_from_tc(tc), img0.astype(np.float32), n)
+    assert placed == int(np.count_nonzero(ofl["val"] >= 0))
+    assert_feats(fl, *oracle_feats(ofl), what="select mindist=%d n=%d" % (mindist, n))
+
+
+def test_replacing_some_cfg1(ctx, cfg1, img1):
+    ctx.configure(make_tc(max_residue=10.0))
+    from pyfeaturetrack_amd.backend import FEAT_DTYPE, REPLACING_SOME
+    fl = np.zeros(100, FEAT_DTYPE)
+    fl["x"], fl["y"], fl["val"] = cfg1["repl_in_x"], cfg1["repl_in_y"], cfg1["repl_in_val"]
+    ctx.upload(2, img1)
+    out, placed = ctx.select(2, 100, mode=REPLACING_SOME, fl=fl)
+    assert placed == int(np.count_nonzero(cfg1["repl_in_val"] < 0))
+    assert_feats(out, cfg1["repl_out_x"], cfg1["repl_out_y"], cfg1["repl_out_val"], "replace lost features")
+
+
+# ---------------------------------------------------------------------------------- tracking
+@pytest.mark.parametrize("tag,mr", [("r10", 10.0), ("rnone", None)])
+def test_track_cfg1(ctx, cfg1, img0, img1, tag, mr):
+    ctx.configure(make_tc(max_residue=mr))
+    ctx.upload(0, img0)
+    ctx.upload(1, img1)
+    ctx.build_pyramids(0, sync=False)
+    ctx.build_pyramids(1, sync=False)
+    fl, _ = ctx.select(0, 100, use_pyramid=False)
+    ctx.track_stats_reset()
+    out, k = ctx.track(0, 1, fl)
+    assert_feats(out, cfg1["trk100_%s_x" % tag], cfg1["trk100_%s_y" % tag], cfg1["trk100_%s_val" % tag], "track " + tag)
+    assert k == int(np.count_nonzero(cfg1["trk100_%s_val" % tag] >= 0))
+    rec = cfg1["trk100_%s_iter" % tag]          # one row per trackFeatureIterateCKLT call: ..., ncols, ..., iterations
+    st = ctx.track_stats()
+    assert st["features"] == 100
+    for lvl, nc in ((0, 320), (1, 80)):
+        rows = rec[rec[:, 2] == nc]
+        assert st["level_visits"][lvl] == len(rows)
+        assert st["iterations"][lvl] == int(rows[:, 6].sum())
+
+
+def test_track_retain(ctx, cfg1, img0, img1):
+    ctx.configure(make_tc(max_residue=10.0, retainTrackers=True))
+    ctx.upload(0, img0)
+    ctx.upload(1, img1)
+    ctx.build_pyramids(0)
+    ctx.build_pyramids(1)
+    fl, _ = ctx.select(0, 100)
+    out, _ = ctx.track(0, 1, fl)
+    assert_feats(out, cfg1["trk100_retain_x"], cfg1["trk100_retain_y"], cfg1["trk100_retain_val"], "track retainTrackers")
+
+
+def test_pingpong_and_lost_features_skipped(ctx, cfg1, img0, img1):
+    ctx.configure(make_tc(max_residue=10.0))
+    ctx.upload(0, img0)
+    ctx.upload(1, img1)
+    ctx.build_pyramids(0)
+    ctx.build_pyramids(1)
+    fl, _ = ctx.select(0, 50)
+    for k in range(6):
+        fl, _ = ctx.track(k % 2, (k + 1) % 2, fl)
+        assert_feats(fl, cfg1["pp50_%d_x" % k], cfg1["pp50_%d_y" % k], cfg1["pp50_%d_val" % k], "ping-pong call %d" % k)
+
+
+def test_sequential_swap_slots(ctx, cfg1, img0, img1):
+    ctx.configure(make_tc(max_residue=10.0))
+    ctx.upload(0, img0)
+    ctx.build_pyramids(0)
+    fl, _ = ctx.select(0, 50)
+    ctx.upload(1, img1)
+    ctx.build_pyramids(1)
+    fl, _ = ctx.track(0, 1, fl)
+    assert_feats(fl, cfg1["seq50_0_x"], cfg1["seq50_0_y"], cfg1["seq50_0_val"], "sequential call 0")
+    ctx.swap_slots(0, 1)                           # frame-2 pyramids become frame 1
+    ctx.upload(1, img0)
+    ctx.build_pyramids(1)
+    fl, _ = ctx.track(0, 1, fl)
+    assert_feats(fl, cfg1["seq50_1_x"], cfg1["seq50_1_y"], cfg1["seq50_1_val"], "sequential call 1")
+
+
+def test_synth251_select_track(ctx, synth251):
+    fr = synth251_frames()
+    tc = make_tc(levels=3, ss=2, max_residue=10.0)
+    ctx.configure(tc)
+    for s in range(3):
+        ctx.upload(s, fr[s])
+        ctx.build_pyramids(s)
+    ctx.upload(3, fr[0])
+    fl, _ = ctx.select(3, 60)
+    assert_same(ctx.select_intermediate(3), synth251["sel_val"], "synth eigenvalue map")
+    assert_feats(fl, synth251["sel60_x"], synth251["sel60_y"], synth251["sel60_val"], "synth select 60")
+    fl2, _ = ctx.select(0, 60, use_pyramid=True)   # level 0 of the pyramids is the same smoothed image
+    assert_feats(fl2, synth251["sel60_x"], synth251["sel60_y"], synth251["sel60_val"], "synth select via pyramid level 0")
+    fl, _ = ctx.track(0, 1, fl)
+    assert_feats(fl, synth251["trk_0_x"], synth251["trk_0_y"], synth251["trk_0_val"], "synth track 0->1")
+    fl, _ = ctx.track(1, 2, fl)
+    assert_feats(fl, synth251["trk_1_x"], synth251["trk_1_y"], synth251["trk_1_val"], "synth track 1->2")
+
+
+def test_synth251_window15(ctx, synth251):
+    fr = synth251_frames()
+    tc = make_tc(levels=2, ss=2, window=15)
+    ctx.configure(tc)
+    ctx.upload(0, fr[0])
+    ctx.upload(1, fr[1])
+    fl, _ = ctx.select(0, 25)
+    assert_feats(fl, synth251["w15_sel_x"], synth251["w15_sel_y"], synth251["w15_sel_val"], "15x15 select")
+    tc.max_residue = 12.0
+    ctx.configure(tc)
+    ctx.build_pyramids(0)
+    ctx.build_pyramids(1)
+    fl, _ = ctx.track(0, 1, fl)
+    assert_feats(fl, synth251["w15_trk_x"], synth251["w15_trk_y"], synth251["w15_trk_val"], "15x15 track")
+
+
+@pytest.mark.parametrize("window,levels,ss", [(3, 2, 2), (5, 2, 4), (9, 3, 2), (11, 2, 2), (21, 2, 2), (31, 1, 2)])
+def test_other_windows_vs_oracle(ctx, ko, window, levels, ss):
+    from pyfeaturetrack_amd import synth
+    W, H = 400, 300
+    base = synth.synth_base(W, H, 5)
+    f0 = synth.shift_frame(base, 0, 0)
+    f1 = synth.shift_frame(base, 1.7, -1.2)
+    tc = make_tc(levels=levels, ss=ss, window=window, max_residue=15.0)
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(0, f0)
+    ctx.upload(1, f1)
+    ctx.build_pyramids(0)
+    ctx.build_pyramids(1)
+    fl, _ = ctx.select(0, 80)
+    ofl = ko.select_good_features(p, f0.astype(np.float32), 80)
+    assert_feats(fl, *oracle_feats(ofl), what="window %d select" % window)
+    out, _ = ctx.track(0, 1, fl)
+    ko.track_features(p, ko.Pyramids(p, f0.astype(np.float32)), ko.Pyramids(p, f1.astype(np.float32)), ofl)
+    assert_feats(out, *oracle_feats(ofl), what="window %d track" % window)
+
+
+# ------------------------------------------------------------------------ full-size (cfg-2)
+def test_cfg2_1080p_vs_oracle_and_known_shift(ctx, ko):
+    """BASELINE cfg-2: 1920x1080, 5000 features, 7x7, 3 levels / ss 4 (border 120)."""
+    from pyfeaturetrack_amd import synth
+    f0, f1 = synth.synth_pair(1920, 1080, 1)
+    tc = make_tc(levels=3, ss=4)
+    assert tc.borderx == 120.0
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(0, f0)
+    ctx.upload(1, f1)
+    ctx.build_pyramids(0, sync=False)
+    ctx.build_pyramids(1, sync=False)
+    fl, placed = ctx.select(0, 5000, use_pyramid=True)
+    ofl, oval = ko.select_good_features(p, f0.astype(np.float32), 5000, want_val=True)
+    assert_same(ctx.select_intermediate(3), oval, "1080p eigenvalue map")
+    assert placed == int(np.count_nonzero(ofl["val"] >= 0)) == 5000
+    assert_feats(fl, *oracle_feats(ofl), what="1080p select 5000")
+    out, k = ctx.track(0, 1, fl)
+    P0, P1 = ko.Pyramids(p, f0.astype(np.float32)), ko.Pyramids(p, f1.astype(np.float32))
+    for l in range(3):
+        for pi, w in enumerate(("img", "gx", "gy")):
+            assert_same(ctx.download_level(1, pi, l), P1.level(w, l), "1080p frame-1 %s level %d" % (w, l))
+    ko.track_features(p, P0, P1, ofl)
+    assert_feats(out, *oracle_feats(ofl), what="1080p track")
+    live = out["val"] == 0
+    assert live.sum() > 4500
+    dx = np.median(out["x"][live] - fl["x"][live])
+    dy = np.median(out["y"][live] - fl["y"][live])
+    assert abs(dx - 3.3) < 0.02 and abs(dy + 2.1) < 0.02, (dx, dy)
+
+
+def test_nms_global_grid_path(ctx, ko):
+    """mindist 2 at 1920x1080 -> the cell grid (960x540 u32) exceeds LDS and lives in global memory"""
+    from pyfeaturetrack_amd import synth
+    f0 = synth.synth_frame(1920, 1080, 2, 0)
+    tc = make_tc(levels=3, ss=4, mindist=2)
+    ctx.configure(tc)
+    ctx.upload(0, f0)
+    fl, _ = ctx.select(0, 4000)
+    ofl = ko.select_good_features(params_from_tc(tc), f0.astype(np.float32), 4000)
+    assert_feats(fl, *oracle_feats(ofl), what="select mindist=2 (global grid)")
+
+
+# ------------------------------------------------------------------------------- Python API
+def test_python_api_example1_flow(cfg1, golden_dir, tmp_path, capsys):
+    """The reference's example1.py call sequence through the reference-shaped API (PIL images)."""
+    PIL = pytest.importorskip("PIL.Image")
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext, KLTCountRemainingFeatures
+    from pyfeaturetrack_amd.selectGoodFeatures import KLTSelectGoodFeatures, KLTReplaceLostFeatures
+    from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures
+    from pyfeaturetrack_amd.writeFeatures import KLTWriteFeatureListToPPM
+    tc = KLT_TrackingContext()
+    tc.max_residue = 10.0
+    i0 = PIL.open(os.path.join(golden_dir, "img0.pgm"))
+    i1 = PIL.open(os.path.join(golden_dir, "img1.pgm"))
+    fl = KLTSelectGoodFeatures(tc, i0, 50)
+    assert [(f.x, f.y, f.val) for f in fl] == [(int(x), int(y), int(v)) for x, y, v in
+                                               zip(cfg1["sel50_x"], cfg1["sel50_y"], cfg1["sel50_val"])]
+    assert isinstance(fl[0].x, int)
+    KLTWriteFeatureListToPPM(fl, i0, str(tmp_path / "feat1.ppm"))
+    for k in range(4):
+        KLTTrackFeatures(tc, i0 if k % 2 == 0 else i1, i1 if k % 2 == 0 else i0, fl)
+        assert [f.val for f in fl] == [int(v) for v in cfg1["pp50_%d_val" % k]]
+        assert np.array_equal(np.array([f.x for f in fl], np.float64), cfg1["pp50_%d_x" % k])
+        assert np.array_equal(np.array([f.y for f in fl], np.float64), cfg1["pp50_%d_y" % k])
+    out = capsys.readouterr().out
+    assert "(KLT) Selecting the 50 best features from a 320 by 240 image...  " in out
+    assert "\t45 features successfully tracked." in out
+    before = KLTCountRemainingFeatures(fl)
+    KLTReplaceLostFeatures(tc, i0, fl)
+    assert KLTCountRemainingFeatures(fl) == 50 > before
+
+
+def test_python_api_sequential_mode(cfg1, golden_dir):
+    PIL = pytest.importorskip("PIL.Image")
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures
+    sgf.KLT_verbose = 0
+    try:
+        tc = KLT_TrackingContext()
+        tc.max_residue = 10.0
+        tc.sequentialMode = True
+        i0 = PIL.open(os.path.join(golden_dir, "img0.pgm"))
+        i1 = PIL.open(os.path.join(golden_dir, "img1.pgm"))
+        fl = sgf.KLTSelectGoodFeatures(tc, i0, 50)
+        KLTTrackFeatures(tc, i0, i1, fl)
+        assert tc.pyramid_last is not None
+        assert np.array_equal(np.array([f.x for f in fl], np.float64), cfg1["seq50_0_x"])
+        KLTTrackFeatures(tc, i0, i0, fl)           # first image ignored: frame-2 pyramids of the last call are used
+        assert np.array_equal(np.array([f.x for f in fl], np.float64), cfg1["seq50_1_x"])
+        assert [f.val for f in fl] == [int(v) for v in cfg1["seq50_1_val"]]
+    finally:
+        sgf.KLT_verbose = 1

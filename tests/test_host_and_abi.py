@@ -1,0 +1,129 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, host logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(REPO, "include", "klt_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(klt_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_agree():
+    from pyfeaturetrack_amd import _abi
+    assert _declared_symbols() == sorted(_abi.SYMBOLS)
+
+
+def test_library_exports_every_symbol():
+    from pyfeaturetrack_amd import _abi
+    if not os.path.exists(_abi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    lib.klt_abi_version.restype = ctypes.c_int
+    assert lib.klt_abi_version() == 1
+
+
+def test_struct_layouts():
+    from pyfeaturetrack_amd import _abi
+    assert ctypes.sizeof(_abi.KltFeat) == 16
+    assert ctypes.sizeof(_abi.KltParams) == 10 * 4 + 4 * 4 + 6 * 8
+    assert ctypes.sizeof(_abi.KltTrackStats) == 8 * 17
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product path must raise, not compute elsewhere."""
+    from pyfeaturetrack_amd import _abi
+    from pyfeaturetrack_amd.backend import Context, KltBackendError
+    lib = _abi.load_library()
+    if lib.klt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(KltBackendError):
+        Context(0)
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.selectGoodFeatures import KLTSelectGoodFeatures
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    sgf.KLT_verbose = 0
+    try:
+        with pytest.raises(KltBackendError):
+            KLTSelectGoodFeatures(KLT_TrackingContext(), np.zeros((64, 64), np.uint8), 5)
+    finally:
+        sgf.KLT_verbose = 1
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "pyfeaturetrack_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "klt_oracle" not in src and "libkltoracle" not in src, os.path.join(root, f)
+
+
+def test_params_packing_and_errors():
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.params import params_from_tc, taps_from_params
+    tc = KLT_TrackingContext()
+    p = params_from_tc(tc)
+    assert (p.nPyramidLevels, p.subsampling, p.borderx, p.use_max_residue) == (2, 4, 30.0, 0)
+    assert abs(p.smooth_sigma - 0.7) < 1e-12 and p.pyramid_sigma == 3.6
+    assert [len(g) for g, _ in taps_from_params(p)] == [5, 21, 7]
+    tc.max_residue = 10.0
+    assert params_from_tc(tc).use_max_residue == 1
+    tc.lighting_insensitive = True
+    with pytest.raises(Exception, match="Not implemented"):      # trackFeaturesUtils.pyx:434-435
+        params_from_tc(tc)
+    tc.lighting_insensitive = False
+    tc.window_height = 9
+    with pytest.raises(ValueError):
+        params_from_tc(tc)
+
+
+def test_window_corrections_and_pyramid_choice(capsys):
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext, KLTCountRemainingFeatures, KLT_Feature
+    tc = KLT_TrackingContext()
+    tc.window_width = tc.window_height = 8
+    tc.KLTChangeTCPyramid(15)
+    assert tc.window_width == 9 and "must be odd" in capsys.readouterr().out
+    tc.window_width = tc.window_height = 1
+    tc.KLTUpdateTCBorder()
+    assert tc.window_width == 3
+    fl = [KLT_Feature() for _ in range(3)]
+    fl[1].val = 5
+    assert KLTCountRemainingFeatures(fl) == 1
+
+
+def test_print_tracking_context(capsys):
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext, KLTPrintTrackingContext
+    KLTPrintTrackingContext(KLT_TrackingContext())
+    out = capsys.readouterr().out
+    assert "\tborderx = 30.0\n" in out and "\tnPyramidLevels = 2\n" in out and "\tmax_residue = None\n" in out
+
+
+def test_synth_known_shift_and_periodicity():
+    from pyfeaturetrack_amd import synth
+    base = synth.synth_base(96, 64, 3)
+    assert base.min() == 0.0 and abs(base.max() - 255.0) < 1e-9
+    f0 = synth.shift_frame(base, 0, 0)
+    f5 = synth.shift_frame(base, 5, -3)
+    assert np.array_equal(np.roll(f0, (-3, 5), axis=(0, 1)), f5)
+    assert np.array_equal(synth.shift_frame(base, 96, 64), f0)       # periodic
+
+
+def test_compat_module_names():
+    import subprocess
+    import sys
+    code = ("from klt import *\nfrom selectGoodFeatures import *\nfrom writeFeatures import *\n"
+            "from trackFeatures import *\nimport time\n"
+            "tc = KLT_TrackingContext(); assert tc.borderx == 30.0 and hasattr(time, 'clock')\n"
+            "assert KLT_verbose == 1 and callable(KLTTrackFeatures) and callable(KLTWriteFeatureListToPPM)\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([REPO, os.path.join(REPO, "pyfeaturetrack_amd", "compat")]))
+    subprocess.run([sys.executable, "-c", code], check=True, env=env)
