@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: features tracked / s and ms per frame pair (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one KLTTrackFeatures-equivalent on one frame pair per rank: build the image / gradx /
+grady pyramids of both frames from the u8 frames already resident in HBM, then track every live
+feature coarse-to-fine (device-resident feature records in, device-resident records out).
+Workload at every N = BASELINE cfg-2 (1920x1080 synthetic pair, 5000 features, 7x7 window,
+3 pyramid levels / subsampling 4, translation only); with N > 1 every rank runs its own pair
+(seed = rank + 1: weak scaling, the path shards by frame pair with no data-path exchange) and the
+16-byte feature records are gathered to every rank with one RCCL all-gather per step, ordered on
+the tracker's HIP stream.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant kernel of the step (largest share of device time), timed with HIP
+                  events on the context's stream in a second pass over the same K steps (events
+                  around every launch would distort the un-instrumented `value`);
+  cpu_baseline -- the CPU oracle (oracle/klt_oracle.c, a bit-exact port of the reference's
+                  Python/Cython/SciPy path) on the same workload, 1 thread, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from pyfeaturetrack_amd import synth                                   # noqa: E402
+from pyfeaturetrack_amd.backend import Context                          # noqa: E402
+from pyfeaturetrack_amd.klt import KLT_TrackingContext                  # noqa: E402
+from pyfeaturetrack_amd.params import params_from_tc                    # noqa: E402
+
+WIDTH, HEIGHT, NFEAT = 1920, 1080, 5000
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FB_SEL, FB_OUT0, FB_OUT1 = 0, 1, 2
+
+
+def cfg2_context():
+    tc = KLT_TrackingContext()
+    tc.nPyramidLevels = 3
+    tc.subsampling = 4
+    tc.KLTUpdateTCBorder()          # border 120
+    return tc
+
+
+def algorithmic_bytes(p, ncols, nrows, stats, nfeat):
+    """minimum traffic per pair = 2 * bytes_pyramid + sum over features of bytes_track."""
+    ss, L = p.subsampling, p.nPyramidLevels
+    n, dims = [], (ncols, nrows)
+    for _ in range(L):
+        n.append(dims[0] * dims[1])
+        dims = (dims[0] // ss, dims[1] // ss)
+    pyr = n[0] * (1 + 4) + sum(4 * (n[l - 1] + n[l]) for l in range(1, L)) + sum(12 * v for v in n)
+    foot = 12.0 * (p.window_width + 1) * (p.window_height + 1)
+    track = foot * (sum(stats["level_visits"][:L]) + sum(stats["iterations"][:L])) + 24.0 * nfeat
+    return pyr, track
+
+
+def cpu_baseline(p, f0, f1, fl):
+    """Oracle timed on the host: bounded sample of the same workload (about 10-20 s of CPU work)."""
+    from oracle import klt_oracle as ko
+    a0, a1 = f0.astype(np.float32), f1.astype(np.float32)
+
+    def one_pair():
+        P0, P1 = ko.Pyramids(p, a0), ko.Pyramids(p, a1)
+        return ko.track_features(p, P0, P1, fl.copy())
+
+    t = time.perf_counter()
+    one_pair()
+    t1 = time.perf_counter() - t
+    reps = int(max(2, min(40, 12.0 / max(t1, 1e-3))))
+    t = time.perf_counter()
+    for _ in range(reps):
+        one_pair()
+    dt = (time.perf_counter() - t) / reps
+    return {"value": NFEAT / dt, "unit": "features/s", "cores": 1, "kind": "port",
+            "ms_per_pair": dt * 1e3,
+            "sample": "%d x (pyramids of both 1920x1080 frames + track 5000 features), oracle/klt_oracle.c, 1 thread" % reps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+    distributed = world > 1
+
+    torch = dist = None
+    if distributed:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    tc = cfg2_context()
+    p = params_from_tc(tc)
+    ctx = Context(local_rank)
+    ctx.set_params(p)
+    f0, f1 = synth.synth_pair(WIDTH, HEIGHT, seed=rank + 1)
+    ctx.upload(0, f0)
+    ctx.upload(1, f1)
+    ctx.build_pyramids(0)
+    fl, placed = ctx.select(0, NFEAT, use_pyramid=True)
+    assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)
+    ctx.featbuf_upload(FB_SEL, fl)
+    ctx.featbuf_upload(FB_OUT0, fl)
+    ctx.featbuf_upload(FB_OUT1, fl)
+
+    gather = None
+    if distributed:
+        from pyfeaturetrack_amd.parallel import FeatureGather
+        gather = FeatureGather(ctx, [FB_OUT0, FB_OUT1], NFEAT, world, torch, dist)
+
+    def step(i):
+        out = FB_OUT0 if i % 2 == 0 else FB_OUT1
+        ctx.build_pyramids(0, sync=False)
+        ctx.build_pyramids(1, sync=False)
+        ctx.track_async(0, 1, FB_SEL, out, NFEAT)
+        if gather is not None:
+            gather.all_gather(out)          # RCCL, enqueued behind the tracker on the same HIP stream
+
+    def fence():
+        ctx.sync()
+        if distributed:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was timed: the last output equals a fresh synchronous track
+    out = ctx.featbuf_download(FB_OUT0 if (args.steps - 1) % 2 == 0 else FB_OUT1, NFEAT)
+    tracked = int(np.count_nonzero(out["val"] >= 0))
+    live = out["val"] == 0
+    shift = (float(np.median(out["x"][live] - fl["x"][live])), float(np.median(out["y"][live] - fl["y"][live])))
+
+    # second pass: per-kernel HIP-event timing + iteration counters for the roofline
+    roofline = None
+    kernels = []
+    if rank == 0:
+        ctx.track_stats_reset()
+        ctx.timing_enable(True)
+        for i in range(args.steps):
+            ctx.build_pyramids(0, sync=False)
+            ctx.build_pyramids(1, sync=False)
+            ctx.track_async(0, 1, FB_SEL, FB_OUT0, NFEAT)
+        kernels = ctx.timing_read()
+        ctx.timing_enable(False)
+        st = ctx.track_stats()
+        st = {k: ([x / args.steps for x in v] if isinstance(v, list) else v / args.steps) for k, v in st.items()}
+        pyr_bytes, track_bytes = algorithmic_bytes(p, WIDTH, HEIGHT, st, NFEAT)
+        for k in kernels:
+            if k["name"] == "track":
+                k["bytes"] = track_bytes * k["launches"]
+        dom = max(kernels, key=lambda k: k["total_ms"])
+        per_launch_ms = dom["total_ms"] / dom["launches"]
+        per_launch_bytes = dom["bytes"] / dom["launches"]
+        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom["name"])
+        dev_ms = sum(k["total_ms"] for k in kernels) / args.steps
+        roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "launch_us": per_launch_ms * 1e3, "launches_per_step": dom["launches"] / args.steps,
+                    "algorithmic_bytes_per_launch": per_launch_bytes,
+                    "step_algorithmic_bytes": 2 * pyr_bytes + track_bytes,
+                    "step_device_ms": dev_ms,
+                    "step_frac": (2 * pyr_bytes + track_bytes) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "newton_iterations_per_level": st["iterations"][:p.nPyramidLevels],
+                    "kernels": {k["name"]: {"us_per_launch": 1e3 * k["total_ms"] / k["launches"],
+                                            "launches_per_step": k["launches"] / args.steps,
+                                            "GBps": k["bytes"] / max(k["total_ms"], 1e-9) / 1e6} for k in kernels}}
+
+    cpu = None
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        cpu = cpu_baseline(p, f0, f1, fl)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "features tracked/sec", "value": world * NFEAT * args.steps / elapsed, "unit": "features/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "ms_per_frame_pair": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (convolutions accumulate in f64)", "data": "synthetic",
+            "config": {"workload": "cfg-2: one 1920x1080 synthetic pair per GPU, 5000 features, 7x7 window, "
+                                   "3 pyramid levels (subsampling 4), translation only; inputs resident in HBM",
+                       "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
+                       "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
+                       "parallelism": "1 pair per GPU" + (", RCCL all-gather of feature records per step" if distributed else "")},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,7 @@ int         klt_create(int device, klt_ctx **out);          /* replaces KLT_Trac
 void        klt_destroy(klt_ctx *ctx);
 const char *klt_last_error(klt_ctx *ctx);                   /* ctx may be NULL: error of the last failed klt_create */
 int         klt_sync(klt_ctx *ctx);                         /* wait for everything enqueued on the context's stream */
+void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hipStream_t, for callers that order RCCL collectives after it */
 
 /* ---- parameters and taps ------------------------------------------------------------------- */
 int klt_set_params(klt_ctx *ctx, const klt_params *p);      /* klt.py:45-73, :84-128, :137-189 */

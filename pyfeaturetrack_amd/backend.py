@@ -56,6 +56,9 @@ class Context:
     def sync(self):
         self._check(self._lib.klt_sync(self._h))
 
+    def stream_handle(self):
+        return self._lib.klt_stream_handle(self._h)
+
     # ---------------------------------------------------------------- parameters
     def set_params(self, p):
         """p: KltParams.  Taps for the three sigmas are generated on the host (convolve.py:27-93)."""
@@ -123,7 +126,7 @@ class Context:
             fl["x"] = -1
             fl["y"] = -1
             fl["val"] = -1
-        fl = np.ascontiguousarray(fl, FEAT_DTYPE)
+        fl = np.array(fl, FEAT_DTYPE)          # always a copy: the caller's array is never modified
         placed = C.c_int()
         self._check(self._lib.klt_select(self._h, slot, mode, int(bool(use_pyramid)), fl.ctypes.data, len(fl), C.byref(placed)))
         return fl, placed.value

@@ -371,6 +371,8 @@ int klt_sync(klt_ctx *c)
     return KLT_OK;
 }
 
+void *klt_stream_handle(klt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
 int klt_set_params(klt_ctx *c, const klt_params *p)
 {
     if (!c || !p) return fail(c, KLT_ERR_ARG, "null argument");
