@@ -127,8 +127,7 @@ def main():
 
     def step(i):
         out = FB_OUT0 if i % 2 == 0 else FB_OUT1
-        ctx.build_pyramids(0, sync=False)
-        ctx.build_pyramids(1, sync=False)
+        ctx.build_pyramids_batch([0, 1])          # both frames share every launch
         ctx.track_async(0, 1, FB_SEL, out, NFEAT)
         if gather is not None:
             gather.all_gather(out)          # RCCL, enqueued behind the tracker on the same HIP stream
@@ -166,8 +165,7 @@ def main():
         ctx.track_stats_reset()
         ctx.timing_enable(True)
         for i in range(args.steps):
-            ctx.build_pyramids(0, sync=False)
-            ctx.build_pyramids(1, sync=False)
+            ctx.build_pyramids_batch([0, 1])
             ctx.track_async(0, 1, FB_SEL, FB_OUT0, NFEAT)
         kernels = ctx.timing_read()
         ctx.timing_enable(False)

@@ -77,6 +77,10 @@ const char *klt_last_error(klt_ctx *ctx);                   /* ctx may be NULL: 
 int         klt_sync(klt_ctx *ctx);                         /* wait for everything enqueued on the context's stream */
 void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hipStream_t, for callers that order RCCL collectives after it */
 
+/* ---- options ------------------------------------------------------------------------------ */
+#define KLT_OPT_FUSED_KERNELS 1   /* 1 (default): LDS-tiled fused pyramid kernels; 0: generic two-pass kernels (any tap count) */
+int klt_set_option(klt_ctx *ctx, int option, int value);
+
 /* ---- parameters and taps ------------------------------------------------------------------- */
 int klt_set_params(klt_ctx *ctx, const klt_params *p);      /* klt.py:45-73, :84-128, :137-189 */
 /* FP64 taps computed on the host exactly as convolve.py:27-93 (_computeKernels).
@@ -91,6 +95,9 @@ int klt_upload_f32(klt_ctx *ctx, int slot, const float *px, int ncols, int nrows
 /* smooth -> pyramid -> gradients of every level: ComputeImagePyramids for one image,
  * trackFeatures.py:165-172 + pyramid.py:37-77 + convolve.py:208-264 */
 int klt_build_pyramids_async(klt_ctx *ctx, int slot);
+/* the same for several slots at once: frames of equal size share kernel launches (both frames of a pair,
+ * or every pair of a batch -- BASELINE cfg-4) */
+int klt_build_pyramids_batch_async(klt_ctx *ctx, const int *slots, int n);
 int klt_build_pyramids(klt_ctx *ctx, int slot);
 /* sequentialMode: the frame-2 pyramids become frame 1 (trackFeatures.py:152-161, :401-404) */
 int klt_swap_slots(klt_ctx *ctx, int a, int b);
@@ -119,6 +126,9 @@ typedef struct {
     uint64_t level_visits[KLT_MAX_LEVELS];   /* _trackFeature calls per pyramid level */
     uint64_t iterations[KLT_MAX_LEVELS];     /* Newton iterations per pyramid level */
 } klt_track_stats;
+/* reset zeroes the counters and starts collecting (a small reduction kernel after every tracker launch);
+ * read returns the totals since the reset and stops collecting.  klt_feat.aux of a tracked record holds
+ * 4 bits per level: 0 = level not visited, v = v-1 Newton iterations (saturating at 14). */
 int klt_track_stats_reset(klt_ctx *ctx);
 int klt_track_stats_read(klt_ctx *ctx, klt_track_stats *out);
 

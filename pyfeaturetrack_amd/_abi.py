@@ -56,6 +56,8 @@ SYMBOLS = {
     "klt_upload_u8": (_I, [_P, _I, _P, _I, _I, _I]),
     "klt_upload_f32": (_I, [_P, _I, _P, _I, _I, _I]),
     "klt_build_pyramids_async": (_I, [_P, _I]),
+    "klt_build_pyramids_batch_async": (_I, [_P, C.POINTER(C.c_int), _I]),
+    "klt_set_option": (_I, [_P, _I, _I]),
     "klt_build_pyramids": (_I, [_P, _I]),
     "klt_swap_slots": (_I, [_P, _I, _I]),
     "klt_featbuf_upload": (_I, [_P, _I, _P, _I]),

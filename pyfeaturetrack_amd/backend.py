@@ -91,6 +91,15 @@ class Context:
         fn = self._lib.klt_build_pyramids if sync else self._lib.klt_build_pyramids_async
         self._check(fn(self._h, slot))
 
+    def build_pyramids_batch(self, slots, sync=False):
+        arr = (C.c_int * len(slots))(*slots)
+        self._check(self._lib.klt_build_pyramids_batch_async(self._h, arr, len(slots)))
+        if sync:
+            self.sync()
+
+    def set_option(self, option, value):
+        self._check(self._lib.klt_set_option(self._h, option, int(value)))
+
     def swap_slots(self, a, b):
         self._check(self._lib.klt_swap_slots(self._h, a, b))
 

@@ -12,10 +12,11 @@
 
 namespace {
 
-enum Family { F_SMOOTH_H, F_SMOOTH_V, F_PYR_H, F_PYR_V, F_GRAD_H, F_GRAD_V, F_TRACK, F_SAT_ROWS, F_SAT_COLS,
-              F_EIGEN, F_SORT, F_NMS, F_SEED, F_COUNT };
-const char *const kFamilyName[F_COUNT] = {"smooth_h", "smooth_v", "pyramid_h", "pyramid_v", "gradient_h", "gradient_v",
-                                          "track", "sat_rows", "sat_cols", "eigen_keys", "sort", "nms", "seed_map"};
+enum Family { F_SMOOTH_GRAD, F_PYR_REDUCE, F_GRAD, F_SMOOTH_H, F_SMOOTH_V, F_PYR_H, F_PYR_V, F_GRAD_H, F_GRAD_V, F_TRACK,
+              F_SAT_ROWS, F_SAT_COLS, F_EIGEN, F_SORT, F_NMS, F_SEED, F_COUNT };
+const char *const kFamilyName[F_COUNT] = {"smooth_grad_l0", "pyramid_reduce", "gradients", "smooth_h", "smooth_v", "pyramid_h",
+                                          "pyramid_v", "gradient_h", "gradient_v", "track", "sat_rows", "sat_cols",
+                                          "eigen_keys", "sort", "nms", "seed_map"};
 
 struct Level { int nc = 0, nr = 0; float *img = nullptr, *gx = nullptr, *gy = nullptr; };
 
@@ -65,6 +66,8 @@ struct klt_ctx {
     const float *last_sel[3] = {nullptr, nullptr, nullptr};
     int sel_nc = 0, sel_nr = 0, sel_nx = 0, sel_ny = 0, sel_npow2 = 0;
     unsigned long long *stats_d = nullptr;
+    bool collect_stats = false;
+    bool use_fused = true;            // LDS-tiled fused kernels (pyramid_kernels.hip); off = generic two-pass kernels
     // timing
     bool timing = false;
     std::vector<Timed> pending;
@@ -303,6 +306,131 @@ int enqueue_gradients(klt_ctx *c, const float *img, int nc, int nr, float *gx, f
     return 0;
 }
 
+constexpr size_t kMaxLds = 150 * 1024;     // leave headroom below the 160 KiB of a CU
+
+int grad_radius(const klt_ctx *c) { return (c->gauss[2].n > c->deriv[2].n ? c->gauss[2].n : c->deriv[2].n) / 2; }
+
+bool fused_smooth_ok(const klt_ctx *c)
+{
+    return c->use_fused && c->gauss[0].sym == 1 && smooth_grad_lds_bytes(c->gauss[0].n / 2, grad_radius(c)) <= kMaxLds;
+}
+bool fused_grad_ok(const klt_ctx *c) { return c->use_fused && smooth_grad_lds_bytes(-1, grad_radius(c)) <= kMaxLds; }
+bool fused_reduce_ok(const klt_ctx *c) { return c->use_fused && pyr_reduce_lds_bytes(c->p.subsampling, c->gauss[1].n) <= kMaxLds; }
+
+// smooth(raw frame) + gradients for up to KLT_MAX_BATCH same-sized frames in one launch
+int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int raw_kind, float *const *img,
+                              float *const *gx, float *const *gy, int nc, int nr)
+{
+    SmoothGradArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int b = 0; b < batch; b++) { a.raw[b] = raw[b]; a.img[b] = img[b]; a.gx[b] = gx[b]; a.gy[b] = gy[b]; }
+    a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
+    a.ncols = nc; a.nrows = nr; a.R = grad_radius(c);
+    const double N = (double)nc * nr * batch;
+    TimerScope t(c, F_SMOOTH_GRAD, N * ((raw_kind == 1 ? 1 : 4) + 4) + N * 12);
+    if (int e = launch_smooth_grad(c->stream, a, batch, raw_kind == 1 ? 0 : 1))
+        return fail(c, KLT_ERR_DEVICE, std::string("smooth_grad launch: ") + hipGetErrorString((hipError_t)e));
+    return 0;
+}
+
+// gradients of up to KLT_MAX_BATCH same-sized f32 images in one launch
+int enqueue_fused_grad(klt_ctx *c, int batch, const float *const *img, float *const *gx, float *const *gy, int nc, int nr,
+                       bool u8_input = false)
+{
+    SmoothGradArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int b = 0; b < batch; b++) { a.raw[b] = img[b]; a.gx[b] = gx[b]; a.gy[b] = gy[b]; }
+    a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
+    a.ncols = nc; a.nrows = nr; a.R = grad_radius(c);
+    TimerScope t(c, F_GRAD, (double)nc * nr * batch * 12);
+    if (int e = launch_smooth_grad(c->stream, a, batch, u8_input ? 3 : 2))
+        return fail(c, KLT_ERR_DEVICE, std::string("gradient launch: ") + hipGetErrorString((hipError_t)e));
+    return 0;
+}
+
+int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
+{
+    if (int rc = check_ready(c)) return rc;
+    if (!slot_ids || n <= 0) return fail(c, KLT_ERR_ARG, "empty slot list");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<Slot *> sl((size_t)n);
+    for (int i = 0; i < n; i++) {
+        if (int rc = get_slot(c, slot_ids[i], &sl[i], false)) return rc;
+        if (sl[i]->raw_kind == 0) return fail(c, KLT_ERR_STATE, "slot has no frame");
+        for (int j = 0; j < i; j++)
+            if (sl[j] == sl[i]) return fail(c, KLT_ERR_ARG, "slot listed twice");
+        if (int rc = layout_pyramid(c, sl[i])) return rc;
+    }
+    const int ss = c->p.subsampling;
+    // groups of frames with the same geometry and input type share launches
+    std::vector<bool> done((size_t)n, false);
+    for (int i0 = 0; i0 < n; i0++) {
+        if (done[i0]) continue;
+        std::vector<Slot *> g;
+        for (int i = i0; i < n && (int)g.size() < KLT_MAX_BATCH; i++)
+            if (!done[i] && sl[i]->nc == sl[i0]->nc && sl[i]->nr == sl[i0]->nr && sl[i]->raw_kind == sl[i0]->raw_kind) {
+                g.push_back(sl[i]);
+                done[i] = true;
+            }
+        const int B = (int)g.size();
+        Slot *s0 = g[0];
+        const void *raw[KLT_MAX_BATCH];
+        const float *src[KLT_MAX_BATCH];
+        float *img[KLT_MAX_BATCH], *gx[KLT_MAX_BATCH], *gy[KLT_MAX_BATCH];
+        if (int rc = ensure_tmp(c, (size_t)s0->nc * s0->nr)) return rc;
+
+        // level 0: smoothed frame (trackFeatures.py:165-166) and its gradients (:171-172)
+        if (fused_smooth_ok(c)) {
+            for (int b = 0; b < B; b++) {
+                raw[b] = g[b]->raw_kind == 1 ? (const void *)g[b]->u8 : (const void *)g[b]->f32;
+                img[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy;
+            }
+            if (int rc = enqueue_fused_smooth_grad(c, B, raw, s0->raw_kind, img, gx, gy, s0->nc, s0->nr)) return rc;
+        } else {
+            for (int b = 0; b < B; b++) {
+                enqueue_smooth_raw(c, g[b], g[b]->lv[0].img);
+                enqueue_gradients(c, g[b]->lv[0].img, g[b]->nc, g[b]->nr, g[b]->lv[0].gx, g[b]->lv[0].gy);
+            }
+        }
+        // levels 1..L-1: smooth with the pyramid sigma, keep pixel (ss*y + ss/2, ss*x + ss/2) (pyramid.py:59-72),
+        // then the gradients of the new level.  Only surviving columns / rows are evaluated.
+        for (int l = 1; l < s0->nlev; l++) {
+            const Level &ls = s0->lv[l - 1];
+            const Level &ld = s0->lv[l];
+            if (fused_reduce_ok(c)) {
+                PyrReduceArgs a;
+                std::memset(&a, 0, sizeof(a));
+                for (int b = 0; b < B; b++) { a.src[b] = g[b]->lv[l - 1].img; a.dst[b] = g[b]->lv[l].img; }
+                a.taps = c->gauss[1];
+                a.src_nc = ls.nc; a.src_nr = ls.nr; a.dst_nc = ld.nc; a.dst_nr = ld.nr; a.ss = ss;
+                TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ls.nc * ls.nr + (double)ld.nc * ld.nr));
+                if (int e = launch_pyr_reduce(c->stream, a, B))
+                    return fail(c, KLT_ERR_DEVICE, std::string("pyr_reduce launch: ") + hipGetErrorString((hipError_t)e));
+            } else {
+                for (int b = 0; b < B; b++) {
+                    {
+                        TimerScope t(c, F_PYR_H, 4.0 * ((double)ls.nc * ls.nr + (double)ld.nc * ls.nr));
+                        launch_hconv_f32(c->stream, g[b]->lv[l - 1].img, ls.nc, ls.nr, c->tmpA, nullptr, ld.nc, ss, ss / 2, c->gauss[1], nullptr);
+                    }
+                    {
+                        TimerScope t(c, F_PYR_V, 4.0 * ((double)ld.nc * ls.nr + (double)ld.nc * ld.nr));
+                        launch_vconv(c->stream, c->tmpA, nullptr, ld.nc, ls.nr, g[b]->lv[l].img, nullptr, ld.nr, ss, ss / 2, c->gauss[1], nullptr);
+                    }
+                }
+            }
+            if (fused_grad_ok(c)) {
+                for (int b = 0; b < B; b++) { src[b] = g[b]->lv[l].img; gx[b] = g[b]->lv[l].gx; gy[b] = g[b]->lv[l].gy; }
+                if (int rc = enqueue_fused_grad(c, B, src, gx, gy, ld.nc, ld.nr)) return rc;
+            } else {
+                for (int b = 0; b < B; b++) enqueue_gradients(c, g[b]->lv[l].img, ld.nc, ld.nr, g[b]->lv[l].gx, g[b]->lv[l].gy);
+            }
+        }
+        for (Slot *s : g) s->pyr_valid = true;
+    }
+    HIPCHK(c, hipGetLastError());
+    return KLT_OK;
+}
+
 }  // namespace
 
 // =============================================================================================== ABI
@@ -415,36 +543,15 @@ int klt_upload_f32(klt_ctx *c, int slot, const float *px, int ncols, int nrows, 
     return upload_raw(c, slot, px, ncols, nrows, pitch, 2);
 }
 
-int klt_build_pyramids_async(klt_ctx *c, int slot)
+int klt_build_pyramids_async(klt_ctx *c, int slot) { return build_pyramids_batch(c, &slot, 1); }
+
+int klt_build_pyramids_batch_async(klt_ctx *c, const int *slots, int n) { return build_pyramids_batch(c, slots, n); }
+
+int klt_set_option(klt_ctx *c, int option, int value)
 {
-    if (int rc = check_ready(c)) return rc;
-    HIPCHK(c, hipSetDevice(c->device));
-    Slot *s;
-    if (int rc = get_slot(c, slot, &s, false)) return rc;
-    if (s->raw_kind == 0) return fail(c, KLT_ERR_STATE, "slot has no frame");
-    if (int rc = layout_pyramid(c, s)) return rc;
-    if (int rc = ensure_tmp(c, (size_t)s->nc * s->nr)) return rc;
-    // level 0: smoothed frame (trackFeatures.py:165-166)
-    enqueue_smooth_raw(c, s, s->lv[0].img);
-    // levels 1..L-1: smooth with the pyramid sigma, keep pixel (ss*y + ss/2, ss*x + ss/2) (pyramid.py:59-72).
-    // Only the surviving columns / rows are evaluated.
-    const int ss = s->ss;
-    for (int l = 1; l < s->nlev; l++) {
-        const Level &src = s->lv[l - 1];
-        const Level &dst = s->lv[l];
-        {
-            TimerScope t(c, F_PYR_H, 4.0 * ((double)src.nc * src.nr + (double)dst.nc * src.nr));
-            launch_hconv_f32(c->stream, src.img, src.nc, src.nr, c->tmpA, nullptr, dst.nc, ss, ss / 2, c->gauss[1], nullptr);
-        }
-        {
-            TimerScope t(c, F_PYR_V, 4.0 * ((double)dst.nc * src.nr + (double)dst.nc * dst.nr));
-            launch_vconv(c->stream, c->tmpA, nullptr, dst.nc, src.nr, dst.img, nullptr, dst.nr, ss, ss / 2, c->gauss[1], nullptr);
-        }
-    }
-    for (int l = 0; l < s->nlev; l++) enqueue_gradients(c, s->lv[l].img, s->lv[l].nc, s->lv[l].nr, s->lv[l].gx, s->lv[l].gy);
-    HIPCHK(c, hipGetLastError());
-    s->pyr_valid = true;
-    return KLT_OK;
+    if (!c) return KLT_ERR_ARG;
+    if (option == KLT_OPT_FUSED_KERNELS) { c->use_fused = value != 0; return KLT_OK; }
+    return fail(c, KLT_ERR_ARG, "unknown option");
 }
 
 int klt_build_pyramids(klt_ctx *c, int slot)
@@ -544,7 +651,13 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
         img = s->lv[0].img; gx = s->lv[0].gx; gy = s->lv[0].gy;
     } else {
         if (s->raw_kind == 0) return fail(c, KLT_ERR_STATE, "slot has no frame");
-        if (p.smoothBeforeSelecting) {
+        bool grads_done = false;
+        if (p.smoothBeforeSelecting && fused_smooth_ok(c)) {
+            const void *raw = s->raw_kind == 1 ? (const void *)s->u8 : (const void *)s->f32;
+            if (int rc = enqueue_fused_smooth_grad(c, 1, &raw, s->raw_kind, &c->sel_img, &c->sel_gx, &c->sel_gy, nc, nr)) return rc;
+            img = c->sel_img;
+            grads_done = true;
+        } else if (p.smoothBeforeSelecting) {
             enqueue_smooth_raw(c, s, c->sel_img);
             img = c->sel_img;
         } else if (s->raw_kind == 2) {
@@ -557,7 +670,10 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
             launch_hconv_u8(c->stream, s->u8, nc, nr, c->sel_img, nullptr, nc, 1, 0, one, nullptr);
             img = c->sel_img;
         }
-        enqueue_gradients(c, img, nc, nr, c->sel_gx, c->sel_gy);
+        if (!grads_done) {
+            if (fused_grad_ok(c)) { if (int rc = enqueue_fused_grad(c, 1, &img, &c->sel_gx, &c->sel_gy, nc, nr)) return rc; }
+            else enqueue_gradients(c, img, nc, nr, c->sel_gx, c->sel_gy);
+        }
         gx = c->sel_gx; gy = c->sel_gy;
     }
     c->last_sel[0] = img; c->last_sel[1] = gx; c->last_sel[2] = gy;
@@ -645,7 +761,7 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
         a.lv[l].i2 = s2->lv[l].img; a.lv[l].gx2 = s2->lv[l].gx; a.lv[l].gy2 = s2->lv[l].gy;
         a.lv[l].nc = s1->lv[l].nc; a.lv[l].nr = s1->lv[l].nr;
     }
-    a.in = c->fbs[fb_in].d; a.out = bo->d; a.stats = c->stats_d;
+    a.in = c->fbs[fb_in].d; a.out = bo->d;
     a.half_window = p.window_width / 2.0;
     a.borderx = p.borderx; a.bordery = p.bordery;
     a.n = n; a.nlevels = s1->nlev; a.window = p.window_width; a.max_iterations = p.max_iterations;
@@ -657,6 +773,7 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
         TimerScope t(c, F_TRACK, (double)n * (foot * 2 * s1->nlev + 32));      // refined by the caller from klt_track_stats
         if (launch_track(c->stream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
     }
+    if (c->collect_stats) launch_track_stats(c->stream, a.in, a.out, n, s1->nlev, c->stats_d);
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -680,6 +797,7 @@ int klt_track_stats_reset(klt_ctx *c)
 {
     if (!c) return KLT_ERR_ARG;
     HIPCHK(c, hipMemsetAsync(c->stats_d, 0, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long), c->stream));
+    c->collect_stats = true;
     return KLT_OK;
 }
 
@@ -689,6 +807,7 @@ int klt_track_stats_read(klt_ctx *c, klt_track_stats *out)
     unsigned long long h[1 + 2 * KLT_MAX_LEVELS];
     HIPCHK(c, hipMemcpyAsync(h, c->stats_d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->collect_stats = false;
     out->features = h[0];
     for (int l = 0; l < KLT_MAX_LEVELS; l++) { out->level_visits[l] = h[1 + l]; out->iterations[l] = h[1 + KLT_MAX_LEVELS + l]; }
     return KLT_OK;

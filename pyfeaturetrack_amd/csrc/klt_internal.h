@@ -13,6 +13,23 @@ struct Taps {
     int sym;   // +1 symmetric, -1 antisymmetric, 0 neither
 };
 
+constexpr int KLT_MAX_BATCH = 32;   // frames per fused pyramid launch (pointer tables travel in the kernarg segment)
+
+struct SmoothGradArgs {
+    const void *raw[KLT_MAX_BATCH];   // u8 or f32 frame (or, for gradients only, the level image)
+    float *img[KLT_MAX_BATCH];        // smoothed image out (unused for gradients only)
+    float *gx[KLT_MAX_BATCH], *gy[KLT_MAX_BATCH];
+    Taps smooth, ggauss, gderiv;
+    int ncols, nrows, R;              // R = max gradient tap radius
+};
+
+struct PyrReduceArgs {
+    const float *src[KLT_MAX_BATCH];
+    float *dst[KLT_MAX_BATCH];
+    Taps taps;
+    int src_nc, src_nr, dst_nc, dst_nr, ss;
+};
+
 struct TrackLevel {
     const float *i1, *gx1, *gy1, *i2, *gx2, *gy2;
     int nc, nr;
@@ -22,7 +39,6 @@ struct TrackArgs {
     TrackLevel lv[KLT_MAX_LEVELS];
     const klt_feat *in;
     klt_feat *out;
-    unsigned long long *stats;   // [0] features, [1..8] level visits, [9..16] iterations
     double half_window;          // window/2 as the Python float (3.5 for 7x7), trackFeatures.py:88-89
     double borderx, bordery;
     int n, nlevels, window, max_iterations, use_max_residue, retain, ncols, nrows;
@@ -54,6 +70,12 @@ void launch_hconv_f32(hipStream_t s, const float *in, int ncols, int nrows, floa
 void launch_vconv(hipStream_t s, const float *inA, const float *inB, int ncols, int nrows, float *outA, float *outB,
                   int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb);
 
+size_t smooth_grad_lds_bytes(int smooth_radius /* -1: no smoothing stage */, int R);
+size_t pyr_reduce_lds_bytes(int ss, int ntaps);
+// kind: 0 = u8 frame + smoothing, 1 = f32 frame + smoothing, 2 = f32 image gradients only, 3 = u8 image gradients only
+int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int kind);
+int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch);
+
 void launch_sat_rows(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows);
 void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows);
 void launch_seed_fill(hipStream_t s, const klt_feat *fl, int nfeat, uint8_t *seedmap, int ncols, int nrows, int d);
@@ -62,4 +84,5 @@ void launch_sort_desc(hipStream_t s, unsigned long long *keys, int npow2);
 int  launch_nms(hipStream_t s, const NmsArgs &a);   // returns 0 or a hipError_t
 void launch_unpack_candidates(hipStream_t s, const unsigned long long *keys, int n, float *val, int *x, int *y);
 
+void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, int n, int nlevels, unsigned long long *stats);
 int launch_track(hipStream_t s, const TrackArgs &a);   // returns 0, or -1 for an unsupported window

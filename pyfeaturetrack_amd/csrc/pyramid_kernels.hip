@@ -1,0 +1,233 @@
+// LDS-tiled, fused pyramid-build kernels for gfx950 (the fast path; conv_kernels.hip is the generic one).
+//
+//   smooth_grad_kernel<TIn, true>   u8/f32 frame -> smoothed level-0 image + gradx + grady   (1 launch, was 4)
+//   smooth_grad_kernel<float,false> level image   -> gradx + grady                            (1 launch, was 2)
+//   pyr_reduce_kernel               level l-1 image -> level l image (smooth + subsample)      (1 launch, was 2)
+//
+// blockIdx.z is the frame of a batch (both frames of a pair, or all pairs of a cfg-4 shard, go through one
+// launch).  Every intermediate of a tile lives in LDS; HBM sees each input once (plus halo) and each output
+// once, in coalesced rows.
+//
+// Bit-exactness.  Every output sample is computed by the same FP64 expression, in the same
+// order, as scipy's correlate1d, with the f32 rounding between the horizontal and the vertical pass.
+// Fusing smoothing and differentiation needs smoothed samples *outside* the frame (scipy reflects the
+// smoothed image when it differentiates it).  The tile is addressed in virtual coordinates and the raw frame
+// is loaded through the reflect map R; for a symmetric tap set k and any virtual x,
+//     sum_j k_j raw[R(x + j)]  ==  sum_j k_j raw[R(R(x) + j)]      (bit for bit)
+// because R(-1 - t) = R(t), R(2n - 1 - t) = R(t), and scipy's symmetric loop adds the pair (x[-j] + x[j])
+// commutatively before multiplying.  So the smoothed value computed at a virtual position equals the smoothed
+// image at the reflected position, which is what the differentiation must see.  The host only takes this
+// path when the smoothing taps are symmetric (they are Gaussians) and the tile fits in LDS.
+#include "klt_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int TW = 64, TH = 16;        // output tile of smooth_grad_kernel
+constexpr int OW = 32, OH = 8;         // output tile of pyr_reduce_kernel
+
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    const int p = 2 * n;
+    int m = i % p;
+    if (m < 0) m += p;
+    return m < n ? m : p - 1 - m;
+}
+
+// correlate1d at `c` (centre sample) of a fully populated LDS line with element stride `stride`
+__device__ __forceinline__ float correlate_lds(const float *c, int stride, const Taps &t)
+{
+    const int size1 = t.n / 2;
+    const int size2 = t.n - size1 - 1;
+    const double *fw = t.k + size1;
+    double acc;
+    if (t.sym > 0) {
+        acc = (double)c[0] * fw[0];
+        for (int jj = -size1; jj < 0; jj++) acc = acc + ((double)c[jj * stride] + (double)c[-jj * stride]) * fw[jj];
+    } else if (t.sym < 0) {
+        acc = (double)c[0] * fw[0];
+        for (int jj = -size1; jj < 0; jj++) acc = acc + ((double)c[jj * stride] - (double)c[-jj * stride]) * fw[jj];
+    } else {
+        acc = (double)c[size2 * stride] * fw[size2];
+        for (int jj = -size1; jj < size2; jj++) acc = acc + (double)c[jj * stride] * fw[jj];
+    }
+    return (float)acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// frame -> [smoothed image] + gradx + grady.  grid = (ceil(ncols/TW), ceil(nrows/TH), batch), block = 256
+template <typename TIn, bool SMOOTH>
+__global__ __launch_bounds__(256) void smooth_grad_kernel(SmoothGradArgs a)
+{
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int nc = a.ncols, nr = a.nrows;
+    const int rs = SMOOTH ? a.smooth.n / 2 : 0;
+    const int R = a.R;                                   // halo of the image tile = max gradient tap radius
+    const int IW = TW + 2 * R, IH = TH + 2 * R;          // image tile
+    const int RW = IW + 2 * rs, RH = IH + 2 * rs;        // raw tile
+    // LDS carve: [A raw RH*RW][B hsmooth RH*IW] overlaid later by [D IH*TW][E IH*TW]; then [C image IH*IW]
+    const int ab = SMOOTH ? RH * RW + RH * IW : 0, de = 2 * IH * TW;
+    float *A = lds, *B = lds + RH * RW, *D = lds, *E = lds + IH * TW;
+    float *C = lds + (ab > de ? ab : de);
+    const TIn *__restrict__ raw = (const TIn *)a.raw[b];
+
+    if (SMOOTH) {
+        for (int i = tid; i < RH * RW; i += 256) {
+            const int r = i / RW, c = i - r * RW;
+            const int gy = reflect_idx(ty0 - R - rs + r, nr), gx = reflect_idx(tx0 - R - rs + c, nc);
+            A[i] = (float)raw[(size_t)gy * nc + gx];
+        }
+        __syncthreads();
+        for (int i = tid; i < RH * IW; i += 256) {       // horizontal smoothing
+            const int r = i / IW, c = i - r * IW;
+            B[i] = correlate_lds(A + r * RW + c + rs, 1, a.smooth);
+        }
+        __syncthreads();
+        float *__restrict__ img = a.img[b];
+        for (int i = tid; i < IH * IW; i += 256) {       // vertical smoothing -> image tile (+ store the interior)
+            const int r = i / IW, c = i - r * IW;
+            const float v = correlate_lds(B + (r + rs) * IW + c, IW, a.smooth);
+            C[i] = v;
+            const int y = ty0 - R + r, x = tx0 - R + c;
+            if (r >= R && r < R + TH && c >= R && c < R + TW && y < nr && x < nc) img[(size_t)y * nc + x] = v;
+        }
+    } else {
+        for (int i = tid; i < IH * IW; i += 256) {
+            const int r = i / IW, c = i - r * IW;
+            const int gy = reflect_idx(ty0 - R + r, nr), gx = reflect_idx(tx0 - R + c, nc);
+            C[i] = (float)raw[(size_t)gy * nc + gx];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < IH * TW; i += 256) {           // horizontal pass of both gradients
+        const int r = i / TW, x = i - r * TW;
+        const float *c = C + r * IW + x + R;
+        D[i] = correlate_lds(c, 1, a.gderiv);            // gradx: derivative taps along x
+        E[i] = correlate_lds(c, 1, a.ggauss);            // grady: Gaussian taps along x
+    }
+    __syncthreads();
+    float *__restrict__ gxo = a.gx[b];
+    float *__restrict__ gyo = a.gy[b];
+    for (int i = tid; i < TH * TW; i += 256) {           // vertical pass -> coalesced stores
+        const int r = i / TW, x = i - r * TW;
+        const int y = ty0 + r, xx = tx0 + x;
+        if (y < nr && xx < nc) {
+            gxo[(size_t)y * nc + xx] = correlate_lds(D + (r + R) * TW + x, TW, a.ggauss);
+            gyo[(size_t)y * nc + xx] = correlate_lds(E + (r + R) * TW + x, TW, a.gderiv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// level l-1 image -> level l image: out(ys, xs) = V(H(src))(ss*ys + ss/2, ss*xs + ss/2)  (pyramid.py:59-72).
+// Only the surviving columns are smoothed horizontally and only the surviving rows vertically.
+// The source tile is stored de-interleaved by column phase (col % ss) so that lanes reading columns
+// ss apart hit consecutive LDS addresses.  grid = (ceil(dc/OW), ceil(dr/OH), batch), block = 256
+__global__ __launch_bounds__(256) void pyr_reduce_kernel(PyrReduceArgs a)
+{
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int ss = a.ss, r = a.taps.n / 2;
+    const int SW = (OW - 1) * ss + 2 * r + 1, SH = (OH - 1) * ss + 2 * r + 1;
+    const int PW = (SW + ss - 1) / ss;                   // entries per phase plane per row
+    const int rowlen = PW * ss;
+    float *S = lds;                                      // SH rows x ss planes x PW
+    float *Hh = lds + SH * rowlen;                       // SH x OW
+    const int xs0 = blockIdx.x * OW, ys0 = blockIdx.y * OH;
+    const int gx0 = xs0 * ss + ss / 2 - r, gy0 = ys0 * ss + ss / 2 - r;   // source coords of tile element (0,0)
+    const float *__restrict__ src = a.src[b];
+    const int nc = a.src_nc, nr = a.src_nr;
+
+    for (int i = tid; i < SH * SW; i += 256) {
+        const int rr = i / SW, c = i - rr * SW;
+        const int gy = reflect_idx(gy0 + rr, nr), gx = reflect_idx(gx0 + c, nc);
+        S[rr * rowlen + (c % ss) * PW + c / ss] = src[(size_t)gy * nc + gx];
+    }
+    __syncthreads();
+    const int size1 = a.taps.n / 2, size2 = a.taps.n - size1 - 1;
+    const double *fw = a.taps.k + size1;
+    for (int i = tid; i < SH * OW; i += 256) {           // horizontal pass at the surviving columns
+        const int rr = i / OW, xs = i - rr * OW;
+        const float *row = S + rr * rowlen;
+        const int cc = xs * ss + r;                      // tile column of the centre sample
+        auto at = [&](int j) -> double { const int c = cc + j; return (double)row[(c % ss) * PW + c / ss]; };
+        double acc;
+        if (a.taps.sym > 0) {
+            acc = at(0) * fw[0];
+            for (int jj = -size1; jj < 0; jj++) acc = acc + (at(jj) + at(-jj)) * fw[jj];
+        } else if (a.taps.sym < 0) {
+            acc = at(0) * fw[0];
+            for (int jj = -size1; jj < 0; jj++) acc = acc + (at(jj) - at(-jj)) * fw[jj];
+        } else {
+            acc = at(size2) * fw[size2];
+            for (int jj = -size1; jj < size2; jj++) acc = acc + at(jj) * fw[jj];
+        }
+        Hh[i] = (float)acc;
+    }
+    __syncthreads();
+    const int xs = tid % OW, ys = tid / OW;              // vertical pass at the surviving rows, one output per thread
+    const int ox = xs0 + xs, oy = ys0 + ys;
+    if (ox < a.dst_nc && oy < a.dst_nr)
+        a.dst[b][(size_t)oy * a.dst_nc + ox] = correlate_lds(Hh + (ys * ss + r) * OW + xs, OW, a.taps);
+}
+
+}  // namespace
+
+size_t smooth_grad_lds_bytes(int rs, int R)
+{
+    const int IW = TW + 2 * R, IH = TH + 2 * R, RW = IW + 2 * rs, RH = IH + 2 * rs;
+    const int ab = rs >= 0 ? RH * RW + RH * IW : 0, de = 2 * IH * TW;
+    return sizeof(float) * (size_t)((ab > de ? ab : de) + IH * IW);
+}
+
+size_t pyr_reduce_lds_bytes(int ss, int ntaps)
+{
+    const int r = ntaps / 2;
+    const int SW = (OW - 1) * ss + 2 * r + 1, SH = (OH - 1) * ss + 2 * r + 1;
+    const int PW = (SW + ss - 1) / ss;
+    return sizeof(float) * (size_t)(SH * PW * ss + SH * OW);
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t lds)
+{
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+// kind: 0 = u8 frame + smoothing, 1 = f32 frame + smoothing, 2 = f32 image, gradients only, 3 = u8 image, gradients only
+int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int kind)
+{
+    const bool smooth = kind < 2;
+    const size_t lds = smooth_grad_lds_bytes(smooth ? a.smooth.n / 2 : -1, a.R);
+    const dim3 grid((a.ncols + TW - 1) / TW, (a.nrows + TH - 1) / TH, batch), block(256);
+    int e = 0;
+    switch (kind) {
+    case 0: if ((e = set_lds(smooth_grad_kernel<uint8_t, true>, lds))) return e;
+            hipLaunchKernelGGL((smooth_grad_kernel<uint8_t, true>), grid, block, lds, s, a); break;
+    case 1: if ((e = set_lds(smooth_grad_kernel<float, true>, lds))) return e;
+            hipLaunchKernelGGL((smooth_grad_kernel<float, true>), grid, block, lds, s, a); break;
+    case 2: if ((e = set_lds(smooth_grad_kernel<float, false>, lds))) return e;
+            hipLaunchKernelGGL((smooth_grad_kernel<float, false>), grid, block, lds, s, a); break;
+    default: if ((e = set_lds(smooth_grad_kernel<uint8_t, false>, lds))) return e;
+            hipLaunchKernelGGL((smooth_grad_kernel<uint8_t, false>), grid, block, lds, s, a); break;
+    }
+    return 0;
+}
+
+int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch)
+{
+    const size_t lds = pyr_reduce_lds_bytes(a.ss, a.taps.n);
+    if (int e = set_lds(pyr_reduce_kernel, lds)) return e;
+    const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch), block(256);
+    hipLaunchKernelGGL(pyr_reduce_kernel, grid, block, lds, s, a);
+    return 0;
+}

@@ -213,19 +213,17 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     for (int r = 0; r < L; r++) { xloc = xloc / a.ss; yloc = yloc / a.ss; }
     float xout = xloc, yout = yloc;
     int val = KLT_TRACKED;
+    uint32_t aux = 0;       // 4 bits per level: 0 = level not visited, v = v-1 Newton iterations (saturating at 14)
     for (int r = L - 1; r >= 0; r--) {
         xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss;
         int it = 0;
         val = track_level<MAXK>(a, a.lv[r], xloc, yloc, xout, yout, lds, lane, it);
-        if (lane == 0 && a.stats) {
-            atomicAdd(&a.stats[1 + r], 1ull);
-            atomicAdd(&a.stats[1 + KLT_MAX_LEVELS + r], (unsigned long long)it);
-        }
+        aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);      // visited level r with `it` Newton iterations
         if (val == KLT_SMALL_DET || val == KLT_OOB) break;             // :284-285
     }
     if (lane == 0) {
         klt_feat o;
-        o.aux = 0;
+        o.aux = (int32_t)aux;
         const double xd = (double)xout, yd = (double)yout;
         const bool oob = val == KLT_OOB ||
                          xd < a.borderx || xd > (double)(a.ncols - 1) - a.borderx ||
@@ -235,11 +233,41 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
             o.x = -1.f; o.y = -1.f; o.val = val;
         } else { o.x = xout; o.y = yout; o.val = KLT_TRACKED; }
         a.out[f] = o;
-        if (a.stats) atomicAdd(&a.stats[0], 1ull);
     }
 }
 
+// Iteration statistics from the per-feature aux words (only launched while statistics are being collected;
+// per-feature atomics on a handful of shared counters would serialise the whole tracker).
+__global__ __launch_bounds__(256) void track_stats_kernel(const klt_feat *__restrict__ in, const klt_feat *__restrict__ out,
+                                                           int n, int nlevels, unsigned long long *stats)
+{
+    __shared__ unsigned int acc[1 + 2 * KLT_MAX_LEVELS];
+    if (threadIdx.x < 1 + 2 * KLT_MAX_LEVELS) acc[threadIdx.x] = 0u;
+    __syncthreads();
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < n && in[f].val >= 0) {
+        atomicAdd(&acc[0], 1u);
+        const uint32_t aux = (uint32_t)out[f].aux;
+        for (int r = 0; r < nlevels; r++) {
+            const uint32_t v = (aux >> (4 * r)) & 15u;
+            if (v) {
+                atomicAdd(&acc[1 + r], 1u);
+                atomicAdd(&acc[1 + KLT_MAX_LEVELS + r], v - 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 1 + 2 * KLT_MAX_LEVELS && acc[threadIdx.x])
+        atomicAdd(&stats[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
+}
+
 }  // namespace
+
+void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, int n, int nlevels, unsigned long long *stats)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(track_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, nlevels, stats);
+}
 
 int launch_track(hipStream_t s, const TrackArgs &a)
 {

@@ -49,11 +49,12 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
             from .error import KLTError
             KLTError("(KLTTrackFeatures) Size of incoming image ({0} by {1}) is different from size of previous image "
                      "({2} by {3})".format(ncols, nrows, tc.pyramid_last.ncols[0], tc.pyramid_last.nrows[0]))
+        ctx.upload(s2, image_to_array(img2))
+        ctx.build_pyramids(s2, sync=False)
     else:
         ctx.upload(s1, image_to_array(img1))
-        ctx.build_pyramids(s1, sync=False)
-    ctx.upload(s2, image_to_array(img2))
-    ctx.build_pyramids(s2, sync=False)
+        ctx.upload(s2, image_to_array(img2))
+        ctx.build_pyramids_batch([s1, s2])            # both frames share every kernel launch
 
     fl_in = features_to_array(featurelist)
     fl_out, _ = ctx.track(s1, s2, fl_in)

@@ -118,6 +118,45 @@ def test_pyramids_synth251(ctx, ko, synth251):
                 assert_same(sha_bytes(got), synth251["%s_%s_%d_sha" % (name, w, l)], "synth %s %s level %d sha" % (name, w, l))
 
 
+def test_generic_path_and_batched_build(ctx, ko, cfg1, img0, img1):
+    """KLT_OPT_FUSED_KERNELS=0 (generic two-pass kernels) and the batched build give the same pyramids."""
+    ctx.configure(make_tc())
+    ctx.upload(0, img0)
+    ctx.upload(1, img1)
+    ctx.upload(2, img1.astype(np.float32))
+    try:
+        ctx.set_option(1, 0)
+        ctx.build_pyramids(0)
+        ctx.build_pyramids(1)
+        for slot, name in ((0, "p0"), (1, "p1")):
+            for l in range(2):
+                for pi, w in enumerate(("img", "gx", "gy")):
+                    assert_same(ctx.download_level(slot, pi, l), cfg1["%s_%s_%d" % (name, w, l)], "generic %s %s %d" % (name, w, l))
+    finally:
+        ctx.set_option(1, 1)
+    ctx.build_pyramids_batch([0, 1, 2], sync=True)      # u8, u8, f32 frames: two launch groups
+    for slot, name in ((0, "p0"), (1, "p1"), (2, "p1")):
+        for l in range(2):
+            for pi, w in enumerate(("img", "gx", "gy")):
+                assert_same(ctx.download_level(slot, pi, l), cfg1["%s_%s_%d" % (name, w, l)], "batched %s %s %d" % (name, w, l))
+
+
+@pytest.mark.parametrize("window,levels,ss,shape", [(7, 3, 8, (700, 900)), (15, 3, 2, (301, 447)), (5, 2, 4, (64, 64)),
+                                                    (7, 4, 2, (123, 77)), (7, 2, 8, (40, 50)), (9, 2, 4, (17, 333))])
+def test_pyramids_various_geometries_vs_oracle(ctx, ko, window, levels, ss, shape):
+    rng = np.random.default_rng(window * 100 + ss)
+    img = (rng.random(shape) * 255).astype(np.uint8)
+    tc = make_tc(levels=levels, ss=ss, window=window)
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(0, img)
+    ctx.build_pyramids(0)
+    P = ko.Pyramids(p, img.astype(np.float32))
+    for l in range(levels):
+        for pi, w in enumerate(("img", "gx", "gy")):
+            assert_same(ctx.download_level(0, pi, l), P.level(w, l), "w%d L%d ss%d %s level %d" % (window, levels, ss, w, l))
+
+
 # --------------------------------------------------------------------------------- selection
 def test_select_internals_cfg1(ctx, cfg1, img0):
     ctx.configure(make_tc())
