@@ -403,6 +403,8 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                 for (int b = 0; b < B; b++) { a.src[b] = g[b]->lv[l - 1].img; a.dst[b] = g[b]->lv[l].img; }
                 a.taps = c->gauss[1];
                 a.src_nc = ls.nc; a.src_nr = ls.nr; a.dst_nc = ld.nc; a.dst_nr = ld.nr; a.ss = ss;
+                a.log2ss = 0;
+                while ((1 << a.log2ss) < ss) a.log2ss++;
                 TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ls.nc * ls.nr + (double)ld.nc * ld.nr));
                 if (int e = launch_pyr_reduce(c->stream, a, B))
                     return fail(c, KLT_ERR_DEVICE, std::string("pyr_reduce launch: ") + hipGetErrorString((hipError_t)e));

@@ -27,7 +27,7 @@ struct PyrReduceArgs {
     const float *src[KLT_MAX_BATCH];
     float *dst[KLT_MAX_BATCH];
     Taps taps;
-    int src_nc, src_nr, dst_nc, dst_nr, ss;
+    int src_nc, src_nr, dst_nc, dst_nr, ss, log2ss;
 };
 
 struct TrackLevel {

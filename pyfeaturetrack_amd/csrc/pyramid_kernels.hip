@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void pyr_reduce_kernel(PyrReduceArgs a)
     for (int i = tid; i < SH * SW; i += 256) {
         const int rr = i / SW, c = i - rr * SW;
         const int gy = reflect_idx(gy0 + rr, nr), gx = reflect_idx(gx0 + c, nc);
-        S[rr * rowlen + (c % ss) * PW + c / ss] = src[(size_t)gy * nc + gx];
+        S[rr * rowlen + (c & (ss - 1)) * PW + (c >> a.log2ss)] = src[(size_t)gy * nc + gx];
     }
     __syncthreads();
     const int size1 = a.taps.n / 2, size2 = a.taps.n - size1 - 1;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void pyr_reduce_kernel(PyrReduceArgs a)
         const int rr = i / OW, xs = i - rr * OW;
         const float *row = S + rr * rowlen;
         const int cc = xs * ss + r;                      // tile column of the centre sample
-        auto at = [&](int j) -> double { const int c = cc + j; return (double)row[(c % ss) * PW + c / ss]; };
+        auto at = [&](int j) -> double { const int c = cc + j; return (double)row[(c & (ss - 1)) * PW + (c >> a.log2ss)]; };
         double acc;
         if (a.taps.sym > 0) {
             acc = at(0) * fw[0];
@@ -174,6 +174,154 @@ __global__ __launch_bounds__(256) void pyr_reduce_kernel(PyrReduceArgs a)
     const int ox = xs0 + xs, oy = ys0 + ys;
     if (ox < a.dst_nc && oy < a.dst_nr)
         a.dst[b][(size_t)oy * a.dst_nc + ox] = correlate_lds(Hh + (ys * ss + r) * OW + xs, OW, a.taps);
+}
+
+// ======================================================================================================
+// Compile-time specialisations.  Tap counts, tile geometry and every LDS offset are constants, the taps sit
+// in scalar registers for the whole kernel and the correlate loops are fully unrolled (same operation order).
+// The runtime-sized kernels above remain the fallback for unusual sigmas.
+
+__device__ __forceinline__ int reflect_fast(int i, int n)
+{
+    if (i < 0) i = -1 - i;
+    else if (i >= n) i = 2 * n - 1 - i;
+    if ((unsigned)i >= (unsigned)n) i = reflect_idx(i, n);      // frames smaller than the halo
+    return i;
+}
+
+template <int NT>
+struct TapRegs { double k[NT]; };
+
+template <int NT>
+__device__ __forceinline__ void load_taps(TapRegs<NT> &r, const Taps &t)
+{
+#pragma unroll
+    for (int i = 0; i < NT; i++) r.k[i] = t.k[i];
+}
+
+// SYM = +1: acc = c0*k0; acc += (c[-j] + c[+j]) * k[-j], j = r..1     (scipy correlate1d, symmetric branch)
+// SYM = -1: acc = c0*k0; acc += (c[-j] - c[+j]) * k[-j]              (antisymmetric branch)
+template <int NT, int SYM, int STRIDE>
+__device__ __forceinline__ float correlate_ct(const float *c, const TapRegs<NT> &t)
+{
+    constexpr int H = NT / 2;
+    double acc = (double)c[0] * t.k[H];
+#pragma unroll
+    for (int jj = -H; jj < 0; jj++) {
+        const double lo = (double)c[jj * STRIDE], hi = (double)c[-jj * STRIDE];
+        const double pr = SYM > 0 ? lo + hi : lo - hi;
+        acc = acc + pr * t.k[H + jj];
+    }
+    return (float)acc;
+}
+
+template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_>
+__global__ __launch_bounds__(256) void smooth_grad_fast(SmoothGradArgs a)
+{
+    constexpr int rs = SMOOTH ? NS / 2 : 0;
+    constexpr int R = (NG > ND ? NG : ND) / 2;
+    constexpr int IW = TW + 2 * R, IH = TH_ + 2 * R, RW = IW + 2 * rs, RH = IH + 2 * rs;
+    constexpr int AB = SMOOTH ? RH * RW + RH * IW : 0, DE = 2 * IH * TW;
+    constexpr int OFF_C = AB > DE ? AB : DE;
+    __shared__ float lds[OFF_C + IH * IW];
+    float *const A = lds, *const B = lds + RH * RW, *const D = lds, *const E = lds + IH * TW, *const C = lds + OFF_C;
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
+    const int nc = a.ncols, nr = a.nrows;
+    const TIn *__restrict__ raw = (const TIn *)a.raw[b];
+    TapRegs<NG> kg;
+    TapRegs<ND> kd;
+    load_taps(kg, a.ggauss);
+    load_taps(kd, a.gderiv);
+
+    if (SMOOTH) {
+        TapRegs<NS> ks;
+        load_taps(ks, a.smooth);
+        for (int i = tid; i < RH * RW; i += 256) {
+            const int r = i / RW, c = i % RW;
+            const int gy = reflect_fast(ty0 - R - rs + r, nr), gx = reflect_fast(tx0 - R - rs + c, nc);
+            A[i] = (float)raw[(size_t)gy * nc + gx];
+        }
+        __syncthreads();
+        for (int i = tid; i < RH * IW; i += 256) {
+            const int r = i / IW, c = i % IW;
+            B[i] = correlate_ct<NS, 1, 1>(A + r * RW + c + rs, ks);
+        }
+        __syncthreads();
+        float *__restrict__ img = a.img[b];
+        for (int i = tid; i < IH * IW; i += 256) {
+            const int r = i / IW, c = i % IW;
+            const float v = correlate_ct<NS, 1, IW>(B + (r + rs) * IW + c, ks);
+            C[i] = v;
+            const int y = ty0 - R + r, x = tx0 - R + c;
+            if (r >= R && r < R + TH_ && c >= R && c < R + TW && y < nr && x < nc) img[(size_t)y * nc + x] = v;
+        }
+    } else {
+        for (int i = tid; i < IH * IW; i += 256) {
+            const int r = i / IW, c = i % IW;
+            const int gy = reflect_fast(ty0 - R + r, nr), gx = reflect_fast(tx0 - R + c, nc);
+            C[i] = (float)raw[(size_t)gy * nc + gx];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < IH * TW; i += 256) {
+        const int r = i / TW, x = i % TW;
+        const float *c = C + r * IW + x + R;
+        D[i] = correlate_ct<ND, -1, 1>(c, kd);
+        E[i] = correlate_ct<NG, 1, 1>(c, kg);
+    }
+    __syncthreads();
+    float *__restrict__ gxo = a.gx[b];
+    float *__restrict__ gyo = a.gy[b];
+    for (int i = tid; i < TH_ * TW; i += 256) {
+        const int r = i / TW, x = i % TW;
+        const int y = ty0 + r, xx = tx0 + x;
+        if (y < nr && xx < nc) {
+            gxo[(size_t)y * nc + xx] = correlate_ct<NG, 1, TW>(D + (r + R) * TW + x, kg);
+            gyo[(size_t)y * nc + xx] = correlate_ct<ND, -1, TW>(E + (r + R) * TW + x, kd);
+        }
+    }
+}
+
+template <int SS, int NT>
+__global__ __launch_bounds__(256) void pyr_reduce_fast(PyrReduceArgs a)
+{
+    constexpr int r = NT / 2;
+    constexpr int SW = (OW - 1) * SS + 2 * r + 1, SH = (OH - 1) * SS + 2 * r + 1;
+    constexpr int PW = (SW + SS - 1) / SS, ROWLEN = PW * SS;
+    __shared__ float S[SH * ROWLEN];
+    __shared__ float Hh[SH * OW];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int xs0 = blockIdx.x * OW, ys0 = blockIdx.y * OH;
+    const int gx0 = xs0 * SS + SS / 2 - r, gy0 = ys0 * SS + SS / 2 - r;
+    const float *__restrict__ src = a.src[b];
+    const int nc = a.src_nc, nr = a.src_nr;
+    TapRegs<NT> k;
+    load_taps(k, a.taps);
+
+    for (int i = tid; i < SH * SW; i += 256) {
+        const int rr = i / SW, c = i % SW;
+        const int gy = reflect_fast(gy0 + rr, nr), gx = reflect_fast(gx0 + c, nc);
+        S[rr * ROWLEN + (c % SS) * PW + c / SS] = src[(size_t)gy * nc + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < SH * OW; i += 256) {
+        const int rr = i / OW, xs = i % OW;
+        const float *row = S + rr * ROWLEN + xs;         // column xs*SS + r + j lives at plane (r+j)%SS, index xs + (r+j)/SS
+        double acc = (double)row[(r % SS) * PW + r / SS] * k.k[r];
+#pragma unroll
+        for (int jj = -r; jj < 0; jj++) {
+            const double lo = (double)row[((r + jj) % SS) * PW + (r + jj) / SS];
+            const double hi = (double)row[((r - jj) % SS) * PW + (r - jj) / SS];
+            acc = acc + (lo + hi) * k.k[r + jj];
+        }
+        Hh[i] = (float)acc;
+    }
+    __syncthreads();
+    const int xs = tid % OW, ys = tid / OW;
+    const int ox = xs0 + xs, oy = ys0 + ys;
+    if (ox < a.dst_nc && oy < a.dst_nr)
+        a.dst[b][(size_t)oy * a.dst_nc + ox] = correlate_ct<NT, 1, OW>(Hh + (ys * SS + r) * OW + xs, k);
 }
 
 }  // namespace
@@ -207,6 +355,16 @@ static int set_lds(K kernel, size_t lds)
 int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int kind)
 {
     const bool smooth = kind < 2;
+    // compile-time specialisations: Gaussian smoothing (symmetric), Gaussian / derivative gradient taps
+    if (a.ggauss.sym == 1 && a.gderiv.sym == -1 && a.ggauss.n == 7 && a.gderiv.n == 7 && (!smooth || a.smooth.sym == 1)) {
+        const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + TH - 1) / TH, batch), blk(256);
+        if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 5, 7, 7, TH>), g, blk, 0, s, a); return 0; }
+        if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<float, true, 5, 7, 7, TH>), g, blk, 0, s, a); return 0; }
+        if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 9, 7, 7, TH>), g, blk, 0, s, a); return 0; }
+        if (kind == 1 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_fast<float, true, 9, 7, 7, TH>), g, blk, 0, s, a); return 0; }
+        if (kind == 2) { hipLaunchKernelGGL((smooth_grad_fast<float, false, 1, 7, 7, TH>), g, blk, 0, s, a); return 0; }
+        if (kind == 3) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, false, 1, 7, 7, TH>), g, blk, 0, s, a); return 0; }
+    }
     const size_t lds = smooth_grad_lds_bytes(smooth ? a.smooth.n / 2 : -1, a.R);
     const dim3 grid((a.ncols + TW - 1) / TW, (a.nrows + TH - 1) / TH, batch), block(256);
     int e = 0;
@@ -225,9 +383,13 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
 
 int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch)
 {
+    const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch), block(256);
+    if (a.taps.sym == 1) {
+        if (a.ss == 4 && a.taps.n == 21) { hipLaunchKernelGGL((pyr_reduce_fast<4, 21>), grid, block, 0, s, a); return 0; }
+        if (a.ss == 2 && a.taps.n == 11) { hipLaunchKernelGGL((pyr_reduce_fast<2, 11>), grid, block, 0, s, a); return 0; }
+    }
     const size_t lds = pyr_reduce_lds_bytes(a.ss, a.taps.n);
     if (int e = set_lds(pyr_reduce_kernel, lds)) return e;
-    const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch), block(256);
     hipLaunchKernelGGL(pyr_reduce_kernel, grid, block, lds, s, a);
     return 0;
 }
