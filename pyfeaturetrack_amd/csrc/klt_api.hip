@@ -770,6 +770,7 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
     a.use_max_residue = p.use_max_residue; a.retain = p.retainTrackers; a.ncols = s1->nc; a.nrows = s1->nr;
     a.small = p.min_determinant; a.th = p.min_displacement; a.step = p.step_factor; a.max_residue = p.max_residue;
     a.ss = (float)s1->ss;
+    a.inv_ss = 1.0f / (float)s1->ss;
     {
         const double foot = 12.0 * (p.window_width + 1) * (p.window_width + 1);
         TimerScope t(c, F_TRACK, (double)n * (foot * 2 * s1->nlev + 32));      // refined by the caller from klt_track_stats

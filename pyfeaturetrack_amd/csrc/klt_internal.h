@@ -42,7 +42,7 @@ struct TrackArgs {
     double half_window;          // window/2 as the Python float (3.5 for 7x7), trackFeatures.py:88-89
     double borderx, bordery;
     int n, nlevels, window, max_iterations, use_max_residue, retain, ncols, nrows;
-    float small, th, step, max_residue, ss;
+    float small, th, step, max_residue, ss, inv_ss;
 };
 
 struct SelectArgs {

@@ -26,6 +26,7 @@ namespace {
 
 constexpr int TW = 64, TH = 16;        // output tile of smooth_grad_kernel
 constexpr int OW = 32, OH = 8;         // output tile of pyr_reduce_kernel
+constexpr int FTH = 16;                // tile height of the compile-time specialised smooth_grad kernels
 
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
@@ -215,6 +216,8 @@ __device__ __forceinline__ float correlate_ct(const float *c, const TapRegs<NT> 
     return (float)acc;
 }
 
+// (An f64-in-LDS variant of this kernel -- widening each sample once when produced -- was measured 20 % slower:
+// twice the LDS bytes and half the resident blocks cost more than the saved conversions.  profiles/r01_v4.)
 template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_>
 __global__ __launch_bounds__(256) void smooth_grad_fast(SmoothGradArgs a)
 {
@@ -283,14 +286,27 @@ __global__ __launch_bounds__(256) void smooth_grad_fast(SmoothGradArgs a)
     }
 }
 
-template <int SS, int NT>
-__global__ __launch_bounds__(256) void pyr_reduce_fast(PyrReduceArgs a)
+// f64 copies in LDS: every source sample is widened once when the tile is loaded instead of once per tap, and the
+// f32-rounded horizontal result is kept as the double it widens to -- the FP64 pipe is the bottleneck of these kernels.
+template <int NT, int STRIDE>
+__device__ __forceinline__ float correlate_sym_f64(const double *c, const TapRegs<NT> &t)
+{
+    constexpr int H = NT / 2;
+    double acc = c[0] * t.k[H];
+#pragma unroll
+    for (int jj = -H; jj < 0; jj++) acc = acc + (c[jj * STRIDE] + c[-jj * STRIDE]) * t.k[H + jj];
+    return (float)acc;
+}
+
+template <int SS, int NT, int NTHR>
+__global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
 {
     constexpr int r = NT / 2;
     constexpr int SW = (OW - 1) * SS + 2 * r + 1, SH = (OH - 1) * SS + 2 * r + 1;
     constexpr int PW = (SW + SS - 1) / SS, ROWLEN = PW * SS;
-    __shared__ float S[SH * ROWLEN];
-    __shared__ float Hh[SH * OW];
+    extern __shared__ __attribute__((aligned(16))) double dlds[];
+    double *const S = dlds;                  // [SH][SS planes][PW]
+    double *const Hd = dlds + SH * ROWLEN;   // [SH][OW]
     const int tid = threadIdx.x, b = blockIdx.z;
     const int xs0 = blockIdx.x * OW, ys0 = blockIdx.y * OH;
     const int gx0 = xs0 * SS + SS / 2 - r, gy0 = ys0 * SS + SS / 2 - r;
@@ -299,29 +315,40 @@ __global__ __launch_bounds__(256) void pyr_reduce_fast(PyrReduceArgs a)
     TapRegs<NT> k;
     load_taps(k, a.taps);
 
-    for (int i = tid; i < SH * SW; i += 256) {
+    for (int i = tid; i < SH * SW; i += NTHR) {
         const int rr = i / SW, c = i % SW;
         const int gy = reflect_fast(gy0 + rr, nr), gx = reflect_fast(gx0 + c, nc);
-        S[rr * ROWLEN + (c % SS) * PW + c / SS] = src[(size_t)gy * nc + gx];
+        S[rr * ROWLEN + (c % SS) * PW + c / SS] = (double)src[(size_t)gy * nc + gx];
     }
     __syncthreads();
-    for (int i = tid; i < SH * OW; i += 256) {
+    for (int i = tid; i < SH * OW; i += NTHR) {
         const int rr = i / OW, xs = i % OW;
-        const float *row = S + rr * ROWLEN + xs;         // column xs*SS + r + j lives at plane (r+j)%SS, index xs + (r+j)/SS
-        double acc = (double)row[(r % SS) * PW + r / SS] * k.k[r];
+        const double *row = S + rr * ROWLEN + xs;        // column xs*SS + r + j lives at plane (r+j)%SS, index xs + (r+j)/SS
+        double acc = row[(r % SS) * PW + r / SS] * k.k[r];
 #pragma unroll
         for (int jj = -r; jj < 0; jj++) {
-            const double lo = (double)row[((r + jj) % SS) * PW + (r + jj) / SS];
-            const double hi = (double)row[((r - jj) % SS) * PW + (r - jj) / SS];
+            const double lo = row[((r + jj) % SS) * PW + (r + jj) / SS];
+            const double hi = row[((r - jj) % SS) * PW + (r - jj) / SS];
             acc = acc + (lo + hi) * k.k[r + jj];
         }
-        Hh[i] = (float)acc;
+        Hd[i] = (double)(float)acc;                      // the f32 rounding between the passes
     }
     __syncthreads();
-    const int xs = tid % OW, ys = tid / OW;
-    const int ox = xs0 + xs, oy = ys0 + ys;
-    if (ox < a.dst_nc && oy < a.dst_nr)
-        a.dst[b][(size_t)oy * a.dst_nc + ox] = correlate_ct<NT, 1, OW>(Hh + (ys * SS + r) * OW + xs, k);
+    if (tid < OW * OH) {
+        const int xs = tid % OW, ys = tid / OW;
+        const int ox = xs0 + xs, oy = ys0 + ys;
+        if (ox < a.dst_nc && oy < a.dst_nr)
+            a.dst[b][(size_t)oy * a.dst_nc + ox] = correlate_sym_f64<NT, OW>(Hd + (ys * SS + r) * OW + xs, k);
+    }
+}
+
+template <int SS, int NT>
+constexpr size_t pyr_reduce_fast_lds()
+{
+    constexpr int r = NT / 2;
+    constexpr int SW = (OW - 1) * SS + 2 * r + 1, SH = (OH - 1) * SS + 2 * r + 1;
+    constexpr int PW = (SW + SS - 1) / SS;
+    return sizeof(double) * (size_t)(SH * PW * SS + SH * OW);
 }
 
 }  // namespace
@@ -357,13 +384,13 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
     const bool smooth = kind < 2;
     // compile-time specialisations: Gaussian smoothing (symmetric), Gaussian / derivative gradient taps
     if (a.ggauss.sym == 1 && a.gderiv.sym == -1 && a.ggauss.n == 7 && a.gderiv.n == 7 && (!smooth || a.smooth.sym == 1)) {
-        const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + TH - 1) / TH, batch), blk(256);
-        if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 5, 7, 7, TH>), g, blk, 0, s, a); return 0; }
-        if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<float, true, 5, 7, 7, TH>), g, blk, 0, s, a); return 0; }
-        if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 9, 7, 7, TH>), g, blk, 0, s, a); return 0; }
-        if (kind == 1 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_fast<float, true, 9, 7, 7, TH>), g, blk, 0, s, a); return 0; }
-        if (kind == 2) { hipLaunchKernelGGL((smooth_grad_fast<float, false, 1, 7, 7, TH>), g, blk, 0, s, a); return 0; }
-        if (kind == 3) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, false, 1, 7, 7, TH>), g, blk, 0, s, a); return 0; }
+        const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + FTH - 1) / FTH, batch), blk(256);
+        if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 5, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
+        if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<float, true, 5, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
+        if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 9, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
+        if (kind == 1 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_fast<float, true, 9, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
+        if (kind == 2) { hipLaunchKernelGGL((smooth_grad_fast<float, false, 1, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
+        if (kind == 3) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, false, 1, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
     }
     const size_t lds = smooth_grad_lds_bytes(smooth ? a.smooth.n / 2 : -1, a.R);
     const dim3 grid((a.ncols + TW - 1) / TW, (a.nrows + TH - 1) / TH, batch), block(256);
@@ -385,8 +412,18 @@ int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch)
 {
     const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch), block(256);
     if (a.taps.sym == 1) {
-        if (a.ss == 4 && a.taps.n == 21) { hipLaunchKernelGGL((pyr_reduce_fast<4, 21>), grid, block, 0, s, a); return 0; }
-        if (a.ss == 2 && a.taps.n == 11) { hipLaunchKernelGGL((pyr_reduce_fast<2, 11>), grid, block, 0, s, a); return 0; }
+        if (a.ss == 4 && a.taps.n == 21) {
+            constexpr size_t l = pyr_reduce_fast_lds<4, 21>();
+            if (int e = set_lds(pyr_reduce_fast<4, 21, 1024>, l)) return e;
+            hipLaunchKernelGGL((pyr_reduce_fast<4, 21, 1024>), grid, dim3(1024), l, s, a);
+            return 0;
+        }
+        if (a.ss == 2 && a.taps.n == 11) {
+            constexpr size_t l = pyr_reduce_fast_lds<2, 11>();
+            if (int e = set_lds(pyr_reduce_fast<2, 11, 512>, l)) return e;
+            hipLaunchKernelGGL((pyr_reduce_fast<2, 11, 512>), grid, dim3(512), l, s, a);
+            return 0;
+        }
     }
     const size_t lds = pyr_reduce_lds_bytes(a.ss, a.taps.n);
     if (int e = set_lds(pyr_reduce_kernel, lds)) return e;

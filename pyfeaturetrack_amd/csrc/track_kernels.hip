@@ -8,10 +8,10 @@
 // Work split inside the wavefront (window w x w, n = w*w samples):
 //   * lane l owns window samples l, l+64, ...; it keeps the image-1 template (intensity, gx, gy) of
 //     those samples in registers for the whole level and re-samples image 2 each Newton iteration;
-//   * the five window sums of an iteration (gxx, gxy, gyy, ex, ey) are accumulated by lanes 0..4 in the
-//     reference's row-major sequential f32 order (trackFeaturesUtils.pyx:263-267, :296-302) out of an
-//     LDS copy of the per-sample terms, then broadcast with wave shuffles; every lane solves the 2x2
-//     system redundantly so the position stays wave-uniform;
+//   * every lane forms the five product terms of its samples (gx*gx, gx*gy, gy*gy, diff*gx, diff*gy) and
+//     writes them to LDS; lanes 0..4 then add one array each in the reference's row-major sequential f32
+//     order (trackFeaturesUtils.pyx:263-267, :296-302) and the five sums are broadcast with wave
+//     shuffles; every lane solves the 2x2 system redundantly so the position stays wave-uniform;
 //   * the residue test reproduces numpy's pairwise f32 sum (trackFeatures.py:124).
 // The arithmetic mirrors the compiled reference exactly: bilinear weights in FP64
 // except the ax*ay*I term which the reference evaluates in f32, products and sums un-fused, f32
@@ -87,13 +87,16 @@ __device__ float pairwise_sum<0>(const float *a, int n)
 }
 
 // _trackFeature for one level.  Returns the status; x2/y2 updated in place; `iters` = Newton iterations.
-template <int MAXK>
+// WCT > 0: window size known at compile time (index math folds, the summation loops unroll and read LDS
+// 16 bytes at a time); WCT == 0: any odd window up to 31.
+template <int MAXK, int WCT>
 __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, float y1, float &x2r, float &y2r,
                            float *lds, int lane, int &iters)
 {
-    const int w = a.window, n = w * w, hw = w / 2;
+    const int w = WCT > 0 ? WCT : a.window, n = w * w, hw = w / 2;
+    const int npad = (n + 3) & ~3;                       // 16-byte aligned sub-arrays
     const int nc = lv.nc, nr = lv.nr;
-    float *l_diff = lds, *l_sx = lds + n, *l_sy = lds + 2 * n;
+    float *l_diff = lds;                                 // residue scratch (aliases product array 0)
     iters = 0;
 
     // image-1 template (trackFeatures.py:102-104)
@@ -128,24 +131,40 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
         }
         const Bilinear b2 = make_bilinear(x2, y2);
         const size_t base = (size_t)(b2.iy - hw) * nc + (b2.ix - hw);
+        // every lane forms the five products of its samples (each product is one rounded f32 multiply, exactly the
+        // term the reference adds); LDS then holds five arrays of n terms
 #pragma unroll
         for (int kk = 0; kk < MAXK; kk++) {
             const int k = lane + 64 * kk;
             if (k < n) {
                 const size_t q = base + off[kk];
-                l_diff[k] = t_i[kk] - sample(lv.i2 + q, nc, b2);          // :82-85
-                l_sx[k] = t_gx[kk] + sample(lv.gx2 + q, nc, b2);          // -( -g1 - g2 ), :128 and :297
-                l_sy[k] = t_gy[kk] + sample(lv.gy2 + q, nc, b2);
+                const float diff = t_i[kk] - sample(lv.i2 + q, nc, b2);          // :82-85
+                const float sx = t_gx[kk] + sample(lv.gx2 + q, nc, b2);          // -( -g1 - g2 ), :128 and :297
+                const float sy = t_gy[kk] + sample(lv.gy2 + q, nc, b2);
+                lds[k] = sx * sx;                  // gxx terms, :299
+                lds[npad + k] = sx * sy;           // gxy terms, :300
+                lds[2 * npad + k] = sy * sy;       // gyy terms, :301
+                lds[3 * npad + k] = diff * sx;     // ex terms,  :265
+                lds[4 * npad + k] = diff * sy;     // ey terms,  :266
             }
         }
         __syncthreads();
+        // lanes 0..4 each add one array in the reference's row-major order (sequential f32 adds)
         float acc = 0.f;
         if (lane < 5) {
-            const float *A = lane < 2 ? l_sx : (lane == 2 ? l_sy : l_diff);
-            const float *B = (lane == 0 || lane == 3) ? l_sx : l_sy;
-            for (int k = 0; k < n; k++) {
-                const float prod = A[k] * B[k];
-                acc = acc + prod;
+            const float *T = lds + lane * npad;
+            if (WCT > 0) {
+                const float4 *T4 = reinterpret_cast<const float4 *>(T);
+#pragma unroll(WCT <= 8 ? 16 : 4)
+                for (int q = 0; q < (WCT * WCT + 3) / 4; q++) {
+                    const float4 v = T4[q];
+                    acc = acc + v.x;
+                    if (4 * q + 1 < WCT * WCT) acc = acc + v.y;
+                    if (4 * q + 2 < WCT * WCT) acc = acc + v.z;
+                    if (4 * q + 3 < WCT * WCT) acc = acc + v.w;
+                }
+            } else {
+                for (int k = 0; k < n; k++) acc = acc + T[k];
             }
         }
         __syncthreads();
@@ -195,10 +214,10 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
     return KLT_TRACKED;
 }
 
-template <int MAXK>
+template <int MAXK, int WCT>
 __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
 {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
     if (f >= a.n) return;
@@ -210,14 +229,14 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     const int L = a.nlevels;
     // trackFeatures.py:255-265: position at the coarsest resolution (divisions by a power of two: exact)
     float xloc = ft.x, yloc = ft.y;
-    for (int r = 0; r < L; r++) { xloc = xloc / a.ss; yloc = yloc / a.ss; }
+    for (int r = 0; r < L; r++) { xloc = xloc * a.inv_ss; yloc = yloc * a.inv_ss; }   // power of two: exact
     float xout = xloc, yout = yloc;
     int val = KLT_TRACKED;
     uint32_t aux = 0;       // 4 bits per level: 0 = level not visited, v = v-1 Newton iterations (saturating at 14)
     for (int r = L - 1; r >= 0; r--) {
         xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss;
         int it = 0;
-        val = track_level<MAXK>(a, a.lv[r], xloc, yloc, xout, yout, lds, lane, it);
+        val = track_level<MAXK, WCT>(a, a.lv[r], xloc, yloc, xout, yout, lds, lane, it);
         aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);      // visited level r with `it` Newton iterations
         if (val == KLT_SMALL_DET || val == KLT_OOB) break;             // :284-285
     }
@@ -273,13 +292,15 @@ int launch_track(hipStream_t s, const TrackArgs &a)
 {
     if (a.n <= 0) return 0;
     const int n = a.window * a.window;
-    const size_t lds = 3 * (size_t)n * sizeof(float);
+    const size_t lds = 5 * (size_t)((n + 3) & ~3) * sizeof(float);
     const dim3 grid(a.n), block(64);
-    if (n <= 64) hipLaunchKernelGGL((track_kernel<1>), grid, block, lds, s, a);
-    else if (n <= 128) hipLaunchKernelGGL((track_kernel<2>), grid, block, lds, s, a);
-    else if (n <= 256) hipLaunchKernelGGL((track_kernel<4>), grid, block, lds, s, a);
-    else if (n <= 512) hipLaunchKernelGGL((track_kernel<8>), grid, block, lds, s, a);
-    else if (n <= 1024) hipLaunchKernelGGL((track_kernel<16>), grid, block, lds, s, a);
+    if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7>), grid, block, lds, s, a);
+    else if (a.window == 15) hipLaunchKernelGGL((track_kernel<4, 15>), grid, block, lds, s, a);
+    else if (n <= 64) hipLaunchKernelGGL((track_kernel<1, 0>), grid, block, lds, s, a);
+    else if (n <= 128) hipLaunchKernelGGL((track_kernel<2, 0>), grid, block, lds, s, a);
+    else if (n <= 256) hipLaunchKernelGGL((track_kernel<4, 0>), grid, block, lds, s, a);
+    else if (n <= 512) hipLaunchKernelGGL((track_kernel<8, 0>), grid, block, lds, s, a);
+    else if (n <= 1024) hipLaunchKernelGGL((track_kernel<16, 0>), grid, block, lds, s, a);
     else return -1;
     return 0;
 }
