@@ -196,6 +196,28 @@ def main():
                                             "launches_per_step": k["launches"] / args.steps,
                                             "GBps": k["bytes"] / max(k["total_ms"], 1e-9) / 1e6} for k in kernels}}
 
+    # secondary figures (never `value`): selection time, and the PCIe-inclusive pair time
+    extra = None
+    if rank == 0:
+        reps = max(5, min(20, args.steps))
+        ctx.sync()
+        t = time.perf_counter()
+        for _ in range(reps):
+            ctx.select_async(0, 1, True, FB_OUT1, NFEAT)      # SELECTING_ALL on the resident level-0 pyramid
+        ctx.sync()
+        ms_select = (time.perf_counter() - t) / reps * 1e3
+        t = time.perf_counter()
+        for _ in range(reps):
+            ctx.upload(0, f0)
+            ctx.upload(1, f1)
+            ctx.build_pyramids_batch([0, 1])
+            ctx.track_async(0, 1, FB_SEL, FB_OUT0, NFEAT)
+            ctx.featbuf_download(FB_OUT0, NFEAT)
+        ms_pcie = (time.perf_counter() - t) / reps * 1e3
+        extra = {"ms_per_select_5000": ms_select,
+                 "pcie_inclusive_ms_per_pair": ms_pcie, "pcie_inclusive_features_per_s": NFEAT / (ms_pcie * 1e-3),
+                 "note": "pcie_inclusive = H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the records"}
+
     cpu = None
     if rank == 0 and not distributed and not args.no_cpu_baseline:
         cpu = cpu_baseline(p, f0, f1, fl)
@@ -212,7 +234,7 @@ def main():
                        "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
                        "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
                        "parallelism": "1 pair per GPU" + (", RCCL all-gather of feature records per step" if distributed else "")},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)
     ctx.close()

@@ -79,6 +79,7 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
 
 /* ---- options ------------------------------------------------------------------------------ */
 #define KLT_OPT_FUSED_KERNELS 1   /* 1 (default): LDS-tiled fused pyramid kernels; 0: generic two-pass kernels (any tap count) */
+#define KLT_OPT_SMOOTH_GRAD_VARIANT 2   /* 0 (default): register-blocked level-0 kernel; 1: one sample per thread (process-wide) */
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
 /* ---- parameters and taps ------------------------------------------------------------------- */

@@ -62,6 +62,8 @@ struct klt_ctx {
     size_t seed_cap = 0;
     uint32_t *grid = nullptr;
     size_t grid_cap = 0;
+    int *nms_slots = nullptr;
+    size_t nms_slots_cap = 0;
     int *placed_d = nullptr;
     const float *last_sel[3] = {nullptr, nullptr, nullptr};
     int sel_nc = 0, sel_nr = 0, sel_nx = 0, sel_ny = 0, sel_npow2 = 0;
@@ -485,7 +487,7 @@ void klt_destroy(klt_ctx *c)
     for (FeatBuf &b : c->fbs) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
-    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->placed_d); hipFree(c->stats_d);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -553,6 +555,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
 {
     if (!c) return KLT_ERR_ARG;
     if (option == KLT_OPT_FUSED_KERNELS) { c->use_fused = value != 0; return KLT_OK; }
+    if (option == KLT_OPT_SMOOTH_GRAD_VARIANT) { g_smooth_grad_variant = value; return KLT_OK; }
     return fail(c, KLT_ERR_ARG, "unknown option");
 }
 
@@ -708,10 +711,13 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     na.keys = c->keys; na.fl = b->d; na.placed_out = c->placed_d;
     na.nkeys = (int)(ncand < npow2 ? ncand : npow2); na.nfeat = n; na.overwrite_all = (mode == KLT_SELECTING_ALL);
     na.d = d; na.cell = d >= 0 ? d + 1 : 1;
+    na.cell_magic = na.cell == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)na.cell) + 1u;
+    if (int rc = ensure(c, c->nms_slots, c->nms_slots_cap, (size_t)n)) return rc;
+    na.slots = c->nms_slots;
     na.gw = (nc + na.cell - 1) / na.cell; na.gh = (nr + na.cell - 1) / na.cell;
     if (d < 0) { na.gw = na.gh = 1; }
     const size_t grid_bytes = (size_t)na.gw * na.gh * sizeof(uint32_t);
-    na.grid_in_lds = grid_bytes <= 144 * 1024;
+    na.grid_in_lds = grid_bytes <= 128 * 1024;     // + 12.4 KiB of static LDS in the kernel
     na.grid_global = nullptr;
     if (!na.grid_in_lds) {
         if (int rc = ensure(c, c->grid, c->grid_cap, (size_t)na.gw * na.gh)) return rc;

@@ -59,6 +59,8 @@ struct NmsArgs {
     klt_feat *fl;
     uint32_t *grid_global;   // used when the cell grid does not fit in LDS
     int *placed_out;
+    int *slots;              // scratch [nfeat]: fillable slot indices (REPLACING_SOME)
+    unsigned cell_magic;     // floor(2^32 / cell) + 1: x / cell == __umulhi(x, cell_magic) for x < 65536
     int nkeys, nfeat, overwrite_all, d /* mindist-1 */, cell, gw, gh, grid_in_lds;
 };
 
@@ -70,6 +72,7 @@ void launch_hconv_f32(hipStream_t s, const float *in, int ncols, int nrows, floa
 void launch_vconv(hipStream_t s, const float *inA, const float *inB, int ncols, int nrows, float *outA, float *outB,
                   int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb);
 
+extern int g_smooth_grad_variant;   // test hook: 0 register-blocked, 1 one-sample-per-thread
 size_t smooth_grad_lds_bytes(int smooth_radius /* -1: no smoothing stage */, int R);
 size_t pyr_reduce_lds_bytes(int ss, int ntaps);
 // kind: 0 = u8 frame + smoothing, 1 = f32 frame + smoothing, 2 = f32 image gradients only, 3 = u8 image gradients only

@@ -18,6 +18,8 @@
 // commutatively before multiplying.  So the smoothed value computed at a virtual position equals the smoothed
 // image at the reflected position, which is what the differentiation must see.  The host only takes this
 // path when the smoothing taps are symmetric (they are Gaussians) and the tile fits in LDS.
+#include <cstdlib>
+
 #include "klt_internal.h"
 
 #pragma clang fp contract(off)
@@ -286,6 +288,170 @@ __global__ __launch_bounds__(256) void smooth_grad_fast(SmoothGradArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Register-blocked variant (the one dispatched for the default sigmas).  Every thread produces 4 horizontally
+// adjacent samples per step: LDS is read 16 bytes at a time (ds_read_b128, one aligned quad per lane), each
+// sample is widened to f64 once per quad instead of once per tap, and the integer index math is amortised over
+// four outputs.  The per-output FP64 expression and its operation order are unchanged.
+// Column frames (relative to the tile's first output column): A (raw) starts at -8, B / C at -4, D / E at 0,
+// all row strides are multiples of 4 floats.  Needs tap radii <= 4.
+template <int NT, int SYM>
+__device__ __forceinline__ float corr_regs(const double *c /* centre */, const TapRegs<NT> &t)
+{
+    constexpr int H = NT / 2;
+    double acc = c[0] * t.k[H];
+#pragma unroll
+    for (int jj = -H; jj < 0; jj++) {
+        const double pr = SYM > 0 ? c[jj] + c[-jj] : c[jj] - c[-jj];
+        acc = acc + pr * t.k[H + jj];
+    }
+    return (float)acc;
+}
+
+__device__ __forceinline__ void widen4(const float4 v, double *d)
+{
+    d[0] = (double)v.x; d[1] = (double)v.y; d[2] = (double)v.z; d[3] = (double)v.w;
+}
+
+template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_>
+__global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
+{
+    constexpr int rs = SMOOTH ? NS / 2 : 0;
+    constexpr int R = (NG > ND ? NG : ND) / 2;
+    static_assert(rs <= 4 && R <= 4, "register-blocked kernel needs tap radii <= 4");
+    constexpr int AW = TW + 16, BW = TW + 8, DW = TW;           // floats per row
+    constexpr int AQ = AW / 4, BQ = BW / 4, DQ = DW / 4;        // quads per row
+    constexpr int IH = TH_ + 2 * R, RH = IH + 2 * rs;
+    constexpr int AB = SMOOTH ? RH * AW + RH * BW : 0, DE = 2 * IH * DW;
+    constexpr int OFF_C = AB > DE ? AB : DE;
+    __shared__ __attribute__((aligned(16))) float lds[OFF_C + IH * BW];
+    float *const A = lds, *const B = lds + RH * AW, *const D = lds, *const E = lds + IH * DW, *const C = lds + OFF_C;
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
+    const int nc = a.ncols, nr = a.nrows;
+    const TIn *__restrict__ raw = (const TIn *)a.raw[b];
+    TapRegs<NG> kg;
+    TapRegs<ND> kd;
+    load_taps(kg, a.ggauss);
+    load_taps(kd, a.gderiv);
+
+    // ---- stage 0: frame -> LDS (through the reflect map)
+    {
+        constexpr int W0 = SMOOTH ? AQ : BQ, H0 = SMOOTH ? RH : IH, X0 = SMOOTH ? -8 : -4, Y0 = -(R + rs);
+        float *const dst = SMOOTH ? A : C;
+        for (int i = tid; i < H0 * W0; i += 256) {
+            const int r = i / W0, q = i % W0;
+            const int gy = reflect_fast(ty0 + Y0 + r, nr);
+            const int x = tx0 + X0 + 4 * q;
+            const TIn *row = raw + (size_t)gy * nc;
+            float4 v;
+            if (x >= 0 && x + 3 < nc) {
+                v.x = (float)row[x]; v.y = (float)row[x + 1]; v.z = (float)row[x + 2]; v.w = (float)row[x + 3];
+            } else {
+                v.x = (float)row[reflect_fast(x, nc)]; v.y = (float)row[reflect_fast(x + 1, nc)];
+                v.z = (float)row[reflect_fast(x + 2, nc)]; v.w = (float)row[reflect_fast(x + 3, nc)];
+            }
+            *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = v;
+        }
+    }
+    __syncthreads();
+    if (SMOOTH) {
+        TapRegs<NS> ks;
+        load_taps(ks, a.smooth);
+        // ---- stage 1: horizontal smoothing, A -> B (B column c = A column c + 4)
+        for (int i = tid; i < RH * BQ; i += 256) {
+            const int r = i / BQ, q = i % BQ;
+            const float4 *src = reinterpret_cast<const float4 *>(A + r * AW + 4 * q);
+            double v[12];
+            widen4(src[0], v); widen4(src[1], v + 4); widen4(src[2], v + 8);
+            float4 o;
+            o.x = corr_regs<NS, 1>(v + 4, ks); o.y = corr_regs<NS, 1>(v + 5, ks);
+            o.z = corr_regs<NS, 1>(v + 6, ks); o.w = corr_regs<NS, 1>(v + 7, ks);
+            *reinterpret_cast<float4 *>(B + r * BW + 4 * q) = o;
+        }
+        __syncthreads();
+        // ---- stage 2: vertical smoothing, B -> C (+ store the tile interior of the smoothed image)
+        float *__restrict__ img = a.img[b];
+        for (int i = tid; i < IH * BQ; i += 256) {
+            const int r = i / BQ, q = i % BQ;
+            double v[4][NS];
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                const float4 t = *reinterpret_cast<const float4 *>(B + (r + j) * BW + 4 * q);
+                v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
+            }
+            float4 o;
+            o.x = corr_regs<NS, 1>(v[0] + rs, ks); o.y = corr_regs<NS, 1>(v[1] + rs, ks);
+            o.z = corr_regs<NS, 1>(v[2] + rs, ks); o.w = corr_regs<NS, 1>(v[3] + rs, ks);
+            *reinterpret_cast<float4 *>(C + r * BW + 4 * q) = o;
+            const int y = ty0 - R + r, x = tx0 - 4 + 4 * q;
+            if (r >= R && r < R + TH_ && q >= 1 && q <= DQ && y < nr) {
+                float *dstp = img + (size_t)y * nc + x;
+                if (x + 3 < nc) { dstp[0] = o.x; dstp[1] = o.y; dstp[2] = o.z; dstp[3] = o.w; }
+                else {
+                    if (x < nc) dstp[0] = o.x;
+                    if (x + 1 < nc) dstp[1] = o.y;
+                    if (x + 2 < nc) dstp[2] = o.z;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- stage 3: horizontal pass of both gradients, C -> D (derivative taps), E (Gaussian taps)
+    for (int i = tid; i < IH * DQ; i += 256) {
+        const int r = i / DQ, q = i % DQ;
+        const float4 *src = reinterpret_cast<const float4 *>(C + r * BW + 4 * q);
+        double v[12];
+        widen4(src[0], v); widen4(src[1], v + 4); widen4(src[2], v + 8);
+        float4 d, e;
+        d.x = corr_regs<ND, -1>(v + 4, kd); d.y = corr_regs<ND, -1>(v + 5, kd);
+        d.z = corr_regs<ND, -1>(v + 6, kd); d.w = corr_regs<ND, -1>(v + 7, kd);
+        e.x = corr_regs<NG, 1>(v + 4, kg); e.y = corr_regs<NG, 1>(v + 5, kg);
+        e.z = corr_regs<NG, 1>(v + 6, kg); e.w = corr_regs<NG, 1>(v + 7, kg);
+        *reinterpret_cast<float4 *>(D + r * DW + 4 * q) = d;
+        *reinterpret_cast<float4 *>(E + r * DW + 4 * q) = e;
+    }
+    __syncthreads();
+    // ---- stage 4: vertical pass, D -> gradx (Gaussian taps), E -> grady (derivative taps)
+    float *__restrict__ gxo = a.gx[b];
+    float *__restrict__ gyo = a.gy[b];
+    for (int i = tid; i < TH_ * DQ; i += 256) {
+        const int r = i / DQ, q = i % DQ;
+        const int y = ty0 + r, x = tx0 + 4 * q;
+        if (y >= nr || x >= nc) continue;
+        float4 ox, oy;
+        {
+            double v[4][NG];
+#pragma unroll
+            for (int j = 0; j < NG; j++) {
+                const float4 t = *reinterpret_cast<const float4 *>(D + (r + R - NG / 2 + j) * DW + 4 * q);
+                v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
+            }
+            ox.x = corr_regs<NG, 1>(v[0] + NG / 2, kg); ox.y = corr_regs<NG, 1>(v[1] + NG / 2, kg);
+            ox.z = corr_regs<NG, 1>(v[2] + NG / 2, kg); ox.w = corr_regs<NG, 1>(v[3] + NG / 2, kg);
+        }
+        {
+            double v[4][ND];
+#pragma unroll
+            for (int j = 0; j < ND; j++) {
+                const float4 t = *reinterpret_cast<const float4 *>(E + (r + R - ND / 2 + j) * DW + 4 * q);
+                v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
+            }
+            oy.x = corr_regs<ND, -1>(v[0] + ND / 2, kd); oy.y = corr_regs<ND, -1>(v[1] + ND / 2, kd);
+            oy.z = corr_regs<ND, -1>(v[2] + ND / 2, kd); oy.w = corr_regs<ND, -1>(v[3] + ND / 2, kd);
+        }
+        float *px = gxo + (size_t)y * nc + x, *py = gyo + (size_t)y * nc + x;
+        if (x + 3 < nc) {
+            px[0] = ox.x; px[1] = ox.y; px[2] = ox.z; px[3] = ox.w;
+            py[0] = oy.x; py[1] = oy.y; py[2] = oy.z; py[3] = oy.w;
+        } else {
+            px[0] = ox.x; py[0] = oy.x;
+            if (x + 1 < nc) { px[1] = ox.y; py[1] = oy.y; }
+            if (x + 2 < nc) { px[2] = ox.z; py[2] = oy.z; }
+        }
+    }
+}
+
 // f64 copies in LDS: every source sample is widened once when the tile is loaded instead of once per tap, and the
 // f32-rounded horizontal result is kept as the double it widens to -- the FP64 pipe is the bottleneck of these kernels.
 template <int NT, int STRIDE>
@@ -353,6 +519,8 @@ constexpr size_t pyr_reduce_fast_lds()
 
 }  // namespace
 
+int g_smooth_grad_variant = 0;     // 0 = register-blocked (default), 1 = one-sample-per-thread LDS kernels
+
 size_t smooth_grad_lds_bytes(int rs, int R)
 {
     const int IW = TW + 2 * R, IH = TH + 2 * R, RW = IW + 2 * rs, RH = IH + 2 * rs;
@@ -384,7 +552,28 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
     const bool smooth = kind < 2;
     // compile-time specialisations: Gaussian smoothing (symmetric), Gaussian / derivative gradient taps
     if (a.ggauss.sym == 1 && a.gderiv.sym == -1 && a.ggauss.n == 7 && a.gderiv.n == 7 && (!smooth || a.smooth.sym == 1)) {
-        const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + FTH - 1) / FTH, batch), blk(256);
+        const dim3 blk(256);
+        if (g_smooth_grad_variant == 0) {
+            // register-blocked kernels; small frames take the shorter tile so that the grid still covers the chip
+            static const int force_th = getenv("KLT_RB_TH") ? atoi(getenv("KLT_RB_TH")) : 0;   // experiment hook
+            const bool tall = force_th ? force_th == 32 : (long long)a.ncols * a.nrows * batch >= 1000000;
+            const int th = tall ? 32 : 16;
+            const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + th - 1) / th, batch);
+#define KLT_RB(T, SM, NSV)                                                                                        \
+    do {                                                                                                          \
+        if (tall) hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 32>), g, blk, 0, s, a);                   \
+        else hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 16>), g, blk, 0, s, a);                        \
+        return 0;                                                                                                 \
+    } while (0)
+            if (kind == 0 && a.smooth.n == 5) KLT_RB(uint8_t, true, 5);
+            if (kind == 1 && a.smooth.n == 5) KLT_RB(float, true, 5);
+            if (kind == 0 && a.smooth.n == 9) KLT_RB(uint8_t, true, 9);
+            if (kind == 1 && a.smooth.n == 9) KLT_RB(float, true, 9);
+            if (kind == 2) KLT_RB(float, false, 1);
+            if (kind == 3) KLT_RB(uint8_t, false, 1);
+#undef KLT_RB
+        }
+        const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + FTH - 1) / FTH, batch);
         if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 5, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
         if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<float, true, 5, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
         if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 9, 7, 7, FTH>), g, blk, 0, s, a); return 0; }

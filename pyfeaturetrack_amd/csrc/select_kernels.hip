@@ -22,42 +22,69 @@
 namespace {
 
 // ------------------------------------------------------------------ SAT, row pass (+ products)
-// block = one wavefront; blockIdx.x = band of 64 rows; blockIdx.y = plane (0: gx*gx, 1: gx*gy, 2: gy*gy)
-__global__ __launch_bounds__(64) void sat_rows_kernel(const float *__restrict__ gx, const float *__restrict__ gy,
-                                                       float *__restrict__ sat, int ncols, int nrows)
+// block = 256 threads = one band of 64 rows; all four waves move 64x64 tiles of gx / gy between HBM and LDS with
+// coalesced 256-byte row segments (the next tile is prefetched into registers while the current one is scanned);
+// waves 0..2 each run the 64 sequential row chains of one plane (0: gx*gx, 1: gx*gy, 2: gy*gy), lane = row.
+constexpr int SAT_LD = 68;      // tile row stride in floats: 16-byte aligned rows, conflict-free b128 column walks
+
+__global__ __launch_bounds__(256) void sat_rows_kernel(const float *__restrict__ gx, const float *__restrict__ gy,
+                                                        float *__restrict__ sat, int ncols, int nrows)
 {
-    __shared__ float tile[64][65];
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float tin[2][64 * SAT_LD];    // gx, gy tiles
+    __shared__ __attribute__((aligned(16))) float tout[3][64 * SAT_LD];   // row-prefix tiles of the three planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * 64;
-    const int plane = blockIdx.y;
-    float *out = sat + (size_t)plane * ncols * nrows;
+    const size_t plane = (size_t)ncols * nrows;
     float carry = 0.f;
+    float pgx[16], pgy[16];
+    auto fetch = [&](int x0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int row = row0 + k * 4 + wave, col = x0 + lane;
+            const bool ok = row < nrows && col < ncols;
+            pgx[k] = ok ? gx[(size_t)row * ncols + col] : 0.f;
+            pgy[k] = ok ? gy[(size_t)row * ncols + col] : 0.f;
+        }
+    };
+    fetch(0);
     for (int x0 = 0; x0 < ncols; x0 += 64) {
-        const int col = x0 + lane;
-#pragma unroll 8
-        for (int r = 0; r < 64; r++) {
-            const int row = row0 + r;
-            float v = 0.f;
-            if (row < nrows && col < ncols) {
-                const float a = gx[(size_t)row * ncols + col];
-                const float b = gy[(size_t)row * ncols + col];
-                v = plane == 0 ? a * a : (plane == 1 ? a * b : b * b);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            tin[0][(k * 4 + wave) * SAT_LD + lane] = pgx[k];
+            tin[1][(k * 4 + wave) * SAT_LD + lane] = pgy[k];
+        }
+        __syncthreads();
+        if (x0 + 64 < ncols) fetch(x0 + 64);                 // in flight during the scan below
+        if (wave < 3) {
+            const float4 *a4 = reinterpret_cast<const float4 *>(&tin[wave == 2 ? 1 : 0][lane * SAT_LD]);
+            const float4 *b4 = reinterpret_cast<const float4 *>(&tin[wave == 0 ? 0 : 1][lane * SAT_LD]);
+            float4 *o4 = reinterpret_cast<float4 *>(&tout[wave][lane * SAT_LD]);
+#pragma unroll 4
+            for (int c = 0; c < 16; c++) {
+                const float4 a = a4[c], b = b4[c];
+                float4 o;
+                { const float p = a.x * b.x; carry = carry + p; o.x = carry; }
+                { const float p = a.y * b.y; carry = carry + p; o.y = carry; }
+                { const float p = a.z * b.z; carry = carry + p; o.z = carry; }
+                { const float p = a.w * b.w; carry = carry + p; o.w = carry; }
+                o4[c] = o;
             }
-            tile[r][lane] = v;
         }
         __syncthreads();
-#pragma unroll 8
-        for (int c = 0; c < 64; c++) {      // lane = row of the band: sequential f32 prefix along x
-            carry = carry + tile[lane][c];
-            tile[lane][c] = carry;
+        const int col = x0 + lane;
+        if (col < ncols) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int r = k * 4 + wave, row = row0 + r;
+                if (row < nrows) {
+                    sat[(size_t)row * ncols + col] = tout[0][r * SAT_LD + lane];
+                    sat[plane + (size_t)row * ncols + col] = tout[1][r * SAT_LD + lane];
+                    sat[2 * plane + (size_t)row * ncols + col] = tout[2][r * SAT_LD + lane];
+                }
+            }
         }
-        __syncthreads();
-#pragma unroll 8
-        for (int r = 0; r < 64; r++) {
-            const int row = row0 + r;
-            if (row < nrows && col < ncols) out[(size_t)row * ncols + col] = tile[r][lane];
-        }
-        __syncthreads();
+        // the next iteration's tin writes are ordered behind this iteration's scan by the barrier above;
+        // tout is rewritten only after the next barrier
     }
 }
 
@@ -213,83 +240,168 @@ __global__ __launch_bounds__(SORT_T) void bitonic_local_merge(unsigned long long
 }
 
 // ------------------------------------------------------------------ greedy minimum-distance pass
-// One wavefront walks the sorted keys 64 at a time.  Every lane tests its candidate against the cell
-// grid, then the free lanes are resolved in rank order (lowest lane = highest rank) with ballots.
-__global__ __launch_bounds__(64) void nms_kernel(NmsArgs a)
+// One workgroup of 16 wavefronts walks the sorted keys 1024 at a time:
+//   1. every thread tests its candidate against the cell grid as it stood at the start of the super-batch
+//      (almost every candidate dies here: it is blocked by a feature accepted long before);
+//   2. the survivors are compacted in rank order;
+//   3. wave 0 resolves them sequentially with ballots -- a survivor can only be blocked by a feature accepted
+//      inside the same super-batch, which is a register compare (plus a grid re-test for survivors beyond the
+//      first 64, whose predecessors in the super-batch are already in the grid).
+// The result is exactly the sequential walk of selectGoodFeatures.py:71-134.
+constexpr int NMS_T = 1024;
+
+template <bool LDSGRID>
+__device__ __forceinline__ uint32_t grid_load(const uint32_t *p)
+{
+    if (LDSGRID) return *p;
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // L2-served: never a stale L1 line
+}
+
+// x / cell for x < 65536 without an integer division: cell_magic = floor(2^32 / cell) + 1
+__device__ __forceinline__ int cell_of(int v, const NmsArgs &a)
+{
+    return a.cell == 1 ? v : (int)__umulhi((unsigned)v, a.cell_magic);
+}
+
+template <bool LDSGRID>
+__device__ __forceinline__ bool grid_free(const uint32_t *grid, const NmsArgs &a, int x, int y)
+{
+    const int cx = cell_of(x, a), cy = cell_of(y, a);
+    bool ok = true;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            const int gx = cx + dx, gy = cy + dy;
+            if (gx < 0 || gy < 0 || gx >= a.gw || gy >= a.gh) continue;
+            const uint32_t v = grid_load<LDSGRID>(&grid[gy * a.gw + gx]);
+            if (v) {
+                const int ax = (int)((v - 1u) >> 16), ay = (int)((v - 1u) & 0xffffu);
+                if (abs(x - ax) <= a.d && abs(y - ay) <= a.d) ok = false;
+            }
+        }
+    return ok;
+}
+
+template <bool LDSGRID>
+__global__ __launch_bounds__(NMS_T) void nms_kernel(NmsArgs a)
 {
     extern __shared__ uint32_t lds_grid[];
-    uint32_t *grid = a.grid_in_lds ? lds_grid : a.grid_global;   // flat pointer: LDS or global
-    const int lane = threadIdx.x;
-    const int ncell = a.gw * a.gh;
-    if (a.grid_in_lds) {
-        for (int i = lane; i < ncell; i += 64) grid[i] = 0u;
+    __shared__ unsigned long long surv[NMS_T];
+    __shared__ int wave_cnt[NMS_T / 64];
+    __shared__ int scan[NMS_T];
+    __shared__ int s_stop, s_nfill;
+    uint32_t *grid = LDSGRID ? lds_grid : a.grid_global;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (LDSGRID)
+        for (int i = tid; i < a.gw * a.gh; i += NMS_T) grid[i] = 0u;
+    if (tid == 0) s_stop = 0;
+
+    // slots that may be filled, in list order (selectGoodFeatures.py:109-110): every slot when overwriting,
+    // otherwise the slots whose feature is lost.  a.slots[k] = index of the k-th fillable slot.
+    int nfill = a.nfeat;
+    if (!a.overwrite_all) {
+        const int per = (a.nfeat + NMS_T - 1) / NMS_T, lo = tid * per, hi = min(lo + per, a.nfeat);
+        int cnt = 0;
+        for (int i = lo; i < hi; i++) cnt += a.fl[i].val < 0;
+        scan[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < NMS_T; off <<= 1) {          // Hillis-Steele inclusive scan
+            const int v = tid >= off ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        int k = scan[tid] - cnt;
+        for (int i = lo; i < hi; i++)
+            if (a.fl[i].val < 0) a.slots[k++] = i;
+        if (tid == NMS_T - 1) s_nfill = scan[tid];
+        __syncthreads();
+        nfill = s_nfill;
     }
     __syncthreads();
 
-    int indx = 0, placed = 0;
-    bool list_full = false, keys_done = false;
-    for (int pos = 0; pos < a.nkeys && !list_full && !keys_done; pos += 64) {
-        const int kidx = pos + lane;
-        const unsigned long long key = kidx < a.nkeys ? a.keys[kidx] : 0ull;
-        const bool valid = key != 0ull;
-        const int x = (int)((key >> 16) & 0xffffull), y = (int)(key & 0xffffull);
-        const float val = __uint_as_float((uint32_t)(key >> 32));
-        bool is_free = valid;
-        if (valid && a.d >= 0) {
-            const int cx = x / a.cell, cy = y / a.cell;
-            for (int dy = -1; dy <= 1; dy++)
-                for (int dx = -1; dx <= 1; dx++) {
-                    const int gx = cx + dx, gy = cy + dy;
-                    if (gx < 0 || gy < 0 || gx >= a.gw || gy >= a.gh) continue;
-                    const uint32_t v = __hip_atomic_load(&grid[gy * a.gw + gx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v) {
-                        const int ax = (int)((v - 1u) >> 16), ay = (int)((v - 1u) & 0xffffu);
-                        if (abs(x - ax) <= a.d && abs(y - ay) <= a.d) is_free = false;
+    int placed = 0;                               // meaningful in wave 0 only
+    bool list_full = nfill == 0;
+    unsigned long long key = tid < a.nkeys ? a.keys[tid] : 0ull;
+    for (int pos = 0; pos < a.nkeys && nfill > 0; pos += NMS_T) {
+        const unsigned long long cur = key;
+        const int nxt = pos + NMS_T + tid;
+        key = nxt < a.nkeys ? a.keys[nxt] : 0ull;                 // prefetch the next super-batch
+        const bool valid = cur != 0ull;
+        const int x = (int)((cur >> 16) & 0xffffull), y = (int)(cur & 0xffffull);
+        bool ok = valid;
+        if (valid && a.d >= 0) ok = grid_free<LDSGRID>(grid, a, x, y);
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        const int ended = __syncthreads_or(!valid);               // a zero key: everything after it is padding
+        int offset = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NMS_T / 64; w++) {
+            const int c = wave_cnt[w];
+            offset += w < wave ? c : 0;
+            total += c;
+        }
+        if (ok) surv[offset + __popcll(m & ((1ull << lane) - 1ull))] = cur;
+        __syncthreads();
+        if (wave == 0) {
+            for (int base = 0; base < total && !list_full; base += 64) {
+                const unsigned long long k = base + lane < total ? surv[base + lane] : 0ull;
+                const int sx = (int)((k >> 16) & 0xffffull), sy = (int)(k & 0xffffull);
+                bool is_free = k != 0ull;
+                if (base > 0 && is_free && a.d >= 0) is_free = grid_free<LDSGRID>(grid, a, sx, sy);
+                unsigned long long mask = __ballot(is_free), accepted = 0ull;
+                int room = nfill - placed;
+                // rank order = lane order: the first free lane is accepted and blocks the later lanes near it
+                while (mask != 0ull && room > 0) {
+                    const int l = __ffsll((long long)mask) - 1;
+                    accepted |= 1ull << l;
+                    room--;
+                    mask &= ~(1ull << l);
+                    if (a.d >= 0) {
+                        const int ax = __builtin_amdgcn_readlane(sx, l), ay = __builtin_amdgcn_readlane(sy, l);
+                        mask &= ~__ballot(abs(sx - ax) <= a.d && abs(sy - ay) <= a.d);
                     }
                 }
-        }
-        unsigned long long mask = __ballot(is_free);
-        if (__ballot(!valid) != 0ull) keys_done = true;    // a zero key: everything after it is padding / rejected
-        while (mask != 0ull) {
-            // next slot to fill (selectGoodFeatures.py:109-112)
-            if (!a.overwrite_all)
-                while (indx < a.nfeat && a.fl[indx].val >= 0) indx++;
-            if (indx >= a.nfeat) { list_full = true; break; }
-            const int l = __ffsll((long long)mask) - 1;
-            const int ax = __shfl(x, l), ay = __shfl(y, l);
-            const float aval = __shfl(val, l);
-            if (lane == l) {
-                klt_feat ft;
-                ft.x = (float)ax;
-                ft.y = (float)ay;
-                ft.val = (int32_t)aval;        // int(val): truncation (selectGoodFeatures.py:119)
-                ft.aux = 0;
-                a.fl[indx] = ft;
-                if (a.d >= 0)
-                    __hip_atomic_store(&grid[(ay / a.cell) * a.gw + (ax / a.cell)], (((uint32_t)ax << 16) | (uint32_t)ay) + 1u,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((accepted >> lane) & 1ull) {
+                    const int rank = placed + __popcll(accepted & ((1ull << lane) - 1ull));
+                    const int slot = a.overwrite_all ? rank : a.slots[rank];
+                    klt_feat ft;
+                    ft.x = (float)sx;
+                    ft.y = (float)sy;
+                    ft.val = (int32_t)__uint_as_float((uint32_t)(k >> 32));      // int(val), selectGoodFeatures.py:119
+                    ft.aux = 0;
+                    a.fl[slot] = ft;
+                    if (a.d >= 0) {
+                        const uint32_t code = (((uint32_t)sx << 16) | (uint32_t)sy) + 1u;
+                        uint32_t *cellp = &grid[cell_of(sy, a) * a.gw + cell_of(sx, a)];
+                        if (LDSGRID) *cellp = code;
+                        else __hip_atomic_store(cellp, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                placed += __popcll(accepted);
+                if (placed >= nfill) list_full = true;                            // :112
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             }
-            indx++;
-            placed++;
-            mask &= ~(1ull << l);
-            // later candidates of this batch that the new feature blocks
-            const bool hit = a.d >= 0 && is_free && lane > l && abs(x - ax) <= a.d && abs(y - ay) <= a.d;
-            mask &= ~__ballot(hit);
+            if (lane == 0 && (list_full || ended)) s_stop = 1;
         }
-        __syncthreads();       // grid / feature-list writes visible to the next batch
+        __syncthreads();
+        if (s_stop) break;
     }
-    // candidates exhausted: selectGoodFeatures.py:78-94 (SELECTING_ALL only; see DESIGN.md for the deviation)
-    if (!list_full && a.overwrite_all) {
-        for (int i = indx + lane; i < a.nfeat; i += 64) {
-            klt_feat ft;
-            ft.x = -1.f;
-            ft.y = -1.f;
-            ft.val = KLT_NOT_FOUND;
-            ft.aux = 0;
-            a.fl[i] = ft;
+    // candidates exhausted: selectGoodFeatures.py:78-94 (SELECTING_ALL only; DESIGN.md lists the deviation)
+    if (wave == 0) {
+        if (!list_full && a.overwrite_all) {
+            for (int i = placed + lane; i < a.nfeat; i += 64) {
+                klt_feat ft;
+                ft.x = -1.f;
+                ft.y = -1.f;
+                ft.val = KLT_NOT_FOUND;
+                ft.aux = 0;
+                a.fl[i] = ft;
+            }
         }
+        if (lane == 0 && a.placed_out) *a.placed_out = placed;
     }
-    if (lane == 0 && a.placed_out) *a.placed_out = placed;
 }
 
 __global__ void unpack_candidates_kernel(const unsigned long long *__restrict__ keys, int n, float *__restrict__ val,
@@ -307,7 +419,7 @@ __global__ void unpack_candidates_kernel(const unsigned long long *__restrict__ 
 
 void launch_sat_rows(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows)
 {
-    hipLaunchKernelGGL(sat_rows_kernel, dim3((nrows + 63) / 64, 3), dim3(64), 0, s, gx, gy, sat, ncols, nrows);
+    hipLaunchKernelGGL(sat_rows_kernel, dim3((nrows + 63) / 64), dim3(256), 0, s, gx, gy, sat, ncols, nrows);
 }
 
 void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows)
@@ -339,12 +451,14 @@ void launch_sort_desc(hipStream_t s, unsigned long long *keys, int n)
 
 int launch_nms(hipStream_t s, const NmsArgs &a)
 {
-    size_t lds = a.grid_in_lds ? (size_t)a.gw * a.gh * sizeof(uint32_t) : 0;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (a.grid_in_lds) {
+        const size_t lds = (size_t)a.gw * a.gh * sizeof(uint32_t);
+        hipError_t e = hipFuncSetAttribute((const void *)nms_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nms_kernel<true>, dim3(1), dim3(NMS_T), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(nms_kernel<false>, dim3(1), dim3(NMS_T), 0, s, a);
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(64), lds, s, a);
     return 0;
 }
 

@@ -141,6 +141,20 @@ def test_generic_path_and_batched_build(ctx, ko, cfg1, img0, img1):
                 assert_same(ctx.download_level(slot, pi, l), cfg1["%s_%s_%d" % (name, w, l)], "batched %s %s %d" % (name, w, l))
 
 
+def test_one_sample_per_thread_variant(ctx, cfg1, img0):
+    """KLT_OPT_SMOOTH_GRAD_VARIANT=1: the non-register-blocked LDS kernels stay bit-identical too."""
+    ctx.configure(make_tc())
+    ctx.upload(0, img0)
+    try:
+        ctx.set_option(2, 1)
+        ctx.build_pyramids(0)
+        for l in range(2):
+            for pi, w in enumerate(("img", "gx", "gy")):
+                assert_same(ctx.download_level(0, pi, l), cfg1["p0_%s_%d" % (w, l)], "variant 1 %s %d" % (w, l))
+    finally:
+        ctx.set_option(2, 0)
+
+
 @pytest.mark.parametrize("window,levels,ss,shape", [(7, 3, 8, (700, 900)), (15, 3, 2, (301, 447)), (5, 2, 4, (64, 64)),
                                                     (7, 4, 2, (123, 77)), (7, 2, 8, (40, 50)), (9, 2, 4, (17, 333))])
 def test_pyramids_various_geometries_vs_oracle(ctx, ko, window, levels, ss, shape):
