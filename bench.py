@@ -97,7 +97,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("KLT_FORCE_DIST") == "1"    # the env var exercises the RCCL path on one GPU
 
     torch = dist = None
     if distributed:
@@ -236,10 +236,14 @@ def main():
                        "parallelism": "1 pair per GPU" + (", RCCL all-gather of feature records per step" if distributed else "")},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     ctx.close()
     if distributed:
-        dist.destroy_process_group()
+        dist.destroy_process_group()        # RCCL may write its own chatter to stdout while shutting down
+    if line is not None:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)  # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":

@@ -121,6 +121,10 @@ int klt_select(klt_ctx *ctx, int slot, int mode, int use_pyramid, klt_feat *inou
  * live feature, coarse to fine, one wavefront per feature.  Pyramids of both slots must be built. */
 int klt_track_async(klt_ctx *ctx, int slot1, int slot2, int fb_in, int fb_out, int n);
 int klt_track(klt_ctx *ctx, int slot1, int slot2, klt_feat *inout, int n, int *n_tracked);
+/* npairs independent frame pairs of equal size in ONE tracker launch (BASELINE cfg-4: a shard of the 256 pairs);
+ * pair i tracks feature buffer fb_in[i] (n records) from slot1[i] to slot2[i] into fb_out[i] */
+int klt_track_batch_async(klt_ctx *ctx, const int *slot1, const int *slot2, const int *fb_in, const int *fb_out,
+                          int npairs, int n);
 
 typedef struct {
     uint64_t features;                       /* live features entering the kernel */

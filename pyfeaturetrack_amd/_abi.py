@@ -67,6 +67,7 @@ SYMBOLS = {
     "klt_select": (_I, [_P, _I, _I, _I, _P, _I, _PI]),
     "klt_track_async": (_I, [_P, _I, _I, _I, _I, _I]),
     "klt_track": (_I, [_P, _I, _I, _P, _I, _PI]),
+    "klt_track_batch_async": (_I, [_P, _PI, _PI, _PI, _PI, _I, _I]),
     "klt_track_stats_reset": (_I, [_P]),
     "klt_track_stats_read": (_I, [_P, C.POINTER(KltTrackStats)]),
     "klt_level_dims": (_I, [_P, _I, _I, _PI, _PI]),

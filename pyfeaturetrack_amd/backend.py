@@ -169,6 +169,11 @@ class Context:
     def track_async(self, slot1, slot2, fb_in, fb_out, n):
         self._check(self._lib.klt_track_async(self._h, slot1, slot2, fb_in, fb_out, n))
 
+    def track_batch_async(self, pairs, n):
+        """pairs: [(slot1, slot2, fb_in, fb_out), ...] -- one tracker launch for all of them."""
+        cols = [(C.c_int * len(pairs))(*[p[k] for p in pairs]) for k in range(4)]
+        self._check(self._lib.klt_track_batch_async(self._h, cols[0], cols[1], cols[2], cols[3], len(pairs), n))
+
     def track_stats_reset(self):
         self._check(self._lib.klt_track_stats_reset(self._h))
 

@@ -64,6 +64,8 @@ struct klt_ctx {
     size_t grid_cap = 0;
     int *nms_slots = nullptr;
     size_t nms_slots_cap = 0;
+    TrackPairDesc *pair_table = nullptr;
+    size_t pair_table_cap = 0;
     int *placed_d = nullptr;
     const float *last_sel[3] = {nullptr, nullptr, nullptr};
     int sel_nc = 0, sel_nr = 0, sel_nx = 0, sel_ny = 0, sel_npow2 = 0;
@@ -487,7 +489,7 @@ void klt_destroy(klt_ctx *c)
     for (FeatBuf &b : c->fbs) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
-    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->placed_d); hipFree(c->stats_d);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -747,29 +749,9 @@ int klt_select(klt_ctx *c, int slot, int mode, int use_pyramid, klt_feat *inout,
 }
 
 // ----------------------------------------------------------------------------------------- tracking
-int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int n)
+static void fill_track_params(const klt_ctx *c, const Slot *s1, TrackArgs &a, int n)
 {
-    if (int rc = check_ready(c)) return rc;
-    if (n < 0) return fail(c, KLT_ERR_ARG, "negative feature count");
-    HIPCHK(c, hipSetDevice(c->device));
-    Slot *s1, *s2;
-    if (int rc = get_slot(c, slot1, &s1, false)) return rc;
-    if (int rc = get_slot(c, slot2, &s2, false)) return rc;
-    if (!s1->pyr_valid || !s2->pyr_valid) return fail(c, KLT_ERR_STATE, "pyramids of both slots must be built before tracking");
-    if (s1->nc != s2->nc || s1->nr != s2->nr || s1->nlev != s2->nlev || s1->ss != s2->ss)
-        return fail(c, KLT_ERR_ARG, "the two frames differ in size");            // trackFeatures.py:156-159, :217
-    if (fb_in < 0 || (size_t)fb_in >= c->fbs.size() || c->fbs[fb_in].cap < n) return fail(c, KLT_ERR_STATE, "input feature buffer not set");
-    FeatBuf *bo;
-    if (int rc = get_fb(c, fb_out, n > 0 ? n : 1, &bo)) return rc;
     const klt_params &p = c->p;
-    TrackArgs a;
-    std::memset(&a, 0, sizeof(a));
-    for (int l = 0; l < s1->nlev; l++) {
-        a.lv[l].i1 = s1->lv[l].img; a.lv[l].gx1 = s1->lv[l].gx; a.lv[l].gy1 = s1->lv[l].gy;
-        a.lv[l].i2 = s2->lv[l].img; a.lv[l].gx2 = s2->lv[l].gx; a.lv[l].gy2 = s2->lv[l].gy;
-        a.lv[l].nc = s1->lv[l].nc; a.lv[l].nr = s1->lv[l].nr;
-    }
-    a.in = c->fbs[fb_in].d; a.out = bo->d;
     a.half_window = p.window_width / 2.0;
     a.borderx = p.borderx; a.bordery = p.bordery;
     a.n = n; a.nlevels = s1->nlev; a.window = p.window_width; a.max_iterations = p.max_iterations;
@@ -777,12 +759,92 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
     a.small = p.min_determinant; a.th = p.min_displacement; a.step = p.step_factor; a.max_residue = p.max_residue;
     a.ss = (float)s1->ss;
     a.inv_ss = 1.0f / (float)s1->ss;
+}
+
+static int check_pair(klt_ctx *c, int slot1, int slot2, Slot **p1, Slot **p2)
+{
+    if (int rc = get_slot(c, slot1, p1, false)) return rc;
+    if (int rc = get_slot(c, slot2, p2, false)) return rc;
+    Slot *s1 = *p1, *s2 = *p2;
+    if (!s1->pyr_valid || !s2->pyr_valid) return fail(c, KLT_ERR_STATE, "pyramids of both slots must be built before tracking");
+    if (s1->nc != s2->nc || s1->nr != s2->nr || s1->nlev != s2->nlev || s1->ss != s2->ss)
+        return fail(c, KLT_ERR_ARG, "the two frames differ in size");            // trackFeatures.py:156-159, :217
+    return 0;
+}
+
+static void fill_levels(const Slot *s1, const Slot *s2, TrackLevel *lv)
+{
+    for (int l = 0; l < s1->nlev; l++) {
+        lv[l].i1 = s1->lv[l].img; lv[l].gx1 = s1->lv[l].gx; lv[l].gy1 = s1->lv[l].gy;
+        lv[l].i2 = s2->lv[l].img; lv[l].gx2 = s2->lv[l].gx; lv[l].gy2 = s2->lv[l].gy;
+        lv[l].nc = s1->lv[l].nc; lv[l].nr = s1->lv[l].nr;
+    }
+}
+
+int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int n)
+{
+    if (int rc = check_ready(c)) return rc;
+    if (n < 0) return fail(c, KLT_ERR_ARG, "negative feature count");
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot *s1, *s2;
+    if (int rc = check_pair(c, slot1, slot2, &s1, &s2)) return rc;
+    if (fb_in < 0 || (size_t)fb_in >= c->fbs.size() || c->fbs[fb_in].cap < n) return fail(c, KLT_ERR_STATE, "input feature buffer not set");
+    FeatBuf *bo;
+    if (int rc = get_fb(c, fb_out, n > 0 ? n : 1, &bo)) return rc;
+    TrackArgs a;
+    std::memset(&a, 0, sizeof(a));
+    fill_levels(s1, s2, a.lv);
+    a.in = c->fbs[fb_in].d; a.out = bo->d;
+    fill_track_params(c, s1, a, n);
     {
-        const double foot = 12.0 * (p.window_width + 1) * (p.window_width + 1);
+        const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
         TimerScope t(c, F_TRACK, (double)n * (foot * 2 * s1->nlev + 32));      // refined by the caller from klt_track_stats
         if (launch_track(c->stream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
     }
     if (c->collect_stats) launch_track_stats(c->stream, a.in, a.out, n, s1->nlev, c->stats_d);
+    HIPCHK(c, hipGetLastError());
+    return KLT_OK;
+}
+
+int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const int *fb_in, const int *fb_out, int npairs, int n)
+{
+    if (int rc = check_ready(c)) return rc;
+    if (!slot1 || !slot2 || !fb_in || !fb_out || npairs <= 0 || npairs > 65535 || n < 0) return fail(c, KLT_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<TrackPairDesc> table((size_t)npairs);
+    Slot *first = nullptr;
+    for (int i = 0; i < npairs; i++) {
+        FeatBuf *bo;                      // may grow c->fbs: do it before taking pointers into it
+        if (int rc = get_fb(c, fb_out[i], n > 0 ? n : 1, &bo)) return rc;
+    }
+    for (int i = 0; i < npairs; i++) {
+        Slot *s1, *s2;
+        if (int rc = check_pair(c, slot1[i], slot2[i], &s1, &s2)) return rc;
+        if (!first) first = s1;
+        if (s1->nc != first->nc || s1->nr != first->nr || s1->nlev != first->nlev)
+            return fail(c, KLT_ERR_ARG, "all pairs of a batch must have the same frame size");
+        if (fb_in[i] < 0 || (size_t)fb_in[i] >= c->fbs.size() || c->fbs[fb_in[i]].cap < n)
+            return fail(c, KLT_ERR_STATE, "input feature buffer not set");
+        std::memset(&table[i], 0, sizeof(TrackPairDesc));
+        fill_levels(s1, s2, table[i].lv);
+        table[i].in = c->fbs[fb_in[i]].d;
+        table[i].out = c->fbs[fb_out[i]].d;
+    }
+    if (int rc = ensure(c, c->pair_table, c->pair_table_cap, (size_t)npairs)) return rc;
+    // pageable source: the runtime stages it before returning; stream order protects the previous launch's table
+    HIPCHK(c, hipMemcpyAsync(c->pair_table, table.data(), (size_t)npairs * sizeof(TrackPairDesc), hipMemcpyHostToDevice, c->stream));
+    TrackArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.pairs = c->pair_table;
+    a.npairs = npairs;
+    fill_track_params(c, first, a, n);
+    {
+        const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
+        TimerScope t(c, F_TRACK, (double)npairs * n * (foot * 2 * first->nlev + 32));
+        if (launch_track(c->stream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
+    }
+    if (c->collect_stats)
+        for (int i = 0; i < npairs; i++) launch_track_stats(c->stream, table[i].in, table[i].out, n, first->nlev, c->stats_d);
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }

@@ -35,10 +35,19 @@ struct TrackLevel {
     int nc, nr;
 };
 
-struct TrackArgs {
+// one frame pair of a batched tracker launch (table in device memory, indexed by blockIdx.y)
+struct TrackPairDesc {
     TrackLevel lv[KLT_MAX_LEVELS];
     const klt_feat *in;
     klt_feat *out;
+};
+
+struct TrackArgs {
+    TrackLevel lv[KLT_MAX_LEVELS];      // single-pair launch: levels travel in the kernarg segment
+    const klt_feat *in;
+    klt_feat *out;
+    const TrackPairDesc *pairs;         // batched launch: npairs descriptors (lv / in / out above unused)
+    int npairs;
     double half_window;          // window/2 as the Python float (3.5 for 7x7), trackFeatures.py:88-89
     double borderx, bordery;
     int n, nlevels, window, max_iterations, use_max_residue, retain, ncols, nrows;

@@ -214,16 +214,19 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
     return KLT_TRACKED;
 }
 
-template <int MAXK, int WCT>
+template <int MAXK, int WCT, bool BATCH>
 __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
     if (f >= a.n) return;
-    const klt_feat ft = a.in[f];
+    const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
+    const klt_feat *fin = BATCH ? a.pairs[blockIdx.y].in : a.in;
+    klt_feat *fout = BATCH ? a.pairs[blockIdx.y].out : a.out;
+    const klt_feat ft = fin[f];
     if (ft.val < 0) {                       // only live features are tracked, trackFeatures.py:253
-        if (lane == 0) a.out[f] = ft;
+        if (lane == 0) fout[f] = ft;
         return;
     }
     const int L = a.nlevels;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     for (int r = L - 1; r >= 0; r--) {
         xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss;
         int it = 0;
-        val = track_level<MAXK, WCT>(a, a.lv[r], xloc, yloc, xout, yout, lds, lane, it);
+        val = track_level<MAXK, WCT>(a, levels[r], xloc, yloc, xout, yout, lds, lane, it);
         aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);      // visited level r with `it` Newton iterations
         if (val == KLT_SMALL_DET || val == KLT_OOB) break;             // :284-285
     }
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
         else if (val == KLT_SMALL_DET || val == KLT_LARGE_RESIDUE || val == KLT_MAX_ITERATIONS) {
             o.x = -1.f; o.y = -1.f; o.val = val;
         } else { o.x = xout; o.y = yout; o.val = KLT_TRACKED; }
-        a.out[f] = o;
+        fout[f] = o;
     }
 }
 
@@ -288,19 +291,26 @@ void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, 
     hipLaunchKernelGGL(track_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, nlevels, stats);
 }
 
+template <bool BATCH>
+static int launch_track_t(hipStream_t s, const TrackArgs &a)
+{
+    const int n = a.window * a.window;
+    const size_t lds = 5 * (size_t)((n + 3) & ~3) * sizeof(float);
+    const dim3 grid(a.n, BATCH ? a.npairs : 1), block(64);
+    if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH>), grid, block, lds, s, a);
+    else if (a.window == 15) hipLaunchKernelGGL((track_kernel<4, 15, BATCH>), grid, block, lds, s, a);
+    else if (n <= 64) hipLaunchKernelGGL((track_kernel<1, 0, BATCH>), grid, block, lds, s, a);
+    else if (n <= 128) hipLaunchKernelGGL((track_kernel<2, 0, BATCH>), grid, block, lds, s, a);
+    else if (n <= 256) hipLaunchKernelGGL((track_kernel<4, 0, BATCH>), grid, block, lds, s, a);
+    else if (n <= 512) hipLaunchKernelGGL((track_kernel<8, 0, BATCH>), grid, block, lds, s, a);
+    else if (n <= 1024) hipLaunchKernelGGL((track_kernel<16, 0, BATCH>), grid, block, lds, s, a);
+    else return -1;
+    return 0;
+}
+
 int launch_track(hipStream_t s, const TrackArgs &a)
 {
     if (a.n <= 0) return 0;
-    const int n = a.window * a.window;
-    const size_t lds = 5 * (size_t)((n + 3) & ~3) * sizeof(float);
-    const dim3 grid(a.n), block(64);
-    if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7>), grid, block, lds, s, a);
-    else if (a.window == 15) hipLaunchKernelGGL((track_kernel<4, 15>), grid, block, lds, s, a);
-    else if (n <= 64) hipLaunchKernelGGL((track_kernel<1, 0>), grid, block, lds, s, a);
-    else if (n <= 128) hipLaunchKernelGGL((track_kernel<2, 0>), grid, block, lds, s, a);
-    else if (n <= 256) hipLaunchKernelGGL((track_kernel<4, 0>), grid, block, lds, s, a);
-    else if (n <= 512) hipLaunchKernelGGL((track_kernel<8, 0>), grid, block, lds, s, a);
-    else if (n <= 1024) hipLaunchKernelGGL((track_kernel<16, 0>), grid, block, lds, s, a);
-    else return -1;
-    return 0;
+    if (a.pairs) return a.npairs > 0 ? launch_track_t<true>(s, a) : 0;
+    return launch_track_t<false>(s, a);
 }

@@ -385,6 +385,103 @@ def test_cfg2_1080p_vs_oracle_and_known_shift(ctx, ko):
     assert abs(dx - 3.3) < 0.02 and abs(dy + 2.1) < 0.02, (dx, dy)
 
 
+def test_cfg3_shape_15x15_4_levels_translation(ctx, ko):
+    """BASELINE cfg-3 geometry (1920x1080, 15x15 window, 4 levels / ss 2, border 108), translation part only:
+    the affine consistency check has no reference implementation to compare with."""
+    from pyfeaturetrack_amd import synth
+    f0, f1 = synth.synth_pair(1920, 1080, 3)
+    tc = make_tc(levels=4, ss=2, window=15, max_residue=10.0)
+    assert tc.borderx == 108.0
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(0, f0)
+    ctx.upload(1, f1)
+    ctx.build_pyramids_batch([0, 1])
+    fl, placed = ctx.select(0, 5000, use_pyramid=True)
+    ofl = ko.select_good_features(p, f0.astype(np.float32), 5000)
+    assert_feats(fl, *oracle_feats(ofl), what="cfg-3 select")
+    out, _ = ctx.track(0, 1, fl)
+    ko.track_features(p, ko.Pyramids(p, f0.astype(np.float32)), ko.Pyramids(p, f1.astype(np.float32)), ofl)
+    assert_feats(out, *oracle_feats(ofl), what="cfg-3 track (translation)")
+    assert (out["val"] == 0).sum() > 4500
+
+
+def test_cfg4_shape_batched_pairs(ctx, ko):
+    """BASELINE cfg-4 geometry (1280x720 pairs, 2000 features, 7x7, 3 levels / ss 4): a shard of 6 pairs goes through
+    one batched pyramid build and ONE tracker launch; every pair equals the oracle."""
+    from pyfeaturetrack_amd import synth
+    NP, NF = 6, 2000
+    tc = make_tc(levels=3, ss=4)
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    frames = [synth.synth_pair(1280, 720, seed) for seed in range(NP)]
+    for i, (a, b) in enumerate(frames):
+        ctx.upload(2 * i, a)
+        ctx.upload(2 * i + 1, b)
+    ctx.build_pyramids_batch(list(range(2 * NP)))
+    for i in range(NP):
+        ctx.select_async(2 * i, 1, True, 2 * i, NF)              # feature buffer 2i <- selection on frame 0 of pair i
+    ctx.track_batch_async([(2 * i, 2 * i + 1, 2 * i, 2 * i + 1) for i in range(NP)], NF)
+    for i, (a, b) in enumerate(frames):
+        sel = ctx.featbuf_download(2 * i, NF)
+        out = ctx.featbuf_download(2 * i + 1, NF)
+        ofl = ko.select_good_features(p, a.astype(np.float32), NF)
+        assert_feats(sel, *oracle_feats(ofl), what="cfg-4 pair %d select" % i)
+        ko.track_features(p, ko.Pyramids(p, a.astype(np.float32)), ko.Pyramids(p, b.astype(np.float32)), ofl)
+        assert_feats(out, *oracle_feats(ofl), what="cfg-4 pair %d track" % i)
+
+
+def test_cfg5_shape_4k_sequence_with_replacement(ctx, ko):
+    """BASELINE cfg-5 geometry (3840x2160, 20000 features, sequential mode, lost features replaced after every
+    frame), three frames.  Pinned at the level the reference implements: tracking + _enforceMinimumDistance in
+    REPLACING_SOME mode on the level-0 images kept from the last track (selectGoodFeatures.py:176-181)."""
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.backend import REPLACING_SOME
+    W, H, NF = 3840, 2160, 20000
+    base = synth.synth_base(W, H, 4)
+    frames = [synth.synth_frame(W, H, 4, k, base=base) for k in range(3)]
+    tc = make_tc(levels=3, ss=4, max_residue=10.0)
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(0, frames[0])
+    ctx.build_pyramids(0)
+    fl, placed = ctx.select(0, NF, use_pyramid=True)
+    ofl = ko.select_good_features(p, frames[0].astype(np.float32), NF)
+    assert placed == NF
+    assert_feats(fl, *oracle_feats(ofl), what="cfg-5 initial select")
+    P_prev = ko.Pyramids(p, frames[0].astype(np.float32))
+    for k in (1, 2):
+        ctx.upload(1, frames[k])
+        ctx.build_pyramids(1)
+        fl, _ = ctx.track(0, 1, fl)
+        ctx.swap_slots(0, 1)                                       # sequential mode
+        P_cur = ko.Pyramids(p, frames[k].astype(np.float32))
+        ko.track_features(p, P_prev, P_cur, ofl)
+        assert_feats(fl, *oracle_feats(ofl), what="cfg-5 track into frame %d" % k)
+        lost = int(np.count_nonzero(fl["val"] < 0))
+        fl, replaced = ctx.select(0, NF, mode=REPLACING_SOME, fl=fl, use_pyramid=True)
+        ofl = ko.select_good_features(p, frames[k].astype(np.float32), NF, mode=2, fl=ofl)
+        assert replaced == lost
+        assert_feats(fl, *oracle_feats(ofl), what="cfg-5 replace after frame %d" % k)
+        P_prev = P_cur
+
+
+def test_rccl_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 code path (process group, zero-copy tensor view of the feature buffer, RCCL all-gather on the
+    tracker's stream) with a single rank."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, KLT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["tracked"] > 4500
+
+
 def test_nms_global_grid_path(ctx, ko):
     """mindist 2 at 1920x1080 -> the cell grid (960x540 u32) exceeds LDS and lives in global memory"""
     from pyfeaturetrack_amd import synth
