@@ -106,6 +106,11 @@ int klt_swap_slots(klt_ctx *ctx, int a, int b);
 /* ---- feature buffers ----------------------------------------------------------------------- */
 int   klt_featbuf_upload(klt_ctx *ctx, int fb, const klt_feat *src, int n);
 int   klt_featbuf_download(klt_ctx *ctx, int fb, klt_feat *dst, int n);
+int   klt_featbuf_alloc(klt_ctx *ctx, int fb, int n);         /* n records, all marked lost (val = -1) */
+/* fb_view becomes a window [offset, offset+n) of fb_parent (a device-side [frames x features] table, cf. the
+ * KLT_FeatureTable stub at klt.py:278-283, can then be gathered with one collective).  The parent must outlive the
+ * view and must not be resized while it exists. */
+int   klt_featbuf_view(klt_ctx *ctx, int fb_view, int fb_parent, int offset, int n);
 void *klt_featbuf_devptr(klt_ctx *ctx, int fb);             /* device address (for RCCL gathers); NULL if unset */
 
 /* ---- selection: _KLTSelectGoodFeatures, selectGoodFeatures.py:141-261 ---------------------- */

@@ -62,6 +62,8 @@ SYMBOLS = {
     "klt_swap_slots": (_I, [_P, _I, _I]),
     "klt_featbuf_upload": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_download": (_I, [_P, _I, _P, _I]),
+    "klt_featbuf_alloc": (_I, [_P, _I, _I]),
+    "klt_featbuf_view": (_I, [_P, _I, _I, _I, _I]),
     "klt_featbuf_devptr": (_P, [_P, _I]),
     "klt_select_async": (_I, [_P, _I, _I, _I, _I, _I]),
     "klt_select": (_I, [_P, _I, _I, _I, _P, _I, _PI]),

@@ -124,6 +124,12 @@ class Context:
         self._check(self._lib.klt_featbuf_download(self._h, fb, out.ctypes.data, n))
         return out
 
+    def featbuf_alloc(self, fb, n):
+        self._check(self._lib.klt_featbuf_alloc(self._h, fb, n))
+
+    def featbuf_view(self, fb_view, fb_parent, offset, n):
+        self._check(self._lib.klt_featbuf_view(self._h, fb_view, fb_parent, offset, n))
+
     def featbuf_devptr(self, fb):
         return self._lib.klt_featbuf_devptr(self._h, fb)
 

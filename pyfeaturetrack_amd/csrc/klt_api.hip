@@ -33,7 +33,7 @@ struct Slot {
     bool pyr_valid = false;
 };
 
-struct FeatBuf { klt_feat *d = nullptr; int cap = 0; };
+struct FeatBuf { klt_feat *d = nullptr; int cap = 0; bool view = false; };
 
 struct Timed { int fam; hipEvent_t a, b; double bytes; };
 
@@ -171,6 +171,7 @@ int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
     if (fb < 0 || fb > 65535) return fail(c, KLT_ERR_ARG, "feature buffer index out of range");
     if ((size_t)fb >= c->fbs.size()) c->fbs.resize(fb + 1);
     FeatBuf &b = c->fbs[fb];
+    if (n > b.cap && b.view) return fail(c, KLT_ERR_ARG, "feature buffer is a view and too small");
     if (n > b.cap) {
         klt_feat *nd = nullptr;
         HIPCHK(c, hipMalloc((void **)&nd, (size_t)n * sizeof(klt_feat)));
@@ -486,7 +487,8 @@ void klt_destroy(klt_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.f32); hipFree(s.planes); }
-    for (FeatBuf &b : c->fbs) hipFree(b.d);
+    for (FeatBuf &b : c->fbs)
+        if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
     hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->placed_d); hipFree(c->stats_d);
@@ -597,6 +599,31 @@ int klt_featbuf_download(klt_ctx *c, int fb, klt_feat *dst, int n)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst, c->fbs[fb].d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KLT_OK;
+}
+
+int klt_featbuf_alloc(klt_ctx *c, int fb, int n)
+{
+    if (!c || n <= 0) return fail(c, KLT_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    FeatBuf *b;
+    if (int rc = get_fb(c, fb, n, &b)) return rc;
+    HIPCHK(c, hipMemsetAsync(b->d, 0xff, (size_t)n * sizeof(klt_feat), c->stream));     // val = -1 everywhere
+    return KLT_OK;
+}
+
+int klt_featbuf_view(klt_ctx *c, int fb_view, int fb_parent, int offset, int n)
+{
+    if (!c || offset < 0 || n <= 0 || fb_view == fb_parent) return fail(c, KLT_ERR_ARG, "bad argument");
+    if (fb_parent < 0 || (size_t)fb_parent >= c->fbs.size() || c->fbs[fb_parent].cap < offset + n || c->fbs[fb_parent].view)
+        return fail(c, KLT_ERR_STATE, "parent feature buffer too small (or itself a view)");
+    if (fb_view < 0 || fb_view > 65535) return fail(c, KLT_ERR_ARG, "feature buffer index out of range");
+    if ((size_t)fb_view >= c->fbs.size()) c->fbs.resize(fb_view + 1);
+    FeatBuf &v = c->fbs[fb_view];
+    if (v.d && !v.view) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(v.d); }
+    v.d = c->fbs[fb_parent].d + offset;
+    v.cap = n;
+    v.view = true;
     return KLT_OK;
 }
 

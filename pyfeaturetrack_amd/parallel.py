@@ -27,31 +27,49 @@ class _DeviceArray:
 
 
 class FeatureGather:
-    """All-gather of device-resident feature buffers, ordered on the context's own HIP stream.
+    """All-gather of device-resident feature buffers, overlapped with the next step's kernels.
 
-    The collective is enqueued with the tracker's stream made current, so it starts when the tracker
-    kernel that produced the buffer has finished and needs no host synchronisation."""
+    The collective runs on a side stream that waits (event) for the tracker launch that produced the buffer; the
+    tracker's own stream never waits for RCCL, except that a buffer is not overwritten before the gather that reads
+    it has finished (`wait_free`).  No host synchronisation anywhere."""
 
     def __init__(self, ctx, fbs, n, world, torch, dist):
+        """fbs: feature buffers of n records each (n may be frames * features of a device-side table)."""
         self.torch, self.dist, self.n, self.world = torch, dist, n, world
         dev = torch.device("cuda", ctx.device)
-        self.stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
-        self.views = {}
+        self.stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)     # the context's own HIP stream
+        self.side = torch.cuda.Stream(device=dev)
+        self.views, self.outs, self.ready, self.done = {}, {}, {}, {}
         for fb in fbs:
             ptr = ctx.featbuf_devptr(fb)
             if not ptr:
                 raise ValueError("feature buffer %d is not allocated" % fb)
             self.views[fb] = torch.as_tensor(_DeviceArray(ptr, (n, 4), "<i4"), device=dev)
-        self.out = torch.empty((world, n, 4), dtype=torch.int32, device=dev)
+            self.outs[fb] = torch.empty((world, n, 4), dtype=torch.int32, device=dev)
+            self.ready[fb] = torch.cuda.Event()
+            self.done[fb] = None
+        self.last = None
+
+    def wait_free(self, fb):
+        """Call before enqueueing work that overwrites buffer `fb`."""
+        if self.done[fb] is not None:
+            self.stream.wait_event(self.done[fb])
 
     def all_gather(self, fb):
-        with self.torch.cuda.stream(self.stream):
-            self.dist.all_gather_into_tensor(self.out, self.views[fb])
+        """Call right after enqueueing the tracker launch that fills buffer `fb`."""
+        self.ready[fb].record(self.stream)
+        self.side.wait_event(self.ready[fb])
+        with self.torch.cuda.stream(self.side):
+            self.dist.all_gather_into_tensor(self.outs[fb], self.views[fb])
+            ev = self.torch.cuda.Event()
+            ev.record(self.side)
+        self.done[fb] = ev
+        self.last = fb
 
     def result(self):
-        """[world, n] structured records on the host (synchronises)."""
-        self.stream.synchronize()
-        return self.out.cpu().numpy().view(FEAT_DTYPE).reshape(self.world, self.n)
+        """[world, n] structured records of the most recent gather, on the host (synchronises)."""
+        self.side.synchronize()
+        return self.outs[self.last].cpu().numpy().view(FEAT_DTYPE).reshape(self.world, self.n)
 
 
 def gather_records_host(local, world, torch, dist, dst=0):

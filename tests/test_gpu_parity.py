@@ -494,6 +494,54 @@ def test_nms_global_grid_path(ctx, ko):
     assert_feats(fl, *oracle_feats(ofl), what="select mindist=2 (global grid)")
 
 
+def test_abi_error_reporting(ctx, img0):
+    """Errors come back as negative status codes with a message; nothing exits or throws across the ABI."""
+    from pyfeaturetrack_amd.backend import Context, KltBackendError, FEAT_DTYPE
+    c = Context(0)
+    try:
+        with pytest.raises(KltBackendError, match="klt_set_params"):
+            c.upload(0, img0)
+            c.build_pyramids(0)                              # parameters never set
+        c.configure(make_tc())
+        c.upload(0, img0)
+        c.upload(1, img0[:100, :200].copy())
+        c.build_pyramids_batch([0, 1], sync=True)            # different sizes: two launch groups, fine
+        fl = np.zeros(10, FEAT_DTYPE)
+        with pytest.raises(KltBackendError, match="differ in size"):
+            c.track(0, 1, fl)
+        with pytest.raises(KltBackendError, match="no frame"):
+            c.build_pyramids(7)
+        c.upload(2, img0)
+        with pytest.raises(KltBackendError, match="pyramids"):
+            c.track(0, 2, fl)                                # slot 2 has a frame but no pyramids
+        p = params_from_tc(make_tc())
+        p.window_width = p.window_height = 8
+        with pytest.raises(KltBackendError, match="window"):
+            c.set_params(p)
+        with pytest.raises(KltBackendError, match="image too small"):
+            c.configure(make_tc(levels=4, ss=8))
+            c.upload(3, img0[:40, :40].copy())
+            c.build_pyramids(3)
+    finally:
+        c.close()
+
+
+def test_feature_table_views(ctx, cfg1, img0, img1):
+    """klt_featbuf_view: tracker output written into a window of a larger device-side record table"""
+    ctx.configure(make_tc(max_residue=10.0))
+    ctx.upload(0, img0)
+    ctx.upload(1, img1)
+    ctx.build_pyramids_batch([0, 1])
+    fl, _ = ctx.select(0, 100, use_pyramid=True)
+    ctx.featbuf_upload(40, fl)
+    ctx.featbuf_alloc(41, 300)
+    ctx.featbuf_view(42, 41, 100, 100)
+    ctx.track_async(0, 1, 40, 42, 100)
+    table = ctx.featbuf_download(41, 300)
+    assert np.all(table["val"][:100] == -1) and np.all(table["val"][200:] == -1)
+    assert_feats(table[100:200], cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "track into a table view")
+
+
 # ------------------------------------------------------------------------------- Python API
 def test_python_api_example1_flow(cfg1, golden_dir, tmp_path, capsys):
     """The reference's example1.py call sequence through the reference-shaped API (PIL images)."""
