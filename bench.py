@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="KLT_OPT_TRACK_STREAM: tracker on a second HIP stream, overlapping the next step's pyramid build "
+                         "(measured slower on MI355X for this step size: event cost > overlap gain; DESIGN.md)")
     args = ap.parse_args()
 
     # stdout must carry exactly one JSON line.  RCCL / the HIP runtime print their own chatter to fd 1 (also at
@@ -120,8 +123,13 @@ def main():
     ctx = Context(local_rank)
     ctx.set_params(p)
     f0, f1 = synth.synth_pair(WIDTH, HEIGHT, seed=rank + 1)
-    ctx.upload(0, f0)
-    ctx.upload(1, f1)
+    # The pair lives in two slot pairs, (0,1) and (2,3), used by alternate steps: with KLT_OPT_TRACK_STREAM the tracker
+    # of step i (its own HIP stream) overlaps the pyramid build of step i+1, which must not overwrite what it reads.
+    for s0 in (0, 2):
+        ctx.upload(s0, f0)
+        ctx.upload(s0 + 1, f1)
+    if args.pipeline:
+        ctx.set_option(3, 1)
     ctx.build_pyramids(0)
     fl, placed = ctx.select(0, NFEAT, use_pyramid=True)
     assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)
@@ -142,15 +150,16 @@ def main():
         gather = FeatureGather(ctx, [FB_RING0, FB_RING1], GATHER_EVERY * NFEAT, world, torch, dist)
 
     def step(i, last=False):
-        ctx.build_pyramids_batch([0, 1])          # both frames share every launch
+        a = 0 if i % 2 == 0 else 2
+        ctx.build_pyramids_batch([a, a + 1])      # both frames share every launch
         if gather is None:
-            ctx.track_async(0, 1, FB_SEL, FB_OUT0 if i % 2 == 0 else FB_OUT1, NFEAT)
+            ctx.track_async(a, a + 1, FB_SEL, FB_OUT0 if i % 2 == 0 else FB_OUT1, NFEAT)
             return
         t, k = (i // GATHER_EVERY) % 2, i % GATHER_EVERY
         ring = FB_RING0 if t == 0 else FB_RING1
         if k == 0:
             gather.wait_free(ring)          # the collective that read this table two rounds ago has finished
-        ctx.track_async(0, 1, FB_SEL, FB_VIEW0 + t * GATHER_EVERY + k, NFEAT)
+        ctx.track_async(a, a + 1, FB_SEL, FB_VIEW0 + t * GATHER_EVERY + k, NFEAT)
         if k == GATHER_EVERY - 1 or last:
             gather.all_gather(ring)         # RCCL on a side stream, behind this tracker launch (event)
 
@@ -194,8 +203,9 @@ def main():
         ctx.track_stats_reset()
         ctx.timing_enable(True)
         for i in range(args.steps):
-            ctx.build_pyramids_batch([0, 1])
-            ctx.track_async(0, 1, FB_SEL, FB_OUT0, NFEAT)
+            a = 0 if i % 2 == 0 else 2
+            ctx.build_pyramids_batch([a, a + 1])
+            ctx.track_async(a, a + 1, FB_SEL, FB_OUT0, NFEAT)
         kernels = ctx.timing_read()
         ctx.timing_enable(False)
         st = ctx.track_stats()
@@ -236,6 +246,12 @@ def main():
         ctx.sync()
         ms_select = (time.perf_counter() - t) / reps * 1e3
         t = time.perf_counter()
+        for _ in range(reps):                                  # un-pipelined latency of one pair
+            ctx.build_pyramids_batch([0, 1])
+            ctx.track_async(0, 1, FB_SEL, FB_OUT0, NFEAT)
+            ctx.sync()
+        ms_latency = (time.perf_counter() - t) / reps * 1e3
+        t = time.perf_counter()
         for _ in range(reps):
             ctx.upload(0, f0)
             ctx.upload(1, f1)
@@ -243,7 +259,8 @@ def main():
             ctx.track_async(0, 1, FB_SEL, FB_OUT0, NFEAT)
             ctx.featbuf_download(FB_OUT0, NFEAT)
         ms_pcie = (time.perf_counter() - t) / reps * 1e3
-        extra = {"host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "ms_per_select_5000": ms_select,
+        extra = {"host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "latency_ms_per_pair_synchronised": ms_latency,
+                 "ms_per_select_5000": ms_select,
                  "pcie_inclusive_ms_per_pair": ms_pcie, "pcie_inclusive_features_per_s": NFEAT / (ms_pcie * 1e-3),
                  "note": "pcie_inclusive = H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the records"}
 
@@ -260,6 +277,8 @@ def main():
             "dtype": "f32 (convolutions accumulate in f64)", "data": "synthetic",
             "config": {"workload": "cfg-2: one 1920x1080 synthetic pair per GPU, 5000 features, 7x7 window, "
                                    "3 pyramid levels (subsampling 4), translation only; inputs resident in HBM",
+                       "pipelining": "none (one HIP stream)" if not args.pipeline else
+                                     "tracker of step i on its own HIP stream overlaps the pyramid build of step i+1 (double-buffered slots)",
                        "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
                        "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
                        "parallelism": "1 pair per GPU" + (", RCCL all-gather of the [%d steps x 5000] record table every %d steps" % (GATHER_EVERY, GATHER_EVERY) if distributed else "")},

@@ -75,11 +75,16 @@ int         klt_create(int device, klt_ctx **out);          /* replaces KLT_Trac
 void        klt_destroy(klt_ctx *ctx);
 const char *klt_last_error(klt_ctx *ctx);                   /* ctx may be NULL: error of the last failed klt_create */
 int         klt_sync(klt_ctx *ctx);                         /* wait for everything enqueued on the context's stream */
+void       *klt_track_stream_handle(klt_ctx *ctx);          /* stream of the tracker launches (== klt_stream_handle unless KLT_OPT_TRACK_STREAM) */
 void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hipStream_t, for callers that order RCCL collectives after it */
 
 /* ---- options ------------------------------------------------------------------------------ */
 #define KLT_OPT_FUSED_KERNELS 1   /* 1 (default): LDS-tiled fused pyramid kernels; 0: generic two-pass kernels (any tap count) */
 #define KLT_OPT_SMOOTH_GRAD_VARIANT 2   /* 0 (default): register-blocked level-0 kernel; 1: one sample per thread (process-wide) */
+/* 1: tracker launches go to a second HIP stream and overlap the pyramid build of the following frames; ordering is
+ * kept with events (a slot is not overwritten before the tracker launches that read it have finished, feature-buffer
+ * consumers wait for the last tracker launch).  0 (default): one stream. */
+#define KLT_OPT_TRACK_STREAM 3
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
 /* ---- parameters and taps ------------------------------------------------------------------- */

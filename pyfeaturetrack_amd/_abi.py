@@ -51,6 +51,7 @@ SYMBOLS = {
     "klt_last_error": (C.c_char_p, [_P]),
     "klt_sync": (_I, [_P]),
     "klt_stream_handle": (_P, [_P]),
+    "klt_track_stream_handle": (_P, [_P]),
     "klt_set_params": (_I, [_P, C.POINTER(KltParams)]),
     "klt_set_kernels": (_I, [_P, _I, C.POINTER(C.c_double), _I, C.POINTER(C.c_double), _I]),
     "klt_upload_u8": (_I, [_P, _I, _P, _I, _I, _I]),

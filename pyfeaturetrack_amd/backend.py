@@ -59,6 +59,9 @@ class Context:
     def stream_handle(self):
         return self._lib.klt_stream_handle(self._h)
 
+    def track_stream_handle(self):
+        return self._lib.klt_track_stream_handle(self._h)
+
     # ---------------------------------------------------------------- parameters
     def set_params(self, p):
         """p: KltParams.  Taps for the three sigmas are generated on the host (convolve.py:27-93)."""

@@ -31,6 +31,8 @@ struct Slot {
     Level lv[KLT_MAX_LEVELS];
     int nlev = 0, ss = 0;
     bool pyr_valid = false;
+    hipEvent_t ev_read = nullptr;     // last tracker launch that read this slot (track-stream mode)
+    bool ev_read_valid = false;
 };
 
 struct FeatBuf { klt_feat *d = nullptr; int cap = 0; bool view = false; };
@@ -43,7 +45,12 @@ std::string g_create_error;
 
 struct klt_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // uploads, pyramid build, selection
+    hipStream_t tstream = nullptr;    // tracker launches when KLT_OPT_TRACK_STREAM is on (else == stream)
+    bool track_stream_on = false;
+    hipEvent_t ev_pyr = nullptr;      // "everything enqueued on `stream` so far" marker the tracker waits for
+    hipEvent_t ev_track = nullptr;    // last tracker launch (feature-buffer consumers on `stream` wait for it)
+    bool ev_track_valid = false;
     std::string err;
     klt_params p{};
     bool have_params = false;
@@ -99,7 +106,8 @@ struct TimerScope {
     klt_ctx *c;
     Timed t;
     bool on;
-    TimerScope(klt_ctx *c_, int fam, double bytes) : c(c_), on(c_->timing)
+    hipStream_t st;
+    TimerScope(klt_ctx *c_, int fam, double bytes, hipStream_t st_ = nullptr) : c(c_), on(c_->timing), st(st_ ? st_ : c_->stream)
     {
         if (!on) return;
         t.fam = fam;
@@ -108,12 +116,12 @@ struct TimerScope {
             if (!c->pool.empty()) { *e = c->pool.back(); c->pool.pop_back(); }
             else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
         }
-        hipEventRecord(t.a, c->stream);
+        hipEventRecord(t.a, st);
     }
     ~TimerScope()
     {
         if (!on) return;
-        hipEventRecord(t.b, c->stream);
+        hipEventRecord(t.b, st);
         c->pending.push_back(t);
     }
 };
@@ -122,6 +130,7 @@ int drain_timers(klt_ctx *c)
 {
     if (c->pending.empty()) return 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
     for (Timed &t : c->pending) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, t.a, t.b);
@@ -187,6 +196,43 @@ int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
     return 0;
 }
 
+// ---- two-stream ordering (KLT_OPT_TRACK_STREAM): the tracker runs on its own stream so that it can overlap the
+// pyramid build of the next frames.  `stream` work that overwrites a slot waits for the last tracker launch that read
+// it; `stream` work that touches feature buffers waits for the last tracker launch.
+int wait_slot_readers(klt_ctx *c, Slot *s)
+{
+    if (c->track_stream_on && s->ev_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_read, 0));
+    return 0;
+}
+
+int wait_tracker(klt_ctx *c)
+{
+    if (c->track_stream_on && c->ev_track_valid) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_track, 0));
+    return 0;
+}
+
+int tracker_begin(klt_ctx *c)
+{
+    if (!c->track_stream_on) return 0;
+    HIPCHK(c, hipEventRecord(c->ev_pyr, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->tstream, c->ev_pyr, 0));
+    return 0;
+}
+
+int tracker_end(klt_ctx *c, Slot *const *slots, int n)
+{
+    if (!c->track_stream_on) return 0;
+    HIPCHK(c, hipEventRecord(c->ev_track, c->tstream));
+    c->ev_track_valid = true;
+    for (int i = 0; i < n; i++) {
+        Slot *s = slots[i];
+        if (!s->ev_read) HIPCHK(c, hipEventCreateWithFlags(&s->ev_read, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(s->ev_read, c->tstream));
+        s->ev_read_valid = true;
+    }
+    return 0;
+}
+
 void make_taps(const double *k, int n, Taps &t)
 {
     // scipy.ndimage.convolve1d: weights[::-1], then correlate1d's symmetry test (|a -+ b| <= DBL_EPSILON)
@@ -215,6 +261,7 @@ int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int p
     HIPCHK(c, hipSetDevice(c->device));
     Slot *s;
     if (int rc = get_slot(c, slot, &s, true)) return rc;
+    if (int rc = wait_slot_readers(c, s)) return rc;
     const size_t px_count = (size_t)ncols * nrows;
     if (px_count > s->raw_cap) {
         if (s->u8) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(s->u8); hipFree(s->f32); s->u8 = nullptr; s->f32 = nullptr; }
@@ -365,6 +412,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         for (int j = 0; j < i; j++)
             if (sl[j] == sl[i]) return fail(c, KLT_ERR_ARG, "slot listed twice");
         if (int rc = layout_pyramid(c, sl[i])) return rc;
+        if (int rc = wait_slot_readers(c, sl[i])) return rc;
     }
     const int ss = c->p.subsampling;
     // groups of frames with the same geometry and input type share launches
@@ -472,11 +520,14 @@ int klt_create(int device, klt_ctx **out)
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void **)&c->stats_d, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void **)&c->placed_d, sizeof(int))) != hipSuccess ||
-        (e = hipMemset(c->stats_d, 0, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMemset(c->stats_d, 0, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_track, hipEventDisableTiming)) != hipSuccess) {
         g_create_error = std::string("device setup failed: ") + hipGetErrorString(e);
         delete c;
         return KLT_ERR_DEVICE;
     }
+    c->tstream = c->stream;
     *out = c;
     return KLT_OK;
 }
@@ -486,7 +537,10 @@ void klt_destroy(klt_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.f32); hipFree(s.planes); }
+    if (c->tstream && c->tstream != c->stream) { hipStreamSynchronize(c->tstream); hipStreamDestroy(c->tstream); }
+    if (c->ev_pyr) hipEventDestroy(c->ev_pyr);
+    if (c->ev_track) hipEventDestroy(c->ev_track);
+    for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.f32); hipFree(s.planes); if (s.ev_read) hipEventDestroy(s.ev_read); }
     for (FeatBuf &b : c->fbs)
         if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB);
@@ -504,8 +558,11 @@ int klt_sync(klt_ctx *c)
 {
     if (!c) return KLT_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
     return KLT_OK;
 }
+
+void *klt_track_stream_handle(klt_ctx *c) { return c ? (void *)c->tstream : nullptr; }
 
 void *klt_stream_handle(klt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
@@ -560,6 +617,23 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (!c) return KLT_ERR_ARG;
     if (option == KLT_OPT_FUSED_KERNELS) { c->use_fused = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SMOOTH_GRAD_VARIANT) { g_smooth_grad_variant = value; return KLT_OK; }
+    if (option == KLT_OPT_TRACK_STREAM) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
+        if (value && c->tstream == c->stream) {
+            hipStream_t t = nullptr;
+            HIPCHK(c, hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
+            c->tstream = t;
+        } else if (!value && c->tstream != c->stream) {
+            HIPCHK(c, hipStreamDestroy(c->tstream));
+            c->tstream = c->stream;
+        }
+        c->track_stream_on = value != 0;
+        c->ev_track_valid = false;
+        for (Slot &sl : c->slots) sl.ev_read_valid = false;
+        return KLT_OK;
+    }
     return fail(c, KLT_ERR_ARG, "unknown option");
 }
 
@@ -587,6 +661,7 @@ int klt_featbuf_upload(klt_ctx *c, int fb, const klt_feat *src, int n)
     HIPCHK(c, hipSetDevice(c->device));
     FeatBuf *b;
     if (int rc = get_fb(c, fb, n > 0 ? n : 1, &b)) return rc;
+    if (int rc = wait_tracker(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(b->d, src, (size_t)n * sizeof(klt_feat), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return KLT_OK;
@@ -597,6 +672,7 @@ int klt_featbuf_download(klt_ctx *c, int fb, klt_feat *dst, int n)
     if (!c || !dst || n < 0) return fail(c, KLT_ERR_ARG, "bad argument");
     if (fb < 0 || (size_t)fb >= c->fbs.size() || c->fbs[fb].cap < n) return fail(c, KLT_ERR_STATE, "feature buffer not that large");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = wait_tracker(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(dst, c->fbs[fb].d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return KLT_OK;
@@ -608,6 +684,7 @@ int klt_featbuf_alloc(klt_ctx *c, int fb, int n)
     HIPCHK(c, hipSetDevice(c->device));
     FeatBuf *b;
     if (int rc = get_fb(c, fb, n, &b)) return rc;
+    if (int rc = wait_tracker(c)) return rc;
     HIPCHK(c, hipMemsetAsync(b->d, 0xff, (size_t)n * sizeof(klt_feat), c->stream));     // val = -1 everywhere
     return KLT_OK;
 }
@@ -646,6 +723,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     const size_t N = (size_t)nc * nr;
     FeatBuf *b;
     if (int rc = get_fb(c, fb, n, &b)) return rc;
+    if (int rc = wait_tracker(c)) return rc;
 
     // borders / half-windows as ScanImageForGoodFeatures receives them: Python floats truncated to C ints
     // (selectGoodFeatures.py:168-169, :215-221, goodFeaturesUtils.pyx:35-37)
@@ -823,12 +901,15 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
     fill_levels(s1, s2, a.lv);
     a.in = c->fbs[fb_in].d; a.out = bo->d;
     fill_track_params(c, s1, a, n);
+    if (int rc = tracker_begin(c)) return rc;
     {
         const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
-        TimerScope t(c, F_TRACK, (double)n * (foot * 2 * s1->nlev + 32));      // refined by the caller from klt_track_stats
-        if (launch_track(c->stream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
+        TimerScope t(c, F_TRACK, (double)n * (foot * 2 * s1->nlev + 32), c->tstream);   // refined by the caller from klt_track_stats
+        if (launch_track(c->tstream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
     }
-    if (c->collect_stats) launch_track_stats(c->stream, a.in, a.out, n, s1->nlev, c->stats_d);
+    if (c->collect_stats) launch_track_stats(c->tstream, a.in, a.out, n, s1->nlev, c->stats_d);
+    Slot *both[2] = {s1, s2};
+    if (int rc = tracker_end(c, both, 2)) return rc;
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -839,6 +920,7 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
     if (!slot1 || !slot2 || !fb_in || !fb_out || npairs <= 0 || npairs > 65535 || n < 0) return fail(c, KLT_ERR_ARG, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<TrackPairDesc> table((size_t)npairs);
+    std::vector<Slot *> used;
     Slot *first = nullptr;
     for (int i = 0; i < npairs; i++) {
         FeatBuf *bo;                      // may grow c->fbs: do it before taking pointers into it
@@ -848,6 +930,8 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
         Slot *s1, *s2;
         if (int rc = check_pair(c, slot1[i], slot2[i], &s1, &s2)) return rc;
         if (!first) first = s1;
+        used.push_back(s1);
+        used.push_back(s2);
         if (s1->nc != first->nc || s1->nr != first->nr || s1->nlev != first->nlev)
             return fail(c, KLT_ERR_ARG, "all pairs of a batch must have the same frame size");
         if (fb_in[i] < 0 || (size_t)fb_in[i] >= c->fbs.size() || c->fbs[fb_in[i]].cap < n)
@@ -859,7 +943,8 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
     }
     if (int rc = ensure(c, c->pair_table, c->pair_table_cap, (size_t)npairs)) return rc;
     // pageable source: the runtime stages it before returning; stream order protects the previous launch's table
-    HIPCHK(c, hipMemcpyAsync(c->pair_table, table.data(), (size_t)npairs * sizeof(TrackPairDesc), hipMemcpyHostToDevice, c->stream));
+    if (int rc = tracker_begin(c)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pair_table, table.data(), (size_t)npairs * sizeof(TrackPairDesc), hipMemcpyHostToDevice, c->tstream));
     TrackArgs a;
     std::memset(&a, 0, sizeof(a));
     a.pairs = c->pair_table;
@@ -867,11 +952,12 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
     fill_track_params(c, first, a, n);
     {
         const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
-        TimerScope t(c, F_TRACK, (double)npairs * n * (foot * 2 * first->nlev + 32));
-        if (launch_track(c->stream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
+        TimerScope t(c, F_TRACK, (double)npairs * n * (foot * 2 * first->nlev + 32), c->tstream);
+        if (launch_track(c->tstream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
     }
     if (c->collect_stats)
-        for (int i = 0; i < npairs; i++) launch_track_stats(c->stream, table[i].in, table[i].out, n, first->nlev, c->stats_d);
+        for (int i = 0; i < npairs; i++) launch_track_stats(c->tstream, table[i].in, table[i].out, n, first->nlev, c->stats_d);
+    if (int rc = tracker_end(c, used.data(), (int)used.size())) return rc;
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -903,6 +989,7 @@ int klt_track_stats_read(klt_ctx *c, klt_track_stats *out)
 {
     if (!c || !out) return fail(c, KLT_ERR_ARG, "null argument");
     unsigned long long h[1 + 2 * KLT_MAX_LEVELS];
+    if (int rc = wait_tracker(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(h, c->stats_d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->collect_stats = false;

@@ -37,7 +37,7 @@ class FeatureGather:
         """fbs: feature buffers of n records each (n may be frames * features of a device-side table)."""
         self.torch, self.dist, self.n, self.world = torch, dist, n, world
         dev = torch.device("cuda", ctx.device)
-        self.stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)     # the context's own HIP stream
+        self.stream = torch.cuda.ExternalStream(ctx.track_stream_handle(), device=dev)   # the stream the tracker runs on
         self.side = torch.cuda.Stream(device=dev)
         self.views, self.outs, self.ready, self.done = {}, {}, {}, {}
         for fb in fbs:

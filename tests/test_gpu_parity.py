@@ -526,6 +526,37 @@ def test_abi_error_reporting(ctx, img0):
         c.close()
 
 
+def test_track_stream_overlap_keeps_results(cfg1, img0, img1):
+    """KLT_OPT_TRACK_STREAM: tracker launches on a second stream, slots rebuilt while earlier launches may still run;
+    every step must still produce the golden result (ordering by events)."""
+    from pyfeaturetrack_amd.backend import Context
+    c = Context(0)
+    try:
+        c.configure(make_tc(max_residue=10.0))
+        c.set_option(3, 1)
+        for s0 in (0, 2):
+            c.upload(s0, img0)
+            c.upload(s0 + 1, img1)
+        c.build_pyramids(0)
+        fl, _ = c.select(0, 100, use_pyramid=True)
+        c.featbuf_upload(0, fl)
+        for i in range(40):
+            a = 0 if i % 2 == 0 else 2
+            if i % 5 == 4:                                   # overwrite frame 1 with garbage, then restore it
+                c.upload(a + 1, (255 - img1))
+            c.upload(a + 1, img1)
+            c.build_pyramids_batch([a, a + 1])
+            c.track_async(a, a + 1, 0, 1 + i % 3, 100)
+        for k in range(3):
+            out = c.featbuf_download(1 + k, 100)
+            assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "two-stream step, buffer %d" % k)
+        c.set_option(3, 0)
+        out, _ = c.track(0, 1, fl)
+        assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "back to one stream")
+    finally:
+        c.close()
+
+
 def test_feature_table_views(ctx, cfg1, img0, img1):
     """klt_featbuf_view: tracker output written into a window of a larger device-side record table"""
     ctx.configure(make_tc(max_residue=10.0))
