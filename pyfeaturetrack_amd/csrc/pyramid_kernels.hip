@@ -345,7 +345,15 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
             const int x = tx0 + X0 + 4 * q;
             const TIn *row = raw + (size_t)gy * nc;
             float4 v;
-            if (x >= 0 && x + 3 < nc) {
+            if (x >= 0 && x + 3 < nc && (nc & 3) == 0) {          // aligned quad: one 4- or 16-byte load
+                if (sizeof(TIn) == 1) {
+                    const uint32_t wq = *reinterpret_cast<const uint32_t *>(row + x);
+                    v.x = (float)(wq & 0xffu); v.y = (float)((wq >> 8) & 0xffu);
+                    v.z = (float)((wq >> 16) & 0xffu); v.w = (float)(wq >> 24);
+                } else {
+                    v = *reinterpret_cast<const float4 *>(row + x);
+                }
+            } else if (x >= 0 && x + 3 < nc) {
                 v.x = (float)row[x]; v.y = (float)row[x + 1]; v.z = (float)row[x + 2]; v.w = (float)row[x + 3];
             } else {
                 v.x = (float)row[reflect_fast(x, nc)]; v.y = (float)row[reflect_fast(x + 1, nc)];
@@ -370,28 +378,34 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
             *reinterpret_cast<float4 *>(B + r * BW + 4 * q) = o;
         }
         __syncthreads();
-        // ---- stage 2: vertical smoothing, B -> C (+ store the tile interior of the smoothed image)
+        // ---- stage 2: vertical smoothing, B -> C (+ store the tile interior of the smoothed image).
+        // A thread produces a quad on two consecutive rows: NS+1 rows are read and widened for 8 outputs.
         float *__restrict__ img = a.img[b];
-        for (int i = tid; i < IH * BQ; i += 256) {
-            const int r = i / BQ, q = i % BQ;
-            double v[4][NS];
+        static_assert(IH % 2 == 0, "tile height must be even");
+        for (int i = tid; i < (IH / 2) * BQ; i += 256) {
+            const int r = 2 * (i / BQ), q = i % BQ;
+            double v[4][NS + 1];
 #pragma unroll
-            for (int j = 0; j < NS; j++) {
+            for (int j = 0; j < NS + 1; j++) {
                 const float4 t = *reinterpret_cast<const float4 *>(B + (r + j) * BW + 4 * q);
                 v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
             }
-            float4 o;
-            o.x = corr_regs<NS, 1>(v[0] + rs, ks); o.y = corr_regs<NS, 1>(v[1] + rs, ks);
-            o.z = corr_regs<NS, 1>(v[2] + rs, ks); o.w = corr_regs<NS, 1>(v[3] + rs, ks);
-            *reinterpret_cast<float4 *>(C + r * BW + 4 * q) = o;
-            const int y = ty0 - R + r, x = tx0 - 4 + 4 * q;
-            if (r >= R && r < R + TH_ && q >= 1 && q <= DQ && y < nr) {
-                float *dstp = img + (size_t)y * nc + x;
-                if (x + 3 < nc) { dstp[0] = o.x; dstp[1] = o.y; dstp[2] = o.z; dstp[3] = o.w; }
-                else {
-                    if (x < nc) dstp[0] = o.x;
-                    if (x + 1 < nc) dstp[1] = o.y;
-                    if (x + 2 < nc) dstp[2] = o.z;
+#pragma unroll
+            for (int dr = 0; dr < 2; dr++) {
+                float4 o;
+                o.x = corr_regs<NS, 1>(v[0] + rs + dr, ks); o.y = corr_regs<NS, 1>(v[1] + rs + dr, ks);
+                o.z = corr_regs<NS, 1>(v[2] + rs + dr, ks); o.w = corr_regs<NS, 1>(v[3] + rs + dr, ks);
+                const int rr = r + dr;
+                *reinterpret_cast<float4 *>(C + rr * BW + 4 * q) = o;
+                const int y = ty0 - R + rr, x = tx0 - 4 + 4 * q;
+                if (rr >= R && rr < R + TH_ && q >= 1 && q <= DQ && y < nr) {
+                    float *dstp = img + (size_t)y * nc + x;
+                    if (x + 3 < nc) { dstp[0] = o.x; dstp[1] = o.y; dstp[2] = o.z; dstp[3] = o.w; }
+                    else {
+                        if (x < nc) dstp[0] = o.x;
+                        if (x + 1 < nc) dstp[1] = o.y;
+                        if (x + 2 < nc) dstp[2] = o.z;
+                    }
                 }
             }
         }
@@ -412,42 +426,54 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
         *reinterpret_cast<float4 *>(E + r * DW + 4 * q) = e;
     }
     __syncthreads();
-    // ---- stage 4: vertical pass, D -> gradx (Gaussian taps), E -> grady (derivative taps)
+    // ---- stage 4: vertical pass, D -> gradx (Gaussian taps), E -> grady (derivative taps); quad x two rows per thread
     float *__restrict__ gxo = a.gx[b];
     float *__restrict__ gyo = a.gy[b];
-    for (int i = tid; i < TH_ * DQ; i += 256) {
-        const int r = i / DQ, q = i % DQ;
-        const int y = ty0 + r, x = tx0 + 4 * q;
-        if (y >= nr || x >= nc) continue;
-        float4 ox, oy;
+    static_assert(TH_ % 2 == 0, "tile height must be even");
+    for (int i = tid; i < (TH_ / 2) * DQ; i += 256) {
+        const int r = 2 * (i / DQ), q = i % DQ;
+        const int x = tx0 + 4 * q;
+        if (ty0 + r >= nr || x >= nc) continue;
+        float4 ox[2], oy[2];
         {
-            double v[4][NG];
+            double v[4][NG + 1];
 #pragma unroll
-            for (int j = 0; j < NG; j++) {
+            for (int j = 0; j < NG + 1; j++) {
                 const float4 t = *reinterpret_cast<const float4 *>(D + (r + R - NG / 2 + j) * DW + 4 * q);
                 v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
             }
-            ox.x = corr_regs<NG, 1>(v[0] + NG / 2, kg); ox.y = corr_regs<NG, 1>(v[1] + NG / 2, kg);
-            ox.z = corr_regs<NG, 1>(v[2] + NG / 2, kg); ox.w = corr_regs<NG, 1>(v[3] + NG / 2, kg);
+#pragma unroll
+            for (int dr = 0; dr < 2; dr++) {
+                ox[dr].x = corr_regs<NG, 1>(v[0] + NG / 2 + dr, kg); ox[dr].y = corr_regs<NG, 1>(v[1] + NG / 2 + dr, kg);
+                ox[dr].z = corr_regs<NG, 1>(v[2] + NG / 2 + dr, kg); ox[dr].w = corr_regs<NG, 1>(v[3] + NG / 2 + dr, kg);
+            }
         }
         {
-            double v[4][ND];
+            double v[4][ND + 1];
 #pragma unroll
-            for (int j = 0; j < ND; j++) {
+            for (int j = 0; j < ND + 1; j++) {
                 const float4 t = *reinterpret_cast<const float4 *>(E + (r + R - ND / 2 + j) * DW + 4 * q);
                 v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
             }
-            oy.x = corr_regs<ND, -1>(v[0] + ND / 2, kd); oy.y = corr_regs<ND, -1>(v[1] + ND / 2, kd);
-            oy.z = corr_regs<ND, -1>(v[2] + ND / 2, kd); oy.w = corr_regs<ND, -1>(v[3] + ND / 2, kd);
+#pragma unroll
+            for (int dr = 0; dr < 2; dr++) {
+                oy[dr].x = corr_regs<ND, -1>(v[0] + ND / 2 + dr, kd); oy[dr].y = corr_regs<ND, -1>(v[1] + ND / 2 + dr, kd);
+                oy[dr].z = corr_regs<ND, -1>(v[2] + ND / 2 + dr, kd); oy[dr].w = corr_regs<ND, -1>(v[3] + ND / 2 + dr, kd);
+            }
         }
-        float *px = gxo + (size_t)y * nc + x, *py = gyo + (size_t)y * nc + x;
-        if (x + 3 < nc) {
-            px[0] = ox.x; px[1] = ox.y; px[2] = ox.z; px[3] = ox.w;
-            py[0] = oy.x; py[1] = oy.y; py[2] = oy.z; py[3] = oy.w;
-        } else {
-            px[0] = ox.x; py[0] = oy.x;
-            if (x + 1 < nc) { px[1] = ox.y; py[1] = oy.y; }
-            if (x + 2 < nc) { px[2] = ox.z; py[2] = oy.z; }
+#pragma unroll
+        for (int dr = 0; dr < 2; dr++) {
+            const int y = ty0 + r + dr;
+            if (y >= nr) break;
+            float *px = gxo + (size_t)y * nc + x, *py = gyo + (size_t)y * nc + x;
+            if (x + 3 < nc) {
+                px[0] = ox[dr].x; px[1] = ox[dr].y; px[2] = ox[dr].z; px[3] = ox[dr].w;
+                py[0] = oy[dr].x; py[1] = oy[dr].y; py[2] = oy[dr].z; py[3] = oy[dr].w;
+            } else {
+                px[0] = ox[dr].x; py[0] = oy[dr].x;
+                if (x + 1 < nc) { px[1] = ox[dr].y; py[1] = oy[dr].y; }
+                if (x + 2 < nc) { px[2] = ox[dr].z; py[2] = oy[dr].z; }
+            }
         }
     }
 }
