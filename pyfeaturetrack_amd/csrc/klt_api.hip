@@ -366,6 +366,11 @@ bool fused_smooth_ok(const klt_ctx *c)
 {
     return c->use_fused && c->gauss[0].sym == 1 && smooth_grad_lds_bytes(c->gauss[0].n / 2, grad_radius(c)) <= kMaxLds;
 }
+// the register-blocked kernels take per-entry geometry (levels of different size in one launch); dims must fit a short
+bool merged_grad_ok(const klt_ctx *c)
+{
+    return g_smooth_grad_variant == 0 && c->gauss[2].sym == 1 && c->deriv[2].sym == -1 && c->gauss[2].n == 7 && c->deriv[2].n == 7;
+}
 bool fused_grad_ok(const klt_ctx *c) { return c->use_fused && smooth_grad_lds_bytes(-1, grad_radius(c)) <= kMaxLds; }
 bool fused_reduce_ok(const klt_ctx *c) { return c->use_fused && pyr_reduce_lds_bytes(c->p.subsampling, c->gauss[1].n) <= kMaxLds; }
 
@@ -473,12 +478,32 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                     }
                 }
             }
+            const bool merged = fused_grad_ok(c) && merged_grad_ok(c) && B * (s0->nlev - 1) <= KLT_MAX_BATCH;
+            if (merged) continue;          // gradients of all levels >= 1 go out in one launch below
             if (fused_grad_ok(c)) {
                 for (int b = 0; b < B; b++) { src[b] = g[b]->lv[l].img; gx[b] = g[b]->lv[l].gx; gy[b] = g[b]->lv[l].gy; }
                 if (int rc = enqueue_fused_grad(c, B, src, gx, gy, ld.nc, ld.nr)) return rc;
             } else {
                 for (int b = 0; b < B; b++) enqueue_gradients(c, g[b]->lv[l].img, ld.nc, ld.nr, g[b]->lv[l].gx, g[b]->lv[l].gy);
             }
+        }
+        if (s0->nlev > 1 && fused_grad_ok(c) && merged_grad_ok(c) && B * (s0->nlev - 1) <= KLT_MAX_BATCH) {
+            // one launch for the gradients of every level >= 1 of every frame: entry = (frame, level), per-entry geometry
+            SmoothGradArgs a;
+            std::memset(&a, 0, sizeof(a));
+            int e = 0;
+            double bytes = 0;
+            for (int l = 1; l < s0->nlev; l++)
+                for (int b = 0; b < B; b++, e++) {
+                    a.raw[e] = g[b]->lv[l].img; a.gx[e] = g[b]->lv[l].gx; a.gy[e] = g[b]->lv[l].gy;
+                    a.dim_c[e] = (short)g[b]->lv[l].nc; a.dim_r[e] = (short)g[b]->lv[l].nr;
+                    bytes += 12.0 * g[b]->lv[l].nc * g[b]->lv[l].nr;
+                }
+            a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
+            a.ncols = s0->lv[1].nc; a.nrows = s0->lv[1].nr; a.R = grad_radius(c);
+            TimerScope t(c, F_GRAD, bytes);
+            if (int er = launch_smooth_grad(c->stream, a, e, 2))
+                return fail(c, KLT_ERR_DEVICE, std::string("gradient launch: ") + hipGetErrorString((hipError_t)er));
         }
         for (Slot *s : g) s->pyr_valid = true;
     }

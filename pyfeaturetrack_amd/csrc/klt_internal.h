@@ -20,7 +20,8 @@ struct SmoothGradArgs {
     float *img[KLT_MAX_BATCH];        // smoothed image out (unused for gradients only)
     float *gx[KLT_MAX_BATCH], *gy[KLT_MAX_BATCH];
     Taps smooth, ggauss, gderiv;
-    int ncols, nrows, R;              // R = max gradient tap radius
+    int ncols, nrows, R;              // R = max gradient tap radius; ncols/nrows = largest entry (grid extent)
+    short dim_c[KLT_MAX_BATCH], dim_r[KLT_MAX_BATCH];   // per-entry geometry when entries differ (0 = use ncols/nrows)
 };
 
 struct PyrReduceArgs {

@@ -328,7 +328,8 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
     float *const A = lds, *const B = lds + RH * AW, *const D = lds, *const E = lds + IH * DW, *const C = lds + OFF_C;
     const int tid = threadIdx.x, b = blockIdx.z;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
-    const int nc = a.ncols, nr = a.nrows;
+    const int nc = a.dim_c[b] ? a.dim_c[b] : a.ncols, nr = a.dim_r[b] ? a.dim_r[b] : a.nrows;
+    if (tx0 >= nc || ty0 >= nr) return;              // entries smaller than the grid extent (mixed pyramid levels)
     const TIn *__restrict__ raw = (const TIn *)a.raw[b];
     TapRegs<NG> kg;
     TapRegs<ND> kd;
@@ -507,10 +508,28 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
     TapRegs<NT> k;
     load_taps(k, a.taps);
 
-    for (int i = tid; i < SH * SW; i += NTHR) {
-        const int rr = i / SW, c = i % SW;
-        const int gy = reflect_fast(gy0 + rr, nr), gx = reflect_fast(gx0 + c, nc);
-        S[rr * ROWLEN + (c % SS) * PW + c / SS] = (double)src[(size_t)gy * nc + gx];
+    // tile load: one aligned 16-byte quad per step where the row allows it (gx0 is a multiple of 4 columns)
+    constexpr int SQ = (SW + 3) / 4;
+    const bool quads = (nc & 3) == 0;
+    for (int i = tid; i < SH * SQ; i += NTHR) {
+        const int rr = i / SQ, q = i % SQ;
+        const int gy = reflect_fast(gy0 + rr, nr);
+        const float *row = src + (size_t)gy * nc;
+        const int x = gx0 + 4 * q;
+        double *dst = S + rr * ROWLEN;
+        if (quads && x >= 0 && x + 3 < nc && 4 * q + 3 < SW) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + x);
+            dst[((4 * q) % SS) * PW + (4 * q) / SS] = (double)v.x;
+            dst[((4 * q + 1) % SS) * PW + (4 * q + 1) / SS] = (double)v.y;
+            dst[((4 * q + 2) % SS) * PW + (4 * q + 2) / SS] = (double)v.z;
+            dst[((4 * q + 3) % SS) * PW + (4 * q + 3) / SS] = (double)v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int c = 4 * q + e;
+                if (c < SW) dst[(c % SS) * PW + c / SS] = (double)row[reflect_fast(gx0 + c, nc)];
+            }
+        }
     }
     __syncthreads();
     for (int i = tid; i < SH * OW; i += NTHR) {
