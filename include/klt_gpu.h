@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 1
+#define KLT_ABI_VERSION 2
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -85,6 +85,9 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
  * kept with events (a slot is not overwritten before the tracker launches that read it have finished, feature-buffer
  * consumers wait for the last tracker launch).  0 (default): one stream. */
 #define KLT_OPT_TRACK_STREAM 3
+/* affine state (klt_affine_alloc id, or -1) whose records klt_select* resets for every slot it fills
+ * (selectGoodFeatures.py:120-128 clears the aff_* fields of a newly placed feature) */
+#define KLT_OPT_SELECT_AFFINE_STATE 4
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
 /* ---- parameters and taps ------------------------------------------------------------------- */
@@ -135,6 +138,25 @@ int klt_track(klt_ctx *ctx, int slot1, int slot2, klt_feat *inout, int n, int *n
  * pair i tracks feature buffer fb_in[i] (n records) from slot1[i] to slot2[i] into fb_out[i] */
 int klt_track_batch_async(klt_ctx *ctx, const int *slot1, const int *slot2, const int *fb_in, const int *fb_out,
                           int npairs, int n);
+
+/* ---- affine consistency check (BASELINE cfg-3) -- PARITY UNPINNED ------------------------- */
+/* The reference calls _am_trackFeatureAffine / _am_getSubFloatImage at trackFeatures.py:347-399 but defines neither
+ * (NameError): the call site pins the interface, upstream KLT 1.3.4 the behaviour.
+ * mode = tc.affineConsistencyCheck (klt.py:67): -1 off, 0 translation, 1 similarity, 2 affine. */
+typedef struct {
+    int32_t mode, window_width, window_height, max_iterations;       /* klt.py:67-70 */
+    float   max_residue, min_displacement, max_displacement_differ;   /* klt.py:71-73 */
+} klt_affine_params;
+/* per-feature state the reference keeps in KLT_Feature (klt.py:255-263); the three (window+2)^2 templates live in a
+ * device array next to these records */
+typedef struct { float aff_x, aff_y, Axx, Ayx, Axy, Ayy; int32_t valid, pad; } klt_affine_rec;
+int klt_set_affine_params(klt_ctx *ctx, const klt_affine_params *p);
+int klt_affine_alloc(klt_ctx *ctx, int state, int n);          /* n feature slots, no templates yet */
+int klt_affine_download(klt_ctx *ctx, int state, klt_affine_rec *dst, int n);
+/* klt_track_async followed by the consistency check of the features it tracked; fb_in != fb_out.  `state` travels
+ * with the feature list (same index = same feature). */
+int klt_track_affine_async(klt_ctx *ctx, int slot1, int slot2, int fb_in, int fb_out, int n, int state);
+int klt_track_affine(klt_ctx *ctx, int slot1, int slot2, klt_feat *inout, int n, int state, int *n_tracked);
 
 typedef struct {
     uint64_t features;                       /* live features entering the kernel */

@@ -194,3 +194,38 @@ def track_features(params, pyr1, pyr2, fl, want_iters=False):
     if rc < 0:
         raise RuntimeError("ko_track_features failed: %d" % rc)
     return (rc, it) if want_iters else rc
+
+
+# ------------------------------------------------------------- affine consistency (parity unpinned)
+AFFINE_DTYPE = np.dtype([("aff_x", np.float32), ("aff_y", np.float32), ("Axx", np.float32), ("Ayx", np.float32),
+                         ("Axy", np.float32), ("Ayy", np.float32), ("valid", np.int32), ("pad", np.int32)])
+
+
+class AffineState:
+    """Per-feature state of the consistency check: records + (window+2)^2 templates (image, gradx, grady)."""
+    def __init__(self, ap, n):
+        self.ap = ap
+        self.rec = np.zeros(n, AFFINE_DTYPE)
+        self.rec["aff_x"] = -1
+        self.rec["aff_y"] = -1
+        self.rec["Axx"] = 1
+        self.rec["Ayy"] = 1
+        self.tpl = np.zeros((n, 3, (ap.window_height + 2) * (ap.window_width + 2)), np.float32)
+
+    def reset(self, idx):
+        self.rec["valid"][idx] = 0
+        self.rec["aff_x"][idx] = -1
+        self.rec["aff_y"][idx] = -1
+        self.rec["Axx"][idx] = 1
+        self.rec["Ayx"][idx] = 0
+        self.rec["Axy"][idx] = 0
+        self.rec["Ayy"][idx] = 1
+
+
+def track_features_affine(params, pyr1, pyr2, fl, state):
+    rc = lib().ko_track_features_affine(C.byref(params), C.byref(state.ap), pyr1.ncols, pyr1.nrows,
+                                        _fp(pyr1.img), _fp(pyr1.gx), _fp(pyr1.gy), _fp(pyr2.img), _fp(pyr2.gx), _fp(pyr2.gy),
+                                        _fp(fl), len(fl), _fp(state.rec), _fp(state.tpl))
+    if rc < 0:
+        raise RuntimeError("ko_track_features_affine failed: %d" % rc)
+    return rc

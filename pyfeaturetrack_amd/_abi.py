@@ -30,6 +30,16 @@ class KltParams(C.Structure):
     ]
 
 
+class KltAffineParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("window_width", C.c_int32), ("window_height", C.c_int32), ("max_iterations", C.c_int32),
+                ("max_residue", C.c_float), ("min_displacement", C.c_float), ("max_displacement_differ", C.c_float)]
+
+
+class KltAffineRec(C.Structure):
+    _fields_ = [("aff_x", C.c_float), ("aff_y", C.c_float), ("Axx", C.c_float), ("Ayx", C.c_float), ("Axy", C.c_float),
+                ("Ayy", C.c_float), ("valid", C.c_int32), ("pad", C.c_int32)]
+
+
 class KltTrackStats(C.Structure):
     _fields_ = [("features", C.c_uint64), ("level_visits", C.c_uint64 * KLT_MAX_LEVELS),
                 ("iterations", C.c_uint64 * KLT_MAX_LEVELS)]
@@ -71,6 +81,11 @@ SYMBOLS = {
     "klt_track_async": (_I, [_P, _I, _I, _I, _I, _I]),
     "klt_track": (_I, [_P, _I, _I, _P, _I, _PI]),
     "klt_track_batch_async": (_I, [_P, _PI, _PI, _PI, _PI, _I, _I]),
+    "klt_set_affine_params": (_I, [_P, C.POINTER(KltAffineParams)]),
+    "klt_affine_alloc": (_I, [_P, _I, _I]),
+    "klt_affine_download": (_I, [_P, _I, _P, _I]),
+    "klt_track_affine_async": (_I, [_P, _I, _I, _I, _I, _I, _I]),
+    "klt_track_affine": (_I, [_P, _I, _I, _P, _I, _I, _PI]),
     "klt_track_stats_reset": (_I, [_P]),
     "klt_track_stats_read": (_I, [_P, C.POINTER(KltTrackStats)]),
     "klt_level_dims": (_I, [_P, _I, _I, _PI, _PI]),

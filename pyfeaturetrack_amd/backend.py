@@ -8,12 +8,15 @@ import ctypes as C
 
 import numpy as np
 
-from ._abi import (KLT_MAX_LEVELS, KltBackendError, KltFeat, KltKernelTime, KltParams, KltTrackStats,
+from ._abi import (KLT_MAX_LEVELS, KltAffineRec, KltBackendError, KltFeat, KltKernelTime, KltParams, KltTrackStats,
                    load_library)
-from .params import params_from_tc, taps_from_params
+from .params import affine_params_from_tc, params_from_tc, taps_from_params
 
 FEAT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("val", np.int32), ("aux", np.int32)])
 assert FEAT_DTYPE.itemsize == C.sizeof(KltFeat)
+AFFINE_DTYPE = np.dtype([("aff_x", np.float32), ("aff_y", np.float32), ("Axx", np.float32), ("Ayx", np.float32),
+                         ("Axy", np.float32), ("Ayy", np.float32), ("valid", np.int32), ("pad", np.int32)])
+assert AFFINE_DTYPE.itemsize == C.sizeof(KltAffineRec)
 
 SELECTING_ALL = 1
 REPLACING_SOME = 2
@@ -76,6 +79,31 @@ class Context:
 
     def configure(self, tc):
         self.set_params(params_from_tc(tc))
+        self.set_affine_params(affine_params_from_tc(tc))
+
+    # ------------------------------------------------ affine consistency check
+    def set_affine_params(self, ap):
+        key = bytes(ap)
+        if key != getattr(self, "_affine_key", None):
+            self._check(self._lib.klt_set_affine_params(self._h, C.byref(ap)))
+            self._affine_key = key
+
+    def affine_alloc(self, state, n):
+        self._check(self._lib.klt_affine_alloc(self._h, state, n))
+
+    def affine_download(self, state, n):
+        out = np.empty(n, AFFINE_DTYPE)
+        self._check(self._lib.klt_affine_download(self._h, state, out.ctypes.data, n))
+        return out
+
+    def track_affine(self, slot1, slot2, fl, state):
+        fl = np.ascontiguousarray(fl, FEAT_DTYPE).copy()
+        k = C.c_int()
+        self._check(self._lib.klt_track_affine(self._h, slot1, slot2, fl.ctypes.data, len(fl), state, C.byref(k)))
+        return fl, k.value
+
+    def track_affine_async(self, slot1, slot2, fb_in, fb_out, n, state):
+        self._check(self._lib.klt_track_affine_async(self._h, slot1, slot2, fb_in, fb_out, n, state))
 
     # -------------------------------------------------------------------- frames
     def upload(self, slot, img):

@@ -1,0 +1,259 @@
+// Affine consistency check (BASELINE cfg-3) -- one wavefront per feature.
+//
+// PARITY UNPINNED: the reference calls _am_trackFeatureAffine / _am_getSubFloatImage
+// (trackFeatures.py:347-399) but never defines them.  This kernel implements upstream KLT 1.3.4's
+// behaviour behind the interface the reference's call site pins: after the
+// translation tracker has succeeded,
+//   * first success of a feature: cut (affine_window+2)^2 templates (image, gradx, grady) out of level 0
+//     of frame 1 around (int)x, (int)y and remember the sub-pixel offset;
+//   * later calls: Newton iterations on [dAxx dAyx dAxy dAyy dx dy] (6x6 normal equations; 4x4 for the
+//     similarity model; 2x2 for translation only) of the template against level 0 of frame 2; the feature
+//     is lost unless this returns KLT_TRACKED; on success the translation result is kept.
+// Window sums: every lane accumulates its own samples, then a 6-step butterfly (wave shuffles) -- there is
+// no reference summation order to reproduce here.  The test oracle restates the same algorithm with
+// sequential sums; tests compare within a tolerance and against synthetic known warps.
+#include "klt_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float bilinear_at(const float *__restrict__ img, int nc, float x, float y)
+{
+    const int ix = (int)x, iy = (int)y;
+    const float ax = (float)((double)x - (double)ix), ay = (float)((double)y - (double)iy);
+    const double w00 = (1. - (double)ax) * (1. - (double)ay), w01 = (double)ax * (1. - (double)ay), w10 = (1. - (double)ax) * (double)ay;
+    const float w11 = ax * ay;
+    const float *q = img + (size_t)iy * nc + ix;
+    const float t4 = w11 * q[nc + 1];
+    double v = w00 * (double)q[0];
+    v = v + w01 * (double)q[1];
+    v = v + w10 * (double)q[nc];
+    v = v + (double)t4;
+    return (float)v;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m);
+    return v;
+}
+
+// Numerical Recipes' gaussj with full pivoting, as upstream's _am_gauss_jordan_elimination
+__device__ int gauss_jordan(float a[6][6], int n, float b[6])
+{
+    int ipiv[6] = {0, 0, 0, 0, 0, 0}, irow = 0, icol = 0;
+    for (int i = 0; i < n; i++) {
+        float big = 0.f;
+        for (int j = 0; j < n; j++)
+            if (ipiv[j] != 1)
+                for (int k = 0; k < n; k++) {
+                    if (ipiv[k] == 0) {
+                        if (fabsf(a[j][k]) >= big) { big = fabsf(a[j][k]); irow = j; icol = k; }
+                    } else if (ipiv[k] > 1) return KLT_SMALL_DET;
+                }
+        ++ipiv[icol];
+        if (irow != icol) {
+            for (int l = 0; l < n; l++) { const float t = a[irow][l]; a[irow][l] = a[icol][l]; a[icol][l] = t; }
+            const float t = b[irow]; b[irow] = b[icol]; b[icol] = t;
+        }
+        if (a[icol][icol] == 0.f) return KLT_SMALL_DET;
+        const float pivinv = 1.0f / a[icol][icol];
+        a[icol][icol] = 1.0f;
+        for (int l = 0; l < n; l++) a[icol][l] = a[icol][l] * pivinv;
+        b[icol] = b[icol] * pivinv;
+        for (int ll = 0; ll < n; ll++)
+            if (ll != icol) {
+                const float dum = a[ll][icol];
+                a[ll][icol] = 0.f;
+                for (int l = 0; l < n; l++) a[ll][l] = a[ll][l] - a[icol][l] * dum;
+                b[ll] = b[ll] - b[icol] * dum;
+            }
+    }
+    return KLT_TRACKED;
+}
+
+__global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    if (f >= a.n) return;
+    const klt_feat before = a.in[f];
+    if (before.val < 0) return;
+    klt_feat after = a.out[f];
+    klt_affine_rec st = a.rec[f];
+    if (after.val != KLT_TRACKED) {                       // lost by the translation tracker: template freed
+        if (lane == 0 && st.valid) { st.valid = 0; a.rec[f] = st; }
+        return;
+    }
+    const int width = a.width, height = a.height, hw = width / 2, hh = height / 2, n = width * height;
+    const int tw = width + 2, th = height + 2, tn = tw * th;
+    float *tpl = a.tpl + (size_t)f * 3 * tn;
+    const int nc = a.ncols, nr = a.nrows;
+
+    if (!st.valid) {
+        // _am_getSubFloatImage: integer-aligned copy around (int)x, (int)y of the feature's frame-1 position
+        const int x0 = (int)before.x, y0 = (int)before.y, thw = tw / 2, thh = th / 2;
+        if (x0 - thw < 0 || y0 - thh < 0 || x0 + thw >= nc || y0 + thh >= nr) return;     // upstream asserts; stay template-less
+        for (int k = lane; k < tn; k += 64) {
+            const size_t o = (size_t)(y0 - thh + k / tw) * nc + (x0 - thw + k % tw);
+            tpl[k] = a.i1[o];
+            tpl[tn + k] = a.gx1[o];
+            tpl[2 * tn + k] = a.gy1[o];
+        }
+        if (lane == 0) {
+            st.aff_x = before.x - (float)x0 + (float)thw;
+            st.aff_y = before.y - (float)y0 + (float)thh;
+            st.Axx = 1.f; st.Ayx = 0.f; st.Axy = 0.f; st.Ayy = 1.f;
+            st.valid = 1;
+            a.rec[f] = st;
+        }
+        return;
+    }
+
+    const float one_plus_eps = 1.001f;
+    const float x1 = st.aff_x, y1 = st.aff_y;
+    float x2 = after.x, y2 = after.y;
+    const float old_x2 = x2, old_y2 = y2;
+    float Axx = st.Axx, Ayx = st.Ayx, Axy = st.Axy, Ayy = st.Ayy;
+    const float *t_img = tpl, *t_gx = tpl + tn, *t_gy = tpl + 2 * tn;
+    const float sxs[4] = {-(float)hw, -(float)hw, (float)hw, (float)hw};
+    const float sys[4] = {(float)hh, -(float)hh, (float)hh, -(float)hh};
+    int iteration = 0, status = KLT_TRACKED;
+    bool convergence = false;
+    do {
+        float dx = 0.f, dy = 0.f;
+        if (a.mode == 0) {
+            if (x1 - hw < 0.0f || tw - (x1 + hw) < one_plus_eps || x2 - hw < 0.0f || nc - (x2 + hw) < one_plus_eps ||
+                y1 - hh < 0.0f || th - (y1 + hh) < one_plus_eps || y2 - hh < 0.0f || nr - (y2 + hh) < one_plus_eps) {
+                status = KLT_OOB;
+                break;
+            }
+            float gxx = 0.f, gxy = 0.f, gyy = 0.f, ex = 0.f, ey = 0.f;
+            for (int k = lane; k < n; k += 64) {
+                const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);
+                const float d = bilinear_at(t_img, tw, x1 + fi, y1 + fj) - bilinear_at(a.i2, nc, x2 + fi, y2 + fj);
+                const float g1 = bilinear_at(t_gx, tw, x1 + fi, y1 + fj) + bilinear_at(a.gx2, nc, x2 + fi, y2 + fj);
+                const float g2 = bilinear_at(t_gy, tw, x1 + fi, y1 + fj) + bilinear_at(a.gy2, nc, x2 + fi, y2 + fj);
+                gxx = gxx + g1 * g1; gxy = gxy + g1 * g2; gyy = gyy + g2 * g2;
+                ex = ex + d * g1; ey = ey + d * g2;
+            }
+            gxx = wave_sum(gxx); gxy = wave_sum(gxy); gyy = wave_sum(gyy);
+            ex = wave_sum(ex) * a.step; ey = wave_sum(ey) * a.step;
+            const float det = gxx * gyy - gxy * gxy;
+            if (det < a.small) { status = KLT_SMALL_DET; }
+            else { dx = (gyy * ex - gxy * ey) / det; dy = (gxx * ey - gxy * ex) / det; status = KLT_TRACKED; }
+            convergence = fabsf(dx) < a.th && fabsf(dy) < a.th;
+            x2 = x2 + dx; y2 = y2 + dy;
+        } else {
+            float cx[4], cy[4];
+            bool oob = (x1 - hw < 0.0f || tw - (x1 + hw) < one_plus_eps || y1 - hh < 0.0f || th - (y1 + hh) < one_plus_eps);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {                // ul, ll, ur, lr corners of the warped window
+                cx[k] = Axx * sxs[k] + Axy * sys[k] + x2;
+                cy[k] = Ayx * sxs[k] + Ayy * sys[k] + y2;
+                if (cx[k] < 0.0f || nc - cx[k] < one_plus_eps || cy[k] < 0.0f || nr - cy[k] < one_plus_eps) oob = true;
+            }
+            if (oob) { status = KLT_OOB; break; }
+            float T[6][6], e[6];
+            for (int r = 0; r < 6; r++) { e[r] = 0.f; for (int q = 0; q < 6; q++) T[r][q] = 0.f; }
+            const int nn = a.mode == 1 ? 4 : 6;
+            for (int k = lane; k < n; k += 64) {
+                const int i = k % width - hw, j = k / width - hh;
+                const float x = (float)i, y = (float)j;
+                const float mi = Axx * x + Axy * y, mj = Ayx * x + Ayy * y;
+                const float d = bilinear_at(t_img, tw, x1 + x, y1 + y) - bilinear_at(a.i2, nc, x2 + mi, y2 + mj);
+                const float g1 = bilinear_at(a.gx2, nc, x2 + mi, y2 + mj);
+                const float g2 = bilinear_at(a.gy2, nc, x2 + mi, y2 + mj);
+                if (a.mode == 1) {
+                    const float u = x * g1 + y * g2, v = x * g2 - y * g1;
+                    e[0] = e[0] + (d * g1 * x + d * g2 * y); e[1] = e[1] + (d * g2 * x - d * g1 * y);
+                    e[2] = e[2] + d * g1; e[3] = e[3] + d * g2;
+                    T[0][0] = T[0][0] + u * u; T[0][1] = T[0][1] + u * v; T[0][2] = T[0][2] + u * g1; T[0][3] = T[0][3] + u * g2;
+                    T[1][1] = T[1][1] + v * v; T[1][2] = T[1][2] + v * g1; T[1][3] = T[1][3] + v * g2;
+                    T[2][2] = T[2][2] + g1 * g1; T[2][3] = T[2][3] + g1 * g2; T[3][3] = T[3][3] + g2 * g2;
+                } else {
+                    const float dgx = d * g1, dgy = d * g2, gxx = g1 * g1, gxy = g1 * g2, gyy = g2 * g2;
+                    const float xx = x * x, xy = x * y, yy = y * y;
+                    e[0] = e[0] + dgx * x; e[1] = e[1] + dgy * x; e[2] = e[2] + dgx * y; e[3] = e[3] + dgy * y;
+                    e[4] = e[4] + dgx; e[5] = e[5] + dgy;
+                    T[0][0] = T[0][0] + xx * gxx; T[0][1] = T[0][1] + xx * gxy; T[0][2] = T[0][2] + xy * gxx;
+                    T[0][3] = T[0][3] + xy * gxy; T[0][4] = T[0][4] + x * gxx; T[0][5] = T[0][5] + x * gxy;
+                    T[1][1] = T[1][1] + xx * gyy; T[1][2] = T[1][2] + xy * gxy; T[1][3] = T[1][3] + xy * gyy;
+                    T[1][4] = T[1][4] + x * gxy; T[1][5] = T[1][5] + x * gyy;
+                    T[2][2] = T[2][2] + yy * gxx; T[2][3] = T[2][3] + yy * gxy; T[2][4] = T[2][4] + y * gxx; T[2][5] = T[2][5] + y * gxy;
+                    T[3][3] = T[3][3] + yy * gyy; T[3][4] = T[3][4] + y * gxy; T[3][5] = T[3][5] + y * gyy;
+                    T[4][4] = T[4][4] + gxx; T[4][5] = T[4][5] + gxy; T[5][5] = T[5][5] + gyy;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                e[r] = wave_sum(e[r]) * 0.5f;
+#pragma unroll
+                for (int q = r; q < 6; q++) T[r][q] = wave_sum(T[r][q]);
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int q = r + 1; q < 6; q++) T[q][r] = T[r][q];
+            status = gauss_jordan(T, nn, e);
+            if (a.mode == 1) { Axx = Axx + e[0]; Ayx = Ayx + e[1]; Ayy = Axx; Axy = -Ayx; dx = e[2]; dy = e[3]; }
+            else { Axx = Axx + e[0]; Ayx = Ayx + e[1]; Axy = Axy + e[2]; Ayy = Ayy + e[3]; dx = e[4]; dy = e[5]; }
+            x2 = x2 + dx; y2 = y2 + dy;
+            convergence = fabsf(dx) < a.th && fabsf(dy) < a.th;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float ddx = cx[k] - (Axx * sxs[k] + Axy * sys[k] + x2), ddy = cy[k] - (Ayx * sxs[k] + Ayy * sys[k] + y2);
+                if (!(fabsf(ddx) < a.th_aff && fabsf(ddy) < a.th_aff)) convergence = false;
+            }
+        }
+        if (status == KLT_SMALL_DET) break;
+        iteration++;
+    } while (!convergence && iteration < a.max_iterations);
+
+    if (x2 - hw < 0.0f || nc - (x2 + hw) < one_plus_eps || y2 - hh < 0.0f || nr - (y2 + hh) < one_plus_eps) status = KLT_OOB;
+    if ((x2 - old_x2) > a.max_differ || (y2 - old_y2) > a.max_differ) status = KLT_OOB;
+    if (status == KLT_TRACKED) {
+        float s = 0.f;
+        for (int k = lane; k < n; k += 64) {
+            const float x = (float)(k % width - hw), y = (float)(k / width - hh);
+            const float mi = a.mode ? Axx * x + Axy * y : x, mj = a.mode ? Ayx * x + Ayy * y : y;
+            s = s + fabsf(bilinear_at(t_img, tw, x1 + x, y1 + y) - bilinear_at(a.i2, nc, x2 + mi, y2 + mj));
+        }
+        s = wave_sum(s);
+        if (s / (float)n > a.max_residue) status = KLT_LARGE_RESIDUE;
+    }
+    if (lane == 0) {
+        st.Axx = Axx; st.Ayx = Ayx; st.Axy = Axy; st.Ayy = Ayy;
+        if (status != KLT_TRACKED) {
+            after.x = -1.f; after.y = -1.f;
+            st.aff_x = -1.f; st.aff_y = -1.f; st.valid = 0;
+        }
+        after.val = status;                                  // translation position kept on success (:396-399)
+        a.out[f] = after;
+        a.rec[f] = st;
+    }
+}
+
+__global__ void affine_reset_kernel(klt_affine_rec *rec, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    klt_affine_rec r;
+    r.aff_x = -1.f; r.aff_y = -1.f; r.Axx = 1.f; r.Ayx = 0.f; r.Axy = 0.f; r.Ayy = 1.f; r.valid = 0; r.pad = 0;
+    rec[i] = r;
+}
+
+}  // namespace
+
+void launch_affine(hipStream_t s, const AffineArgs &a)
+{
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(affine_kernel, dim3(a.n), dim3(64), 0, s, a);
+}
+
+void launch_affine_reset(hipStream_t s, klt_affine_rec *rec, int n)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(affine_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rec, n);
+}

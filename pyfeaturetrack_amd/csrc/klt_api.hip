@@ -13,10 +13,10 @@
 namespace {
 
 enum Family { F_SMOOTH_GRAD, F_PYR_REDUCE, F_GRAD, F_SMOOTH_H, F_SMOOTH_V, F_PYR_H, F_PYR_V, F_GRAD_H, F_GRAD_V, F_TRACK,
-              F_SAT_ROWS, F_SAT_COLS, F_EIGEN, F_SORT, F_NMS, F_SEED, F_COUNT };
+              F_SAT_ROWS, F_SAT_COLS, F_EIGEN, F_SORT, F_NMS, F_SEED, F_AFFINE, F_COUNT };
 const char *const kFamilyName[F_COUNT] = {"smooth_grad_l0", "pyramid_reduce", "gradients", "smooth_h", "smooth_v", "pyramid_h",
                                           "pyramid_v", "gradient_h", "gradient_v", "track", "sat_rows", "sat_cols",
-                                          "eigen_keys", "sort", "nms", "seed_map"};
+                                          "eigen_keys", "sort", "nms", "seed_map", "affine_check"};
 
 struct Level { int nc = 0, nr = 0; float *img = nullptr, *gx = nullptr, *gy = nullptr; };
 
@@ -36,6 +36,8 @@ struct Slot {
 };
 
 struct FeatBuf { klt_feat *d = nullptr; int cap = 0; bool view = false; };
+
+struct AffState { klt_affine_rec *rec = nullptr; float *tpl = nullptr; int n = 0, tn = 0; };
 
 struct Timed { int fam; hipEvent_t a, b; double bytes; };
 
@@ -73,6 +75,9 @@ struct klt_ctx {
     size_t nms_slots_cap = 0;
     TrackPairDesc *pair_table = nullptr;
     size_t pair_table_cap = 0;
+    klt_affine_params ap{-1, 15, 15, 10, 10.f, 0.02f, 1.5f};      // klt.py:67-73 defaults
+    std::vector<AffState> aff;
+    int select_aff_state = -1;
     int *placed_d = nullptr;
     const float *last_sel[3] = {nullptr, nullptr, nullptr};
     int sel_nc = 0, sel_nr = 0, sel_nx = 0, sel_ny = 0, sel_npow2 = 0;
@@ -570,7 +575,8 @@ void klt_destroy(klt_ctx *c)
         if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
-    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->placed_d); hipFree(c->stats_d);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table);
+    for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -642,6 +648,11 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (!c) return KLT_ERR_ARG;
     if (option == KLT_OPT_FUSED_KERNELS) { c->use_fused = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SMOOTH_GRAD_VARIANT) { g_smooth_grad_variant = value; return KLT_OK; }
+    if (option == KLT_OPT_SELECT_AFFINE_STATE) {
+        if (value >= 0 && ((size_t)value >= c->aff.size() || !c->aff[value].rec)) return fail(c, KLT_ERR_STATE, "affine state not allocated");
+        c->select_aff_state = value;
+        return KLT_OK;
+    }
     if (option == KLT_OPT_TRACK_STREAM) {
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -846,6 +857,12 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     na.cell_magic = na.cell == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)na.cell) + 1u;
     if (int rc = ensure(c, c->nms_slots, c->nms_slots_cap, (size_t)n)) return rc;
     na.slots = c->nms_slots;
+    na.aff_rec = nullptr;
+    if (c->select_aff_state >= 0) {
+        AffState &as = c->aff[c->select_aff_state];
+        if (as.n < n) return fail(c, KLT_ERR_STATE, "affine state smaller than the feature list");
+        na.aff_rec = as.rec;
+    }
     na.gw = (nc + na.cell - 1) / na.cell; na.gh = (nr + na.cell - 1) / na.cell;
     if (d < 0) { na.gw = na.gh = 1; }
     const size_t grid_bytes = (size_t)na.gw * na.gh * sizeof(uint32_t);
@@ -993,6 +1010,96 @@ int klt_track(klt_ctx *c, int slot1, int slot2, klt_feat *inout, int n, int *n_t
     const int fi = 65534, fo = 65535;
     if (int rc = klt_featbuf_upload(c, fi, inout, n)) return rc;
     if (int rc = klt_track_async(c, slot1, slot2, fi, fo, n)) return rc;
+    if (int rc = klt_featbuf_download(c, fo, inout, n)) return rc;
+    if (n_tracked) {
+        int k = 0;
+        for (int i = 0; i < n; i++) k += inout[i].val >= 0;
+        *n_tracked = k;
+    }
+    return KLT_OK;
+}
+
+// ------------------------------------------------------------------------- affine consistency check
+int klt_set_affine_params(klt_ctx *c, const klt_affine_params *p)
+{
+    if (!c || !p) return fail(c, KLT_ERR_ARG, "null argument");
+    if (p->mode < -1 || p->mode > 2) return fail(c, KLT_ERR_ARG, "affineConsistencyCheck must be -1, 0, 1 or 2");
+    if (p->mode >= 0 && (p->window_width < 3 || p->window_height < 3 || !(p->window_width & 1) || !(p->window_height & 1) ||
+                         p->window_width > 63 || p->window_height > 63 || p->max_iterations < 1))
+        return fail(c, KLT_ERR_ARG, "affine window must be odd, 3..63; max_iterations >= 1");
+    if (c->ap.window_width != p->window_width || c->ap.window_height != p->window_height)
+        for (AffState &a : c->aff)
+            if (a.rec) return fail(c, KLT_ERR_STATE, "affine window cannot change while affine states exist");
+    c->ap = *p;
+    return KLT_OK;
+}
+
+int klt_affine_alloc(klt_ctx *c, int state, int n)
+{
+    if (!c || state < 0 || state > 4095 || n <= 0) return fail(c, KLT_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((size_t)state >= c->aff.size()) c->aff.resize(state + 1);
+    AffState &a = c->aff[state];
+    const int tn = (c->ap.window_width + 2) * (c->ap.window_height + 2);
+    if (a.n < n || a.tn != tn) {
+        if (a.rec) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(a.rec); hipFree(a.tpl); a.rec = nullptr; a.tpl = nullptr; }
+        HIPCHK(c, hipMalloc((void **)&a.rec, (size_t)n * sizeof(klt_affine_rec)));
+        HIPCHK(c, hipMalloc((void **)&a.tpl, (size_t)n * 3 * tn * sizeof(float)));
+        a.n = n;
+        a.tn = tn;
+    }
+    if (int rc = wait_tracker(c)) return rc;
+    launch_affine_reset(c->stream, a.rec, a.n);
+    HIPCHK(c, hipGetLastError());
+    return KLT_OK;
+}
+
+int klt_affine_download(klt_ctx *c, int state, klt_affine_rec *dst, int n)
+{
+    if (!c || !dst || state < 0 || (size_t)state >= c->aff.size() || !c->aff[state].rec || c->aff[state].n < n)
+        return fail(c, KLT_ERR_STATE, "affine state not allocated (or smaller than requested)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = wait_tracker(c)) return rc;
+    HIPCHK(c, hipMemcpyAsync(dst, c->aff[state].rec, (size_t)n * sizeof(klt_affine_rec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KLT_OK;
+}
+
+int klt_track_affine_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int n, int state)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (fb_in == fb_out) return fail(c, KLT_ERR_ARG, "the consistency check needs the records before and after: fb_in != fb_out");
+    if (c->ap.mode >= 0 && (state < 0 || (size_t)state >= c->aff.size() || !c->aff[state].rec || c->aff[state].n < n))
+        return fail(c, KLT_ERR_STATE, "affine state not allocated (klt_affine_alloc) or smaller than the feature list");
+    if (int rc = klt_track_async(c, slot1, slot2, fb_in, fb_out, n)) return rc;
+    if (c->ap.mode < 0 || n == 0) return KLT_OK;
+    Slot *s1 = &c->slots[slot1], *s2 = &c->slots[slot2];
+    AffState &as = c->aff[state];
+    AffineArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = c->fbs[fb_in].d; a.out = c->fbs[fb_out].d; a.rec = as.rec; a.tpl = as.tpl;
+    a.i1 = s1->lv[0].img; a.gx1 = s1->lv[0].gx; a.gy1 = s1->lv[0].gy;
+    a.i2 = s2->lv[0].img; a.gx2 = s2->lv[0].gx; a.gy2 = s2->lv[0].gy;
+    a.n = n; a.ncols = s1->nc; a.nrows = s1->nr; a.mode = c->ap.mode;
+    a.width = c->ap.window_width; a.height = c->ap.window_height; a.max_iterations = c->ap.max_iterations;
+    a.step = c->p.step_factor; a.small = c->p.min_determinant; a.th = c->p.min_displacement;
+    a.th_aff = c->ap.min_displacement; a.max_residue = c->ap.max_residue; a.max_differ = c->ap.max_displacement_differ;
+    {
+        TimerScope t(c, F_AFFINE, (double)n * 12.0 * (a.width + 1) * (a.height + 1) * 3, c->tstream);
+        launch_affine(c->tstream, a);
+    }
+    Slot *both[2] = {s1, s2};
+    if (int rc = tracker_end(c, both, 2)) return rc;
+    HIPCHK(c, hipGetLastError());
+    return KLT_OK;
+}
+
+int klt_track_affine(klt_ctx *c, int slot1, int slot2, klt_feat *inout, int n, int state, int *n_tracked)
+{
+    if (!c || !inout) return fail(c, KLT_ERR_ARG, "null argument");
+    const int fi = 65534, fo = 65535;
+    if (int rc = klt_featbuf_upload(c, fi, inout, n)) return rc;
+    if (int rc = klt_track_affine_async(c, slot1, slot2, fi, fo, n, state)) return rc;
     if (int rc = klt_featbuf_download(c, fo, inout, n)) return rc;
     if (n_tracked) {
         int k = 0;

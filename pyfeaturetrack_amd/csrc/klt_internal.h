@@ -55,6 +55,16 @@ struct TrackArgs {
     float small, th, step, max_residue, ss, inv_ss;
 };
 
+struct AffineArgs {
+    const klt_feat *in;      // records before the translation tracker (frame-1 positions)
+    klt_feat *out;           // records after it (updated in place)
+    klt_affine_rec *rec;     // per-feature state
+    float *tpl;              // [n][3][(height+2)*(width+2)] templates: image, gradx, grady
+    const float *i1, *gx1, *gy1, *i2, *gx2, *gy2;     // level 0 of the two frames
+    int n, ncols, nrows, mode, width, height, max_iterations;
+    float step, small, th, th_aff, max_residue, max_differ;
+};
+
 struct SelectArgs {
     const float *sat;        // 3 planes (gxx, gxy, gyy), each ncols*nrows
     float *valmap;           // [ny][nx]
@@ -70,6 +80,7 @@ struct NmsArgs {
     uint32_t *grid_global;   // used when the cell grid does not fit in LDS
     int *placed_out;
     int *slots;              // scratch [nfeat]: fillable slot indices (REPLACING_SOME)
+    klt_affine_rec *aff_rec; // optional: affine state reset for every slot filled (selectGoodFeatures.py:120-128)
     unsigned cell_magic;     // floor(2^32 / cell) + 1: x / cell == __umulhi(x, cell_magic) for x < 65536
     int nkeys, nfeat, overwrite_all, d /* mindist-1 */, cell, gw, gh, grid_in_lds;
 };
@@ -98,4 +109,6 @@ int  launch_nms(hipStream_t s, const NmsArgs &a);   // returns 0 or a hipError_t
 void launch_unpack_candidates(hipStream_t s, const unsigned long long *keys, int n, float *val, int *x, int *y);
 
 void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, int n, int nlevels, unsigned long long *stats);
-int launch_track(hipStream_t s, const TrackArgs &a);   // returns 0, or -1 for an unsupported window
+int launch_track(hipStream_t s, const TrackArgs &a);
+void launch_affine(hipStream_t s, const AffineArgs &a);
+void launch_affine_reset(hipStream_t s, klt_affine_rec *rec, int n);   // returns 0, or -1 for an unsupported window

@@ -372,6 +372,11 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(NmsArgs a)
                     ft.val = (int32_t)__uint_as_float((uint32_t)(k >> 32));      // int(val), selectGoodFeatures.py:119
                     ft.aux = 0;
                     a.fl[slot] = ft;
+                    if (a.aff_rec) {
+                        klt_affine_rec r;
+                        r.aff_x = -1.f; r.aff_y = -1.f; r.Axx = 1.f; r.Ayx = 0.f; r.Axy = 0.f; r.Ayy = 1.f; r.valid = 0; r.pad = 0;
+                        a.aff_rec[slot] = r;
+                    }
                     if (a.d >= 0) {
                         const uint32_t code = (((uint32_t)sx << 16) | (uint32_t)sy) + 1u;
                         uint32_t *cellp = &grid[cell_of(sy, a) * a.gw + cell_of(sx, a)];

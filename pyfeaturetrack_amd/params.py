@@ -1,5 +1,5 @@
 """KLT_TrackingContext -> klt_params (include/klt_gpu.h) and the three tap sets."""
-from ._abi import KltParams
+from ._abi import KltAffineParams, KltParams
 from .convolve import _computeKernels
 from .klt_util import KLTComputeSmoothSigma
 
@@ -45,3 +45,16 @@ def params_from_tc(tc):
 def taps_from_params(p):
     """[(gauss, deriv)] for smoothing, pyramid and gradient sigma (klt_set_kernels `which` 0, 1, 2)."""
     return [_computeKernels(p.smooth_sigma), _computeKernels(p.pyramid_sigma), _computeKernels(p.grad_sigma)]
+
+
+def affine_params_from_tc(tc):
+    """klt.py:67-73 -> klt_affine_params (mode -1 = consistency check off)."""
+    a = KltAffineParams()
+    a.mode = int(tc.affineConsistencyCheck)
+    a.window_width = int(tc.affine_window_width)
+    a.window_height = int(tc.affine_window_height)
+    a.max_iterations = int(tc.affine_max_iterations)
+    a.max_residue = float(tc.affine_max_residue)
+    a.min_displacement = float(tc.affine_min_displacement)
+    a.max_displacement_differ = float(tc.affine_max_displacement_differ)
+    return a

@@ -88,7 +88,14 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
         slot = slots[2]
         ctx.upload(slot, image_to_array(img))
     fl_in = features_to_array(featurelist) if mode == selectionMode.REPLACING_SOME else None
-    fl, _ = ctx.select(slot, len(featurelist), mode=mode, fl=fl_in, use_pyramid=reuse)
+    aff = getattr(tc, "_klt_affine_states", {}).get(id(featurelist))
+    if aff is not None and aff[1] == len(featurelist):
+        ctx.set_option(4, aff[0])       # newly placed features lose their affine templates (:120-128)
+    try:
+        fl, _ = ctx.select(slot, len(featurelist), mode=mode, fl=fl_in, use_pyramid=reuse)
+    finally:
+        if aff is not None:
+            ctx.set_option(4, -1)
     for feat, rec, old in zip(featurelist, fl, fl_in if fl_in is not None else fl):
         if mode == selectionMode.REPLACING_SOME and old["val"] >= 0:
             continue                # live features are left untouched (:109-110)

@@ -71,3 +71,26 @@ def synth_frame(width, height, seed, k, shift=DEFAULT_SHIFT, base=None):
 def synth_pair(width, height, seed, shift=DEFAULT_SHIFT):
     base = synth_base(width, height, seed)
     return shift_frame(base, 0.0, 0.0), shift_frame(base, shift[0], shift[1])
+
+
+def warp_frame(base, A, t=(0.0, 0.0)):
+    """uint8 frame whose content is `base` mapped by p -> c + A (p - c) + t about the frame centre c
+    (periodic texture, bilinear resampling).  Known answer for the affine consistency check: a feature at p in
+    `base` is found at c + A (p - c) + t, and its neighbourhood is deformed by the 2x2 matrix A."""
+    h, w = base.shape
+    A = np.asarray(A, np.float64)
+    Ai = np.linalg.inv(A)
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    dx, dy = xs - cx - t[0], ys - cy - t[1]
+    sx = Ai[0, 0] * dx + Ai[0, 1] * dy + cx          # source position in `base`
+    sy = Ai[1, 0] * dx + Ai[1, 1] * dy + cy
+    x0 = np.floor(sx)
+    y0 = np.floor(sy)
+    ax, ay = sx - x0, sy - y0
+    x0 = x0.astype(np.int64) % w
+    y0 = y0.astype(np.int64) % h
+    x1, y1 = (x0 + 1) % w, (y0 + 1) % h
+    out = (base[y0, x0] * ((1 - ax) * (1 - ay)) + base[y0, x1] * (ax * (1 - ay))
+           + base[y1, x0] * ((1 - ax) * ay) + base[y1, x1] * (ax * ay))
+    return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)

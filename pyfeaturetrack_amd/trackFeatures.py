@@ -23,6 +23,23 @@ class _ResidentPyramids:
         return "<device pyramid %s of slot %d, %dx%d>" % (self.which, self.slot, self.ncols[0], self.nrows[0])
 
 
+_DEVICE_TEMPLATE = "<template on device>"      # what feat.aff_img* hold while the device keeps the templates
+
+
+def _affine_state_of(tc, ctx, featurelist):
+    """Device affine-state id of a feature list (allocated on first use; the list object is the key, as the
+    reference keeps the state in the KLT_Feature objects of the list)."""
+    table = tc.__dict__.setdefault("_klt_affine_states", {})
+    key = id(featurelist)
+    entry = table.get(key)
+    if entry is None or entry[1] != len(featurelist):
+        sid = getattr(ctx, "_next_affine_state", 0)
+        ctx._next_affine_state = sid + 1
+        ctx.affine_alloc(sid, len(featurelist))
+        entry = table[key] = (sid, len(featurelist))
+    return entry[0]
+
+
 def _outOfBounds(x, y, ncols, nrows, borderx, bordery):
     """trackFeatures.py:140-141"""
     return x < borderx or x > ncols - 1 - borderx or y < bordery or y > nrows - 1 - bordery
@@ -37,9 +54,6 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
         print("(KLT) Tracking {0} features in a {1} by {2} image...  ".format(
             KLTCountRemainingFeatures(featurelist), ncols, nrows))
     _fix_window(tc)
-    if tc.affineConsistencyCheck >= 0:
-        raise NotImplementedError("affine consistency check: not implemented by the reference "
-                                  "(trackFeatures.py:347-399 raises NameError); planned, see DESIGN.md")
     ctx = default_context()
     ctx.configure(tc)
     s1, s2, _ = _slots_of(tc)
@@ -57,8 +71,23 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
         ctx.build_pyramids_batch([s1, s2])            # both frames share every kernel launch
 
     fl_in = features_to_array(featurelist)
-    fl_out, _ = ctx.track(s1, s2, fl_in)
-    for feat, old, new in zip(featurelist, fl_in, fl_out):
+    affine = tc.affineConsistencyCheck >= 0
+    if affine:
+        # The reference calls _am_trackFeatureAffine here but never defines it (trackFeatures.py:347-399); behaviour
+        # follows upstream KLT 1.3.4.  The per-feature templates / A matrices live on the device, keyed
+        # by the feature list object.
+        state = _affine_state_of(tc, ctx, featurelist)
+        fl_out, _ = ctx.track_affine(s1, s2, fl_in, state)
+        rec = ctx.affine_download(state, len(featurelist))
+    else:
+        fl_out, _ = ctx.track(s1, s2, fl_in)
+    for i, (feat, old, new) in enumerate(zip(featurelist, fl_in, fl_out)):
+        if affine and old["val"] >= 0:
+            r = rec[i]
+            feat.aff_x, feat.aff_y = float(r["aff_x"]), float(r["aff_y"])
+            feat.aff_Axx, feat.aff_Ayx, feat.aff_Axy, feat.aff_Ayy = (float(r["Axx"]), float(r["Ayx"]), float(r["Axy"]),
+                                                                      float(r["Ayy"]))
+            feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = (_DEVICE_TEMPLATE if r["valid"] else None)
         if old["val"] < 0:
             continue                                  # only live features are tracked (:253)
         if new["val"] == kltState.KLT_TRACKED:
