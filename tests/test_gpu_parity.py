@@ -141,6 +141,35 @@ def test_generic_path_and_batched_build(ctx, ko, cfg1, img0, img1):
                 assert_same(ctx.download_level(slot, pi, l), cfg1["%s_%s_%d" % (name, w, l)], "batched %s %s %d" % (name, w, l))
 
 
+@pytest.mark.parametrize("attrs,window,levels,ss", [({"grad_sigma": 1.5}, 7, 2, 4), ({"grad_sigma": 0.7}, 7, 3, 2),
+                                                     ({"smooth_sigma_fact": 0.3}, 7, 2, 2), ({}, 21, 2, 4),
+                                                     ({"pyramid_sigma_fact": 0.6}, 7, 3, 4), ({"grad_sigma": 2.2}, 9, 2, 8)])
+def test_unusual_sigmas_take_the_runtime_sized_kernels(ctx, ko, attrs, window, levels, ss):
+    """Tap counts other than 5 / 21 / 7+7 fall back to the runtime-sized LDS kernels (or the generic two-pass ones);
+    results stay bit-identical to the oracle, selection and tracking included."""
+    from pyfeaturetrack_amd import synth
+    base = synth.synth_base(300, 220, 21)
+    f0, f1 = synth.shift_frame(base, 0, 0), synth.shift_frame(base, 1.4, 0.9)
+    tc = make_tc(levels=levels, ss=ss, window=window, max_residue=20.0, **attrs)
+    tc.KLTUpdateTCBorder()
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(0, f0)
+    ctx.upload(1, f1)
+    ctx.build_pyramids_batch([0, 1])
+    P0, P1 = ko.Pyramids(p, f0.astype(np.float32)), ko.Pyramids(p, f1.astype(np.float32))
+    for l in range(levels):
+        for pi, w in enumerate(("img", "gx", "gy")):
+            assert_same(ctx.download_level(1, pi, l), P1.level(w, l), "%s level %d %s" % (attrs, l, w))
+    if 2 * tc.borderx + 20 < 300 and 2 * tc.bordery + 20 < 220:
+        fl, _ = ctx.select(0, 30, use_pyramid=True)
+        ofl = ko.select_good_features(p, f0.astype(np.float32), 30)
+        assert_feats(fl, *oracle_feats(ofl), what="%s select" % attrs)
+        out, _ = ctx.track(0, 1, fl)
+        ko.track_features(p, P0, P1, ofl)
+        assert_feats(out, *oracle_feats(ofl), what="%s track" % attrs)
+
+
 def test_one_sample_per_thread_variant(ctx, cfg1, img0):
     """KLT_OPT_SMOOTH_GRAD_VARIANT=1: the non-register-blocked LDS kernels stay bit-identical too."""
     ctx.configure(make_tc())
