@@ -87,12 +87,75 @@ def cpu_baseline(p, f0, f1, fl):
             "sample": "%d x (pyramids of both 1920x1080 frames + track 5000 features), oracle/klt_oracle.c, 1 thread" % reps}
 
 
+def run_cfg4(args, json_fd):
+    """BASELINE cfg-4 (not the headline line): a shard of independent 1280x720 pairs, 2000 features each, 7x7,
+    3 levels / ss 4.  One batched pyramid build (frames share launches through blockIdx.z) and ONE tracker launch
+    per step; shows what the kernels do when the grids are large."""
+    pairs, w, h, nf = args.pairs, 1280, 720, 2000
+    tc = cfg2_context()
+    p = params_from_tc(tc)
+    ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    ctx.set_params(p)
+    for i in range(pairs):
+        f0, f1 = synth.synth_pair(w, h, seed=i)
+        ctx.upload(2 * i, f0)
+        ctx.upload(2 * i + 1, f1)
+    slots = list(range(2 * pairs))
+    ctx.build_pyramids_batch(slots, sync=True)
+    for i in range(pairs):
+        ctx.select_async(2 * i, 1, True, 2 * i, nf)
+    ctx.sync()
+    table = [(2 * i, 2 * i + 1, 2 * i, 2 * i + 1) for i in range(pairs)]
+
+    def step():
+        ctx.build_pyramids_batch(slots)
+        ctx.track_batch_async(table, nf)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    ctx.track_stats_reset()
+    ctx.timing_enable(True)
+    for _ in range(args.steps):
+        step()
+    kernels = ctx.timing_read()
+    ctx.timing_enable(False)
+    st = ctx.track_stats()
+    st = {k: ([x / (args.steps * pairs) for x in v] if isinstance(v, list) else v / (args.steps * pairs)) for k, v in st.items()}
+    pyr_bytes, track_bytes = algorithmic_bytes(p, w, h, st, nf)
+    step_bytes = pairs * (2 * pyr_bytes + track_bytes)
+    tracked = sum(int(np.count_nonzero(ctx.featbuf_download(2 * i + 1, nf)["val"] >= 0)) for i in range(pairs))
+    line = {"metric": "features tracked/sec", "value": pairs * nf * args.steps / elapsed, "unit": "features/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_frame_pair": elapsed / args.steps / pairs * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (convolutions accumulate in f64)", "data": "synthetic",
+            "config": {"workload": "cfg-4 shard: %d independent 1280x720 pairs per step, 2000 features each, 7x7, 3 levels "
+                                   "(subsampling 4); batched pyramid build + one tracker launch" % pairs,
+                       "pairs_per_step": pairs, "tracked": tracked},
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "step_algorithmic_bytes": step_bytes,
+                         "achieved": step_bytes / elapsed * args.steps / 1e9,
+                         "frac": step_bytes / elapsed * args.steps / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernels": {k["name"]: {"us_per_launch": 1e3 * k["total_ms"] / k["launches"],
+                                                 "launches_per_step": k["launches"] / args.steps} for k in kernels}},
+            "cpu_baseline": None}
+    ctx.close()
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["cfg2", "cfg4"], default="cfg2",
+                    help="cfg2 (default, the headline line) or cfg4 (a shard of 1280x720 pairs, single GPU, informative)")
+    ap.add_argument("--pairs", type=int, default=32, help="pairs per step for --config cfg4")
     ap.add_argument("--pipeline", action="store_true",
                     help="KLT_OPT_TRACK_STREAM: tracker on a second HIP stream, overlapping the next step's pyramid build "
                          "(measured slower on MI355X for this step size: event cost > overlap gain; DESIGN.md)")
@@ -103,6 +166,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    if args.config == "cfg4":
+        return run_cfg4(args, json_fd)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -483,7 +483,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                     }
                 }
             }
-            const bool merged = fused_grad_ok(c) && merged_grad_ok(c) && B * (s0->nlev - 1) <= KLT_MAX_BATCH;
+            const bool merged = fused_grad_ok(c) && merged_grad_ok(c) && B * (s0->nlev - 1) <= KLT_MAX_BATCH && s0->nc / s0->ss <= 32767 && s0->nr / s0->ss <= 32767;
             if (merged) continue;          // gradients of all levels >= 1 go out in one launch below
             if (fused_grad_ok(c)) {
                 for (int b = 0; b < B; b++) { src[b] = g[b]->lv[l].img; gx[b] = g[b]->lv[l].gx; gy[b] = g[b]->lv[l].gy; }
@@ -492,7 +492,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                 for (int b = 0; b < B; b++) enqueue_gradients(c, g[b]->lv[l].img, ld.nc, ld.nr, g[b]->lv[l].gx, g[b]->lv[l].gy);
             }
         }
-        if (s0->nlev > 1 && fused_grad_ok(c) && merged_grad_ok(c) && B * (s0->nlev - 1) <= KLT_MAX_BATCH) {
+        if (s0->nlev > 1 && fused_grad_ok(c) && merged_grad_ok(c) && B * (s0->nlev - 1) <= KLT_MAX_BATCH && s0->nc / s0->ss <= 32767 && s0->nr / s0->ss <= 32767) {
             // one launch for the gradients of every level >= 1 of every frame: entry = (frame, level), per-entry geometry
             SmoothGradArgs a;
             std::memset(&a, 0, sizeof(a));
