@@ -88,6 +88,10 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
 /* affine state (klt_affine_alloc id, or -1) whose records klt_select* resets for every slot it fills
  * (selectGoodFeatures.py:120-128 clears the aff_* fields of a newly placed feature) */
 #define KLT_OPT_SELECT_AFFINE_STATE 4
+/* 1 (default): klt_select* sorts only the highest-scoring candidates (histogram threshold keeping >= 64 per requested
+ * feature) and falls back to the full sort if the greedy walk runs off their end; 0: always the full sort.  With the
+ * prefilter klt_select_async reads two small results back and therefore synchronises internally. */
+#define KLT_OPT_TOPK_PREFILTER 5
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
 /* ---- parameters and taps ------------------------------------------------------------------- */

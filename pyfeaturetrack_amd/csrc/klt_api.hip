@@ -73,6 +73,14 @@ struct klt_ctx {
     size_t grid_cap = 0;
     int *nms_slots = nullptr;
     size_t nms_slots_cap = 0;
+    unsigned long long *keys2 = nullptr;      // compacted top-K keys
+    size_t keys2_cap = 0;
+    unsigned *topk_hist = nullptr;            // 8192 bins + 4 words of info
+    klt_feat *fl_snapshot = nullptr;
+    size_t fl_snapshot_cap = 0;
+    bool use_topk = true;
+    const unsigned long long *sorted_keys = nullptr;   // what the last selection walked (test hook)
+    int sorted_count = 0;
     TrackPairDesc *pair_table = nullptr;
     size_t pair_table_cap = 0;
     klt_affine_params ap{-1, 15, 15, 10, 10.f, 0.02f, 1.5f};      // klt.py:67-73 defaults
@@ -549,7 +557,7 @@ int klt_create(int device, klt_ctx **out)
     c->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void **)&c->stats_d, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->placed_d, sizeof(int))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->placed_d, 2 * sizeof(int))) != hipSuccess ||
         (e = hipMemset(c->stats_d, 0, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_track, hipEventDisableTiming)) != hipSuccess) {
@@ -575,7 +583,7 @@ void klt_destroy(klt_ctx *c)
         if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
-    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
@@ -648,6 +656,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (!c) return KLT_ERR_ARG;
     if (option == KLT_OPT_FUSED_KERNELS) { c->use_fused = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SMOOTH_GRAD_VARIANT) { g_smooth_grad_variant = value; return KLT_OK; }
+    if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_AFFINE_STATE) {
         if (value >= 0 && ((size_t)value >= c->aff.size() || !c->aff[value].rec)) return fail(c, KLT_ERR_STATE, "affine state not allocated");
         c->select_aff_state = value;
@@ -848,11 +857,10 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     sa.ncols = nc; sa.nrows = nr; sa.bx = bx; sa.by = by; sa.step = step; sa.nx = nx; sa.ny = ny;
     sa.hw = hw; sa.hh = hh; sa.npow2 = (int)npow2;
     { TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8)); launch_eigen(c->stream, sa); }
-    { TimerScope t(c, F_SORT, (double)npow2 * 16); launch_sort_desc(c->stream, c->keys, (int)npow2); }
-
     NmsArgs na;
-    na.keys = c->keys; na.fl = b->d; na.placed_out = c->placed_d;
-    na.nkeys = (int)(ncand < npow2 ? ncand : npow2); na.nfeat = n; na.overwrite_all = (mode == KLT_SELECTING_ALL);
+    std::memset(&na, 0, sizeof(na));
+    na.fl = b->d; na.placed_out = c->placed_d;
+    na.nfeat = n; na.overwrite_all = (mode == KLT_SELECTING_ALL);
     na.d = d; na.cell = d >= 0 ? d + 1 : 1;
     na.cell_magic = na.cell == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)na.cell) + 1u;
     if (int rc = ensure(c, c->nms_slots, c->nms_slots_cap, (size_t)n)) return rc;
@@ -870,14 +878,52 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     na.grid_global = nullptr;
     if (!na.grid_in_lds) {
         if (int rc = ensure(c, c->grid, c->grid_cap, (size_t)na.gw * na.gh)) return rc;
-        HIPCHK(c, hipMemsetAsync(c->grid, 0, grid_bytes, c->stream));
         na.grid_global = c->grid;
     }
-    {
+    auto run_nms = [&](const unsigned long long *keys, int nkeys) -> int {
+        na.keys = keys;
+        na.nkeys = nkeys;
+        if (!na.grid_in_lds) HIPCHK(c, hipMemsetAsync(c->grid, 0, grid_bytes, c->stream));
         TimerScope t(c, F_NMS, (double)n * 16);
         const int e = launch_nms(c->stream, na);
         if (e) return fail(c, KLT_ERR_DEVICE, std::string("nms launch: ") + hipGetErrorString((hipError_t)e));
+        return 0;
+    };
+
+    // top-K prefilter: sort only the candidates the greedy walk can plausibly reach (one small D2H read-back)
+    long long target = 64LL * n;
+    if (target < 65536) target = 65536;
+    if (c->use_topk && ncand > 262144 && target < ncand / 2) {
+        if (int rc = ensure(c, c->keys2, c->keys2_cap, (size_t)npow2)) return rc;
+        size_t hcap = c->topk_hist ? 8192 + 4 : 0;
+        if (int rc = ensure(c, c->topk_hist, hcap, (size_t)8192 + 4)) return rc;
+        if (int rc = ensure(c, c->fl_snapshot, c->fl_snapshot_cap, (size_t)n)) return rc;
+        HIPCHK(c, hipMemsetAsync(c->topk_hist, 0, (8192 + 4) * sizeof(unsigned), c->stream));
+        unsigned info[4] = {0, 0, 0, 0};
+        {
+            TimerScope t(c, F_SORT, (double)ncand * 16);
+            launch_topk_prefilter(c->stream, c->keys, (int)ncand, (unsigned)target, c->topk_hist, c->topk_hist + 8192, c->keys2);
+        }
+        HIPCHK(c, hipMemcpyAsync(info, c->topk_hist + 8192, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const long long kept = info[3], valid = info[2];
+        long long np2 = 2048;
+        while (np2 < kept) np2 <<= 1;
+        if (kept < np2) HIPCHK(c, hipMemsetAsync(c->keys2 + kept, 0, (size_t)(np2 - kept) * sizeof(unsigned long long), c->stream));
+        { TimerScope t(c, F_SORT, (double)np2 * 16); launch_sort_desc(c->stream, c->keys2, (int)np2); }
+        HIPCHK(c, hipMemcpyAsync(c->fl_snapshot, b->d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+        if (int rc = run_nms(c->keys2, (int)kept)) return rc;
+        c->sorted_keys = c->keys2; c->sorted_count = (int)kept;
+        int res[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(res, c->placed_d, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!(res[1] && kept < valid)) { HIPCHK(c, hipGetLastError()); return KLT_OK; }
+        // the kept candidates ran out before the list was full: restore the list and take the full sort
+        HIPCHK(c, hipMemcpyAsync(b->d, c->fl_snapshot, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
     }
+    { TimerScope t(c, F_SORT, (double)npow2 * 16); launch_sort_desc(c->stream, c->keys, (int)npow2); }
+    if (int rc = run_nms(c->keys, (int)(ncand < npow2 ? ncand : npow2))) return rc;
+    c->sorted_keys = c->keys; c->sorted_count = (int)(ncand < npow2 ? ncand : npow2);
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -1181,10 +1227,11 @@ int klt_download_sorted_candidates(klt_ctx *c, float *val, int32_t *x, int32_t *
 {
     if (!c || !val || !x || !y || n < 0) return fail(c, KLT_ERR_ARG, "bad argument");
     if (c->sel_nc == 0) return fail(c, KLT_ERR_STATE, "no selection has run");
-    if (n > c->sel_npow2) n = c->sel_npow2;
-    std::vector<unsigned long long> h((size_t)n);
+    if (!c->sorted_keys) return fail(c, KLT_ERR_STATE, "no selection has run");
+    if (n > c->sorted_count) n = c->sorted_count;
+    std::vector<unsigned long long> h((size_t)(n > 0 ? n : 1));
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(h.data(), c->keys, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->sorted_keys, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int k = 0;
     for (; k < n && h[k] != 0ull; k++) {

@@ -78,7 +78,7 @@ struct NmsArgs {
     const unsigned long long *keys;
     klt_feat *fl;
     uint32_t *grid_global;   // used when the cell grid does not fit in LDS
-    int *placed_out;
+    int *placed_out;         // [0] features placed, [1] 1 if the candidates ran out before the list was full
     int *slots;              // scratch [nfeat]: fillable slot indices (REPLACING_SOME)
     klt_affine_rec *aff_rec; // optional: affine state reset for every slot filled (selectGoodFeatures.py:120-128)
     unsigned cell_magic;     // floor(2^32 / cell) + 1: x / cell == __umulhi(x, cell_magic) for x < 65536
@@ -105,6 +105,8 @@ void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows);
 void launch_seed_fill(hipStream_t s, const klt_feat *fl, int nfeat, uint8_t *seedmap, int ncols, int nrows, int d);
 void launch_eigen(hipStream_t s, const SelectArgs &a);
 void launch_sort_desc(hipStream_t s, unsigned long long *keys, int npow2);
+void launch_topk_prefilter(hipStream_t s, const unsigned long long *keys, int n, unsigned target, unsigned *hist,
+                           unsigned *info /* [0] bin, [1] kept (histogram), [2] valid, [3] compaction counter */, unsigned long long *out);
 int  launch_nms(hipStream_t s, const NmsArgs &a);   // returns 0 or a hipError_t
 void launch_unpack_candidates(hipStream_t s, const unsigned long long *keys, int n, float *val, int *x, int *y);
 

@@ -511,6 +511,27 @@ def test_rccl_path_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["tracked"] > 4500
 
 
+def test_topk_prefilter_and_its_fallback(ctx, ko):
+    """At 1080p only the best candidates are sorted (KLT_OPT_TOPK_PREFILTER).  Same result as the full sort; when the
+    greedy walk needs more candidates than were kept (large mindist, more features than fit) the full sort takes over."""
+    from pyfeaturetrack_amd import synth
+    f0 = synth.synth_frame(1920, 1080, 6, 0)
+    for mindist, n in ((10, 5000), (60, 4000), (25, 1500)):
+        tc = make_tc(levels=3, ss=4, mindist=mindist)
+        ctx.configure(tc)
+        ctx.upload(0, f0)
+        ofl = ko.select_good_features(params_from_tc(tc), f0.astype(np.float32), n)
+        fl, placed = ctx.select(0, n)
+        assert placed == int(np.count_nonzero(ofl["val"] >= 0))
+        assert_feats(fl, *oracle_feats(ofl), what="prefiltered select mindist=%d n=%d" % (mindist, n))
+        try:
+            ctx.set_option(5, 0)
+            fl2, _ = ctx.select(0, n)
+        finally:
+            ctx.set_option(5, 1)
+        assert_feats(fl2, *oracle_feats(ofl), what="full-sort select mindist=%d n=%d" % (mindist, n))
+
+
 def test_nms_global_grid_path(ctx, ko):
     """mindist 2 at 1920x1080 -> the cell grid (960x540 u32) exceeds LDS and lives in global memory"""
     from pyfeaturetrack_amd import synth
