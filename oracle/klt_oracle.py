@@ -35,7 +35,13 @@ def lib():
         build()
         _lib = C.CDLL(_LIB)
         _lib.ko_abs_sum_f32.restype = C.c_float
+        _lib.ko_set_threads(1)           # single-threaded unless a caller asks otherwise
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads of the oracle (results do not depend on it); returns the count in effect."""
+    return int(lib().ko_set_threads(int(n)))
 
 
 def _fp(a):
