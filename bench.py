@@ -65,6 +65,27 @@ def algorithmic_bytes(p, ncols, nrows, stats, nfeat):
     return pyr, track
 
 
+def usable_cores(cap=32):
+    """Cores this process can really run on: scheduler affinity, clipped by the cgroup CPU quota and by `cap`."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(p, f0, f1, fl):
     """Oracle timed on the host: bounded sample of the same workload (about 10-20 s of CPU work)."""
     from oracle import klt_oracle as ko
@@ -83,13 +104,14 @@ def cpu_baseline(p, f0, f1, fl):
     for _ in range(reps):
         one_pair()
     dt = (time.perf_counter() - t) / reps
-    # the same port on all host cores (OpenMP over image lines / features; bit-identical results)
-    ncores = ko.set_threads(os.cpu_count() or 1)
-    one_pair()
-    reps_all = int(max(2, min(80, 5.0 / max(dt / max(ncores, 1) * 2, 1e-3))))
+    # the same port on the host cores this process may actually use (OpenMP over image lines / features;
+    # bit-identical results).  Time-bounded: a container with a CPU quota can make many threads slower than one.
+    ncores = ko.set_threads(usable_cores())
     t = time.perf_counter()
-    for _ in range(reps_all):
+    reps_all = 0
+    while reps_all < 40 and (reps_all < 2 or time.perf_counter() - t < 4.0) and time.perf_counter() - t < 20.0:
         one_pair()
+        reps_all += 1
     dt_all = (time.perf_counter() - t) / reps_all
     ko.set_threads(1)
     return {"value": NFEAT / dt, "unit": "features/s", "cores": 1, "kind": "port",
