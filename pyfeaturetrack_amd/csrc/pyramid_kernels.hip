@@ -479,8 +479,8 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
     }
 }
 
-// f64 copies in LDS: every source sample is widened once when the tile is loaded instead of once per tap, and the
-// f32-rounded horizontal result is kept as the double it widens to -- the FP64 pipe is the bottleneck of these kernels.
+// The f32-rounded horizontal result is kept in LDS as the double it widens to (one widening per sample instead of one
+// per tap of the vertical pass); the source tile stays f32 (an f64 tile was measured slower: half the LDS matters more).
 template <int NT, int STRIDE>
 __device__ __forceinline__ float correlate_sym_f64(const double *c, const TapRegs<NT> &t)
 {
@@ -491,15 +491,16 @@ __device__ __forceinline__ float correlate_sym_f64(const double *c, const TapReg
     return (float)acc;
 }
 
-template <int SS, int NT, int NTHR>
+// TS = element type of the source tile in LDS: double (widened once at load) or float (half the LDS, widened per tap)
+template <int SS, int NT, int NTHR, typename TS>
 __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
 {
     constexpr int r = NT / 2;
     constexpr int SW = (OW - 1) * SS + 2 * r + 1, SH = (OH - 1) * SS + 2 * r + 1;
     constexpr int PW = (SW + SS - 1) / SS, ROWLEN = PW * SS;
     extern __shared__ __attribute__((aligned(16))) double dlds[];
-    double *const S = dlds;                  // [SH][SS planes][PW]
-    double *const Hd = dlds + SH * ROWLEN;   // [SH][OW]
+    double *const Hd = dlds;                                     // [SH][OW]
+    TS *const S = reinterpret_cast<TS *>(dlds + SH * OW);        // [SH][SS planes][PW]
     const int tid = threadIdx.x, b = blockIdx.z;
     const int xs0 = blockIdx.x * OW, ys0 = blockIdx.y * OH;
     const int gx0 = xs0 * SS + SS / 2 - r, gy0 = ys0 * SS + SS / 2 - r;
@@ -516,30 +517,30 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
         const int gy = reflect_fast(gy0 + rr, nr);
         const float *row = src + (size_t)gy * nc;
         const int x = gx0 + 4 * q;
-        double *dst = S + rr * ROWLEN;
+        TS *dst = S + rr * ROWLEN;
         if (quads && x >= 0 && x + 3 < nc && 4 * q + 3 < SW) {
             const float4 v = *reinterpret_cast<const float4 *>(row + x);
-            dst[((4 * q) % SS) * PW + (4 * q) / SS] = (double)v.x;
-            dst[((4 * q + 1) % SS) * PW + (4 * q + 1) / SS] = (double)v.y;
-            dst[((4 * q + 2) % SS) * PW + (4 * q + 2) / SS] = (double)v.z;
-            dst[((4 * q + 3) % SS) * PW + (4 * q + 3) / SS] = (double)v.w;
+            dst[((4 * q) % SS) * PW + (4 * q) / SS] = (TS)v.x;
+            dst[((4 * q + 1) % SS) * PW + (4 * q + 1) / SS] = (TS)v.y;
+            dst[((4 * q + 2) % SS) * PW + (4 * q + 2) / SS] = (TS)v.z;
+            dst[((4 * q + 3) % SS) * PW + (4 * q + 3) / SS] = (TS)v.w;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int c = 4 * q + e;
-                if (c < SW) dst[(c % SS) * PW + c / SS] = (double)row[reflect_fast(gx0 + c, nc)];
+                if (c < SW) dst[(c % SS) * PW + c / SS] = (TS)row[reflect_fast(gx0 + c, nc)];
             }
         }
     }
     __syncthreads();
     for (int i = tid; i < SH * OW; i += NTHR) {
         const int rr = i / OW, xs = i % OW;
-        const double *row = S + rr * ROWLEN + xs;        // column xs*SS + r + j lives at plane (r+j)%SS, index xs + (r+j)/SS
-        double acc = row[(r % SS) * PW + r / SS] * k.k[r];
+        const TS *row = S + rr * ROWLEN + xs;            // column xs*SS + r + j lives at plane (r+j)%SS, index xs + (r+j)/SS
+        double acc = (double)row[(r % SS) * PW + r / SS] * k.k[r];
 #pragma unroll
         for (int jj = -r; jj < 0; jj++) {
-            const double lo = row[((r + jj) % SS) * PW + (r + jj) / SS];
-            const double hi = row[((r - jj) % SS) * PW + (r - jj) / SS];
+            const double lo = (double)row[((r + jj) % SS) * PW + (r + jj) / SS];
+            const double hi = (double)row[((r - jj) % SS) * PW + (r - jj) / SS];
             acc = acc + (lo + hi) * k.k[r + jj];
         }
         Hd[i] = (double)(float)acc;                      // the f32 rounding between the passes
@@ -553,13 +554,22 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
     }
 }
 
-template <int SS, int NT>
+template <int SS, int NT, typename TS>
 constexpr size_t pyr_reduce_fast_lds()
 {
     constexpr int r = NT / 2;
     constexpr int SW = (OW - 1) * SS + 2 * r + 1, SH = (OH - 1) * SS + 2 * r + 1;
     constexpr int PW = (SW + SS - 1) / SS;
-    return sizeof(double) * (size_t)(SH * PW * SS + SH * OW);
+    return sizeof(double) * (size_t)(SH * OW) + sizeof(TS) * (size_t)(SH * PW * SS);
+}
+
+template <int SS, int NT, int NTHR, typename TS>
+static int launch_pyr_reduce_fast(hipStream_t s, const PyrReduceArgs &a, dim3 grid)
+{
+    constexpr size_t l = pyr_reduce_fast_lds<SS, NT, TS>();
+    if (int e = set_lds(pyr_reduce_fast<SS, NT, NTHR, TS>, l)) return e;
+    hipLaunchKernelGGL((pyr_reduce_fast<SS, NT, NTHR, TS>), grid, dim3(NTHR), l, s, a);
+    return 0;
 }
 
 }  // namespace
@@ -646,18 +656,10 @@ int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch)
 {
     const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch), block(256);
     if (a.taps.sym == 1) {
-        if (a.ss == 4 && a.taps.n == 21) {
-            constexpr size_t l = pyr_reduce_fast_lds<4, 21>();
-            if (int e = set_lds(pyr_reduce_fast<4, 21, 1024>, l)) return e;
-            hipLaunchKernelGGL((pyr_reduce_fast<4, 21, 1024>), grid, dim3(1024), l, s, a);
-            return 0;
-        }
-        if (a.ss == 2 && a.taps.n == 11) {
-            constexpr size_t l = pyr_reduce_fast_lds<2, 11>();
-            if (int e = set_lds(pyr_reduce_fast<2, 11, 512>, l)) return e;
-            hipLaunchKernelGGL((pyr_reduce_fast<2, 11, 512>), grid, dim3(512), l, s, a);
-            return 0;
-        }
+        // measured at cfg-2 (us per launch, two frames, both levels averaged): f32 tile / 1024 threads 11.6,
+        // f64 tile / 1024 threads 12.4, f32 / 512 14.1, f64 / 512 15.4 (profiles/README.md)
+        if (a.ss == 4 && a.taps.n == 21) return launch_pyr_reduce_fast<4, 21, 1024, float>(s, a, grid);
+        if (a.ss == 2 && a.taps.n == 11) return launch_pyr_reduce_fast<2, 11, 512, float>(s, a, grid);
     }
     const size_t lds = pyr_reduce_lds_bytes(a.ss, a.taps.n);
     if (int e = set_lds(pyr_reduce_kernel, lds)) return e;
