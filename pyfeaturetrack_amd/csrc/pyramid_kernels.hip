@@ -28,6 +28,9 @@ namespace {
 
 constexpr int TW = 64, TH = 16;        // output tile of smooth_grad_kernel
 constexpr int OW = 32, OH = 8;         // output tile of pyr_reduce_kernel
+}
+constexpr int OW_DEFAULT = 32, OH_DEFAULT = 8;
+namespace {
 constexpr int FTH = 16;                // tile height of the compile-time specialised smooth_grad kernels
 
 __device__ __forceinline__ int reflect_idx(int i, int n)
@@ -492,7 +495,7 @@ __device__ __forceinline__ float correlate_sym_f64(const double *c, const TapReg
 }
 
 // TS = element type of the source tile in LDS: double (widened once at load) or float (half the LDS, widened per tap)
-template <int SS, int NT, int NTHR, typename TS>
+template <int SS, int NT, int NTHR, typename TS, int OW = ::OW_DEFAULT, int OH = ::OH_DEFAULT>
 __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
 {
     constexpr int r = NT / 2;
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
     }
 }
 
-template <int SS, int NT, typename TS>
+template <int SS, int NT, typename TS, int OW, int OH>
 constexpr size_t pyr_reduce_fast_lds()
 {
     constexpr int r = NT / 2;
@@ -563,12 +566,13 @@ constexpr size_t pyr_reduce_fast_lds()
     return sizeof(double) * (size_t)(SH * OW) + sizeof(TS) * (size_t)(SH * PW * SS);
 }
 
-template <int SS, int NT, int NTHR, typename TS>
-static int launch_pyr_reduce_fast(hipStream_t s, const PyrReduceArgs &a, dim3 grid)
+template <int SS, int NT, int NTHR, typename TS, int OW, int OH>
+static int launch_pyr_reduce_fast(hipStream_t s, const PyrReduceArgs &a, int batch)
 {
-    constexpr size_t l = pyr_reduce_fast_lds<SS, NT, TS>();
-    if (int e = set_lds(pyr_reduce_fast<SS, NT, NTHR, TS>, l)) return e;
-    hipLaunchKernelGGL((pyr_reduce_fast<SS, NT, NTHR, TS>), grid, dim3(NTHR), l, s, a);
+    constexpr size_t l = pyr_reduce_fast_lds<SS, NT, TS, OW, OH>();
+    if (int e = set_lds(pyr_reduce_fast<SS, NT, NTHR, TS, OW, OH>, l)) return e;
+    const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch);
+    hipLaunchKernelGGL((pyr_reduce_fast<SS, NT, NTHR, TS, OW, OH>), grid, dim3(NTHR), l, s, a);
     return 0;
 }
 
@@ -658,8 +662,9 @@ int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch)
     if (a.taps.sym == 1) {
         // measured at cfg-2 (us per launch, two frames, both levels averaged): f32 tile / 1024 threads 11.6,
         // f64 tile / 1024 threads 12.4, f32 / 512 14.1, f64 / 512 15.4 (profiles/README.md)
-        if (a.ss == 4 && a.taps.n == 21) return launch_pyr_reduce_fast<4, 21, 1024, float>(s, a, grid);
-        if (a.ss == 2 && a.taps.n == 11) return launch_pyr_reduce_fast<2, 11, 512, float>(s, a, grid);
+        // tile shapes 64x8, 32x16, 32x4 and 16x16 were measured too: 32x8 is the fastest (profiles/README.md)
+        if (a.ss == 4 && a.taps.n == 21) return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 8>(s, a, batch);
+        if (a.ss == 2 && a.taps.n == 11) return launch_pyr_reduce_fast<2, 11, 512, float, 32, 8>(s, a, batch);
     }
     const size_t lds = pyr_reduce_lds_bytes(a.ss, a.taps.n);
     if (int e = set_lds(pyr_reduce_kernel, lds)) return e;
