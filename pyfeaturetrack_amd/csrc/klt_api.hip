@@ -25,7 +25,7 @@ struct Slot {
     int raw_kind = 0;                 // 0 none, 1 u8, 2 f32
     uint8_t *u8 = nullptr;
     float *f32 = nullptr;
-    size_t raw_cap = 0;               // pixels
+    size_t u8_cap = 0, f32_cap = 0;   // pixels
     float *planes = nullptr;          // 3 pyramids, level-concatenated
     size_t planes_cap = 0;            // floats
     Level lv[KLT_MAX_LEVELS];
@@ -157,11 +157,19 @@ int drain_timers(klt_ctx *c)
     return 0;
 }
 
+// both streams idle: required before freeing anything a queued kernel may still use
+int sync_all(klt_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->tstream && c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
+    return 0;
+}
+
 template <typename T>
 int ensure(klt_ctx *c, T *&ptr, size_t &cap, size_t want)
 {
     if (want <= cap && ptr) return 0;
-    if (ptr) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(ptr)); ptr = nullptr; cap = 0; }
+    if (ptr) { if (int rc = sync_all(c)) return rc; HIPCHK(c, hipFree(ptr)); ptr = nullptr; cap = 0; }
     HIPCHK(c, hipMalloc((void **)&ptr, want * sizeof(T)));
     cap = want;
     return 0;
@@ -170,7 +178,7 @@ int ensure(klt_ctx *c, T *&ptr, size_t &cap, size_t want)
 int ensure_tmp(klt_ctx *c, size_t pixels)
 {
     if (pixels <= c->tmp_cap && c->tmpA) return 0;
-    if (c->tmpA) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->tmpA); hipFree(c->tmpB); c->tmpA = c->tmpB = nullptr; }
+    if (c->tmpA) { if (int rc = sync_all(c)) return rc; hipFree(c->tmpA); hipFree(c->tmpB); c->tmpA = c->tmpB = nullptr; c->tmp_cap = 0; }
     HIPCHK(c, hipMalloc((void **)&c->tmpA, pixels * sizeof(float)));
     HIPCHK(c, hipMalloc((void **)&c->tmpB, pixels * sizeof(float)));
     c->tmp_cap = pixels;
@@ -188,6 +196,8 @@ int get_slot(klt_ctx *c, int slot, Slot **out, bool create)
     return 0;
 }
 
+int wait_tracker(klt_ctx *c);
+
 int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
 {
     if (fb < 0 || fb > 65535) return fail(c, KLT_ERR_ARG, "feature buffer index out of range");
@@ -198,8 +208,9 @@ int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
         klt_feat *nd = nullptr;
         HIPCHK(c, hipMalloc((void **)&nd, (size_t)n * sizeof(klt_feat)));
         if (b.d) {
+            if (int rc = wait_tracker(c)) return rc;
             HIPCHK(c, hipMemcpyAsync(nd, b.d, (size_t)b.cap * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (int rc = sync_all(c)) return rc;
             hipFree(b.d);
         }
         b.d = nd;
@@ -276,12 +287,8 @@ int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int p
     if (int rc = get_slot(c, slot, &s, true)) return rc;
     if (int rc = wait_slot_readers(c, s)) return rc;
     const size_t px_count = (size_t)ncols * nrows;
-    if (px_count > s->raw_cap) {
-        if (s->u8) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(s->u8); hipFree(s->f32); s->u8 = nullptr; s->f32 = nullptr; }
-        HIPCHK(c, hipMalloc((void **)&s->u8, px_count));
-        HIPCHK(c, hipMalloc((void **)&s->f32, px_count * sizeof(float)));
-        s->raw_cap = px_count;
-    }
+    if (kind == 1) { if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc; }
+    else { if (int rc = ensure(c, s->f32, s->f32_cap, px_count)) return rc; }
     const size_t esz = kind == 1 ? 1 : sizeof(float);
     void *dst = kind == 1 ? (void *)s->u8 : (void *)s->f32;
     HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)ncols * esz, px, (size_t)pitch * esz, (size_t)ncols * esz, nrows,
@@ -307,7 +314,7 @@ int layout_pyramid(klt_ctx *c, Slot *s)
         nr /= ss;
     }
     if (3 * total > s->planes_cap) {
-        if (s->planes) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(s->planes); s->planes = nullptr; }
+        if (s->planes) { if (int rc = sync_all(c)) return rc; hipFree(s->planes); s->planes = nullptr; s->planes_cap = 0; }
         HIPCHK(c, hipMalloc((void **)&s->planes, 3 * total * sizeof(float)));
         s->planes_cap = 3 * total;
     }
@@ -742,7 +749,7 @@ int klt_featbuf_view(klt_ctx *c, int fb_view, int fb_parent, int offset, int n)
     if (fb_view < 0 || fb_view > 65535) return fail(c, KLT_ERR_ARG, "feature buffer index out of range");
     if ((size_t)fb_view >= c->fbs.size()) c->fbs.resize(fb_view + 1);
     FeatBuf &v = c->fbs[fb_view];
-    if (v.d && !v.view) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(v.d); }
+    if (v.d && !v.view) { if (int rc = sync_all(c)) return rc; hipFree(v.d); }
     v.d = c->fbs[fb_parent].d + offset;
     v.cap = n;
     v.view = true;
@@ -789,7 +796,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
 
     // scratch
     if (N > c->sel_cap) {
-        if (c->sel_img) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap); }
+        if (c->sel_img) { if (int rc = sync_all(c)) return rc; hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap); }
         c->sel_img = c->sel_gx = c->sel_gy = c->sat = c->valmap = nullptr;
         HIPCHK(c, hipMalloc((void **)&c->sel_img, N * sizeof(float)));
         HIPCHK(c, hipMalloc((void **)&c->sel_gx, N * sizeof(float)));
@@ -1088,7 +1095,7 @@ int klt_affine_alloc(klt_ctx *c, int state, int n)
     AffState &a = c->aff[state];
     const int tn = (c->ap.window_width + 2) * (c->ap.window_height + 2);
     if (a.n < n || a.tn != tn) {
-        if (a.rec) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(a.rec); hipFree(a.tpl); a.rec = nullptr; a.tpl = nullptr; }
+        if (a.rec) { if (int rc = sync_all(c)) return rc; hipFree(a.rec); hipFree(a.tpl); a.rec = nullptr; a.tpl = nullptr; a.n = 0; }
         HIPCHK(c, hipMalloc((void **)&a.rec, (size_t)n * sizeof(klt_affine_rec)));
         HIPCHK(c, hipMalloc((void **)&a.tpl, (size_t)n * 3 * tn * sizeof(float)));
         a.n = n;
