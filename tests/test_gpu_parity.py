@@ -286,6 +286,23 @@ def test_track_cfg1(ctx, cfg1, img0, img1, tag, mr):
         assert st["iterations"][lvl] == int(rows[:, 6].sum())
 
 
+def test_lost_features_pass_through(ctx, cfg1, img0, img1):
+    """features with val < 0 are not tracked and come back untouched (trackFeatures.py:253)"""
+    ctx.configure(make_tc(max_residue=10.0))
+    ctx.upload(0, img0)
+    ctx.upload(1, img1)
+    ctx.build_pyramids_batch([0, 1])
+    fl, _ = ctx.select(0, 100, use_pyramid=True)
+    out, _ = ctx.track(0, 1, fl)
+    fl2 = fl.copy()
+    fl2["val"][::3] = -4
+    fl2["x"][::3] = -1
+    out2, _ = ctx.track(0, 1, fl2)
+    keep = fl2["val"] >= 0
+    assert np.array_equal(out2[["x", "y", "val"]][~keep], fl2[["x", "y", "val"]][~keep])
+    assert np.array_equal(out2["x"][keep], out["x"][keep]) and np.array_equal(out2["val"][keep], out["val"][keep])
+
+
 def test_track_retain(ctx, cfg1, img0, img1):
     ctx.configure(make_tc(max_residue=10.0, retainTrackers=True))
     ctx.upload(0, img0)
