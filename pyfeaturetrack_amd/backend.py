@@ -118,6 +118,21 @@ class Context:
             a = np.ascontiguousarray(a, np.float32)
             self._check(self._lib.klt_upload_f32(self._h, slot, a.ctypes.data, a.shape[1], a.shape[0], a.shape[1]))
 
+    def pinned_array(self, shape, dtype=np.uint8):
+        """numpy array backed by pinned host memory (valid until the context is closed)."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.klt_host_alloc(self._h, nbytes, C.byref(p)))
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def upload_async(self, slot, img):
+        """img: 2-D uint8 array from pinned_array(); enqueued on the copy stream, no host synchronisation."""
+        if img.dtype != np.uint8 or img.ndim != 2 or not img.flags["C_CONTIGUOUS"]:
+            raise ValueError("upload_async takes a C-contiguous 2-D uint8 array in pinned memory")
+        self._check(self._lib.klt_upload_u8_async(self._h, slot, img.ctypes.data, img.shape[1], img.shape[0], img.shape[1]))
+
     def build_pyramids(self, slot, sync=True):
         fn = self._lib.klt_build_pyramids if sync else self._lib.klt_build_pyramids_async
         self._check(fn(self._h, slot))

@@ -33,6 +33,16 @@ struct Slot {
     bool pyr_valid = false;
     hipEvent_t ev_read = nullptr;     // last tracker launch that read this slot (track-stream mode)
     bool ev_read_valid = false;
+    hipEvent_t ev_upload = nullptr;   // asynchronous ingest: frame copy finished (the build waits for it)
+    hipEvent_t ev_consumed = nullptr; // last kernel on `stream` that read the raw frame u8
+    bool upload_pending = false, consumed_valid = false;
+    // asynchronous ingest alternates between two raw buffers so that a copy never has to wait (on the device) for
+    // kernels still reading the previous frame: making the copy stream wait on a compute-stream event blocks the
+    // HOST for the duration of the queued work on this runtime (measured 150-800 us per step)
+    uint8_t *u8_alt = nullptr;
+    size_t u8_alt_cap = 0;
+    hipEvent_t ev_consumed_alt = nullptr;
+    bool consumed_alt_valid = false;
 };
 
 struct FeatBuf { klt_feat *d = nullptr; int cap = 0; bool view = false; };
@@ -50,6 +60,13 @@ struct klt_ctx {
     hipStream_t stream = nullptr;     // uploads, pyramid build, selection
     hipStream_t tstream = nullptr;    // tracker launches when KLT_OPT_TRACK_STREAM is on (else == stream)
     bool track_stream_on = false;
+    hipStream_t cstream = nullptr;    // asynchronous frame ingest from pinned host memory (created on first use)
+    std::vector<void *> pinned;       // klt_host_alloc allocations
+    // Ordering events come from one ring and are never re-recorded while a waiter may still be queued on them
+    // (re-recording a pending event makes hipEventRecord block the host until the device has caught up -- measured:
+    // 400-800 us per step).  256 events ~ 25 steps of history.
+    std::vector<hipEvent_t> ring;
+    size_t ring_next = 0;
     hipEvent_t ev_pyr = nullptr;      // "everything enqueued on `stream` so far" marker the tracker waits for
     hipEvent_t ev_track = nullptr;    // last tracker launch (feature-buffer consumers on `stream` wait for it)
     bool ev_track_valid = false;
@@ -162,6 +179,7 @@ int sync_all(klt_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->tstream && c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
+    if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
     return 0;
 }
 
@@ -223,6 +241,21 @@ int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
 // ---- two-stream ordering (KLT_OPT_TRACK_STREAM): the tracker runs on its own stream so that it can overlap the
 // pyramid build of the next frames.  `stream` work that overwrites a slot waits for the last tracker launch that read
 // it; `stream` work that touches feature buffers waits for the last tracker launch.
+int fresh_event(klt_ctx *c, hipEvent_t *out)
+{
+    constexpr size_t kRing = 256;
+    if (c->ring.size() < kRing) {
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ring.push_back(e);
+        *out = e;
+        return 0;
+    }
+    *out = c->ring[c->ring_next];
+    c->ring_next = (c->ring_next + 1) % kRing;
+    return 0;
+}
+
 int wait_slot_readers(klt_ctx *c, Slot *s)
 {
     if (c->track_stream_on && s->ev_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_read, 0));
@@ -238,6 +271,7 @@ int wait_tracker(klt_ctx *c)
 int tracker_begin(klt_ctx *c)
 {
     if (!c->track_stream_on) return 0;
+    if (int rc = fresh_event(c, &c->ev_pyr)) return rc;
     HIPCHK(c, hipEventRecord(c->ev_pyr, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->tstream, c->ev_pyr, 0));
     return 0;
@@ -246,12 +280,13 @@ int tracker_begin(klt_ctx *c)
 int tracker_end(klt_ctx *c, Slot *const *slots, int n)
 {
     if (!c->track_stream_on) return 0;
+    if (int rc = fresh_event(c, &c->ev_track)) return rc;
     HIPCHK(c, hipEventRecord(c->ev_track, c->tstream));
     c->ev_track_valid = true;
     for (int i = 0; i < n; i++) {
         Slot *s = slots[i];
-        if (!s->ev_read) HIPCHK(c, hipEventCreateWithFlags(&s->ev_read, hipEventDisableTiming));
-        HIPCHK(c, hipEventRecord(s->ev_read, c->tstream));
+        s->ev_read = c->ev_track;          // the event recorded just above marks the end of this launch
+
         s->ev_read_valid = true;
     }
     return 0;
@@ -286,13 +321,15 @@ int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int p
     Slot *s;
     if (int rc = get_slot(c, slot, &s, true)) return rc;
     if (int rc = wait_slot_readers(c, s)) return rc;
+    if (s->upload_pending) { HIPCHK(c, hipStreamSynchronize(c->cstream)); s->upload_pending = false; }
     const size_t px_count = (size_t)ncols * nrows;
     if (kind == 1) { if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc; }
     else { if (int rc = ensure(c, s->f32, s->f32_cap, px_count)) return rc; }
     const size_t esz = kind == 1 ? 1 : sizeof(float);
     void *dst = kind == 1 ? (void *)s->u8 : (void *)s->f32;
-    HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)ncols * esz, px, (size_t)pitch * esz, (size_t)ncols * esz, nrows,
-                                hipMemcpyHostToDevice, c->stream));
+    if (pitch == ncols) HIPCHK(c, hipMemcpyAsync(dst, px, px_count * esz, hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)ncols * esz, px, (size_t)pitch * esz, (size_t)ncols * esz, nrows,
+                                    hipMemcpyHostToDevice, c->stream));
     // pageable host memory: the copy above is staged before returning, but make it explicit
     HIPCHK(c, hipStreamSynchronize(c->stream));
     s->nc = ncols;
@@ -438,6 +475,10 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
             if (sl[j] == sl[i]) return fail(c, KLT_ERR_ARG, "slot listed twice");
         if (int rc = layout_pyramid(c, sl[i])) return rc;
         if (int rc = wait_slot_readers(c, sl[i])) return rc;
+        if (sl[i]->upload_pending) {                        // asynchronous ingest: the frame must have landed
+            HIPCHK(c, hipStreamWaitEvent(c->stream, sl[i]->ev_upload, 0));
+            sl[i]->upload_pending = false;
+        }
     }
     const int ss = c->p.subsampling;
     // groups of frames with the same geometry and input type share launches
@@ -527,6 +568,13 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         }
         for (Slot *s : g) s->pyr_valid = true;
     }
+    // the next asynchronous copy into these slots waits for this build
+    if (c->cstream) {
+        hipEvent_t e;
+        if (int rc = fresh_event(c, &e)) return rc;
+        HIPCHK(c, hipEventRecord(e, c->stream));
+        for (Slot *s : sl) { s->ev_consumed = e; s->consumed_valid = true; }
+    }
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -565,9 +613,7 @@ int klt_create(int device, klt_ctx **out)
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void **)&c->stats_d, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void **)&c->placed_d, 2 * sizeof(int))) != hipSuccess ||
-        (e = hipMemset(c->stats_d, 0, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_track, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipMemset(c->stats_d, 0, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess) {
         g_create_error = std::string("device setup failed: ") + hipGetErrorString(e);
         delete c;
         return KLT_ERR_DEVICE;
@@ -583,9 +629,10 @@ void klt_destroy(klt_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->tstream && c->tstream != c->stream) { hipStreamSynchronize(c->tstream); hipStreamDestroy(c->tstream); }
-    if (c->ev_pyr) hipEventDestroy(c->ev_pyr);
-    if (c->ev_track) hipEventDestroy(c->ev_track);
-    for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.f32); hipFree(s.planes); if (s.ev_read) hipEventDestroy(s.ev_read); }
+    if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
+    for (void *p : c->pinned) hipHostFree(p);
+    for (hipEvent_t e : c->ring) hipEventDestroy(e);
+    for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes); }
     for (FeatBuf &b : c->fbs)
         if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB);
@@ -603,6 +650,7 @@ const char *klt_last_error(klt_ctx *c) { return c ? c->err.c_str() : g_create_er
 int klt_sync(klt_ctx *c)
 {
     if (!c) return KLT_ERR_ARG;
+    if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
     return KLT_OK;
@@ -652,6 +700,68 @@ int klt_upload_u8(klt_ctx *c, int slot, const uint8_t *px, int ncols, int nrows,
 int klt_upload_f32(klt_ctx *c, int slot, const float *px, int ncols, int nrows, int pitch)
 {
     return upload_raw(c, slot, px, ncols, nrows, pitch, 2);
+}
+
+int klt_host_alloc(klt_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || bytes == 0) return fail(c, KLT_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    c->pinned.push_back(p);
+    *out = p;
+    return KLT_OK;
+}
+
+int klt_host_free(klt_ctx *c, void *p)
+{
+    if (!c || !p) return fail(c, KLT_ERR_ARG, "bad argument");
+    for (size_t i = 0; i < c->pinned.size(); i++)
+        if (c->pinned[i] == p) {
+            if (int rc = sync_all(c)) return rc;
+            HIPCHK(c, hipHostFree(p));
+            c->pinned.erase(c->pinned.begin() + (long)i);
+            return KLT_OK;
+        }
+    return fail(c, KLT_ERR_ARG, "pointer was not allocated with klt_host_alloc");
+}
+
+int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int nrows, int pitch)
+{
+    if (!c || !px) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535 || pitch < ncols) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipPointerAttribute_t attr;                           // the source must be pinned: a pageable copy would be staged synchronously
+    if (hipPointerGetAttributes(&attr, px) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return fail(c, KLT_ERR_ARG, "klt_upload_u8_async needs pinned host memory (klt_host_alloc)");
+    }
+    if (!c->cstream) HIPCHK(c, hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    Slot *s;
+    if (int rc = get_slot(c, slot, &s, true)) return rc;
+    const size_t px_count = (size_t)ncols * nrows;
+    // write into the buffer the build before last read (normally long finished: poll, block only if it is not)
+    std::swap(s->u8, s->u8_alt);
+    std::swap(s->u8_cap, s->u8_alt_cap);
+    std::swap(s->ev_consumed, s->ev_consumed_alt);
+    std::swap(s->consumed_valid, s->consumed_alt_valid);
+    if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc;
+    if (s->consumed_valid) {
+        const hipError_t q = hipEventQuery(s->ev_consumed);
+        if (q == hipErrorNotReady) HIPCHK(c, hipEventSynchronize(s->ev_consumed));
+        else if (q != hipSuccess) return fail(c, KLT_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        s->consumed_valid = false;
+    }
+    if (pitch == ncols) HIPCHK(c, hipMemcpyAsync(s->u8, px, px_count, hipMemcpyHostToDevice, c->cstream));
+    else HIPCHK(c, hipMemcpy2DAsync(s->u8, (size_t)ncols, px, (size_t)pitch, (size_t)ncols, nrows, hipMemcpyHostToDevice, c->cstream));
+    if (int rc = fresh_event(c, &s->ev_upload)) return rc;
+    HIPCHK(c, hipEventRecord(s->ev_upload, c->cstream));
+    s->upload_pending = true;
+    s->nc = ncols;
+    s->nr = nrows;
+    s->raw_kind = 1;
+    s->pyr_valid = false;
+    return KLT_OK;
 }
 
 int klt_build_pyramids_async(klt_ctx *c, int slot) { return build_pyramids_batch(c, &slot, 1); }
@@ -815,6 +925,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
         img = s->lv[0].img; gx = s->lv[0].gx; gy = s->lv[0].gy;
     } else {
         if (s->raw_kind == 0) return fail(c, KLT_ERR_STATE, "slot has no frame");
+        if (s->upload_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_upload, 0)); s->upload_pending = false; }
         bool grads_done = false;
         if (p.smoothBeforeSelecting && fused_smooth_ok(c)) {
             const void *raw = s->raw_kind == 1 ? (const void *)s->u8 : (const void *)s->f32;

@@ -624,6 +624,36 @@ def test_track_stream_overlap_keeps_results(cfg1, img0, img1):
         c.close()
 
 
+def test_async_ingest_from_pinned_memory(cfg1, img0, img1):
+    """klt_upload_u8_async: frames copied from pinned memory on the copy stream; builds wait for the copy, copies wait
+    for the builds that still read the slot; results equal the synchronous path."""
+    from pyfeaturetrack_amd.backend import Context, KltBackendError
+    c = Context(0)
+    try:
+        c.configure(make_tc(max_residue=10.0))
+        p0, p1, scratch = c.pinned_array(img0.shape), c.pinned_array(img1.shape), c.pinned_array(img1.shape)
+        p0[:] = img0
+        p1[:] = img1
+        scratch[:] = 255 - img1
+        c.upload_async(0, p0)
+        c.upload_async(1, p1)
+        c.build_pyramids_batch([0, 1])
+        fl, _ = c.select(0, 100, use_pyramid=True)
+        c.featbuf_upload(0, fl)
+        for i in range(12):
+            c.upload_async(1, scratch if i % 2 == 0 else p1)      # overwrite frame 2 while earlier work may be queued
+            c.upload_async(1, p1)
+            c.build_pyramids_batch([1])
+            c.track_async(0, 1, 0, 1 + i % 2, 100)
+        for k in (1, 2):
+            out = c.featbuf_download(k, 100)
+            assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "async ingest, buffer %d" % k)
+        with pytest.raises(KltBackendError, match="pinned"):
+            c.upload_async(1, np.ascontiguousarray(img1))         # pageable memory is refused
+    finally:
+        c.close()
+
+
 def test_feature_table_views(ctx, cfg1, img0, img1):
     """klt_featbuf_view: tracker output written into a window of a larger device-side record table"""
     ctx.configure(make_tc(max_residue=10.0))
