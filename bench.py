@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-l0", action="store_true", help="KLT_OPT_SPLIT_L0: fork/join pyramid build on two streams")
     ap.add_argument("--config", choices=["cfg2", "cfg4"], default="cfg2",
                     help="cfg2 (default, the headline line) or cfg4 (a shard of 1280x720 pairs, single GPU, informative)")
     ap.add_argument("--pairs", type=int, default=32, help="pairs per step for --config cfg4")
@@ -230,6 +231,8 @@ def main():
         ctx.upload(s0 + 1, f1)
     if args.pipeline:
         ctx.set_option(3, 1)
+    if args.split_l0:
+        ctx.set_option(7, 1)
     ctx.build_pyramids(0)
     fl, placed = ctx.select(0, NFEAT, use_pyramid=True)
     assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)

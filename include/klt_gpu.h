@@ -92,6 +92,9 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
  * feature) and falls back to the full sort if the greedy walk runs off their end; 0: always the full sort.  With the
  * prefilter klt_select_async reads two small results back and therefore synchronises internally. */
 #define KLT_OPT_TOPK_PREFILTER 5
+/* 1: the pyramid build smooths level 0 alone, then runs the level-0 gradients on the main stream concurrently with the
+ * reductions / small-level gradients on a side stream (fork/join with events); 0 (default): fused level-0 kernel. */
+#define KLT_OPT_SPLIT_L0 7
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
 /* ---- parameters and taps ------------------------------------------------------------------- */

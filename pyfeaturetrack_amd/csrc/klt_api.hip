@@ -61,6 +61,9 @@ struct klt_ctx {
     hipStream_t tstream = nullptr;    // tracker launches when KLT_OPT_TRACK_STREAM is on (else == stream)
     bool track_stream_on = false;
     hipStream_t cstream = nullptr;    // asynchronous frame ingest from pinned host memory (created on first use)
+    hipStream_t sstream = nullptr;    // side stream of the pyramid build (KLT_OPT_SPLIT_L0), created on first use
+    hipStream_t work = nullptr;       // stream the pyramid-build helpers currently enqueue on (stream or sstream)
+    bool split_l0 = false;
     std::vector<void *> pinned;       // klt_host_alloc allocations
     // Ordering events come from one ring and are never re-recorded while a waiter may still be queued on them
     // (re-recording a pending event makes hipEventRecord block the host until the device has caught up -- measured:
@@ -137,7 +140,7 @@ struct TimerScope {
     Timed t;
     bool on;
     hipStream_t st;
-    TimerScope(klt_ctx *c_, int fam, double bytes, hipStream_t st_ = nullptr) : c(c_), on(c_->timing), st(st_ ? st_ : c_->stream)
+    TimerScope(klt_ctx *c_, int fam, double bytes, hipStream_t st_ = nullptr) : c(c_), on(c_->timing), st(st_ ? st_ : c_->work)
     {
         if (!on) return;
         t.fam = fam;
@@ -180,6 +183,7 @@ int sync_all(klt_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->tstream && c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
+    if (c->sstream) HIPCHK(c, hipStreamSynchronize(c->sstream));
     return 0;
 }
 
@@ -390,12 +394,12 @@ int enqueue_smooth_raw(klt_ctx *c, Slot *s, float *dst)
     const Taps &g = c->gauss[0];
     {
         TimerScope t(c, F_SMOOTH_H, N * ((s->raw_kind == 1 ? 1 : 4) + 4));
-        if (s->raw_kind == 1) launch_hconv_u8(c->stream, s->u8, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
-        else launch_hconv_f32(c->stream, s->f32, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+        if (s->raw_kind == 1) launch_hconv_u8(c->work, s->u8, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+        else launch_hconv_f32(c->work, s->f32, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
     }
     {
         TimerScope t(c, F_SMOOTH_V, N * 8);
-        launch_vconv(c->stream, c->tmpA, nullptr, nc, nr, dst, nullptr, nr, 1, 0, g, nullptr);
+        launch_vconv(c->work, c->tmpA, nullptr, nc, nr, dst, nullptr, nr, 1, 0, g, nullptr);
     }
     return 0;
 }
@@ -406,11 +410,11 @@ int enqueue_gradients(klt_ctx *c, const float *img, int nc, int nr, float *gx, f
     const double N = (double)nc * nr;
     {
         TimerScope t(c, F_GRAD_H, N * 12);
-        launch_hconv_f32(c->stream, img, nc, nr, c->tmpA, c->tmpB, nc, 1, 0, c->deriv[2], &c->gauss[2]);
+        launch_hconv_f32(c->work, img, nc, nr, c->tmpA, c->tmpB, nc, 1, 0, c->deriv[2], &c->gauss[2]);
     }
     {
         TimerScope t(c, F_GRAD_V, N * 16);
-        launch_vconv(c->stream, c->tmpA, c->tmpB, nc, nr, gx, gy, nr, 1, 0, c->gauss[2], &c->deriv[2]);
+        launch_vconv(c->work, c->tmpA, c->tmpB, nc, nr, gx, gy, nr, 1, 0, c->gauss[2], &c->deriv[2]);
     }
     return 0;
 }
@@ -442,7 +446,7 @@ int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int
     a.ncols = nc; a.nrows = nr; a.R = grad_radius(c);
     const double N = (double)nc * nr * batch;
     TimerScope t(c, F_SMOOTH_GRAD, N * ((raw_kind == 1 ? 1 : 4) + 4) + N * 12);
-    if (int e = launch_smooth_grad(c->stream, a, batch, raw_kind == 1 ? 0 : 1))
+    if (int e = launch_smooth_grad(c->work, a, batch, raw_kind == 1 ? 0 : 1))
         return fail(c, KLT_ERR_DEVICE, std::string("smooth_grad launch: ") + hipGetErrorString((hipError_t)e));
     return 0;
 }
@@ -457,7 +461,7 @@ int enqueue_fused_grad(klt_ctx *c, int batch, const float *const *img, float *co
     a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
     a.ncols = nc; a.nrows = nr; a.R = grad_radius(c);
     TimerScope t(c, F_GRAD, (double)nc * nr * batch * 12);
-    if (int e = launch_smooth_grad(c->stream, a, batch, u8_input ? 3 : 2))
+    if (int e = launch_smooth_grad(c->work, a, batch, u8_input ? 3 : 2))
         return fail(c, KLT_ERR_DEVICE, std::string("gradient launch: ") + hipGetErrorString((hipError_t)e));
     return 0;
 }
@@ -465,6 +469,7 @@ int enqueue_fused_grad(klt_ctx *c, int batch, const float *const *img, float *co
 int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
 {
     if (int rc = check_ready(c)) return rc;
+    c->work = c->stream;
     if (!slot_ids || n <= 0) return fail(c, KLT_ERR_ARG, "empty slot list");
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<Slot *> sl((size_t)n);
@@ -499,7 +504,33 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         if (int rc = ensure_tmp(c, (size_t)s0->nc * s0->nr)) return rc;
 
         // level 0: smoothed frame (trackFeatures.py:165-166) and its gradients (:171-172)
-        if (fused_smooth_ok(c)) {
+        const bool split = c->split_l0 && fused_smooth_ok(c) && fused_grad_ok(c) && merged_grad_ok(c) && s0->nlev > 1 &&
+                           (c->gauss[0].n == 5 || c->gauss[0].n == 9);
+        hipEvent_t ev_join = nullptr;
+        if (split) {
+            // KLT_OPT_SPLIT_L0: smooth alone, then the (VALU-bound) level-0 gradients on the main stream overlap the
+            // (latency-bound) reductions and small-level gradients on the side stream; both only need the level-0 image
+            SmoothGradArgs sa;
+            std::memset(&sa, 0, sizeof(sa));
+            for (int b = 0; b < B; b++) {
+                sa.raw[b] = g[b]->raw_kind == 1 ? (const void *)g[b]->u8 : (const void *)g[b]->f32;
+                sa.img[b] = g[b]->lv[0].img;
+            }
+            sa.smooth = c->gauss[0]; sa.ggauss = c->gauss[2]; sa.gderiv = c->deriv[2];
+            sa.ncols = s0->nc; sa.nrows = s0->nr; sa.R = grad_radius(c);
+            {
+                TimerScope t(c, F_SMOOTH_GRAD, (double)s0->nc * s0->nr * B * ((s0->raw_kind == 1 ? 1 : 4) + 4));
+                if (launch_smooth_only(c->stream, sa, B, s0->raw_kind == 1)) return fail(c, KLT_ERR_STATE, "no smoothing kernel");
+            }
+            if (!c->sstream) HIPCHK(c, hipStreamCreateWithFlags(&c->sstream, hipStreamNonBlocking));
+            hipEvent_t ev_fork;
+            if (int rc = fresh_event(c, &ev_fork)) return rc;
+            HIPCHK(c, hipEventRecord(ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->sstream, ev_fork, 0));
+            for (int b = 0; b < B; b++) { src[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy; }
+            if (int rc = enqueue_fused_grad(c, B, src, gx, gy, s0->nc, s0->nr)) return rc;      // main stream
+            c->work = c->sstream;                                                             // the rest: side stream
+        } else if (fused_smooth_ok(c)) {
             for (int b = 0; b < B; b++) {
                 raw[b] = g[b]->raw_kind == 1 ? (const void *)g[b]->u8 : (const void *)g[b]->f32;
                 img[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy;
@@ -525,17 +556,17 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                 a.log2ss = 0;
                 while ((1 << a.log2ss) < ss) a.log2ss++;
                 TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ls.nc * ls.nr + (double)ld.nc * ld.nr));
-                if (int e = launch_pyr_reduce(c->stream, a, B))
+                if (int e = launch_pyr_reduce(c->work, a, B))
                     return fail(c, KLT_ERR_DEVICE, std::string("pyr_reduce launch: ") + hipGetErrorString((hipError_t)e));
             } else {
                 for (int b = 0; b < B; b++) {
                     {
                         TimerScope t(c, F_PYR_H, 4.0 * ((double)ls.nc * ls.nr + (double)ld.nc * ls.nr));
-                        launch_hconv_f32(c->stream, g[b]->lv[l - 1].img, ls.nc, ls.nr, c->tmpA, nullptr, ld.nc, ss, ss / 2, c->gauss[1], nullptr);
+                        launch_hconv_f32(c->work, g[b]->lv[l - 1].img, ls.nc, ls.nr, c->tmpA, nullptr, ld.nc, ss, ss / 2, c->gauss[1], nullptr);
                     }
                     {
                         TimerScope t(c, F_PYR_V, 4.0 * ((double)ld.nc * ls.nr + (double)ld.nc * ld.nr));
-                        launch_vconv(c->stream, c->tmpA, nullptr, ld.nc, ls.nr, g[b]->lv[l].img, nullptr, ld.nr, ss, ss / 2, c->gauss[1], nullptr);
+                        launch_vconv(c->work, c->tmpA, nullptr, ld.nc, ls.nr, g[b]->lv[l].img, nullptr, ld.nr, ss, ss / 2, c->gauss[1], nullptr);
                     }
                 }
             }
@@ -563,8 +594,14 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
             a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
             a.ncols = s0->lv[1].nc; a.nrows = s0->lv[1].nr; a.R = grad_radius(c);
             TimerScope t(c, F_GRAD, bytes);
-            if (int er = launch_smooth_grad(c->stream, a, e, 2))
+            if (int er = launch_smooth_grad(c->work, a, e, 2))
                 return fail(c, KLT_ERR_DEVICE, std::string("gradient launch: ") + hipGetErrorString((hipError_t)er));
+        }
+        if (split) {
+            if (int rc = fresh_event(c, &ev_join)) { c->work = c->stream; return rc; }
+            const hipError_t e1 = hipEventRecord(ev_join, c->sstream), e2 = hipStreamWaitEvent(c->stream, ev_join, 0);
+            c->work = c->stream;
+            if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, KLT_ERR_DEVICE, "fork/join of the pyramid build failed");
         }
         for (Slot *s : g) s->pyr_valid = true;
     }
@@ -619,6 +656,7 @@ int klt_create(int device, klt_ctx **out)
         return KLT_ERR_DEVICE;
     }
     c->tstream = c->stream;
+    c->work = c->stream;
     *out = c;
     return KLT_OK;
 }
@@ -630,6 +668,7 @@ void klt_destroy(klt_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->tstream && c->tstream != c->stream) { hipStreamSynchronize(c->tstream); hipStreamDestroy(c->tstream); }
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
+    if (c->sstream) { hipStreamSynchronize(c->sstream); hipStreamDestroy(c->sstream); }
     for (void *p : c->pinned) hipHostFree(p);
     for (hipEvent_t e : c->ring) hipEventDestroy(e);
     for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes); }
@@ -774,6 +813,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_FUSED_KERNELS) { c->use_fused = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SMOOTH_GRAD_VARIANT) { g_smooth_grad_variant = value; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
+    if (option == KLT_OPT_SPLIT_L0) { c->split_l0 = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_AFFINE_STATE) {
         if (value >= 0 && ((size_t)value >= c->aff.size() || !c->aff[value].rec)) return fail(c, KLT_ERR_STATE, "affine state not allocated");
         c->select_aff_state = value;

@@ -99,6 +99,7 @@ size_t pyr_reduce_lds_bytes(int ss, int ntaps);
 // kind: 0 = u8 frame + smoothing, 1 = f32 frame + smoothing, 2 = f32 image gradients only, 3 = u8 image gradients only
 int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int kind);
 int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch);
+int launch_smooth_only(hipStream_t s, const SmoothGradArgs &a, int batch, bool u8_input);   // 1: no specialised kernel
 
 void launch_sat_rows(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows);
 void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows);

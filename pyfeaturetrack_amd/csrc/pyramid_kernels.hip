@@ -482,6 +482,85 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
     }
 }
 
+// Smoothing only (frame -> level-0 image), register-blocked like smooth_grad_rb.  Used when the level-0 gradients are
+// computed by a separate launch that overlaps the pyramid reduction on a second stream (KLT_OPT_SPLIT_L0).
+template <typename TIn, int NS, int TH_>
+__global__ __launch_bounds__(256) void smooth_only_rb(SmoothGradArgs a)
+{
+    constexpr int rs = NS / 2;
+    static_assert(rs <= 4, "needs a tap radius <= 4");
+    constexpr int AW = TW + 8, BW = TW, AQ = AW / 4, BQ = BW / 4;
+    constexpr int RH = TH_ + 2 * rs;
+    __shared__ __attribute__((aligned(16))) float lds[RH * AW + RH * BW];
+    float *const A = lds, *const B = lds + RH * AW;
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
+    const int nc = a.ncols, nr = a.nrows;
+    const TIn *__restrict__ raw = (const TIn *)a.raw[b];
+    TapRegs<NS> ks;
+    load_taps(ks, a.smooth);
+    for (int i = tid; i < RH * AQ; i += 256) {
+        const int r = i / AQ, q = i % AQ;
+        const int gy = reflect_fast(ty0 - rs + r, nr);
+        const int x = tx0 - 4 + 4 * q;
+        const TIn *row = raw + (size_t)gy * nc;
+        float4 v;
+        if (x >= 0 && x + 3 < nc && (nc & 3) == 0) {
+            if (sizeof(TIn) == 1) {
+                const uint32_t wq = *reinterpret_cast<const uint32_t *>(row + x);
+                v.x = (float)(wq & 0xffu); v.y = (float)((wq >> 8) & 0xffu);
+                v.z = (float)((wq >> 16) & 0xffu); v.w = (float)(wq >> 24);
+            } else {
+                v = *reinterpret_cast<const float4 *>(row + x);
+            }
+        } else {
+            v.x = (float)row[reflect_fast(x, nc)]; v.y = (float)row[reflect_fast(x + 1, nc)];
+            v.z = (float)row[reflect_fast(x + 2, nc)]; v.w = (float)row[reflect_fast(x + 3, nc)];
+        }
+        *reinterpret_cast<float4 *>(A + (size_t)i * 4) = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < RH * BQ; i += 256) {               // horizontal pass (B column c = A column c + 4)
+        const int r = i / BQ, q = i % BQ;
+        const float4 *src = reinterpret_cast<const float4 *>(A + r * AW + 4 * q);
+        double v[12];
+        widen4(src[0], v); widen4(src[1], v + 4); widen4(src[2], v + 8);
+        float4 o;
+        o.x = corr_regs<NS, 1>(v + 4, ks); o.y = corr_regs<NS, 1>(v + 5, ks);
+        o.z = corr_regs<NS, 1>(v + 6, ks); o.w = corr_regs<NS, 1>(v + 7, ks);
+        *reinterpret_cast<float4 *>(B + r * BW + 4 * q) = o;
+    }
+    __syncthreads();
+    float *__restrict__ img = a.img[b];
+    static_assert(TH_ % 2 == 0, "tile height must be even");
+    for (int i = tid; i < (TH_ / 2) * BQ; i += 256) {        // vertical pass, quad x two rows per thread
+        const int r = 2 * (i / BQ), q = i % BQ;
+        const int x = tx0 + 4 * q;
+        if (ty0 + r >= nr || x >= nc) continue;
+        double v[4][NS + 1];
+#pragma unroll
+        for (int j = 0; j < NS + 1; j++) {
+            const float4 t = *reinterpret_cast<const float4 *>(B + (r + j) * BW + 4 * q);
+            v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
+        }
+#pragma unroll
+        for (int dr = 0; dr < 2; dr++) {
+            const int y = ty0 + r + dr;
+            if (y >= nr) break;
+            float4 o;
+            o.x = corr_regs<NS, 1>(v[0] + rs + dr, ks); o.y = corr_regs<NS, 1>(v[1] + rs + dr, ks);
+            o.z = corr_regs<NS, 1>(v[2] + rs + dr, ks); o.w = corr_regs<NS, 1>(v[3] + rs + dr, ks);
+            float *dstp = img + (size_t)y * nc + x;
+            if (x + 3 < nc) { dstp[0] = o.x; dstp[1] = o.y; dstp[2] = o.z; dstp[3] = o.w; }
+            else {
+                dstp[0] = o.x;
+                if (x + 1 < nc) dstp[1] = o.y;
+                if (x + 2 < nc) dstp[2] = o.z;
+            }
+        }
+    }
+}
+
 // The f32-rounded horizontal result is kept in LDS as the double it widens to (one widening per sample instead of one
 // per tap of the vertical pass); the source tile stays f32 (an f64 tile was measured slower: half the LDS matters more).
 template <int NT, int STRIDE>
@@ -653,6 +732,18 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
     default: if ((e = set_lds(smooth_grad_kernel<uint8_t, false>, lds))) return e;
             hipLaunchKernelGGL((smooth_grad_kernel<uint8_t, false>), grid, block, lds, s, a); break;
     }
+    return 0;
+}
+
+// smoothing only (u8 or f32 frame -> level-0 image); returns 1 if there is no compile-time kernel for these taps
+int launch_smooth_only(hipStream_t s, const SmoothGradArgs &a, int batch, bool u8_input)
+{
+    if (a.smooth.sym != 1 || (a.smooth.n != 5 && a.smooth.n != 9)) return 1;
+    const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + 31) / 32, batch), blk(256);
+    if (u8_input && a.smooth.n == 5) hipLaunchKernelGGL((smooth_only_rb<uint8_t, 5, 32>), g, blk, 0, s, a);
+    else if (u8_input) hipLaunchKernelGGL((smooth_only_rb<uint8_t, 9, 32>), g, blk, 0, s, a);
+    else if (a.smooth.n == 5) hipLaunchKernelGGL((smooth_only_rb<float, 5, 32>), g, blk, 0, s, a);
+    else hipLaunchKernelGGL((smooth_only_rb<float, 9, 32>), g, blk, 0, s, a);
     return 0;
 }
 

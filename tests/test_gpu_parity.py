@@ -170,6 +170,29 @@ def test_unusual_sigmas_take_the_runtime_sized_kernels(ctx, ko, attrs, window, l
         assert_feats(out, *oracle_feats(ofl), what="%s track" % attrs)
 
 
+def test_split_level0_fork_join_build(cfg1, img0, img1):
+    """KLT_OPT_SPLIT_L0: smoothing alone, then level-0 gradients and the reductions on two streams; same pyramids."""
+    from pyfeaturetrack_amd.backend import Context
+    c = Context(0)
+    try:
+        c.configure(make_tc(max_residue=10.0))
+        c.set_option(7, 1)
+        c.upload(0, img0)
+        c.upload(1, img1)
+        for _ in range(3):
+            c.build_pyramids_batch([0, 1])
+        c.sync()
+        for slot, name in ((0, "p0"), (1, "p1")):
+            for l in range(2):
+                for pi, w in enumerate(("img", "gx", "gy")):
+                    assert_same(c.download_level(slot, pi, l), cfg1["%s_%s_%d" % (name, w, l)], "split %s %s %d" % (name, w, l))
+        fl, _ = c.select(0, 100, use_pyramid=True)
+        out, _ = c.track(0, 1, fl)
+        assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "track after a split build")
+    finally:
+        c.close()
+
+
 def test_one_sample_per_thread_variant(ctx, cfg1, img0):
     """KLT_OPT_SMOOTH_GRAD_VARIANT=1: the non-register-blocked LDS kernels stay bit-identical too."""
     ctx.configure(make_tc())
