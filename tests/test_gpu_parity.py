@@ -309,6 +309,34 @@ def test_track_cfg1(ctx, cfg1, img0, img1, tag, mr):
         assert st["iterations"][lvl] == int(rows[:, 6].sum())
 
 
+def test_empty_and_degenerate_inputs(ctx, ko, img0, img1):
+    """empty feature list, a list with only lost features, a frame too small to hold any candidate"""
+    from pyfeaturetrack_amd.backend import FEAT_DTYPE
+    tc = make_tc(max_residue=10.0)
+    ctx.configure(tc)
+    ctx.upload(0, img0)
+    ctx.upload(1, img1)
+    ctx.build_pyramids_batch([0, 1])
+    out, k = ctx.track(0, 1, np.zeros(0, FEAT_DTYPE))
+    assert len(out) == 0 and k == 0
+    lost = np.zeros(7, FEAT_DTYPE)
+    lost["val"] = [-1, -2, -3, -4, -5, -1, -4]
+    lost["x"] = lost["y"] = -1
+    out, k = ctx.track(0, 1, lost)
+    assert k == 0 and np.array_equal(out[["x", "y", "val"]], lost[["x", "y", "val"]])
+    small = img0[:50, :56].copy()                     # border 30 on every side leaves no interior pixel
+    ctx.upload(2, small)
+    fl, placed = ctx.select(2, 10)
+    assert placed == 0 and np.all(fl["val"] == -1) and np.all(fl["x"] == -1)
+    ofl = ko.select_good_features(params_from_tc(tc), small.astype(np.float32), 10)
+    assert np.array_equal(fl["val"], ofl["val"])
+    strip = img0[:61, :].copy()                       # exactly one candidate row
+    ctx.upload(2, strip)
+    fl, placed = ctx.select(2, 40)
+    ofl = ko.select_good_features(params_from_tc(tc), strip.astype(np.float32), 40)
+    assert_feats(fl, *oracle_feats(ofl), what="one-row candidate strip")
+
+
 def test_lost_features_pass_through(ctx, cfg1, img0, img1):
     """features with val < 0 are not tracked and come back untouched (trackFeatures.py:253)"""
     ctx.configure(make_tc(max_residue=10.0))
