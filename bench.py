@@ -181,6 +181,154 @@ def run_cfg4(args, json_fd):
     os.write(json_fd, (json.dumps(line) + "\n").encode())
 
 
+def _emit(json_fd, line):
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+
+def _base_line(value, steps, warmup, ms_step, workload, extra_cfg=None, pairs=1):
+    cfg = {"workload": workload}
+    cfg.update(extra_cfg or {})
+    return {"metric": "features tracked/sec", "value": value, "unit": "features/s", "n_gpus": 1, "steps": steps,
+            "warmup": warmup, "ms_per_step": ms_step, "ms_per_frame_pair": ms_step / pairs, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (convolutions accumulate in f64)", "data": "synthetic",
+            "config": cfg, "roofline": None, "cpu_baseline": None}
+
+
+def run_cfg1(args, json_fd):
+    """BASELINE cfg-1: img0.pgm -> img1.pgm, 100 features, default context (7x7, 2 levels / ss 4), max_residue 10."""
+    from tests.conftest import read_pgm
+    g = os.path.join(ROOT, "tests", "golden")
+    i0, i1 = read_pgm(os.path.join(g, "img0.pgm")), read_pgm(os.path.join(g, "img1.pgm"))
+    tc = KLT_TrackingContext()
+    tc.max_residue = 10.0
+    ctx = Context(0)
+    ctx.configure(tc)
+    ctx.upload(0, i0)
+    ctx.upload(1, i1)
+    ctx.build_pyramids_batch([0, 1], sync=True)
+    t = time.perf_counter()
+    fl, _ = ctx.select(0, 100, use_pyramid=True)
+    ms_select = (time.perf_counter() - t) * 1e3
+    ctx.featbuf_upload(0, fl)
+
+    def step():
+        ctx.build_pyramids_batch([0, 1])
+        ctx.track_async(0, 1, 0, 1, 100)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    el = time.perf_counter() - t0
+    out = ctx.featbuf_download(1, 100)
+    ctx.close()
+    _emit(json_fd, _base_line(100 * args.steps / el, args.steps, args.warmup, el / args.steps * 1e3,
+                              "cfg-1: img0.pgm -> img1.pgm (320x240), 100 features, 7x7, 2 levels (ss 4), max_residue 10",
+                              {"tracked": int((out["val"] >= 0).sum()), "ms_select_100": ms_select}))
+
+
+def run_cfg3(args, json_fd):
+    """BASELINE cfg-3: 1920x1080, 15x15 window, 4 levels / ss 2 (border 108), 5000 features, affine consistency check
+    (mode 2, 15x15 affine window) -- 3-frame sequence; the first call only stores templates, steps time later calls."""
+    tc = KLT_TrackingContext()
+    tc.window_width = tc.window_height = 15
+    tc.nPyramidLevels, tc.subsampling = 4, 2
+    tc.KLTUpdateTCBorder()
+    tc.affineConsistencyCheck = 2
+    n = 5000
+    ctx = Context(0)
+    ctx.configure(tc)
+    base = synth.synth_base(WIDTH, HEIGHT, 1)
+    frames = [synth.synth_frame(WIDTH, HEIGHT, 1, k, shift=(1.1, -0.7), base=base) for k in range(3)]
+    for k, f in enumerate(frames):
+        ctx.upload(k, f)
+    ctx.build_pyramids_batch([0, 1, 2], sync=True)
+    fl, placed = ctx.select(0, n, use_pyramid=True)
+    ctx.affine_alloc(0, n)
+    ctx.featbuf_upload(0, fl)
+    ctx.track_affine_async(0, 1, 0, 1, n, 0)            # stores the templates
+    ctx.sync()
+    live1 = int((ctx.featbuf_download(1, n)["val"] >= 0).sum())
+
+    def step():                                          # frame 1 -> frame 2 with the affine check active
+        ctx.build_pyramids_batch([1, 2])
+        ctx.track_affine_async(1, 2, 1, 2, n, 0)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    el = time.perf_counter() - t0
+    out = ctx.featbuf_download(2, n)
+    ctx.timing_enable(True)
+    for _ in range(min(args.steps, 20)):
+        step()
+    kern = {k["name"]: round(1e3 * k["total_ms"] / k["launches"], 1) for k in ctx.timing_read()}
+    ctx.close()
+    _emit(json_fd, _base_line(live1 * args.steps / el, args.steps, args.warmup, el / args.steps * 1e3,
+                              "cfg-3: 1920x1080, %d features placed (%d live), 15x15 window, 4 levels (ss 2), affine consistency "
+                              "check mode 2 (parity unpinned); per step: pyramids of both frames + translation tracker + affine check"
+                              % (placed, live1),
+                              {"tracked_after_affine": int((out["val"] >= 0).sum()), "kernel_us": kern}))
+
+
+def run_cfg5(args, json_fd):
+    """BASELINE cfg-5 (single GPU): 3840x2160 sequence, 20000 features, sequential mode, lost features replaced after every
+    frame.  Per step: upload is excluded (frames resident), pyramid of the new frame, track, REPLACING_SOME selection."""
+    w, h, n = 3840, 2160, 20000
+    nframes = 8
+    tc = cfg2_context()
+    tc.max_residue = 10.0
+    ctx = Context(0)
+    ctx.configure(tc)
+    base = synth.synth_base(w, h, 4)
+    for k in range(nframes):
+        ctx.upload(10 + k, synth.synth_frame(w, h, 4, k, base=base))
+    ctx.build_pyramids(10)
+    fl, placed = ctx.select(10, n, use_pyramid=True)
+    ctx.featbuf_upload(0, fl)
+    ctx.sync()
+
+    def run_sequence(timed):
+        t_sel = 0.0
+        for k in range(1, nframes):
+            ctx.build_pyramids(10 + k, sync=False)
+            ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)
+            if timed:
+                ctx.sync()
+                t = time.perf_counter()
+            ctx.select_async(10 + k, 2, True, k % 2, n)       # KLTReplaceLostFeatures on the resident level-0 images
+            if timed:
+                ctx.sync()
+                t_sel += time.perf_counter() - t
+        ctx.sync()
+        return t_sel
+
+    ctx.featbuf_upload(0, fl)
+    run_sequence(False)
+    reps = max(1, args.steps // (nframes - 1))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.featbuf_upload(0, fl)
+        run_sequence(False)
+    el = time.perf_counter() - t0
+    ctx.featbuf_upload(0, fl)
+    t_sel = run_sequence(True)
+    out = ctx.featbuf_download((nframes - 1) % 2, n)
+    frames_done = reps * (nframes - 1)
+    ctx.close()
+    _emit(json_fd, _base_line(n * frames_done / el, frames_done, 0, el / frames_done * 1e3,
+                              "cfg-5 (one GPU): 3840x2160 sequence, 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost "
+                              "features replaced after every frame; per frame: pyramid of the new frame + track + replacement",
+                              {"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,8 +336,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-l0", action="store_true", help="KLT_OPT_SPLIT_L0: fork/join pyramid build on two streams")
-    ap.add_argument("--config", choices=["cfg2", "cfg4"], default="cfg2",
-                    help="cfg2 (default, the headline line) or cfg4 (a shard of 1280x720 pairs, single GPU, informative)")
+    ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
+                    help="cfg2 (default, the headline line); the others are the remaining BASELINE configs on one GPU, informative")
     ap.add_argument("--pairs", type=int, default=32, help="pairs per step for --config cfg4")
     ap.add_argument("--pipeline", action="store_true",
                     help="KLT_OPT_TRACK_STREAM: tracker on a second HIP stream, overlapping the next step's pyramid build "
@@ -202,8 +350,8 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    if args.config == "cfg4":
-        return run_cfg4(args, json_fd)
+    if args.config != "cfg2":
+        return {"cfg1": run_cfg1, "cfg3": run_cfg3, "cfg4": run_cfg4, "cfg5": run_cfg5}[args.config](args, json_fd)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

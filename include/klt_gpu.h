@@ -110,11 +110,12 @@ int klt_upload_u8(klt_ctx *ctx, int slot, const uint8_t *px, int ncols, int nrow
 int klt_upload_f32(klt_ctx *ctx, int slot, const float *px, int ncols, int nrows, int pitch);
 /* Asynchronous ingest: the frame is copied from PINNED host memory on a dedicated copy stream and overlaps
  * the kernels of earlier frames; the next build / selection of the slot waits for it on the device, the copy itself
- * waits for queued work that still reads the slot.  `px` must stay untouched until klt_sync or the next upload into the
- * same slot has been issued AND a later klt_sync returned. */
+ * waits for queued work that still reads the slot.  `px` must stay untouched until klt_upload_wait (or klt_sync) has
+ * returned after the call. */
 int klt_host_alloc(klt_ctx *ctx, size_t bytes, void **out);     /* pinned host memory, freed by klt_host_free / klt_destroy */
 int klt_host_free(klt_ctx *ctx, void *p);
 int klt_upload_u8_async(klt_ctx *ctx, int slot, const uint8_t *px, int ncols, int nrows, int pitch);
+int klt_upload_wait(klt_ctx *ctx);      /* host waits for the copies issued so far (only the copy stream; kernels keep running) */
 /* smooth -> pyramid -> gradients of every level: ComputeImagePyramids for one image,
  * trackFeatures.py:165-172 + pyramid.py:37-77 + convolve.py:208-264 */
 int klt_build_pyramids_async(klt_ctx *ctx, int slot);

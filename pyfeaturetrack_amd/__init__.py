@@ -14,7 +14,7 @@ __version__ = "0.1.0"
 def __getattr__(name):
     # lazy: these modules bind the HIP library on first use
     import importlib
-    for mod in ("selectGoodFeatures", "trackFeatures", "writeFeatures"):
+    for mod in ("selectGoodFeatures", "trackFeatures", "writeFeatures", "storeFeatures", "trackSequence"):
         m = importlib.import_module("." + mod, __name__)
         if hasattr(m, name):
             return getattr(m, name)

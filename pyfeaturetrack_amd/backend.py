@@ -133,6 +133,18 @@ class Context:
             raise ValueError("upload_async takes a C-contiguous 2-D uint8 array in pinned memory")
         self._check(self._lib.klt_upload_u8_async(self._h, slot, img.ctypes.data, img.shape[1], img.shape[0], img.shape[1]))
 
+    def upload_wait(self):
+        """Host waits until every upload_async issued so far has left its pinned source buffer."""
+        self._check(self._lib.klt_upload_wait(self._h))
+
+    def staging(self, shape, count=2):
+        """`count` pinned uint8 staging buffers of `shape`, cached per context (pinned memory is never handed out twice)."""
+        cache = self.__dict__.setdefault("_staging", {})
+        key = (tuple(shape), count)
+        if key not in cache:
+            cache[key] = [self.pinned_array(shape) for _ in range(count)]
+        return cache[key]
+
     def build_pyramids(self, slot, sync=True):
         fn = self._lib.klt_build_pyramids if sync else self._lib.klt_build_pyramids_async
         self._check(fn(self._h, slot))

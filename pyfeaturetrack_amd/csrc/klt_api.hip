@@ -803,6 +803,14 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
     return KLT_OK;
 }
 
+int klt_upload_wait(klt_ctx *c)
+{
+    if (!c) return KLT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
+    return KLT_OK;
+}
+
 int klt_build_pyramids_async(klt_ctx *c, int slot) { return build_pyramids_batch(c, &slot, 1); }
 
 int klt_build_pyramids_batch_async(klt_ctx *c, const int *slots, int n) { return build_pyramids_batch(c, slots, n); }

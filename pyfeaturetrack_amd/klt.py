@@ -10,6 +10,8 @@ from __future__ import print_function
 import math
 import time
 
+import numpy as np
+
 from .convolve import KLTGetKernelWidths
 from .error import KLTError, KLTWarning  # noqa: F401  (re-exported like the reference's star imports)
 from .klt_util import KLTComputeSmoothSigma
@@ -138,12 +140,54 @@ class KLT_Feature:
         self.aff_Ayy = 1.0
 
 
-class KLT_FeatureHistory:      # klt.py:272-276 (empty stub in the reference)
-    pass
+_REC_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("val", np.int32), ("aux", np.int32)])   # == klt_feat
 
 
-class KLT_FeatureTable:        # klt.py:278-283 (empty stub in the reference)
-    pass
+def _lost_records(shape):
+    rec = np.zeros(shape, _REC_DTYPE)
+    rec["x"] = -1
+    rec["y"] = -1
+    rec["val"] = kltState.KLT_NOT_FOUND
+    return rec
+
+
+class KLT_FeatureHistory:
+    """One feature over all frames (klt.py:272-276 is an empty stub; upstream KLT 1.3.4's KLT_FeatureHistoryRec).
+    `rec` is the [nFrames] record array (x, y, val); fh[frame] gives a KLT_Feature copy."""
+
+    def __init__(self, nFrames=0):
+        self.nFrames = nFrames
+        self.rec = _lost_records(nFrames)
+
+    def __len__(self):
+        return self.nFrames
+
+    def __getitem__(self, frame):
+        return _feature_of(self.rec[frame])
+
+
+class KLT_FeatureTable:
+    """All features over all frames (klt.py:278-283 is an empty stub; upstream KLT 1.3.4's KLT_FeatureTableRec).
+    `rec` is a [nFrames, nFeatures] array of 16-byte records (x, y, val, aux) -- exactly the layout of the
+    device-side table KLTTrackSequence fills, so a tracked sequence comes back with ONE download.  Upstream indexes
+    feature-major (ft->feature[feat][frame]); `ft.feature(feat, frame)` mirrors that."""
+
+    def __init__(self, nFrames=0, nFeatures=0):
+        self.nFrames, self.nFeatures = nFrames, nFeatures
+        self.rec = _lost_records((nFrames, nFeatures))
+
+    x = property(lambda self: self.rec["x"])
+    y = property(lambda self: self.rec["y"])
+    val = property(lambda self: self.rec["val"])
+
+    def feature(self, feat, frame):
+        return _feature_of(self.rec[frame, feat])
+
+
+def _feature_of(r):
+    f = KLT_Feature()
+    f.x, f.y, f.val = float(r["x"]), float(r["y"]), int(r["val"])
+    return f
 
 
 def KLTPrintTrackingContext(tc):

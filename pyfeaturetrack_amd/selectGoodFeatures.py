@@ -38,9 +38,12 @@ def _image_size(img):
 
 
 def features_to_array(featurelist):
+    """KLT_Feature list -> record array (column-wise: three list comprehensions, no per-record numpy calls)."""
     fl = np.zeros(len(featurelist), FEAT_DTYPE)
-    for i, f in enumerate(featurelist):
-        fl[i] = (f.x, f.y, f.val, 0)
+    if len(featurelist):
+        fl["x"] = [f.x for f in featurelist]
+        fl["y"] = [f.y for f in featurelist]
+        fl["val"] = [f.val for f in featurelist]
     return fl
 
 
@@ -96,13 +99,15 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
     finally:
         if aff is not None:
             ctx.set_option(4, -1)
-    for feat, rec, old in zip(featurelist, fl, fl_in if fl_in is not None else fl):
-        if mode == selectionMode.REPLACING_SOME and old["val"] >= 0:
+    xs, ys, vals = fl["x"].tolist(), fl["y"].tolist(), fl["val"].tolist()
+    olds = fl_in["val"].tolist() if mode == selectionMode.REPLACING_SOME else None
+    for i, feat in enumerate(featurelist):
+        if olds is not None and olds[i] >= 0:
             continue                # live features are left untouched (:109-110)
-        if rec["val"] >= 0:
-            feat.x = int(rec["x"])
-            feat.y = int(rec["y"])
-            feat.val = int(rec["val"])
+        if vals[i] >= 0:
+            feat.x = int(xs[i])
+            feat.y = int(ys[i])
+            feat.val = vals[i]
         elif mode == selectionMode.SELECTING_ALL:
             feat.x = -1
             feat.y = -1

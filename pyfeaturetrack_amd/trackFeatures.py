@@ -81,23 +81,25 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
         rec = ctx.affine_download(state, len(featurelist))
     else:
         fl_out, _ = ctx.track(s1, s2, fl_in)
-    for i, (feat, old, new) in enumerate(zip(featurelist, fl_in, fl_out)):
-        if affine and old["val"] >= 0:
-            r = rec[i]
-            feat.aff_x, feat.aff_y = float(r["aff_x"]), float(r["aff_y"])
-            feat.aff_Axx, feat.aff_Ayx, feat.aff_Axy, feat.aff_Ayy = (float(r["Axx"]), float(r["Ayx"]), float(r["Axy"]),
-                                                                      float(r["Ayy"]))
-            feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = (_DEVICE_TEMPLATE if r["valid"] else None)
-        if old["val"] < 0:
+    olds = fl_in["val"].tolist()
+    xs, ys, vals = fl_out["x"].tolist(), fl_out["y"].tolist(), fl_out["val"].tolist()
+    if affine:
+        rcols = [rec[k].tolist() for k in ("aff_x", "aff_y", "Axx", "Ayx", "Axy", "Ayy", "valid")]
+    for i, feat in enumerate(featurelist):
+        if olds[i] < 0:
             continue                                  # only live features are tracked (:253)
-        if new["val"] == kltState.KLT_TRACKED:
-            feat.x = float(new["x"])
-            feat.y = float(new["y"])
+        if affine:
+            feat.aff_x, feat.aff_y = rcols[0][i], rcols[1][i]
+            feat.aff_Axx, feat.aff_Ayx, feat.aff_Axy, feat.aff_Ayy = rcols[2][i], rcols[3][i], rcols[4][i], rcols[5][i]
+            feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = (_DEVICE_TEMPLATE if rcols[6][i] else None)
+        if vals[i] == kltState.KLT_TRACKED:
+            feat.x = xs[i]
+            feat.y = ys[i]
             feat.val = kltState.KLT_TRACKED
         else:
             feat.x = -1.0
             feat.y = -1.0
-            feat.val = int(new["val"])
+            feat.val = vals[i]
             feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = None
 
     if tc.sequentialMode:

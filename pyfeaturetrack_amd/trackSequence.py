@@ -1,0 +1,110 @@
+"""Device-resident sequence tracking: the call pattern of upstream KLT's example3 (select once; per frame
+KLTTrackFeatures in sequentialMode, KLTReplaceLostFeatures, KLTStoreFeatureList) without a host round trip per frame.
+
+The per-frame feature lists are the rows of ONE device-side [nFrames x nFeatures] record array (feature-buffer views,
+include/klt_gpu.h klt_featbuf_view); row k-1 is the tracker's input and row k its output, replacement runs in place on
+row k, and the whole table is downloaded once at the end into a KLT_FeatureTable.  Results
+are bit-identical to the per-frame host API loop, which the GPU tests check.
+"""
+from __future__ import print_function
+
+import numpy as np
+
+from .backend import REPLACING_SOME, SELECTING_ALL, default_context
+from .klt import KLT_FeatureTable
+from .selectGoodFeatures import _fix_window, _slots_of, image_to_array
+
+_FB_TABLE = 60000            # feature-buffer ids used by this module: the table, then one view per frame
+_FB_ROW0 = 60001
+_MAX_FRAMES = 65535 - _FB_ROW0
+_OPT_SELECT_AFFINE_STATE = 4
+
+
+def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True):
+    """Track `nFeatures` features through `frames` (an iterable of equally sized 8-bit images) and return the
+    KLT_FeatureTable: row 0 = the selected features, row k = the features after tracking frame k-1 -> k (and, with
+    `replace_lost`, after replacing the lost ones on frame k: new features carry their eigenvalue in `val`, as after
+    KLTReplaceLostFeatures).  tc.affineConsistencyCheck >= 0 runs the affine check on every step."""
+    frames = iter(frames)
+    _fix_window(tc)
+    ctx = default_context()
+    ctx.configure(tc)
+    s = list(_slots_of(tc)[:2])
+    first = image_to_array(next(frames))
+    rows = [first]
+    nrows, ncols = first.shape
+    affine = tc.affineConsistencyCheck >= 0
+
+    # frames are consumed lazily; the table grows in chunks so that a generator of unknown length works
+    chunk = 64
+    tables = []                         # [(fb_table, first_row, n_rows)]
+
+    def row_fb(k):
+        ci, off = divmod(k, chunk)
+        if ci == len(tables):
+            if ci * (chunk + 1) + chunk + 1 > _MAX_FRAMES:
+                raise ValueError("sequence too long for one call")
+            base = _FB_TABLE + ci * (chunk + 1)
+            ctx.featbuf_alloc(base, chunk * nFeatures)
+            for j in range(chunk):
+                ctx.featbuf_view(base + 1 + j, base, j * nFeatures, nFeatures)
+            tables.append(base)
+        return tables[ci] + 1 + off
+
+    stage = ctx.staging((nrows, ncols)) if async_ingest and first.dtype == np.uint8 else None
+
+    def ingest(slot, img, k):
+        if img.shape != (nrows, ncols):
+            from .error import KLTError
+            KLTError("(KLTTrackSequence) Size of incoming image ({0} by {1}) is different from size of previous image "
+                     "({2} by {3})".format(img.shape[1], img.shape[0], ncols, nrows))
+        if stage is None or img.dtype != np.uint8:
+            ctx.upload(slot, img)
+        else:
+            buf = stage[k % 2]
+            ctx.upload_wait()               # the copy that last read this staging buffer has finished (kernels keep running)
+            buf[...] = img
+            ctx.upload_async(slot, buf)
+
+    ingest(s[0], first, 0)
+    ctx.build_pyramids(s[0], sync=False)
+    ctx.select_async(s[0], SELECTING_ALL, True, row_fb(0), nFeatures)
+    state = None
+    if affine:
+        state = getattr(ctx, "_next_affine_state", 0)
+        ctx._next_affine_state = state + 1
+        ctx.affine_alloc(state, nFeatures)
+    k = 0
+    try:
+        if affine:
+            ctx.set_option(_OPT_SELECT_AFFINE_STATE, state)
+        for k, img in enumerate(frames, start=1):
+            cur, prev = s[k % 2], s[(k - 1) % 2]
+            ingest(cur, image_to_array(img), k)
+            ctx.build_pyramids(cur, sync=False)
+            if affine:
+                ctx.track_affine_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures, state)
+            else:
+                ctx.track_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures)
+            if replace_lost:
+                ctx.select_async(cur, REPLACING_SOME, True, row_fb(k), nFeatures)
+    finally:
+        if affine:
+            ctx.set_option(_OPT_SELECT_AFFINE_STATE, -1)
+    nframes = k + 1
+    ft = KLT_FeatureTable(nframes, nFeatures)
+    for ci, base in enumerate(tables):
+        lo = ci * chunk
+        hi = min(nframes, lo + chunk)
+        ft.rec[lo:hi] = ctx.featbuf_download(base, (hi - lo) * nFeatures).reshape(hi - lo, nFeatures)
+    ft.rec["aux"] = 0
+    if tc.sequentialMode:
+        # leave the context as the per-frame API would: the last frame's pyramids are "frame 1" of the next call
+        from .trackFeatures import _ResidentPyramids
+        last = s[(nframes - 1) % 2]
+        if last != s[0]:
+            ctx.swap_slots(s[0], s[1])
+        tc.pyramid_last = _ResidentPyramids(s[0], ncols, nrows, "img")
+        tc.pyramid_last_gradx = _ResidentPyramids(s[0], ncols, nrows, "gradx")
+        tc.pyramid_last_grady = _ResidentPyramids(s[0], ncols, nrows, "grady")
+    return ft

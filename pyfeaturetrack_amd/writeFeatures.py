@@ -33,3 +33,16 @@ def KLTWriteFeatureList(featurelist, filename, fmt="%5.1f"):
         f.write("# KLT feature list: %d features\n" % len(featurelist))
         for i, feat in enumerate(featurelist):
             f.write("%d %s %s %d\n" % (i, fmt % feat.x, fmt % feat.y, feat.val))
+
+
+def KLTWriteFeatureTable(ft, filename, fmt="%5.1f"):
+    """Text dump of a KLT_FeatureTable (upstream KLTWriteFeatureTable's text form: one line per feature, one
+    `(x,y)=val` group per frame)."""
+    with open(filename, "w") as f:
+        f.write("# KLT feature table: %d frames x %d features\n" % (ft.nFrames, ft.nFeatures))
+        xs, ys, vs = ft.x.T.tolist(), ft.y.T.tolist(), ft.val.T.tolist()
+        for i in range(ft.nFeatures):
+            f.write("%d |" % i)
+            for x, y, v in zip(xs[i], ys[i], vs[i]):
+                f.write(" (%s,%s)=%d" % (fmt % x, fmt % y, v))
+            f.write("\n")

@@ -772,3 +772,67 @@ def test_python_api_sequential_mode(cfg1, golden_dir):
         assert [f.val for f in fl] == [int(v) for v in cfg1["seq50_1_val"]]
     finally:
         sgf.KLT_verbose = 1
+
+
+def _host_api_sequence(tc, frames, n, replace):
+    """The per-frame loop KLTTrackSequence replaces (upstream example3's order: track, replace, store)."""
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import storeFeatures as sf
+    from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures
+    ft = sf.KLTCreateFeatureTable(len(frames), n)
+    fl = sgf.KLTSelectGoodFeatures(tc, frames[0], n)
+    sf.KLTStoreFeatureList(fl, ft, 0)
+    for k in range(1, len(frames)):
+        KLTTrackFeatures(tc, frames[k - 1], frames[k], fl)
+        if replace:
+            sgf.KLTReplaceLostFeatures(tc, frames[k], fl)
+        sf.KLTStoreFeatureList(fl, ft, k)
+    return ft
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("replace,affine,ingest", [(True, False, True), (False, False, False), (True, True, True)])
+def test_track_sequence_matches_per_frame_api(replace, affine, ingest):
+    """KLTTrackSequence (device-resident [frames x features] table, one download) gives exactly the rows the per-frame
+    host API loop produces; with a generator as the frame source."""
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.trackSequence import KLTTrackSequence
+    w, h, n, nf = 400, 300, 300, 7
+    base = synth.synth_base(w, h, 11)
+    frames = [synth.synth_frame(w, h, 11, k, shift=(2.3, -1.4), base=base) for k in range(nf)]
+    frames[4] = frames[4].copy()
+    frames[4][90:170, 120:260] = 128                      # wipe a region: features there are lost and replaced elsewhere
+
+    def make():
+        tc = KLT_TrackingContext()
+        tc.sequentialMode = True
+        tc.max_residue = 10.0
+        if affine:
+            tc.affineConsistencyCheck = 2
+        return tc
+
+    sgf.KLT_verbose = 0
+    try:
+        want = _host_api_sequence(make(), frames, n, replace)
+        tc = make()
+        got = KLTTrackSequence(tc, (f for f in frames), n, replace_lost=replace, async_ingest=ingest)
+        assert got.nFrames == nf and got.nFeatures == n
+        assert (want.val[1:] < 0).sum() > 0 or replace      # the wiped region does lose features
+        if replace:
+            assert (got.val[4:] > 0).sum() > 0              # ... and they are replaced (new features carry their eigenvalue)
+        assert np.array_equal(got.val, want.val)
+        assert np.array_equal(got.x, want.x) and np.array_equal(got.y, want.y)
+        # the context is left as the per-frame API leaves it: the next KLTTrackFeatures call continues the sequence
+        from pyfeaturetrack_amd import storeFeatures as sf
+        from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures
+        nxt = synth.synth_frame(w, h, 11, nf, shift=(2.3, -1.4), base=base)
+        fl = sf.KLTCreateFeatureList(n)
+        sf.KLTExtractFeatureList(fl, got, nf - 1)
+        if not affine:
+            KLTTrackFeatures(tc, frames[-1], nxt, fl)
+            live = [(f.x, f.y) for f in fl if f.val == 0]
+            assert len(live) > n // 2
+    finally:
+        sgf.KLT_verbose = 1
