@@ -95,6 +95,9 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
 /* 1: the pyramid build smooths level 0 alone, then runs the level-0 gradients on the main stream concurrently with the
  * reductions / small-level gradients on a side stream (fork/join with events); 0 (default): fused level-0 kernel. */
 #define KLT_OPT_SPLIT_L0 7
+/* 1 (default): minimum-distance enforcement as parallel passes over all candidates (a candidate is accepted once every
+ * higher-ranked neighbour is rejected; same result as the walk); 0: sort all candidates and walk them in order */
+#define KLT_OPT_SELECT_PARALLEL_NMS 8
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
 /* ---- parameters and taps ------------------------------------------------------------------- */

@@ -99,6 +99,11 @@ struct klt_ctx {
     klt_feat *fl_snapshot = nullptr;
     size_t fl_snapshot_cap = 0;
     bool use_topk = true;
+    bool use_mis = true;                      // parallel minimum-distance passes instead of the sorted serial walk
+    int mis_rounds_hint = 6;
+    uint32_t *mis_st = nullptr, *mis_list = nullptr;
+    unsigned *mis_cnt = nullptr;              // [tiles] + kMisRounds remaining counters + accepted counter
+    size_t mis_st_cap = 0, mis_list_cap = 0, mis_cnt_cap = 0;
     const unsigned long long *sorted_keys = nullptr;   // what the last selection walked (test hook)
     int sorted_count = 0;
     TrackPairDesc *pair_table = nullptr;
@@ -649,7 +654,7 @@ int klt_create(int device, klt_ctx **out)
     c->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void **)&c->stats_d, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->placed_d, 2 * sizeof(int))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->placed_d, 4 * sizeof(int))) != hipSuccess ||
         (e = hipMemset(c->stats_d, 0, (1 + 2 * KLT_MAX_LEVELS) * sizeof(unsigned long long))) != hipSuccess) {
         g_create_error = std::string("device setup failed: ") + hipGetErrorString(e);
         delete c;
@@ -676,7 +681,7 @@ void klt_destroy(klt_ctx *c)
         if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
-    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
@@ -822,6 +827,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_SMOOTH_GRAD_VARIANT) { g_smooth_grad_variant = value; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SPLIT_L0) { c->split_l0 = value != 0; return KLT_OK; }
+    if (option == KLT_OPT_SELECT_PARALLEL_NMS) { c->use_mis = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_AFFINE_STATE) {
         if (value >= 0 && ((size_t)value >= c->aff.size() || !c->aff[value].rec)) return fail(c, KLT_ERR_STATE, "affine state not allocated");
         c->select_aff_state = value;
@@ -1056,10 +1062,110 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
         return 0;
     };
 
-    // top-K prefilter: sort only the candidates the greedy walk can plausibly reach (one small D2H read-back)
     long long target = 64LL * n;
     if (target < 65536) target = 65536;
-    if (c->use_topk && ncand > 262144 && target < ncand / 2) {
+    const bool prefilter = c->use_topk && ncand > 262144 && target < ncand / 2;
+
+    // ---- parallel minimum distance (default): decide every candidate in a few passes, rank the accepted ones, and
+    // fill the free slots with the best of them (same result as the sorted serial walk below)
+    const int R = d >= 0 ? d / step : -1;
+    if (c->use_mis && ncand > 0 && mis_stage_bytes(R) <= 120 * 1024) {
+        // passes enqueued before the host looks at the outcome: what the previous selection needed (frames of a sequence
+        // behave alike); an idle pass costs 5 us, a second look costs a host round trip
+        const int kMisRounds = c->mis_rounds_hint;
+        constexpr int kMaxRounds = 512;
+        const int tiles = mis_tiles(nx, ny);
+        // two accepted candidates are more than R cells apart in x or in y: at most one per (R+1)x(R+1) block of cells
+        const long long bound = R < 0 ? ncand : (long long)((nx + R) / (R + 1)) * ((ny + R) / (R + 1));
+        const bool by_rank = bound <= 98304;                // rank by counting; beyond that sort the accepted keys
+        long long np2 = 2048;
+        while (np2 < bound) np2 <<= 1;
+        // one allocation of counters: [tiles] list lengths | [kMaxRounds] undecided left after pass r | accepted count |
+        // 8192 histogram bins + 4 words of prefilter info | [bound] ranks
+        const size_t off_rem = (size_t)tiles, off_acc = off_rem + kMaxRounds, off_hist = off_acc + 1, off_rank = off_hist + 8192 + 4;
+        const size_t n_cnt = off_rank + (by_rank ? (size_t)bound : 0);
+        if (int rc = ensure(c, c->keys2, c->keys2_cap, (size_t)(np2 > npow2 ? np2 : npow2))) return rc;
+        if (int rc = ensure(c, c->mis_st, c->mis_st_cap, (size_t)ncand)) return rc;
+        if (int rc = ensure(c, c->mis_list, c->mis_list_cap, (size_t)tiles * 1024)) return rc;
+        if (int rc = ensure(c, c->mis_cnt, c->mis_cnt_cap, n_cnt)) return rc;
+        if (int rc = ensure(c, c->fl_snapshot, c->fl_snapshot_cap, (size_t)n)) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->fl_snapshot, b->d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+        unsigned *const info_d = c->mis_cnt + off_hist + 8192, *const rank_d = c->mis_cnt + off_rank;
+        int *const nfill_d = c->placed_d + 2;
+        MisArgs ma;
+        ma.keys = c->keys; ma.st = c->mis_st; ma.list = c->mis_list; ma.cnt = c->mis_cnt;
+        ma.remaining = c->mis_cnt + off_rem; ma.acc_count = c->mis_cnt + off_acc;
+        ma.acc_keys = c->keys2; ma.info = info_d;
+        ma.nx = nx; ma.ny = ny; ma.R = R; ma.stage = 1; ma.iterations = 1;   // more iterations per launch did not save launches
+        NmsArgs pa = na;                                    // placement: the accepted candidates never exclude each other
+        pa.d = -1; pa.cell = 1; pa.cell_magic = 0u; pa.gw = pa.gh = 1; pa.grid_in_lds = 1; pa.grid_global = nullptr;
+        pa.keys = c->keys2; pa.nkeys = (int)np2;
+        if (by_rank) launch_free_slots(c->stream, b->d, n, pa.overwrite_all, pa.slots, nfill_d);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const bool filtered = prefilter && attempt == 0;
+            HIPCHK(c, hipMemsetAsync(c->mis_cnt + off_rem, 0, (n_cnt - off_rem) * sizeof(unsigned), c->stream));
+            if (!by_rank) HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)np2 * sizeof(unsigned long long), c->stream));
+            if (filtered) {
+                TimerScope t(c, F_SORT, (double)ncand * 8);
+                launch_key_threshold(c->stream, c->keys, (int)ncand, (unsigned)target, c->mis_cnt + off_hist, info_d);
+            }
+            int round = 0;
+            {
+                TimerScope t(c, F_NMS, (double)ncand * 12);
+                launch_mis_init(c->stream, ma);
+            }
+            unsigned left = 0, info[4] = {0, 0, 0, 0};
+            int res[2] = {0, 0};
+            for (;;) {
+                {
+                    TimerScope t(c, F_NMS, (double)n * 16);
+                    for (int r = 0; r < kMisRounds; r++, round++)
+                        if (const int e = launch_mis_round(c->stream, ma, round))
+                            return fail(c, KLT_ERR_DEVICE, std::string("minimum-distance pass: ") + hipGetErrorString((hipError_t)e));
+                }
+                unsigned rem[64];
+                const int look = round < 64 ? round : 64;                        // the last `look` passes
+                HIPCHK(c, hipMemcpyAsync(rem, ma.remaining + round - look, look * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                if (by_rank) {
+                    TimerScope t(c, F_NMS, (double)n * 16);
+                    launch_mis_place(c->stream, pa, ma.acc_count, rank_d, nfill_d, (int)bound);
+                } else {
+                    { TimerScope t(c, F_SORT, (double)np2 * 16); launch_sort_desc(c->stream, c->keys2, (int)np2); }
+                    TimerScope t(c, F_NMS, (double)n * 16);
+                    const int e = launch_nms(c->stream, pa);
+                    if (e) return fail(c, KLT_ERR_DEVICE, std::string("nms launch: ") + hipGetErrorString((hipError_t)e));
+                }
+                HIPCHK(c, hipMemcpyAsync(res, c->placed_d, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(info, info_d, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                left = rem[look - 1];
+                if (left == 0u) {
+                    int needed = look;                                           // learn how many passes were needed
+                    while (needed > 1 && rem[needed - 2] == 0u) needed--;
+                    needed += round - look;
+                    c->mis_rounds_hint = needed < 2 ? 2 : (needed > 32 ? 32 : needed);
+                    break;
+                }
+                // a dependency chain longer than the passes run so far: put the list back and keep going
+                if (round + kMisRounds > kMaxRounds) return fail(c, KLT_ERR_DEVICE, "minimum-distance passes did not settle");
+                HIPCHK(c, hipMemcpyAsync(b->d, c->fl_snapshot, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+                if (by_rank) HIPCHK(c, hipMemsetAsync(rank_d, 0, (size_t)bound * sizeof(unsigned), c->stream));
+            }
+            c->sorted_keys = by_rank ? nullptr : c->keys2; c->sorted_count = by_rank ? 0 : (int)np2;
+            // ran out of accepted candidates although the prefilter dropped some: repeat with every candidate
+            if (filtered && res[1] && info[1] < info[2]) {
+                HIPCHK(c, hipMemcpyAsync(b->d, c->fl_snapshot, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+                continue;
+            }
+            break;
+        }
+        HIPCHK(c, hipGetLastError());
+        return KLT_OK;
+    }
+
+    // ---- sorted serial walk (KLT_OPT_SELECT_PARALLEL_NMS = 0, or an exclusion square too large for the LDS tile)
+    // top-K prefilter: sort only the candidates the greedy walk can plausibly reach (one small D2H read-back)
+    if (prefilter) {
         if (int rc = ensure(c, c->keys2, c->keys2_cap, (size_t)npow2)) return rc;
         size_t hcap = c->topk_hist ? 8192 + 4 : 0;
         if (int rc = ensure(c, c->topk_hist, hcap, (size_t)8192 + 4)) return rc;
@@ -1393,7 +1499,7 @@ int klt_download_sorted_candidates(klt_ctx *c, float *val, int32_t *x, int32_t *
 {
     if (!c || !val || !x || !y || n < 0) return fail(c, KLT_ERR_ARG, "bad argument");
     if (c->sel_nc == 0) return fail(c, KLT_ERR_STATE, "no selection has run");
-    if (!c->sorted_keys) return fail(c, KLT_ERR_STATE, "no selection has run");
+    if (!c->sorted_keys) return fail(c, KLT_ERR_STATE, "the last selection kept no sorted candidate list (KLT_OPT_SELECT_PARALLEL_NMS = 0 keeps one)");
     if (n > c->sorted_count) n = c->sorted_count;
     std::vector<unsigned long long> h((size_t)(n > 0 ? n : 1));
     HIPCHK(c, hipSetDevice(c->device));

@@ -85,6 +85,19 @@ struct NmsArgs {
     int nkeys, nfeat, overwrite_all, d /* mindist-1 */, cell, gw, gh, grid_in_lds;
 };
 
+// parallel minimum-distance passes (select_kernels.hip)
+struct MisArgs {
+    const unsigned long long *keys;   // [ny*nx] candidate keys of the eigenvalue pass (0 = no candidate)
+    uint32_t *st;                     // [ny*nx] state per candidate cell
+    uint32_t *list;                   // [tiles * 1024] undecided cells of every 32x32 tile
+    unsigned *cnt;                    // [tiles] length of each tile's list
+    unsigned *remaining;              // [rounds] undecided candidates left after pass r
+    unsigned long long *acc_keys;     // accepted candidates (unsorted)
+    unsigned *acc_count;
+    const unsigned *info;             // info[0] = lowest key bin that takes part (top-K prefilter)
+    int nx, ny, R /* exclusion radius in cells */, stage /* 1: stage tile + halo in LDS */, iterations /* per launch */;
+};
+
 // ---- launchers (each enqueues on `s`; no synchronisation) ----
 void launch_hconv_u8(hipStream_t s, const uint8_t *in, int ncols, int nrows, float *outA, float *outB,
                      int out_cols, int xstride, int xoff, const Taps &ta, const Taps *tb);
@@ -109,6 +122,13 @@ void launch_sort_desc(hipStream_t s, unsigned long long *keys, int npow2);
 void launch_topk_prefilter(hipStream_t s, const unsigned long long *keys, int n, unsigned target, unsigned *hist,
                            unsigned *info /* [0] bin, [1] kept (histogram), [2] valid, [3] compaction counter */, unsigned long long *out);
 int  launch_nms(hipStream_t s, const NmsArgs &a);   // returns 0 or a hipError_t
+void launch_key_threshold(hipStream_t s, const unsigned long long *keys, int n, unsigned target, unsigned *hist, unsigned *info);
+int  mis_tiles(int nx, int ny);
+size_t mis_stage_bytes(int R);
+void launch_mis_init(hipStream_t s, const MisArgs &a);
+int  launch_mis_round(hipStream_t s, const MisArgs &a, int round);   // returns 0 or a hipError_t
+void launch_free_slots(hipStream_t s, const klt_feat *fl, int nfeat, int overwrite_all, int *slots, int *nfill_out);
+void launch_mis_place(hipStream_t s, const NmsArgs &a, const unsigned *count, unsigned *rank, const int *nfill, int bound);
 void launch_unpack_candidates(hipStream_t s, const unsigned long long *keys, int n, float *val, int *x, int *y);
 
 void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, int n, int nlevels, unsigned long long *stats);

@@ -446,6 +446,11 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(NmsArgs a)
                 if (base > 0 && is_free && a.d >= 0) is_free = grid_free<LDSGRID>(grid, a, sx, sy);
                 unsigned long long mask = __ballot(is_free), accepted = 0ull;
                 int room = nfill - placed;
+                if (a.d < 0) {                   // nothing excludes anything: the first `room` free lanes are accepted
+                    const bool take = ((mask >> lane) & 1ull) && __popcll(mask & ((1ull << lane) - 1ull)) < room;
+                    accepted = __ballot(take);
+                    mask = 0ull;
+                }
                 // rank order = lane order: the first free lane is accepted and blocks the later lanes near it
                 while (mask != 0ull && room > 0) {
                     const int l = __ffsll((long long)mask) - 1;
@@ -506,6 +511,272 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(NmsArgs a)
     }
 }
 
+// ------------------------------------------------------------------ minimum distance without the serial walk
+// _enforceMinimumDistance (selectGoodFeatures.py:45-135) accepts a candidate iff no candidate of higher rank within
+// the exclusion square was accepted.  That fixed point is unique, so it can be reached in any order: a candidate is
+// ACCEPTED as soon as every higher-ranked candidate within the square is rejected, and REJECTED as soon as one
+// accepted candidate lies within the square.  Every decision taken is final and equals the sequential walk's; stale
+// reads of a neighbour (still "undecided" although it has just been decided) only postpone a decision.  One launch =
+// one such pass over the undecided candidates; 6 passes settle 320 000 candidates of a 1080p frame.  The accepted
+// candidates are then sorted by rank and the first `free slots` of them are exactly what the walk would have placed.
+//
+// State per candidate cell (u32): 0 = no candidate / rejected, f32 bits of the eigenvalue (>= 1.0f) = undecided,
+// bits | 0x80000000 = accepted.  Rank order = (value, x, y) descending, so for equal values the neighbour to the right
+// wins, and in the same column the neighbour below.
+// Each workgroup owns one 32x32 tile of the candidate grid and the list of its undecided cells (compacted in place).
+constexpr int MIS_TILE = 32, MIS_CAP = MIS_TILE * MIS_TILE, MIS_T = 256;
+
+__global__ __launch_bounds__(MIS_T) void mis_init_kernel(MisArgs a)
+{
+    __shared__ unsigned s_cursor;
+    const int tiles_x = (a.nx + MIS_TILE - 1) / MIS_TILE;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const unsigned thr = a.info[0];
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_cursor = 0u;
+    __syncthreads();
+    uint32_t *list = a.list + (size_t)blockIdx.x * MIS_CAP;
+    for (int k0 = 0; k0 < MIS_CAP; k0 += MIS_T) {
+        const int k = k0 + threadIdx.x;
+        const int xi = tx * MIS_TILE + (k & (MIS_TILE - 1)), yi = ty * MIS_TILE + k / MIS_TILE;
+        const bool inside = xi < a.nx && yi < a.ny;
+        const int p = yi * a.nx + xi;
+        const unsigned long long key = inside ? a.keys[p] : 0ull;
+        const bool keep = key != 0ull && key_bin(key) >= thr;
+        if (inside) a.st[p] = keep ? (uint32_t)(key >> 32) : 0u;
+        const unsigned long long m = __ballot(keep);
+        unsigned wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&s_cursor, (unsigned)__popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (keep) list[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.cnt[blockIdx.x] = s_cursor;
+}
+
+__global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
+{
+    // staged tiles: K = keys of the tile + halo ((32 + 2R)^2 u64: state << 32 | x << 16 | y, so the accepted bit and the
+    // rank order both survive a plain max), H = max of K over the horizontal window, interior columns only.  The tile
+    // is iterated a few times per launch: decisions taken inside the tile are visible to the next iteration at once,
+    // the halo keeps the states it had when the tile was staged (stale = still undecided = a decision postponed).
+    extern __shared__ unsigned long long lds64[];
+    __shared__ uint32_t acc_local[MIS_CAP];
+    __shared__ unsigned s_cursor, s_acc, s_base, s_progress;
+    unsigned n = a.cnt[blockIdx.x];
+    if (n == 0u) return;
+    const int tiles_x = (a.nx + MIS_TILE - 1) / MIS_TILE;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int R = a.R, W = MIS_TILE + 2 * R, L = 2 * R + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool staged = a.stage && R > 0;
+    unsigned long long *K = lds64, *H = lds64 + (staged ? W * W : 0);
+    const int ox = tx * MIS_TILE - R, oy = ty * MIS_TILE - R;
+    uint32_t *list = a.list + (size_t)blockIdx.x * MIS_CAP;
+    if (threadIdx.x == 0) s_acc = 0u;
+    if (staged) {
+        for (int cx0 = 0; cx0 < W; cx0 += 64)
+            for (int r0 = 0; r0 < W; r0 += 64) {            // 16 rows per wavefront in flight at once
+                const int cx = cx0 + lane, gx = ox + cx;
+                uint32_t v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int r = r0 + wave + 4 * u, gy = oy + r;
+                    v[u] = (cx < W && r < W && gx >= 0 && gx < a.nx && gy >= 0 && gy < a.ny) ? a.st[(size_t)gy * a.nx + gx] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int r = r0 + wave + 4 * u, gy = oy + r;
+                    if (cx < W && r < W)
+                        K[r * W + cx] = v[u] ? ((unsigned long long)v[u] << 32) | ((unsigned long long)gx << 16) | (unsigned long long)gy : 0ull;
+                }
+            }
+    }
+    const int iterations = staged ? a.iterations : 1;
+    for (int it = 0; it < iterations && n > 0u; it++) {
+        __syncthreads();                                     // K complete / updated; s_* of the last iteration consumed
+        if (threadIdx.x == 0) { s_cursor = 0u; s_progress = 0u; }
+        const unsigned acc_before = s_acc;
+        if (staged) {
+            for (int k = threadIdx.x; k < W * MIS_TILE; k += MIS_T) {
+                const unsigned long long *row = &K[(k / MIS_TILE) * W + (k % MIS_TILE)];     // window [c, c + 2R] of the row
+                unsigned long long m = row[0];
+#pragma unroll 6
+                for (int dx = 1; dx <= 2 * R; dx++) m = max(m, row[dx]);
+                H[k] = m;
+            }
+        }
+        __syncthreads();
+        for (unsigned base = 0; base < n; base += MIS_T) {
+            const unsigned i = base + threadIdx.x;
+            const bool valid = i < n;
+            const int p = valid ? (int)list[i] : 0;
+            const int xi = p % a.nx, yi = p / a.nx;
+            bool near_accepted = false, blocked = false, gone = false;
+            uint32_t sp = 0u;
+            int kidx = 0;
+            if (valid && staged) {
+                const int lx = xi - tx * MIS_TILE, ly = yi - ty * MIS_TILE;          // interior coordinates
+                kidx = (ly + R) * W + lx + R;
+                const unsigned long long kp = K[kidx];
+                sp = (uint32_t)(kp >> 32);
+                gone = kp == 0ull;                                                   // rejected by a neighbour's push
+                unsigned long long m = 0ull;
+                const unsigned long long *col = &H[ly * MIS_TILE + lx];              // rows ly .. ly + 2R of H
+#pragma unroll 6
+                for (int dy = 0; dy <= 2 * R; dy++) m = max(m, col[dy * MIS_TILE]);
+                near_accepted = (m >> 63) != 0ull;
+                blocked = m > kp;
+            } else if (valid) {
+                sp = a.st[p];
+                gone = sp == 0u;
+                const int x0 = max(xi - R, 0), x1 = min(xi + R, a.nx - 1), y0 = max(yi - R, 0), y1 = min(yi + R, a.ny - 1);
+                for (int yy = y0; yy <= y1 && !near_accepted && !gone; yy++) {
+                    const uint32_t *row = a.st + (size_t)yy * a.nx;
+                    for (int xx = x0; xx <= x1; xx++) {
+                        const uint32_t s = row[xx];
+                        near_accepted |= (s >> 31) != 0u;
+                        blocked |= s > sp || (s == sp && (xx > xi || (xx == xi && yy > yi)));
+                    }
+                }
+            }
+            const bool live = valid && !gone;
+            const bool reject = live && near_accepted;
+            const bool wait = live && !near_accepted && blocked;
+            const bool accept = live && !near_accepted && !blocked;
+            if (reject) a.st[p] = 0u;
+            if (accept) {
+                a.st[p] = sp | 0x80000000u;
+                acc_local[atomicAdd(&s_acc, 1u)] = (uint32_t)p;
+                if (!staged) {                               // push: every undecided neighbour is rejected right away
+                    const int x0 = max(xi - R, 0), x1 = min(xi + R, a.nx - 1), y0 = max(yi - R, 0), y1 = min(yi + R, a.ny - 1);
+                    for (int yy = y0; yy <= y1; yy++)
+                        for (int xx = x0; xx <= x1; xx++) {
+                            uint32_t *q = a.st + (size_t)yy * a.nx + xx;
+                            const uint32_t s = *q;
+                            if ((xx != xi || yy != yi) && s != 0u && (s >> 31) == 0u) *q = 0u;
+                        }
+                }
+            }
+            if ((reject || accept || (valid && gone)) && staged) s_progress = 1u;
+            __syncthreads();                                 // every read of this batch of the list (and of K by it) is done
+            if (staged && reject) K[kidx] = 0ull;
+            if (staged && accept) K[kidx] |= 1ull << 63;
+            const unsigned long long m = __ballot(wait);
+            unsigned wbase = 0;
+            if (lane == 0 && m) wbase = atomicAdd(&s_cursor, (unsigned)__popcll(m));
+            wbase = __shfl(wbase, 0);
+            if (wait) list[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
+        }
+        __syncthreads();
+        n = s_cursor;
+        const unsigned nacc = s_acc;
+        if (staged && nacc > acc_before) {                   // push for the staged tile: the block shares the windows
+            for (unsigned idx = threadIdx.x; idx < (nacc - acc_before) * (unsigned)(L * L); idx += MIS_T) {
+                const int p = (int)acc_local[acc_before + idx / (unsigned)(L * L)], w = (int)(idx % (unsigned)(L * L));
+                const int gx = p % a.nx - R + w % L, gy = p / a.nx - R + w / L;
+                const int kq = (gy - oy) * W + (gx - ox);
+                const unsigned long long k = K[kq];
+                if (k != 0ull && (k >> 63) == 0ull) {
+                    K[kq] = 0ull;
+                    a.st[(size_t)gy * a.nx + gx] = 0u;
+                }
+            }
+        }
+        if (!s_progress) break;                              // nothing moved: the rest waits for other tiles
+    }
+    __syncthreads();
+    const unsigned nacc = s_acc;
+    if (threadIdx.x == 0) {
+        a.cnt[blockIdx.x] = n;
+        if (n) atomicAdd(&a.remaining[round], n);
+        s_base = nacc ? atomicAdd(a.acc_count, nacc) : 0u;
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < nacc; i += MIS_T) a.acc_keys[s_base + i] = a.keys[acc_local[i]];
+}
+
+// ---- placement of the accepted candidates: rank by counting, then the first `free slots` fill the list
+// free slots in list order (selectGoodFeatures.py:109-110): every slot when overwriting, else the lost features
+__global__ __launch_bounds__(1024) void free_slots_kernel(const klt_feat *__restrict__ fl, int nfeat, int overwrite_all,
+                                                          int *__restrict__ slots, int *__restrict__ nfill_out)
+{
+    __shared__ int scan[1024];
+    const int tid = threadIdx.x;
+    if (overwrite_all) { if (tid == 0) *nfill_out = nfeat; return; }
+    const int per = (nfeat + 1023) / 1024, lo = tid * per, hi = min(lo + per, nfeat);
+    int cnt = 0;
+    for (int i = lo; i < hi; i++) cnt += fl[i].val < 0;
+    scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    int k = scan[tid] - cnt;
+    for (int i = lo; i < hi; i++)
+        if (fl[i].val < 0) slots[k++] = i;
+    if (tid == 1023) *nfill_out = scan[tid];
+}
+
+// rank[i] += number of accepted keys in chunk blockIdx.y that are greater than key i (keys are distinct)
+constexpr int RANK_T = 256;
+__global__ __launch_bounds__(RANK_T) void mis_rank_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ count,
+                                                          unsigned *__restrict__ rank)
+{
+    __shared__ unsigned long long other[RANK_T];
+    const unsigned n = *count;
+    const unsigned i = blockIdx.x * RANK_T + threadIdx.x, j0 = blockIdx.y * RANK_T;
+    if (blockIdx.x * RANK_T >= n || j0 >= n) return;
+    other[threadIdx.x] = j0 + threadIdx.x < n ? keys[j0 + threadIdx.x] : 0ull;
+    __syncthreads();
+    if (i >= n) return;
+    const unsigned long long key = keys[i];
+    unsigned greater = 0;
+#pragma unroll 8
+    for (int j = 0; j < RANK_T; j++) greater += other[j] > key ? 1u : 0u;
+    if (greater) atomicAdd(&rank[i], greater);
+}
+
+__global__ __launch_bounds__(256) void mis_place_kernel(NmsArgs a, const unsigned *__restrict__ count, const unsigned *__restrict__ rank,
+                                                        const int *__restrict__ nfill_in)
+{
+    const int n = (int)*count, nfill = *nfill_in;
+    const int placed = min(n, nfill);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int r = (int)rank[i];
+        if (r < nfill) {
+            const unsigned long long k = a.keys[i];
+            const int slot = a.overwrite_all ? r : a.slots[r];
+            klt_feat ft;
+            ft.x = (float)(int)((k >> 16) & 0xffffull);
+            ft.y = (float)(int)(k & 0xffffull);
+            ft.val = (int32_t)__uint_as_float((uint32_t)(k >> 32));          // int(val), selectGoodFeatures.py:119
+            ft.aux = 0;
+            a.fl[slot] = ft;
+            if (a.aff_rec) {
+                klt_affine_rec rec;
+                rec.aff_x = -1.f; rec.aff_y = -1.f; rec.Axx = 1.f; rec.Ayx = 0.f; rec.Axy = 0.f; rec.Ayy = 1.f; rec.valid = 0; rec.pad = 0;
+                a.aff_rec[slot] = rec;
+            }
+        }
+    }
+    // candidates exhausted: selectGoodFeatures.py:78-94 (SELECTING_ALL only; DESIGN.md lists the deviation)
+    if (a.overwrite_all)
+        for (int s = placed + i; s < a.nfeat; s += gridDim.x * 256) {
+            klt_feat ft;
+            ft.x = -1.f; ft.y = -1.f; ft.val = KLT_NOT_FOUND; ft.aux = 0;
+            a.fl[s] = ft;
+        }
+    if (i == 0 && a.placed_out) {
+        a.placed_out[0] = placed;
+        a.placed_out[1] = placed < nfill ? 1 : 0;       // 1: the candidates ran out before the list was full
+    }
+}
+
 __global__ void unpack_candidates_kernel(const unsigned long long *__restrict__ keys, int n, float *__restrict__ val,
                                          int *__restrict__ x, int *__restrict__ y)
 {
@@ -546,6 +817,49 @@ void launch_topk_prefilter(hipStream_t s, const unsigned long long *keys, int n,
     hipLaunchKernelGGL(key_hist_kernel, dim3(256), dim3(256), 0, s, keys, n, hist);
     hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, hist, target, info);
     hipLaunchKernelGGL(key_compact_kernel, dim3(512), dim3(256), 0, s, keys, n, info, out, info + 3);
+}
+
+void launch_key_threshold(hipStream_t s, const unsigned long long *keys, int n, unsigned target, unsigned *hist, unsigned *info)
+{
+    hipLaunchKernelGGL(key_hist_kernel, dim3(256), dim3(256), 0, s, keys, n, hist);
+    hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, hist, target, info);
+}
+
+int mis_tiles(int nx, int ny) { return ((nx + MIS_TILE - 1) / MIS_TILE) * ((ny + MIS_TILE - 1) / MIS_TILE); }
+
+size_t mis_stage_bytes(int R)
+{
+    const size_t W = MIS_TILE + 2 * (R > 0 ? R : 0);
+    return R > 0 ? (W * W + W * MIS_TILE) * sizeof(unsigned long long) : 0;
+}
+
+void launch_mis_init(hipStream_t s, const MisArgs &a)
+{
+    hipLaunchKernelGGL(mis_init_kernel, dim3(mis_tiles(a.nx, a.ny)), dim3(MIS_T), 0, s, a);
+}
+
+int launch_mis_round(hipStream_t s, const MisArgs &a, int round)
+{
+    const size_t lds = a.stage ? mis_stage_bytes(a.R) : 0;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)mis_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(mis_round_kernel, dim3(mis_tiles(a.nx, a.ny)), dim3(MIS_T), lds, s, a, round);
+    return 0;
+}
+
+void launch_free_slots(hipStream_t s, const klt_feat *fl, int nfeat, int overwrite_all, int *slots, int *nfill_out)
+{
+    hipLaunchKernelGGL(free_slots_kernel, dim3(1), dim3(1024), 0, s, fl, nfeat, overwrite_all, slots, nfill_out);
+}
+
+// keys[0 .. *count) unsorted accepted candidates, *count <= bound; rank[] zeroed by the caller
+void launch_mis_place(hipStream_t s, const NmsArgs &a, const unsigned *count, unsigned *rank, const int *nfill, int bound)
+{
+    const int chunks = (bound + RANK_T - 1) / RANK_T;
+    hipLaunchKernelGGL(mis_rank_kernel, dim3(chunks, chunks), dim3(RANK_T), 0, s, a.keys, count, rank);
+    hipLaunchKernelGGL(mis_place_kernel, dim3((bound + 255) / 256), dim3(256), 0, s, a, count, rank, nfill);
 }
 
 void launch_sort_desc(hipStream_t s, unsigned long long *keys, int n)

@@ -233,6 +233,13 @@ def test_select_internals_cfg1(ctx, cfg1, img0):
     assert_same(ctx.select_intermediate(1), cfg1["sel_gx"], "selection gradx")
     assert_same(ctx.select_intermediate(2), cfg1["sel_gy"], "selection grady")
     assert_same(ctx.select_intermediate(3), cfg1["sel_val"], "eigenvalue map")
+    assert_feats(fl, cfg1["sel100_x"], cfg1["sel100_y"], cfg1["sel100_val"], "select 100 (parallel minimum distance)")
+    ctx.set_option(8, 0)                          # the sorted serial walk keeps the full sorted candidate list
+    try:
+        fl, placed = ctx.select(2, 100)
+    finally:
+        ctx.set_option(8, 1)
+    assert placed == 100
     val, x, y = ctx.sorted_candidates(20000)
     n = len(val)
     gv = cfg1["sel_sorted_val"]
@@ -836,3 +843,47 @@ def test_track_sequence_matches_per_frame_api(replace, affine, ingest):
             assert len(live) > n // 2
     finally:
         sgf.KLT_verbose = 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,n", [(dict(), 100), (dict(mindist=1), 300), (dict(mindist=0), 300), (dict(mindist=3), 2000),
+                                  (dict(mindist=25), 400), (dict(mindist=70), 30), (dict(nSkippedPixels=1, mindist=12), 150),
+                                  (dict(nSkippedPixels=3, mindist=2), 500), (dict(min_eigenvalue=2000), 400)])
+def test_parallel_min_distance_equals_serial_walk(ctx, ko, img0, kw, n):
+    """KLT_OPT_SELECT_PARALLEL_NMS: both formulations of _enforceMinimumDistance (selectGoodFeatures.py:45-135) give the
+    oracle's list -- exclusion radii from none to larger than the LDS tile allows (falls back to the walk), skipped
+    pixels, lists that cannot be filled."""
+    tc = make_tc(**kw)
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    want = ko.select_good_features(p, img0.astype(np.float32), n)
+    got = {}
+    try:
+        for algo in (1, 0):
+            ctx.set_option(8, algo)
+            ctx.upload(2, img0)
+            got[algo], placed = ctx.select(2, n)
+            assert placed == int((want["val"] >= 0).sum())
+            assert_feats(got[algo], want["x"], want["y"], want["val"], "algo %d %r" % (algo, kw))
+    finally:
+        ctx.set_option(8, 1)
+
+
+@pytest.mark.gpu
+def test_parallel_min_distance_long_dependency_chain(ctx, ko):
+    """A smooth ramp of corner strength gives a dependency chain far longer than the eight passes enqueued at first:
+    the host keeps adding passes until nothing is undecided; result = the oracle's walk."""
+    h, w = 200, 1200
+    rng = np.random.default_rng(5)
+    ys, xs = np.mgrid[0:h, 0:w]
+    amp = 20.0 + 200.0 * xs / w                                   # texture contrast grows monotonically to the right
+    img = np.clip(128 + amp * 0.5 * (np.sin(xs * 0.9) * np.sin(ys * 0.9)) + rng.normal(0, 0.3, (h, w)), 0, 255).astype(np.uint8)
+    tc = make_tc(mindist=10)
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    n = 1500
+    want = ko.select_good_features(p, img.astype(np.float32), n)
+    ctx.upload(2, img)
+    got, placed = ctx.select(2, n)
+    assert placed == int((want["val"] >= 0).sum())
+    assert_feats(got, want["x"], want["y"], want["val"], "ramp")
