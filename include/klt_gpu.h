@@ -195,6 +195,10 @@ int klt_download_f32(klt_ctx *ctx, int slot, int pyramid, int level, float *dst)
  * 3 = eigenvalue map [ny][nx] (scan order, goodFeaturesUtils.pyx:53-54).  dims via klt_select_dims. */
 int klt_select_dims(klt_ctx *ctx, int what, int *ncols, int *nrows);
 int klt_download_select_f32(klt_ctx *ctx, int what, float *dst);
+/* the NEXT klt_select* takes `count` = nx*ny eigenvalues from `val` (scan order, as what = 3 above returns them) instead
+ * of computing them: lets the tests drive _enforceMinimumDistance (selectGoodFeatures.py:45-135) with equal scores and
+ * long dependency chains that real frames rarely contain.  The override is consumed by one selection. */
+int klt_set_score_override(klt_ctx *ctx, const float *val, int count);
 /* first `n` sorted candidates of the last klt_select* as (val, x, y), selectGoodFeatures.py:234-236 */
 int klt_download_sorted_candidates(klt_ctx *ctx, float *val, int32_t *x, int32_t *y, int n, int *n_valid);
 

@@ -214,6 +214,11 @@ class Context:
         self._check(self._lib.klt_download_select_f32(self._h, what, out.ctypes.data))
         return out
 
+    def set_score_override(self, val):
+        """Test hook: the next selection uses this [ny][nx] eigenvalue map instead of computing one."""
+        val = np.ascontiguousarray(val, np.float32)
+        self._check(self._lib.klt_set_score_override(self._h, val.ctypes.data, val.size))
+
     def sorted_candidates(self, n):
         val = np.empty(n, np.float32)
         x = np.empty(n, np.int32)

@@ -101,7 +101,13 @@ struct klt_ctx {
     bool use_topk = true;
     bool use_mis = true;                      // parallel minimum-distance passes instead of the sorted serial walk
     int mis_rounds_hint = 6;
+    unsigned *readback = nullptr;             // pinned scratch for small results
+    float *score_override = nullptr;          // test hook (klt_set_score_override)
+    size_t score_override_cap = 0;
+    int score_override_n = 0;
     uint32_t *mis_st = nullptr, *mis_list = nullptr;
+    unsigned long long *mis_tile_keys = nullptr;
+    size_t mis_tile_keys_cap = 0;
     unsigned *mis_cnt = nullptr;              // [tiles] + kMisRounds remaining counters + accepted counter
     size_t mis_st_cap = 0, mis_list_cap = 0, mis_cnt_cap = 0;
     const unsigned long long *sorted_keys = nullptr;   // what the last selection walked (test hook)
@@ -681,7 +687,7 @@ void klt_destroy(klt_ctx *c)
         if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
-    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
@@ -1014,8 +1020,10 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
 
     int mindist = p.mindist < 0 ? 0 : p.mindist;          // selectGoodFeatures.py:241-243
     const int d = mindist - 1;                            // :61
+    const int R = d >= 0 ? d / step : -1;                 // exclusion radius in candidate cells
+    const bool parallel_nms = c->use_mis && ncand > 0 && mis_stage_bytes(R) <= 120 * 1024;
     const uint8_t *seed = nullptr;
-    if (mode == KLT_REPLACING_SOME && d >= 0) {
+    if (mode == KLT_REPLACING_SOME && d >= 0 && !parallel_nms) {
         if (int rc = ensure(c, c->seedmap, c->seed_cap, N)) return rc;
         HIPCHK(c, hipMemsetAsync(c->seedmap, 0, N, c->stream));
         TimerScope t(c, F_SEED, (double)n * 16);
@@ -1025,10 +1033,18 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
 
     SelectArgs sa;
     sa.sat = c->sat; sa.valmap = c->valmap; sa.keys = c->keys; sa.seedmap = seed;
+    sa.val_in = nullptr;
+    sa.hist = sa.ticket = sa.info = nullptr; sa.hist_target = 0;
+    if (c->score_override_n) {
+        const int given = c->score_override_n;
+        c->score_override_n = 0;
+        if (given != ncand) return fail(c, KLT_ERR_ARG, "score override does not match the candidate grid");
+        sa.val_in = c->score_override;
+    }
     sa.min_eig = p.min_eigenvalue < 1 ? 1.0 : p.min_eigenvalue;          // :53
     sa.ncols = nc; sa.nrows = nr; sa.bx = bx; sa.by = by; sa.step = step; sa.nx = nx; sa.ny = ny;
     sa.hw = hw; sa.hh = hh; sa.npow2 = (int)npow2;
-    { TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8)); launch_eigen(c->stream, sa); }
+    if (!parallel_nms) { TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8)); launch_eigen(c->stream, sa); }
     NmsArgs na;
     std::memset(&na, 0, sizeof(na));
     na.fl = b->d; na.placed_out = c->placed_d;
@@ -1068,54 +1084,67 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
 
     // ---- parallel minimum distance (default): decide every candidate in a few passes, rank the accepted ones, and
     // fill the free slots with the best of them (same result as the sorted serial walk below)
-    const int R = d >= 0 ? d / step : -1;
-    if (c->use_mis && ncand > 0 && mis_stage_bytes(R) <= 120 * 1024) {
+    if (parallel_nms) {
+        constexpr int kMaxRounds = 512;
         // passes enqueued before the host looks at the outcome: what the previous selection needed (frames of a sequence
         // behave alike); an idle pass costs 5 us, a second look costs a host round trip
         const int kMisRounds = c->mis_rounds_hint;
-        constexpr int kMaxRounds = 512;
         const int tiles = mis_tiles(nx, ny);
         // two accepted candidates are more than R cells apart in x or in y: at most one per (R+1)x(R+1) block of cells
         const long long bound = R < 0 ? ncand : (long long)((nx + R) / (R + 1)) * ((ny + R) / (R + 1));
         const bool by_rank = bound <= 98304;                // rank by counting; beyond that sort the accepted keys
         long long np2 = 2048;
         while (np2 < bound) np2 <<= 1;
-        // one allocation of counters: [tiles] list lengths | [kMaxRounds] undecided left after pass r | accepted count |
-        // 8192 histogram bins + 4 words of prefilter info | [bound] ranks
-        const size_t off_rem = (size_t)tiles, off_acc = off_rem + kMaxRounds, off_hist = off_acc + 1, off_rank = off_hist + 8192 + 4;
+        // one allocation of counters: [tiles] list lengths | [kMaxRounds] "undecided left after pass r" | accepted count |
+        // workgroup ticket | [tiles] accepted per tile | 8192 histogram bins + 4 words of prefilter info | [bound] ranks
+        const size_t off_rem = (size_t)tiles, off_acc = off_rem + kMaxRounds, off_ticket = off_acc + 1, off_tacc = off_ticket + 1,
+                     off_hist = off_tacc + tiles, off_rank = off_hist + 8192 + 4;
+        const int tile_cap = mis_tile_capacity(R);
         const size_t n_cnt = off_rank + (by_rank ? (size_t)bound : 0);
         if (int rc = ensure(c, c->keys2, c->keys2_cap, (size_t)(np2 > npow2 ? np2 : npow2))) return rc;
         if (int rc = ensure(c, c->mis_st, c->mis_st_cap, (size_t)ncand)) return rc;
         if (int rc = ensure(c, c->mis_list, c->mis_list_cap, (size_t)tiles * 1024)) return rc;
         if (int rc = ensure(c, c->mis_cnt, c->mis_cnt_cap, n_cnt)) return rc;
+        if (int rc = ensure(c, c->mis_tile_keys, c->mis_tile_keys_cap, (size_t)tiles * tile_cap)) return rc;
         if (int rc = ensure(c, c->fl_snapshot, c->fl_snapshot_cap, (size_t)n)) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->fl_snapshot, b->d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+        // results come back through pinned host memory the kernels write to directly
+        if (!c->readback) {
+            void *hp = nullptr;
+            HIPCHK(c, hipHostMalloc(&hp, 128 * sizeof(unsigned), hipHostMallocDefault));
+            c->readback = (unsigned *)hp;
+            c->pinned.push_back(hp);
+        }
+        unsigned *const rem = c->readback, *const info = c->readback + 64;
+        const unsigned *const res = c->readback + 72;
         unsigned *const info_d = c->mis_cnt + off_hist + 8192, *const rank_d = c->mis_cnt + off_rank;
+        unsigned *const acc_count_d = c->mis_cnt + off_acc;
         int *const nfill_d = c->placed_d + 2;
         MisArgs ma;
         ma.keys = c->keys; ma.st = c->mis_st; ma.list = c->mis_list; ma.cnt = c->mis_cnt;
-        ma.remaining = c->mis_cnt + off_rem; ma.acc_count = c->mis_cnt + off_acc;
-        ma.acc_keys = c->keys2; ma.info = info_d;
-        ma.nx = nx; ma.ny = ny; ma.R = R; ma.stage = 1; ma.iterations = 1;   // more iterations per launch did not save launches
+        ma.remaining = c->mis_cnt + off_rem; ma.acc_cnt = c->mis_cnt + off_tacc; ma.acc_cap = tile_cap;
+        ma.acc_keys = c->mis_tile_keys; ma.info = info_d;
+        ma.nx = nx; ma.ny = ny; ma.R = R; ma.stage = 1; ma.bx = bx; ma.by = by; ma.step = step;
         NmsArgs pa = na;                                    // placement: the accepted candidates never exclude each other
         pa.d = -1; pa.cell = 1; pa.cell_magic = 0u; pa.gw = pa.gh = 1; pa.grid_in_lds = 1; pa.grid_global = nullptr;
         pa.keys = c->keys2; pa.nkeys = (int)np2;
-        if (by_rank) launch_free_slots(c->stream, b->d, n, pa.overwrite_all, pa.slots, nfill_d);
         for (int attempt = 0; attempt < 2; attempt++) {
             const bool filtered = prefilter && attempt == 0;
-            HIPCHK(c, hipMemsetAsync(c->mis_cnt + off_rem, 0, (n_cnt - off_rem) * sizeof(unsigned), c->stream));
-            if (!by_rank) HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)np2 * sizeof(unsigned long long), c->stream));
-            if (filtered) {
-                TimerScope t(c, F_SORT, (double)ncand * 8);
-                launch_key_threshold(c->stream, c->keys, (int)ncand, (unsigned)target, c->mis_cnt + off_hist, info_d);
+            if (attempt == 0) {
+                launch_mis_prepare(c->stream, b->d, n, pa.overwrite_all, pa.slots, nfill_d, c->fl_snapshot, c->mis_cnt + off_rem, n_cnt - off_rem);
+                if (filtered) { sa.hist = c->mis_cnt + off_hist; sa.ticket = c->mis_cnt + off_ticket; sa.info = info_d; sa.hist_target = (unsigned)((target + 3) / 4); }
+                TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8));
+                launch_eigen_hist(c->stream, sa);
+            } else {
+                launch_zero_words(c->stream, c->mis_cnt + off_rem, n_cnt - off_rem);      // threshold bin 0: every candidate
             }
+            if (!by_rank) HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)np2 * sizeof(unsigned long long), c->stream));
             int round = 0;
             {
                 TimerScope t(c, F_NMS, (double)ncand * 12);
                 launch_mis_init(c->stream, ma);
+                if (mode == KLT_REPLACING_SOME && d >= 0) launch_mis_seed(c->stream, c->fl_snapshot, n, ma, d);
             }
-            unsigned left = 0, info[4] = {0, 0, 0, 0};
-            int res[2] = {0, 0};
+            unsigned left = 0;
             for (;;) {
                 {
                     TimerScope t(c, F_NMS, (double)n * 16);
@@ -1123,20 +1152,19 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
                         if (const int e = launch_mis_round(c->stream, ma, round))
                             return fail(c, KLT_ERR_DEVICE, std::string("minimum-distance pass: ") + hipGetErrorString((hipError_t)e));
                 }
-                unsigned rem[64];
                 const int look = round < 64 ? round : 64;                        // the last `look` passes
-                HIPCHK(c, hipMemcpyAsync(rem, ma.remaining + round - look, look * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                const unsigned *rem_d = ma.remaining + round - look;
+                launch_mis_compact(c->stream, ma, c->keys2, acc_count_d);
                 if (by_rank) {
                     TimerScope t(c, F_NMS, (double)n * 16);
-                    launch_mis_place(c->stream, pa, ma.acc_count, rank_d, nfill_d, (int)bound);
+                    launch_mis_place(c->stream, pa, acc_count_d, rank_d, nfill_d, (int)bound, c->readback, rem_d, look, info_d);
                 } else {
                     { TimerScope t(c, F_SORT, (double)np2 * 16); launch_sort_desc(c->stream, c->keys2, (int)np2); }
                     TimerScope t(c, F_NMS, (double)n * 16);
                     const int e = launch_nms(c->stream, pa);
                     if (e) return fail(c, KLT_ERR_DEVICE, std::string("nms launch: ") + hipGetErrorString((hipError_t)e));
+                    launch_mis_results(c->stream, c->readback, rem_d, look, info_d, c->placed_d);
                 }
-                HIPCHK(c, hipMemcpyAsync(res, c->placed_d, sizeof(res), hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipMemcpyAsync(info, info_d, sizeof(info), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 left = rem[look - 1];
                 if (left == 0u) {
@@ -1149,7 +1177,8 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
                 // a dependency chain longer than the passes run so far: put the list back and keep going
                 if (round + kMisRounds > kMaxRounds) return fail(c, KLT_ERR_DEVICE, "minimum-distance passes did not settle");
                 HIPCHK(c, hipMemcpyAsync(b->d, c->fl_snapshot, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
-                if (by_rank) HIPCHK(c, hipMemsetAsync(rank_d, 0, (size_t)bound * sizeof(unsigned), c->stream));
+                if (by_rank) launch_zero_words(c->stream, rank_d, (size_t)bound);
+                else HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)np2 * sizeof(unsigned long long), c->stream));
             }
             c->sorted_keys = by_rank ? nullptr : c->keys2; c->sorted_count = by_rank ? 0 : (int)np2;
             // ran out of accepted candidates although the prefilter dropped some: repeat with every candidate
@@ -1492,6 +1521,17 @@ int klt_download_select_f32(klt_ctx *c, int what, float *dst)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst, src, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KLT_OK;
+}
+
+int klt_set_score_override(klt_ctx *c, const float *val, int count)
+{
+    if (!c || !val || count <= 0) return fail(c, KLT_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure(c, c->score_override, c->score_override_cap, (size_t)count)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->score_override, val, (size_t)count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->score_override_n = count;
     return KLT_OK;
 }
 

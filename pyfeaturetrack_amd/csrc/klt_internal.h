@@ -70,6 +70,9 @@ struct SelectArgs {
     float *valmap;           // [ny][nx]
     unsigned long long *keys;
     const uint8_t *seedmap;  // may be null
+    const float *val_in;     // test hook: eigenvalues given instead of computed (may be null)
+    unsigned *hist, *ticket, *info;   // eigen_hist_kernel: 8192 bins, workgroup ticket, threshold info (hist may be null)
+    unsigned hist_target;
     double min_eig;
     int ncols, nrows, bx, by, step, nx, ny, hw, hh, npow2;
 };
@@ -92,10 +95,12 @@ struct MisArgs {
     uint32_t *list;                   // [tiles * 1024] undecided cells of every 32x32 tile
     unsigned *cnt;                    // [tiles] length of each tile's list
     unsigned *remaining;              // [rounds] undecided candidates left after pass r
-    unsigned long long *acc_keys;     // accepted candidates (unsorted)
-    unsigned *acc_count;
+    unsigned long long *acc_keys;     // [tiles * acc_cap] accepted candidates of every tile
+    unsigned *acc_cnt;                // [tiles] how many of them
+    int acc_cap;
     const unsigned *info;             // info[0] = lowest key bin that takes part (top-K prefilter)
-    int nx, ny, R /* exclusion radius in cells */, stage /* 1: stage tile + halo in LDS */, iterations /* per launch */;
+    int nx, ny, R /* exclusion radius in cells */, stage /* 1: stage tile + halo in LDS */;
+    int bx, by, step;                 // pixel position of cell (i, j) = (bx + i * step, by + j * step)
 };
 
 // ---- launchers (each enqueues on `s`; no synchronisation) ----
@@ -127,8 +132,16 @@ int  mis_tiles(int nx, int ny);
 size_t mis_stage_bytes(int R);
 void launch_mis_init(hipStream_t s, const MisArgs &a);
 int  launch_mis_round(hipStream_t s, const MisArgs &a, int round);   // returns 0 or a hipError_t
-void launch_free_slots(hipStream_t s, const klt_feat *fl, int nfeat, int overwrite_all, int *slots, int *nfill_out);
-void launch_mis_place(hipStream_t s, const NmsArgs &a, const unsigned *count, unsigned *rank, const int *nfill, int bound);
+void launch_mis_compact(hipStream_t s, const MisArgs &a, unsigned long long *out, unsigned *out_count);
+int  mis_tile_capacity(int R);
+void launch_zero_words(hipStream_t s, unsigned *p, size_t n);
+void launch_mis_prepare(hipStream_t s, const klt_feat *fl, int nfeat, int overwrite_all, int *slots, int *nfill_out, klt_feat *snapshot,
+                        unsigned *zero, size_t zero_n);
+void launch_mis_seed(hipStream_t s, const klt_feat *fl, int nfeat, const MisArgs &a, int d);
+void launch_eigen_hist(hipStream_t s, const SelectArgs &a);
+void launch_mis_results(hipStream_t s, unsigned *host_out, const unsigned *rem, int look, const unsigned *info, const int *placed);
+void launch_mis_place(hipStream_t s, const NmsArgs &a, const unsigned *count, unsigned *rank, const int *nfill, int bound,
+                      unsigned *host_out, const unsigned *rem, int look, const unsigned *info);
 void launch_unpack_candidates(hipStream_t s, const unsigned long long *keys, int n, float *val, int *x, int *y);
 
 void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, int n, int nlevels, unsigned long long *stats);

@@ -22,95 +22,181 @@
 namespace {
 
 // ------------------------------------------------------------------ SAT, row pass (+ products)
-// block = 256 threads = one band of 64 rows; all four waves move 64x64 tiles of gx / gy between HBM and LDS with
-// coalesced 256-byte row segments (the next tile is prefetched into registers while the current one is scanned);
-// waves 0..2 each run the 64 sequential row chains of one plane (0: gx*gx, 1: gx*gy, 2: gy*gy), lane = row.
-constexpr int SAT_LD = 68;      // tile row stride in floats: 16-byte aligned rows, conflict-free b128 column walks
+// The only serial work is the chain itself: 64 dependent f32 adds per 64-column tile and row.  Everything else is kept
+// off the chain's wavefront.  block = 5 wavefronts = one band of 16 rows: wavefront 0 runs the 48 chains of the band
+// (lane = plane * 16 + row; planes gx*gx, gx*gy, gy*gy) from LDS to LDS; wavefronts 1..4 load gx / gy (coalesced
+// 256-byte row segments, a ring of SR_D tiles in flight per lane to cover HBM latency), write the three products of
+// the next tile into LDS and store the finished prefix tile of the previous step.  One barrier per tile.
+constexpr int SR_ROWS = 16, SR_LD = 68, SR_D = 8, SR_T = 320;
 
-__global__ __launch_bounds__(256) void sat_rows_kernel(const float *__restrict__ gx, const float *__restrict__ gy,
-                                                        float *__restrict__ sat, int ncols, int nrows)
+__global__ __launch_bounds__(SR_T) void sat_rows_kernel(const float *__restrict__ gx, const float *__restrict__ gy,
+                                                         float *__restrict__ sat, int ncols, int nrows)
 {
-    __shared__ __attribute__((aligned(16))) float tin[2][64 * SAT_LD];    // gx, gy tiles
-    __shared__ __attribute__((aligned(16))) float tout[3][64 * SAT_LD];   // row-prefix tiles of the three planes
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * 64;
+    __shared__ __attribute__((aligned(16))) float prod[2][3][SR_ROWS * SR_LD];
+    __shared__ __attribute__((aligned(16))) float outp[2][3][SR_ROWS * SR_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool chain = tid < 64;
+    const int row0 = blockIdx.x * SR_ROWS;
+    const int ntiles = (ncols + 63) / 64;
     const size_t plane = (size_t)ncols * nrows;
-    float carry = 0.f;
-    float pgx[16], pgy[16];
-    auto fetch = [&](int x0) {
+    const int lr = (tid - 64) >> 6, lc = lane;                 // loader lanes: rows lr, lr + 4, lr + 8, lr + 12 of the band
+    float rgx[SR_D][4], rgy[SR_D][4];
+    auto fetch = [&](int slot, int t) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int row = row0 + k * 4 + wave, col = x0 + lane;
-            const bool ok = row < nrows && col < ncols;
-            pgx[k] = ok ? gx[(size_t)row * ncols + col] : 0.f;
-            pgy[k] = ok ? gy[(size_t)row * ncols + col] : 0.f;
+        for (int k = 0; k < 4; k++) {
+            const int row = row0 + lr + 4 * k, col = t * 64 + lc;
+            const bool ok = t < ntiles && row < nrows && col < ncols;
+            rgx[slot][k] = ok ? gx[(size_t)row * ncols + col] : 0.f;
+            rgy[slot][k] = ok ? gy[(size_t)row * ncols + col] : 0.f;
         }
     };
-    fetch(0);
-    for (int x0 = 0; x0 < ncols; x0 += 64) {
+    auto put = [&](int slot, int buf) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            tin[0][(k * 4 + wave) * SAT_LD + lane] = pgx[k];
-            tin[1][(k * 4 + wave) * SAT_LD + lane] = pgy[k];
+        for (int k = 0; k < 4; k++) {
+            const int o = (lr + 4 * k) * SR_LD + lc;
+            const float a = rgx[slot][k], b = rgy[slot][k];
+            prod[buf][0][o] = a * a;
+            prod[buf][1][o] = a * b;
+            prod[buf][2][o] = b * b;
         }
-        __syncthreads();
-        if (x0 + 64 < ncols) fetch(x0 + 64);                 // in flight during the scan below
-        if (wave < 3) {
-            const float4 *a4 = reinterpret_cast<const float4 *>(&tin[wave == 2 ? 1 : 0][lane * SAT_LD]);
-            const float4 *b4 = reinterpret_cast<const float4 *>(&tin[wave == 0 ? 0 : 1][lane * SAT_LD]);
-            float4 *o4 = reinterpret_cast<float4 *>(&tout[wave][lane * SAT_LD]);
-#pragma unroll 4
-            for (int c = 0; c < 16; c++) {
-                const float4 a = a4[c], b = b4[c];
-                float4 o;
-                { const float p = a.x * b.x; carry = carry + p; o.x = carry; }
-                { const float p = a.y * b.y; carry = carry + p; o.y = carry; }
-                { const float p = a.z * b.z; carry = carry + p; o.z = carry; }
-                { const float p = a.w * b.w; carry = carry + p; o.w = carry; }
-                o4[c] = o;
-            }
-        }
-        __syncthreads();
-        const int col = x0 + lane;
+    };
+    auto store = [&](int buf, int t) {
+        const int col = t * 64 + lc;
         if (col < ncols) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int r = k * 4 + wave, row = row0 + r;
+            for (int k = 0; k < 4; k++) {
+                const int r = lr + 4 * k, row = row0 + r;
                 if (row < nrows) {
-                    sat[(size_t)row * ncols + col] = tout[0][r * SAT_LD + lane];
-                    sat[plane + (size_t)row * ncols + col] = tout[1][r * SAT_LD + lane];
-                    sat[2 * plane + (size_t)row * ncols + col] = tout[2][r * SAT_LD + lane];
+                    sat[(size_t)row * ncols + col] = outp[buf][0][r * SR_LD + lc];
+                    sat[plane + (size_t)row * ncols + col] = outp[buf][1][r * SR_LD + lc];
+                    sat[2 * plane + (size_t)row * ncols + col] = outp[buf][2][r * SR_LD + lc];
                 }
             }
         }
-        // the next iteration's tin writes are ordered behind this iteration's scan by the barrier above;
-        // tout is rewritten only after the next barrier
+    };
+    float carry = 0.f;
+    const int cpl = lane >> 4, cr = lane & 15;                 // chain lanes: plane, row (lanes 48..63 idle)
+    auto scan = [&](int buf) {
+        if (lane < 48) {
+            const float4 *a4 = reinterpret_cast<const float4 *>(&prod[buf][cpl][cr * SR_LD]);
+            float4 *o4 = reinterpret_cast<float4 *>(&outp[buf][cpl][cr * SR_LD]);
+            float4 v[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) v[c] = a4[c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                float4 o;
+                carry = carry + v[c].x; o.x = carry;
+                carry = carry + v[c].y; o.y = carry;
+                carry = carry + v[c].z; o.z = carry;
+                carry = carry + v[c].w; o.w = carry;
+                o4[c] = o;
+            }
+        }
+    };
+    if (!chain) {
+#pragma unroll
+        for (int s = 0; s < SR_D; s++) fetch(s, s);
+        put(0, 0);
+        fetch(0, SR_D);
     }
+    __syncthreads();
+    for (int t0 = 0; t0 < ntiles; t0 += SR_D) {
+#pragma unroll
+        for (int k = 0; k < SR_D; k++) {
+            const int t = t0 + k;
+            if (t < ntiles) {                                   // uniform
+                if (chain) {
+                    scan(k & 1);
+                } else {
+                    if (t + 1 < ntiles) {
+                        put((k + 1) % SR_D, (k + 1) & 1);
+                        fetch((k + 1) % SR_D, t + 1 + SR_D);
+                    }
+                    if (t >= 1) store((k + 1) & 1, t - 1);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (!chain) store((ntiles - 1) & 1, ntiles - 1);
 }
 
 // ------------------------------------------------------------------ SAT, column pass (in place)
-// thread = one column of one plane; sequential f32 prefix along y; loads are issued 8 rows ahead
-__global__ __launch_bounds__(64) void sat_cols_kernel(float *__restrict__ sat, int ncols, int nrows)
+// Same structure: block = 32 columns of one plane; wavefront 0 runs the 32 column chains (lane = column) on 32-row
+// tiles in LDS, wavefronts 1..4 stream the tiles in (ring of SC_D tiles per lane) and the finished tiles out.
+constexpr int SC_COLS = 32, SC_ROWS = 32, SC_D = 12, SC_T = 320;
+
+__global__ __launch_bounds__(SC_T) void sat_cols_kernel(float *__restrict__ sat, int ncols, int nrows)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    if (x >= ncols) return;
-    float *s = sat + (size_t)blockIdx.y * ncols * nrows + x;
+    __shared__ float tin[2][SC_ROWS * SC_COLS], tout[2][SC_ROWS * SC_COLS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool chain = tid < 64;
+    const int x0 = blockIdx.x * SC_COLS;
+    float *s = sat + (size_t)blockIdx.y * ncols * nrows;
+    const int ntiles = (nrows + SC_ROWS - 1) / SC_ROWS;
+    const int lr = (tid - 64) >> 5, lc = (tid - 64) & 31;       // loader lanes: rows lr, lr + 8, lr + 16, lr + 24 of the tile
+    float rg[SC_D][4];
+    auto fetch = [&](int slot, int t) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int row = t * SC_ROWS + lr + 8 * k, col = x0 + lc;
+            rg[slot][k] = (t < ntiles && row < nrows && col < ncols) ? s[(size_t)row * ncols + col] : 0.f;
+        }
+    };
+    auto put = [&](int slot, int buf) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) tin[buf][(lr + 8 * k) * SC_COLS + lc] = rg[slot][k];
+    };
+    auto store = [&](int buf, int t) {
+        const int col = x0 + lc;
+        if (col < ncols) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = lr + 8 * k, row = t * SC_ROWS + r;
+                if (row < nrows) s[(size_t)row * ncols + col] = tout[buf][r * SC_COLS + lc];
+            }
+        }
+    };
     float carry = 0.f;
-    int y = 0;
-    for (; y + 8 <= nrows; y += 8) {
-        float v[8];
+    auto scan = [&](int buf) {
+        if (lane < SC_COLS) {
+            float v[SC_ROWS];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = s[(size_t)(y + u) * ncols];
+            for (int r = 0; r < SC_ROWS; r++) v[r] = tin[buf][r * SC_COLS + lane];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            carry = carry + v[u];
-            s[(size_t)(y + u) * ncols] = carry;
+            for (int r = 0; r < SC_ROWS; r++) {
+                carry = carry + v[r];
+                tout[buf][r * SC_COLS + lane] = carry;
+            }
+        }
+    };
+    if (!chain) {
+#pragma unroll
+        for (int k = 0; k < SC_D; k++) fetch(k, k);
+        put(0, 0);
+        fetch(0, SC_D);
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < ntiles; t0 += SC_D) {
+#pragma unroll
+        for (int k = 0; k < SC_D; k++) {
+            const int t = t0 + k;
+            if (t < ntiles) {                                   // uniform
+                if (chain) {
+                    scan(k & 1);
+                } else {
+                    if (t + 1 < ntiles) {
+                        put((k + 1) % SC_D, (k + 1) & 1);
+                        fetch((k + 1) % SC_D, t + 1 + SC_D);
+                    }
+                    if (t >= 1) store((k + 1) & 1, t - 1);
+                }
+                __syncthreads();
+            }
         }
     }
-    for (; y < nrows; y++) {
-        carry = carry + s[(size_t)y * ncols];
-        s[(size_t)y * ncols] = carry;
-    }
+    if (!chain) store((ntiles - 1) & 1, ntiles - 1);
 }
 
 // ------------------------------------------------------------------ seed map for REPLACING_SOME
@@ -139,12 +225,9 @@ __device__ __forceinline__ float window_sum(const float *__restrict__ s, int nco
     return ((c + a) - b) - d;
 }
 
-__global__ __launch_bounds__(256) void eigen_kernel(SelectArgs a)
+// key of candidate k (0 = not a candidate); also stores the eigenvalue
+__device__ __forceinline__ unsigned long long eigen_key(const SelectArgs &a, int k)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= a.npow2) return;
-    const int ncand = a.nx * a.ny;
-    if (k >= ncand) { a.keys[k] = 0ull; return; }     // padding sorts last
     const int xi = k % a.nx, yi = k / a.nx;
     const int x = a.bx + xi * a.step, y = a.by + yi * a.step;
     const size_t plane = (size_t)a.ncols * a.nrows;
@@ -159,13 +242,18 @@ __global__ __launch_bounds__(256) void eigen_kernel(SelectArgs a)
     const float s = (float)sqrt(t);
     const float sum = gxx + gyy;
     const float num = sum - s;
-    const float val = (float)((double)num / 2.0);
+    const float val = a.val_in ? a.val_in[k] : (float)((double)num / 2.0);
     a.valmap[k] = val;
     bool ok = (double)val >= a.min_eig;                // val >= max(min_eigenvalue, 1) > 0
     if (ok && a.seedmap) ok = a.seedmap[(size_t)y * a.ncols + x] == 0;
-    a.keys[k] = ok ? (((unsigned long long)__float_as_uint(val) << 32) | ((unsigned long long)x << 16) |
-                      (unsigned long long)y)
-                   : 0ull;
+    return ok ? (((unsigned long long)__float_as_uint(val) << 32) | ((unsigned long long)x << 16) | (unsigned long long)y) : 0ull;
+}
+
+__global__ __launch_bounds__(256) void eigen_kernel(SelectArgs a)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.npow2) return;
+    a.keys[k] = k < a.nx * a.ny ? eigen_key(a, k) : 0ull;     // padding sorts last
 }
 
 // ------------------------------------------------------------------ top-K prefilter for the sort
@@ -177,12 +265,13 @@ __global__ __launch_bounds__(256) void eigen_kernel(SelectArgs a)
 constexpr int HIST_BINS = 8192;
 __device__ __forceinline__ unsigned key_bin(unsigned long long key) { return (unsigned)(key >> 50) & (HIST_BINS - 1); }
 
-__global__ __launch_bounds__(256) void key_hist_kernel(const unsigned long long *__restrict__ keys, int n, unsigned *__restrict__ hist)
+// stride > 1: every stride-th key only (an estimate is enough where the threshold is just a work-saving cut)
+__global__ __launch_bounds__(256) void key_hist_kernel(const unsigned long long *__restrict__ keys, int n, unsigned *__restrict__ hist, int stride)
 {
     __shared__ unsigned h[HIST_BINS];
     for (int i = threadIdx.x; i < HIST_BINS; i += 256) h[i] = 0u;
     __syncthreads();
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * stride; i < n; i += gridDim.x * 256 * stride) {
         const unsigned long long key = keys[i];
         if (key) atomicAdd(&h[key_bin(key)], 1u);
     }
@@ -221,6 +310,31 @@ __global__ __launch_bounds__(1024) void key_threshold_kernel(const unsigned *__r
         }
         if (b == 8 * t) acc = suf[t];
         info[0] = (unsigned)b; info[1] = acc; info[2] = total;
+    }
+}
+
+// Eigenvalues, keys, and -- for the parallel minimum-distance passes -- the histogram behind the prefilter threshold in the
+// same launch: every 4th workgroup histograms its keys (an estimate is enough: the threshold only saves work, any value
+// is correct); key_threshold_kernel turns it into the threshold bin.  a.hist == nullptr: keys only.
+__global__ __launch_bounds__(256) void eigen_hist_kernel(SelectArgs a)
+{
+    __shared__ unsigned h[HIST_BINS];
+    const int tid = threadIdx.x, ncand = a.nx * a.ny;
+    const bool sampler = a.hist != nullptr && (blockIdx.x & 3) == 0;
+    if (sampler) {
+        for (int i = tid; i < HIST_BINS; i += 256) h[i] = 0u;
+        __syncthreads();
+    }
+    for (int k = blockIdx.x * 256 + tid; k < ncand; k += gridDim.x * 256) {
+        const unsigned long long key = eigen_key(a, k);
+        a.keys[k] = key;
+        if (sampler && key) atomicAdd(&h[key_bin(key)], 1u);
+    }
+    if (!a.hist) return;
+    if (sampler) {
+        __syncthreads();
+        for (int i = tid; i < HIST_BINS; i += 256)
+            if (h[i]) atomicAdd(&a.hist[i], h[i]);
     }
 }
 
@@ -556,24 +670,29 @@ __global__ __launch_bounds__(MIS_T) void mis_init_kernel(MisArgs a)
 
 __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
 {
-    // staged tiles: K = keys of the tile + halo ((32 + 2R)^2 u64: state << 32 | x << 16 | y, so the accepted bit and the
-    // rank order both survive a plain max), H = max of K over the horizontal window, interior columns only.  The tile
-    // is iterated a few times per launch: decisions taken inside the tile are visible to the next iteration at once,
-    // the halo keeps the states it had when the tile was staged (stale = still undecided = a decision postponed).
-    extern __shared__ unsigned long long lds64[];
-    __shared__ uint32_t acc_local[MIS_CAP];
-    __shared__ unsigned s_cursor, s_acc, s_base, s_progress;
-    unsigned n = a.cnt[blockIdx.x];
+    // staged tiles: S = states of the tile + halo ((32 + 2R)^2 u32), H = per row of S and interior column the maximum
+    // state over the horizontal window; a candidate then needs the 2R + 1 values of H above and below it.  The maximum
+    // carries the accepted bit.  States compare like the rank except for equal eigenvalues: a candidate whose value
+    // equals the window maximum scans the window for an equal neighbour of higher rank (right of it, or below it in
+    // the same column).
+    extern __shared__ uint32_t lds32[];
+    __shared__ unsigned short acc_local[MIS_CAP], top_local[MIS_CAP];
+    __shared__ unsigned char top_blocked[MIS_CAP];
+    __shared__ unsigned s_cursor, s_acc, s_top;
+    const unsigned n = a.cnt[blockIdx.x];
     if (n == 0u) return;
+    const unsigned have = a.acc_cnt[blockIdx.x];             // accepted candidates of this tile so far
     const int tiles_x = (a.nx + MIS_TILE - 1) / MIS_TILE;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int R = a.R, W = MIS_TILE + 2 * R, L = 2 * R + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool staged = a.stage && R > 0;
-    unsigned long long *K = lds64, *H = lds64 + (staged ? W * W : 0);
+    uint32_t *H = lds32;                      // [W][32]
+    uint32_t *S = lds32 + W * MIS_TILE;       // [W][W]
     const int ox = tx * MIS_TILE - R, oy = ty * MIS_TILE - R;
     uint32_t *list = a.list + (size_t)blockIdx.x * MIS_CAP;
-    if (threadIdx.x == 0) s_acc = 0u;
+    unsigned next_p = threadIdx.x < n ? list[threadIdx.x] : 0u;           // first batch, in flight during the staging
+    if (threadIdx.x == 0) { s_acc = 0u; s_cursor = 0u; s_top = 0u; }
     if (staged) {
         for (int cx0 = 0; cx0 < W; cx0 += 64)
             for (int r0 = 0; r0 < W; r0 += 64) {            // 16 rows per wavefront in flight at once
@@ -586,123 +705,192 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
                 }
 #pragma unroll
                 for (int u = 0; u < 16; u++) {
-                    const int r = r0 + wave + 4 * u, gy = oy + r;
-                    if (cx < W && r < W)
-                        K[r * W + cx] = v[u] ? ((unsigned long long)v[u] << 32) | ((unsigned long long)gx << 16) | (unsigned long long)gy : 0ull;
+                    const int r = r0 + wave + 4 * u;
+                    if (cx < W && r < W) S[r * W + cx] = v[u];
                 }
             }
-    }
-    const int iterations = staged ? a.iterations : 1;
-    for (int it = 0; it < iterations && n > 0u; it++) {
-        __syncthreads();                                     // K complete / updated; s_* of the last iteration consumed
-        if (threadIdx.x == 0) { s_cursor = 0u; s_progress = 0u; }
-        const unsigned acc_before = s_acc;
-        if (staged) {
-            for (int k = threadIdx.x; k < W * MIS_TILE; k += MIS_T) {
-                const unsigned long long *row = &K[(k / MIS_TILE) * W + (k % MIS_TILE)];     // window [c, c + 2R] of the row
-                unsigned long long m = row[0];
-#pragma unroll 6
-                for (int dx = 1; dx <= 2 * R; dx++) m = max(m, row[dx]);
-                H[k] = m;
-            }
-        }
         __syncthreads();
-        for (unsigned base = 0; base < n; base += MIS_T) {
-            const unsigned i = base + threadIdx.x;
-            const bool valid = i < n;
-            const int p = valid ? (int)list[i] : 0;
-            const int xi = p % a.nx, yi = p / a.nx;
-            bool near_accepted = false, blocked = false, gone = false;
-            uint32_t sp = 0u;
-            int kidx = 0;
-            if (valid && staged) {
-                const int lx = xi - tx * MIS_TILE, ly = yi - ty * MIS_TILE;          // interior coordinates
-                kidx = (ly + R) * W + lx + R;
-                const unsigned long long kp = K[kidx];
-                sp = (uint32_t)(kp >> 32);
-                gone = kp == 0ull;                                                   // rejected by a neighbour's push
-                unsigned long long m = 0ull;
-                const unsigned long long *col = &H[ly * MIS_TILE + lx];              // rows ly .. ly + 2R of H
-#pragma unroll 6
-                for (int dy = 0; dy <= 2 * R; dy++) m = max(m, col[dy * MIS_TILE]);
-                near_accepted = (m >> 63) != 0ull;
-                blocked = m > kp;
-            } else if (valid) {
-                sp = a.st[p];
-                gone = sp == 0u;
-                const int x0 = max(xi - R, 0), x1 = min(xi + R, a.nx - 1), y0 = max(yi - R, 0), y1 = min(yi + R, a.ny - 1);
-                for (int yy = y0; yy <= y1 && !near_accepted && !gone; yy++) {
-                    const uint32_t *row = a.st + (size_t)yy * a.nx;
-                    for (int xx = x0; xx <= x1; xx++) {
-                        const uint32_t s = row[xx];
-                        near_accepted |= (s >> 31) != 0u;
-                        blocked |= s > sp || (s == sp && (xx > xi || (xx == xi && yy > yi)));
-                    }
-                }
-            }
-            const bool live = valid && !gone;
-            const bool reject = live && near_accepted;
-            const bool wait = live && !near_accepted && blocked;
-            const bool accept = live && !near_accepted && !blocked;
-            if (reject) a.st[p] = 0u;
-            if (accept) {
-                a.st[p] = sp | 0x80000000u;
-                acc_local[atomicAdd(&s_acc, 1u)] = (uint32_t)p;
-                if (!staged) {                               // push: every undecided neighbour is rejected right away
-                    const int x0 = max(xi - R, 0), x1 = min(xi + R, a.nx - 1), y0 = max(yi - R, 0), y1 = min(yi + R, a.ny - 1);
-                    for (int yy = y0; yy <= y1; yy++)
-                        for (int xx = x0; xx <= x1; xx++) {
-                            uint32_t *q = a.st + (size_t)yy * a.nx + xx;
-                            const uint32_t s = *q;
-                            if ((xx != xi || yy != yi) && s != 0u && (s >> 31) == 0u) *q = 0u;
-                        }
-                }
-            }
-            if ((reject || accept || (valid && gone)) && staged) s_progress = 1u;
-            __syncthreads();                                 // every read of this batch of the list (and of K by it) is done
-            if (staged && reject) K[kidx] = 0ull;
-            if (staged && accept) K[kidx] |= 1ull << 63;
-            const unsigned long long m = __ballot(wait);
-            unsigned wbase = 0;
-            if (lane == 0 && m) wbase = atomicAdd(&s_cursor, (unsigned)__popcll(m));
-            wbase = __shfl(wbase, 0);
-            if (wait) list[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
+        for (int k = threadIdx.x; k < W * MIS_TILE; k += MIS_T) {
+            const uint32_t *row = &S[(k / MIS_TILE) * W + (k % MIS_TILE)];     // window = columns c .. c + 2R of the row
+            uint32_t m = row[0];
+#pragma unroll 8
+            for (int dx = 1; dx <= 2 * R; dx++) m = max(m, row[dx]);
+            H[k] = m;
         }
-        __syncthreads();
-        n = s_cursor;
-        const unsigned nacc = s_acc;
-        if (staged && nacc > acc_before) {                   // push for the staged tile: the block shares the windows
-            for (unsigned idx = threadIdx.x; idx < (nacc - acc_before) * (unsigned)(L * L); idx += MIS_T) {
-                const int p = (int)acc_local[acc_before + idx / (unsigned)(L * L)], w = (int)(idx % (unsigned)(L * L));
-                const int gx = p % a.nx - R + w % L, gy = p / a.nx - R + w / L;
-                const int kq = (gy - oy) * W + (gx - ox);
-                const unsigned long long k = K[kq];
-                if (k != 0ull && (k >> 63) == 0ull) {
-                    K[kq] = 0ull;
-                    a.st[(size_t)gy * a.nx + gx] = 0u;
-                }
-            }
-        }
-        if (!s_progress) break;                              // nothing moved: the rest waits for other tiles
     }
     __syncthreads();
-    const unsigned nacc = s_acc;
+    for (unsigned base = 0; base < n; base += MIS_T) {
+        const unsigned i = base + threadIdx.x;
+        const bool valid = i < n;
+        const int p = (int)next_p;
+        if (base + MIS_T + threadIdx.x < n) next_p = list[base + MIS_T + threadIdx.x];
+        const int xi = p % a.nx, yi = p / a.nx;
+        const int lx = xi - tx * MIS_TILE, ly = yi - ty * MIS_TILE;              // interior coordinates
+        bool near_accepted = false, blocked = false, gone = false, top = false;
+        uint32_t sp = 0u;
+        if (valid && staged) {
+            sp = S[(ly + R) * W + lx + R];
+            gone = sp == 0u;                                                     // rejected by a neighbour's push
+            uint32_t m = 0u;
+            const uint32_t *col = &H[ly * MIS_TILE + lx];                        // rows ly .. ly + 2R of H
+#pragma unroll 8
+            for (int dy = 0; dy <= 2 * R; dy++) m = max(m, col[dy * MIS_TILE]);
+            near_accepted = (m >> 31) != 0u;
+            blocked = m > sp;
+            top = !gone && m == sp;              // holds the window maximum: accepted unless an equal neighbour outranks it
+        } else if (valid) {
+            sp = a.st[p];
+            gone = sp == 0u;
+            const int x0 = max(xi - R, 0), x1 = min(xi + R, a.nx - 1), y0 = max(yi - R, 0), y1 = min(yi + R, a.ny - 1);
+            for (int yy = y0; yy <= y1 && !near_accepted && !gone; yy++) {
+                const uint32_t *row = a.st + (size_t)yy * a.nx;
+                for (int xx = x0; xx <= x1; xx++) {
+                    const uint32_t sv = row[xx];
+                    near_accepted |= (sv >> 31) != 0u;
+                    blocked |= sv > sp || (sv == sp && (xx > xi || (xx == xi && yy > yi)));
+                }
+            }
+        }
+        const bool live = valid && !gone;
+        const bool reject = live && near_accepted;
+        const bool wait = live && !near_accepted && blocked;
+        const bool accept = live && !near_accepted && !blocked && !top;
+        if (reject) a.st[p] = 0u;
+        if (top) {                                       // decided after the loop, by the whole workgroup
+            const unsigned e = atomicAdd(&s_top, 1u);
+            top_local[e] = (unsigned short)(ly * MIS_TILE + lx);
+            top_blocked[e] = 0;
+        }
+        if (accept) {
+            a.st[p] = sp | 0x80000000u;
+            acc_local[atomicAdd(&s_acc, 1u)] = (unsigned short)(ly * MIS_TILE + lx);
+        }
+        __syncthreads();                                 // every read of this batch of the list is done
+        const unsigned long long m = __ballot(wait);
+        unsigned wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&s_cursor, (unsigned)__popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (wait) list[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
+    }
+    __syncthreads();
+    const unsigned ntop = s_top;
+    if (ntop) {
+        // equal eigenvalues inside one window are ranked by position; the workgroup shares each window's scan
+        const unsigned magic = (unsigned)((1ull << 32) / (unsigned)L) + 1u;      // w / L for w < 65536
+        for (unsigned e = 0; e < ntop; e++) {
+            const int q = (int)top_local[e], lx = q % MIS_TILE, ly = q / MIS_TILE;
+            const uint32_t sp = S[(ly + R) * W + lx + R];
+            bool outranked = false;
+            for (int w = threadIdx.x; w < L * L; w += MIS_T) {
+                const int wy = (int)__umulhi((unsigned)w, magic), dx = w - wy * L - R, dy = wy - R;
+                outranked |= S[(ly + R + dy) * W + lx + R + dx] == sp && (dx > 0 || (dx == 0 && dy > 0));
+            }
+            if (outranked) top_blocked[e] = 1;
+        }
+        __syncthreads();
+        for (unsigned e = threadIdx.x; e < ntop; e += MIS_T) {
+            const int q = (int)top_local[e], lx = q % MIS_TILE, ly = q / MIS_TILE;
+            const int p = (ty * MIS_TILE + ly) * a.nx + tx * MIS_TILE + lx;
+            if (top_blocked[e]) {
+                list[atomicAdd(&s_cursor, 1u)] = (uint32_t)p;
+            } else {
+                a.st[p] = S[(ly + R) * W + lx + R] | 0x80000000u;
+                acc_local[atomicAdd(&s_acc, 1u)] = (unsigned short)q;
+            }
+        }
+        __syncthreads();
+    }
+    // no atomics on shared words here: a word that every workgroup increments serialises the whole launch (~90 returning
+    // atomics per microsecond chip-wide).  "Something is left" is a plain store of 1; the accepted candidates go to the
+    // tile's own slots and are compacted once, after the last pass.
+    unsigned nacc = s_acc;
+    const unsigned left = s_cursor;
+    if (have + nacc > (unsigned)a.acc_cap) nacc = (unsigned)a.acc_cap - have;      // cannot happen (one per (R+1)^2 cells)
     if (threadIdx.x == 0) {
-        a.cnt[blockIdx.x] = n;
-        if (n) atomicAdd(&a.remaining[round], n);
-        s_base = nacc ? atomicAdd(a.acc_count, nacc) : 0u;
+        a.cnt[blockIdx.x] = left;
+        if (left) a.remaining[round] = 1u;
+        a.acc_cnt[blockIdx.x] = have + nacc;
+    }
+    const size_t s_base = (size_t)blockIdx.x * a.acc_cap + have;
+    // push: every cell within the exclusion square of a newly accepted candidate is rejected right away.  None of them
+    // can be accepted (two accepted candidates never lie within each other's square), so the whole square is cleared.
+    if (R > 0 && nacc) {
+        const unsigned magic = (unsigned)((1ull << 32) / (unsigned)L) + 1u;      // w / L for w < 65536
+        for (int w = threadIdx.x; w < L * L; w += MIS_T) {
+            const int wy = (int)__umulhi((unsigned)w, magic), dx = w - wy * L - R, dy = wy - R;
+            if ((dx | dy) == 0) continue;
+            for (unsigned k = 0; k < nacc; k++) {
+                const int q = (int)acc_local[k];
+                const int gx = tx * MIS_TILE + (q % MIS_TILE) + dx, gy = ty * MIS_TILE + q / MIS_TILE + dy;
+                if (gx >= 0 && gy >= 0 && gx < a.nx && gy < a.ny) a.st[(size_t)gy * a.nx + gx] = 0u;
+            }
+        }
     }
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < nacc; i += MIS_T) a.acc_keys[s_base + i] = a.keys[acc_local[i]];
+    for (unsigned i = threadIdx.x; i < nacc; i += MIS_T) {
+        const int q = (int)acc_local[i];
+        const int xi = tx * MIS_TILE + q % MIS_TILE, yi = ty * MIS_TILE + q / MIS_TILE;
+        const uint32_t sp = staged ? S[(q / MIS_TILE + R) * W + q % MIS_TILE + R] : a.st[(size_t)yi * a.nx + xi] & 0x7fffffffu;
+        a.acc_keys[s_base + i] = ((unsigned long long)sp << 32) | ((unsigned long long)(a.bx + xi * a.step) << 16) |
+                                 (unsigned long long)(a.by + yi * a.step);
+    }
+}
+
+// accepted candidates of all tiles -> one dense array (tile order) + their number
+__global__ __launch_bounds__(1024) void mis_compact_kernel(const unsigned long long *__restrict__ tile_keys, const unsigned *__restrict__ acc_cnt,
+                                                           int tiles, int cap, unsigned long long *__restrict__ out, unsigned *__restrict__ out_count)
+{
+    __shared__ unsigned scan[1024];
+    __shared__ unsigned s_running;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_running = 0u;
+    __syncthreads();
+    for (int t0 = 0; t0 < tiles; t0 += 1024) {
+        const int t = t0 + tid;
+        const unsigned c = t < tiles ? acc_cnt[t] : 0u;
+        scan[tid] = c;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned v = tid >= off ? scan[tid - off] : 0u;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const unsigned running = s_running;
+        {                                                                  // thread = tile; 8 loads in flight at a time
+            const unsigned long long *src = tile_keys + (size_t)t * cap;
+            unsigned long long *dst = out + running + scan[tid] - c;
+            for (unsigned k0 = 0; k0 < c; k0 += 8) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = k0 + u < c ? src[k0 + u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (k0 + u < c) dst[k0 + u] = v[u];
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) s_running = running + scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *out_count = s_running;
 }
 
 // ---- placement of the accepted candidates: rank by counting, then the first `free slots` fill the list
 // free slots in list order (selectGoodFeatures.py:109-110): every slot when overwriting, else the lost features
-__global__ __launch_bounds__(1024) void free_slots_kernel(const klt_feat *__restrict__ fl, int nfeat, int overwrite_all,
-                                                          int *__restrict__ slots, int *__restrict__ nfill_out)
+// one launch before the passes: workgroup 0 lists the free slots and keeps a copy of the list (a repeated attempt starts
+// from it), the other workgroups clear the counters
+__global__ __launch_bounds__(1024) void mis_prepare_kernel(const klt_feat *__restrict__ fl, int nfeat, int overwrite_all, int *__restrict__ slots,
+                                                           int *__restrict__ nfill_out, klt_feat *__restrict__ snapshot,
+                                                           unsigned *__restrict__ zero, size_t zero_n)
 {
+    if (blockIdx.x > 0) {
+        for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < zero_n; i += (size_t)(gridDim.x - 1) * 1024) zero[i] = 0u;
+        return;
+    }
     __shared__ int scan[1024];
     const int tid = threadIdx.x;
+    for (int i = tid; i < nfeat; i += 1024) snapshot[i] = fl[i];
     if (overwrite_all) { if (tid == 0) *nfill_out = nfeat; return; }
     const int per = (nfeat + 1023) / 1024, lo = tid * per, hi = min(lo + per, nfeat);
     int cnt = 0;
@@ -719,6 +907,36 @@ __global__ __launch_bounds__(1024) void free_slots_kernel(const klt_feat *__rest
     for (int i = lo; i < hi; i++)
         if (fl[i].val < 0) slots[k++] = i;
     if (tid == 1023) *nfill_out = scan[tid];
+}
+
+// REPLACING_SOME (selectGoodFeatures.py:64-69): every live feature clears the candidates within its exclusion square
+__global__ void mis_seed_kernel(const klt_feat *__restrict__ fl, int nfeat, MisArgs a, int d)
+{
+    const int f = blockIdx.x;
+    if (f >= nfeat) return;
+    const klt_feat ft = fl[f];
+    if (ft.val < 0) return;
+    const int cx = (int)ft.x, cy = (int)ft.y, side = 2 * d + 1;
+    for (int k = threadIdx.x; k < side * side; k += blockDim.x) {
+        const int px = cx - d + k % side - a.bx, py = cy - d + k / side - a.by;      // pixel offset from the first candidate
+        if (px < 0 || py < 0 || px % a.step || py % a.step) continue;
+        const int xi = px / a.step, yi = py / a.step;
+        if (xi < a.nx && yi < a.ny) a.st[(size_t)yi * a.nx + xi] = 0u;
+    }
+}
+
+// the few words the host looks at, written straight into pinned host memory: [0, look) "undecided left" flags of the
+// last passes, [64, 68) prefilter info, [72] placed, [73] candidates ran out
+__device__ __forceinline__ void write_results(unsigned *host_out, const unsigned *rem, int look, const unsigned *info, int placed, int ranout)
+{
+    for (int i = threadIdx.x; i < look; i += blockDim.x) host_out[i] = rem[i];
+    if (threadIdx.x < 4) host_out[64 + threadIdx.x] = info[threadIdx.x];
+    if (threadIdx.x == 0) { host_out[72] = (unsigned)placed; host_out[73] = (unsigned)ranout; }
+}
+
+__global__ void mis_results_kernel(unsigned *host_out, const unsigned *rem, int look, const unsigned *info, const int *placed)
+{
+    write_results(host_out, rem, look, info, placed[0], placed[1]);
 }
 
 // rank[i] += number of accepted keys in chunk blockIdx.y that are greater than key i (keys are distinct)
@@ -741,7 +959,8 @@ __global__ __launch_bounds__(RANK_T) void mis_rank_kernel(const unsigned long lo
 }
 
 __global__ __launch_bounds__(256) void mis_place_kernel(NmsArgs a, const unsigned *__restrict__ count, const unsigned *__restrict__ rank,
-                                                        const int *__restrict__ nfill_in)
+                                                        const int *__restrict__ nfill_in, unsigned *host_out, const unsigned *rem, int look,
+                                                        const unsigned *info)
 {
     const int n = (int)*count, nfill = *nfill_in;
     const int placed = min(n, nfill);
@@ -775,6 +994,7 @@ __global__ __launch_bounds__(256) void mis_place_kernel(NmsArgs a, const unsigne
         a.placed_out[0] = placed;
         a.placed_out[1] = placed < nfill ? 1 : 0;       // 1: the candidates ran out before the list was full
     }
+    if (blockIdx.x == 0) write_results(host_out, rem, look, info, placed, placed < nfill ? 1 : 0);
 }
 
 __global__ void unpack_candidates_kernel(const unsigned long long *__restrict__ keys, int n, float *__restrict__ val,
@@ -792,12 +1012,12 @@ __global__ void unpack_candidates_kernel(const unsigned long long *__restrict__ 
 
 void launch_sat_rows(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows)
 {
-    hipLaunchKernelGGL(sat_rows_kernel, dim3((nrows + 63) / 64), dim3(256), 0, s, gx, gy, sat, ncols, nrows);
+    hipLaunchKernelGGL(sat_rows_kernel, dim3((nrows + SR_ROWS - 1) / SR_ROWS), dim3(SR_T), 0, s, gx, gy, sat, ncols, nrows);
 }
 
 void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows)
 {
-    hipLaunchKernelGGL(sat_cols_kernel, dim3((ncols + 63) / 64, 3), dim3(64), 0, s, sat, ncols, nrows);
+    hipLaunchKernelGGL(sat_cols_kernel, dim3((ncols + SC_COLS - 1) / SC_COLS, 3), dim3(SC_T), 0, s, sat, ncols, nrows);
 }
 
 void launch_seed_fill(hipStream_t s, const klt_feat *fl, int nfeat, uint8_t *seedmap, int ncols, int nrows, int d)
@@ -814,15 +1034,27 @@ void launch_eigen(hipStream_t s, const SelectArgs &a)
 void launch_topk_prefilter(hipStream_t s, const unsigned long long *keys, int n, unsigned target, unsigned *hist,
                            unsigned *info /* [0..2] + counter at [3] */, unsigned long long *out)
 {
-    hipLaunchKernelGGL(key_hist_kernel, dim3(256), dim3(256), 0, s, keys, n, hist);
+    hipLaunchKernelGGL(key_hist_kernel, dim3(256), dim3(256), 0, s, keys, n, hist, 1);
     hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, hist, target, info);
     hipLaunchKernelGGL(key_compact_kernel, dim3(512), dim3(256), 0, s, keys, n, info, out, info + 3);
 }
 
+// threshold bin for the parallel passes from a histogram of every 4th key (counts in info[] are in sampled units)
 void launch_key_threshold(hipStream_t s, const unsigned long long *keys, int n, unsigned target, unsigned *hist, unsigned *info)
 {
-    hipLaunchKernelGGL(key_hist_kernel, dim3(256), dim3(256), 0, s, keys, n, hist);
-    hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, hist, target, info);
+    hipLaunchKernelGGL(key_hist_kernel, dim3(256), dim3(256), 0, s, keys, n, hist, 4);
+    hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, hist, (target + 3u) / 4u, info);
+}
+
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned *__restrict__ p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+
+void launch_zero_words(hipStream_t s, unsigned *p, size_t n)
+{
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 1024 ? (blocks ? blocks : 1) : 1024)), dim3(256), 0, s, p, n);
 }
 
 int mis_tiles(int nx, int ny) { return ((nx + MIS_TILE - 1) / MIS_TILE) * ((ny + MIS_TILE - 1) / MIS_TILE); }
@@ -830,7 +1062,7 @@ int mis_tiles(int nx, int ny) { return ((nx + MIS_TILE - 1) / MIS_TILE) * ((ny +
 size_t mis_stage_bytes(int R)
 {
     const size_t W = MIS_TILE + 2 * (R > 0 ? R : 0);
-    return R > 0 ? (W * W + W * MIS_TILE) * sizeof(unsigned long long) : 0;
+    return R > 0 ? (W * MIS_TILE + W * W) * sizeof(uint32_t) : 0;
 }
 
 void launch_mis_init(hipStream_t s, const MisArgs &a)
@@ -849,17 +1081,50 @@ int launch_mis_round(hipStream_t s, const MisArgs &a, int round)
     return 0;
 }
 
-void launch_free_slots(hipStream_t s, const klt_feat *fl, int nfeat, int overwrite_all, int *slots, int *nfill_out)
+void launch_mis_compact(hipStream_t s, const MisArgs &a, unsigned long long *out, unsigned *out_count)
 {
-    hipLaunchKernelGGL(free_slots_kernel, dim3(1), dim3(1024), 0, s, fl, nfeat, overwrite_all, slots, nfill_out);
+    hipLaunchKernelGGL(mis_compact_kernel, dim3(1), dim3(1024), 0, s, a.acc_keys, a.acc_cnt, mis_tiles(a.nx, a.ny), a.acc_cap, out, out_count);
+}
+
+int mis_tile_capacity(int R)
+{
+    if (R < 0) return MIS_CAP;
+    const int per_side = (MIS_TILE + R) / (R + 1);      // accepted candidates are more than R cells apart in x or in y
+    return per_side * per_side < MIS_CAP ? per_side * per_side : MIS_CAP;
+}
+
+void launch_mis_prepare(hipStream_t s, const klt_feat *fl, int nfeat, int overwrite_all, int *slots, int *nfill_out, klt_feat *snapshot,
+                        unsigned *zero, size_t zero_n)
+{
+    const size_t zb = (zero_n + 1023) / 1024;
+    hipLaunchKernelGGL(mis_prepare_kernel, dim3(1 + (unsigned)(zb < 1 ? 1 : (zb > 64 ? 64 : zb))), dim3(1024), 0, s, fl, nfeat, overwrite_all, slots,
+                       nfill_out, snapshot, zero, zero_n);
+}
+
+void launch_mis_seed(hipStream_t s, const klt_feat *fl, int nfeat, const MisArgs &a, int d)
+{
+    hipLaunchKernelGGL(mis_seed_kernel, dim3(nfeat), dim3(128), 0, s, fl, nfeat, a, d);
+}
+
+void launch_eigen_hist(hipStream_t s, const SelectArgs &a)
+{
+    const int blocks = (a.nx * a.ny + 255) / 256;
+    hipLaunchKernelGGL(eigen_hist_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, a);
+    if (a.hist) hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, a.hist, a.hist_target, a.info);
+}
+
+void launch_mis_results(hipStream_t s, unsigned *host_out, const unsigned *rem, int look, const unsigned *info, const int *placed)
+{
+    hipLaunchKernelGGL(mis_results_kernel, dim3(1), dim3(64), 0, s, host_out, rem, look, info, placed);
 }
 
 // keys[0 .. *count) unsorted accepted candidates, *count <= bound; rank[] zeroed by the caller
-void launch_mis_place(hipStream_t s, const NmsArgs &a, const unsigned *count, unsigned *rank, const int *nfill, int bound)
+void launch_mis_place(hipStream_t s, const NmsArgs &a, const unsigned *count, unsigned *rank, const int *nfill, int bound,
+                      unsigned *host_out, const unsigned *rem, int look, const unsigned *info)
 {
     const int chunks = (bound + RANK_T - 1) / RANK_T;
     hipLaunchKernelGGL(mis_rank_kernel, dim3(chunks, chunks), dim3(RANK_T), 0, s, a.keys, count, rank);
-    hipLaunchKernelGGL(mis_place_kernel, dim3((bound + 255) / 256), dim3(256), 0, s, a, count, rank, nfill);
+    hipLaunchKernelGGL(mis_place_kernel, dim3((bound + 255) / 256), dim3(256), 0, s, a, count, rank, nfill, host_out, rem, look, info);
 }
 
 void launch_sort_desc(hipStream_t s, unsigned long long *keys, int n)

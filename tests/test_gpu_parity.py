@@ -887,3 +887,61 @@ def test_parallel_min_distance_long_dependency_chain(ctx, ko):
     got, placed = ctx.select(2, n)
     assert placed == int((want["val"] >= 0).sum())
     assert_feats(got, want["x"], want["y"], want["val"], "ramp")
+
+
+def _oracle_min_distance(ko, val, ncols, nrows, tc, n, fl=None):
+    p = params_from_tc(tc)
+    bx, by, _, _ = ko.scan_borders(p)
+    cand = ko.sorted_candidates(val, ncols, nrows, bx, by, p.nSkippedPixels)
+    out = ko.make_featurelist(n) if fl is None else fl.copy()
+    ko.enforce_min_distance(cand, out, ncols, nrows, p.mindist, p.min_eigenvalue, fl is None)
+    return out
+
+
+@pytest.mark.parametrize("case", ["ties", "plateau", "ramp", "checker", "random_replace"])
+def test_min_distance_on_given_scores(ctx, ko, case):
+    """_enforceMinimumDistance (selectGoodFeatures.py:45-135) driven with eigenvalue maps real frames rarely produce
+    (klt_set_score_override): equal scores inside one exclusion square (rank = x, then y), a constant plateau, a
+    monotone ramp (one dependency chain across the frame), a checkerboard of two values, random scores with live
+    features to keep (REPLACING_SOME).  Both formulations must give the oracle's list."""
+    from pyfeaturetrack_amd import synth
+    ncols, nrows, n = 500, 300, 400
+    tc = make_tc(mindist=10)
+    ctx.configure(tc)
+    frame = synth.synth_frame(ncols, nrows, 3, 0)
+    p = params_from_tc(tc)
+    bx, by, _, _ = ko.scan_borders(p)
+    nx, ny = ncols - 2 * bx, nrows - 2 * by
+    rng = np.random.default_rng(17)
+    ys, xs = np.mgrid[0:ny, 0:nx]
+    if case == "ties":
+        val = rng.integers(1, 40, (ny, nx)).astype(np.float32) * 8.0          # only 39 distinct scores
+    elif case == "plateau":
+        val = np.full((ny, nx), 50.0, np.float32)
+    elif case == "ramp":
+        val = (10.0 + xs + 0.001 * ys).astype(np.float32)
+    elif case == "checker":
+        val = np.where((xs // 3 + ys // 3) % 2 == 0, 100.0, 7.0).astype(np.float32)
+    else:
+        val = (rng.random((ny, nx)) * 1000.0).astype(np.float32)
+        val[rng.random((ny, nx)) < 0.3] = 0.5                                  # below min_eigenvalue
+    fl_in = None
+    if case == "random_replace":
+        fl_in = ko.make_featurelist(n)
+        keep = rng.choice(n, 150, replace=False)
+        fl_in["x"][keep] = rng.uniform(bx, ncols - bx - 1, 150).astype(np.float32)
+        fl_in["y"][keep] = rng.uniform(by, nrows - by - 1, 150).astype(np.float32)
+        fl_in["val"][keep] = 0
+    want = _oracle_min_distance(ko, val, ncols, nrows, tc, n, fl_in)
+    ctx.upload(2, frame)
+    try:
+        for algo in (1, 0):
+            ctx.set_option(8, algo)
+            ctx.set_score_override(val)
+            if fl_in is None:
+                got, placed = ctx.select(2, n)
+            else:
+                got, placed = ctx.select(2, n, mode=2, fl=fl_in)
+            assert_feats(got, *oracle_feats(want), what="%s algo %d" % (case, algo))
+    finally:
+        ctx.set_option(8, 1)
