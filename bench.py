@@ -206,6 +206,7 @@ def run_cfg1(args, json_fd):
     ctx.upload(0, i0)
     ctx.upload(1, i1)
     ctx.build_pyramids_batch([0, 1], sync=True)
+    ctx.select(0, 100, use_pyramid=True)                 # first call allocates the selection scratch
     t = time.perf_counter()
     fl, _ = ctx.select(0, 100, use_pyramid=True)
     ms_select = (time.perf_counter() - t) * 1e3
