@@ -40,36 +40,43 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// Numerical Recipes' gaussj with full pivoting, as upstream's _am_gauss_jordan_elimination
-__device__ int gauss_jordan(float a[6][6], int n, float b[6])
+// Numerical Recipes' gaussj with full pivoting, as upstream's _am_gauss_jordan_elimination, spread over the wavefront:
+// lane r * 6 + c holds a[r][c] (lanes 0..35), lane 36 + r holds b[r].  Every element goes through exactly the operations
+// of the sequential routine (there are no sums), so the result is the sequential one; the pivot search reproduces the
+// scan order of the original (`>=`: the last largest element in (row, column) order wins).  Returns the status; the
+// solution is left in the b lanes.
+__device__ __forceinline__ int gauss_jordan_wave(float &val, int n, int lane)
 {
-    int ipiv[6] = {0, 0, 0, 0, 0, 0}, irow = 0, icol = 0;
+    const int r = lane < 36 ? lane / 6 : lane - 36, c = lane < 36 ? lane % 6 : -1;
+    const bool is_a = lane < 36 && r < n && c < n, is_b = lane >= 36 && lane < 42 && r < n;
+    unsigned used = 0u;                                     // bit k: column k has been a pivot (ipiv[k] == 1)
     for (int i = 0; i < n; i++) {
-        float big = 0.f;
-        for (int j = 0; j < n; j++)
-            if (ipiv[j] != 1)
-                for (int k = 0; k < n; k++) {
-                    if (ipiv[k] == 0) {
-                        if (fabsf(a[j][k]) >= big) { big = fabsf(a[j][k]); irow = j; icol = k; }
-                    } else if (ipiv[k] > 1) return KLT_SMALL_DET;
-                }
-        ++ipiv[icol];
-        if (irow != icol) {
-            for (int l = 0; l < n; l++) { const float t = a[irow][l]; a[irow][l] = a[icol][l]; a[icol][l] = t; }
-            const float t = b[irow]; b[irow] = b[icol]; b[icol] = t;
+        const bool eligible = is_a && !((used >> r) & 1u) && !((used >> c) & 1u);
+        const float mag = eligible ? fabsf(val) : -1.f;
+        float big = mag;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) big = fmaxf(big, __shfl_xor(big, m));
+        const unsigned long long at_max = __ballot(eligible && mag == big);
+        if (at_max == 0ull) return KLT_SMALL_DET;            // NaNs: nothing compares equal
+        const int sel = 63 - __builtin_clzll(at_max);
+        const int irow = sel / 6, icol = sel % 6;
+        used |= 1u << icol;
+        if (irow != icol) {                                  // swap rows irow and icol of a and b
+            const int partner = is_a ? (r == irow ? icol * 6 + c : (r == icol ? irow * 6 + c : lane))
+                                     : (is_b ? (r == irow ? 36 + icol : (r == icol ? 36 + irow : lane)) : lane);
+            val = __shfl(val, partner);
         }
-        if (a[icol][icol] == 0.f) return KLT_SMALL_DET;
-        const float pivinv = 1.0f / a[icol][icol];
-        a[icol][icol] = 1.0f;
-        for (int l = 0; l < n; l++) a[icol][l] = a[icol][l] * pivinv;
-        b[icol] = b[icol] * pivinv;
-        for (int ll = 0; ll < n; ll++)
-            if (ll != icol) {
-                const float dum = a[ll][icol];
-                a[ll][icol] = 0.f;
-                for (int l = 0; l < n; l++) a[ll][l] = a[ll][l] - a[icol][l] * dum;
-                b[ll] = b[ll] - b[icol] * dum;
-            }
+        const float piv = __shfl(val, icol * 6 + icol);
+        if (piv == 0.f) return KLT_SMALL_DET;
+        const float pivinv = 1.0f / piv;
+        if (lane == icol * 6 + icol) val = 1.0f;
+        if ((is_a || is_b) && r == icol) val = val * pivinv;
+        const float pivot_row = __shfl(val, is_b ? 36 + icol : icol * 6 + (c < 0 ? 0 : c));      // a[icol][l] or b[icol]
+        const float dum = __shfl(val, r * 6 + icol);                                                  // a[ll][icol]
+        if ((is_a || is_b) && r != icol) {
+            const float base = (is_a && c == icol) ? 0.f : val;
+            val = base - pivot_row * dum;
+        }
     }
     return KLT_TRACKED;
 }
@@ -117,6 +124,40 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
     const float old_x2 = x2, old_y2 = y2;
     float Axx = st.Axx, Ayx = st.Ayx, Axy = st.Axy, Ayy = st.Ayy;
     const float *t_img = tpl, *t_gx = tpl + tn, *t_gy = tpl + 2 * tn;
+    // The template is sampled at (x1 + i, y1 + j), the same positions in every iteration: each lane keeps the samples of
+    // its (up to four) window pixels in registers.  Windows of more than 256 pixels sample inside the loops.
+    const bool hoist = n <= 256;
+    float ts_i[4] = {0.f, 0.f, 0.f, 0.f}, ts_gx[4] = {0.f, 0.f, 0.f, 0.f}, ts_gy[4] = {0.f, 0.f, 0.f, 0.f};
+    if (hoist) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = lane + 64 * q;
+            if (k < n) {
+                const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);
+                ts_i[q] = bilinear_at(t_img, tw, x1 + fi, y1 + fj);
+                if (a.mode == 0) {
+                    ts_gx[q] = bilinear_at(t_gx, tw, x1 + fi, y1 + fj);
+                    ts_gy[q] = bilinear_at(t_gy, tw, x1 + fi, y1 + fj);
+                }
+            }
+        }
+    }
+    // body(k, template image, template gradx, template grady) for every window pixel of this lane
+    auto for_samples = [&](auto body) {
+        if (hoist) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int k = lane + 64 * q;
+                if (k < n) body(k, ts_i[q], ts_gx[q], ts_gy[q]);
+            }
+        } else {
+            for (int k = lane; k < n; k += 64) {
+                const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);
+                body(k, bilinear_at(t_img, tw, x1 + fi, y1 + fj), a.mode == 0 ? bilinear_at(t_gx, tw, x1 + fi, y1 + fj) : 0.f,
+                     a.mode == 0 ? bilinear_at(t_gy, tw, x1 + fi, y1 + fj) : 0.f);
+            }
+        }
+    };
     const float sxs[4] = {-(float)hw, -(float)hw, (float)hw, (float)hw};
     const float sys[4] = {(float)hh, -(float)hh, (float)hh, -(float)hh};
     int iteration = 0, status = KLT_TRACKED;
@@ -130,14 +171,14 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
                 break;
             }
             float gxx = 0.f, gxy = 0.f, gyy = 0.f, ex = 0.f, ey = 0.f;
-            for (int k = lane; k < n; k += 64) {
+            for_samples([&](int k, float ti, float tgx, float tgy) {
                 const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);
-                const float d = bilinear_at(t_img, tw, x1 + fi, y1 + fj) - bilinear_at(a.i2, nc, x2 + fi, y2 + fj);
-                const float g1 = bilinear_at(t_gx, tw, x1 + fi, y1 + fj) + bilinear_at(a.gx2, nc, x2 + fi, y2 + fj);
-                const float g2 = bilinear_at(t_gy, tw, x1 + fi, y1 + fj) + bilinear_at(a.gy2, nc, x2 + fi, y2 + fj);
+                const float d = ti - bilinear_at(a.i2, nc, x2 + fi, y2 + fj);
+                const float g1 = tgx + bilinear_at(a.gx2, nc, x2 + fi, y2 + fj);
+                const float g2 = tgy + bilinear_at(a.gy2, nc, x2 + fi, y2 + fj);
                 gxx = gxx + g1 * g1; gxy = gxy + g1 * g2; gyy = gyy + g2 * g2;
                 ex = ex + d * g1; ey = ey + d * g2;
-            }
+            });
             gxx = wave_sum(gxx); gxy = wave_sum(gxy); gyy = wave_sum(gyy);
             ex = wave_sum(ex) * a.step; ey = wave_sum(ey) * a.step;
             const float det = gxx * gyy - gxy * gxy;
@@ -158,11 +199,11 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
             float T[6][6], e[6];
             for (int r = 0; r < 6; r++) { e[r] = 0.f; for (int q = 0; q < 6; q++) T[r][q] = 0.f; }
             const int nn = a.mode == 1 ? 4 : 6;
-            for (int k = lane; k < n; k += 64) {
+            for_samples([&](int k, float ti, float, float) {
                 const int i = k % width - hw, j = k / width - hh;
                 const float x = (float)i, y = (float)j;
                 const float mi = Axx * x + Axy * y, mj = Ayx * x + Ayy * y;
-                const float d = bilinear_at(t_img, tw, x1 + x, y1 + y) - bilinear_at(a.i2, nc, x2 + mi, y2 + mj);
+                const float d = ti - bilinear_at(a.i2, nc, x2 + mi, y2 + mj);
                 const float g1 = bilinear_at(a.gx2, nc, x2 + mi, y2 + mj);
                 const float g2 = bilinear_at(a.gy2, nc, x2 + mi, y2 + mj);
                 if (a.mode == 1) {
@@ -185,18 +226,21 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
                     T[3][3] = T[3][3] + yy * gyy; T[3][4] = T[3][4] + y * gxy; T[3][5] = T[3][5] + y * gyy;
                     T[4][4] = T[4][4] + gxx; T[4][5] = T[4][5] + gxy; T[5][5] = T[5][5] + gyy;
                 }
-            }
+            });
+            float mine = 0.f;                                // this lane's element of the normal equations
 #pragma unroll
             for (int r = 0; r < 6; r++) {
-                e[r] = wave_sum(e[r]) * 0.5f;
+                const float er = wave_sum(e[r]) * 0.5f;
+                if (lane == 36 + r) mine = er;
 #pragma unroll
-                for (int q = r; q < 6; q++) T[r][q] = wave_sum(T[r][q]);
+                for (int q = r; q < 6; q++) {
+                    const float t = wave_sum(T[r][q]);
+                    if (lane == r * 6 + q || lane == q * 6 + r) mine = t;
+                }
             }
+            status = gauss_jordan_wave(mine, nn, lane);
 #pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int q = r + 1; q < 6; q++) T[q][r] = T[r][q];
-            status = gauss_jordan(T, nn, e);
+            for (int r = 0; r < 6; r++) e[r] = __shfl(mine, 36 + r);
             if (a.mode == 1) { Axx = Axx + e[0]; Ayx = Ayx + e[1]; Ayy = Axx; Axy = -Ayx; dx = e[2]; dy = e[3]; }
             else { Axx = Axx + e[0]; Ayx = Ayx + e[1]; Axy = Axy + e[2]; Ayy = Ayy + e[3]; dx = e[4]; dy = e[5]; }
             x2 = x2 + dx; y2 = y2 + dy;
@@ -215,11 +259,11 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
     if ((x2 - old_x2) > a.max_differ || (y2 - old_y2) > a.max_differ) status = KLT_OOB;
     if (status == KLT_TRACKED) {
         float s = 0.f;
-        for (int k = lane; k < n; k += 64) {
+        for_samples([&](int k, float ti, float, float) {
             const float x = (float)(k % width - hw), y = (float)(k / width - hh);
             const float mi = a.mode ? Axx * x + Axy * y : x, mj = a.mode ? Ayx * x + Ayy * y : y;
-            s = s + fabsf(bilinear_at(t_img, tw, x1 + x, y1 + y) - bilinear_at(a.i2, nc, x2 + mi, y2 + mj));
-        }
+            s = s + fabsf(ti - bilinear_at(a.i2, nc, x2 + mi, y2 + mj));
+        });
         s = wave_sum(s);
         if (s / (float)n > a.max_residue) status = KLT_LARGE_RESIDUE;
     }
