@@ -120,24 +120,33 @@ class KLT_TrackingContext:
 
 class KLT_Feature:
     """klt.py:249-263.  The reference's __init__ assigns locals only; real attributes are set on
-    first placement (selectGoodFeatures.py:117-128).  Here they always exist."""
+    first placement (selectGoodFeatures.py:117-128).  Here they always exist: x, y, val are set by __init__, the
+    affine-consistency fields read as their defaults until something assigns them (a list of 20 000 features is
+    created and updated in Python on every selection, so the constructor stays small)."""
 
     __slots__ = ("x", "y", "val", "aff_img", "aff_img_gradx", "aff_img_grady",
                  "aff_x", "aff_y", "aff_Axx", "aff_Ayx", "aff_Axy", "aff_Ayy")
+    _AFF_DEFAULTS = {"aff_img": None, "aff_img_gradx": None, "aff_img_grady": None, "aff_x": -1.0, "aff_y": -1.0,
+                     "aff_Axx": 1.0, "aff_Ayx": 0.0, "aff_Axy": 0.0, "aff_Ayy": 1.0}
 
     def __init__(self):
         self.x = -1
         self.y = -1
         self.val = kltState.KLT_NOT_FOUND
-        self.aff_img = None
-        self.aff_img_gradx = None
-        self.aff_img_grady = None
-        self.aff_x = -1.0
-        self.aff_y = -1.0
-        self.aff_Axx = 1.0
-        self.aff_Ayx = 0.0
-        self.aff_Axy = 0.0
-        self.aff_Ayy = 1.0
+
+    def __getattr__(self, name):                  # only reached for a slot that was never assigned
+        try:
+            return KLT_Feature._AFF_DEFAULTS[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def _reset_affine(self):
+        """Back to the state of a newly placed feature (selectGoodFeatures.py:120-128)."""
+        for name in KLT_Feature._AFF_DEFAULTS:
+            try:
+                delattr(self, name)
+            except AttributeError:
+                pass
 
 
 _REC_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("val", np.int32), ("aux", np.int32)])   # == klt_feat

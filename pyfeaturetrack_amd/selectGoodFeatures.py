@@ -99,6 +99,7 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
     finally:
         if aff is not None:
             ctx.set_option(4, -1)
+    affine_used = aff is not None or tc.affineConsistencyCheck >= 0     # otherwise the affine fields were never assigned
     xs, ys, vals = fl["x"].tolist(), fl["y"].tolist(), fl["val"].tolist()
     olds = fl_in["val"].tolist() if mode == selectionMode.REPLACING_SOME else None
     for i, feat in enumerate(featurelist):
@@ -114,9 +115,8 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
             feat.val = kltState.KLT_NOT_FOUND
         else:
             continue
-        feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = None
-        feat.aff_x = feat.aff_y = -1.0
-        feat.aff_Axx, feat.aff_Ayx, feat.aff_Axy, feat.aff_Ayy = 1.0, 0.0, 0.0, 1.0
+        if affine_used:
+            feat._reset_affine()
     return featurelist
 
 
