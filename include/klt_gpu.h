@@ -88,15 +88,15 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
 /* affine state (klt_affine_alloc id, or -1) whose records klt_select* resets for every slot it fills
  * (selectGoodFeatures.py:120-128 clears the aff_* fields of a newly placed feature) */
 #define KLT_OPT_SELECT_AFFINE_STATE 4
-/* 1 (default): klt_select* sorts only the highest-scoring candidates (histogram threshold keeping >= 64 per requested
- * feature) and falls back to the full sort if the greedy walk runs off their end; 0: always the full sort.  With the
- * prefilter klt_select_async reads two small results back and therefore synchronises internally. */
+/* 1 (default): klt_select* only considers the highest-scoring candidates (histogram threshold keeping about 64 per
+ * requested feature) and repeats with every candidate if they run out before the list is full; 0: always every candidate. */
 #define KLT_OPT_TOPK_PREFILTER 5
 /* 1: the pyramid build smooths level 0 alone, then runs the level-0 gradients on the main stream concurrently with the
  * reductions / small-level gradients on a side stream (fork/join with events); 0 (default): fused level-0 kernel. */
 #define KLT_OPT_SPLIT_L0 7
 /* 1 (default): minimum-distance enforcement as parallel passes over all candidates (a candidate is accepted once every
- * higher-ranked neighbour is rejected; same result as the walk); 0: sort all candidates and walk them in order */
+ * higher-ranked neighbour is rejected; same result as the walk); 0: sort all candidates and walk them in order.
+ * Either way klt_select_async synchronises once internally (it reads back whether the list was filled / settled). */
 #define KLT_OPT_SELECT_PARALLEL_NMS 8
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
