@@ -636,6 +636,102 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
     }
 }
 
+// Variant of the fused reduce (KLT_OPT_PYR_REDUCE_VARIANT = 1, measured slower, kept for the comparison): 512 threads and f32 everywhere in LDS (35 KB for ss 4 / 21 taps), so that four
+// workgroups fit a CU and all tiles of a 1080p pair are resident at once; the tile load of an interior tile is a batch of
+// unconditional aligned quads (a guarded load is a branch, and every join drains vmcnt); the vertical pass widens per tap.
+template <int NT, int STRIDE>
+__device__ __forceinline__ float correlate_sym_f32src(const float *c, const TapRegs<NT> &t)
+{
+    constexpr int H = NT / 2;
+    double acc = (double)c[0] * t.k[H];
+#pragma unroll
+    for (int jj = -H; jj < 0; jj++) acc = acc + ((double)c[jj * STRIDE] + (double)c[-jj * STRIDE]) * t.k[H + jj];
+    return (float)acc;
+}
+
+template <int SS, int NT, int NTHR, int OW, int OH>
+__global__ __launch_bounds__(NTHR) void pyr_reduce_v2(PyrReduceArgs a)
+{
+    constexpr int r = NT / 2;
+    constexpr int SW = (OW - 1) * SS + 2 * r + 1, SH = (OH - 1) * SS + 2 * r + 1;
+    constexpr int PW = (SW + SS - 1) / SS, ROWLEN = PW * SS;
+    constexpr int SQ = (SW + 3) / 4, NQ = SH * SQ, QPT = (NQ + NTHR - 1) / NTHR;
+    extern __shared__ __attribute__((aligned(16))) float flds[];
+    float *const Hf = flds;                                      // [SH][OW]   horizontal results (f32, as between the passes)
+    float *const S = flds + SH * OW;                             // [SH][SS planes][PW]
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int xs0 = blockIdx.x * OW, ys0 = blockIdx.y * OH;
+    const int gx0 = xs0 * SS + SS / 2 - r, gy0 = ys0 * SS + SS / 2 - r;
+    const float *__restrict__ src = a.src[b];
+    const int nc = a.src_nc, nr = a.src_nr;
+    TapRegs<NT> k;
+    load_taps(k, a.taps);
+
+    // gx0 is a multiple of 4 columns for SS = 4 (and even for SS = 2): interior tiles load whole aligned quads
+    const bool interior = (nc & 3) == 0 && (gx0 & 3) == 0 && gx0 >= 0 && gy0 >= 0 && gx0 + 4 * SQ <= nc && gy0 + SH <= nr;
+    if (interior) {
+        float4 v[QPT];
+#pragma unroll
+        for (int u = 0; u < QPT; u++) {
+            const int i = min(tid + u * NTHR, NQ - 1);                    // clamped: the last threads repeat the last quad
+            const int rr = i / SQ, q = i - rr * SQ;
+            v[u] = *reinterpret_cast<const float4 *>(src + (size_t)(gy0 + rr) * nc + gx0 + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < QPT; u++) {
+            const int i = tid + u * NTHR;
+            if (i < NQ) {
+                const int rr = i / SQ, q = i - rr * SQ;
+                float *dst = S + rr * ROWLEN;
+                const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const int c = 4 * q + w;
+                    if (c < SW) dst[(c % SS) * PW + c / SS] = e[w];
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < SH * SW; i += NTHR) {
+            const int rr = i / SW, c = i - rr * SW;
+            S[rr * ROWLEN + (c % SS) * PW + c / SS] = src[(size_t)reflect_fast(gy0 + rr, nr) * nc + reflect_fast(gx0 + c, nc)];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < SH * OW; i += NTHR) {
+        const int rr = i / OW, xs = i % OW;
+        const float *row = S + rr * ROWLEN + xs;         // column xs*SS + r + j lives at plane (r+j)%SS, index xs + (r+j)/SS
+        double acc = (double)row[(r % SS) * PW + r / SS] * k.k[r];
+#pragma unroll
+        for (int jj = -r; jj < 0; jj++) {
+            const double lo = (double)row[((r + jj) % SS) * PW + (r + jj) / SS];
+            const double hi = (double)row[((r - jj) % SS) * PW + (r - jj) / SS];
+            acc = acc + (lo + hi) * k.k[r + jj];
+        }
+        Hf[i] = (float)acc;                              // the f32 rounding between the passes
+    }
+    __syncthreads();
+    if (tid < OW * OH) {
+        const int xs = tid % OW, ys = tid / OW;
+        const int ox = xs0 + xs, oy = ys0 + ys;
+        if (ox < a.dst_nc && oy < a.dst_nr)
+            a.dst[b][(size_t)oy * a.dst_nc + ox] = correlate_sym_f32src<NT, OW>(Hf + (ys * SS + r) * OW + xs, k);
+    }
+}
+
+template <int SS, int NT, int NTHR, int OW, int OH>
+static int launch_pyr_reduce_v2(hipStream_t s, const PyrReduceArgs &a, int batch)
+{
+    constexpr int r = NT / 2;
+    constexpr int SW = (OW - 1) * SS + 2 * r + 1, SH = (OH - 1) * SS + 2 * r + 1;
+    constexpr int PW = (SW + SS - 1) / SS;
+    constexpr size_t l = sizeof(float) * (size_t)(SH * OW + SH * PW * SS);
+    if (int e = set_lds(pyr_reduce_v2<SS, NT, NTHR, OW, OH>, l)) return e;
+    const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch);
+    hipLaunchKernelGGL((pyr_reduce_v2<SS, NT, NTHR, OW, OH>), grid, dim3(NTHR), l, s, a);
+    return 0;
+}
+
 template <int SS, int NT, typename TS, int OW, int OH>
 constexpr size_t pyr_reduce_fast_lds()
 {
@@ -658,6 +754,7 @@ static int launch_pyr_reduce_fast(hipStream_t s, const PyrReduceArgs &a, int bat
 }  // namespace
 
 int g_smooth_grad_variant = 0;     // 0 = register-blocked (default), 1 = one-sample-per-thread LDS kernels
+int g_pyr_reduce_variant = 0;      // 0 = 1024-thread kernel, f64 horizontal intermediate (default), 1 = 512-thread all-f32 kernel
 
 size_t smooth_grad_lds_bytes(int rs, int R)
 {
@@ -754,6 +851,10 @@ int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch)
         // measured at cfg-2 (us per launch, two frames, both levels averaged): f32 tile / 1024 threads 11.6,
         // f64 tile / 1024 threads 12.4, f32 / 512 14.1, f64 / 512 15.4 (profiles/README.md)
         // tile shapes 64x8, 32x16, 32x4 and 16x16 were measured too: 32x8 is the fastest (profiles/README.md)
+        if (g_pyr_reduce_variant == 1) {      // measured slower at cfg-2: 13.8 vs 11.7 us per launch (profiles/README.md)
+            if (a.ss == 4 && a.taps.n == 21) return launch_pyr_reduce_v2<4, 21, 512, 32, 8>(s, a, batch);
+            if (a.ss == 2 && a.taps.n == 11) return launch_pyr_reduce_v2<2, 11, 512, 32, 8>(s, a, batch);
+        }
         if (a.ss == 4 && a.taps.n == 21) return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 8>(s, a, batch);
         if (a.ss == 2 && a.taps.n == 11) return launch_pyr_reduce_fast<2, 11, 512, float, 32, 8>(s, a, batch);
     }

@@ -207,6 +207,25 @@ def test_one_sample_per_thread_variant(ctx, cfg1, img0):
         ctx.set_option(2, 0)
 
 
+@pytest.mark.parametrize("levels,ss,shape", [(3, 4, (1080, 1920)), (3, 2, (240, 320)), (2, 4, (187, 251))])
+def test_pyramid_reduce_variant(ctx, ko, levels, ss, shape):
+    """KLT_OPT_PYR_REDUCE_VARIANT=1 (512 threads, all-f32 LDS, batched interior loads): bit-identical pyramids."""
+    from pyfeaturetrack_amd import synth
+    img = synth.synth_frame(shape[1], shape[0], 9, 0)
+    tc = make_tc(levels=levels, ss=ss)
+    ctx.configure(tc)
+    P = ko.Pyramids(params_from_tc(tc), img.astype(np.float32))
+    try:
+        ctx.set_option(9, 1)
+        ctx.upload(0, img)
+        ctx.build_pyramids(0)
+        for l in range(levels):
+            for pi, w in enumerate(("img", "gx", "gy")):
+                assert_same(ctx.download_level(0, pi, l), P.level(w, l), "reduce variant 1 ss%d %s level %d" % (ss, w, l))
+    finally:
+        ctx.set_option(9, 0)
+
+
 @pytest.mark.parametrize("window,levels,ss,shape", [(7, 3, 8, (700, 900)), (15, 3, 2, (301, 447)), (5, 2, 4, (64, 64)),
                                                     (7, 4, 2, (123, 77)), (7, 2, 8, (40, 50)), (9, 2, 4, (17, 333))])
 def test_pyramids_various_geometries_vs_oracle(ctx, ko, window, levels, ss, shape):
