@@ -9,7 +9,7 @@ feature coarse-to-fine (device-resident feature records in, device-resident reco
 Workload at every N = BASELINE cfg-2 (1920x1080 synthetic pair, 5000 features, 7x7 window,
 3 pyramid levels / subsampling 4, translation only); with N > 1 every rank runs its own pair
 (seed = rank + 1: weak scaling, the path shards by frame pair with no data-path exchange) and the
-16-byte feature records of 32 consecutive steps are collected in a device-side table and gathered to
+16-byte feature records of 128 consecutive steps are collected in a device-side table and gathered to
 every rank with one RCCL all-gather on a side stream (event-ordered behind the tracker launch,
 overlapped with the next steps' kernels).
 
@@ -41,7 +41,7 @@ WIDTH, HEIGHT, NFEAT = 1920, 1080, 5000
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FB_SEL, FB_OUT0, FB_OUT1 = 0, 1, 2
 FB_RING0, FB_RING1, FB_VIEW0 = 3, 4, 100
-GATHER_EVERY = 32
+GATHER_EVERY = 128
 
 
 def cfg2_context():
