@@ -340,6 +340,9 @@ def main():
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 (default, the headline line); the others are the remaining BASELINE configs on one GPU, informative")
     ap.add_argument("--pairs", type=int, default=32, help="pairs per step for --config cfg4")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent pairs in flight per GPU: consecutive steps go round-robin to this many contexts (one HIP "
+                         "stream each, no events between them), so kernels of different pairs overlap; 1 = a single stream")
     ap.add_argument("--pipeline", action="store_true",
                     help="KLT_OPT_TRACK_STREAM: tracker on a second HIP stream, overlapping the next step's pyramid build "
                          "(measured slower on MI355X for this step size: event cost > overlap gain; DESIGN.md)")
@@ -370,53 +373,72 @@ def main():
 
     tc = cfg2_context()
     p = params_from_tc(tc)
-    ctx = Context(local_rank)
-    ctx.set_params(p)
     f0, f1 = synth.synth_pair(WIDTH, HEIGHT, seed=rank + 1)
-    # The pair lives in two slot pairs, (0,1) and (2,3), used by alternate steps: with KLT_OPT_TRACK_STREAM the tracker
-    # of step i (its own HIP stream) overlaps the pyramid build of step i+1, which must not overwrite what it reads.
-    for s0 in (0, 2):
-        ctx.upload(s0, f0)
-        ctx.upload(s0 + 1, f1)
-    if args.pipeline:
-        ctx.set_option(3, 1)
-    if args.split_l0:
-        ctx.set_option(7, 1)
-    ctx.build_pyramids(0)
-    fl, placed = ctx.select(0, NFEAT, use_pyramid=True)
-    assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)
-    ctx.featbuf_upload(FB_SEL, fl)
-    ctx.featbuf_upload(FB_OUT0, fl)
-    ctx.featbuf_upload(FB_OUT1, fl)
+    # `--inflight` contexts per GPU, each with its own HIP stream, slots and feature buffers.  Step i runs on context
+    # i % inflight: pairs are independent (the path shards by frame pair), so nothing orders the streams against each other
+    # and the GPU overlaps the kernels of different pairs -- the drain / ramp between dependent kernels of one pair and the
+    # latency-bound tracker are filled with the next pair's convolutions.
+    nctx = max(1, args.inflight)
+    ctxs, gathers = [], []
+    fl = None
+    for c in range(nctx):
+        cx = Context(local_rank)
+        cx.set_params(p)
+        # The pair lives in two slot pairs, (0,1) and (2,3), used by alternate steps of a context: with KLT_OPT_TRACK_STREAM
+        # the tracker of one step overlaps the pyramid build of the next, which must not overwrite what it reads.
+        for s0 in (0, 2):
+            cx.upload(s0, f0)
+            cx.upload(s0 + 1, f1)
+        if args.pipeline:
+            cx.set_option(3, 1)
+        if args.split_l0:
+            cx.set_option(7, 1)
+        cx.build_pyramids(0)
+        fl_c, placed = cx.select(0, NFEAT, use_pyramid=True)
+        assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)
+        assert fl is None or np.array_equal(fl, fl_c), "contexts selected different features"
+        fl = fl_c
+        cx.featbuf_upload(FB_SEL, fl)
+        cx.featbuf_upload(FB_OUT0, fl)
+        cx.featbuf_upload(FB_OUT1, fl)
+        # N > 1: the records of GATHER_EVERY consecutive steps of a context land in one device-side [steps x features] table
+        # (two tables, used alternately) and each full table is all-gathered with ONE RCCL collective on a side stream --
+        # cfg-4's "gather once per shard", and the host cost of a collective is not paid per step.
+        if distributed:
+            from pyfeaturetrack_amd.parallel import FeatureGather
+            for t, ring in enumerate((FB_RING0, FB_RING1)):
+                cx.featbuf_alloc(ring, GATHER_EVERY * NFEAT)
+                for k in range(GATHER_EVERY):
+                    cx.featbuf_view(FB_VIEW0 + t * GATHER_EVERY + k, ring, k * NFEAT, NFEAT)
+            gathers.append(FeatureGather(cx, [FB_RING0, FB_RING1], GATHER_EVERY * NFEAT, world, torch, dist))
+        ctxs.append(cx)
+    ctx = ctxs[0]
 
-    # N > 1: the records of GATHER_EVERY consecutive steps land in one device-side [steps x features] table (two
-    # tables, used alternately) and each full table is all-gathered with ONE RCCL collective on a side stream --
-    # cfg-4's "gather once per shard", and the host cost of a collective is not paid per 80 us step.
-    gather = None
-    if distributed:
-        from pyfeaturetrack_amd.parallel import FeatureGather
-        for t, ring in enumerate((FB_RING0, FB_RING1)):
-            ctx.featbuf_alloc(ring, GATHER_EVERY * NFEAT)
-            for k in range(GATHER_EVERY):
-                ctx.featbuf_view(FB_VIEW0 + t * GATHER_EVERY + k, ring, k * NFEAT, NFEAT)
-        gather = FeatureGather(ctx, [FB_RING0, FB_RING1], GATHER_EVERY * NFEAT, world, torch, dist)
+    def out_buffer(j):
+        """feature buffer that local step j of a context writes"""
+        if not distributed:
+            return FB_OUT0 if j % 2 == 0 else FB_OUT1
+        return FB_VIEW0 + ((j // GATHER_EVERY) % 2) * GATHER_EVERY + j % GATHER_EVERY
 
     def step(i, last=False):
-        a = 0 if i % 2 == 0 else 2
-        ctx.build_pyramids_batch([a, a + 1])      # both frames share every launch
-        if gather is None:
-            ctx.track_async(a, a + 1, FB_SEL, FB_OUT0 if i % 2 == 0 else FB_OUT1, NFEAT)
+        c, j = i % nctx, i // nctx                # context, and the step's index among that context's steps
+        cx = ctxs[c]
+        a = 0 if j % 2 == 0 else 2
+        cx.build_pyramids_batch([a, a + 1])       # both frames share every launch
+        if not distributed:
+            cx.track_async(a, a + 1, FB_SEL, out_buffer(j), NFEAT)
             return
-        t, k = (i // GATHER_EVERY) % 2, i % GATHER_EVERY
+        t, k = (j // GATHER_EVERY) % 2, j % GATHER_EVERY
         ring = FB_RING0 if t == 0 else FB_RING1
         if k == 0:
-            gather.wait_free(ring)          # the collective that read this table two rounds ago has finished
-        ctx.track_async(a, a + 1, FB_SEL, FB_VIEW0 + t * GATHER_EVERY + k, NFEAT)
+            gathers[c].wait_free(ring)      # the collective that read this table two rounds ago has finished
+        cx.track_async(a, a + 1, FB_SEL, out_buffer(j), NFEAT)
         if k == GATHER_EVERY - 1 or last:
-            gather.all_gather(ring)         # RCCL on a side stream, behind this tracker launch (event)
+            gathers[c].all_gather(ring)     # RCCL on a side stream, behind this tracker launch (event)
 
     def fence():
-        ctx.sync()
+        for cx in ctxs:
+            cx.sync()
         if distributed:
             torch.cuda.synchronize()
             dist.barrier()
@@ -436,13 +458,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # correctness of what was timed: the last output equals a fresh synchronous track
+    # correctness of what was timed: the last step's records (and, N > 1, what the gather delivered of them); every
+    # context's last output is the same list (same pair, same features)
     last_i = args.steps - 1
-    last_fb = (FB_OUT0 if last_i % 2 == 0 else FB_OUT1) if gather is None else \
-        FB_VIEW0 + ((last_i // GATHER_EVERY) % 2) * GATHER_EVERY + last_i % GATHER_EVERY
-    out = ctx.featbuf_download(last_fb, NFEAT)
-    if gather is not None:          # what rank 0 received from itself equals what it produced
-        got = gather.result()[rank].reshape(GATHER_EVERY, NFEAT)[last_i % GATHER_EVERY]
+    last_c, last_j = last_i % nctx, last_i // nctx
+    out = ctxs[last_c].featbuf_download(out_buffer(last_j), NFEAT)
+    for c in range(nctx):
+        nsteps_c = (args.steps - c + nctx - 1) // nctx
+        if nsteps_c > 0:
+            o = ctxs[c].featbuf_download(out_buffer(nsteps_c - 1), NFEAT)
+            assert np.array_equal(o["x"], out["x"]) and np.array_equal(o["y"], out["y"]) and np.array_equal(o["val"], out["val"]), \
+                "contexts disagree on the tracked records"
+    if distributed:                 # what rank 0 received from itself equals what it produced
+        got = gathers[last_c].result()[rank].reshape(GATHER_EVERY, NFEAT)[last_j % GATHER_EVERY]
         assert np.array_equal(got["x"], out["x"]) and np.array_equal(got["val"], out["val"]), "gathered records differ"
     tracked = int(np.count_nonzero(out["val"] >= 0))
     live = out["val"] == 0
@@ -498,6 +526,13 @@ def main():
         ctx.sync()
         ms_select = (time.perf_counter() - t) / reps * 1e3
         t = time.perf_counter()
+        for i in range(args.steps):                            # the same K steps on ONE stream (one pair in flight)
+            a = 0 if i % 2 == 0 else 2
+            ctx.build_pyramids_batch([a, a + 1])
+            ctx.track_async(a, a + 1, FB_SEL, FB_OUT0 if i % 2 == 0 else FB_OUT1, NFEAT)
+        ctx.sync()
+        ms_single = (time.perf_counter() - t) / args.steps * 1e3
+        t = time.perf_counter()
         for _ in range(reps):                                  # un-pipelined latency of one pair
             ctx.build_pyramids_batch([0, 1])
             ctx.track_async(0, 1, FB_SEL, FB_OUT0, NFEAT)
@@ -543,6 +578,7 @@ def main():
         assert np.array_equal(table[-NFEAT:]["x"], out["x"]), "pipelined ingest changed the result"
         extra = {"pcie_pipelined_ms_per_pair": ms_pipe, "pcie_pipelined_features_per_s": NFEAT / (ms_pipe * 1e-3),
                  "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "latency_ms_per_pair_synchronised": ms_latency,
+                 "single_stream_ms_per_pair": ms_single, "single_stream_features_per_s": NFEAT / (ms_single * 1e-3),
                  "ms_per_select_5000": ms_select,
                  "pcie_inclusive_ms_per_pair": ms_pcie, "pcie_inclusive_features_per_s": NFEAT / (ms_pcie * 1e-3),
                  "note": "pcie_inclusive = H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the "
@@ -562,8 +598,11 @@ def main():
             "dtype": "f32 (convolutions accumulate in f64)", "data": "synthetic",
             "config": {"workload": "cfg-2: one 1920x1080 synthetic pair per GPU, 5000 features, 7x7 window, "
                                    "3 pyramid levels (subsampling 4), translation only; inputs resident in HBM",
-                       "pipelining": "none (one HIP stream)" if not args.pipeline else
-                                     "tracker of step i on its own HIP stream overlaps the pyramid build of step i+1 (double-buffered slots)",
+                       "pipelining": ("none (one HIP stream)" if nctx == 1 else
+                                      "%d independent pairs in flight: steps go round-robin to %d contexts, one HIP stream each, no "
+                                      "ordering between them (pairs are independent); every step does the full work of one pair" % (nctx, nctx))
+                                     + ("; tracker of a step on its own HIP stream (KLT_OPT_TRACK_STREAM)" if args.pipeline else ""),
+                       "pairs_in_flight": nctx,
                        "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
                        "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
                        "parallelism": "1 pair per GPU" + (", RCCL all-gather of the [%d steps x 5000] record table every %d steps" % (GATHER_EVERY, GATHER_EVERY) if distributed else "")},
@@ -571,7 +610,8 @@ def main():
         }
     else:
         line = None
-    ctx.close()
+    for cx in ctxs:
+        cx.close()
     if distributed:
         dist.destroy_process_group()        # RCCL may write its own chatter to stdout while shutting down
     if line is not None:

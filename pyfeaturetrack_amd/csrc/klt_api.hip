@@ -101,6 +101,7 @@ struct klt_ctx {
     bool use_topk = true;
     bool use_mis = true;                      // parallel minimum-distance passes instead of the sorted serial walk
     int mis_rounds_hint = 6;
+    int sat_variant = 0;                      // 0: barrier-coupled SAT kernels, 1: wavefront pipelines (sat_pipeline.hip)
     unsigned *readback = nullptr;             // pinned scratch for small results
     float *score_override = nullptr;          // test hook (klt_set_score_override)
     size_t score_override_cap = 0;
@@ -832,6 +833,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_FUSED_KERNELS) { c->use_fused = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SMOOTH_GRAD_VARIANT) { g_smooth_grad_variant = value; return KLT_OK; }
     if (option == KLT_OPT_PYR_REDUCE_VARIANT) { g_pyr_reduce_variant = value; return KLT_OK; }
+    if (option == KLT_OPT_SAT_VARIANT) { c->sat_variant = value; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SPLIT_L0) { c->split_l0 = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_PARALLEL_NMS) { c->use_mis = value != 0; return KLT_OK; }
@@ -1016,8 +1018,17 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     c->sel_nc = nc; c->sel_nr = nr; c->sel_nx = nx; c->sel_ny = ny; c->sel_npow2 = (int)npow2;
 
     // summed-area tables (goodFeaturesUtils.pyx:49-51)
-    { TimerScope t(c, F_SAT_ROWS, (double)N * (8 + 12)); launch_sat_rows(c->stream, gx, gy, c->sat, nc, nr); }
-    { TimerScope t(c, F_SAT_COLS, (double)N * 24); launch_sat_cols(c->stream, c->sat, nc, nr); }
+    if (c->sat_variant == 1) {
+        // wavefront pipelines; a timed-out wait raises placed_d[3], checked below with the other results
+        HIPCHK(c, hipMemsetAsync(c->placed_d + 3, 0, sizeof(int), c->stream));
+        { TimerScope t(c, F_SAT_ROWS, (double)N * (8 + 12));
+          if (const int e = launch_sat_rows_pipe(c->stream, gx, gy, c->sat, nc, nr, c->placed_d + 3)) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e)); }
+        { TimerScope t(c, F_SAT_COLS, (double)N * 24);
+          if (const int e = launch_sat_cols_pipe(c->stream, c->sat, nc, nr, c->placed_d + 3)) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e)); }
+    } else {
+        { TimerScope t(c, F_SAT_ROWS, (double)N * (8 + 12)); launch_sat_rows(c->stream, gx, gy, c->sat, nc, nr); }
+        { TimerScope t(c, F_SAT_COLS, (double)N * 24); launch_sat_cols(c->stream, c->sat, nc, nr); }
+    }
 
     int mindist = p.mindist < 0 ? 0 : p.mindist;          // selectGoodFeatures.py:241-243
     const int d = mindist - 1;                            // :61

@@ -24,6 +24,29 @@
 
 #pragma clang fp contract(off)
 
+// tools/mb/l0_stages.hip builds this file with KLT_STAGE_CLOCKS to time the stages of one workgroup; a no-op otherwise
+#ifdef KLT_STAGE_CLOCKS
+__device__ long long g_stage_clk[64 * 8];
+__device__ long long g_block_clk[8192 * 2];       // start / end of every workgroup, and the XCC / CU it ran on
+__device__ unsigned g_block_hw[8192];
+#define STAGE_MARK(n)                                                                                   \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.y == 8 && blockIdx.z == 0 && blockIdx.x < 64) g_stage_clk[blockIdx.x * 8 + (n)] = wall_clock64(); \
+        if (threadIdx.x == 0 && ((n) == 0 || (n) == 5)) {                                                \
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);         \
+            if (lin < 8192) {                                                                            \
+                g_block_clk[2 * lin + ((n) == 5)] = wall_clock64();                                      \
+                unsigned hw, xcc;                                                                        \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                         \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                       \
+                g_block_hw[lin] = (hw & 0xffff) | (xcc << 16);                                           \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+#else
+#define STAGE_MARK(n) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TW = 64, TH = 16;        // output tile of smooth_grad_kernel
@@ -316,8 +339,22 @@ __device__ __forceinline__ void widen4(const float4 v, double *d)
     d[0] = (double)v.x; d[1] = (double)v.y; d[2] = (double)v.z; d[3] = (double)v.w;
 }
 
+// Three aligned quads of an LDS row, widened.  The loads are volatile so that they stay three ds_read_b128: when only 8 or
+// 10 of the 12 samples are used the compiler otherwise narrows them to ds_read2_b32 pairs, and dword reads at a lane stride
+// of 16 bytes are 4-way bank conflicts.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void widen12(const float *row, double *d)
+{
+    typedef const volatile __attribute__((address_space(3))) f32x4 *lds_quad_ptr;
+    const lds_quad_ptr p = (lds_quad_ptr)row;
+    const f32x4 a = p[0], b = p[1], c = p[2];
+    d[0] = (double)a.x; d[1] = (double)a.y; d[2] = (double)a.z; d[3] = (double)a.w;
+    d[4] = (double)b.x; d[5] = (double)b.y; d[6] = (double)b.z; d[7] = (double)b.w;
+    d[8] = (double)c.x; d[9] = (double)c.y; d[10] = (double)c.z; d[11] = (double)c.w;
+}
+
 template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_>
-__global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
+__global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
 {
     constexpr int rs = SMOOTH ? NS / 2 : 0;
     constexpr int R = (NG > ND ? NG : ND) / 2;
@@ -339,10 +376,68 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
     load_taps(kg, a.ggauss);
     load_taps(kd, a.gderiv);
 
+    STAGE_MARK(0);
     // ---- stage 0: frame -> LDS (through the reflect map)
     {
         constexpr int W0 = SMOOTH ? AQ : BQ, H0 = SMOOTH ? RH : IH, X0 = SMOOTH ? -8 : -4, Y0 = -(R + rs);
         float *const dst = SMOOTH ? A : C;
+        constexpr int N0 = H0 * W0, U0 = (N0 + 255) / 256;
+        // Tiles whose halo lies inside the frame (most of them): every load of the thread is issued before the first one
+        // is used.  The general loop below waits for each of its 3-4 loads in turn -- 2.2 of the 9 us a workgroup lives.
+        const bool interior = (nc & 3) == 0 && tx0 + X0 >= 0 && tx0 + X0 + 4 * W0 <= nc && ty0 + Y0 >= 0 && ty0 + Y0 + H0 <= nr;
+        if (interior) {
+            const TIn *const base = raw + (size_t)(ty0 + Y0) * nc + (tx0 + X0);
+            if (sizeof(TIn) == 1) {
+                uint32_t w[U0];
+#pragma unroll
+                for (int u = 0; u < U0; u++) {
+                    const int i = min(tid + u * 256, N0 - 1);          // clamped, unconditional (the last threads repeat a quad)
+                    w[u] = *reinterpret_cast<const uint32_t *>(base + (size_t)(i / W0) * nc + 4 * (i % W0));
+                }
+#pragma unroll
+                for (int u = 0; u < U0; u++) {
+                    const int i = tid + u * 256;
+                    float4 v;
+                    v.x = (float)(w[u] & 0xffu); v.y = (float)((w[u] >> 8) & 0xffu);
+                    v.z = (float)((w[u] >> 16) & 0xffu); v.w = (float)(w[u] >> 24);
+                    if (i < N0) *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = v;
+                }
+            } else {
+                float4 w[U0];
+#pragma unroll
+                for (int u = 0; u < U0; u++) {
+                    const int i = min(tid + u * 256, N0 - 1);
+                    w[u] = *reinterpret_cast<const float4 *>(base + (size_t)(i / W0) * nc + 4 * (i % W0));
+                }
+#pragma unroll
+                for (int u = 0; u < U0; u++) {
+                    const int i = tid + u * 256;
+                    if (i < N0) *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = w[u];
+                }
+            }
+        } else if (nc >= 2 * TW && nr >= 2 * TH_) {
+            // frame-edge tiles of frames large enough that one reflection brings every index inside: branch-free index
+            // map, all element loads of the thread in flight together
+            TIn e[U0][4];
+#pragma unroll
+            for (int u = 0; u < U0; u++) {
+                const int i = min(tid + u * 256, N0 - 1);
+                const int y = ty0 + Y0 + i / W0, x = tx0 + X0 + 4 * (i % W0);
+                const TIn *row = raw + (size_t)(y < 0 ? -1 - y : y >= nr ? 2 * nr - 1 - y : y) * nc;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int xx = x + k;
+                    e[u][k] = row[xx < 0 ? -1 - xx : xx >= nc ? 2 * nc - 1 - xx : xx];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U0; u++) {
+                const int i = tid + u * 256;
+                float4 v;
+                v.x = (float)e[u][0]; v.y = (float)e[u][1]; v.z = (float)e[u][2]; v.w = (float)e[u][3];
+                if (i < N0) *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = v;
+            }
+        } else
         for (int i = tid; i < H0 * W0; i += 256) {
             const int r = i / W0, q = i % W0;
             const int gy = reflect_fast(ty0 + Y0 + r, nr);
@@ -367,21 +462,22 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
         }
     }
     __syncthreads();
+    STAGE_MARK(1);
     if (SMOOTH) {
         TapRegs<NS> ks;
         load_taps(ks, a.smooth);
         // ---- stage 1: horizontal smoothing, A -> B (B column c = A column c + 4)
         for (int i = tid; i < RH * BQ; i += 256) {
             const int r = i / BQ, q = i % BQ;
-            const float4 *src = reinterpret_cast<const float4 *>(A + r * AW + 4 * q);
             double v[12];
-            widen4(src[0], v); widen4(src[1], v + 4); widen4(src[2], v + 8);
+            widen12(A + r * AW + 4 * q, v);
             float4 o;
             o.x = corr_regs<NS, 1>(v + 4, ks); o.y = corr_regs<NS, 1>(v + 5, ks);
             o.z = corr_regs<NS, 1>(v + 6, ks); o.w = corr_regs<NS, 1>(v + 7, ks);
             *reinterpret_cast<float4 *>(B + r * BW + 4 * q) = o;
         }
         __syncthreads();
+        STAGE_MARK(2);
         // ---- stage 2: vertical smoothing, B -> C (+ store the tile interior of the smoothed image).
         // A thread produces a quad on two consecutive rows: NS+1 rows are read and widened for 8 outputs.
         float *__restrict__ img = a.img[b];
@@ -415,12 +511,14 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
         }
         __syncthreads();
     }
+    STAGE_MARK(3);
     // ---- stage 3: horizontal pass of both gradients, C -> D (derivative taps), E (Gaussian taps)
-    for (int i = tid; i < IH * DQ; i += 256) {
+    // (the partial last round of this loop goes to wavefronts 2 and 3: stage 2 gave its partial round to wavefronts 0
+    // and 1, and wavefront w of every workgroup of a CU sits on SIMD w -- the rotation evens out the SIMDs)
+    for (int i = (tid + 128) & 255; i < IH * DQ; i += 256) {
         const int r = i / DQ, q = i % DQ;
-        const float4 *src = reinterpret_cast<const float4 *>(C + r * BW + 4 * q);
         double v[12];
-        widen4(src[0], v); widen4(src[1], v + 4); widen4(src[2], v + 8);
+        widen12(C + r * BW + 4 * q, v);
         float4 d, e;
         d.x = corr_regs<ND, -1>(v + 4, kd); d.y = corr_regs<ND, -1>(v + 5, kd);
         d.z = corr_regs<ND, -1>(v + 6, kd); d.w = corr_regs<ND, -1>(v + 7, kd);
@@ -430,6 +528,7 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
         *reinterpret_cast<float4 *>(E + r * DW + 4 * q) = e;
     }
     __syncthreads();
+    STAGE_MARK(4);
     // ---- stage 4: vertical pass, D -> gradx (Gaussian taps), E -> grady (derivative taps); quad x two rows per thread
     float *__restrict__ gxo = a.gx[b];
     float *__restrict__ gyo = a.gy[b];
@@ -480,6 +579,7 @@ __global__ __launch_bounds__(256) void smooth_grad_rb(SmoothGradArgs a)
             }
         }
     }
+    STAGE_MARK(5);
 }
 
 // Smoothing only (frame -> level-0 image), register-blocked like smooth_grad_rb.  Used when the level-0 gradients are
