@@ -690,10 +690,55 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
     const int nc = a.src_nc, nr = a.src_nr;
     TapRegs<NT> k;
     load_taps(k, a.taps);
+    STAGE_MARK(0);
 
     // tile load: one aligned 16-byte quad per step where the row allows it (gx0 is a multiple of 4 columns)
     constexpr int SQ = (SW + 3) / 4;
     const bool quads = (nc & 3) == 0;
+    // tiles inside the frame: all quads of the thread are requested before the first is used (the general loop waits for
+    // each load in turn, and the tile load is 2.3 of the 3.7 us a workgroup lives)
+    constexpr int NQ = SH * SQ, QPT = (NQ + NTHR - 1) / NTHR;
+    const bool interior = quads && (gx0 & 3) == 0 && gx0 >= 0 && gy0 >= 0 && gx0 + 4 * SQ <= nc && gy0 + SH <= nr;
+    if (interior) {
+        float4 v[QPT];
+#pragma unroll
+        for (int u = 0; u < QPT; u++) {
+            const int i = min(tid + u * NTHR, NQ - 1);                    // clamped: the last threads repeat the last quad
+            const int rr = i / SQ, q = i - rr * SQ;
+            v[u] = *reinterpret_cast<const float4 *>(src + (size_t)(gy0 + rr) * nc + gx0 + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < QPT; u++) {
+            const int i = tid + u * NTHR;
+            if (i < NQ) {
+                const int rr = i / SQ, q = i - rr * SQ;
+                TS *dst = S + rr * ROWLEN;
+                const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const int c = 4 * q + w;
+                    if (c < SW) dst[(c % SS) * PW + c / SS] = (TS)e[w];
+                }
+            }
+        }
+    } else if (nc >= 2 * SW && nr >= 2 * SH) {
+        // frame-edge tiles of frames large enough that one reflection brings every index inside: branch-free index map,
+        // every element load of the thread in flight together
+        constexpr int NE = SH * SW, EPT = (NE + NTHR - 1) / NTHR;
+        float e[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            const int i = min(tid + u * NTHR, NE - 1);
+            const int y = gy0 + i / SW, x = gx0 + i % SW;
+            e[u] = src[(size_t)(y < 0 ? -1 - y : y >= nr ? 2 * nr - 1 - y : y) * nc + (x < 0 ? -1 - x : x >= nc ? 2 * nc - 1 - x : x)];
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            const int i = tid + u * NTHR;
+            const int rr = i / SW, c = i % SW;
+            if (i < NE) S[rr * ROWLEN + (c % SS) * PW + c / SS] = (TS)e[u];
+        }
+    } else
     for (int i = tid; i < SH * SQ; i += NTHR) {
         const int rr = i / SQ, q = i % SQ;
         const int gy = reflect_fast(gy0 + rr, nr);
@@ -715,6 +760,7 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
         }
     }
     __syncthreads();
+    STAGE_MARK(1);
     for (int i = tid; i < SH * OW; i += NTHR) {
         const int rr = i / OW, xs = i % OW;
         const TS *row = S + rr * ROWLEN + xs;            // column xs*SS + r + j lives at plane (r+j)%SS, index xs + (r+j)/SS
@@ -728,12 +774,14 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
         Hd[i] = (double)(float)acc;                      // the f32 rounding between the passes
     }
     __syncthreads();
+    STAGE_MARK(2);
     if (tid < OW * OH) {
         const int xs = tid % OW, ys = tid / OW;
         const int ox = xs0 + xs, oy = ys0 + ys;
         if (ox < a.dst_nc && oy < a.dst_nr)
             a.dst[b][(size_t)oy * a.dst_nc + ox] = correlate_sym_f64<NT, OW>(Hd + (ys * SS + r) * OW + xs, k);
     }
+    STAGE_MARK(5);
 }
 
 // Variant of the fused reduce (KLT_OPT_PYR_REDUCE_VARIANT = 1, measured slower, kept for the comparison): 512 threads and f32 everywhere in LDS (35 KB for ss 4 / 21 taps), so that four
@@ -955,7 +1003,12 @@ int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch)
             if (a.ss == 4 && a.taps.n == 21) return launch_pyr_reduce_v2<4, 21, 512, 32, 8>(s, a, batch);
             if (a.ss == 2 && a.taps.n == 11) return launch_pyr_reduce_v2<2, 11, 512, 32, 8>(s, a, batch);
         }
-        if (a.ss == 4 && a.taps.n == 21) return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 8>(s, a, batch);
+        if (a.ss == 4 && a.taps.n == 21) {
+            static const int oh = getenv("KLT_PYR_OH") ? atoi(getenv("KLT_PYR_OH")) : 8;      // experiment hook
+            if (oh == 16) return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 16>(s, a, batch);
+            if (oh == 12) return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 12>(s, a, batch);
+            return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 8>(s, a, batch);
+        }
         if (a.ss == 2 && a.taps.n == 11) return launch_pyr_reduce_fast<2, 11, 512, float, 32, 8>(s, a, batch);
     }
     const size_t lds = pyr_reduce_lds_bytes(a.ss, a.taps.n);

@@ -15,8 +15,9 @@ static void gauss_taps(Taps &g, Taps &d, double sigma, int n)
     g.n = d.n = n; g.sym = 1; d.sym = -1;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool reduce = argc > 1 && argv[1][0] == 'r';
     const int nc = 1920, nr = 1080;
     SmoothGradArgs a = {};
     Taps dummy;
@@ -31,28 +32,35 @@ int main()
         hipMemcpy(raw, h.data(), h.size(), hipMemcpyHostToDevice);
         a.raw[b] = raw; a.img[b] = img; a.gx[b] = gx; a.gy[b] = gy;
     }
+    PyrReduceArgs pr = {};
+    gauss_taps(pr.taps, dummy, 3.6, 21);
+    pr.src_nc = nc; pr.src_nr = nr; pr.dst_nc = nc / 4; pr.dst_nr = nr / 4; pr.ss = 4; pr.log2ss = 2;
+    for (int b = 0; b < 2; b++) { pr.src[b] = a.img[b]; pr.dst[b] = a.gx[b]; }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int rep = 0; rep < 3; rep++) launch_smooth_grad(0, a, 2, 0);
+    auto go = [&]() { if (reduce) launch_pyr_reduce(0, pr, 2); else launch_smooth_grad(0, a, 2, 0); };
+    for (int rep = 0; rep < 3; rep++) go();
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int rep = 0; rep < 20; rep++) launch_smooth_grad(0, a, 2, 0);
+    for (int rep = 0; rep < 20; rep++) go();
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("kernel: %.2f us per launch\n", ms * 1000 / 20);
     long long clk[64 * 8];
     hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_stage_clk), sizeof(clk));
     long long t0 = clk[0];
-    for (int b = 0; b < 30; b++) t0 = clk[b * 8] < t0 ? clk[b * 8] : t0;
+    const int nrow = reduce ? 15 : 30;
+    for (int b = 0; b < nrow; b++) t0 = clk[b * 8] < t0 ? clk[b * 8] : t0;
     printf("ticks of 10 ns; tile row 8 of frame 0\nblock  start | load  hsm  vsm  hgrad vgrad | total\n");
-    for (int b = 0; b < 30; b++) {
+    for (int b = 0; b < nrow; b++) {
         const long long *c = clk + b * 8;
-        printf("%4d %6lld | %4lld %4lld %4lld %4lld %4lld | %5lld\n", b, c[0] - t0, c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4], c[5] - c[0]);
+        if (reduce) printf("%4d %6lld | load %4lld  hpass %4lld  vpass %4lld | %5lld\n", b, c[0] - t0, c[1] - c[0], c[2] - c[1], c[5] - c[2], c[5] - c[0]);
+        else printf("%4d %6lld | %4lld %4lld %4lld %4lld %4lld | %5lld\n", b, c[0] - t0, c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4], c[5] - c[0]);
     }
     static long long bc[8192 * 2];
     static unsigned hw[8192];
     hipMemcpyFromSymbol(bc, HIP_SYMBOL(g_block_clk), sizeof(bc));
     hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_block_hw), sizeof(hw));
-    const int nb = 30 * 34 * 2;
+    const int nb = reduce ? 15 * 34 * 2 : 30 * 34 * 2;
     long long b0 = bc[0], b1 = 0;
     for (int i = 0; i < nb; i++) { if (bc[2 * i] < b0) b0 = bc[2 * i]; if (bc[2 * i + 1] > b1) b1 = bc[2 * i + 1]; }
     printf("first start -> last end: %lld ticks\n", b1 - b0);
