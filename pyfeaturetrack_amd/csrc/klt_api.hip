@@ -834,6 +834,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_SMOOTH_GRAD_VARIANT) { g_smooth_grad_variant = value; return KLT_OK; }
     if (option == KLT_OPT_PYR_REDUCE_VARIANT) { g_pyr_reduce_variant = value; return KLT_OK; }
     if (option == KLT_OPT_SAT_VARIANT) { c->sat_variant = value; return KLT_OK; }
+    if (option == KLT_OPT_TRACK_VARIANT) { g_track_variant = value; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SPLIT_L0) { c->split_l0 = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_PARALLEL_NMS) { c->use_mis = value != 0; return KLT_OK; }

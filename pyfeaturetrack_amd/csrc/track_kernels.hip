@@ -17,6 +17,8 @@
 // except the ax*ay*I term which the reference evaluates in f32, products and sums un-fused, f32
 // position updates, the in-loop bounds test with the integer half-window and the post-loop one with
 // the Python-3 float half-window.
+#include <cstdlib>
+
 #include "klt_internal.h"
 
 #pragma clang fp contract(off)
@@ -155,7 +157,7 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
             const float *T = lds + lane * npad;
             if (WCT > 0) {
                 const float4 *T4 = reinterpret_cast<const float4 *>(T);
-#pragma unroll(WCT <= 8 ? 16 : 4)
+#pragma unroll WCT <= 8 ? 16 : 4
                 for (int q = 0; q < (WCT * WCT + 3) / 4; q++) {
                     const float4 v = T4[q];
                     acc = acc + v.x;
@@ -258,6 +260,260 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Prefetching variant for windows of at most 64 samples (one sample per lane), the default for them.
+//
+// A feature is a chain of dependent global-memory round trips: per level the template footprint, then one footprint per
+// Newton iteration (each position depends on the previous solve), then the footprint of the final position for the
+// residue.  At cfg-2 that is ~10 round trips of 1-2 us each, and the whole launch lasts as long as the slowest chains.
+// The arithmetic below is track_level's, statement for statement; only the *loads* move:
+//   * the image-1 footprint of level r-1 is requested when level r starts (the template position is known up front);
+//   * after every position update the image-2 footprint of the new position is requested at once -- it is what the next
+//     iteration samples, or, if the loop ends here, what the residue test samples (same position, same weights);
+//   * when the loop ends, the image-2 footprint of the first iteration of level r-1 (position * subsampling) is requested
+//     together with it.
+// Round trips per feature: (Newton iterations + 1) instead of (iterations + 2 * levels).  Loads are unconditional with
+// clamped addresses (a guarded load is a branch, and the wait-count model drains every outstanding load at the join); the
+// single wavefront of the workgroup orders its LDS traffic with s_waitcnt lgkmcnt(0) instead of __syncthreads(), which
+// would also wait for the prefetches.
+// One footprint = the (w+1) x (w+1) pixels under a window; lane (r, c) of a (w+1)-wide grid loads pixel (r, c) of each of the
+// three images ONCE (for 7x7 windows the grid is exactly the 64 lanes) and gets its right / lower / diagonal neighbours
+// from the lanes that loaded them (ds_bpermute), instead of every lane loading its own four pixels of every image: 3 vector
+// loads per footprint instead of 12.  Vector-memory issue (64 scattered addresses per instruction through the address
+// unit) is what the tracker spends its time on after the round trips.
+struct Px3 { float i, gx, gy; };
+
+__device__ __forceinline__ void load_px3(const float *__restrict__ pi, const float *__restrict__ pgx, const float *__restrict__ pgy,
+                                         unsigned q, Px3 &o)
+{
+    o.i = pi[q]; o.gx = pgx[q]; o.gy = pgy[q];
+}
+
+// sample() on the 2x2 neighbourhood {v, right, below, diagonal} (same expression, same order)
+__device__ __forceinline__ float sample_nb(float v, int G, const Bilinear &b)
+{
+    const float v01 = __shfl_down(v, 1), v10 = __shfl_down(v, G), v11 = __shfl_down(v, G + 1);
+    const float t4 = b.w11 * v11;
+    double d = b.w00 * (double)v;
+    d = d + b.w01 * (double)v01;
+    d = d + b.w10 * (double)v10;
+    d = d + (double)t4;
+    return (float)d;
+}
+
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Every decision below is wave-uniform (positions come out of wave shuffles); saying so keeps the branches scalar and the
+// level index and the positions in SGPRs -- otherwise the level descriptors are fetched with vector loads (and waiting for
+// those drains the prefetches) and every position costs vector registers (the kernel must stay under 96 VGPRs: 5 wavefronts
+// per SIMD keep all 5000 features of a cfg-2 pair resident at once).
+__device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+#ifndef KLT_TRACK_WAVES
+#define KLT_TRACK_WAVES 4
+#endif
+template <int WCT, bool BATCH>
+__global__ __launch_bounds__(64, KLT_TRACK_WAVES) void track_kernel_pf(TrackArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (f >= a.n) return;
+    const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
+    const klt_feat *fin = BATCH ? a.pairs[blockIdx.y].in : a.in;
+    klt_feat *fout = BATCH ? a.pairs[blockIdx.y].out : a.out;
+    const klt_feat ft = fin[f];
+    if (ft.val < 0) {                       // only live features are tracked, trackFeatures.py:253
+        if (lane == 0) fout[f] = ft;
+        return;
+    }
+    const int L = a.nlevels;
+    const int w = WCT > 0 ? WCT : a.window, n = w * w, hw = w / 2;
+    const int npad = (n + 3) & ~3;
+    const int G = w + 1;                                               // footprint grid (w+1) x (w+1), lane = r * G + c
+    const bool in_grid = lane < G * G;
+    const int kr = in_grid ? lane / G : 0, kc = in_grid ? lane % G : 0; // lanes beyond the grid shadow pixel (0, 0)
+    const bool mine = in_grid && kr < w && kc < w;                     // grid lanes with r, c < w own window sample (r, c)
+    const int ks = kr * w + kc;                                        // its row-major index (order of the reference's sums)
+    const float one_plus_eps = 1.001f;
+
+    auto tmpl_inside = [&](const TrackLevel &lv, float x, float y) {
+        const int ix = (int)x, iy = (int)y;
+        return uni(ix - hw >= 0 && iy - hw >= 0 && ix + hw + 2 <= lv.nc && iy + hw + 2 <= lv.nr);
+    };
+    auto inloop_oob = [&](const TrackLevel &lv, float x2, float y2) {        // trackFeaturesUtils.pyx:428-431
+        return uni((double)(x2 - (float)hw) < 0. || (float)lv.nc - (x2 + (float)hw) < one_plus_eps ||
+                   (double)(y2 - (float)hw) < 0. || (float)lv.nr - (y2 + (float)hw) < one_plus_eps);
+    };
+    // element offset of my sample's footprint for a window centred at (x, y); 0 (a valid address) when it must not be read
+    auto footprint = [&](const TrackLevel &lv, float x, float y, bool ok) -> unsigned {
+        return ok ? (unsigned)(((int)y - hw + kr) * lv.nc + ((int)x - hw + kc)) : 0u;
+    };
+
+    // trackFeatures.py:255-265
+    float xloc = ft.x, yloc = ft.y;
+    for (int r = 0; r < L; r++) { xloc = xloc * a.inv_ss; yloc = yloc * a.inv_ss; }
+    float xout = xloc, yout = yloc;
+    int val = KLT_TRACKED;
+    uint32_t aux = 0;
+
+    int r = L - 1;
+    xloc = unif(xloc * a.ss); yloc = unif(yloc * a.ss); xout = unif(xout * a.ss); yout = unif(yout * a.ss);
+    bool t_ok = tmpl_inside(levels[r], xloc, yloc);
+    bool have2 = !inloop_oob(levels[r], xout, yout);
+    Px3 rt, r2;
+    load_px3(levels[r].i1, levels[r].gx1, levels[r].gy1, footprint(levels[r], xloc, yloc, t_ok), rt);
+    load_px3(levels[r].i2, levels[r].gx2, levels[r].gy2, footprint(levels[r], xout, yout, have2), r2);
+
+    for (;;) {
+        r = __builtin_amdgcn_readfirstlane(r);
+        const TrackLevel &lv = levels[r];
+        const TrackLevel &ln = levels[r > 0 ? r - 1 : 0];
+        const int nc = lv.nc, nr = lv.nr;
+        const float xloc_n = unif(xloc * a.ss), yloc_n = unif(yloc * a.ss);     // template position at the next finer level
+        int it = 0, status = KLT_OOB;
+        float x2 = xout, y2 = yout;
+        bool pref = false, have2n = false, tn_ok = false;
+        Px3 rtn = rt, r2n = r2;
+        if (!t_ok) {
+            val = KLT_OOB;       // the reference asserts here (trackFeaturesUtils.pyx:35); see DESIGN.md
+        } else {
+            float t_i, t_gx, t_gy;
+            {
+                const Bilinear b1 = make_bilinear(xloc, yloc);
+                t_i = sample_nb(rt.i, G, b1); t_gx = sample_nb(rt.gx, G, b1); t_gy = sample_nb(rt.gy, G, b1);
+            }
+            for (;;) {
+                if (!have2) { status = KLT_OOB; break; }
+                {
+                    const Bilinear b2 = make_bilinear(x2, y2);
+                    const float diff = t_i - sample_nb(r2.i, G, b2);
+                    const float sx = t_gx + sample_nb(r2.gx, G, b2);
+                    const float sy = t_gy + sample_nb(r2.gy, G, b2);
+                    if (mine) {
+                        lds[ks] = sx * sx;
+                        lds[npad + ks] = sx * sy;
+                        lds[2 * npad + ks] = sy * sy;
+                        lds[3 * npad + ks] = diff * sx;
+                        lds[4 * npad + ks] = diff * sy;
+                    }
+                }
+                wave_lds_sync();
+                float acc = 0.f;
+                if (lane < 5) {
+                    const float *T = lds + lane * npad;
+                    if (WCT > 0) {
+                        // (quads are read in groups of four: the whole array in flight at once costs 52 VGPRs, and the
+                        // kernel has to fit 96)
+                        const float4 *T4 = reinterpret_cast<const float4 *>(T);
+                        constexpr int NQ = (WCT * WCT + 3) / 4;
+#pragma unroll
+                        for (int q0 = 0; q0 < NQ; q0 += 4) {
+                            float4 v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) v[u] = T4[q0 + u < NQ ? q0 + u : NQ - 1];
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const int q = q0 + u;
+                                if (q < NQ) {
+                                    acc = acc + v[u].x;
+                                    if (4 * q + 1 < WCT * WCT) acc = acc + v[u].y;
+                                    if (4 * q + 2 < WCT * WCT) acc = acc + v[u].z;
+                                    if (4 * q + 3 < WCT * WCT) acc = acc + v[u].w;
+                                }
+                            }
+                        }
+                    } else {
+                        for (int k = 0; k < n; k++) acc = acc + T[k];
+                    }
+                }
+                wave_lds_sync();
+                const float gxx = __shfl(acc, 0), gxy = __shfl(acc, 1), gyy = __shfl(acc, 2);
+                const float ex = __shfl(acc, 3) * a.step, ey = __shfl(acc, 4) * a.step;
+                const float p1 = gxx * gyy, p2 = gxy * gxy;
+                const float det = p1 - p2;
+                if (uni(det < a.small)) { status = KLT_SMALL_DET; break; }
+                const float n1 = gyy * ex, n2 = gxy * ey, n3 = gxx * ey, n4 = gxy * ex;
+                const float dx = (n1 - n2) / det;
+                const float dy = (n3 - n4) / det;
+                status = KLT_TRACKED;
+                x2 = unif(x2 + dx);
+                y2 = unif(y2 + dy);
+                it++;
+                const bool more = uni((fabsf(dx) >= a.th || fabsf(dy) >= a.th) && it < a.max_iterations);
+                // the footprint of the new position: the next iteration's, or the residue test's
+                have2 = !inloop_oob(lv, x2, y2);
+                load_px3(lv.i2, lv.gx2, lv.gy2, footprint(lv, x2, y2, have2), r2);
+                if (!more) {
+                    // ... and, the loop ending here, the template and the first footprint of the next finer level
+                    const float x2n = unif(x2 * a.ss), y2n = unif(y2 * a.ss);
+                    tn_ok = r > 0 && tmpl_inside(ln, xloc_n, yloc_n);
+                    have2n = r > 0 && !inloop_oob(ln, x2n, y2n);
+                    load_px3(ln.i1, ln.gx1, ln.gy1, footprint(ln, xloc_n, yloc_n, tn_ok), rtn);
+                    load_px3(ln.i2, ln.gx2, ln.gy2, footprint(ln, x2n, y2n, have2n), r2n);
+                    pref = true;
+                    break;
+                }
+            }
+            // trackFeatures.py:110 -- Python floats: half-window 3.5, eps 1.001 as doubles
+            const double x2d = (double)x2, y2d = (double)y2, hwd = a.half_window;
+            if (uni(x2d - hwd < 0.0 || (double)nc - (x2d + hwd) < 1.001 || y2d - hwd < 0.0 || (double)nr - (y2d + hwd) < 1.001))
+                status = KLT_OOB;
+            // residue, trackFeatures.py:118-125 (status TRACKED here implies the final position passed the in-loop
+            // bounds test, so r2 holds its footprint)
+            if (status == KLT_TRACKED && a.use_max_residue) {
+                {
+                    const Bilinear b2 = make_bilinear(x2, y2);
+                    const float ad = fabsf(t_i - sample_nb(r2.i, G, b2));
+                    if (mine) lds[ks] = ad;
+                }
+                wave_lds_sync();
+                float sres = 0.f;
+                if (lane == 0) sres = pairwise_sum<3>(lds, n);
+                wave_lds_sync();
+                sres = __shfl(sres, 0);
+                if (uni(sres / (float)n > a.max_residue)) status = KLT_LARGE_RESIDUE;
+            }
+            if (a.retain) val = KLT_TRACKED;                                   // :127-129
+            else if (status == KLT_SMALL_DET || status == KLT_OOB || status == KLT_LARGE_RESIDUE) val = status;
+            else if (it >= a.max_iterations) val = KLT_MAX_ITERATIONS;
+            else val = KLT_TRACKED;
+            xout = x2;
+            yout = y2;
+        }
+        aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);
+        val = __builtin_amdgcn_readfirstlane(val);
+        if (val == KLT_SMALL_DET || val == KLT_OOB) break;             // :284-285
+        if (r == 0) break;
+        // next finer level
+        r--;
+        xloc = xloc_n; yloc = yloc_n;
+        xout = unif(xout * a.ss); yout = unif(yout * a.ss);
+        if (pref) { t_ok = tn_ok; have2 = have2n; rt = rtn; r2 = r2n; }
+        else {      // (retainTrackers after a failed level: nothing was requested ahead)
+            t_ok = tmpl_inside(levels[r], xloc, yloc);
+            have2 = !inloop_oob(levels[r], xout, yout);
+            load_px3(levels[r].i1, levels[r].gx1, levels[r].gy1, footprint(levels[r], xloc, yloc, t_ok), rt);
+            load_px3(levels[r].i2, levels[r].gx2, levels[r].gy2, footprint(levels[r], xout, yout, have2), r2);
+        }
+    }
+    if (lane == 0) {
+        klt_feat o;
+        o.aux = (int32_t)aux;
+        const double xd = (double)xout, yd = (double)yout;
+        const bool oob = val == KLT_OOB ||
+                         xd < a.borderx || xd > (double)(a.ncols - 1) - a.borderx ||
+                         yd < a.bordery || yd > (double)(a.nrows - 1) - a.bordery;   // :288-308
+        if (oob) { o.x = -1.f; o.y = -1.f; o.val = KLT_OOB; }
+        else if (val == KLT_SMALL_DET || val == KLT_LARGE_RESIDUE || val == KLT_MAX_ITERATIONS) {
+            o.x = -1.f; o.y = -1.f; o.val = val;
+        } else { o.x = xout; o.y = yout; o.val = KLT_TRACKED; }
+        fout[f] = o;
+    }
+}
+
 // Iteration statistics from the per-feature aux words (only launched while statistics are being collected;
 // per-feature atomics on a handful of shared counters would serialise the whole tracker).
 __global__ __launch_bounds__(256) void track_stats_kernel(const klt_feat *__restrict__ in, const klt_feat *__restrict__ out,
@@ -291,12 +547,23 @@ void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, 
     hipLaunchKernelGGL(track_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, nlevels, stats);
 }
 
+// 0 (default): track_kernel for every window; 1: track_kernel_pf for windows of <= 64 samples (a third of the dependent
+// round trips and a quarter of the vector loads, bit-identical records -- and no faster: the tracker is bound by
+// instruction issue, ~1800 instructions per feature on 5 wavefronts per SIMD, not by latency; 20.5 vs 21.5 us at cfg-2,
+// 0.60 vs 0.64 ms for a cfg-4 shard).  KLT_TRACK_VARIANT in the environment sets the initial value.
+int g_track_variant = getenv("KLT_TRACK_VARIANT") ? atoi(getenv("KLT_TRACK_VARIANT")) : 0;
+
 template <bool BATCH>
 static int launch_track_t(hipStream_t s, const TrackArgs &a)
 {
     const int n = a.window * a.window;
     const size_t lds = 5 * (size_t)((n + 3) & ~3) * sizeof(float);
     const dim3 grid(a.n, BATCH ? a.npairs : 1), block(64);
+    if (g_track_variant == 1 && n <= 64) {
+        if (a.window == 7) hipLaunchKernelGGL((track_kernel_pf<7, BATCH>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((track_kernel_pf<0, BATCH>), grid, block, lds, s, a);
+        return 0;
+    }
     if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH>), grid, block, lds, s, a);
     else if (a.window == 15) hipLaunchKernelGGL((track_kernel<4, 15, BATCH>), grid, block, lds, s, a);
     else if (n <= 64) hipLaunchKernelGGL((track_kernel<1, 0, BATCH>), grid, block, lds, s, a);

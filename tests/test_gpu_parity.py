@@ -391,6 +391,34 @@ def test_track_retain(ctx, cfg1, img0, img1):
     assert_feats(out, cfg1["trk100_retain_x"], cfg1["trk100_retain_y"], cfg1["trk100_retain_val"], "track retainTrackers")
 
 
+@pytest.mark.parametrize("window,levels,ss,retain,mr", [(7, 2, 4, False, 10.0), (7, 2, 4, True, 10.0), (7, 3, 2, False, None),
+                                                        (5, 2, 4, False, 10.0), (3, 2, 2, False, 5.0)])
+def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, retain, mr):
+    """KLT_OPT_TRACK_VARIANT=1 (footprints requested ahead, one pixel per lane + lane shuffles): same records as the
+    oracle, and for the default context as the reference's goldens."""
+    tc = make_tc(levels=levels, ss=ss, window=window, max_residue=mr, retainTrackers=retain)
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(0, img0)
+    ctx.upload(1, img1)
+    ctx.build_pyramids(0)
+    ctx.build_pyramids(1)
+    fl, _ = ctx.select(0, 100)
+    try:
+        ctx.set_option(11, 1)
+        out, _ = ctx.track(0, 1, fl)
+    finally:
+        ctx.set_option(11, 0)
+    ref, _ = ctx.track(0, 1, fl)
+    assert np.array_equal(out, ref), "tracker variants disagree"
+    a0, a1 = np.asarray(img0, np.float32), np.asarray(img1, np.float32)
+    ofl = ko.select_good_features(p, a0, 100)
+    ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), ofl)
+    assert_feats(out, *oracle_feats(ofl), what="prefetching tracker, window %d" % window)
+    if (window, levels, ss, retain, mr) == (7, 2, 4, False, 10.0):
+        assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "prefetching tracker vs golden")
+
+
 def test_pingpong_and_lost_features_skipped(ctx, cfg1, img0, img1):
     ctx.configure(make_tc(max_residue=10.0))
     ctx.upload(0, img0)
