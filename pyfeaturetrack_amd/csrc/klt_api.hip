@@ -101,7 +101,7 @@ struct klt_ctx {
     bool use_topk = true;
     bool use_mis = true;                      // parallel minimum-distance passes instead of the sorted serial walk
     int mis_rounds_hint = 6;
-    int sat_variant = 0;                      // 0: barrier-coupled SAT kernels, 1: wavefront pipelines (sat_pipeline.hip)
+    int sat_variant = 1;                      // 1: step-synchronous wavefront pipelines (sat_pipeline.hip), 0: barrier-coupled SAT kernels
     unsigned *readback = nullptr;             // pinned scratch for small results
     float *score_override = nullptr;          // test hook (klt_set_score_override)
     size_t score_override_cap = 0;
@@ -1019,16 +1019,18 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     c->sel_nc = nc; c->sel_nr = nr; c->sel_nx = nx; c->sel_ny = ny; c->sel_npow2 = (int)npow2;
 
     // summed-area tables (goodFeaturesUtils.pyx:49-51)
-    if (c->sat_variant == 1) {
-        // wavefront pipelines; a timed-out wait raises placed_d[3], checked below with the other results
-        HIPCHK(c, hipMemsetAsync(c->placed_d + 3, 0, sizeof(int), c->stream));
+    {
+        // step-synchronous wavefront pipelines (sat_pipeline.hip) where whole aligned quads can be moved, else the
+        // barrier-coupled kernels of select_kernels.hip
+        const bool pipe = c->sat_variant == 1;
         { TimerScope t(c, F_SAT_ROWS, (double)N * (8 + 12));
-          if (const int e = launch_sat_rows_pipe(c->stream, gx, gy, c->sat, nc, nr, c->placed_d + 3)) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e)); }
+          const int e = pipe ? launch_sat_rows_pipe(c->stream, gx, gy, c->sat, nc, nr) : -1;
+          if (e > 0) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e));
+          if (e < 0) launch_sat_rows(c->stream, gx, gy, c->sat, nc, nr); }
         { TimerScope t(c, F_SAT_COLS, (double)N * 24);
-          if (const int e = launch_sat_cols_pipe(c->stream, c->sat, nc, nr, c->placed_d + 3)) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e)); }
-    } else {
-        { TimerScope t(c, F_SAT_ROWS, (double)N * (8 + 12)); launch_sat_rows(c->stream, gx, gy, c->sat, nc, nr); }
-        { TimerScope t(c, F_SAT_COLS, (double)N * 24); launch_sat_cols(c->stream, c->sat, nc, nr); }
+          const int e = pipe ? launch_sat_cols_pipe(c->stream, c->sat, nc, nr) : -1;
+          if (e > 0) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e));
+          if (e < 0) launch_sat_cols(c->stream, c->sat, nc, nr); }
     }
 
     int mindist = p.mindist < 0 ? 0 : p.mindist;          // selectGoodFeatures.py:241-243

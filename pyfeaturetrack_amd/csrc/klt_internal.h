@@ -123,9 +123,9 @@ int launch_smooth_only(hipStream_t s, const SmoothGradArgs &a, int batch, bool u
 
 void launch_sat_rows(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows);
 void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows);
-// wavefront-pipeline variants (sat_pipeline.hip); *error_flag is set if a wait inside a workgroup times out; return 0 or a hipError_t
-int  launch_sat_rows_pipe(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows, int *error_flag);
-int  launch_sat_cols_pipe(hipStream_t s, float *sat, int ncols, int nrows, int *error_flag);
+// step-synchronous wavefront pipelines (sat_pipeline.hip); return 0 or a hipError_t
+int  launch_sat_rows_pipe(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows);
+int  launch_sat_cols_pipe(hipStream_t s, float *sat, int ncols, int nrows);
 void launch_seed_fill(hipStream_t s, const klt_feat *fl, int nfeat, uint8_t *seedmap, int ncols, int nrows, int d);
 void launch_eigen(hipStream_t s, const SelectArgs &a);
 void launch_sort_desc(hipStream_t s, unsigned long long *keys, int npow2);

@@ -1,254 +1,254 @@
-// Summed-area tables as a wavefront pipeline (KLT_OPT_SAT_VARIANT = 1).
+// Summed-area tables as a step-synchronous wavefront pipeline (KLT_OPT_SAT_VARIANT = 1, the default).
 //
-// numpy's cumsum(1).cumsum(0) on f32 (goodFeaturesUtils.pyx:49-51) is one strictly sequential f32 chain per row and
-// then per column; the chains cannot be split, so the time of a pass is (chain length) x (time per element of the one
-// wavefront that runs a band of chains).  Here that wavefront does nothing but read products from LDS, add, and write
-// prefixes to LDS.  Loader wavefronts stream tiles from HBM into a ring of LDS slots, storer wavefronts drain a ring of
-// finished tiles; the three kinds of wavefront are coupled only by counters in LDS (no workgroup barrier, so nobody
-// waits for anybody's global memory traffic, and no register ring for the compiler to rotate).  Every wait is bounded:
-// if a counter does not move for 2^20 polls the workgroup gives up and raises a flag the host checks.
+// numpy's cumsum(1).cumsum(0) on f32 (goodFeaturesUtils.pyx:49-51) is one strictly sequential f32 chain per row and then
+// per column; a chain cannot be split without changing the rounding, so the time of a pass is
+//     (chain length) x (latency of one dependent v_add_f32, ~9 clocks on gfx950: tools/mb/valu_rate.hip)
+// = 7.2 us for a 1920-long row and 4 us for a 1080-long column if the wavefront that runs a band of chains does nothing
+// else.  Here it does nothing else: per step it scans one tile that already sits in LDS, in place.  Loader wavefronts
+// bring tiles from HBM into a ring of three LDS slots (and form the products gx*gx, gx*gy, gy*gy on the way, row pass),
+// storer wavefronts drain scanned tiles.  One s_barrier per step couples them -- and nothing else does:
+//   * a loader owns every NLW-th tile and has exactly one tile of loads in flight, requested NLW steps before it is
+//     needed, so its wait is for its own oldest loads only (no register ring for the compiler to rotate, the reason the
+//     barrier-coupled kernels in select_kernels.hip drain vmcnt every step);
+//   * the barrier is `s_waitcnt lgkmcnt(0); s_barrier`, not __syncthreads(): it orders LDS traffic and leaves global
+//     loads and stores in flight.
+// Tile t is written to slot t % 3 during step t, scanned during step t + 1, read back during step t + 2.
 #include "klt_internal.h"
 
 #pragma clang fp contract(off)
 
 #ifdef SAT_PIPE_DEBUG
-__device__ long long g_sat_dbg[8 * 256];      // block 0: per tile {wait loaded, wait stored, compute done} clocks
+__device__ long long g_sat_dbg[6 * 64 * 3];       // workgroup 0: per wavefront and step {step start, work done, barrier passed}
+#define SAT_MARK(w, s, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (s) >= 0 && (s) < 64) g_sat_dbg[((w) * 64 + (s)) * 3 + (i)] = wall_clock64(); } while (0)
+#else
+#define SAT_MARK(w, s, i) do { } while (0)
 #endif
 
 namespace {
 
-constexpr int P_NS = 8;            // input slots = loader wavefronts (each owns a slot)
-constexpr int P_NO = 4;            // output slots = storer wavefronts
-constexpr int P_T = 64 * (1 + P_NS + P_NO);
-constexpr int P_SPIN = 1 << 20;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void lds_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+constexpr int NLW = 3;                         // loader wavefronts
+constexpr int NSW = 2;                         // storer wavefronts
+constexpr int NSLOT = 3;
+constexpr int PIPE_THREADS = 64 * (1 + NLW + NSW);
 
-// wait until *p >= need (written by another wavefront of the workgroup); false: timed out
-__device__ __forceinline__ bool wait_ge(volatile int *p, int need, volatile int *err)
-{
-    int guard = 0;
-    while (*p < need) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++guard > P_SPIN || *err) { *err = 1; return false; }
-    }
-    asm volatile("" ::: "memory");
-    return true;
-}
+__device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ------------------------------------------------------------------ row pass (+ products)
-constexpr int R_ROWS = 16, R_LD = 68;
+// workgroup = band of RB rows, all three planes; tile = RB rows x RT columns; chain wavefront: lane = plane * RB + row
+constexpr int RB = 16, RT = 128, RLD = RT + 4;                 // row pitch 132 floats: lanes hit distinct quads of banks
+constexpr int RSLOT = 3 * RB * RLD;                            // floats per slot
 
-__global__ __launch_bounds__(P_T) void sat_rows_pipe(const float *__restrict__ gx, const float *__restrict__ gy, float *__restrict__ sat,
-                                                     int ncols, int nrows, int *__restrict__ error_flag)
+__global__ __launch_bounds__(PIPE_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) void sat_rows_pipe(const float *__restrict__ gx, const float *__restrict__ gy,
+                                                                float *__restrict__ sat, int ncols, int nrows)
 {
     extern __shared__ __attribute__((aligned(16))) float pipe_lds[];
-    typedef float Tile[R_ROWS * R_LD];
-    Tile *const in_gx = reinterpret_cast<Tile *>(pipe_lds);                       // [P_NS]
-    Tile *const in_gy = in_gx + P_NS;                                             // [P_NS]
-    Tile(*const outp)[3] = reinterpret_cast<Tile(*)[3]>(in_gy + P_NS);            // [P_NO][3]
-    __shared__ int loaded[P_NS], stored[P_NO], chain_pos, err;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * R_ROWS;
-    const int ntiles = (ncols + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * RB;
+    const int ntiles = (ncols + RT - 1) / RT;
+    const int nsteps = ntiles + 2;
     const size_t plane = (size_t)ncols * nrows;
-    if (tid < P_NS) loaded[tid] = 0;
-    if (tid < P_NO) stored[tid] = 0;
-    if (tid == 0) { chain_pos = 0; err = 0; }
-    __syncthreads();
 
-    if (wave == 0) {                                            // ---- the chains: lane = plane * 16 + row
-        __builtin_amdgcn_s_setprio(3);
-        const int pl = lane >> 4, r = lane & 15;
+    if (wave == 0) {                                            // ---- the chains
+        const int pl = lane / RB, r = lane % RB;                // lanes 48..63 idle
         float carry = 0.f;
-        for (int t = 0; t < ntiles; t++) {
-            const int slot = t % P_NS, oslot = t % P_NO;
-#ifdef SAT_PIPE_DEBUG
-            const long long c0 = wall_clock64();
-#endif
-            if (!wait_ge(&loaded[slot], t + 1, &err)) break;
-#ifdef SAT_PIPE_DEBUG
-            const long long c1 = wall_clock64();
-#endif
-            if (t >= P_NO && !wait_ge(&stored[oslot], t - P_NO + 1, &err)) break;
-#ifdef SAT_PIPE_DEBUG
-            const long long c2 = wall_clock64();
-#endif
-            if (lane < 48) {
-                const float4 *a4 = reinterpret_cast<const float4 *>(pl == 2 ? &in_gy[slot][r * R_LD] : &in_gx[slot][r * R_LD]);
-                const float4 *b4 = reinterpret_cast<const float4 *>(pl == 0 ? &in_gx[slot][r * R_LD] : &in_gy[slot][r * R_LD]);
-                float4 *o4 = reinterpret_cast<float4 *>(&outp[oslot][pl][r * R_LD]);
-                float4 p[16];
+        for (int s = 0; s < nsteps; s++) {
+            SAT_MARK(0, s, 0);
+            if (s >= 1 && s <= ntiles && lane < 3 * RB) {
+                float4 *row = reinterpret_cast<float4 *>(pipe_lds + ((s - 1) % NSLOT) * RSLOT + (pl * RB + r) * RLD);
+                // the whole tile row is requested from LDS up front (128 VGPRs); the 128 dependent adds then run back to
+                // back, the writes trailing them
+                float4 v[RT / 4];
 #pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    const float4 a = a4[c], b = b4[c];
-                    p[c].x = a.x * b.x; p[c].y = a.y * b.y; p[c].z = a.z * b.z; p[c].w = a.w * b.w;
-                }
+                for (int u = 0; u < RT / 4; u++) v[u] = row[u];
 #pragma unroll
-                for (int c = 0; c < 16; c++) {
+                for (int u = 0; u < RT / 4; u++) {
                     float4 o;
-                    carry = carry + p[c].x; o.x = carry;
-                    carry = carry + p[c].y; o.y = carry;
-                    carry = carry + p[c].z; o.z = carry;
-                    carry = carry + p[c].w; o.w = carry;
-                    o4[c] = o;
+                    carry = carry + v[u].x; o.x = carry;
+                    carry = carry + v[u].y; o.y = carry;
+                    carry = carry + v[u].z; o.z = carry;
+                    carry = carry + v[u].w; o.w = carry;
+                    row[u] = o;
                 }
             }
-            lds_done();
-            if (lane == 0) *(volatile int *)&chain_pos = t + 1;
-#ifdef SAT_PIPE_DEBUG
-            if (blockIdx.x == 0 && lane == 0 && t < 256) {
-                g_sat_dbg[8 * t] = c0; g_sat_dbg[8 * t + 1] = c1; g_sat_dbg[8 * t + 2] = c2; g_sat_dbg[8 * t + 3] = wall_clock64();
-            }
-#endif
+            SAT_MARK(0, s, 1);
+            step_barrier();
+            SAT_MARK(0, s, 2);
         }
-    } else if (wave <= P_NS) {                                  // ---- loaders: lane = column, slot = wavefront
-        const int slot = wave - 1;
-        for (int t = slot; t < ntiles; t += P_NS) {
-            if (t >= P_NS && !wait_ge(&chain_pos, t - P_NS + 1, &err)) break;
-            const int col = t * 64 + lane, colc = min(col, ncols - 1);
-            float vx[R_ROWS], vy[R_ROWS];
+    } else if (wave <= NLW) {                                   // ---- loaders: lane = (row parity, quad of the tile row)
+        const int j = wave - 1;
+        const int half = lane >> 5, q = lane & 31;
+        float4 vx[RB / 2], vy[RB / 2];
+        auto request = [&](int t) {
+            const int c = min(t * RT + 4 * q, ncols - 4);       // clamped, unconditional (ncols % 4 == 0)
 #pragma unroll
-            for (int r = 0; r < R_ROWS; r++) {                  // clamped, unconditional
-                const size_t o = (size_t)min(row0 + r, nrows - 1) * ncols + colc;
-                vx[r] = gx[o];
-                vy[r] = gy[o];
+            for (int rp = 0; rp < RB / 2; rp++) {
+                const size_t o = (size_t)min(row0 + 2 * rp + half, nrows - 1) * ncols + c;
+                vx[rp] = *reinterpret_cast<const float4 *>(gx + o);
+                vy[rp] = *reinterpret_cast<const float4 *>(gy + o);
             }
+        };
+        for (int s = -NLW; s < nsteps; s++) {                   // (steps -NLW .. -1: the first requests only; one request site)
+            SAT_MARK(wave, s, 0);
+            if (s >= 0 && s % NLW == j && s < ntiles) {
+                float *slot = pipe_lds + (s % NSLOT) * RSLOT;
 #pragma unroll
-            for (int r = 0; r < R_ROWS; r++) {
-                const bool ok = col < ncols && row0 + r < nrows;
-                in_gx[slot][r * R_LD + lane] = ok ? vx[r] : 0.f;
-                in_gy[slot][r * R_LD + lane] = ok ? vy[r] : 0.f;
+                for (int rp = 0; rp < RB / 2; rp++) {
+                    const float4 a = vx[rp], b = vy[rp];
+                    const int r = 2 * rp + half;
+                    float4 xx, xy, yy;
+                    xx.x = a.x * a.x; xx.y = a.y * a.y; xx.z = a.z * a.z; xx.w = a.w * a.w;       // goodFeaturesUtils.pyx:49
+                    xy.x = a.x * b.x; xy.y = a.y * b.y; xy.z = a.z * b.z; xy.w = a.w * b.w;       // :50
+                    yy.x = b.x * b.x; yy.y = b.y * b.y; yy.z = b.z * b.z; yy.w = b.w * b.w;       // :51
+                    *reinterpret_cast<float4 *>(slot + (0 * RB + r) * RLD + 4 * q) = xx;
+                    *reinterpret_cast<float4 *>(slot + (1 * RB + r) * RLD + 4 * q) = xy;
+                    *reinterpret_cast<float4 *>(slot + (2 * RB + r) * RLD + 4 * q) = yy;
+                }
             }
-            lds_done();
-            if (lane == 0) *(volatile int *)&loaded[slot] = t + 1;
+            if ((s + NLW) % NLW == j && s + NLW < ntiles) request(s + NLW);
+            SAT_MARK(wave, s, 1);
+            if (s >= 0) step_barrier();
+            SAT_MARK(wave, s, 2);
         }
-    } else {                                                    // ---- storers: lane = column, output slot = wavefront
-        const int oslot = wave - 1 - P_NS;
-        for (int t = oslot; t < ntiles; t += P_NO) {
-            if (!wait_ge(&chain_pos, t + 1, &err)) break;
-            float v[3][R_ROWS];
+    } else {                                                    // ---- storers
+        const int k = wave - 1 - NLW;
+        const int half = lane >> 5, q = lane & 31;
+        for (int s = 0; s < nsteps; s++) {
+            const int t = s - 2;
+            SAT_MARK(wave, s, 0);
+            if (t >= 0 && t % NSW == k) {
+                const float *slot = pipe_lds + (t % NSLOT) * RSLOT;
+                float4 v[3][RB / 2];
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
+                for (int pl = 0; pl < 3; pl++)
 #pragma unroll
-                for (int r = 0; r < R_ROWS; r++) v[pl][r] = outp[oslot][pl][r * R_LD + lane];
-            lds_done();
-            if (lane == 0) *(volatile int *)&stored[oslot] = t + 1;
-            const int col = t * 64 + lane;
-            if (col < ncols) {
+                    for (int rp = 0; rp < RB / 2; rp++)
+                        v[pl][rp] = *reinterpret_cast<const float4 *>(slot + (pl * RB + 2 * rp + half) * RLD + 4 * q);
+                const int col = t * RT + 4 * q;
+                if (col < ncols) {
 #pragma unroll
-                for (int r = 0; r < R_ROWS; r++) {
-                    const int row = row0 + r;
-                    if (row < nrows) {
-                        sat[(size_t)row * ncols + col] = v[0][r];
-                        sat[plane + (size_t)row * ncols + col] = v[1][r];
-                        sat[2 * plane + (size_t)row * ncols + col] = v[2][r];
+                    for (int rp = 0; rp < RB / 2; rp++) {
+                        const int row = row0 + 2 * rp + half;
+                        if (row < nrows) {
+#pragma unroll
+                            for (int pl = 0; pl < 3; pl++)
+                                *reinterpret_cast<float4 *>(sat + pl * plane + (size_t)row * ncols + col) = v[pl][rp];
+                        }
                     }
                 }
             }
+            SAT_MARK(wave, s, 1);
+            step_barrier();
+            SAT_MARK(wave, s, 2);
         }
     }
-    if (err && lane == 0) *error_flag = 1;
 }
 
 // ------------------------------------------------------------------ column pass (in place)
-constexpr int C_COLS = 32, C_ROWS = 64;
+// workgroup = strip of 64 columns of one plane; tile = CT rows x 64 columns; chain wavefront: lane = column
+constexpr int CT = 64, CSLOT = CT * 64;
 
-__global__ __launch_bounds__(P_T) void sat_cols_pipe(float *__restrict__ sat, int ncols, int nrows, int *__restrict__ error_flag)
+__global__ __launch_bounds__(PIPE_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) void sat_cols_pipe(float *__restrict__ sat, int ncols, int nrows)
 {
     extern __shared__ __attribute__((aligned(16))) float pipe_lds[];
-    typedef float CTile[C_ROWS * C_COLS];
-    CTile *const tin = reinterpret_cast<CTile *>(pipe_lds);                       // [P_NS]
-    CTile *const tout = tin + P_NS;                                               // [P_NO]
-    __shared__ int loaded[P_NS], stored[P_NO], chain_pos, err;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * C_COLS;
-    float *s = sat + (size_t)blockIdx.y * ncols * nrows;
-    const int ntiles = (nrows + C_ROWS - 1) / C_ROWS;
-    if (tid < P_NS) loaded[tid] = 0;
-    if (tid < P_NO) stored[tid] = 0;
-    if (tid == 0) { chain_pos = 0; err = 0; }
-    __syncthreads();
-    const int lc = lane & 31, lh = lane >> 5;                   // loaders / storers: column, row parity
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *s_ = sat + (size_t)blockIdx.y * ncols * nrows;
+    const int ntiles = (nrows + CT - 1) / CT;
+    const int nsteps = ntiles + 2;
 
-    if (wave == 0) {                                            // ---- the chains: lane = column (lanes 32..63 idle)
-        __builtin_amdgcn_s_setprio(3);
+    if (wave == 0) {
         float carry = 0.f;
-        for (int t = 0; t < ntiles; t++) {
-            const int slot = t % P_NS, oslot = t % P_NO;
-            if (!wait_ge(&loaded[slot], t + 1, &err)) break;
-            if (t >= P_NO && !wait_ge(&stored[oslot], t - P_NO + 1, &err)) break;
-            if (lane < C_COLS) {
-                float v[C_ROWS];
+        for (int s = 0; s < nsteps; s++) {
+            if (s >= 1 && s <= ntiles) {
+                float *tile = pipe_lds + ((s - 1) % NSLOT) * CSLOT + lane;
+                float v[CT];
 #pragma unroll
-                for (int r = 0; r < C_ROWS; r++) v[r] = tin[slot][r * C_COLS + lane];
+                for (int u = 0; u < CT; u++) v[u] = tile[u * 64];
 #pragma unroll
-                for (int r = 0; r < C_ROWS; r++) {
-                    carry = carry + v[r];
-                    tout[oslot][r * C_COLS + lane] = carry;
+                for (int u = 0; u < CT; u++) {
+                    carry = carry + v[u];
+                    tile[u * 64] = carry;
                 }
             }
-            lds_done();
-            if (lane == 0) *(volatile int *)&chain_pos = t + 1;
+            step_barrier();
         }
-    } else if (wave <= P_NS) {
-        const int slot = wave - 1;
-        const int col = min(x0 + lc, ncols - 1);
-        for (int t = slot; t < ntiles; t += P_NS) {
-            if (t >= P_NS && !wait_ge(&chain_pos, t - P_NS + 1, &err)) break;
-            float v[C_ROWS / 2];
+    } else if (wave <= NLW) {                                   // ---- loaders: lane = (row of a group of four, quad of the strip)
+        const int j = wave - 1;
+        const int rsub = lane >> 4, q = lane & 15;
+        const int c = min(blockIdx.x * 64 + 4 * q, ncols - 4);
+        f32x4 v[CT / 4];
+        for (int s = -NLW; s < nsteps; s++) {
+            if (s >= 0 && s % NLW == j && s < ntiles) {
+                float *tile = pipe_lds + (s % NSLOT) * CSLOT;
 #pragma unroll
-            for (int i = 0; i < C_ROWS / 2; i++) v[i] = s[(size_t)min(t * C_ROWS + 2 * i + lh, nrows - 1) * ncols + col];
+                for (int g = 0; g < CT / 4; g++) *reinterpret_cast<f32x4 *>(tile + (4 * g + rsub) * 64 + 4 * q) = v[g];
+            }
+            if ((s + NLW) % NLW == j && s + NLW < ntiles) {
+                const int t = s + NLW;
 #pragma unroll
-            for (int i = 0; i < C_ROWS / 2; i++) tin[slot][(2 * i + lh) * C_COLS + lc] = v[i];
-            lds_done();
-            if (lane == 0) *(volatile int *)&loaded[slot] = t + 1;
+                for (int g = 0; g < CT / 4; g++)
+                    v[g] = *reinterpret_cast<const f32x4 *>(s_ + (size_t)min(t * CT + 4 * g + rsub, nrows - 1) * ncols + c);
+            }
+            if (s >= 0) step_barrier();
         }
-    } else {
-        const int oslot = wave - 1 - P_NS;
-        for (int t = oslot; t < ntiles; t += P_NO) {
-            if (!wait_ge(&chain_pos, t + 1, &err)) break;
-            float v[C_ROWS / 2];
+    } else {                                                    // ---- storers
+        const int k = wave - 1 - NLW;
+        const int rsub = lane >> 4, q = lane & 15;
+        const int c = blockIdx.x * 64 + 4 * q;
+        for (int s = 0; s < nsteps; s++) {
+            const int t = s - 2;
+            if (t >= 0 && t % NSW == k) {
+                const float *tile = pipe_lds + (t % NSLOT) * CSLOT;
+                f32x4 v[CT / 4];
 #pragma unroll
-            for (int i = 0; i < C_ROWS / 2; i++) v[i] = tout[oslot][(2 * i + lh) * C_COLS + lc];
-            lds_done();
-            if (lane == 0) *(volatile int *)&stored[oslot] = t + 1;
-            if (x0 + lc < ncols) {
+                for (int g = 0; g < CT / 4; g++) v[g] = *reinterpret_cast<const f32x4 *>(tile + (4 * g + rsub) * 64 + 4 * q);
+                if (c < ncols) {
 #pragma unroll
-                for (int i = 0; i < C_ROWS / 2; i++) {
-                    const int row = t * C_ROWS + 2 * i + lh;
-                    if (row < nrows) s[(size_t)row * ncols + x0 + lc] = v[i];
+                    for (int g = 0; g < CT / 4; g++) {
+                        const int row = t * CT + 4 * g + rsub;
+                        if (row < nrows) *reinterpret_cast<f32x4 *>(s_ + (size_t)row * ncols + c) = v[g];
+                    }
                 }
             }
+            step_barrier();
         }
     }
-    if (err && lane == 0) *error_flag = 1;
 }
 
 }  // namespace
 
-int launch_sat_rows_pipe(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows, int *error_flag)
+// Both passes move whole aligned quads: they need ncols % 4 == 0 and 16-byte aligned planes; -1 = not applicable (the caller
+// falls back to the kernels in select_kernels.hip).
+static bool quads_ok(const void *a, const void *b, const void *c, int ncols, int nrows)
 {
-    constexpr size_t lds = sizeof(float) * R_ROWS * R_LD * (2 * P_NS + 3 * P_NO);
+    return ncols >= 4 && (ncols & 3) == 0 && ((((size_t)a | (size_t)b | (size_t)c) & 15) == 0) && (((size_t)ncols * nrows) & 3) == 0;
+}
+
+int launch_sat_rows_pipe(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows)
+{
+    if (!quads_ok(gx, gy, sat, ncols, nrows)) return -1;
+    constexpr size_t lds = sizeof(float) * NSLOT * RSLOT;
     static bool set = false;
     if (!set) {
         hipError_t e = hipFuncSetAttribute((const void *)sat_rows_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         set = true;
     }
-    hipLaunchKernelGGL(sat_rows_pipe, dim3((nrows + R_ROWS - 1) / R_ROWS), dim3(P_T), lds, s, gx, gy, sat, ncols, nrows, error_flag);
+    hipLaunchKernelGGL(sat_rows_pipe, dim3((nrows + RB - 1) / RB), dim3(PIPE_THREADS), lds, s, gx, gy, sat, ncols, nrows);
     return 0;
 }
 
-int launch_sat_cols_pipe(hipStream_t s, float *sat, int ncols, int nrows, int *error_flag)
+int launch_sat_cols_pipe(hipStream_t s, float *sat, int ncols, int nrows)
 {
-    constexpr size_t lds = sizeof(float) * C_ROWS * C_COLS * (P_NS + P_NO);
+    if (!quads_ok(sat, sat, sat, ncols, nrows)) return -1;
+    constexpr size_t lds = sizeof(float) * NSLOT * CSLOT;
     static bool set = false;
     if (!set) {
         hipError_t e = hipFuncSetAttribute((const void *)sat_cols_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         set = true;
     }
-    hipLaunchKernelGGL(sat_cols_pipe, dim3((ncols + C_COLS - 1) / C_COLS, 3), dim3(P_T), lds, s, sat, ncols, nrows, error_flag);
+    hipLaunchKernelGGL(sat_cols_pipe, dim3((ncols + 63) / 64, 3), dim3(PIPE_THREADS), lds, s, sat, ncols, nrows);
     return 0;
 }

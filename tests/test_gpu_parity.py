@@ -279,6 +279,28 @@ def test_select_cfg1(ctx, cfg1, img0, n):
     assert_feats(fl, cfg1["sel%d_x" % n], cfg1["sel%d_y" % n], cfg1["sel%d_val" % n], "select %d" % n)
 
 
+@pytest.mark.parametrize("shape", [(1080, 1920), (240, 320), (187, 251), (133, 260), (64, 68)])
+def test_sat_variants_agree_with_oracle(ctx, ko, shape):
+    """Summed-area tables: the step-synchronous wavefront pipelines (default; frames with ncols % 4 == 0) and the
+    barrier-coupled kernels (KLT_OPT_SAT_VARIANT = 0, also the fallback for other widths) give the oracle's eigenvalue map."""
+    from pyfeaturetrack_amd import synth
+    img = synth.synth_frame(shape[1], shape[0], 3, 0)
+    tc = make_tc(levels=2, ss=2) if min(shape) < 200 else make_tc()
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(0, img)
+    n = 50
+    ofl, oval = ko.select_good_features(p, img.astype(np.float32), n, want_val=True)
+    for variant in (1, 0):
+        try:
+            ctx.set_option(10, variant)
+            fl, placed = ctx.select(0, n)
+            assert_same(ctx.select_intermediate(3), oval, "eigenvalue map, SAT variant %d, %dx%d" % (variant, shape[1], shape[0]))
+            assert_feats(fl, *oracle_feats(ofl), what="selection, SAT variant %d" % variant)
+        finally:
+            ctx.set_option(10, 1)
+
+
 def test_select_skip_mindist_nosmooth(ctx, cfg1, img0):
     ctx.configure(make_tc(nSkippedPixels=2, mindist=15, smoothBeforeSelecting=False))
     ctx.upload(2, img0)
