@@ -353,8 +353,8 @@ __device__ __forceinline__ void widen12(const float *row, double *d)
     d[8] = (double)c.x; d[9] = (double)c.y; d[10] = (double)c.z; d[11] = (double)c.w;
 }
 
-template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_>
-__global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
+template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_, int NTHR = 256>
+__global__ __launch_bounds__(NTHR, 4) void smooth_grad_rb(SmoothGradArgs a)
 {
     constexpr int rs = SMOOTH ? NS / 2 : 0;
     constexpr int R = (NG > ND ? NG : ND) / 2;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
     {
         constexpr int W0 = SMOOTH ? AQ : BQ, H0 = SMOOTH ? RH : IH, X0 = SMOOTH ? -8 : -4, Y0 = -(R + rs);
         float *const dst = SMOOTH ? A : C;
-        constexpr int N0 = H0 * W0, U0 = (N0 + 255) / 256;
+        constexpr int N0 = H0 * W0, U0 = (N0 + NTHR - 1) / NTHR;
         // Tiles whose halo lies inside the frame (most of them): every load of the thread is issued before the first one
         // is used.  The general loop below waits for each of its 3-4 loads in turn -- 2.2 of the 9 us a workgroup lives.
         const bool interior = (nc & 3) == 0 && tx0 + X0 >= 0 && tx0 + X0 + 4 * W0 <= nc && ty0 + Y0 >= 0 && ty0 + Y0 + H0 <= nr;
@@ -391,12 +391,12 @@ __global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
                 uint32_t w[U0];
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
-                    const int i = min(tid + u * 256, N0 - 1);          // clamped, unconditional (the last threads repeat a quad)
+                    const int i = min(tid + u * NTHR, N0 - 1);          // clamped, unconditional (the last threads repeat a quad)
                     w[u] = *reinterpret_cast<const uint32_t *>(base + (size_t)(i / W0) * nc + 4 * (i % W0));
                 }
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
-                    const int i = tid + u * 256;
+                    const int i = tid + u * NTHR;
                     float4 v;
                     v.x = (float)(w[u] & 0xffu); v.y = (float)((w[u] >> 8) & 0xffu);
                     v.z = (float)((w[u] >> 16) & 0xffu); v.w = (float)(w[u] >> 24);
@@ -406,12 +406,12 @@ __global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
                 float4 w[U0];
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
-                    const int i = min(tid + u * 256, N0 - 1);
+                    const int i = min(tid + u * NTHR, N0 - 1);
                     w[u] = *reinterpret_cast<const float4 *>(base + (size_t)(i / W0) * nc + 4 * (i % W0));
                 }
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
-                    const int i = tid + u * 256;
+                    const int i = tid + u * NTHR;
                     if (i < N0) *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = w[u];
                 }
             }
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
             TIn e[U0][4];
 #pragma unroll
             for (int u = 0; u < U0; u++) {
-                const int i = min(tid + u * 256, N0 - 1);
+                const int i = min(tid + u * NTHR, N0 - 1);
                 const int y = ty0 + Y0 + i / W0, x = tx0 + X0 + 4 * (i % W0);
                 const TIn *row = raw + (size_t)(y < 0 ? -1 - y : y >= nr ? 2 * nr - 1 - y : y) * nc;
 #pragma unroll
@@ -432,13 +432,13 @@ __global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
             }
 #pragma unroll
             for (int u = 0; u < U0; u++) {
-                const int i = tid + u * 256;
+                const int i = tid + u * NTHR;
                 float4 v;
                 v.x = (float)e[u][0]; v.y = (float)e[u][1]; v.z = (float)e[u][2]; v.w = (float)e[u][3];
                 if (i < N0) *reinterpret_cast<float4 *>(dst + (size_t)i * 4) = v;
             }
         } else
-        for (int i = tid; i < H0 * W0; i += 256) {
+        for (int i = tid; i < H0 * W0; i += NTHR) {
             const int r = i / W0, q = i % W0;
             const int gy = reflect_fast(ty0 + Y0 + r, nr);
             const int x = tx0 + X0 + 4 * q;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
         TapRegs<NS> ks;
         load_taps(ks, a.smooth);
         // ---- stage 1: horizontal smoothing, A -> B (B column c = A column c + 4)
-        for (int i = tid; i < RH * BQ; i += 256) {
+        for (int i = tid; i < RH * BQ; i += NTHR) {
             const int r = i / BQ, q = i % BQ;
             double v[12];
             widen12(A + r * AW + 4 * q, v);
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
         // A thread produces a quad on two consecutive rows: NS+1 rows are read and widened for 8 outputs.
         float *__restrict__ img = a.img[b];
         static_assert(IH % 2 == 0, "tile height must be even");
-        for (int i = tid; i < (IH / 2) * BQ; i += 256) {
+        for (int i = tid; i < (IH / 2) * BQ; i += NTHR) {
             const int r = 2 * (i / BQ), q = i % BQ;
             double v[4][NS + 1];
 #pragma unroll
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
     // ---- stage 3: horizontal pass of both gradients, C -> D (derivative taps), E (Gaussian taps)
     // (the partial last round of this loop goes to wavefronts 2 and 3: stage 2 gave its partial round to wavefronts 0
     // and 1, and wavefront w of every workgroup of a CU sits on SIMD w -- the rotation evens out the SIMDs)
-    for (int i = (tid + 128) & 255; i < IH * DQ; i += 256) {
+    for (int i = (tid + NTHR / 2) & (NTHR - 1); i < IH * DQ; i += NTHR) {
         const int r = i / DQ, q = i % DQ;
         double v[12];
         widen12(C + r * BW + 4 * q, v);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 4) void smooth_grad_rb(SmoothGradArgs a)
     float *__restrict__ gxo = a.gx[b];
     float *__restrict__ gyo = a.gy[b];
     static_assert(TH_ % 2 == 0, "tile height must be even");
-    for (int i = tid; i < (TH_ / 2) * DQ; i += 256) {
+    for (int i = tid; i < (TH_ / 2) * DQ; i += NTHR) {
         const int r = 2 * (i / DQ), q = i % DQ;
         const int x = tx0 + 4 * q;
         if (ty0 + r >= nr || x >= nc) continue;

@@ -52,7 +52,7 @@ def main():
     write = read(sys.argv[2], "WRITE_SIZE")
     out = {"_unit": "bytes per launch (largest launch of the family)", "_formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
     if "sat_cols" in fetch and "sat_cols" in write:
-        out["_calibration"] = {"kernel": "sat_cols_kernel (reads == writes == 3*ncols*nrows*4 bytes, dword per lane)",
+        out["_calibration"] = {"kernel": "SAT column pass (reads == writes == 3*ncols*nrows*4 bytes)",
                                "WRITE_SIZE_KiB": max(write["sat_cols"]), "FETCH_SIZE_KiB": max(fetch["sat_cols"]),
                                "fetch_over_known_read": max(fetch["sat_cols"]) / max(write["sat_cols"])}
     for fam in sorted(set(fetch) | set(write)):
