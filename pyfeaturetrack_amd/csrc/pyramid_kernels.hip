@@ -353,8 +353,11 @@ __device__ __forceinline__ void widen12(const float *row, double *d)
     d[8] = (double)c.x; d[9] = (double)c.y; d[10] = (double)c.z; d[11] = (double)c.w;
 }
 
+#ifndef KLT_L0_WAVES
+#define KLT_L0_WAVES 4
+#endif
 template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_, int NTHR = 256>
-__global__ __launch_bounds__(NTHR, 4) void smooth_grad_rb(SmoothGradArgs a)
+__global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradArgs a)
 {
     constexpr int rs = SMOOTH ? NS / 2 : 0;
     constexpr int R = (NG > ND ? NG : ND) / 2;
@@ -942,9 +945,10 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
             const bool tall = force_th ? force_th == 32 : (long long)a.ncols * a.nrows * batch >= 1000000;
             const int th = tall ? 32 : 16;
             const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + th - 1) / th, batch);
+            static const size_t pad_lds = getenv("KLT_RB_PAD_LDS") ? (size_t)atoi(getenv("KLT_RB_PAD_LDS")) : 0;   // occupancy experiment
 #define KLT_RB(T, SM, NSV)                                                                                        \
     do {                                                                                                          \
-        if (tall) hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 32>), g, blk, 0, s, a);                   \
+        if (tall) hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 32>), g, blk, pad_lds, s, a);             \
         else hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 16>), g, blk, 0, s, a);                        \
         return 0;                                                                                                 \
     } while (0)

@@ -23,6 +23,21 @@
 
 #pragma clang fp contract(off)
 
+// tools/track_clocks.py builds this file with KLT_TRACK_CLOCKS into a private copy of the library: lane 0 of the first 256
+// features of a launch records wall-clock ticks at the marks below (every mark first waits for all outstanding memory
+// operations, so the build is for reading the time line, not for timing the kernel).
+#ifdef KLT_TRACK_CLOCKS
+__device__ long long g_tclk[256 * 32];
+#define TCLK(i)                                                                                               \
+    do {                                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+        if (threadIdx.x == 0 && blockIdx.x < 256 && (i) < 32) g_tclk[blockIdx.x * 32 + (i)] = wall_clock64();   \
+    } while (0)
+extern "C" int klt_debug_track_clocks(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tclk), sizeof(g_tclk)); }
+#else
+#define TCLK(i) do { } while (0)
+#endif
+
 namespace {
 
 struct Bilinear {
@@ -56,36 +71,43 @@ __device__ __forceinline__ float sample(const float *__restrict__ q, int nc, con
     return (float)v;
 }
 
-// numpy's pairwise summation for one block of n <= 128 floats (and the n < 8 loop)
-__device__ float pairwise_block(const float *a, int n)
+// numpy's pairwise summation of n floats in LDS (trackFeatures.py:124), computed by the whole wavefront; the result is valid in
+// lane 0.  For a block of 8 <= n <= 128 numpy keeps eight running sums r[j] = a[j] + a[8 + j] + a[16 + j] + ... (each a
+// sequential chain, independent of the others), folds them as ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) and then adds
+// the n % 8 tail one by one.  Lanes 0..7 run the eight chains side by side and three shuffles do the fold: the same
+// additions in the same order as the 1-lane loop, in 5 + 3 + tail steps instead of n.
+__device__ __forceinline__ float pairwise_block_wave(const float *a, int n, int lane)
 {
     if (n < 8) {
         float res = 0.f;
         for (int i = 0; i < n; i++) res = res + a[i];
         return res;
     }
-    float r[8];
-    for (int j = 0; j < 8; j++) r[j] = a[j];
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8)
-        for (int j = 0; j < 8; j++) r[j] = r[j] + a[i + j];
-    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res = res + a[i];
+    const int nn = n - (n % 8);
+    float r = 0.f;
+    if (lane < 8) {
+        r = a[lane];
+        for (int i = 8; i < nn; i += 8) r = r + a[i + lane];
+    }
+    r = r + __shfl_down(r, 1);          // lanes 0, 2, 4, 6: r0 + r1, r2 + r3, r4 + r5, r6 + r7
+    r = r + __shfl_down(r, 2);          // lanes 0, 4
+    float res = r + __shfl_down(r, 4);  // lane 0
+    for (int i = nn; i < n; i++) res = res + a[i];
     return res;
 }
 
 template <int DEPTH>
-__device__ float pairwise_sum(const float *a, int n)
+__device__ float pairwise_sum(const float *a, int n, int lane)
 {
-    if (n <= 128) return pairwise_block(a, n);
+    if (n <= 128) return pairwise_block_wave(a, n, lane);
     int n2 = n / 2;
     n2 -= n2 % 8;
-    return pairwise_sum<DEPTH - 1>(a, n2) + pairwise_sum<DEPTH - 1>(a + n2, n - n2);
+    return pairwise_sum<DEPTH - 1>(a, n2, lane) + pairwise_sum<DEPTH - 1>(a + n2, n - n2, lane);
 }
 template <>
-__device__ float pairwise_sum<0>(const float *a, int n)
+__device__ float pairwise_sum<0>(const float *a, int n, int lane)
 {
-    return pairwise_block(a, n < 128 ? n : 128);
+    return pairwise_block_wave(a, n < 128 ? n : 128, lane);
 }
 
 // _trackFeature for one level.  Returns the status; x2/y2 updated in place; `iters` = Newton iterations.
@@ -93,7 +115,7 @@ __device__ float pairwise_sum<0>(const float *a, int n)
 // 16 bytes at a time); WCT == 0: any odd window up to 31.
 template <int MAXK, int WCT>
 __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, float y1, float &x2r, float &y2r,
-                           float *lds, int lane, int &iters)
+                           float *lds, int lane, int &iters, int clk0 = 0)
 {
     const int w = WCT > 0 ? WCT : a.window, n = w * w, hw = w / 2;
     const int npad = (n + 3) & ~3;                       // 16-byte aligned sub-arrays
@@ -121,6 +143,7 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
         }
     }
 
+    TCLK(clk0);                                          // template sampled
     float x2 = x2r, y2 = y2r;
     int status;
     const float one_plus_eps = 1.001f;
@@ -151,6 +174,7 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
             }
         }
         __syncthreads();
+        if (iters < 3) TCLK(clk0 + 1 + 2 * iters);       // image 2 sampled, products in LDS
         // lanes 0..4 each add one array in the reference's row-major order (sequential f32 adds)
         float acc = 0.f;
         if (lane < 5) {
@@ -182,11 +206,13 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
         status = KLT_TRACKED;
         x2 = x2 + dx;
         y2 = y2 + dy;
+        if (iters < 3) TCLK(clk0 + 2 + 2 * iters);       // sums, solve, update
         iters++;
         if (!((fabsf(dx) >= a.th || fabsf(dy) >= a.th) && iters < a.max_iterations)) break;
     }
     x2r = x2;
     y2r = y2;
+    TCLK(clk0 + 7);                                      // Newton loop left
 
     // trackFeatures.py:110 -- Python floats: half-window 3.5, eps 1.001 as doubles
     const double x2d = (double)x2, y2d = (double)y2, hwd = a.half_window;
@@ -203,12 +229,12 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
             if (k < n) l_diff[k] = fabsf(t_i[kk] - sample(lv.i2 + base + off[kk], nc, b2));
         }
         __syncthreads();
-        float s = 0.f;
-        if (lane == 0) s = pairwise_sum<3>(l_diff, n);
+        float s = pairwise_sum<3>(l_diff, n, lane);
         __syncthreads();
         s = __shfl(s, 0);
         if (s / (float)n > a.max_residue) status = KLT_LARGE_RESIDUE;
     }
+    TCLK(clk0 + 8);                                      // residue test done
 
     if (a.retain) return KLT_TRACKED;                                   // :127-129
     if (status == KLT_SMALL_DET || status == KLT_OOB || status == KLT_LARGE_RESIDUE) return status;
@@ -232,6 +258,7 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
         return;
     }
     const int L = a.nlevels;
+    TCLK(0);
     // trackFeatures.py:255-265: position at the coarsest resolution (divisions by a power of two: exact)
     float xloc = ft.x, yloc = ft.y;
     for (int r = 0; r < L; r++) { xloc = xloc * a.inv_ss; yloc = yloc * a.inv_ss; }   // power of two: exact
@@ -241,7 +268,7 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     for (int r = L - 1; r >= 0; r--) {
         xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss;
         int it = 0;
-        val = track_level<MAXK, WCT>(a, levels[r], xloc, yloc, xout, yout, lds, lane, it);
+        val = track_level<MAXK, WCT>(a, levels[r], xloc, yloc, xout, yout, lds, lane, it, 1 + 9 * (L - 1 - r));
         aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);      // visited level r with `it` Newton iterations
         if (val == KLT_SMALL_DET || val == KLT_OOB) break;             // :284-285
     }
@@ -470,8 +497,7 @@ __global__ __launch_bounds__(64, KLT_TRACK_WAVES) void track_kernel_pf(TrackArgs
                     if (mine) lds[ks] = ad;
                 }
                 wave_lds_sync();
-                float sres = 0.f;
-                if (lane == 0) sres = pairwise_sum<3>(lds, n);
+                float sres = pairwise_sum<3>(lds, n, lane);
                 wave_lds_sync();
                 sres = __shfl(sres, 0);
                 if (uni(sres / (float)n > a.max_residue)) status = KLT_LARGE_RESIDUE;
