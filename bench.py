@@ -502,9 +502,21 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom["name"])
+        # the same kernel against the roof that actually bounds it: VALU issue.  Wavefront-instructions per launch come from a
+        # rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/sq_counters.json, tools/pmc_sq.py); 4.5 clocks per instruction and SIMD
+        # is what the FP64-rate instruction mix of the convolutions sustains on gfx950 (tools/mb/valu_rate.hip, fp64_mix.hip).
+        issue = None
+        spath = os.path.join(ROOT, "profiles", "sq_counters.json")
+        if os.path.exists(spath):
+            sq = json.load(open(spath)).get(dom["name"])
+            if sq and sq.get("SQ_INSTS_VALU"):
+                simds, cpi, mhz = 256 * 4, 4.5, 2400.0
+                ideal_us = sq["SQ_INSTS_VALU"] / simds * cpi / mhz
+                issue = {"valu_wavefront_instructions_per_launch": sq["SQ_INSTS_VALU"], "simds": simds, "clocks_per_instruction": cpi,
+                         "clock_mhz": mhz, "ideal_us": ideal_us, "frac": ideal_us / (per_launch_ms * 1e3)}
         dev_ms = sum(k["total_ms"] for k in kernels) / args.steps
         roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "issue_bound": issue,
                     "launch_us": per_launch_ms * 1e3, "launches_per_step": dom["launches"] / args.steps,
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "step_algorithmic_bytes": 2 * pyr_bytes + track_bytes,

@@ -9,4 +9,5 @@ cp "$(find $O/prof_$TAG -name '*kernel_stats.csv' | head -1)" $P/r01_${TAG}_kern
 cp "$(find $O/prof_${TAG}_select -name '*kernel_stats.csv' | head -1)" $P/r01_${TAG}_select_kernel_stats.csv
 cp $O/traffic_$TAG.json $P/r01_${TAG}_pmc_traffic.json
 cp $O/traffic_$TAG.json $P/traffic.json
+if [ -f $O/sq_counters_$TAG.json ]; then cp $O/sq_counters_$TAG.json $P/r01_${TAG}_sq_counters.json; cp $O/sq_counters_$TAG.json $P/sq_counters.json; fi
 ls -la $P | grep $TAG

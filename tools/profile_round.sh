@@ -16,5 +16,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_select -o
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${TAG}_fetch -o run -- python3 bench.py --inflight 1 --steps 20 --warmup 2 --no-cpu-baseline > $O/pmc_${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${TAG}_write -o run -- python3 bench.py --inflight 1 --steps 20 --warmup 2 --no-cpu-baseline > $O/pmc_${TAG}_write.log 2>&1
 python3 tools/pmc_traffic.py $O/pmc_${TAG}_fetch $O/pmc_${TAG}_write $O/traffic_$TAG.json > /dev/null 2>> $O/bench_$TAG.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/pmc_${TAG}_sq1 -o run -- python3 bench.py --inflight 1 --steps 20 --warmup 2 --no-cpu-baseline > $O/pmc_${TAG}_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_${TAG}_sq2 -o run -- python3 bench.py --inflight 1 --steps 20 --warmup 2 --no-cpu-baseline > $O/pmc_${TAG}_sq2.log 2>&1
+python3 tools/pmc_sq.py $O/sq_counters_$TAG.json $O/pmc_${TAG}_sq1 $O/pmc_${TAG}_sq2 > /dev/null 2>> $O/bench_$TAG.err
 find $O/prof_$TAG $O/prof_${TAG}_select -name "*kernel_stats.csv" | head
 tail -c 600 $O/bench_$TAG.json
