@@ -3,6 +3,7 @@
 // conv_kernels.hip / select_kernels.hip / track_kernels.hip.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -82,6 +83,9 @@ struct klt_ctx {
     std::vector<FeatBuf> fbs;
     float *tmpA = nullptr, *tmpB = nullptr;
     size_t tmp_cap = 0;
+    float *h1 = nullptr;                      // H1 planes of the fused first reduction (one per frame of a batch)
+    size_t h1_cap = 0;
+    bool fuse_hreduce = true;                 // KLT_OPT_FUSED_HREDUCE
     // selection scratch
     float *sel_img = nullptr, *sel_gx = nullptr, *sel_gy = nullptr, *sat = nullptr, *valmap = nullptr;
     size_t sel_cap = 0;               // pixels
@@ -216,6 +220,15 @@ int ensure_tmp(klt_ctx *c, size_t pixels)
     HIPCHK(c, hipMalloc((void **)&c->tmpA, pixels * sizeof(float)));
     HIPCHK(c, hipMalloc((void **)&c->tmpB, pixels * sizeof(float)));
     c->tmp_cap = pixels;
+    return 0;
+}
+
+int ensure_h1(klt_ctx *c, size_t floats)
+{
+    if (floats <= c->h1_cap && c->h1) return 0;
+    if (c->h1) { if (int rc = sync_all(c)) return rc; hipFree(c->h1); c->h1 = nullptr; c->h1_cap = 0; }
+    HIPCHK(c, hipMalloc((void **)&c->h1, floats * sizeof(float)));
+    c->h1_cap = floats;
     return 0;
 }
 
@@ -448,17 +461,32 @@ bool fused_grad_ok(const klt_ctx *c) { return c->use_fused && smooth_grad_lds_by
 bool fused_reduce_ok(const klt_ctx *c) { return c->use_fused && pyr_reduce_lds_bytes(c->p.subsampling, c->gauss[1].n) <= kMaxLds; }
 
 // smooth(raw frame) + gradients for up to KLT_MAX_BATCH same-sized frames in one launch
+// *fused_h1 (optional, in/out): in = the caller wants the horizontal pass of the first reduction fused into this launch; out =
+// whether it was (then c->h1 holds one H1 plane of nr x (nc / ss) floats per frame)
 int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int raw_kind, float *const *img,
-                              float *const *gx, float *const *gy, int nc, int nr)
+                              float *const *gx, float *const *gy, int nc, int nr, bool *fused_h1 = nullptr)
 {
     SmoothGradArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int b = 0; b < batch; b++) { a.raw[b] = raw[b]; a.img[b] = img[b]; a.gx[b] = gx[b]; a.gy[b] = gy[b]; }
     a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
     a.ncols = nc; a.nrows = nr; a.R = grad_radius(c);
+    const int kind = raw_kind == 1 ? 0 : 1;
+    bool hred = fused_h1 && *fused_h1 && c->fuse_hreduce && smooth_grad_hred_ok(a, batch, kind, c->gauss[1], c->p.subsampling);
+    if (hred) {
+        const size_t plane = (size_t)nr * (nc / c->p.subsampling);
+        if (int rc = ensure_h1(c, plane * batch)) return rc;
+        a.reduce = c->gauss[1];
+        a.h1_nc = nc / c->p.subsampling;
+        for (int b = 0; b < batch; b++) a.h1[b] = c->h1 + plane * b;
+    }
+    if (fused_h1) *fused_h1 = hred;
     const double N = (double)nc * nr * batch;
-    TimerScope t(c, F_SMOOTH_GRAD, N * ((raw_kind == 1 ? 1 : 4) + 4) + N * 12);
-    if (int e = launch_smooth_grad(c->work, a, batch, raw_kind == 1 ? 0 : 1))
+    // algorithmic bytes: smoothing b_in + 4, gradients 12 per pixel; with the fused horizontal reduction this
+    // launch also consumes the reduction stage's input (4 per pixel of level 0 -- the part of 4 (N0 + N1) that no longer
+    // touches HBM); pyr_vreduce is charged the stage's output, so the step total is unchanged
+    TimerScope t(c, F_SMOOTH_GRAD, N * ((raw_kind == 1 ? 1 : 4) + 4) + N * 12 + (hred ? 4.0 * N : 0.0));
+    if (int e = launch_smooth_grad(c->work, a, batch, kind, hred))
         return fail(c, KLT_ERR_DEVICE, std::string("smooth_grad launch: ") + hipGetErrorString((hipError_t)e));
     return 0;
 }
@@ -519,6 +547,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         const bool split = c->split_l0 && fused_smooth_ok(c) && fused_grad_ok(c) && merged_grad_ok(c) && s0->nlev > 1 &&
                            (c->gauss[0].n == 5 || c->gauss[0].n == 9);
         hipEvent_t ev_join = nullptr;
+        bool h1_fused = false;              // level 1 comes from the H1 planes written by the level-0 kernel
         if (split) {
             // KLT_OPT_SPLIT_L0: smooth alone, then the (VALU-bound) level-0 gradients on the main stream overlap the
             // (latency-bound) reductions and small-level gradients on the side stream; both only need the level-0 image
@@ -547,7 +576,8 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                 raw[b] = g[b]->raw_kind == 1 ? (const void *)g[b]->u8 : (const void *)g[b]->f32;
                 img[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy;
             }
-            if (int rc = enqueue_fused_smooth_grad(c, B, raw, s0->raw_kind, img, gx, gy, s0->nc, s0->nr)) return rc;
+            h1_fused = s0->nlev > 1 && fused_reduce_ok(c);
+            if (int rc = enqueue_fused_smooth_grad(c, B, raw, s0->raw_kind, img, gx, gy, s0->nc, s0->nr, &h1_fused)) return rc;
         } else {
             for (int b = 0; b < B; b++) {
                 enqueue_smooth_raw(c, g[b], g[b]->lv[0].img);
@@ -567,9 +597,18 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                 a.src_nc = ls.nc; a.src_nr = ls.nr; a.dst_nc = ld.nc; a.dst_nr = ld.nr; a.ss = ss;
                 a.log2ss = 0;
                 while ((1 << a.log2ss) < ss) a.log2ss++;
-                TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ls.nc * ls.nr + (double)ld.nc * ld.nr));
-                if (int e = launch_pyr_reduce(c->work, a, B))
-                    return fail(c, KLT_ERR_DEVICE, std::string("pyr_reduce launch: ") + hipGetErrorString((hipError_t)e));
+                if (l == 1 && h1_fused) {
+                    // vertical pass only: H1 (level-0 rows x level-1 columns) -> level 1
+                    const size_t plane = (size_t)ls.nr * ld.nc;
+                    for (int b = 0; b < B; b++) a.src[b] = c->h1 + plane * b;
+                    TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ld.nc * ld.nr));
+                    if (int e = launch_pyr_vreduce(c->work, a, B))
+                        return fail(c, KLT_ERR_DEVICE, std::string("pyr_vreduce launch: ") + hipGetErrorString((hipError_t)e));
+                } else {
+                    TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ls.nc * ls.nr + (double)ld.nc * ld.nr));
+                    if (int e = launch_pyr_reduce(c->work, a, B))
+                        return fail(c, KLT_ERR_DEVICE, std::string("pyr_reduce launch: ") + hipGetErrorString((hipError_t)e));
+                }
             } else {
                 for (int b = 0; b < B; b++) {
                     {
@@ -669,6 +708,7 @@ int klt_create(int device, klt_ctx **out)
     }
     c->tstream = c->stream;
     c->work = c->stream;
+    if (const char *v = getenv("KLT_FUSED_HREDUCE")) c->fuse_hreduce = atoi(v) != 0;      // experiment hook (initial value of the option)
     *out = c;
     return KLT_OK;
 }
@@ -686,7 +726,7 @@ void klt_destroy(klt_ctx *c)
     for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes); }
     for (FeatBuf &b : c->fbs)
         if (!b.view) hipFree(b.d);
-    hipFree(c->tmpA); hipFree(c->tmpB);
+    hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
     hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
@@ -835,6 +875,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_PYR_REDUCE_VARIANT) { g_pyr_reduce_variant = value; return KLT_OK; }
     if (option == KLT_OPT_SAT_VARIANT) { c->sat_variant = value; return KLT_OK; }
     if (option == KLT_OPT_TRACK_VARIANT) { g_track_variant = value; return KLT_OK; }
+    if (option == KLT_OPT_FUSED_HREDUCE) { c->fuse_hreduce = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SPLIT_L0) { c->split_l0 = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_PARALLEL_NMS) { c->use_mis = value != 0; return KLT_OK; }

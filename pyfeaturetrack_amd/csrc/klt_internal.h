@@ -22,6 +22,10 @@ struct SmoothGradArgs {
     Taps smooth, ggauss, gderiv;
     int ncols, nrows, R;              // R = max gradient tap radius; ncols/nrows = largest entry (grid extent)
     short dim_c[KLT_MAX_BATCH], dim_r[KLT_MAX_BATCH];   // per-entry geometry when entries differ (0 = use ncols/nrows)
+    // fused horizontal pass of the first pyramid reduction (smooth_grad_rb<..., HRED>): taps, H1 planes [nrows][h1_nc]
+    Taps reduce;
+    float *h1[KLT_MAX_BATCH];
+    int h1_nc;
 };
 
 struct PyrReduceArgs {
@@ -117,7 +121,9 @@ extern int g_pyr_reduce_variant;    // test hook: 0 1024-thread reduce (default)
 size_t smooth_grad_lds_bytes(int smooth_radius /* -1: no smoothing stage */, int R);
 size_t pyr_reduce_lds_bytes(int ss, int ntaps);
 // kind: 0 = u8 frame + smoothing, 1 = f32 frame + smoothing, 2 = f32 image gradients only, 3 = u8 image gradients only
-int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int kind);
+int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int kind, bool hred = false);
+bool smooth_grad_hred_ok(const SmoothGradArgs &a, int batch, int kind, const Taps &reduce, int ss);
+int launch_pyr_vreduce(hipStream_t s, const PyrReduceArgs &a, int batch);   // level 1 from the H1 planes (src = H1, src_nr rows x dst_nc columns)
 int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch);
 int launch_smooth_only(hipStream_t s, const SmoothGradArgs &a, int batch, bool u8_input);   // 1: no specialised kernel
 

@@ -356,13 +356,21 @@ __device__ __forceinline__ void widen12(const float *row, double *d)
 #ifndef KLT_L0_WAVES
 #define KLT_L0_WAVES 4
 #endif
-template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_, int NTHR = 256>
+// HRED: the kernel also runs the HORIZONTAL pass of the first pyramid reduction (subsampling 4, 21 taps) on the smoothed tile while it
+// is in LDS, and writes H1[y][x] = hsmooth(image)(y, 4x + 2) (f32, nrows x ncols/4); pyr_vreduce_kernel finishes level 1 from
+// H1.  The image tile carries a halo of 12 columns instead of 4 for that (+22 % smoothing work in this kernel), and the separate
+// reduction kernel -- with its halo re-reads of the level-0 image, its 1.6x redundant horizontal pass and its latency-bound
+// tile loads -- disappears for level 1.  Same values: the tile is addressed in virtual coordinates whose smoothed values equal
+// the reflected ones (header of this file), which is what the reference's reduction reads beyond the frame edge.
+template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_, int NTHR = 256, bool HRED = false>
 __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradArgs a)
 {
+    static_assert(!HRED || SMOOTH, "the fused horizontal reduction needs the smoothing stages");
+    constexpr int HB = HRED ? 12 : 4;                           // halo columns of the image tile (B, C) on each side
     constexpr int rs = SMOOTH ? NS / 2 : 0;
     constexpr int R = (NG > ND ? NG : ND) / 2;
     static_assert(rs <= 4 && R <= 4, "register-blocked kernel needs tap radii <= 4");
-    constexpr int AW = TW + 16, BW = TW + 8, DW = TW;           // floats per row
+    constexpr int AW = TW + 2 * HB + 8, BW = TW + 2 * HB, DW = TW;   // floats per row (A starts at column -HB-4, B / C at -HB, D / E at 0)
     constexpr int AQ = AW / 4, BQ = BW / 4, DQ = DW / 4;        // quads per row
     constexpr int IH = TH_ + 2 * R, RH = IH + 2 * rs;
     constexpr int AB = SMOOTH ? RH * AW + RH * BW : 0, DE = 2 * IH * DW;
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
     STAGE_MARK(0);
     // ---- stage 0: frame -> LDS (through the reflect map)
     {
-        constexpr int W0 = SMOOTH ? AQ : BQ, H0 = SMOOTH ? RH : IH, X0 = SMOOTH ? -8 : -4, Y0 = -(R + rs);
+        constexpr int W0 = SMOOTH ? AQ : BQ, H0 = SMOOTH ? RH : IH, X0 = SMOOTH ? -(HB + 4) : -HB, Y0 = -(R + rs);
         float *const dst = SMOOTH ? A : C;
         constexpr int N0 = H0 * W0, U0 = (N0 + NTHR - 1) / NTHR;
         // Tiles whose halo lies inside the frame (most of them): every load of the thread is issued before the first one
@@ -500,8 +508,8 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
                 o.z = corr_regs<NS, 1>(v[2] + rs + dr, ks); o.w = corr_regs<NS, 1>(v[3] + rs + dr, ks);
                 const int rr = r + dr;
                 *reinterpret_cast<float4 *>(C + rr * BW + 4 * q) = o;
-                const int y = ty0 - R + rr, x = tx0 - 4 + 4 * q;
-                if (rr >= R && rr < R + TH_ && q >= 1 && q <= DQ && y < nr) {
+                const int y = ty0 - R + rr, x = tx0 - HB + 4 * q;
+                if (rr >= R && rr < R + TH_ && q >= HB / 4 && q < HB / 4 + DQ && y < nr) {
                     float *dstp = img + (size_t)y * nc + x;
                     if (x + 3 < nc) { dstp[0] = o.x; dstp[1] = o.y; dstp[2] = o.z; dstp[3] = o.w; }
                     else {
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
     for (int i = (tid + NTHR / 2) & (NTHR - 1); i < IH * DQ; i += NTHR) {
         const int r = i / DQ, q = i % DQ;
         double v[12];
-        widen12(C + r * BW + 4 * q, v);
+        widen12(C + r * BW + 4 * q + (HB - 4), v);
         float4 d, e;
         d.x = corr_regs<ND, -1>(v + 4, kd); d.y = corr_regs<ND, -1>(v + 5, kd);
         d.z = corr_regs<ND, -1>(v + 6, kd); d.w = corr_regs<ND, -1>(v + 7, kd);
@@ -529,6 +537,33 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
         e.z = corr_regs<NG, 1>(v + 6, kg); e.w = corr_regs<NG, 1>(v + 7, kg);
         *reinterpret_cast<float4 *>(D + r * DW + 4 * q) = d;
         *reinterpret_cast<float4 *>(E + r * DW + 4 * q) = e;
+    }
+    if (HRED) {
+        // ---- stage 3b: horizontal pass of the pyramid reduction at the surviving columns 4x + 2 of the tile's own rows
+        // (pyramid.py:59-72 -> correlate1d along x, symmetric branch; f32 result, as between the reference's two passes)
+        constexpr int NR = 21, HR = NR / 2;
+        TapRegs<HR + 1> kr;                                     // k[0..HR]: the taps left of and at the centre (symmetric)
+#pragma unroll
+        for (int t = 0; t <= HR; t++) kr.k[t] = a.reduce.k[t];
+        float *__restrict__ h1 = a.h1[b];
+        const int h1_nc = a.h1_nc;
+        for (int i = tid; i < TH_ * DQ; i += NTHR) {
+            const int r = i / DQ, xs = i % DQ;
+            // centre = image column 4 xs + 2 = C index HB + 4 xs + 2; samples -10 .. +10 start at C index 4 xs + HB - 8 (a quad)
+            typedef const volatile __attribute__((address_space(3))) f32x4 *lds_quad_ptr;
+            const lds_quad_ptr p = (lds_quad_ptr)(C + (r + R) * BW + 4 * xs + (HB - 8));
+            double v[24];
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const f32x4 t = p[u];
+                v[4 * u] = (double)t.x; v[4 * u + 1] = (double)t.y; v[4 * u + 2] = (double)t.z; v[4 * u + 3] = (double)t.w;
+            }
+            double acc = v[HR] * kr.k[HR];
+#pragma unroll
+            for (int jj = -HR; jj < 0; jj++) acc = acc + (v[HR + jj] + v[HR - jj]) * kr.k[HR + jj];
+            const int y = ty0 + r, xg = tx0 / 4 + xs;
+            if (y < nr && xg < h1_nc) h1[(size_t)y * h1_nc + xg] = (float)acc;
+        }
     }
     __syncthreads();
     STAGE_MARK(4);
@@ -902,6 +937,57 @@ static int launch_pyr_reduce_fast(hipStream_t s, const PyrReduceArgs &a, int bat
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Second half of the fused first reduction: level 1 (ys, xs) = V(H1)(4 ys + 2, xs), H1 = the horizontally reduced level-0 image
+// written by smooth_grad_rb<..., HRED>.  Tile = 64 columns x 16 output rows; a thread makes 4 consecutive output rows of one
+// column from 33 input rows (widened once).  Rows beyond the frame are read through the reflect map, as the reference does.
+template <int SS, int NT>
+__global__ __launch_bounds__(256) void pyr_vreduce_kernel(PyrReduceArgs a)
+{
+    constexpr int r = NT / 2, VW = 64, VH = 16, SH = (VH - 1) * SS + 2 * r + 1;       // 81 source rows
+    __shared__ float T[SH * VW];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int xs0 = blockIdx.x * VW, ys0 = blockIdx.y * VH;
+    const int nc = a.dst_nc, nr = a.src_nr;                     // H1 is src_nr rows x dst_nc columns
+    const float *__restrict__ src = a.src[b];
+    TapRegs<r + 1> k;
+#pragma unroll
+    for (int t = 0; t <= r; t++) k.k[t] = a.taps.k[t];
+    const int gy0 = ys0 * SS + SS / 2 - r;
+    {
+        constexpr int N = SH * VW, U = (N + 255) / 256;
+        const int col = min(xs0 + (tid & 63), nc - 1);
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {                            // clamped, unconditional; all loads in flight together
+            const int rr = min((tid >> 6) + 4 * u, SH - 1);
+            int y = gy0 + rr;
+            y = y < 0 ? -1 - y : y >= nr ? 2 * nr - 1 - y : y;
+            y = min(max(y, 0), nr - 1);                          // (frames shorter than the halo never take this kernel)
+            v[u] = src[(size_t)y * nc + col];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int rr = (tid >> 6) + 4 * u;
+            if (rr < SH) T[rr * VW + (tid & 63)] = v[u];
+        }
+    }
+    __syncthreads();
+    const int xs = tid & 63, yq = tid >> 6;                      // output rows ys0 + 4 yq .. + 3
+    double v[3 * SS + 2 * r + 1];                                // 33 rows
+#pragma unroll
+    for (int j = 0; j < 3 * SS + 2 * r + 1; j++) v[j] = (double)T[(4 * yq * SS + j) * VW + xs];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const double *c = v + o * SS + r;
+        double acc = c[0] * k.k[r];
+#pragma unroll
+        for (int jj = -r; jj < 0; jj++) acc = acc + (c[jj] + c[-jj]) * k.k[r + jj];
+        const int oy = ys0 + 4 * yq + o, ox = xs0 + xs;
+        if (oy < a.dst_nr && ox < a.dst_nc) a.dst[b][(size_t)oy * a.dst_nc + ox] = (float)acc;
+    }
+}
+
 }  // namespace
 
 int g_smooth_grad_variant = 0;     // 0 = register-blocked (default), 1 = one-sample-per-thread LDS kernels
@@ -933,7 +1019,25 @@ static int set_lds(K kernel, size_t lds)
 }
 
 // kind: 0 = u8 frame + smoothing, 1 = f32 frame + smoothing, 2 = f32 image, gradients only, 3 = u8 image, gradients only
-int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int kind)
+// Is the fused horizontal reduction available for this launch?  (specialised taps, tall tiles, subsampling 4 with 21 taps,
+// frames tall enough that the vertical pass needs a single reflection)
+bool smooth_grad_hred_ok(const SmoothGradArgs &a, int batch, int kind, const Taps &reduce, int ss)
+{
+    static const int force_th = getenv("KLT_RB_TH") ? atoi(getenv("KLT_RB_TH")) : 0;
+    const bool tall = force_th ? force_th == 32 : (long long)a.ncols * a.nrows * batch >= 1000000;
+    return g_smooth_grad_variant == 0 && tall && kind < 2 && a.smooth.sym == 1 && (a.smooth.n == 5 || a.smooth.n == 9) &&
+           a.ggauss.sym == 1 && a.gderiv.sym == -1 && a.ggauss.n == 7 && a.gderiv.n == 7 && ss == 4 && reduce.sym == 1 && reduce.n == 21 &&
+           a.nrows >= 64 && a.ncols >= 64;
+}
+
+int launch_pyr_vreduce(hipStream_t s, const PyrReduceArgs &a, int batch)
+{
+    const dim3 grid((a.dst_nc + 63) / 64, (a.dst_nr + 15) / 16, batch);
+    hipLaunchKernelGGL((pyr_vreduce_kernel<4, 21>), grid, dim3(256), 0, s, a);
+    return 0;
+}
+
+int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int kind, bool hred)
 {
     const bool smooth = kind < 2;
     // compile-time specialisations: Gaussian smoothing (symmetric), Gaussian / derivative gradient taps
@@ -952,6 +1056,13 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
         else hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 16>), g, blk, 0, s, a);                        \
         return 0;                                                                                                 \
     } while (0)
+            if (hred) {
+                if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+                if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+                if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+                if (kind == 1 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+                return -1;
+            }
             if (kind == 0 && a.smooth.n == 5) KLT_RB(uint8_t, true, 5);
             if (kind == 1 && a.smooth.n == 5) KLT_RB(float, true, 5);
             if (kind == 0 && a.smooth.n == 9) KLT_RB(uint8_t, true, 9);

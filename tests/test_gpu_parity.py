@@ -226,6 +226,28 @@ def test_pyramid_reduce_variant(ctx, ko, levels, ss, shape):
         ctx.set_option(9, 0)
 
 
+@pytest.mark.parametrize("shape,f32_input", [((1080, 1920), False), ((1080, 1920), True), ((1013, 1250), False), ((2160, 3840), False),
+                                             ((1100, 1001), False)])
+def test_fused_first_reduction_on_and_off(ctx, ko, shape, f32_input):
+    """KLT_OPT_FUSED_HREDUCE: level 1 from the H1 planes written by the level-0 kernel + the vertical-pass kernel (default for
+    subsampling 4 on large frames), or from the separate reduction kernel: both equal the oracle's pyramids, every level."""
+    from pyfeaturetrack_amd import synth
+    img = synth.synth_frame(shape[1], shape[0], 5, 0)
+    tc = make_tc(levels=3, ss=4)
+    ctx.configure(tc)
+    P = ko.Pyramids(params_from_tc(tc), img.astype(np.float32))
+    for fused in (1, 0):
+        try:
+            ctx.set_option(12, fused)
+            ctx.upload(0, img.astype(np.float32) if f32_input else img)
+            ctx.build_pyramids(0)
+            for l in range(3):
+                for pi, w in enumerate(("img", "gx", "gy")):
+                    assert_same(ctx.download_level(0, pi, l), P.level(w, l), "fused reduction %d, %s level %d, %dx%d" % (fused, w, l, shape[1], shape[0]))
+        finally:
+            ctx.set_option(12, 1)
+
+
 @pytest.mark.parametrize("window,levels,ss,shape", [(7, 3, 8, (700, 900)), (15, 3, 2, (301, 447)), (5, 2, 4, (64, 64)),
                                                     (7, 4, 2, (123, 77)), (7, 2, 8, (40, 50)), (9, 2, 4, (17, 333))])
 def test_pyramids_various_geometries_vs_oracle(ctx, ko, window, levels, ss, shape):

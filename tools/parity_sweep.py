@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: random frame sizes / pyramid geometries / windows, HIP path against the CPU oracle
 (pyramids, eigenvalue map, selected list, tracked list, bit for bit).  Not part of the test suite: a longer soak of the kernels'
-tile-edge, alignment and fallback paths.   python tools/parity_sweep.py [cases] [seed]"""
+tile-edge, alignment and fallback paths.   python tools/parity_sweep.py [cases] [seed] [max_width] [max_height]
+(frames of a megapixel and more take the tall-tile level-0 kernel with the fused first reduction)"""
 import os
 import sys
 import time
@@ -19,6 +20,8 @@ from oracle import klt_oracle as ko                         # noqa: E402
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+max_w = int(sys.argv[3]) if len(sys.argv) > 3 else 900
+max_h = int(sys.argv[4]) if len(sys.argv) > 4 else 700
 ctx = Context(0)
 ko.set_threads(8)
 bad = 0
@@ -28,8 +31,8 @@ for case in range(ncases):
     levels, ss = [(1, 2), (2, 2), (2, 4), (3, 2), (3, 4), (2, 8)][int(rng.integers(6))]
     tc = make_tc(levels=levels, ss=ss, window=window, max_residue=[None, 10.0, 25.0][int(rng.integers(3))])
     need = int(2 * tc.borderx + 40)
-    w = int(rng.integers(max(need, 64), 900))
-    h = int(rng.integers(max(int(2 * tc.bordery + 40), 48), 700))
+    w = int(rng.integers(max(need, 64), max(max_w, need + 65)))
+    h = int(rng.integers(max(int(2 * tc.bordery + 40), 48), max(max_h, int(2 * tc.bordery + 40) + 49)))
     if rng.random() < 0.5:
         w -= w % 4                                            # quad-aligned widths take the vector paths
     shift = (float(rng.uniform(-2.5, 2.5)), float(rng.uniform(-2.5, 2.5)))
