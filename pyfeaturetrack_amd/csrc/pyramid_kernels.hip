@@ -1049,15 +1049,15 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
             const bool tall = force_th ? force_th == 32 : (long long)a.ncols * a.nrows * batch >= 1000000;
             const int th = tall ? 32 : 16;
             const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + th - 1) / th, batch);
-            static const size_t pad_lds = getenv("KLT_RB_PAD_LDS") ? (size_t)atoi(getenv("KLT_RB_PAD_LDS")) : 0;   // occupancy experiment
 #define KLT_RB(T, SM, NSV)                                                                                        \
     do {                                                                                                          \
         if (tall) hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 32>), g, blk, pad_lds, s, a);             \
         else hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 16>), g, blk, 0, s, a);                        \
         return 0;                                                                                                 \
     } while (0)
+            static const size_t pad_lds = getenv("KLT_RB_PAD_LDS") ? (size_t)atoi(getenv("KLT_RB_PAD_LDS")) : 0;   // occupancy experiment
             if (hred) {
-                if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+                if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 5, 7, 7, 32, 256, true>), g, blk, pad_lds, s, a); return 0; }
                 if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
                 if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
                 if (kind == 1 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
