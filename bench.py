@@ -99,7 +99,7 @@ def cpu_baseline(p, f0, f1, fl):
     t = time.perf_counter()
     one_pair()
     t1 = time.perf_counter() - t
-    reps = int(max(2, min(40, 10.0 / max(t1, 1e-3))))
+    reps = int(max(2, min(200, 12.0 / max(t1, 1e-3))))      # about 12 s of single-thread work
     t = time.perf_counter()
     for _ in range(reps):
         one_pair()
