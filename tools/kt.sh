@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel event timings of the cfg-2 step (compact); usage: tools/kt.sh [bench args]
-python bench.py --steps 300 --warmup 30 --no-cpu-baseline "$@" 2>/dev/null | python -c '
+python bench.py --steps 2000 --warmup 200 --no-cpu-baseline "$@" 2>/dev/null | python -c '
 import sys, json
 for line in sys.stdin:
     line = line.strip()
