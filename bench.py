@@ -13,6 +13,11 @@ Workload at every N = BASELINE cfg-2 (1920x1080 synthetic pair, 5000 features, 7
 every rank with one RCCL all-gather on a side stream (event-ordered behind the tracker launch,
 overlapped with the next steps' kernels).
 
+Consecutive steps go round-robin to `--inflight` contexts (default 3; one HIP stream each, nothing ordering them): frame pairs
+are independent, so the GPU overlaps the kernels of different pairs.  Every step does the full work of one pair; `--inflight 1`
+and `extra.single_stream_ms_per_pair` give the one-stream figure.  Before the W warm-up steps 60 ms of untimed steps bring the
+GPU to its steady state (`--prewarm-ms`).
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the dominant kernel of the step (largest share of device time), timed with HIP
                   events on the context's stream in a second pass over the same K steps (events
@@ -343,7 +348,7 @@ def main():
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 (default, the headline line); the others are the remaining BASELINE configs on one GPU, informative")
     ap.add_argument("--pairs", type=int, default=32, help="pairs per step for --config cfg4")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="independent pairs in flight per GPU: consecutive steps go round-robin to this many contexts (one HIP "
                          "stream each, no events between them), so kernels of different pairs overlap; 1 = a single stream")
     ap.add_argument("--pipeline", action="store_true",

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Independent frame pairs with two pairs in flight on one GPU (the configuration `bench.py` reports).
+"""Independent frame pairs with several pairs in flight on one GPU (the configuration `bench.py` reports).
 
 Frame pairs that do not depend on each other (BASELINE cfg-4: a batch of pairs; or the pairs of several cameras) can be
 enqueued on different contexts of the same device.  Each context owns one HIP stream, its slots and its feature buffers;
@@ -13,8 +13,8 @@ records of every pair land in a device-side table that is read back once per `--
 
 Measured on one MI355X (1080p, 5000 features): when the frames cross PCIe for every pair the link is the bound (two 2 MB frames =
 0.09 ms) and one context is best -- 0.113 ms per pair with the frames already in pinned memory, 0.25 ms when the host also copies them
-there; more contexts only make the copy streams compete (0.140 / 0.155 ms with 2 / 3).  The second pair in flight pays off when the
-frames are already resident in HBM (`bench.py`: 0.061 -> 0.047 ms per pair) -- e.g. produced on the device by a decoder or a
+there; more contexts only make the copy streams compete (0.140 / 0.155 ms with 2 / 3).  More pairs in flight pay off when the
+frames are already resident in HBM (`bench.py`: 0.058 -> 0.0415 ms per pair with three) -- e.g. produced on the device by a decoder or a
 previous stage.
 """
 import argparse
