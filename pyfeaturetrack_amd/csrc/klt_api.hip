@@ -86,6 +86,9 @@ struct klt_ctx {
     float *h1 = nullptr;                      // H1 planes of the fused first reduction (one per frame of a batch)
     size_t h1_cap = 0;
     bool fuse_hreduce = true;                 // KLT_OPT_FUSED_HREDUCE
+    bool track_xcd_order = false;             // KLT_OPT_TRACK_XCD_ORDER
+    uint32_t *track_order = nullptr;
+    size_t track_order_cap = 0;
     // selection scratch
     float *sel_img = nullptr, *sel_gx = nullptr, *sel_gy = nullptr, *sat = nullptr, *valmap = nullptr;
     size_t sel_cap = 0;               // pixels
@@ -709,6 +712,7 @@ int klt_create(int device, klt_ctx **out)
     c->tstream = c->stream;
     c->work = c->stream;
     if (const char *v = getenv("KLT_FUSED_HREDUCE")) c->fuse_hreduce = atoi(v) != 0;      // experiment hook (initial value of the option)
+    if (const char *v = getenv("KLT_TRACK_XCD_ORDER")) c->track_xcd_order = atoi(v) != 0;
     *out = c;
     return KLT_OK;
 }
@@ -726,7 +730,7 @@ void klt_destroy(klt_ctx *c)
     for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes); }
     for (FeatBuf &b : c->fbs)
         if (!b.view) hipFree(b.d);
-    hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1);
+    hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1); hipFree(c->track_order);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
     hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
@@ -876,6 +880,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_SAT_VARIANT) { c->sat_variant = value; return KLT_OK; }
     if (option == KLT_OPT_TRACK_VARIANT) { g_track_variant = value; return KLT_OK; }
     if (option == KLT_OPT_FUSED_HREDUCE) { c->fuse_hreduce = value != 0; return KLT_OK; }
+    if (option == KLT_OPT_TRACK_XCD_ORDER) { c->track_xcd_order = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SPLIT_L0) { c->split_l0 = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_PARALLEL_NMS) { c->use_mis = value != 0; return KLT_OK; }
@@ -1346,6 +1351,11 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
     fill_levels(s1, s2, a.lv);
     a.in = c->fbs[fb_in].d; a.out = bo->d;
     fill_track_params(c, s1, a, n);
+    if (c->track_xcd_order && n >= 64 && c->p.window_width == 7) {
+        if (int rc = ensure(c, c->track_order, c->track_order_cap, (size_t)n)) return rc;
+        a.order = c->track_order;
+        a.order_chunk = (n + 7) / 8;
+    }
     if (int rc = tracker_begin(c)) return rc;
     {
         const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);

@@ -53,6 +53,8 @@ struct TrackArgs {
     klt_feat *out;
     const TrackPairDesc *pairs;         // batched launch: npairs descriptors (lv / in / out above unused)
     int npairs;
+    uint32_t *order;                    // single-pair launch, optional: scratch [n] for the XCD-aware feature order (see track_order_kernel)
+    int order_chunk;                    // ceil(n / 8): features per XCD
     double half_window;          // window/2 as the Python float (3.5 for 7x7), trackFeatures.py:88-89
     double borderx, bordery;
     int n, nlevels, window, max_iterations, use_max_residue, retain, ncols, nrows;

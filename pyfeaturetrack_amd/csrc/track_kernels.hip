@@ -246,7 +246,14 @@ template <int MAXK, int WCT, bool BATCH>
 __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int f = blockIdx.x;
+    int f = blockIdx.x;
+    if (!BATCH && a.order) {
+        // XCD-aware order: workgroup b runs on XCD b % 8; XCD c takes the c-th eighth of the features sorted by row, so that
+        // the eight L2s each see one band of the pyramids instead of all of every plane
+        const int c = blockIdx.x & 7, j = blockIdx.x >> 3, pos = c * a.order_chunk + j;
+        if (j >= a.order_chunk || pos >= a.n) return;
+        f = (int)a.order[pos];
+    }
     const int lane = threadIdx.x;
     if (f >= a.n) return;
     const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
@@ -540,6 +547,243 @@ __global__ __launch_bounds__(64, KLT_TRACK_WAVES) void track_kernel_pf(TrackArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Four features per wavefront (windows of at most 64 samples): KLT_OPT_TRACK_VARIANT = 2.
+//
+// With several frame pairs in flight the tracker is bound by instruction issue, not by latency (tools/stage_throughput.py: it
+// reaches exactly its VALU issue time), and most of a Newton iteration is work that one feature cannot spread over a wavefront:
+// the five sequential 49-term sums occupy 5 lanes, the bounds tests, bilinear weights and the 2x2 solve are the same in every
+// lane.  Here a feature owns 16 lanes (sample k of its window -> lane k % 16, round k / 16), so those instructions serve four
+// features at once; only the sampling rounds cost the same per feature as before.  The four features of a wavefront iterate in
+// lock step under per-feature predicates (a finished feature keeps its state and idles), so a wavefront runs as many Newton
+// iterations as its slowest feature.  Every feature's arithmetic is track_level's, operation for operation.
+__device__ __forceinline__ float pairwise_block_group(const float *a, int n, int s)      // result in the group's lane s == 0
+{
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; i++) res = res + a[i];
+        return res;
+    }
+    const int nn = n - (n % 8);
+    float r = 0.f;
+    if (s < 8) {
+        r = a[s];
+        for (int i = 8; i < nn; i += 8) r = r + a[i + s];
+    }
+    r = r + __shfl_down(r, 1);
+    r = r + __shfl_down(r, 2);
+    float res = r + __shfl_down(r, 4);
+    for (int i = nn; i < n; i++) res = res + a[i];
+    return res;
+}
+
+template <int WCT, bool BATCH>
+__global__ __launch_bounds__(64) void track_kernel_q(TrackArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int MAXK = 4;                                  // 16 lanes x 4 rounds >= 64 samples
+    const int lane = threadIdx.x, g = lane >> 4, s = lane & 15, glead = lane & 48;
+    const int f = 4 * blockIdx.x + g;
+    const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
+    const klt_feat *fin = BATCH ? a.pairs[blockIdx.y].in : a.in;
+    klt_feat *fout = BATCH ? a.pairs[blockIdx.y].out : a.out;
+    const bool valid = f < a.n;
+    const klt_feat ft = fin[valid ? f : a.n - 1];
+    const bool tracked_feature = valid && ft.val >= 0;       // only live features are tracked, trackFeatures.py:253
+    if (valid && ft.val < 0 && s == 0) fout[f] = ft;
+    if (!__any(tracked_feature)) return;
+    const int L = a.nlevels;
+    const int w = WCT > 0 ? WCT : a.window, n = w * w, hw = w / 2;
+    const int npad = (n + 3) & ~3;
+    float *const gl = lds + g * 5 * npad;                    // this feature's five product arrays
+    const float one_plus_eps = 1.001f;
+
+    // trackFeatures.py:255-265
+    float xloc = ft.x, yloc = ft.y;
+    for (int r = 0; r < L; r++) { xloc = xloc * a.inv_ss; yloc = yloc * a.inv_ss; }
+    float xout = xloc, yout = yloc;
+    int val = KLT_TRACKED;
+    uint32_t aux = 0;
+    bool alive = tracked_feature;                            // still descending the pyramid
+
+    for (int r = L - 1; r >= 0; r--) {
+        if (!__any(alive)) break;
+        const TrackLevel &lv = levels[r];
+        const int nc = lv.nc, nr = lv.nr;
+        if (alive) { xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss; }
+
+        // image-1 template (trackFeatures.py:102-104); a window that leaves image 1 ends the feature
+        const Bilinear b1 = make_bilinear(xloc, yloc);
+        const bool t_ok = b1.ix - hw >= 0 && b1.iy - hw >= 0 && b1.ix + hw + 2 <= nc && b1.iy + hw + 2 <= nr;
+        const bool run = alive && t_ok;
+        float t_i[MAXK], t_gx[MAXK], t_gy[MAXK];
+        int off[MAXK];
+#pragma unroll
+        for (int m = 0; m < MAXK; m++) {
+            const int k = s + 16 * m;
+            t_i[m] = t_gx[m] = t_gy[m] = 0.f;
+            off[m] = 0;
+            if (k < n) {
+                off[m] = (k / w) * nc + (k % w);
+                const size_t q = run ? (size_t)(b1.iy - hw) * nc + (b1.ix - hw) + off[m] : (size_t)0;
+                t_i[m] = sample(lv.i1 + q, nc, b1);
+                t_gx[m] = sample(lv.gx1 + q, nc, b1);
+                t_gy[m] = sample(lv.gy1 + q, nc, b1);
+            }
+        }
+
+        int it = 0, status = KLT_OOB;
+        float x2 = xout, y2 = yout;
+        bool iterating = run;
+        while (__any(iterating)) {
+            // trackFeaturesUtils.pyx:428-431
+            const bool oob = (double)(x2 - (float)hw) < 0. || (float)nc - (x2 + (float)hw) < one_plus_eps ||
+                             (double)(y2 - (float)hw) < 0. || (float)nr - (y2 + (float)hw) < one_plus_eps;
+            if (iterating && oob) { status = KLT_OOB; iterating = false; }
+            const bool act = iterating;
+            const Bilinear b2 = make_bilinear(x2, y2);
+            const size_t base = act ? (size_t)(b2.iy - hw) * nc + (b2.ix - hw) : (size_t)0;
+#pragma unroll
+            for (int m = 0; m < MAXK; m++) {
+                const int k = s + 16 * m;
+                if (k < n) {
+                    const size_t q = act ? base + off[m] : (size_t)0;
+                    const float diff = t_i[m] - sample(lv.i2 + q, nc, b2);
+                    const float sx = t_gx[m] + sample(lv.gx2 + q, nc, b2);
+                    const float sy = t_gy[m] + sample(lv.gy2 + q, nc, b2);
+                    gl[k] = sx * sx;
+                    gl[npad + k] = sx * sy;
+                    gl[2 * npad + k] = sy * sy;
+                    gl[3 * npad + k] = diff * sx;
+                    gl[4 * npad + k] = diff * sy;
+                }
+            }
+            wave_lds_sync();
+            float acc = 0.f;
+            if (s < 5) {
+                const float *T = gl + s * npad;
+                if (WCT > 0) {
+                    const float4 *T4 = reinterpret_cast<const float4 *>(T);
+#pragma unroll
+                    for (int q = 0; q < (WCT * WCT + 3) / 4; q++) {
+                        const float4 v = T4[q];
+                        acc = acc + v.x;
+                        if (4 * q + 1 < WCT * WCT) acc = acc + v.y;
+                        if (4 * q + 2 < WCT * WCT) acc = acc + v.z;
+                        if (4 * q + 3 < WCT * WCT) acc = acc + v.w;
+                    }
+                } else {
+                    for (int k = 0; k < n; k++) acc = acc + T[k];
+                }
+            }
+            wave_lds_sync();
+            const float gxx = __shfl(acc, glead), gxy = __shfl(acc, glead + 1), gyy = __shfl(acc, glead + 2);
+            const float ex = __shfl(acc, glead + 3) * a.step, ey = __shfl(acc, glead + 4) * a.step;
+            const float p1 = gxx * gyy, p2 = gxy * gxy;
+            const float det = p1 - p2;
+            const bool small_det = det < a.small;
+            if (act && small_det) { status = KLT_SMALL_DET; iterating = false; }
+            const float n1 = gyy * ex, n2 = gxy * ey, n3 = gxx * ey, n4 = gxy * ex;
+            const float dx = (n1 - n2) / det;
+            const float dy = (n3 - n4) / det;
+            if (act && !small_det) {
+                status = KLT_TRACKED;
+                x2 = x2 + dx;
+                y2 = y2 + dy;
+                it++;
+                iterating = (fabsf(dx) >= a.th || fabsf(dy) >= a.th) && it < a.max_iterations;
+            }
+        }
+        if (run) { xout = x2; yout = y2; }
+
+        // trackFeatures.py:110 -- Python floats: half-window 3.5, eps 1.001 as doubles
+        const double x2d = (double)x2, y2d = (double)y2, hwd = a.half_window;
+        if (run && (x2d - hwd < 0.0 || (double)nc - (x2d + hwd) < 1.001 || y2d - hwd < 0.0 || (double)nr - (y2d + hwd) < 1.001))
+            status = KLT_OOB;
+
+        // residue, trackFeatures.py:118-125
+        const bool need_res = run && status == KLT_TRACKED && a.use_max_residue;
+        if (__any(need_res)) {
+            const Bilinear b2 = make_bilinear(x2, y2);
+            const size_t base = need_res ? (size_t)(b2.iy - hw) * nc + (b2.ix - hw) : (size_t)0;
+#pragma unroll
+            for (int m = 0; m < MAXK; m++) {
+                const int k = s + 16 * m;
+                if (k < n) gl[k] = fabsf(t_i[m] - sample(lv.i2 + (need_res ? base + off[m] : (size_t)0), nc, b2));
+            }
+            wave_lds_sync();
+            float sres = pairwise_block_group(gl, n, s);
+            wave_lds_sync();
+            sres = __shfl(sres, glead);
+            if (need_res && sres / (float)n > a.max_residue) status = KLT_LARGE_RESIDUE;
+        }
+
+        int lvl_val;
+        if (!t_ok) lvl_val = KLT_OOB;
+        else if (a.retain) lvl_val = KLT_TRACKED;                                               // :127-129
+        else if (status == KLT_SMALL_DET || status == KLT_OOB || status == KLT_LARGE_RESIDUE) lvl_val = status;
+        else if (it >= a.max_iterations) lvl_val = KLT_MAX_ITERATIONS;
+        else lvl_val = KLT_TRACKED;
+        if (alive) {
+            val = lvl_val;
+            aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);
+            alive = !(val == KLT_SMALL_DET || val == KLT_OOB);                                  // :284-285
+        }
+    }
+    if (tracked_feature && s == 0) {
+        klt_feat o;
+        o.aux = (int32_t)aux;
+        const double xd = (double)xout, yd = (double)yout;
+        const bool oob = val == KLT_OOB ||
+                         xd < a.borderx || xd > (double)(a.ncols - 1) - a.borderx ||
+                         yd < a.bordery || yd > (double)(a.nrows - 1) - a.bordery;   // :288-308
+        if (oob) { o.x = -1.f; o.y = -1.f; o.val = KLT_OOB; }
+        else if (val == KLT_SMALL_DET || val == KLT_LARGE_RESIDUE || val == KLT_MAX_ITERATIONS) {
+            o.x = -1.f; o.y = -1.f; o.val = val;
+        } else { o.x = xout; o.y = yout; o.val = KLT_TRACKED; }
+        fout[f] = o;
+    }
+}
+
+// Features sorted by image row (counting sort, one workgroup): order[0..n) = feature indices by ascending (int)y; lost
+// features go last.  The order within a row is whatever the atomics give -- every feature is still tracked exactly once and
+// written to its own slot, so the result does not depend on it.
+constexpr int ORDER_BINS = 4096, ORDER_T = 1024;
+__global__ __launch_bounds__(ORDER_T) void track_order_kernel(const klt_feat *__restrict__ in, int n, uint32_t *__restrict__ order)
+{
+    __shared__ unsigned hist[ORDER_BINS], start[ORDER_BINS];
+    __shared__ unsigned wsum[ORDER_T / 64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ORDER_BINS; i += ORDER_T) hist[i] = 0u;
+    __syncthreads();
+    auto bin_of = [&](const klt_feat &ft) {
+        if (ft.val < 0) return ORDER_BINS - 1;
+        const int y = (int)ft.y;
+        return y < 0 ? 0 : y > ORDER_BINS - 2 ? ORDER_BINS - 2 : y;
+    };
+    for (int i = tid; i < n; i += ORDER_T) atomicAdd(&hist[bin_of(in[i])], 1u);
+    __syncthreads();
+    // exclusive scan of the 4096 bins: 4 bins per thread, wave scan, then the 16 wave totals
+    unsigned v[4], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = hist[4 * tid + k]; tsum += v[k]; }
+    unsigned inc = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(inc, d);
+        if ((tid & 63) >= d) inc += o;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int wv = 0; wv < (tid >> 6); wv++) base += wsum[wv];
+    unsigned run = base + inc - tsum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { start[4 * tid + k] = run; run += v[k]; }
+    __syncthreads();
+    for (int i = tid; i < n; i += ORDER_T) order[atomicAdd(&start[bin_of(in[i])], 1u)] = (uint32_t)i;
+}
+
 // Iteration statistics from the per-feature aux words (only launched while statistics are being collected;
 // per-feature atomics on a handful of shared counters would serialise the whole tracker).
 __global__ __launch_bounds__(256) void track_stats_kernel(const klt_feat *__restrict__ in, const klt_feat *__restrict__ out,
@@ -573,10 +817,12 @@ void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, 
     hipLaunchKernelGGL(track_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, nlevels, stats);
 }
 
-// 0 (default): track_kernel for every window; 1: track_kernel_pf for windows of <= 64 samples (a third of the dependent
-// round trips and a quarter of the vector loads, bit-identical records -- and no faster: the tracker is bound by
-// instruction issue, ~1800 instructions per feature on 5 wavefronts per SIMD, not by latency; 20.5 vs 21.5 us at cfg-2,
-// 0.60 vs 0.64 ms for a cfg-4 shard).  KLT_TRACK_VARIANT in the environment sets the initial value.
+// 0 (default): track_kernel for every window; for windows of <= 64 samples also 1: track_kernel_pf (a third of the dependent
+// round trips and a quarter of the vector loads) and 2: track_kernel_q (four features per wavefront, ~30 % fewer VALU
+// instructions per feature).  All three give bit-identical records, and with several pairs in flight all three settle at the
+// same 11.4-11.8 us per 5000 features (tools/stage_throughput.py); on one stream 0 is the fastest (20.5 / 21.5 / 25.2 us).  Nor
+// does halving the HBM traffic help (KLT_OPT_TRACK_XCD_ORDER: 55 -> 30 MB per launch, 13.0 us).  KLT_TRACK_VARIANT in the
+// environment sets the initial value.
 int g_track_variant = getenv("KLT_TRACK_VARIANT") ? atoi(getenv("KLT_TRACK_VARIANT")) : 0;
 
 template <bool BATCH>
@@ -585,10 +831,21 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     const int n = a.window * a.window;
     const size_t lds = 5 * (size_t)((n + 3) & ~3) * sizeof(float);
     const dim3 grid(a.n, BATCH ? a.npairs : 1), block(64);
+    if (g_track_variant == 2 && n <= 64) {
+        const dim3 gq((a.n + 3) / 4, BATCH ? a.npairs : 1);
+        if (a.window == 7) hipLaunchKernelGGL((track_kernel_q<7, BATCH>), gq, block, 4 * lds, s, a);
+        else hipLaunchKernelGGL((track_kernel_q<0, BATCH>), gq, block, 4 * lds, s, a);
+        return 0;
+    }
     if (g_track_variant == 1 && n <= 64) {
         if (a.window == 7) hipLaunchKernelGGL((track_kernel_pf<7, BATCH>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((track_kernel_pf<0, BATCH>), grid, block, lds, s, a);
         return 0;
+    }
+    if (!BATCH && a.order && g_track_variant == 0) {
+        hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
+        const dim3 gx(8 * a.order_chunk);
+        if (a.window == 7) { hipLaunchKernelGGL((track_kernel<1, 7, BATCH>), gx, block, lds, s, a); return 0; }
     }
     if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH>), grid, block, lds, s, a);
     else if (a.window == 15) hipLaunchKernelGGL((track_kernel<4, 15, BATCH>), grid, block, lds, s, a);

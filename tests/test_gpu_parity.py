@@ -435,11 +435,12 @@ def test_track_retain(ctx, cfg1, img0, img1):
     assert_feats(out, cfg1["trk100_retain_x"], cfg1["trk100_retain_y"], cfg1["trk100_retain_val"], "track retainTrackers")
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("window,levels,ss,retain,mr", [(7, 2, 4, False, 10.0), (7, 2, 4, True, 10.0), (7, 3, 2, False, None),
                                                         (5, 2, 4, False, 10.0), (3, 2, 2, False, 5.0)])
-def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, retain, mr):
-    """KLT_OPT_TRACK_VARIANT=1 (footprints requested ahead, one pixel per lane + lane shuffles): same records as the
-    oracle, and for the default context as the reference's goldens."""
+def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, retain, mr, variant):
+    """KLT_OPT_TRACK_VARIANT=1 (footprints requested ahead, one pixel per lane + lane shuffles) and =2 (four features per
+    wavefront): same records as the oracle, and for the default context as the reference's goldens."""
     tc = make_tc(levels=levels, ss=ss, window=window, max_residue=mr, retainTrackers=retain)
     p = params_from_tc(tc)
     ctx.configure(tc)
@@ -449,7 +450,7 @@ def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, r
     ctx.build_pyramids(1)
     fl, _ = ctx.select(0, 100)
     try:
-        ctx.set_option(11, 1)
+        ctx.set_option(11, variant)
         out, _ = ctx.track(0, 1, fl)
     finally:
         ctx.set_option(11, 0)
@@ -461,6 +462,29 @@ def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, r
     assert_feats(out, *oracle_feats(ofl), what="prefetching tracker, window %d" % window)
     if (window, levels, ss, retain, mr) == (7, 2, 4, False, 10.0):
         assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "prefetching tracker vs golden")
+
+
+def test_track_xcd_aware_order(ctx, ko):
+    """KLT_OPT_TRACK_XCD_ORDER: features handed to the tracker sorted by row, one band per XCD -- same records, lost features
+    (passed through) included."""
+    from pyfeaturetrack_amd import synth
+    f0, f1 = synth.synth_pair(1280, 720, 4)
+    tc = make_tc(levels=3, ss=4, max_residue=10.0)
+    ctx.configure(tc)
+    ctx.upload(0, f0)
+    ctx.upload(1, f1)
+    ctx.build_pyramids(0)
+    ctx.build_pyramids(1)
+    fl, _ = ctx.select(0, 1500)
+    fl["val"][::7] = -3                     # some lost features in the list
+    ref, _ = ctx.track(0, 1, fl)
+    try:
+        ctx.set_option(13, 1)
+        out, _ = ctx.track(0, 1, fl)
+    finally:
+        ctx.set_option(13, 0)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(out["val"][::7], fl["val"][::7])
 
 
 def test_pingpong_and_lost_features_skipped(ctx, cfg1, img0, img1):
