@@ -99,7 +99,7 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
  * Either way klt_select_async synchronises once internally (it reads back whether the list was filled / settled). */
 #define KLT_OPT_SELECT_PARALLEL_NMS 8
 #define KLT_OPT_SAT_VARIANT 10           /* summed-area tables: 1 (default) step-synchronous wavefront pipelines (frames with ncols % 4 == 0), 0 barrier-coupled kernels */
-#define KLT_OPT_TRACK_VARIANT 11         /* 0 (default): plain tracker kernel; 1: footprints requested ahead, one pixel per lane; 2: four features per wavefront (1, 2: windows of <= 64 samples; same records, measured no faster) (process-wide) */
+#define KLT_OPT_TRACK_VARIANT 11         /* 7x7 windows: 4 (default) four features per wavefront with 16-byte loads; 0: one feature per wavefront; 1: footprints requested ahead; 2: four features per wavefront, per-sample loads; 3: one pixel per lane (same records; process-wide) */
 #define KLT_OPT_FUSED_HREDUCE 12         /* 1 (default): the level-0 kernel also runs the horizontal pass of the first pyramid reduction (subsampling 4); 0: separate reduction kernel */
 #define KLT_OPT_TRACK_XCD_ORDER 13        /* 1: features are handed to the tracker sorted by row, one band per XCD (7x7 windows, plain kernel); 0 (default): list order */
 #define KLT_OPT_PYR_REDUCE_VARIANT 9    /* 0 (default): 1024-thread pyramid reduce; 1: 512-thread all-f32 variant, measured slower (process-wide) */

@@ -118,7 +118,7 @@ void launch_vconv(hipStream_t s, const float *inA, const float *inB, int ncols, 
                   int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb);
 
 extern int g_smooth_grad_variant;   // test hook: 0 register-blocked, 1 one-sample-per-thread
-extern int g_track_variant;         // 0 (default): track_kernel; 1: prefetching tracker kernel for windows of <= 64 samples
+extern int g_track_variant;         // tracker kernel for 7x7 windows: 4 (default) track_kernel_qv, 0 track_kernel, 1 _pf, 2 _q, 3 <GRID>
 extern int g_pyr_reduce_variant;    // test hook: 0 1024-thread reduce (default), 1 512-thread all-f32 reduce
 size_t smooth_grad_lds_bytes(int smooth_radius /* -1: no smoothing stage */, int R);
 size_t pyr_reduce_lds_bytes(int ss, int ntaps);

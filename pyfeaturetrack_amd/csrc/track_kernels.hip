@@ -110,14 +110,51 @@ __device__ float pairwise_sum<0>(const float *a, int n, int lane)
     return pairwise_block_wave(a, n < 128 ? n : 128, lane);
 }
 
+// One footprint = the (w+1) x (w+1) pixels under a window; lane (r, c) of a (w+1)-wide grid loads pixel (r, c) of each of the
+// three images ONCE (for 7x7 windows the grid is exactly the 64 lanes) and gets its right / lower / diagonal neighbours
+// from the lanes that loaded them (ds_bpermute), instead of every lane loading its own four pixels of every image: 3 vector
+// loads per footprint instead of 12.  Vector-memory issue (64 scattered addresses per instruction through the address
+// unit) is what the tracker spends its time on after the round trips.
+struct Px3 { float i, gx, gy; };
+
+__device__ __forceinline__ void load_px3(const float *__restrict__ pi, const float *__restrict__ pgx, const float *__restrict__ pgy,
+                                         unsigned q, Px3 &o)
+{
+    o.i = pi[q]; o.gx = pgx[q]; o.gy = pgy[q];
+}
+
+// sample() on the 2x2 neighbourhood {v, right, below, diagonal} (same expression, same order)
+__device__ __forceinline__ float sample_nb(float v, int G, const Bilinear &b)
+{
+    const float v01 = __shfl_down(v, 1), v10 = __shfl_down(v, G), v11 = __shfl_down(v, G + 1);
+    const float t4 = b.w11 * v11;
+    double d = b.w00 * (double)v;
+    d = d + b.w01 * (double)v01;
+    d = d + b.w10 * (double)v10;
+    d = d + (double)t4;
+    return (float)d;
+}
+
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // _trackFeature for one level.  Returns the status; x2/y2 updated in place; `iters` = Newton iterations.
 // WCT > 0: window size known at compile time (index math folds, the summation loops unroll and read LDS
 // 16 bytes at a time); WCT == 0: any odd window up to 31.
-template <int MAXK, int WCT>
+// GRID (windows of at most 7x7, MAXK = 1): lane (r, c) of a (w+1)-wide grid loads ONE pixel of each image per footprint and takes its
+// three neighbours from the lanes that loaded them, instead of every lane loading its own four pixels: half the L1 line accesses
+// (a footprint row is touched once, not once for y and once for y + 1) and a quarter of the vector-load lanes.
+template <int MAXK, int WCT, bool GRID = false>
 __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, float y1, float &x2r, float &y2r,
                            float *lds, int lane, int &iters, int clk0 = 0)
 {
+    static_assert(!GRID || MAXK == 1, "grid sampling handles one sample per lane");
     const int w = WCT > 0 ? WCT : a.window, n = w * w, hw = w / 2;
+    const int G = w + 1;
+    const bool in_grid = lane < G * G;
+    const int gr = in_grid ? lane / G : 0, gc = in_grid ? lane % G : 0;
+    const bool mine = in_grid && gr < w && gc < w;
+    const int ks = gr * w + gc;                          // row-major index of this lane's window sample (GRID)
+    const int goff = gr * lv.nc + gc;                    // its pixel relative to the footprint's top-left corner
     const int npad = (n + 3) & ~3;                       // 16-byte aligned sub-arrays
     const int nc = lv.nc, nr = lv.nr;
     float *l_diff = lds;                                 // residue scratch (aliases product array 0)
@@ -129,6 +166,13 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
         return KLT_OOB;      // the reference asserts here (trackFeaturesUtils.pyx:35); see DESIGN.md
     float t_i[MAXK], t_gx[MAXK], t_gy[MAXK];
     int off[MAXK];           // sample offset relative to the window's top-left footprint pixel
+    if (GRID) {
+        const size_t q = (size_t)(b1.iy - hw) * nc + (b1.ix - hw) + goff;
+        t_i[0] = sample_nb(lv.i1[q], G, b1);
+        t_gx[0] = sample_nb(lv.gx1[q], G, b1);
+        t_gy[0] = sample_nb(lv.gy1[q], G, b1);
+        off[0] = 0;
+    } else
 #pragma unroll
     for (int kk = 0; kk < MAXK; kk++) {
         const int k = lane + 64 * kk;
@@ -158,6 +202,19 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
         const size_t base = (size_t)(b2.iy - hw) * nc + (b2.ix - hw);
         // every lane forms the five products of its samples (each product is one rounded f32 multiply, exactly the
         // term the reference adds); LDS then holds five arrays of n terms
+        if (GRID) {
+            const size_t q = base + goff;
+            const float diff = t_i[0] - sample_nb(lv.i2[q], G, b2);
+            const float sx = t_gx[0] + sample_nb(lv.gx2[q], G, b2);
+            const float sy = t_gy[0] + sample_nb(lv.gy2[q], G, b2);
+            if (mine) {
+                lds[ks] = sx * sx;
+                lds[npad + ks] = sx * sy;
+                lds[2 * npad + ks] = sy * sy;
+                lds[3 * npad + ks] = diff * sx;
+                lds[4 * npad + ks] = diff * sy;
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < MAXK; kk++) {
             const int k = lane + 64 * kk;
@@ -223,6 +280,10 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
     if (status == KLT_TRACKED && a.use_max_residue) {
         const Bilinear b2 = make_bilinear(x2, y2);
         const size_t base = (size_t)(b2.iy - hw) * nc + (b2.ix - hw);
+        if (GRID) {
+            const float ad = fabsf(t_i[0] - sample_nb(lv.i2[base + goff], G, b2));
+            if (mine) l_diff[ks] = ad;
+        } else
 #pragma unroll
         for (int kk = 0; kk < MAXK; kk++) {
             const int k = lane + 64 * kk;
@@ -242,7 +303,7 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
     return KLT_TRACKED;
 }
 
-template <int MAXK, int WCT, bool BATCH>
+template <int MAXK, int WCT, bool BATCH, bool GRID = false>
 __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -275,7 +336,7 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     for (int r = L - 1; r >= 0; r--) {
         xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss;
         int it = 0;
-        val = track_level<MAXK, WCT>(a, levels[r], xloc, yloc, xout, yout, lds, lane, it, 1 + 9 * (L - 1 - r));
+        val = track_level<MAXK, WCT, GRID>(a, levels[r], xloc, yloc, xout, yout, lds, lane, it, 1 + 9 * (L - 1 - r));
         aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);      // visited level r with `it` Newton iterations
         if (val == KLT_SMALL_DET || val == KLT_OOB) break;             // :284-285
     }
@@ -310,33 +371,6 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
 // clamped addresses (a guarded load is a branch, and the wait-count model drains every outstanding load at the join); the
 // single wavefront of the workgroup orders its LDS traffic with s_waitcnt lgkmcnt(0) instead of __syncthreads(), which
 // would also wait for the prefetches.
-// One footprint = the (w+1) x (w+1) pixels under a window; lane (r, c) of a (w+1)-wide grid loads pixel (r, c) of each of the
-// three images ONCE (for 7x7 windows the grid is exactly the 64 lanes) and gets its right / lower / diagonal neighbours
-// from the lanes that loaded them (ds_bpermute), instead of every lane loading its own four pixels of every image: 3 vector
-// loads per footprint instead of 12.  Vector-memory issue (64 scattered addresses per instruction through the address
-// unit) is what the tracker spends its time on after the round trips.
-struct Px3 { float i, gx, gy; };
-
-__device__ __forceinline__ void load_px3(const float *__restrict__ pi, const float *__restrict__ pgx, const float *__restrict__ pgy,
-                                         unsigned q, Px3 &o)
-{
-    o.i = pi[q]; o.gx = pgx[q]; o.gy = pgy[q];
-}
-
-// sample() on the 2x2 neighbourhood {v, right, below, diagonal} (same expression, same order)
-__device__ __forceinline__ float sample_nb(float v, int G, const Bilinear &b)
-{
-    const float v01 = __shfl_down(v, 1), v10 = __shfl_down(v, G), v11 = __shfl_down(v, G + 1);
-    const float t4 = b.w11 * v11;
-    double d = b.w00 * (double)v;
-    d = d + b.w01 * (double)v01;
-    d = d + b.w10 * (double)v10;
-    d = d + (double)t4;
-    return (float)d;
-}
-
-__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
 // Every decision below is wave-uniform (positions come out of wave shuffles); saying so keeps the branches scalar and the
 // level index and the positions in SGPRs -- otherwise the level descriptors are fetched with vector loads (and waiting for
 // those drains the prefetches) and every position costs vector registers (the kernel must stay under 96 VGPRs: 5 wavefronts
@@ -745,6 +779,203 @@ __global__ __launch_bounds__(64) void track_kernel_q(TrackArgs a)
     }
 }
 
+// Four 7x7 features per wavefront with QUAD loads (KLT_OPT_TRACK_VARIANT = 4).  The 8x8 footprint of a feature is 16 quads of four
+// pixels; lane (row r = s / 2, half h = s % 2) of the feature's 16 lanes loads quad (r, 4h .. 4h + 3) of each image with one
+// 16-byte load -- 3 vector loads per footprint for four features, where track_kernel_q issues 24 and track_kernel 6 per feature --
+// and computes the window samples (r, 4h .. 4h + 3) from its own quad, the quad below (lane s + 2) and the first pixels of the two
+// quads to the right (lanes s + 1, s + 3).  Instruction count of track_kernel_q, a sixth of its L1 accesses.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 load_quad(const float *p)      // 4-byte aligned 16-byte load
+{
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    return *reinterpret_cast<const f32x4_u *>(p);
+}
+
+// the four window samples of a lane from its quad `a`: pairs (a.x,a.y), (a.y,a.z), (a.z,a.w), (a.w, right neighbour) and the same
+// pairs of the row below
+__device__ __forceinline__ void sample_quad(const f32x4 a, const Bilinear &b, float out[4])
+{
+    f32x4 lo;
+    lo.x = __shfl_down(a.x, 2); lo.y = __shfl_down(a.y, 2); lo.z = __shfl_down(a.z, 2); lo.w = __shfl_down(a.w, 2);
+    const float rx = __shfl_down(a.x, 1), dx = __shfl_down(a.x, 3);
+    const float v00[4] = {a.x, a.y, a.z, a.w}, v01[4] = {a.y, a.z, a.w, rx};
+    const float v10[4] = {lo.x, lo.y, lo.z, lo.w}, v11[4] = {lo.y, lo.z, lo.w, dx};
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const float t4 = b.w11 * v11[m];
+        double d = b.w00 * (double)v00[m];
+        d = d + b.w01 * (double)v01[m];
+        d = d + b.w10 * (double)v10[m];
+        d = d + (double)t4;
+        out[m] = (float)d;
+    }
+}
+
+template <bool BATCH>
+__global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x, g = lane >> 4, s = lane & 15, glead = lane & 48;
+    const int f = 4 * blockIdx.x + g;
+    const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
+    const klt_feat *fin = BATCH ? a.pairs[blockIdx.y].in : a.in;
+    klt_feat *fout = BATCH ? a.pairs[blockIdx.y].out : a.out;
+    const bool valid = f < a.n;
+    const klt_feat ft = fin[valid ? f : a.n - 1];
+    const bool tracked_feature = valid && ft.val >= 0;       // only live features are tracked, trackFeatures.py:253
+    if (valid && ft.val < 0 && s == 0) fout[f] = ft;
+    if (!__any(tracked_feature)) return;
+    const int L = a.nlevels;
+    constexpr int WCT = 7, w = 7, n = 49, hw = 3;
+    constexpr int npad = (n + 3) & ~3;
+    float *const gl = lds + g * 5 * npad;                    // this feature's five product arrays
+    const int qr = s >> 1, qh = s & 1;                       // my quad: footprint row qr, columns 4 qh .. 4 qh + 3
+    const int k0 = qr * w + 4 * qh;                          // window index of my first sample (qr, 4 qh)
+    const float one_plus_eps = 1.001f;
+
+    // trackFeatures.py:255-265
+    float xloc = ft.x, yloc = ft.y;
+    for (int r = 0; r < L; r++) { xloc = xloc * a.inv_ss; yloc = yloc * a.inv_ss; }
+    float xout = xloc, yout = yloc;
+    int val = KLT_TRACKED;
+    uint32_t aux = 0;
+    bool alive = tracked_feature;                            // still descending the pyramid
+
+    for (int r = L - 1; r >= 0; r--) {
+        if (!__any(alive)) break;
+        const TrackLevel &lv = levels[r];
+        const int nc = lv.nc, nr = lv.nr;
+        if (alive) { xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss; }
+
+        // image-1 template (trackFeatures.py:102-104); a window that leaves image 1 ends the feature
+        const Bilinear b1 = make_bilinear(xloc, yloc);
+        const bool t_ok = b1.ix - hw >= 0 && b1.iy - hw >= 0 && b1.ix + hw + 2 <= nc && b1.iy + hw + 2 <= nr;
+        const bool run = alive && t_ok;
+        float t_i[4], t_gx[4], t_gy[4];
+        {
+            const size_t q = run ? (size_t)(b1.iy - hw + qr) * nc + (b1.ix - hw + 4 * qh) : (size_t)0;
+            sample_quad(load_quad(lv.i1 + q), b1, t_i);
+            sample_quad(load_quad(lv.gx1 + q), b1, t_gx);
+            sample_quad(load_quad(lv.gy1 + q), b1, t_gy);
+        }
+
+        int it = 0, status = KLT_OOB;
+        float x2 = xout, y2 = yout;
+        bool iterating = run;
+        while (__any(iterating)) {
+            // trackFeaturesUtils.pyx:428-431
+            const bool oob = (double)(x2 - (float)hw) < 0. || (float)nc - (x2 + (float)hw) < one_plus_eps ||
+                             (double)(y2 - (float)hw) < 0. || (float)nr - (y2 + (float)hw) < one_plus_eps;
+            if (iterating && oob) { status = KLT_OOB; iterating = false; }
+            const bool act = iterating;
+            const Bilinear b2 = make_bilinear(x2, y2);
+            const size_t q = act ? (size_t)(b2.iy - hw + qr) * nc + (b2.ix - hw + 4 * qh) : (size_t)0;
+            float s_i[4], s_gx[4], s_gy[4];
+            sample_quad(load_quad(lv.i2 + q), b2, s_i);
+            sample_quad(load_quad(lv.gx2 + q), b2, s_gx);
+            sample_quad(load_quad(lv.gy2 + q), b2, s_gy);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if (qr < w && 4 * qh + m < w) {
+                    const int k = k0 + m;
+                    const float diff = t_i[m] - s_i[m];
+                    const float sx = t_gx[m] + s_gx[m];
+                    const float sy = t_gy[m] + s_gy[m];
+                    gl[k] = sx * sx;
+                    gl[npad + k] = sx * sy;
+                    gl[2 * npad + k] = sy * sy;
+                    gl[3 * npad + k] = diff * sx;
+                    gl[4 * npad + k] = diff * sy;
+                }
+            }
+            wave_lds_sync();
+            float acc = 0.f;
+            if (s < 5) {
+                const float *T = gl + s * npad;
+                if (WCT > 0) {
+                    const float4 *T4 = reinterpret_cast<const float4 *>(T);
+#pragma unroll
+                    for (int q = 0; q < (WCT * WCT + 3) / 4; q++) {
+                        const float4 v = T4[q];
+                        acc = acc + v.x;
+                        if (4 * q + 1 < WCT * WCT) acc = acc + v.y;
+                        if (4 * q + 2 < WCT * WCT) acc = acc + v.z;
+                        if (4 * q + 3 < WCT * WCT) acc = acc + v.w;
+                    }
+                } else {
+                    for (int k = 0; k < n; k++) acc = acc + T[k];
+                }
+            }
+            wave_lds_sync();
+            const float gxx = __shfl(acc, glead), gxy = __shfl(acc, glead + 1), gyy = __shfl(acc, glead + 2);
+            const float ex = __shfl(acc, glead + 3) * a.step, ey = __shfl(acc, glead + 4) * a.step;
+            const float p1 = gxx * gyy, p2 = gxy * gxy;
+            const float det = p1 - p2;
+            const bool small_det = det < a.small;
+            if (act && small_det) { status = KLT_SMALL_DET; iterating = false; }
+            const float n1 = gyy * ex, n2 = gxy * ey, n3 = gxx * ey, n4 = gxy * ex;
+            const float dx = (n1 - n2) / det;
+            const float dy = (n3 - n4) / det;
+            if (act && !small_det) {
+                status = KLT_TRACKED;
+                x2 = x2 + dx;
+                y2 = y2 + dy;
+                it++;
+                iterating = (fabsf(dx) >= a.th || fabsf(dy) >= a.th) && it < a.max_iterations;
+            }
+        }
+        if (run) { xout = x2; yout = y2; }
+
+        // trackFeatures.py:110 -- Python floats: half-window 3.5, eps 1.001 as doubles
+        const double x2d = (double)x2, y2d = (double)y2, hwd = a.half_window;
+        if (run && (x2d - hwd < 0.0 || (double)nc - (x2d + hwd) < 1.001 || y2d - hwd < 0.0 || (double)nr - (y2d + hwd) < 1.001))
+            status = KLT_OOB;
+
+        // residue, trackFeatures.py:118-125
+        const bool need_res = run && status == KLT_TRACKED && a.use_max_residue;
+        if (__any(need_res)) {
+            const Bilinear b2 = make_bilinear(x2, y2);
+            const size_t q = need_res ? (size_t)(b2.iy - hw + qr) * nc + (b2.ix - hw + 4 * qh) : (size_t)0;
+            float s_i[4];
+            sample_quad(load_quad(lv.i2 + q), b2, s_i);
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                if (qr < w && 4 * qh + m < w) gl[k0 + m] = fabsf(t_i[m] - s_i[m]);
+            wave_lds_sync();
+            float sres = pairwise_block_group(gl, n, s);
+            wave_lds_sync();
+            sres = __shfl(sres, glead);
+            if (need_res && sres / (float)n > a.max_residue) status = KLT_LARGE_RESIDUE;
+        }
+
+        int lvl_val;
+        if (!t_ok) lvl_val = KLT_OOB;
+        else if (a.retain) lvl_val = KLT_TRACKED;                                               // :127-129
+        else if (status == KLT_SMALL_DET || status == KLT_OOB || status == KLT_LARGE_RESIDUE) lvl_val = status;
+        else if (it >= a.max_iterations) lvl_val = KLT_MAX_ITERATIONS;
+        else lvl_val = KLT_TRACKED;
+        if (alive) {
+            val = lvl_val;
+            aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);
+            alive = !(val == KLT_SMALL_DET || val == KLT_OOB);                                  // :284-285
+        }
+    }
+    if (tracked_feature && s == 0) {
+        klt_feat o;
+        o.aux = (int32_t)aux;
+        const double xd = (double)xout, yd = (double)yout;
+        const bool oob = val == KLT_OOB ||
+                         xd < a.borderx || xd > (double)(a.ncols - 1) - a.borderx ||
+                         yd < a.bordery || yd > (double)(a.nrows - 1) - a.bordery;   // :288-308
+        if (oob) { o.x = -1.f; o.y = -1.f; o.val = KLT_OOB; }
+        else if (val == KLT_SMALL_DET || val == KLT_LARGE_RESIDUE || val == KLT_MAX_ITERATIONS) {
+            o.x = -1.f; o.y = -1.f; o.val = val;
+        } else { o.x = xout; o.y = yout; o.val = KLT_TRACKED; }
+        fout[f] = o;
+    }
+}
+
 // Features sorted by image row (counting sort, one workgroup): order[0..n) = feature indices by ascending (int)y; lost
 // features go last.  The order within a row is whatever the atomics give -- every feature is still tracked exactly once and
 // written to its own slot, so the result does not depend on it.
@@ -817,13 +1048,17 @@ void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, 
     hipLaunchKernelGGL(track_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, nlevels, stats);
 }
 
-// 0 (default): track_kernel for every window; for windows of <= 64 samples also 1: track_kernel_pf (a third of the dependent
-// round trips and a quarter of the vector loads) and 2: track_kernel_q (four features per wavefront, ~30 % fewer VALU
-// instructions per feature).  All three give bit-identical records, and with several pairs in flight all three settle at the
-// same 11.4-11.8 us per 5000 features (tools/stage_throughput.py); on one stream 0 is the fastest (20.5 / 21.5 / 25.2 us).  Nor
-// does halving the HBM traffic help (KLT_OPT_TRACK_XCD_ORDER: 55 -> 30 MB per launch, 13.0 us).  KLT_TRACK_VARIANT in the
-// environment sets the initial value.
-int g_track_variant = getenv("KLT_TRACK_VARIANT") ? atoi(getenv("KLT_TRACK_VARIANT")) : 0;
+// Tracker kernel for 7x7 windows (other windows always take track_kernel, or 1 / 2 / 3 where they apply):
+//   4 (default)  track_kernel_qv  four features per wavefront, one 16-byte load per lane, image and footprint;
+//   0            track_kernel     one feature per wavefront (the fastest on ONE stream: 17.6 vs 18.6 us per 5000 features);
+//   1            track_kernel_pf  footprints requested ahead, one pixel per lane;
+//   2            track_kernel_q   four features per wavefront, per-sample loads;
+//   3            track_kernel<GRID>  one feature per wavefront, one pixel per lane.
+// All give bit-identical records.  With pairs in flight 0-3 share one throughput floor (1.93 ns per feature: 0 is bound by VALU
+// issue, 2 -- with 42 % fewer VALU instructions -- by the address / L1 path; nor does halving the HBM traffic help,
+// KLT_OPT_TRACK_XCD_ORDER); 4 removes both and reaches 1.62 ns (tools/track_scaling.py).  KLT_TRACK_VARIANT in the environment
+// sets the initial value.
+int g_track_variant = getenv("KLT_TRACK_VARIANT") ? atoi(getenv("KLT_TRACK_VARIANT")) : 4;
 
 template <bool BATCH>
 static int launch_track_t(hipStream_t s, const TrackArgs &a)
@@ -831,6 +1066,25 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     const int n = a.window * a.window;
     const size_t lds = 5 * (size_t)((n + 3) & ~3) * sizeof(float);
     const dim3 grid(a.n, BATCH ? a.npairs : 1), block(64);
+    if (g_track_variant == 3 && a.window <= 7) {
+        if (!BATCH && a.order) {
+            hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
+            const dim3 gx(8 * a.order_chunk);
+            if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH, true>), gx, block, lds, s, a);
+            else hipLaunchKernelGGL((track_kernel<1, 0, BATCH, true>), gx, block, lds, s, a);
+            return 0;
+        }
+        if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((track_kernel<1, 0, BATCH, true>), grid, block, lds, s, a);
+        return 0;
+    }
+    // (short lists keep one feature per wavefront: with a few hundred features the launch is pure latency, which four features
+    // in lock step lengthen)
+    if (g_track_variant == 4 && a.window == 7 && (long long)a.n * (BATCH ? a.npairs : 1) >= 2048) {
+        const dim3 gq((a.n + 3) / 4, BATCH ? a.npairs : 1);
+        hipLaunchKernelGGL((track_kernel_qv<BATCH>), gq, block, 4 * lds, s, a);
+        return 0;
+    }
     if (g_track_variant == 2 && n <= 64) {
         const dim3 gq((a.n + 3) / 4, BATCH ? a.npairs : 1);
         if (a.window == 7) hipLaunchKernelGGL((track_kernel_q<7, BATCH>), gq, block, 4 * lds, s, a);

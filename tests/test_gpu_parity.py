@@ -435,12 +435,13 @@ def test_track_retain(ctx, cfg1, img0, img1):
     assert_feats(out, cfg1["trk100_retain_x"], cfg1["trk100_retain_y"], cfg1["trk100_retain_val"], "track retainTrackers")
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("window,levels,ss,retain,mr", [(7, 2, 4, False, 10.0), (7, 2, 4, True, 10.0), (7, 3, 2, False, None),
                                                         (5, 2, 4, False, 10.0), (3, 2, 2, False, 5.0)])
 def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, retain, mr, variant):
     """KLT_OPT_TRACK_VARIANT=1 (footprints requested ahead, one pixel per lane + lane shuffles) and =2 (four features per
-    wavefront): same records as the oracle, and for the default context as the reference's goldens."""
+    wavefront), =3 (one pixel per lane), =4 (four features per wavefront with quad loads, the default for 7x7): same records as
+    the plain kernel (=0) and the oracle, and for the default context as the reference's goldens."""
     tc = make_tc(levels=levels, ss=ss, window=window, max_residue=mr, retainTrackers=retain)
     p = params_from_tc(tc)
     ctx.configure(tc)
@@ -452,9 +453,10 @@ def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, r
     try:
         ctx.set_option(11, variant)
         out, _ = ctx.track(0, 1, fl)
-    finally:
         ctx.set_option(11, 0)
-    ref, _ = ctx.track(0, 1, fl)
+        ref, _ = ctx.track(0, 1, fl)
+    finally:
+        ctx.set_option(11, 4)               # the default
     assert np.array_equal(out, ref), "tracker variants disagree"
     a0, a1 = np.asarray(img0, np.float32), np.asarray(img1, np.float32)
     ofl = ko.select_good_features(p, a0, 100)
@@ -462,6 +464,37 @@ def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, r
     assert_feats(out, *oracle_feats(ofl), what="prefetching tracker, window %d" % window)
     if (window, levels, ss, retain, mr) == (7, 2, 4, False, 10.0):
         assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "prefetching tracker vs golden")
+
+
+@pytest.mark.parametrize("mr,retain", [(10.0, False), (None, False), (10.0, True)])
+def test_track_quad_kernel_long_list(ctx, ko, mr, retain):
+    """The default tracker for 7x7 windows and lists of 2048 features and more (four features per wavefront, 16-byte loads) against
+    the one-feature-per-wavefront kernel and the oracle, with lost features and a list length that is not a multiple of four."""
+    from pyfeaturetrack_amd import synth
+    f0, f1 = synth.synth_pair(1280, 720, 6)
+    tc = make_tc(levels=3, ss=4, max_residue=mr, retainTrackers=retain)
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(0, f0)
+    ctx.upload(1, f1)
+    ctx.build_pyramids(0)
+    ctx.build_pyramids(1)
+    fl, placed = ctx.select(0, 2303)
+    assert placed == 2303
+    fl["val"][5::11] = -4
+    try:
+        ctx.set_option(11, 4)
+        out, _ = ctx.track(0, 1, fl)
+        ctx.set_option(11, 0)
+        ref, _ = ctx.track(0, 1, fl)
+    finally:
+        ctx.set_option(11, 4)
+    assert np.array_equal(out, ref)
+    a0, a1 = f0.astype(np.float32), f1.astype(np.float32)
+    ofl = ko.select_good_features(p, a0, 2303)
+    ofl["val"][5::11] = -4
+    ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), ofl)
+    assert_feats(out, *oracle_feats(ofl), what="quad tracker, 2303 features")
 
 
 def test_track_xcd_aware_order(ctx, ko):
@@ -477,12 +510,14 @@ def test_track_xcd_aware_order(ctx, ko):
     ctx.build_pyramids(1)
     fl, _ = ctx.select(0, 1500)
     fl["val"][::7] = -3                     # some lost features in the list
-    ref, _ = ctx.track(0, 1, fl)
     try:
+        ctx.set_option(11, 0)               # the option applies to the one-feature-per-wavefront kernels
+        ref, _ = ctx.track(0, 1, fl)
         ctx.set_option(13, 1)
         out, _ = ctx.track(0, 1, fl)
     finally:
         ctx.set_option(13, 0)
+        ctx.set_option(11, 4)
     assert np.array_equal(out, ref)
     assert np.array_equal(out["val"][::7], fl["val"][::7])
 
