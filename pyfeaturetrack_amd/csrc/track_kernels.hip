@@ -817,7 +817,13 @@ __global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x, g = lane >> 4, s = lane & 15, glead = lane & 48;
-    const int f = 4 * blockIdx.x + g;
+    int f = 4 * blockIdx.x + g;
+    if (!BATCH && a.order) {
+        // XCD-aware order (KLT_OPT_TRACK_XCD_ORDER): workgroup b runs on XCD b % 8 and takes four consecutive features of that
+        // XCD's band of the row-sorted list
+        const int c = blockIdx.x & 7, pos = c * a.order_chunk + 4 * (blockIdx.x >> 3) + g;
+        f = (4 * (blockIdx.x >> 3) + g < a.order_chunk && pos < a.n) ? (int)a.order[pos] : a.n;
+    }
     const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
     const klt_feat *fin = BATCH ? a.pairs[blockIdx.y].in : a.in;
     klt_feat *fout = BATCH ? a.pairs[blockIdx.y].out : a.out;
@@ -1081,6 +1087,11 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     // (short lists keep one feature per wavefront: with a few hundred features the launch is pure latency, which four features
     // in lock step lengthen)
     if (g_track_variant == 4 && a.window == 7 && (long long)a.n * (BATCH ? a.npairs : 1) >= 2048) {
+        if (!BATCH && a.order) {
+            hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
+            hipLaunchKernelGGL((track_kernel_qv<BATCH>), dim3(8 * ((a.order_chunk + 3) / 4)), block, 4 * lds, s, a);
+            return 0;
+        }
         const dim3 gq((a.n + 3) / 4, BATCH ? a.npairs : 1);
         hipLaunchKernelGGL((track_kernel_qv<BATCH>), gq, block, 4 * lds, s, a);
         return 0;
@@ -1096,7 +1107,7 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
         else hipLaunchKernelGGL((track_kernel_pf<0, BATCH>), grid, block, lds, s, a);
         return 0;
     }
-    if (!BATCH && a.order && g_track_variant == 0) {
+    if (!BATCH && a.order) {                 // (the API sets `order` for 7x7 windows only)
         hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
         const dim3 gx(8 * a.order_chunk);
         if (a.window == 7) { hipLaunchKernelGGL((track_kernel<1, 7, BATCH>), gx, block, lds, s, a); return 0; }
