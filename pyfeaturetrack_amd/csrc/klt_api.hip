@@ -86,9 +86,10 @@ struct klt_ctx {
     float *h1 = nullptr;                      // H1 planes of the fused first reduction (one per frame of a batch)
     size_t h1_cap = 0;
     bool fuse_hreduce = true;                 // KLT_OPT_FUSED_HREDUCE
-    bool track_xcd_order = false;             // KLT_OPT_TRACK_XCD_ORDER
+    bool track_xcd_order = true;              // KLT_OPT_TRACK_XCD_ORDER
     uint32_t *track_order = nullptr;
     size_t track_order_cap = 0;
+    int order_n = -1, order_age = 0;          // length of the list the stored order was computed from, and how many launches ago
     // selection scratch
     float *sel_img = nullptr, *sel_gx = nullptr, *sel_gy = nullptr, *sat = nullptr, *valmap = nullptr;
     size_t sel_cap = 0;               // pixels
@@ -1355,6 +1356,12 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
         if (int rc = ensure(c, c->track_order, c->track_order_cap, (size_t)n)) return rc;
         a.order = c->track_order;
         a.order_chunk = (n + 7) / 8;
+        // the order is only a locality hint (any permutation of 0..n-1 tracks every feature exactly once): it is recomputed when
+        // the list length changes and every 64th launch (a sequence's features drift, and its lists alternate between two
+        // buffers); in between the stored permutation is reused
+        a.order_refresh = (c->order_n != n || c->order_age >= 64) ? 1 : 0;
+        if (a.order_refresh) { c->order_n = n; c->order_age = 0; }
+        c->order_age++;
     }
     if (int rc = tracker_begin(c)) return rc;
     {

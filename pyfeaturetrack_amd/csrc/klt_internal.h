@@ -55,6 +55,8 @@ struct TrackArgs {
     int npairs;
     uint32_t *order;                    // single-pair launch, optional: scratch [n] for the XCD-aware feature order (see track_order_kernel)
     int order_chunk;                    // ceil(n / 8): features per XCD
+    int order_refresh;                  // 1: sort before this launch; 0: reuse the order of an earlier launch on the same buffer (any
+                                        // permutation of 0..n-1 is correct; an old one is only a little less local)
     double half_window;          // window/2 as the Python float (3.5 for 7x7), trackFeatures.py:88-89
     double borderx, bordery;
     int n, nlevels, window, max_iterations, use_max_residue, retain, ncols, nrows;

@@ -1074,7 +1074,7 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     const dim3 grid(a.n, BATCH ? a.npairs : 1), block(64);
     if (g_track_variant == 3 && a.window <= 7) {
         if (!BATCH && a.order) {
-            hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
+            if (a.order_refresh) hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
             const dim3 gx(8 * a.order_chunk);
             if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH, true>), gx, block, lds, s, a);
             else hipLaunchKernelGGL((track_kernel<1, 0, BATCH, true>), gx, block, lds, s, a);
@@ -1088,7 +1088,7 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     // in lock step lengthen)
     if (g_track_variant == 4 && a.window == 7 && (long long)a.n * (BATCH ? a.npairs : 1) >= 2048) {
         if (!BATCH && a.order) {
-            hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
+            if (a.order_refresh) hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
             hipLaunchKernelGGL((track_kernel_qv<BATCH>), dim3(8 * ((a.order_chunk + 3) / 4)), block, 4 * lds, s, a);
             return 0;
         }
@@ -1108,7 +1108,7 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
         return 0;
     }
     if (!BATCH && a.order) {                 // (the API sets `order` for 7x7 windows only)
-        hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
+        if (a.order_refresh) hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
         const dim3 gx(8 * a.order_chunk);
         if (a.window == 7) { hipLaunchKernelGGL((track_kernel<1, 7, BATCH>), gx, block, lds, s, a); return 0; }
     }

@@ -498,8 +498,8 @@ def test_track_quad_kernel_long_list(ctx, ko, mr, retain):
 
 
 def test_track_xcd_aware_order(ctx, ko):
-    """KLT_OPT_TRACK_XCD_ORDER: features handed to the tracker sorted by row, one band per XCD -- same records, lost features
-    (passed through) included."""
+    """KLT_OPT_TRACK_XCD_ORDER (default on): features handed to the tracker sorted by row, one band per XCD, the order kept for
+    later launches of the same length -- same records as in list order, lost features (passed through) included."""
     from pyfeaturetrack_amd import synth
     f0, f1 = synth.synth_pair(1280, 720, 4)
     tc = make_tc(levels=3, ss=4, max_residue=10.0)
@@ -510,15 +510,20 @@ def test_track_xcd_aware_order(ctx, ko):
     ctx.build_pyramids(1)
     fl, _ = ctx.select(0, 1500)
     fl["val"][::7] = -3                     # some lost features in the list
+    ref = None
     try:
-        ctx.set_option(11, 0)               # the option applies to the one-feature-per-wavefront kernels
-        ref, _ = ctx.track(0, 1, fl)
-        ctx.set_option(13, 1)
-        out, _ = ctx.track(0, 1, fl)
+        for variant in (0, 3, 4):
+            ctx.set_option(11, variant)
+            ctx.set_option(13, 0)
+            ref, _ = ctx.track(0, 1, fl)
+            ctx.set_option(13, 1)
+            out, _ = ctx.track(0, 1, fl)                 # sorts
+            out2, _ = ctx.track(0, 1, fl[::-1].copy())   # same length, other list: the stored order is reused
+            assert np.array_equal(out, ref), variant
+            assert np.array_equal(out2[::-1], ref), variant
     finally:
-        ctx.set_option(13, 0)
+        ctx.set_option(13, 1)
         ctx.set_option(11, 4)
-    assert np.array_equal(out, ref)
     assert np.array_equal(out["val"][::7], fl["val"][::7])
 
 
