@@ -5,7 +5,7 @@ from pyfeaturetrack_amd.backend import Context
 from pyfeaturetrack_amd.klt import KLT_TrackingContext
 from pyfeaturetrack_amd.params import params_from_tc
 f0, f1 = synth.synth_pair(1920, 1080, seed=1)
-for levels in (1, 3):
+for levels in (1, 2, 3):
     tc = KLT_TrackingContext(); tc.nPyramidLevels, tc.subsampling = levels, 4; tc.KLTUpdateTCBorder()
     p = params_from_tc(tc)
     for nctx in (1, 2, 3):
