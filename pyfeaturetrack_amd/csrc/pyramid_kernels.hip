@@ -403,7 +403,7 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
                     const int i = min(tid + u * NTHR, N0 - 1);          // clamped, unconditional (the last threads repeat a quad)
-                    w[u] = *reinterpret_cast<const uint32_t *>(base + (size_t)(i / W0) * nc + 4 * (i % W0));
+                    w[u] = *reinterpret_cast<const uint32_t *>(base + (unsigned)((i / W0) * nc + 4 * (i % W0)));
                 }
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
