@@ -45,7 +45,7 @@ for case in range(ncases):
     ctx.configure(tc)
     ctx.upload(0, f0); ctx.upload(1, f1)
     ctx.build_pyramids(0); ctx.build_pyramids(1)
-    n = int(rng.integers(20, 400))
+    n = int(rng.integers(20, 400)) if w * h < 1000000 or window != 7 else int(rng.integers(2048, 7000))   # long 7x7 lists: the quad tracker
     fl, placed = ctx.select(0, n, use_pyramid=bool(rng.integers(2)))
     val = ctx.select_intermediate(3)
     out, _ = ctx.track(0, 1, fl)
