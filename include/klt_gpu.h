@@ -102,6 +102,7 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
 #define KLT_OPT_TRACK_VARIANT 11         /* 7x7 windows: 4 (default) four features per wavefront with 16-byte loads; 0: one feature per wavefront; 1: footprints requested ahead; 2: four features per wavefront, per-sample loads; 3: one pixel per lane (same records; process-wide) */
 #define KLT_OPT_FUSED_HREDUCE 12         /* 1 (default): the level-0 kernel also runs the horizontal pass of the first pyramid reduction (subsampling 4); 0: separate reduction kernel */
 #define KLT_OPT_TRACK_XCD_ORDER 13        /* 1 (default): features are handed to the tracker sorted by row, one band of the image per XCD (7x7 windows, single-pair launches; the order is refreshed every 64 launches); 0: list order */
+#define KLT_OPT_FUSED_LEVELS 14           /* 1: every pyramid level >= 1 is ONE launch (vertical reduction from the previous level's H planes + gradients + next H planes; needs KLT_OPT_FUSED_HREDUCE, subsampling 4); 0: separate reduction and gradient launches */
 #define KLT_OPT_PYR_REDUCE_VARIANT 9    /* 0 (default): 1024-thread pyramid reduce; 1: 512-thread all-f32 variant, measured slower (process-wide) */
 int klt_set_option(klt_ctx *ctx, int option, int value);
 

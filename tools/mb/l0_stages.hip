@@ -18,6 +18,7 @@ static void gauss_taps(Taps &g, Taps &d, double sigma, int n)
 int main(int argc, char **argv)
 {
     const bool reduce = argc > 1 && argv[1][0] == 'r';
+    const bool level = argc > 1 && argv[1][0] == 'l';      // pyr_level_kernel on a 480x270 level
     const int nc = 1920, nr = 1080;
     SmoothGradArgs a = {};
     Taps dummy;
@@ -37,7 +38,11 @@ int main(int argc, char **argv)
     pr.src_nc = nc; pr.src_nr = nr; pr.dst_nc = nc / 4; pr.dst_nr = nr / 4; pr.ss = 4; pr.log2ss = 2;
     for (int b = 0; b < 2; b++) { pr.src[b] = a.img[b]; pr.dst[b] = a.gx[b]; }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto go = [&]() { if (reduce) launch_pyr_reduce(0, pr, 2); else launch_smooth_grad(0, a, 2, 0); };
+    LevelArgs la = {};
+    la.reduce = pr.taps; la.ggauss = a.ggauss; la.gderiv = a.gderiv;
+    la.src_nr = nr; la.nc = nc / 4; la.nr = nr / 4; la.hnext_nc = nc / 16;
+    for (int b = 0; b < 2; b++) { la.hsrc[b] = a.img[b]; la.img[b] = a.gx[b]; la.gx[b] = a.gy[b]; la.gy[b] = a.gy[b] + nc * nr / 2; float *h; hipMalloc(&h, 4 * (size_t)(nr / 4) * (nc / 16)); la.hnext[b] = h; }
+    auto go = [&]() { if (level) launch_pyr_level(0, la, 2, true); else if (reduce) launch_pyr_reduce(0, pr, 2); else launch_smooth_grad(0, a, 2, 0); };
     for (int rep = 0; rep < 3; rep++) go();
     hipDeviceSynchronize();
     hipEventRecord(e0);
@@ -48,7 +53,7 @@ int main(int argc, char **argv)
     long long clk[64 * 8];
     hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_stage_clk), sizeof(clk));
     long long t0 = clk[0];
-    const int nrow = reduce ? 15 : 30;
+    const int nrow = level ? 8 : reduce ? 15 : 30;
     for (int b = 0; b < nrow; b++) t0 = clk[b * 8] < t0 ? clk[b * 8] : t0;
     printf("ticks of 10 ns; tile row 8 of frame 0\nblock  start | load  hsm  vsm  hgrad vgrad | total\n");
     for (int b = 0; b < nrow; b++) {
@@ -60,7 +65,7 @@ int main(int argc, char **argv)
     static unsigned hw[8192];
     hipMemcpyFromSymbol(bc, HIP_SYMBOL(g_block_clk), sizeof(bc));
     hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_block_hw), sizeof(hw));
-    const int nb = reduce ? 15 * 34 * 2 : 30 * 34 * 2;
+    const int nb = level ? 8 * 17 * 2 : reduce ? 15 * 34 * 2 : 30 * 34 * 2;
     long long b0 = bc[0], b1 = 0;
     for (int i = 0; i < nb; i++) { if (bc[2 * i] < b0) b0 = bc[2 * i]; if (bc[2 * i + 1] > b1) b1 = bc[2 * i + 1]; }
     printf("first start -> last end: %lld ticks\n", b1 - b0);
