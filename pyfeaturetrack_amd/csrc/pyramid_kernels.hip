@@ -1026,6 +1026,8 @@ __global__ __launch_bounds__(NTHR) void pyr_level_kernel(LevelArgs a)
     const int srow0 = SS * y_first + SS / 2 - HR;                // first staged H row (virtual)
     const int nstage = min(SS * (y_last - y_first) + NR, SH);    // staged H rows
     // ---- stage 0: H rows -> LDS (rows and columns through the reflect maps)
+    __shared__ int ymap[IH];                                     // image row under each tile row (an integer division per entry)
+    if (tid < IH) ymap[tid] = reflect_idx(ty0 - R + tid, nr);
     {
         const bool interior = (nc & 3) == 0 && tx0 - HB >= 0 && tx0 - HB + BW <= nc && srow0 >= 0 && srow0 + nstage <= snr;
         if (interior) {
@@ -1067,26 +1069,54 @@ __global__ __launch_bounds__(NTHR) void pyr_level_kernel(LevelArgs a)
     }
     __syncthreads();
     STAGE_MARK(1);
-    // ---- stage 1: vertical pass -> image tile C (virtual coordinates), interior stored
+    // ---- stage 1: vertical pass -> image tile C (virtual coordinates), interior stored.  A thread makes two vertically adjacent
+    // elements of a column: where the second row is simply the next image row (everywhere but across a reflected border) the two
+    // windows share 17 of their 21 H rows, which are read and widened once.
     {
         float *__restrict__ img = a.img[b];
-        for (int i = tid; i < IH * BW; i += NTHR) {
-            const int r = i / BW, c = i % BW;
-            const int y = reflect_idx(ty0 - R + r, nr);
-            float val = 0.f;
-            if (y >= y_first && y <= y_last) {                   // (always, by construction; guards the LDS index)
-                const float *col = S + (SS * (y - y_first)) * BW + c;      // H row 4 y + 2 - 10 of this column
-                double v[NR];
+        static_assert(IH % 2 == 0, "row pairs");
+        for (int i = tid; i < (IH / 2) * BW; i += NTHR) {
+            const int r = 2 * (i / BW), c = i % BW;
+            const int y0 = ymap[r], y1 = ymap[r + 1];
+            const bool ok0 = y0 >= y_first && y0 <= y_last, ok1 = y1 >= y_first && y1 <= y_last;
+            float val0 = 0.f, val1 = 0.f;
+            if (ok0 && ok1 && y1 == y0 + 1) {
+                const float *col = S + (SS * (y0 - y_first)) * BW + c;
+                double v[NR + SS];
 #pragma unroll
-                for (int j = 0; j < NR; j++) v[j] = (double)col[j * BW];
-                double acc = v[HR] * kr.k[HR];
+                for (int j = 0; j < NR + SS; j++) v[j] = (double)col[j * BW];
+                double a0 = v[HR] * kr.k[HR], a1 = v[HR + SS] * kr.k[HR];
 #pragma unroll
-                for (int jj = -HR; jj < 0; jj++) acc = acc + (v[HR + jj] + v[HR - jj]) * kr.k[HR + jj];
-                val = (float)acc;
+                for (int jj = -HR; jj < 0; jj++) {
+                    a0 = a0 + (v[HR + jj] + v[HR - jj]) * kr.k[HR + jj];
+                    a1 = a1 + (v[HR + SS + jj] + v[HR + SS - jj]) * kr.k[HR + jj];
+                }
+                val0 = (float)a0;
+                val1 = (float)a1;
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int y = h ? y1 : y0;
+                    if (h ? ok1 : ok0) {
+                        const float *col = S + (SS * (y - y_first)) * BW + c;
+                        double v[NR];
+#pragma unroll
+                        for (int j = 0; j < NR; j++) v[j] = (double)col[j * BW];
+                        double acc = v[HR] * kr.k[HR];
+#pragma unroll
+                        for (int jj = -HR; jj < 0; jj++) acc = acc + (v[HR + jj] + v[HR - jj]) * kr.k[HR + jj];
+                        (h ? val1 : val0) = (float)acc;
+                    }
+                }
             }
-            C[i] = val;
-            const int yy = ty0 - R + r, xx = tx0 - HB + c;
-            if (r >= R && r < R + TH_ && c >= HB && c < HB + TW && yy < nr && xx < nc) img[(size_t)yy * nc + xx] = val;
+            C[r * BW + c] = val0;
+            C[(r + 1) * BW + c] = val1;
+            const int xx = tx0 - HB + c;
+            if (c >= HB && c < HB + TW && xx < nc) {
+                const int yy = ty0 - R + r;
+                if (r >= R && r < R + TH_ && yy < nr) img[(size_t)yy * nc + xx] = val0;
+                if (r + 1 >= R && r + 1 < R + TH_ && yy + 1 < nr) img[(size_t)(yy + 1) * nc + xx] = val1;
+            }
         }
     }
     __syncthreads();
