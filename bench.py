@@ -10,15 +10,24 @@ Workload at every N = BASELINE cfg-2 (1920x1080 synthetic pair, 5000 features, 7
 3 pyramid levels / subsampling 4, translation only); with N > 1 every rank runs its own pair
 (seed = rank + 1: weak scaling, the path shards by frame pair with no data-path exchange) and the
 16-byte feature records of 128 consecutive steps are collected in a device-side table and gathered to
-every rank with one RCCL all-gather on a side stream (event-ordered behind the tracker launch,
-overlapped with the next steps' kernels).
+every rank with one RCCL all-gather issued by libkltgpu.so on its side stream (event-ordered behind the
+tracker launch, overlapped with the next steps' kernels).  No torch anywhere.
+
+Launching.  `--gpus N` with N > 1 and no RANK in the environment: this process -- before it touches
+the GPU in any way -- starts N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE and a rendezvous
+file in their environment), forwards rank 0's JSON line and exits non-zero if any rank failed.  Under an
+external launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) the same
+variables are already set and every process is a rank.  The RCCL unique id travels through the
+rendezvous file (pyfeaturetrack_amd/parallel.py).
 
 Consecutive steps go round-robin to `--inflight` contexts (default 3; one HIP stream each, nothing ordering them): frame pairs
 are independent, so the GPU overlaps the kernels of different pairs.  Every step does the full work of one pair; `--inflight 1`
-and `extra.single_stream_ms_per_pair` give the one-stream figure.  Before the W warm-up steps 60 ms of untimed steps bring the
-GPU to its steady state (`--prewarm-ms`).
+and `ms_per_frame_pair` (= `extra.single_stream_ms_per_pair`) give the one-stream figure.  The K-step timed region (barrier +
+synchronise on both sides, MAX over ranks) is repeated `--repeats` times; `ms_per_step` is the median region, the spread is
+in `extra.region_ms_per_step`.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  parity_checked -- the records of the timed steps equal the CPU oracle's on the same pair (the run fails otherwise);
   roofline     -- the dominant kernel of the step (largest share of device time), timed with HIP
                   events on the context's stream in a second pass over the same K steps (events
                   around every launch would distort the un-instrumented `value`);
@@ -26,8 +35,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   Python/Cython/SciPy path) on the same workload, 1 thread, rank 0, N = 1 only.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -37,16 +48,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from pyfeaturetrack_amd import synth                                   # noqa: E402
+# importing the package does not touch the GPU (the library is bound on first use)
+from pyfeaturetrack_amd import parallel, synth                          # noqa: E402
 from pyfeaturetrack_amd.backend import Context                          # noqa: E402
 from pyfeaturetrack_amd.klt import KLT_TrackingContext                  # noqa: E402
 from pyfeaturetrack_amd.params import params_from_tc                    # noqa: E402
 
 WIDTH, HEIGHT, NFEAT = 1920, 1080, 5000
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TOL_PX = 1e-3             # north_star: sub-pixel x/y within 1e-3 (observed: 0)
 FB_SEL, FB_OUT0, FB_OUT1 = 0, 1, 2
-FB_RING0, FB_RING1, FB_VIEW0 = 3, 4, 100
+FB_RING0, FB_RING1, FB_GATH0, FB_GATH1, FB_VIEW0 = 3, 4, 5, 6, 100
 GATHER_EVERY = 128
+DTYPE = "f32 (convolutions accumulate in f64)"
 
 
 def cfg2_context():
@@ -91,7 +105,31 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(p, f0, f1, fl):
+def oracle_track(p, f0, f1, fl):
+    """The CPU oracle's records for one pair (the checker; never the thing measured).  None if the oracle is not built."""
+    try:
+        from oracle import klt_oracle as ko
+    except (ImportError, OSError) as e:
+        print("oracle unavailable: %s" % e, file=sys.stderr)
+        return None
+    a0, a1 = f0.astype(np.float32), f1.astype(np.float32)
+    ofl = fl.copy()
+    ko.set_threads(1)
+    ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), ofl)
+    return ofl
+
+
+def parity_against(out, ofl):
+    """{parity_checked, max_abs_dx, ...} of timed records `out` against the oracle's `ofl` (None: unchecked)."""
+    if ofl is None:
+        return {"parity_checked": False, "parity_note": "oracle library not built on this box"}
+    same_val = bool(np.array_equal(out["val"], ofl["val"]))
+    dx = float(max(np.abs(out["x"].astype(np.float64) - ofl["x"]).max(), np.abs(out["y"].astype(np.float64) - ofl["y"]).max()))
+    return {"parity_checked": bool(same_val and dx <= TOL_PX), "max_abs_dx": dx, "status_codes_equal": same_val,
+            "parity_tolerance_px": TOL_PX, "parity_against": "oracle/klt_oracle.c (pinned to reference-generated goldens)"}
+
+
+def cpu_baseline(p, f0, f1, fl, nfeat, label):
     """Oracle timed on the host: bounded sample of the same workload (about 10-20 s of CPU work)."""
     from oracle import klt_oracle as ko
     a0, a1 = f0.astype(np.float32), f1.astype(np.float32)
@@ -104,7 +142,7 @@ def cpu_baseline(p, f0, f1, fl):
     t = time.perf_counter()
     one_pair()
     t1 = time.perf_counter() - t
-    reps = int(max(2, min(200, 12.0 / max(t1, 1e-3))))      # about 12 s of single-thread work
+    reps = int(max(2, min(200, 10.0 / max(t1, 1e-3))))      # about 10 s of single-thread work
     t = time.perf_counter()
     for _ in range(reps):
         one_pair()
@@ -114,91 +152,216 @@ def cpu_baseline(p, f0, f1, fl):
     ncores = ko.set_threads(usable_cores())
     t = time.perf_counter()
     reps_all = 0
-    while reps_all < 40 and (reps_all < 2 or time.perf_counter() - t < 4.0) and time.perf_counter() - t < 20.0:
+    while reps_all < 40 and (reps_all < 2 or time.perf_counter() - t < 4.0) and time.perf_counter() - t < 12.0:
         one_pair()
         reps_all += 1
     dt_all = (time.perf_counter() - t) / reps_all
     ko.set_threads(1)
-    return {"value": NFEAT / dt, "unit": "features/s", "cores": 1, "kind": "port",
+    return {"value": nfeat / dt, "unit": "features/s", "cores": 1, "kind": "port",
             "ms_per_pair": dt * 1e3,
-            "sample": "%d x (pyramids of both 1920x1080 frames + track 5000 features), oracle/klt_oracle.c, 1 thread" % reps,
-            "all_cores": {"value": NFEAT / dt_all, "cores": ncores, "ms_per_pair": dt_all * 1e3,
+            "sample": "%d x (pyramids of both frames + track %d features) of %s, oracle/klt_oracle.c, 1 thread" % (reps, nfeat, label),
+            "all_cores": {"value": nfeat / dt_all, "cores": ncores, "ms_per_pair": dt_all * 1e3,
                           "sample": "%d x the same pair, OpenMP over image lines and features" % reps_all}}
 
 
-def run_cfg4(args, json_fd):
-    """BASELINE cfg-4 (not the headline line): a shard of independent 1280x720 pairs, 2000 features each, 7x7,
-    3 levels / ss 4.  One batched pyramid build (frames share launches through blockIdx.z) and ONE tracker launch
-    per step; shows what the kernels do when the grids are large."""
-    pairs, w, h, nf = args.pairs, 1280, 720, 2000
-    tc = cfg2_context()
-    p = params_from_tc(tc)
-    ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
-    ctx.set_params(p)
-    for i in range(pairs):
-        f0, f1 = synth.synth_pair(w, h, seed=i)
-        ctx.upload(2 * i, f0)
-        ctx.upload(2 * i + 1, f1)
-    slots = list(range(2 * pairs))
-    ctx.build_pyramids_batch(slots, sync=True)
-    for i in range(pairs):
-        ctx.select_async(2 * i, 1, True, 2 * i, nf)
-    ctx.sync()
-    table = [(2 * i, 2 * i + 1, 2 * i, 2 * i + 1) for i in range(pairs)]
-
-    def step():
-        ctx.build_pyramids_batch(slots)
-        ctx.track_batch_async(table, nf)
-
-    for _ in range(args.warmup):
-        step()
-    ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync()
-    elapsed = time.perf_counter() - t0
-    ctx.track_stats_reset()
-    ctx.timing_enable(True)
-    for _ in range(args.steps):
-        step()
-    kernels = ctx.timing_read()
-    ctx.timing_enable(False)
-    st = ctx.track_stats()
-    st = {k: ([x / (args.steps * pairs) for x in v] if isinstance(v, list) else v / (args.steps * pairs)) for k, v in st.items()}
-    pyr_bytes, track_bytes = algorithmic_bytes(p, w, h, st, nf)
-    step_bytes = pairs * (2 * pyr_bytes + track_bytes)
-    tracked = sum(int(np.count_nonzero(ctx.featbuf_download(2 * i + 1, nf)["val"] >= 0)) for i in range(pairs))
-    line = {"metric": "features tracked/sec", "value": pairs * nf * args.steps / elapsed, "unit": "features/s", "n_gpus": 1,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "ms_per_frame_pair": elapsed / args.steps / pairs * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (convolutions accumulate in f64)", "data": "synthetic",
-            "config": {"workload": "cfg-4 shard: %d independent 1280x720 pairs per step, 2000 features each, 7x7, 3 levels "
-                                   "(subsampling 4); batched pyramid build + one tracker launch" % pairs,
-                       "pairs_per_step": pairs, "tracked": tracked},
-            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "step_algorithmic_bytes": step_bytes,
-                         "achieved": step_bytes / elapsed * args.steps / 1e9,
-                         "frac": step_bytes / elapsed * args.steps / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernels": {k["name"]: {"us_per_launch": 1e3 * k["total_ms"] / k["launches"],
-                                                 "launches_per_step": k["launches"] / args.steps} for k in kernels}},
-            "cpu_baseline": None}
-    ctx.close()
-    os.write(json_fd, (json.dumps(line) + "\n").encode())
+def file_sha16(rel):
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
-def _emit(json_fd, line):
-    os.write(json_fd, (json.dumps(line) + "\n").encode())
+def committed_counters(name, kernel_family):
+    """Per-launch PMC figures of `kernel_family` from profiles/<name> -- NOT measurements of this run: they come from the
+    builder's rocprofv3 --pmc passes (tools/pmc_traffic.py, tools/pmc_sq.py) and carry their provenance; they are dropped when
+    the kernel source they were collected for is no longer the one in the tree."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    data = json.load(open(path))
+    meta = data.get("_meta", {})
+    for rel, sha in (meta.get("kernel_source_sha16") or {}).items():
+        if file_sha16(rel) != sha:
+            return None, "profiles/%s is stale: %s changed since it was collected" % (name, rel)
+    if not meta:
+        return None, "profiles/%s carries no provenance record" % name
+    return data.get(kernel_family), "profiles/%s, %s" % (name, meta.get("source", "builder gpurun"))
 
 
-def _base_line(value, steps, warmup, ms_step, workload, extra_cfg=None, pairs=1):
+# ================================================================================== timing helpers
+class Ranks:
+    """Rank bookkeeping + the barrier / max-over-ranks of the timing contract, through libkltgpu's RCCL entry points."""
+
+    def __init__(self, args):
+        self.rank, self.local_rank, self.world = parallel.world_from_env()
+        if self.world != args.gpus and self.world > 1:
+            print("warning: WORLD_SIZE=%d but --gpus %d" % (self.world, args.gpus), file=sys.stderr)
+        self.distributed = self.world > 1 or os.environ.get("KLT_FORCE_DIST") == "1"   # the env var exercises the RCCL path on one GPU
+        self.ctxs = []
+
+    def attach(self, ctxs):
+        """One communicator per context, same order on every rank."""
+        self.ctxs = list(ctxs)
+        if self.distributed:
+            parallel.init_communicators(self.ctxs, self.rank, self.world)
+            self.max_over_ranks(0.0)                      # first collective: RCCL's lazy set-up, and every rank has joined
+            parallel.cleanup_rendezvous(self.rank)
+
+    def sync_local(self):
+        for cx in self.ctxs:
+            cx.sync()                                      # stream + copy stream + this context's collectives
+
+    def max_over_ranks(self, v):
+        if not self.distributed:
+            return v
+        return self.ctxs[0].comm_allreduce_max([float(v)])[0]
+
+    def fence(self):
+        """everything enqueued so far has finished on every rank"""
+        self.sync_local()
+        self.max_over_ranks(0.0)
+
+    def timed(self, fn):
+        """fence; run fn(); synchronise; elapsed seconds = MAX over ranks"""
+        self.fence()
+        t0 = time.perf_counter()
+        fn()
+        enq = time.perf_counter() - t0
+        self.sync_local()
+        el = time.perf_counter() - t0
+        return self.max_over_ranks(el), enq
+
+
+def timed_regions(ranks, run_region, steps, repeats, budget_s=25.0):
+    """`repeats` K-step regions (each bracketed as the contract says).  Returns (median seconds per region, all regions, host
+    enqueue seconds of the median region).  The repeat count shrinks (never below 5) if the regions are long."""
+    el, enq = ranks.timed(run_region)
+    regions = [(el, enq)]
+    n = repeats
+    if el * repeats > budget_s:
+        n = max(5, int(budget_s / max(el, 1e-9)))
+    n = int(ranks.max_over_ranks(n)) if ranks.distributed else n      # every rank runs the same number of regions
+    while len(regions) < n:
+        regions.append(ranks.timed(run_region))
+    regions.sort()
+    med = regions[len(regions) // 2]
+    return med[0], [r[0] for r in regions], med[1]
+
+
+def emit(json_fd, line):
+    os.write(json_fd, (json.dumps(line) + "\n").encode())      # the ONE JSON line on the real stdout
+
+
+def base_line(value, n_gpus, steps, warmup, ms_step, ms_pair, workload, scaling="weak", extra_cfg=None):
     cfg = {"workload": workload}
     cfg.update(extra_cfg or {})
-    return {"metric": "features tracked/sec", "value": value, "unit": "features/s", "n_gpus": 1, "steps": steps,
-            "warmup": warmup, "ms_per_step": ms_step, "ms_per_frame_pair": ms_step / pairs, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (convolutions accumulate in f64)", "data": "synthetic",
+    return {"metric": "features tracked/sec", "value": value, "unit": "features/s", "n_gpus": n_gpus, "steps": steps,
+            "warmup": warmup, "ms_per_step": ms_step, "ms_per_frame_pair": ms_pair, "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": cfg, "roofline": None, "cpu_baseline": None}
 
 
+# ========================================================================================== cfg-4
+def run_cfg4(args, json_fd):
+    """BASELINE cfg-4: 256 independent 1280x720 pairs (seeds 0..255), 2000 features each, 7x7, 3 levels / ss 4, sharded
+    contiguously over the ranks (32 per GPU at N = 8), frames resident in HBM.  Per step every rank builds the pyramids
+    of its whole shard (frames share launches through blockIdx.z), tracks it with ONE launch into a device-side
+    [pairs x features] table and the table is gathered to rank 0 with one RCCL gather.  Total work is fixed: strong scaling."""
+    ranks = Ranks(args)
+    total, w, h, nf = args.pairs, 1280, 720, 2000
+    mine = parallel.shard_range(total, ranks.world, ranks.rank)
+    pairs = len(mine)
+    if ranks.distributed and total % ranks.world:
+        raise SystemExit("--pairs must be a multiple of the number of ranks")
+    tc = cfg2_context()
+    p = params_from_tc(tc)
+    ctx = Context(ranks.local_rank)
+    ctx.set_params(p)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, usable_cores(16) // max(1, min(ranks.world, 8)))) as ex:
+        frames = list(ex.map(lambda i: synth.synth_pair(w, h, seed=i), mine))
+    for k, (f0, f1) in enumerate(frames):
+        ctx.upload(2 * k, f0)
+        ctx.upload(2 * k + 1, f1)
+    slots = list(range(2 * pairs))
+    ctx.build_pyramids_batch(slots, sync=True)
+    T_IN, T_OUT, T_ALL, V_IN, V_OUT = 0, 1, 2, 1000, 1000 + pairs
+    ctx.featbuf_alloc(T_IN, pairs * nf)
+    ctx.featbuf_alloc(T_OUT, pairs * nf)
+    for k in range(pairs):
+        ctx.featbuf_view(V_IN + k, T_IN, k * nf, nf)
+        ctx.featbuf_view(V_OUT + k, T_OUT, k * nf, nf)
+        ctx.select_async(2 * k, 1, True, V_IN + k, nf)
+    ctx.sync()
+    table = [(2 * k, 2 * k + 1, V_IN + k, V_OUT + k) for k in range(pairs)]
+    ranks.attach([ctx])
+    gather = parallel.ShardGather(ctx, T_OUT, T_ALL, pairs, nf, root=0) if ranks.distributed else None
+
+    def step():
+        ctx.build_pyramids_batch(slots)
+        if gather:
+            ctx.comm_fence_featbuf(T_OUT)          # the gather of the previous step has read the table
+        ctx.track_batch_async(table, nf)
+        if gather:
+            gather.gather_async()
+
+    def region():
+        for _ in range(args.steps):
+            step()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    el, regions, enq = timed_regions(ranks, region, args.steps, args.repeats)
+    # what was timed, against the oracle: the first pair of rank 0's shard
+    out = ctx.featbuf_download(T_OUT, pairs * nf).reshape(pairs, nf)
+    fl0 = ctx.featbuf_download(V_IN, nf)
+    par = parity_against(out[0], oracle_track(p, frames[0][0], frames[0][1], fl0)) if ranks.rank == 0 else {}
+    gathered_ok = None
+    if gather:
+        full = gather.result()
+        if ranks.rank == 0:
+            gathered_ok = bool(full.shape == (total, nf) and np.array_equal(full[:pairs], out))
+    roof = None
+    if ranks.rank == 0:
+        ctx.track_stats_reset()
+        ctx.timing_enable(True)
+        for _ in range(min(args.steps, 20)):
+            ctx.build_pyramids_batch(slots)
+            ctx.track_batch_async(table, nf)
+        kernels = ctx.timing_read()
+        ctx.timing_enable(False)
+        nst = min(args.steps, 20)
+        st = ctx.track_stats()
+        st = {k: ([x / (nst * pairs) for x in v] if isinstance(v, list) else v / (nst * pairs)) for k, v in st.items()}
+        pyr_bytes, track_bytes = algorithmic_bytes(p, w, h, st, nf)
+        step_bytes = total * (2 * pyr_bytes + track_bytes)
+        roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS * ranks.world, "step_algorithmic_bytes": step_bytes,
+                "achieved": step_bytes / el * args.steps / 1e9, "frac": step_bytes / el * args.steps / 1e9 / (HBM_PEAK_GBS * ranks.world),
+                "traffic": None,
+                "kernels_rank0": {k["name"]: {"us_per_launch": 1e3 * k["total_ms"] / k["launches"],
+                                              "launches_per_step": k["launches"] / nst} for k in kernels}}
+    ctx.close()
+    if ranks.rank == 0:
+        ms_step = el / args.steps * 1e3
+        tracked = int(np.count_nonzero(out["val"] >= 0))
+        line = base_line(total * nf * args.steps / el, ranks.world, args.steps, args.warmup, ms_step, ms_step / total,
+                         "cfg-4: %d independent 1280x720 pairs per step (%d per GPU), 2000 features each, 7x7, 3 levels "
+                         "(subsampling 4); per rank: batched pyramid build + one tracker launch + one RCCL gather of the "
+                         "[pairs x 2000] record table to rank 0" % (total, pairs), scaling="strong",
+                         extra_cfg={"pairs_per_step": total, "pairs_per_rank": pairs, "tracked_rank0": tracked,
+                                    "rccl_ranks": ranks.world if ranks.distributed else 0, "gathered_table_ok": gathered_ok,
+                                    "parallelism": "pairs sharded contiguously, %d per GPU; no data-path collective, one gather" % pairs})
+        line.update(par)
+        line["roofline"] = roof
+        line["extra"] = {"region_ms_per_step": {"median": ms_step, "min": min(regions) / args.steps * 1e3,
+                                                "max": max(regions) / args.steps * 1e3, "regions": len(regions)},
+                         "host_enqueue_ms_per_step": enq / args.steps * 1e3}
+        emit(json_fd, line)
+        if par and not par.get("parity_checked") and "max_abs_dx" in par:
+            raise SystemExit("timed records differ from the oracle: %r" % par)
+
+
+# ==================================================================================== cfg-1 / 3 / 5
 def run_cfg1(args, json_fd):
     """BASELINE cfg-1: img0.pgm -> img1.pgm, 100 features, default context (7x7, 2 levels / ss 4), max_residue 10."""
     from tests.conftest import read_pgm
@@ -231,9 +394,11 @@ def run_cfg1(args, json_fd):
     el = time.perf_counter() - t0
     out = ctx.featbuf_download(1, 100)
     ctx.close()
-    _emit(json_fd, _base_line(100 * args.steps / el, args.steps, args.warmup, el / args.steps * 1e3,
-                              "cfg-1: img0.pgm -> img1.pgm (320x240), 100 features, 7x7, 2 levels (ss 4), max_residue 10",
-                              {"tracked": int((out["val"] >= 0).sum()), "ms_select_100": ms_select}))
+    line = base_line(100 * args.steps / el, 1, args.steps, args.warmup, el / args.steps * 1e3, el / args.steps * 1e3,
+                     "cfg-1: img0.pgm -> img1.pgm (320x240), 100 features, 7x7, 2 levels (ss 4), max_residue 10",
+                     extra_cfg={"tracked": int((out["val"] >= 0).sum()), "ms_select_100": ms_select})
+    line.update(parity_against(out, oracle_track(params_from_tc(tc), i0, i1, fl)))
+    emit(json_fd, line)
 
 
 def run_cfg3(args, json_fd):
@@ -277,11 +442,11 @@ def run_cfg3(args, json_fd):
         step()
     kern = {k["name"]: round(1e3 * k["total_ms"] / k["launches"], 1) for k in ctx.timing_read()}
     ctx.close()
-    _emit(json_fd, _base_line(live1 * args.steps / el, args.steps, args.warmup, el / args.steps * 1e3,
-                              "cfg-3: 1920x1080, %d features placed (%d live), 15x15 window, 4 levels (ss 2), affine consistency "
-                              "check mode 2 (parity unpinned); per step: pyramids of both frames + translation tracker + affine check"
-                              % (placed, live1),
-                              {"tracked_after_affine": int((out["val"] >= 0).sum()), "kernel_us": kern}))
+    emit(json_fd, base_line(live1 * args.steps / el, 1, args.steps, args.warmup, el / args.steps * 1e3, el / args.steps * 1e3,
+                            "cfg-3: 1920x1080, %d features placed (%d live), 15x15 window, 4 levels (ss 2), affine consistency "
+                            "check mode 2 (parity unpinned); per step: pyramids of both frames + translation tracker + affine check"
+                            % (placed, live1),
+                            extra_cfg={"tracked_after_affine": int((out["val"] >= 0).sum()), "kernel_us": kern}))
 
 
 def run_cfg5(args, json_fd):
@@ -329,32 +494,68 @@ def run_cfg5(args, json_fd):
     out = ctx.featbuf_download((nframes - 1) % 2, n)
     frames_done = reps * (nframes - 1)
     ctx.close()
-    _emit(json_fd, _base_line(n * frames_done / el, frames_done, 0, el / frames_done * 1e3,
-                              "cfg-5 (one GPU): 3840x2160 sequence, 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost "
-                              "features replaced after every frame; per frame: pyramid of the new frame + track + replacement",
-                              {"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3}))
+    emit(json_fd, base_line(n * frames_done / el, 1, frames_done, 0, el / frames_done * 1e3, el / frames_done * 1e3,
+                            "cfg-5 (one GPU): 3840x2160 sequence, 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost "
+                            "features replaced after every frame; per frame: pyramid of the new frame + track + replacement",
+                            extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3}))
 
 
+# ================================================================================= launcher dry run
+def dry_run(args, json_fd):
+    """KLT_BENCH_DRYRUN=1: launcher + rendezvous + shard arithmetic without a GPU (the collective is stubbed by files).
+    Exercised by the CPU tests with 2 processes."""
+    rank, local_rank, world = parallel.world_from_env()
+    path = parallel.rendezvous_file()
+    ids = parallel.exchange_ids(rank, world, 3, lambda: os.urandom(parallel.KLT_COMM_ID_BYTES), path=path, timeout=60)
+    digest = hashlib.sha256(b"".join(ids)).hexdigest()
+    mine = list(parallel.shard_range(args.pairs, world, rank))
+    if os.environ.get("KLT_DRYRUN_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    with open("%s.rank%d" % (path, rank), "w") as f:
+        json.dump({"digest": digest, "pairs": mine, "local_rank": local_rank}, f)
+    if rank != 0:
+        return
+    seen = []
+    t0 = time.monotonic()
+    for r in range(world):
+        while True:
+            try:
+                seen.append(json.load(open("%s.rank%d" % (path, r))))
+                break
+            except (OSError, ValueError):
+                if time.monotonic() - t0 > 60:
+                    raise SystemExit("rank %d never reported" % r)
+                time.sleep(0.01)
+    emit(json_fd, {"dryrun": True, "n_gpus": world, "ids_agree": all(s["digest"] == digest for s in seen),
+                   "pairs_covered": sorted(i for s in seen for i in s["pairs"]) == list(range(args.pairs)),
+                   "local_ranks": [s["local_rank"] for s in seen], "spawned": os.environ.get("KLT_SPAWNED") == "1"})
+
+
+# ============================================================================================ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="how many times the K-step timed region is run (median reported; fewer, never below 5, when a region is long)")
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed hot-path work before the W warm-up steps: the GPU needs ~10 ms of load to reach its steady clocks / "
                          "cache state (a 200-step run right after start-up measures 50 us per pair, the same loop after 50 ms 43 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--split-l0", action="store_true", help="KLT_OPT_SPLIT_L0: fork/join pyramid build on two streams")
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
-                    help="cfg2 (default, the headline line); the others are the remaining BASELINE configs on one GPU, informative")
-    ap.add_argument("--pairs", type=int, default=32, help="pairs per step for --config cfg4")
+                    help="cfg2 (default, the headline line); cfg4 = the 256-pair batch sharded over --gpus ranks; the others are "
+                         "the remaining BASELINE configs on one GPU, informative")
+    ap.add_argument("--pairs", type=int, default=256, help="total pairs per step for --config cfg4 (sharded over the ranks)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent pairs in flight per GPU: consecutive steps go round-robin to this many contexts (one HIP "
                          "stream each, no events between them), so kernels of different pairs overlap; 1 = a single stream")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="KLT_OPT_TRACK_STREAM: tracker on a second HIP stream, overlapping the next step's pyramid build "
-                         "(measured slower on MI355X for this step size: event cost > overlap gain; DESIGN.md)")
     args = ap.parse_args()
+
+    # N > 1 without a launcher: start the ranks ourselves.  Nothing above or below this point has touched the GPU yet
+    # (no HIP call, no library load): the children are fresh processes, this one only waits for them.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(parallel.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     # stdout must carry exactly one JSON line.  RCCL / the HIP runtime print their own chatter to fd 1 (also at
     # process exit), so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved descriptor.
@@ -362,23 +563,13 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if os.environ.get("KLT_BENCH_DRYRUN") == "1":
+        return dry_run(args, json_fd)
     if args.config != "cfg2":
         return {"cfg1": run_cfg1, "cfg3": run_cfg3, "cfg4": run_cfg4, "cfg5": run_cfg5}[args.config](args, json_fd)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
-    distributed = world > 1 or os.environ.get("KLT_FORCE_DIST") == "1"    # the env var exercises the RCCL path on one GPU
-
-    torch = dist = None
-    if distributed:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
+    ranks = Ranks(args)
+    rank, world, distributed = ranks.rank, ranks.world, ranks.distributed
     tc = cfg2_context()
     p = params_from_tc(tc)
     f0, f1 = synth.synth_pair(WIDTH, HEIGHT, seed=rank + 1)
@@ -387,20 +578,15 @@ def main():
     # and the GPU overlaps the kernels of different pairs -- the drain / ramp between dependent kernels of one pair and the
     # latency-bound tracker are filled with the next pair's convolutions.
     nctx = max(1, args.inflight)
-    ctxs, gathers = [], []
+    ctxs = []
     fl = None
     for c in range(nctx):
-        cx = Context(local_rank)
+        cx = Context(ranks.local_rank)
         cx.set_params(p)
-        # The pair lives in two slot pairs, (0,1) and (2,3), used by alternate steps of a context: with KLT_OPT_TRACK_STREAM
-        # the tracker of one step overlaps the pyramid build of the next, which must not overwrite what it reads.
+        # the pair lives in two slot pairs, (0,1) and (2,3), used by alternate steps of a context
         for s0 in (0, 2):
             cx.upload(s0, f0)
             cx.upload(s0 + 1, f1)
-        if args.pipeline:
-            cx.set_option(3, 1)
-        if args.split_l0:
-            cx.set_option(7, 1)
         cx.build_pyramids(0)
         fl_c, placed = cx.select(0, NFEAT, use_pyramid=True)
         assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)
@@ -410,17 +596,16 @@ def main():
         cx.featbuf_upload(FB_OUT0, fl)
         cx.featbuf_upload(FB_OUT1, fl)
         # N > 1: the records of GATHER_EVERY consecutive steps of a context land in one device-side [steps x features] table
-        # (two tables, used alternately) and each full table is all-gathered with ONE RCCL collective on a side stream --
-        # cfg-4's "gather once per shard", and the host cost of a collective is not paid per step.
+        # (two tables, used alternately) and each full table is all-gathered with ONE RCCL collective on the library's side
+        # stream -- cfg-4's "gather once per shard", and the host cost of a collective is not paid per step.
         if distributed:
-            from pyfeaturetrack_amd.parallel import FeatureGather
             for t, ring in enumerate((FB_RING0, FB_RING1)):
                 cx.featbuf_alloc(ring, GATHER_EVERY * NFEAT)
                 for k in range(GATHER_EVERY):
                     cx.featbuf_view(FB_VIEW0 + t * GATHER_EVERY + k, ring, k * NFEAT, NFEAT)
-            gathers.append(FeatureGather(cx, [FB_RING0, FB_RING1], GATHER_EVERY * NFEAT, world, torch, dist))
         ctxs.append(cx)
     ctx = ctxs[0]
+    ranks.attach(ctxs)
 
     def out_buffer(j):
         """feature buffer that local step j of a context writes"""
@@ -437,20 +622,12 @@ def main():
             cx.track_async(a, a + 1, FB_SEL, out_buffer(j), NFEAT)
             return
         t, k = (j // GATHER_EVERY) % 2, j % GATHER_EVERY
-        ring = FB_RING0 if t == 0 else FB_RING1
+        ring, gath = (FB_RING0, FB_GATH0) if t == 0 else (FB_RING1, FB_GATH1)
         if k == 0:
-            gathers[c].wait_free(ring)      # the collective that read this table two rounds ago has finished
+            cx.comm_fence_featbuf(ring)       # the collective that read this table two rounds ago has finished
         cx.track_async(a, a + 1, FB_SEL, out_buffer(j), NFEAT)
         if k == GATHER_EVERY - 1 or last:
-            gathers[c].all_gather(ring)     # RCCL on a side stream, behind this tracker launch (event)
-
-    def fence():
-        for cx in ctxs:
-            cx.sync()
-        if distributed:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            cx.allgather_featbuf_async(ring, gath, GATHER_EVERY * NFEAT)     # RCCL on the side stream, behind this tracker launch
 
     # bring the GPU to its steady state first (the same work as a step, into the plain output buffers)
     t_pre = time.perf_counter()
@@ -465,23 +642,13 @@ def main():
         for cx in ctxs:
             cx.sync()
     for i in range(args.warmup):
-        step(i)
-    if distributed:
-        # the first collective of a process group pays for RCCL's lazy set-up (channels, kernels): take it out of the timed region
-        for gth in gathers:
-            gth.all_gather(FB_RING0)
-            gth.all_gather(FB_RING1)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, last=(i == args.steps - 1))
-    enqueue_s = time.perf_counter() - t0      # host time to enqueue K steps (no synchronisation inside)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        step(i, last=(i == args.warmup - 1))
+
+    def region():
+        for i in range(args.steps):
+            step(i, last=(i >= args.steps - nctx))       # every context closes its open table with a gather
+
+    elapsed, regions, enqueue_s = timed_regions(ranks, region, args.steps, args.repeats)
 
     # correctness of what was timed: the last step's records (and, N > 1, what the gather delivered of them); every
     # context's last output is the same list (same pair, same features)
@@ -494,12 +661,15 @@ def main():
             o = ctxs[c].featbuf_download(out_buffer(nsteps_c - 1), NFEAT)
             assert np.array_equal(o["x"], out["x"]) and np.array_equal(o["y"], out["y"]) and np.array_equal(o["val"], out["val"]), \
                 "contexts disagree on the tracked records"
-    if distributed:                 # what rank 0 received from itself equals what it produced
-        got = gathers[last_c].result()[rank].reshape(GATHER_EVERY, NFEAT)[last_j % GATHER_EVERY]
-        assert np.array_equal(got["x"], out["x"]) and np.array_equal(got["val"], out["val"]), "gathered records differ"
+    if distributed:                 # what this rank received from itself equals what it produced
+        gath = FB_GATH0 if (last_j // GATHER_EVERY) % 2 == 0 else FB_GATH1
+        got = ctxs[last_c].featbuf_download(gath, world * GATHER_EVERY * NFEAT).reshape(world, GATHER_EVERY, NFEAT)
+        mine = got[rank][last_j % GATHER_EVERY]
+        assert np.array_equal(mine["x"], out["x"]) and np.array_equal(mine["val"], out["val"]), "gathered records differ"
     tracked = int(np.count_nonzero(out["val"] >= 0))
     live = out["val"] == 0
     shift = (float(np.median(out["x"][live] - fl["x"][live])), float(np.median(out["y"][live] - fl["y"][live])))
+    parity = parity_against(out, oracle_track(p, f0, f1, fl)) if rank == 0 else {}
 
     # second pass: per-kernel HIP-event timing + iteration counters for the roofline
     roofline = None
@@ -523,25 +693,24 @@ def main():
         per_launch_ms = dom["total_ms"] / dom["launches"]
         per_launch_bytes = dom["bytes"] / dom["launches"]
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom["name"])
+        # PMC-derived figures are NOT measured by this run: committed results of the builder's rocprofv3 --pmc passes, with their
+        # provenance, dropped when the kernel source changed since (committed_counters)
+        traffic, traffic_source = committed_counters("traffic.json", dom["name"])
         # the same kernel against the roof that actually bounds it: VALU issue.  Wavefront-instructions per launch come from a
         # rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/sq_counters.json, tools/pmc_sq.py); 4.5 clocks per instruction and SIMD
         # is what the FP64-rate instruction mix of the convolutions sustains on gfx950 (tools/mb/valu_rate.hip, fp64_mix.hip).
         issue = None
-        spath = os.path.join(ROOT, "profiles", "sq_counters.json")
-        if os.path.exists(spath):
-            sq = json.load(open(spath)).get(dom["name"])
-            if sq and sq.get("SQ_INSTS_VALU"):
-                simds, cpi, mhz = 256 * 4, 4.5, 2400.0
-                ideal_us = sq["SQ_INSTS_VALU"] / simds * cpi / mhz
-                issue = {"valu_wavefront_instructions_per_launch": sq["SQ_INSTS_VALU"], "simds": simds, "clocks_per_instruction": cpi,
-                         "clock_mhz": mhz, "ideal_us": ideal_us, "frac": ideal_us / (per_launch_ms * 1e3)}
+        sq, sq_source = committed_counters("sq_counters.json", dom["name"])
+        if sq and sq.get("SQ_INSTS_VALU"):
+            simds, cpi, mhz = 256 * 4, 4.5, 2400.0
+            ideal_us = sq["SQ_INSTS_VALU"] / simds * cpi / mhz
+            issue = {"valu_wavefront_instructions_per_launch": sq["SQ_INSTS_VALU"], "simds": simds, "clocks_per_instruction": cpi,
+                     "clock_mhz": mhz, "ideal_us": ideal_us, "frac": ideal_us / (per_launch_ms * 1e3), "source": sq_source}
+        elif sq_source:
+            issue = {"source": sq_source}
         dev_ms = sum(k["total_ms"] for k in kernels) / args.steps
         roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "issue_bound": issue,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "issue_bound": issue,
                     "launch_us": per_launch_ms * 1e3, "launches_per_step": dom["launches"] / args.steps,
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "step_algorithmic_bytes": 2 * pyr_bytes + track_bytes,
@@ -552,8 +721,9 @@ def main():
                                             "launches_per_step": k["launches"] / args.steps,
                                             "GBps": k["bytes"] / max(k["total_ms"], 1e-9) / 1e6} for k in kernels}}
 
-    # secondary figures (never `value`): selection time, and the PCIe-inclusive pair time
+    # secondary figures (never `value`): selection time, the one-stream figure, and the PCIe-inclusive pair time
     extra = None
+    ms_single = None
     if rank == 0:
         reps = max(5, min(20, args.steps))
         ctx.sync()
@@ -562,13 +732,16 @@ def main():
             ctx.select_async(0, 1, True, FB_OUT1, NFEAT)      # SELECTING_ALL on the resident level-0 pyramid
         ctx.sync()
         ms_select = (time.perf_counter() - t) / reps * 1e3
-        t = time.perf_counter()
-        for i in range(args.steps):                            # the same K steps on ONE stream (one pair in flight)
-            a = 0 if i % 2 == 0 else 2
-            ctx.build_pyramids_batch([a, a + 1])
-            ctx.track_async(a, a + 1, FB_SEL, FB_OUT0 if i % 2 == 0 else FB_OUT1, NFEAT)
-        ctx.sync()
-        ms_single = (time.perf_counter() - t) / args.steps * 1e3
+        singles = []
+        for _ in range(5):
+            t = time.perf_counter()
+            for i in range(args.steps):                        # the same K steps on ONE stream (one pair in flight)
+                a = 0 if i % 2 == 0 else 2
+                ctx.build_pyramids_batch([a, a + 1])
+                ctx.track_async(a, a + 1, FB_SEL, FB_OUT0 if i % 2 == 0 else FB_OUT1, NFEAT)
+            ctx.sync()
+            singles.append((time.perf_counter() - t) / args.steps * 1e3)
+        ms_single = statistics.median(singles)
         t = time.perf_counter()
         for _ in range(reps):                                  # un-pipelined latency of one pair
             ctx.build_pyramids_batch([0, 1])
@@ -613,46 +786,49 @@ def main():
         ctx.sync()
         ms_pipe = (time.perf_counter() - t) / npipe * 1e3
         assert np.array_equal(table[-NFEAT:]["x"], out["x"]), "pipelined ingest changed the result"
-        extra = {"pcie_pipelined_ms_per_pair": ms_pipe, "pcie_pipelined_features_per_s": NFEAT / (ms_pipe * 1e-3),
+        extra = {"region_ms_per_step": {"median": elapsed / args.steps * 1e3, "min": min(regions) / args.steps * 1e3,
+                                        "max": max(regions) / args.steps * 1e3, "regions": len(regions)},
+                 "overlapped_ms_per_pair": elapsed / args.steps * 1e3,
+                 "pcie_pipelined_ms_per_pair": ms_pipe, "pcie_pipelined_features_per_s": NFEAT / (ms_pipe * 1e-3),
                  "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "latency_ms_per_pair_synchronised": ms_latency,
                  "single_stream_ms_per_pair": ms_single, "single_stream_features_per_s": NFEAT / (ms_single * 1e-3),
+                 "single_stream_runs_ms": singles,
                  "ms_per_select_5000": ms_select,
                  "pcie_inclusive_ms_per_pair": ms_pcie, "pcie_inclusive_features_per_s": NFEAT / (ms_pcie * 1e-3),
-                 "note": "pcie_inclusive = H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the "
+                 "note": "ms_per_frame_pair = single_stream_ms_per_pair: one pair at a time on ONE stream, no overlap with other "
+                         "pairs (ms_per_step is the inverse throughput with pairs_in_flight pairs overlapping).  "
+                         "pcie_inclusive = H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the "
                          "records, synchronised per pair; pcie_pipelined = the same bytes with klt_upload_u8_async from "
                          "pinned memory on a copy stream and the records read back every 16 pairs"}
 
     cpu = None
     if rank == 0 and not distributed and not args.no_cpu_baseline:
-        cpu = cpu_baseline(p, f0, f1, fl)
+        cpu = cpu_baseline(p, f0, f1, fl, NFEAT, "cfg-2 (1920x1080, 5000 features)")
 
+    line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        line = {
-            "metric": "features tracked/sec", "value": world * NFEAT * args.steps / elapsed, "unit": "features/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "ms_per_frame_pair": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (convolutions accumulate in f64)", "data": "synthetic",
-            "config": {"workload": "cfg-2: one 1920x1080 synthetic pair per GPU, 5000 features, 7x7 window, "
-                                   "3 pyramid levels (subsampling 4), translation only; inputs resident in HBM",
-                       "pipelining": ("none (one HIP stream)" if nctx == 1 else
-                                      "%d independent pairs in flight: steps go round-robin to %d contexts, one HIP stream each, no "
-                                      "ordering between them (pairs are independent); every step does the full work of one pair" % (nctx, nctx))
-                                     + ("; tracker of a step on its own HIP stream (KLT_OPT_TRACK_STREAM)" if args.pipeline else ""),
-                       "pairs_in_flight": nctx,
-                       "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
-                       "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
-                       "parallelism": "1 pair per GPU" + (", RCCL all-gather of the [%d steps x 5000] record table every %d steps" % (GATHER_EVERY, GATHER_EVERY) if distributed else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
-        }
-    else:
-        line = None
+        line = base_line(world * NFEAT * args.steps / elapsed, world, args.steps, args.warmup, ms_per_step,
+                         ms_single if ms_single is not None else ms_per_step,
+                         "cfg-2: one 1920x1080 synthetic pair per GPU, 5000 features, 7x7 window, "
+                         "3 pyramid levels (subsampling 4), translation only; inputs resident in HBM",
+                         extra_cfg={
+                             "pipelining": ("none (one HIP stream)" if nctx == 1 else
+                                            "%d independent pairs in flight: steps go round-robin to %d contexts, one HIP stream each, no "
+                                            "ordering between them (pairs are independent); every step does the full work of one pair" % (nctx, nctx)),
+                             "pairs_in_flight": nctx, "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
+                             "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
+                             "rccl_ranks": world if distributed else 0,
+                             "parallelism": "1 pair per GPU" + (", RCCL all-gather (libkltgpu side stream) of the [%d steps x 5000] record "
+                                                                "table every %d steps" % (GATHER_EVERY, GATHER_EVERY) if distributed else "")})
+        line.update(parity)
+        line["roofline"], line["cpu_baseline"], line["extra"] = roofline, cpu, extra
     for cx in ctxs:
         cx.close()
-    if distributed:
-        dist.destroy_process_group()        # RCCL may write its own chatter to stdout while shutting down
     if line is not None:
-        os.write(json_fd, (json.dumps(line) + "\n").encode())      # the ONE JSON line on the real stdout
+        emit(json_fd, line)
+        if parity and not parity.get("parity_checked") and "max_abs_dx" in parity:
+            raise SystemExit("timed records differ from the oracle: %r" % parity)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 2
+#define KLT_ABI_VERSION 3
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -75,35 +75,25 @@ int         klt_create(int device, klt_ctx **out);          /* replaces KLT_Trac
 void        klt_destroy(klt_ctx *ctx);
 const char *klt_last_error(klt_ctx *ctx);                   /* ctx may be NULL: error of the last failed klt_create */
 int         klt_sync(klt_ctx *ctx);                         /* wait for everything enqueued on the context's stream */
-void       *klt_track_stream_handle(klt_ctx *ctx);          /* stream of the tracker launches (== klt_stream_handle unless KLT_OPT_TRACK_STREAM) */
 void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hipStream_t, for callers that order RCCL collectives after it */
 
 /* ---- options ------------------------------------------------------------------------------ */
 #define KLT_OPT_FUSED_KERNELS 1   /* 1 (default): LDS-tiled fused pyramid kernels; 0: generic two-pass kernels (any tap count) */
-#define KLT_OPT_SMOOTH_GRAD_VARIANT 2   /* 0 (default): register-blocked level-0 kernel; 1: one sample per thread (process-wide) */
-/* 1: tracker launches go to a second HIP stream and overlap the pyramid build of the following frames; ordering is
- * kept with events (a slot is not overwritten before the tracker launches that read it have finished, feature-buffer
- * consumers wait for the last tracker launch).  0 (default): one stream. */
-#define KLT_OPT_TRACK_STREAM 3
 /* affine state (klt_affine_alloc id, or -1) whose records klt_select* resets for every slot it fills
  * (selectGoodFeatures.py:120-128 clears the aff_* fields of a newly placed feature) */
 #define KLT_OPT_SELECT_AFFINE_STATE 4
 /* 1 (default): klt_select* only considers the highest-scoring candidates (histogram threshold keeping about 64 per
  * requested feature) and repeats with every candidate if they run out before the list is full; 0: always every candidate. */
 #define KLT_OPT_TOPK_PREFILTER 5
-/* 1: the pyramid build smooths level 0 alone, then runs the level-0 gradients on the main stream concurrently with the
- * reductions / small-level gradients on a side stream (fork/join with events); 0 (default): fused level-0 kernel. */
-#define KLT_OPT_SPLIT_L0 7
 /* 1 (default): minimum-distance enforcement as parallel passes over all candidates (a candidate is accepted once every
  * higher-ranked neighbour is rejected; same result as the walk); 0: sort all candidates and walk them in order.
  * Either way klt_select_async synchronises once internally (it reads back whether the list was filled / settled). */
 #define KLT_OPT_SELECT_PARALLEL_NMS 8
 #define KLT_OPT_SAT_VARIANT 10           /* summed-area tables: 1 (default) step-synchronous wavefront pipelines (frames with ncols % 4 == 0), 0 barrier-coupled kernels */
-#define KLT_OPT_TRACK_VARIANT 11         /* 7x7 windows: 4 (default) four features per wavefront with 16-byte loads; 0: one feature per wavefront; 1: footprints requested ahead; 2: four features per wavefront, per-sample loads; 3: one pixel per lane (same records; process-wide) */
+#define KLT_OPT_TRACK_VARIANT 11         /* 4 (default): quad-load tracker kernels (7x7: four features per wavefront; 15x15: one 16-byte load per lane and image); 0: plain one-feature-per-wavefront kernel for every window (same records; process-wide) */
 #define KLT_OPT_FUSED_HREDUCE 12         /* 1 (default): the level-0 kernel also runs the horizontal pass of the first pyramid reduction (subsampling 4); 0: separate reduction kernel */
-#define KLT_OPT_TRACK_XCD_ORDER 13        /* 1 (default): features are handed to the tracker sorted by row, one band of the image per XCD (7x7 windows, single-pair launches; the order is refreshed every 64 launches); 0: list order */
+#define KLT_OPT_TRACK_XCD_ORDER 13        /* 1 (default): features are handed to the tracker sorted by row, one band of the image per XCD (single-pair and batched launches; the order is refreshed every 64 launches); 0: list order */
 #define KLT_OPT_FUSED_LEVELS 14           /* 1: every pyramid level >= 1 is ONE launch (vertical reduction from the previous level's H planes + gradients + next H planes; needs KLT_OPT_FUSED_HREDUCE, subsampling 4); 0: separate reduction and gradient launches */
-#define KLT_OPT_PYR_REDUCE_VARIANT 9    /* 0 (default): 1024-thread pyramid reduce; 1: 512-thread all-f32 variant, measured slower (process-wide) */
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
 /* ---- parameters and taps ------------------------------------------------------------------- */
@@ -132,6 +122,9 @@ int klt_build_pyramids_async(klt_ctx *ctx, int slot);
  * or every pair of a batch -- BASELINE cfg-4) */
 int klt_build_pyramids_batch_async(klt_ctx *ctx, const int *slots, int n);
 int klt_build_pyramids(klt_ctx *ctx, int slot);
+/* bit 0: the slot holds a frame; bit 1: its pyramids are built and match the current parameters / taps (what
+ * `tc.pyramid_last is not None` means in the reference, trackFeatures.py:152); 0 for a slot never used */
+int klt_slot_state(klt_ctx *ctx, int slot);
 /* sequentialMode: the frame-2 pyramids become frame 1 (trackFeatures.py:152-161, :401-404) */
 int klt_swap_slots(klt_ctx *ctx, int a, int b);
 
@@ -192,6 +185,34 @@ typedef struct {
  * 4 bits per level: 0 = level not visited, v = v-1 Newton iterations (saturating at 14). */
 int klt_track_stats_reset(klt_ctx *ctx);
 int klt_track_stats_read(klt_ctx *ctx, klt_track_stats *out);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (BASELINE cfg-4) --------------------- */
+/* The reference has no counterpart (single process, single thread; its only concurrency is the GUI's multiprocessing
+ * queue, examplegui.py:22-29).  The path shards by frame pair, so ranks never exchange pixels: the only collective is
+ * the gather of 16-byte feature records at the end of a shard.  librccl is opened on first use (dlopen); a process that
+ * never calls these entry points never loads it.  Collectives run on a side stream of the context, event-ordered behind
+ * everything enqueued on the context's stream when they are issued; the context's stream itself never waits for RCCL
+ * unless klt_comm_fence_async is called. */
+#define KLT_COMM_ID_BYTES 128
+/* rank 0: a fresh RCCL unique id (ncclGetUniqueId); the caller hands the 128 bytes to the other ranks (file, socket, env) */
+int klt_comm_unique_id(void *out128);
+/* every rank, same id: joins the communicator of `nranks` processes (ncclCommInitRank on the context's device) */
+int klt_comm_init_rank(klt_ctx *ctx, int nranks, int rank, const void *unique_id);
+int klt_comm_destroy(klt_ctx *ctx);
+int klt_comm_info(klt_ctx *ctx, int *nranks, int *rank);       /* 1 / 0 when the context has no communicator */
+/* all-gather / gather of the first n records of feature buffer fb_src into fb_dst (nranks * n records in rank order;
+ * allocated here if needed; for the gather only `root` needs / gets fb_dst, other ranks may pass -1).  n may cover a
+ * whole device-side [pairs x features] table (klt_featbuf_view). */
+int klt_allgather_featbuf_async(klt_ctx *ctx, int fb_src, int fb_dst, int n);
+int klt_gather_featbuf_async(klt_ctx *ctx, int fb_src, int fb_dst, int n, int root);
+int klt_comm_fence_async(klt_ctx *ctx);    /* the context's stream waits (on the device) for the collectives issued so far */
+/* ... only for the last collective that read or wrote feature buffer fb (call it before overwriting a table whose
+ * gather may still be in flight; collectives on other tables keep overlapping) */
+int klt_comm_fence_featbuf_async(klt_ctx *ctx, int fb);
+int klt_comm_wait(klt_ctx *ctx);           /* the host waits for them */
+/* element-wise maximum over all ranks of n <= 16 doubles (host in, host out; synchronous -- also the barrier the
+ * benchmark brackets its timed region with) */
+int klt_comm_allreduce_max(klt_ctx *ctx, double *inout, int n);
 
 /* ---- test / inspection hooks --------------------------------------------------------------- */
 /* pyramid: 0 = image, 1 = gradx, 2 = grady; dst holds level_ncols*level_nrows floats */

@@ -61,7 +61,6 @@ SYMBOLS = {
     "klt_last_error": (C.c_char_p, [_P]),
     "klt_sync": (_I, [_P]),
     "klt_stream_handle": (_P, [_P]),
-    "klt_track_stream_handle": (_P, [_P]),
     "klt_set_params": (_I, [_P, C.POINTER(KltParams)]),
     "klt_set_kernels": (_I, [_P, _I, C.POINTER(C.c_double), _I, C.POINTER(C.c_double), _I]),
     "klt_upload_u8": (_I, [_P, _I, _P, _I, _I, _I]),
@@ -74,6 +73,7 @@ SYMBOLS = {
     "klt_build_pyramids_batch_async": (_I, [_P, C.POINTER(C.c_int), _I]),
     "klt_set_option": (_I, [_P, _I, _I]),
     "klt_build_pyramids": (_I, [_P, _I]),
+    "klt_slot_state": (_I, [_P, _I]),
     "klt_swap_slots": (_I, [_P, _I, _I]),
     "klt_featbuf_upload": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_download": (_I, [_P, _I, _P, _I]),
@@ -100,6 +100,16 @@ SYMBOLS = {
     "klt_download_sorted_candidates": (_I, [_P, _P, _P, _P, _I, _PI]),
     "klt_smooth_f32": (_I, [_P, _P, _I, _I, C.POINTER(C.c_double), _I, _P]),
     "klt_gradients_f32": (_I, [_P, _P, _I, _I, C.POINTER(C.c_double), _I, C.POINTER(C.c_double), _I, _P, _P]),
+    "klt_comm_unique_id": (_I, [_P]),
+    "klt_comm_init_rank": (_I, [_P, _I, _I, _P]),
+    "klt_comm_destroy": (_I, [_P]),
+    "klt_comm_info": (_I, [_P, _PI, _PI]),
+    "klt_allgather_featbuf_async": (_I, [_P, _I, _I, _I]),
+    "klt_gather_featbuf_async": (_I, [_P, _I, _I, _I, _I]),
+    "klt_comm_fence_async": (_I, [_P]),
+    "klt_comm_fence_featbuf_async": (_I, [_P, _I]),
+    "klt_comm_wait": (_I, [_P]),
+    "klt_comm_allreduce_max": (_I, [_P, C.POINTER(C.c_double), _I]),
     "klt_timing_enable": (_I, [_P, _I]),
     "klt_timing_read": (_I, [_P, C.POINTER(KltKernelTime), _I]),
 }

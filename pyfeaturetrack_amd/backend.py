@@ -62,9 +62,6 @@ class Context:
     def stream_handle(self):
         return self._lib.klt_stream_handle(self._h)
 
-    def track_stream_handle(self):
-        return self._lib.klt_track_stream_handle(self._h)
-
     # ---------------------------------------------------------------- parameters
     def set_params(self, p):
         """p: KltParams.  Taps for the three sigmas are generated on the host (convolve.py:27-93)."""
@@ -72,8 +69,13 @@ class Context:
         if key == self._params_key:
             return
         self._check(self._lib.klt_set_params(self._h, C.byref(p)))
-        for which, (g, d) in enumerate(taps_from_params(p)):
-            self._check(self._lib.klt_set_kernels(self._h, which, _dp(g), len(g), _dp(d), len(d)))
+        # taps depend on the three sigmas only: a change of mindist / max_residue / ... must not touch them (the library
+        # invalidates resident pyramids when taps change -- sequentialMode keeps tc.pyramid_last across such changes)
+        sig = (p.smooth_sigma, p.pyramid_sigma, p.grad_sigma)
+        if sig != getattr(self, "_sigma_key", None):
+            for which, (g, d) in enumerate(taps_from_params(p)):
+                self._check(self._lib.klt_set_kernels(self._h, which, _dp(g), len(g), _dp(d), len(d)))
+            self._sigma_key = sig
         self._params_key = key
         self.params = p
 
@@ -157,6 +159,10 @@ class Context:
 
     def set_option(self, option, value):
         self._check(self._lib.klt_set_option(self._h, option, int(value)))
+
+    def pyramids_valid(self, slot):
+        """True while the slot's pyramids are built and match the current parameters."""
+        return bool(self._check(self._lib.klt_slot_state(self._h, slot)) & 2)
 
     def swap_slots(self, a, b):
         self._check(self._lib.klt_swap_slots(self._h, a, b))
@@ -252,6 +258,43 @@ class Context:
         return {"features": int(s.features),
                 "level_visits": [int(v) for v in s.level_visits],
                 "iterations": [int(v) for v in s.iterations]}
+
+    # ------------------------------------------------------- multi-GPU (RCCL inside libkltgpu)
+    def comm_init(self, nranks, rank, unique_id):
+        """unique_id: the 128 bytes rank 0 got from klt_comm_unique_id (parallel.init_communicators exchanges them)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.klt_comm_init_rank(self._h, int(nranks), int(rank), buf))
+
+    def comm_destroy(self):
+        self._check(self._lib.klt_comm_destroy(self._h))
+
+    def comm_info(self):
+        n, r = C.c_int(), C.c_int()
+        self._check(self._lib.klt_comm_info(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def allgather_featbuf_async(self, fb_src, fb_dst, n):
+        self._check(self._lib.klt_allgather_featbuf_async(self._h, fb_src, fb_dst, n))
+
+    def gather_featbuf_async(self, fb_src, fb_dst, n, root=0):
+        self._check(self._lib.klt_gather_featbuf_async(self._h, fb_src, fb_dst, n, root))
+
+    def comm_fence(self):
+        """The context's stream waits (on the device) for the collectives issued so far."""
+        self._check(self._lib.klt_comm_fence_async(self._h))
+
+    def comm_fence_featbuf(self, fb):
+        """... only for the last collective that read or wrote feature buffer `fb`."""
+        self._check(self._lib.klt_comm_fence_featbuf_async(self._h, fb))
+
+    def comm_wait(self):
+        self._check(self._lib.klt_comm_wait(self._h))
+
+    def comm_allreduce_max(self, values):
+        """Element-wise max over all ranks of up to 16 floats; synchronous (doubles as a barrier)."""
+        a = (C.c_double * len(values))(*values)
+        self._check(self._lib.klt_comm_allreduce_max(self._h, a, len(values)))
+        return list(a)
 
     # -------------------------------------------------- standalone convolutions
     def smooth(self, img, gauss):

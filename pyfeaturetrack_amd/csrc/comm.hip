@@ -1,0 +1,236 @@
+// Multi-GPU plumbing of libkltgpu.so: one process per GPU, RCCL over xGMI.
+//
+// The KLT path shards by frame pair -- ranks never exchange pixels or pyramids -- so the only
+// communication is the gather of 16-byte feature records (klt_feat) at the end of a shard, plus a
+// barrier / max-reduction for timing.  The reference has nothing here (its only concurrency is the
+// GUI's multiprocessing queue, examplegui.py:22-29, out of scope).
+//
+// librccl is opened with dlopen the first time a communicator is needed: a single-GPU process never
+// loads it, and the library has no link-time dependency on it.  Collectives run on a side stream of
+// the communicator that is event-ordered behind the producer stream (the context's stream), so the
+// tracker's stream never waits for RCCL unless the caller asks (comm_fence).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "klt_internal.h"
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+Rccl g_rccl;
+
+template <typename F>
+bool sym(F &fn, const char *name)
+{
+    fn = reinterpret_cast<F>(dlsym(g_rccl.handle, name));
+    if (!fn) g_rccl.error = std::string("librccl lacks ") + name;
+    return fn != nullptr;
+}
+
+bool load_rccl(std::string &err)
+{
+    if (g_rccl.handle && g_rccl.error.empty()) return true;
+    if (!g_rccl.handle) {
+        const char *names[] = {getenv("KLT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (g_rccl.handle) break;
+        }
+        if (!g_rccl.handle) {
+            err = std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "not found");
+            return false;
+        }
+        g_rccl.error.clear();
+        sym(g_rccl.GetUniqueId, "ncclGetUniqueId") && sym(g_rccl.CommInitRank, "ncclCommInitRank") &&
+            sym(g_rccl.CommDestroy, "ncclCommDestroy") && sym(g_rccl.AllGather, "ncclAllGather") &&
+            sym(g_rccl.AllReduce, "ncclAllReduce") && sym(g_rccl.Send, "ncclSend") && sym(g_rccl.Recv, "ncclRecv") &&
+            sym(g_rccl.GroupStart, "ncclGroupStart") && sym(g_rccl.GroupEnd, "ncclGroupEnd") &&
+            sym(g_rccl.GetErrorString, "ncclGetErrorString");
+    }
+    if (!g_rccl.error.empty()) { err = g_rccl.error; return false; }
+    return true;
+}
+
+}  // namespace
+
+struct KltComm {
+    int device = 0, nranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t side = nullptr;            // collectives run here
+    std::vector<hipEvent_t> ring;          // ordering events; never re-recorded while a waiter may be queued
+    size_t ring_next = 0;
+    hipEvent_t last_done = nullptr;        // end of the most recent collective
+    double *scratch = nullptr;             // device scratch for the small reductions (16 doubles)
+};
+
+#define COMM_HIP(call)                                                                  \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return KLT_ERR_DEVICE; } \
+    } while (0)
+#define COMM_NCCL(call)                                                                 \
+    do {                                                                                \
+        ncclResult_t r_ = (call);                                                       \
+        if (r_ != ncclSuccess) { err = std::string(#call) + ": " + g_rccl.GetErrorString(r_); return KLT_ERR_DEVICE; } \
+    } while (0)
+
+static int comm_event(KltComm *k, hipEvent_t *out, std::string &err)
+{
+    constexpr size_t kRing = 128;
+    if (k->ring.size() < kRing) {
+        hipEvent_t e = nullptr;
+        COMM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        k->ring.push_back(e);
+        *out = e;
+        return 0;
+    }
+    *out = k->ring[k->ring_next];
+    k->ring_next = (k->ring_next + 1) % kRing;
+    return 0;
+}
+
+int comm_unique_id(void *out128, std::string &err)
+{
+    if (!out128) { err = "null argument"; return KLT_ERR_ARG; }
+    if (!load_rccl(err)) return KLT_ERR_DEVICE;
+    ncclUniqueId id;
+    COMM_NCCL(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == KLT_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    std::memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+
+int comm_create(int device, int nranks, int rank, const void *unique_id, KltComm **out, std::string &err)
+{
+    if (!unique_id || !out || nranks < 1 || rank < 0 || rank >= nranks) { err = "bad communicator arguments"; return KLT_ERR_ARG; }
+    if (!load_rccl(err)) return KLT_ERR_DEVICE;
+    COMM_HIP(hipSetDevice(device));
+    KltComm *k = new KltComm();
+    k->device = device; k->nranks = nranks; k->rank = rank;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&k->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r);
+        delete k;
+        return KLT_ERR_DEVICE;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&k->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&k->scratch, 16 * sizeof(double));
+    if (e != hipSuccess) {
+        err = std::string("communicator stream / scratch: ") + hipGetErrorString(e);
+        comm_destroy(k);
+        return KLT_ERR_DEVICE;
+    }
+    *out = k;
+    return 0;
+}
+
+void comm_destroy(KltComm *k)
+{
+    if (!k) return;
+    hipSetDevice(k->device);
+    if (k->side) hipStreamSynchronize(k->side);
+    if (k->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(k->comm);
+    for (hipEvent_t e : k->ring) hipEventDestroy(e);
+    if (k->scratch) hipFree(k->scratch);
+    if (k->side) hipStreamDestroy(k->side);
+    delete k;
+}
+
+hipEvent_t comm_last_done(const KltComm *k) { return k ? k->last_done : nullptr; }
+int comm_nranks(const KltComm *k) { return k ? k->nranks : 1; }
+int comm_rank(const KltComm *k) { return k ? k->rank : 0; }
+
+// side stream waits for everything enqueued on `producer` so far
+static int comm_order_behind(KltComm *k, hipStream_t producer, std::string &err)
+{
+    hipEvent_t ready;
+    if (int rc = comm_event(k, &ready, err)) return rc;
+    COMM_HIP(hipEventRecord(ready, producer));
+    COMM_HIP(hipStreamWaitEvent(k->side, ready, 0));
+    return 0;
+}
+
+static int comm_mark_done(KltComm *k, std::string &err)
+{
+    hipEvent_t done;
+    if (int rc = comm_event(k, &done, err)) return rc;
+    COMM_HIP(hipEventRecord(done, k->side));
+    k->last_done = done;
+    return 0;
+}
+
+int comm_allgather(KltComm *k, hipStream_t producer, const void *src, void *dst, size_t bytes, std::string &err)
+{
+    COMM_HIP(hipSetDevice(k->device));
+    if (int rc = comm_order_behind(k, producer, err)) return rc;
+    COMM_NCCL(g_rccl.AllGather(src, dst, bytes, ncclUint8, k->comm, k->side));
+    return comm_mark_done(k, err);
+}
+
+// every rank sends `bytes` to `root`, which receives them in rank order (its own part is a device copy)
+int comm_gather(KltComm *k, hipStream_t producer, const void *src, void *dst, size_t bytes, int root, std::string &err)
+{
+    if (root < 0 || root >= k->nranks) { err = "gather root out of range"; return KLT_ERR_ARG; }
+    COMM_HIP(hipSetDevice(k->device));
+    if (int rc = comm_order_behind(k, producer, err)) return rc;
+    if (k->rank == root) {
+        if (!dst) { err = "the gather root needs a destination buffer"; return KLT_ERR_ARG; }
+        COMM_HIP(hipMemcpyAsync((char *)dst + (size_t)root * bytes, src, bytes, hipMemcpyDeviceToDevice, k->side));
+        if (k->nranks > 1) {
+            COMM_NCCL(g_rccl.GroupStart());
+            for (int r = 0; r < k->nranks; r++)
+                if (r != root) COMM_NCCL(g_rccl.Recv((char *)dst + (size_t)r * bytes, bytes, ncclUint8, r, k->comm, k->side));
+            COMM_NCCL(g_rccl.GroupEnd());
+        }
+    } else {
+        COMM_NCCL(g_rccl.Send(src, bytes, ncclUint8, root, k->comm, k->side));
+    }
+    return comm_mark_done(k, err);
+}
+
+// `consumer` waits (on the device) for every collective issued so far
+int comm_fence(KltComm *k, hipStream_t consumer, std::string &err)
+{
+    if (k->last_done) COMM_HIP(hipStreamWaitEvent(consumer, k->last_done, 0));
+    return 0;
+}
+
+int comm_wait(KltComm *k, std::string &err)
+{
+    COMM_HIP(hipSetDevice(k->device));
+    COMM_HIP(hipStreamSynchronize(k->side));
+    return 0;
+}
+
+// max over ranks of up to 16 doubles, host in / host out, synchronous (bench timing: MAX over ranks); doubles as the barrier
+int comm_allreduce_max(KltComm *k, double *inout, int n, std::string &err)
+{
+    if (!inout || n < 1 || n > 16) { err = "allreduce takes 1..16 doubles"; return KLT_ERR_ARG; }
+    COMM_HIP(hipSetDevice(k->device));
+    COMM_HIP(hipMemcpyAsync(k->scratch, inout, n * sizeof(double), hipMemcpyHostToDevice, k->side));
+    COMM_NCCL(g_rccl.AllReduce(k->scratch, k->scratch, (size_t)n, ncclDouble, ncclMax, k->comm, k->side));
+    COMM_HIP(hipMemcpyAsync(inout, k->scratch, n * sizeof(double), hipMemcpyDeviceToHost, k->side));
+    COMM_HIP(hipStreamSynchronize(k->side));
+    return 0;
+}

@@ -32,8 +32,6 @@ struct Slot {
     Level lv[KLT_MAX_LEVELS];
     int nlev = 0, ss = 0;
     bool pyr_valid = false;
-    hipEvent_t ev_read = nullptr;     // last tracker launch that read this slot (track-stream mode)
-    bool ev_read_valid = false;
     hipEvent_t ev_upload = nullptr;   // asynchronous ingest: frame copy finished (the build waits for it)
     hipEvent_t ev_consumed = nullptr; // last kernel on `stream` that read the raw frame u8
     bool upload_pending = false, consumed_valid = false;
@@ -46,7 +44,7 @@ struct Slot {
     bool consumed_alt_valid = false;
 };
 
-struct FeatBuf { klt_feat *d = nullptr; int cap = 0; bool view = false; };
+struct FeatBuf { klt_feat *d = nullptr; int cap = 0; bool view = false; hipEvent_t comm_done = nullptr; /* last collective that touched it */ };
 
 struct AffState { klt_affine_rec *rec = nullptr; float *tpl = nullptr; int n = 0, tn = 0; };
 
@@ -58,22 +56,15 @@ std::string g_create_error;
 
 struct klt_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;     // uploads, pyramid build, selection
-    hipStream_t tstream = nullptr;    // tracker launches when KLT_OPT_TRACK_STREAM is on (else == stream)
-    bool track_stream_on = false;
+    hipStream_t stream = nullptr;     // uploads, pyramid build, selection, tracker
     hipStream_t cstream = nullptr;    // asynchronous frame ingest from pinned host memory (created on first use)
-    hipStream_t sstream = nullptr;    // side stream of the pyramid build (KLT_OPT_SPLIT_L0), created on first use
-    hipStream_t work = nullptr;       // stream the pyramid-build helpers currently enqueue on (stream or sstream)
-    bool split_l0 = false;
+    KltComm *comm = nullptr;          // RCCL communicator + side stream (klt_comm_init_rank), comm.hip
     std::vector<void *> pinned;       // klt_host_alloc allocations
     // Ordering events come from one ring and are never re-recorded while a waiter may still be queued on them
     // (re-recording a pending event makes hipEventRecord block the host until the device has caught up -- measured:
     // 400-800 us per step).  256 events ~ 25 steps of history.
     std::vector<hipEvent_t> ring;
     size_t ring_next = 0;
-    hipEvent_t ev_pyr = nullptr;      // "everything enqueued on `stream` so far" marker the tracker waits for
-    hipEvent_t ev_track = nullptr;    // last tracker launch (feature-buffer consumers on `stream` wait for it)
-    bool ev_track_valid = false;
     std::string err;
     klt_params p{};
     bool have_params = false;
@@ -90,7 +81,7 @@ struct klt_ctx {
     bool track_xcd_order = true;              // KLT_OPT_TRACK_XCD_ORDER
     uint32_t *track_order = nullptr;
     size_t track_order_cap = 0;
-    int order_n = -1, order_age = 0;          // length of the list the stored order was computed from, and how many launches ago
+    int order_n = -1, order_pairs = 0, order_age = 0;   // shape (list length, pairs) the stored order was computed for, and how many launches ago
     // selection scratch
     float *sel_img = nullptr, *sel_gx = nullptr, *sel_gy = nullptr, *sat = nullptr, *valmap = nullptr;
     size_t sel_cap = 0;               // pixels
@@ -124,6 +115,7 @@ struct klt_ctx {
     int sorted_count = 0;
     TrackPairDesc *pair_table = nullptr;
     size_t pair_table_cap = 0;
+    std::vector<TrackPairDesc> pair_table_host;   // what pair_table holds
     klt_affine_params ap{-1, 15, 15, 10, 10.f, 0.02f, 1.5f};      // klt.py:67-73 defaults
     std::vector<AffState> aff;
     int select_aff_state = -1;
@@ -161,7 +153,7 @@ struct TimerScope {
     Timed t;
     bool on;
     hipStream_t st;
-    TimerScope(klt_ctx *c_, int fam, double bytes, hipStream_t st_ = nullptr) : c(c_), on(c_->timing), st(st_ ? st_ : c_->work)
+    TimerScope(klt_ctx *c_, int fam, double bytes, hipStream_t st_ = nullptr) : c(c_), on(c_->timing), st(st_ ? st_ : c_->stream)
     {
         if (!on) return;
         t.fam = fam;
@@ -184,7 +176,6 @@ int drain_timers(klt_ctx *c)
 {
     if (c->pending.empty()) return 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
     for (Timed &t : c->pending) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, t.a, t.b);
@@ -198,13 +189,11 @@ int drain_timers(klt_ctx *c)
     return 0;
 }
 
-// both streams idle: required before freeing anything a queued kernel may still use
+// every stream idle: required before freeing anything a queued kernel may still use
 int sync_all(klt_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->tstream && c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
-    if (c->sstream) HIPCHK(c, hipStreamSynchronize(c->sstream));
     return 0;
 }
 
@@ -248,8 +237,6 @@ int get_slot(klt_ctx *c, int slot, Slot **out, bool create)
     return 0;
 }
 
-int wait_tracker(klt_ctx *c);
-
 int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
 {
     if (fb < 0 || fb > 65535) return fail(c, KLT_ERR_ARG, "feature buffer index out of range");
@@ -260,7 +247,6 @@ int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
         klt_feat *nd = nullptr;
         HIPCHK(c, hipMalloc((void **)&nd, (size_t)n * sizeof(klt_feat)));
         if (b.d) {
-            if (int rc = wait_tracker(c)) return rc;
             HIPCHK(c, hipMemcpyAsync(nd, b.d, (size_t)b.cap * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
             if (int rc = sync_all(c)) return rc;
             hipFree(b.d);
@@ -272,9 +258,7 @@ int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
     return 0;
 }
 
-// ---- two-stream ordering (KLT_OPT_TRACK_STREAM): the tracker runs on its own stream so that it can overlap the
-// pyramid build of the next frames.  `stream` work that overwrites a slot waits for the last tracker launch that read
-// it; `stream` work that touches feature buffers waits for the last tracker launch.
+// ordering events for the asynchronous ingest come from a ring (see klt_ctx::ring)
 int fresh_event(klt_ctx *c, hipEvent_t *out)
 {
     constexpr size_t kRing = 256;
@@ -287,42 +271,6 @@ int fresh_event(klt_ctx *c, hipEvent_t *out)
     }
     *out = c->ring[c->ring_next];
     c->ring_next = (c->ring_next + 1) % kRing;
-    return 0;
-}
-
-int wait_slot_readers(klt_ctx *c, Slot *s)
-{
-    if (c->track_stream_on && s->ev_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_read, 0));
-    return 0;
-}
-
-int wait_tracker(klt_ctx *c)
-{
-    if (c->track_stream_on && c->ev_track_valid) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_track, 0));
-    return 0;
-}
-
-int tracker_begin(klt_ctx *c)
-{
-    if (!c->track_stream_on) return 0;
-    if (int rc = fresh_event(c, &c->ev_pyr)) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_pyr, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->tstream, c->ev_pyr, 0));
-    return 0;
-}
-
-int tracker_end(klt_ctx *c, Slot *const *slots, int n)
-{
-    if (!c->track_stream_on) return 0;
-    if (int rc = fresh_event(c, &c->ev_track)) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_track, c->tstream));
-    c->ev_track_valid = true;
-    for (int i = 0; i < n; i++) {
-        Slot *s = slots[i];
-        s->ev_read = c->ev_track;          // the event recorded just above marks the end of this launch
-
-        s->ev_read_valid = true;
-    }
     return 0;
 }
 
@@ -354,7 +302,6 @@ int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int p
     HIPCHK(c, hipSetDevice(c->device));
     Slot *s;
     if (int rc = get_slot(c, slot, &s, true)) return rc;
-    if (int rc = wait_slot_readers(c, s)) return rc;
     if (s->upload_pending) { HIPCHK(c, hipStreamSynchronize(c->cstream)); s->upload_pending = false; }
     const size_t px_count = (size_t)ncols * nrows;
     if (kind == 1) { if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc; }
@@ -424,12 +371,12 @@ int enqueue_smooth_raw(klt_ctx *c, Slot *s, float *dst)
     const Taps &g = c->gauss[0];
     {
         TimerScope t(c, F_SMOOTH_H, N * ((s->raw_kind == 1 ? 1 : 4) + 4));
-        if (s->raw_kind == 1) launch_hconv_u8(c->work, s->u8, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
-        else launch_hconv_f32(c->work, s->f32, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+        if (s->raw_kind == 1) launch_hconv_u8(c->stream, s->u8, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+        else launch_hconv_f32(c->stream, s->f32, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
     }
     {
         TimerScope t(c, F_SMOOTH_V, N * 8);
-        launch_vconv(c->work, c->tmpA, nullptr, nc, nr, dst, nullptr, nr, 1, 0, g, nullptr);
+        launch_vconv(c->stream, c->tmpA, nullptr, nc, nr, dst, nullptr, nr, 1, 0, g, nullptr);
     }
     return 0;
 }
@@ -440,11 +387,11 @@ int enqueue_gradients(klt_ctx *c, const float *img, int nc, int nr, float *gx, f
     const double N = (double)nc * nr;
     {
         TimerScope t(c, F_GRAD_H, N * 12);
-        launch_hconv_f32(c->work, img, nc, nr, c->tmpA, c->tmpB, nc, 1, 0, c->deriv[2], &c->gauss[2]);
+        launch_hconv_f32(c->stream, img, nc, nr, c->tmpA, c->tmpB, nc, 1, 0, c->deriv[2], &c->gauss[2]);
     }
     {
         TimerScope t(c, F_GRAD_V, N * 16);
-        launch_vconv(c->work, c->tmpA, c->tmpB, nc, nr, gx, gy, nr, 1, 0, c->gauss[2], &c->deriv[2]);
+        launch_vconv(c->stream, c->tmpA, c->tmpB, nc, nr, gx, gy, nr, 1, 0, c->gauss[2], &c->deriv[2]);
     }
     return 0;
 }
@@ -460,7 +407,7 @@ bool fused_smooth_ok(const klt_ctx *c)
 // the register-blocked kernels take per-entry geometry (levels of different size in one launch); dims must fit a short
 bool merged_grad_ok(const klt_ctx *c)
 {
-    return g_smooth_grad_variant == 0 && c->gauss[2].sym == 1 && c->deriv[2].sym == -1 && c->gauss[2].n == 7 && c->deriv[2].n == 7;
+    return c->gauss[2].sym == 1 && c->deriv[2].sym == -1 && c->gauss[2].n == 7 && c->deriv[2].n == 7;
 }
 bool fused_grad_ok(const klt_ctx *c) { return c->use_fused && smooth_grad_lds_bytes(-1, grad_radius(c)) <= kMaxLds; }
 bool fused_reduce_ok(const klt_ctx *c) { return c->use_fused && pyr_reduce_lds_bytes(c->p.subsampling, c->gauss[1].n) <= kMaxLds; }
@@ -491,7 +438,7 @@ int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int
     // launch also consumes the reduction stage's input (4 per pixel of level 0 -- the part of 4 (N0 + N1) that no longer
     // touches HBM); pyr_vreduce is charged the stage's output, so the step total is unchanged
     TimerScope t(c, F_SMOOTH_GRAD, N * ((raw_kind == 1 ? 1 : 4) + 4) + N * 12 + (hred ? 4.0 * N : 0.0));
-    if (int e = launch_smooth_grad(c->work, a, batch, kind, hred))
+    if (int e = launch_smooth_grad(c->stream, a, batch, kind, hred))
         return fail(c, KLT_ERR_DEVICE, std::string("smooth_grad launch: ") + hipGetErrorString((hipError_t)e));
     return 0;
 }
@@ -506,7 +453,7 @@ int enqueue_fused_grad(klt_ctx *c, int batch, const float *const *img, float *co
     a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
     a.ncols = nc; a.nrows = nr; a.R = grad_radius(c);
     TimerScope t(c, F_GRAD, (double)nc * nr * batch * 12);
-    if (int e = launch_smooth_grad(c->work, a, batch, u8_input ? 3 : 2))
+    if (int e = launch_smooth_grad(c->stream, a, batch, u8_input ? 3 : 2))
         return fail(c, KLT_ERR_DEVICE, std::string("gradient launch: ") + hipGetErrorString((hipError_t)e));
     return 0;
 }
@@ -514,7 +461,6 @@ int enqueue_fused_grad(klt_ctx *c, int batch, const float *const *img, float *co
 int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
 {
     if (int rc = check_ready(c)) return rc;
-    c->work = c->stream;
     if (!slot_ids || n <= 0) return fail(c, KLT_ERR_ARG, "empty slot list");
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<Slot *> sl((size_t)n);
@@ -524,7 +470,6 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         for (int j = 0; j < i; j++)
             if (sl[j] == sl[i]) return fail(c, KLT_ERR_ARG, "slot listed twice");
         if (int rc = layout_pyramid(c, sl[i])) return rc;
-        if (int rc = wait_slot_readers(c, sl[i])) return rc;
         if (sl[i]->upload_pending) {                        // asynchronous ingest: the frame must have landed
             HIPCHK(c, hipStreamWaitEvent(c->stream, sl[i]->ev_upload, 0));
             sl[i]->upload_pending = false;
@@ -549,35 +494,9 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         if (int rc = ensure_tmp(c, (size_t)s0->nc * s0->nr)) return rc;
 
         // level 0: smoothed frame (trackFeatures.py:165-166) and its gradients (:171-172)
-        const bool split = c->split_l0 && fused_smooth_ok(c) && fused_grad_ok(c) && merged_grad_ok(c) && s0->nlev > 1 &&
-                           (c->gauss[0].n == 5 || c->gauss[0].n == 9);
-        hipEvent_t ev_join = nullptr;
         bool h1_fused = false;              // level 1 comes from the H1 planes written by the level-0 kernel
         bool levels_fused = false;          // ... and every level >= 1 is one pyr_level_kernel launch
-        if (split) {
-            // KLT_OPT_SPLIT_L0: smooth alone, then the (VALU-bound) level-0 gradients on the main stream overlap the
-            // (latency-bound) reductions and small-level gradients on the side stream; both only need the level-0 image
-            SmoothGradArgs sa;
-            std::memset(&sa, 0, sizeof(sa));
-            for (int b = 0; b < B; b++) {
-                sa.raw[b] = g[b]->raw_kind == 1 ? (const void *)g[b]->u8 : (const void *)g[b]->f32;
-                sa.img[b] = g[b]->lv[0].img;
-            }
-            sa.smooth = c->gauss[0]; sa.ggauss = c->gauss[2]; sa.gderiv = c->deriv[2];
-            sa.ncols = s0->nc; sa.nrows = s0->nr; sa.R = grad_radius(c);
-            {
-                TimerScope t(c, F_SMOOTH_GRAD, (double)s0->nc * s0->nr * B * ((s0->raw_kind == 1 ? 1 : 4) + 4));
-                if (launch_smooth_only(c->stream, sa, B, s0->raw_kind == 1)) return fail(c, KLT_ERR_STATE, "no smoothing kernel");
-            }
-            if (!c->sstream) HIPCHK(c, hipStreamCreateWithFlags(&c->sstream, hipStreamNonBlocking));
-            hipEvent_t ev_fork;
-            if (int rc = fresh_event(c, &ev_fork)) return rc;
-            HIPCHK(c, hipEventRecord(ev_fork, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->sstream, ev_fork, 0));
-            for (int b = 0; b < B; b++) { src[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy; }
-            if (int rc = enqueue_fused_grad(c, B, src, gx, gy, s0->nc, s0->nr)) return rc;      // main stream
-            c->work = c->sstream;                                                             // the rest: side stream
-        } else if (fused_smooth_ok(c)) {
+        if (fused_smooth_ok(c)) {
             for (int b = 0; b < B; b++) {
                 raw[b] = g[b]->raw_kind == 1 ? (const void *)g[b]->u8 : (const void *)g[b]->f32;
                 img[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy;
@@ -617,7 +536,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                 a.src_nr = ls.nr; a.nc = ld.nc; a.nr = ld.nr; a.hnext_nc = more ? s0->lv[l + 1].nc : 0;
                 // algorithmic bytes: the level's output (4 N_l) + its gradients (12 N_l) + the next reduction's input (4 N_l)
                 TimerScope t(c, F_PYR_REDUCE, (double)B * ld.nc * ld.nr * (4.0 + 12.0 + (more ? 4.0 : 0.0)));
-                if (int e = launch_pyr_level(c->work, a, B, more))
+                if (int e = launch_pyr_level(c->stream, a, B, more))
                     return fail(c, KLT_ERR_DEVICE, std::string("pyr_level launch: ") + hipGetErrorString((hipError_t)e));
                 hoff += plane * B;
             }
@@ -638,22 +557,22 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                     const size_t plane = (size_t)ls.nr * ld.nc;
                     for (int b = 0; b < B; b++) a.src[b] = c->h1 + plane * b;
                     TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ld.nc * ld.nr));
-                    if (int e = launch_pyr_vreduce(c->work, a, B))
+                    if (int e = launch_pyr_vreduce(c->stream, a, B))
                         return fail(c, KLT_ERR_DEVICE, std::string("pyr_vreduce launch: ") + hipGetErrorString((hipError_t)e));
                 } else {
                     TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ls.nc * ls.nr + (double)ld.nc * ld.nr));
-                    if (int e = launch_pyr_reduce(c->work, a, B))
+                    if (int e = launch_pyr_reduce(c->stream, a, B))
                         return fail(c, KLT_ERR_DEVICE, std::string("pyr_reduce launch: ") + hipGetErrorString((hipError_t)e));
                 }
             } else {
                 for (int b = 0; b < B; b++) {
                     {
                         TimerScope t(c, F_PYR_H, 4.0 * ((double)ls.nc * ls.nr + (double)ld.nc * ls.nr));
-                        launch_hconv_f32(c->work, g[b]->lv[l - 1].img, ls.nc, ls.nr, c->tmpA, nullptr, ld.nc, ss, ss / 2, c->gauss[1], nullptr);
+                        launch_hconv_f32(c->stream, g[b]->lv[l - 1].img, ls.nc, ls.nr, c->tmpA, nullptr, ld.nc, ss, ss / 2, c->gauss[1], nullptr);
                     }
                     {
                         TimerScope t(c, F_PYR_V, 4.0 * ((double)ld.nc * ls.nr + (double)ld.nc * ld.nr));
-                        launch_vconv(c->work, c->tmpA, nullptr, ld.nc, ls.nr, g[b]->lv[l].img, nullptr, ld.nr, ss, ss / 2, c->gauss[1], nullptr);
+                        launch_vconv(c->stream, c->tmpA, nullptr, ld.nc, ls.nr, g[b]->lv[l].img, nullptr, ld.nr, ss, ss / 2, c->gauss[1], nullptr);
                     }
                 }
             }
@@ -681,14 +600,8 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
             a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
             a.ncols = s0->lv[1].nc; a.nrows = s0->lv[1].nr; a.R = grad_radius(c);
             TimerScope t(c, F_GRAD, bytes);
-            if (int er = launch_smooth_grad(c->work, a, e, 2))
+            if (int er = launch_smooth_grad(c->stream, a, e, 2))
                 return fail(c, KLT_ERR_DEVICE, std::string("gradient launch: ") + hipGetErrorString((hipError_t)er));
-        }
-        if (split) {
-            if (int rc = fresh_event(c, &ev_join)) { c->work = c->stream; return rc; }
-            const hipError_t e1 = hipEventRecord(ev_join, c->sstream), e2 = hipStreamWaitEvent(c->stream, ev_join, 0);
-            c->work = c->stream;
-            if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, KLT_ERR_DEVICE, "fork/join of the pyramid build failed");
         }
         for (Slot *s : g) s->pyr_valid = true;
     }
@@ -708,6 +621,8 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
 // =============================================================================================== ABI
 
 extern "C" {
+
+int klt_comm_fence_async(klt_ctx *c);
 
 int klt_abi_version(void) { return KLT_ABI_VERSION; }
 
@@ -742,8 +657,6 @@ int klt_create(int device, klt_ctx **out)
         delete c;
         return KLT_ERR_DEVICE;
     }
-    c->tstream = c->stream;
-    c->work = c->stream;
     if (const char *v = getenv("KLT_FUSED_HREDUCE")) c->fuse_hreduce = atoi(v) != 0;      // experiment hook (initial value of the option)
     if (const char *v = getenv("KLT_TRACK_XCD_ORDER")) c->track_xcd_order = atoi(v) != 0;
     if (const char *v = getenv("KLT_FUSED_LEVELS")) c->fuse_levels = atoi(v) != 0;
@@ -756,9 +669,8 @@ void klt_destroy(klt_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->tstream && c->tstream != c->stream) { hipStreamSynchronize(c->tstream); hipStreamDestroy(c->tstream); }
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
-    if (c->sstream) { hipStreamSynchronize(c->sstream); hipStreamDestroy(c->sstream); }
+    if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
     for (void *p : c->pinned) hipHostFree(p);
     for (hipEvent_t e : c->ring) hipEventDestroy(e);
     for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes); }
@@ -781,11 +693,9 @@ int klt_sync(klt_ctx *c)
     if (!c) return KLT_ERR_ARG;
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
+    if (c->comm) { std::string err; if (int rc = comm_wait(c->comm, err)) return fail(c, rc, err); }
     return KLT_OK;
 }
-
-void *klt_track_stream_handle(klt_ctx *c) { return c ? (void *)c->tstream : nullptr; }
 
 void *klt_stream_handle(klt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
@@ -814,8 +724,15 @@ int klt_set_kernels(klt_ctx *c, int which, const double *gauss, int ng, const do
     if (which < 0 || which > 2) return fail(c, KLT_ERR_ARG, "which must be 0, 1 or 2");
     if (ng < 1 || nd < 1 || ng > KLT_MAX_KERNEL_WIDTH || nd > KLT_MAX_KERNEL_WIDTH || !(ng & 1) || !(nd & 1))
         return fail(c, KLT_ERR_ARG, "tap counts must be odd and at most 71");
-    make_taps(gauss, ng, c->gauss[which]);
-    make_taps(deriv, nd, c->deriv[which]);
+    Taps g, d;
+    make_taps(gauss, ng, g);
+    make_taps(deriv, nd, d);
+    // resident pyramids (sequentialMode: tc.pyramid_last, trackFeatures.py:152-161) stay valid unless the taps really change
+    const bool same = c->have_taps[which] && std::memcmp(&g, &c->gauss[which], sizeof(Taps)) == 0 &&
+                      std::memcmp(&d, &c->deriv[which], sizeof(Taps)) == 0;
+    if (same) return KLT_OK;
+    c->gauss[which] = g;
+    c->deriv[which] = d;
     c->have_taps[which] = true;
     for (Slot &s : c->slots) s.pyr_valid = false;
     return KLT_OK;
@@ -909,36 +826,16 @@ int klt_set_option(klt_ctx *c, int option, int value)
 {
     if (!c) return KLT_ERR_ARG;
     if (option == KLT_OPT_FUSED_KERNELS) { c->use_fused = value != 0; return KLT_OK; }
-    if (option == KLT_OPT_SMOOTH_GRAD_VARIANT) { g_smooth_grad_variant = value; return KLT_OK; }
-    if (option == KLT_OPT_PYR_REDUCE_VARIANT) { g_pyr_reduce_variant = value; return KLT_OK; }
     if (option == KLT_OPT_SAT_VARIANT) { c->sat_variant = value; return KLT_OK; }
     if (option == KLT_OPT_TRACK_VARIANT) { g_track_variant = value; return KLT_OK; }
     if (option == KLT_OPT_FUSED_HREDUCE) { c->fuse_hreduce = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TRACK_XCD_ORDER) { c->track_xcd_order = value != 0; return KLT_OK; }
     if (option == KLT_OPT_FUSED_LEVELS) { c->fuse_levels = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
-    if (option == KLT_OPT_SPLIT_L0) { c->split_l0 = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_PARALLEL_NMS) { c->use_mis = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_AFFINE_STATE) {
         if (value >= 0 && ((size_t)value >= c->aff.size() || !c->aff[value].rec)) return fail(c, KLT_ERR_STATE, "affine state not allocated");
         c->select_aff_state = value;
-        return KLT_OK;
-    }
-    if (option == KLT_OPT_TRACK_STREAM) {
-        HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->tstream != c->stream) HIPCHK(c, hipStreamSynchronize(c->tstream));
-        if (value && c->tstream == c->stream) {
-            hipStream_t t = nullptr;
-            HIPCHK(c, hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
-            c->tstream = t;
-        } else if (!value && c->tstream != c->stream) {
-            HIPCHK(c, hipStreamDestroy(c->tstream));
-            c->tstream = c->stream;
-        }
-        c->track_stream_on = value != 0;
-        c->ev_track_valid = false;
-        for (Slot &sl : c->slots) sl.ev_read_valid = false;
         return KLT_OK;
     }
     return fail(c, KLT_ERR_ARG, "unknown option");
@@ -948,6 +845,14 @@ int klt_build_pyramids(klt_ctx *c, int slot)
 {
     if (int rc = klt_build_pyramids_async(c, slot)) return rc;
     return klt_sync(c);
+}
+
+int klt_slot_state(klt_ctx *c, int slot)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (slot < 0 || (size_t)slot >= c->slots.size()) return 0;
+    const Slot &s = c->slots[slot];
+    return (s.raw_kind != 0 ? 1 : 0) | (s.pyr_valid ? 2 : 0);
 }
 
 int klt_swap_slots(klt_ctx *c, int a, int b)
@@ -968,7 +873,6 @@ int klt_featbuf_upload(klt_ctx *c, int fb, const klt_feat *src, int n)
     HIPCHK(c, hipSetDevice(c->device));
     FeatBuf *b;
     if (int rc = get_fb(c, fb, n > 0 ? n : 1, &b)) return rc;
-    if (int rc = wait_tracker(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(b->d, src, (size_t)n * sizeof(klt_feat), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return KLT_OK;
@@ -979,7 +883,7 @@ int klt_featbuf_download(klt_ctx *c, int fb, klt_feat *dst, int n)
     if (!c || !dst || n < 0) return fail(c, KLT_ERR_ARG, "bad argument");
     if (fb < 0 || (size_t)fb >= c->fbs.size() || c->fbs[fb].cap < n) return fail(c, KLT_ERR_STATE, "feature buffer not that large");
     HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = wait_tracker(c)) return rc;
+    if (int rc = klt_comm_fence_async(c)) return rc;        // a gathered table is complete before it is read back
     HIPCHK(c, hipMemcpyAsync(dst, c->fbs[fb].d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return KLT_OK;
@@ -991,7 +895,6 @@ int klt_featbuf_alloc(klt_ctx *c, int fb, int n)
     HIPCHK(c, hipSetDevice(c->device));
     FeatBuf *b;
     if (int rc = get_fb(c, fb, n, &b)) return rc;
-    if (int rc = wait_tracker(c)) return rc;
     HIPCHK(c, hipMemsetAsync(b->d, 0xff, (size_t)n * sizeof(klt_feat), c->stream));     // val = -1 everywhere
     return KLT_OK;
 }
@@ -1030,7 +933,6 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     const size_t N = (size_t)nc * nr;
     FeatBuf *b;
     if (int rc = get_fb(c, fb, n, &b)) return rc;
-    if (int rc = wait_tracker(c)) return rc;
 
     // borders / half-windows as ScanImageForGoodFeatures receives them: Python floats truncated to C ints
     // (selectGoodFeatures.py:168-169, :215-221, goodFeaturesUtils.pyx:35-37)
@@ -1351,6 +1253,21 @@ static void fill_track_params(const klt_ctx *c, const Slot *s1, TrackArgs &a, in
     a.inv_ss = 1.0f / (float)s1->ss;
 }
 
+// XCD-aware feature order (KLT_OPT_TRACK_XCD_ORDER): one permutation of 0..n-1 per pair of the launch.  It is only a locality
+// hint (any permutation tracks every feature exactly once), so it is recomputed when the shape of the launch changes and every
+// 64th launch (a sequence's features drift, and its lists alternate between two buffers); in between the stored one is reused.
+static int set_track_order(klt_ctx *c, TrackArgs &a, int n, int npairs)
+{
+    if (!c->track_xcd_order || n < 64) return 0;
+    if (int rc = ensure(c, c->track_order, c->track_order_cap, (size_t)n * npairs)) return rc;
+    a.order = c->track_order;
+    a.order_chunk = (n + 7) / 8;
+    a.order_refresh = (c->order_n != n || c->order_pairs != npairs || c->order_age >= 64) ? 1 : 0;
+    if (a.order_refresh) { c->order_n = n; c->order_pairs = npairs; c->order_age = 0; }
+    c->order_age++;
+    return 0;
+}
+
 static int check_pair(klt_ctx *c, int slot1, int slot2, Slot **p1, Slot **p2)
 {
     if (int rc = get_slot(c, slot1, p1, false)) return rc;
@@ -1386,26 +1303,13 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
     fill_levels(s1, s2, a.lv);
     a.in = c->fbs[fb_in].d; a.out = bo->d;
     fill_track_params(c, s1, a, n);
-    if (c->track_xcd_order && n >= 64 && c->p.window_width == 7) {
-        if (int rc = ensure(c, c->track_order, c->track_order_cap, (size_t)n)) return rc;
-        a.order = c->track_order;
-        a.order_chunk = (n + 7) / 8;
-        // the order is only a locality hint (any permutation of 0..n-1 tracks every feature exactly once): it is recomputed when
-        // the list length changes and every 64th launch (a sequence's features drift, and its lists alternate between two
-        // buffers); in between the stored permutation is reused
-        a.order_refresh = (c->order_n != n || c->order_age >= 64) ? 1 : 0;
-        if (a.order_refresh) { c->order_n = n; c->order_age = 0; }
-        c->order_age++;
-    }
-    if (int rc = tracker_begin(c)) return rc;
+    if (int rc = set_track_order(c, a, n, 1)) return rc;
     {
         const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
-        TimerScope t(c, F_TRACK, (double)n * (foot * 2 * s1->nlev + 32), c->tstream);   // refined by the caller from klt_track_stats
-        if (launch_track(c->tstream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
+        TimerScope t(c, F_TRACK, (double)n * (foot * 2 * s1->nlev + 32), c->stream);   // refined by the caller from klt_track_stats
+        if (launch_track(c->stream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
     }
-    if (c->collect_stats) launch_track_stats(c->tstream, a.in, a.out, n, s1->nlev, c->stats_d);
-    Slot *both[2] = {s1, s2};
-    if (int rc = tracker_end(c, both, 2)) return rc;
+    if (c->collect_stats) launch_track_stats(c->stream, a.in, a.out, n, s1->nlev, c->stats_d);
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -1438,22 +1342,27 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
         table[i].out = c->fbs[fb_out[i]].d;
     }
     if (int rc = ensure(c, c->pair_table, c->pair_table_cap, (size_t)npairs)) return rc;
-    // pageable source: the runtime stages it before returning; stream order protects the previous launch's table
-    if (int rc = tracker_begin(c)) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->pair_table, table.data(), (size_t)npairs * sizeof(TrackPairDesc), hipMemcpyHostToDevice, c->tstream));
+    // the descriptor table is uploaded only when it differs from the one already on the device (a shard that is tracked
+    // repeatedly keeps its slots and buffers).  Pageable source: the runtime stages it before returning; stream order protects
+    // the previous launch's table
+    if (c->pair_table_host.size() != table.size() ||
+        std::memcmp(c->pair_table_host.data(), table.data(), table.size() * sizeof(TrackPairDesc)) != 0) {
+        HIPCHK(c, hipMemcpyAsync(c->pair_table, table.data(), (size_t)npairs * sizeof(TrackPairDesc), hipMemcpyHostToDevice, c->stream));
+        c->pair_table_host = table;
+    }
     TrackArgs a;
     std::memset(&a, 0, sizeof(a));
     a.pairs = c->pair_table;
     a.npairs = npairs;
     fill_track_params(c, first, a, n);
+    if (int rc = set_track_order(c, a, n, npairs)) return rc;
     {
         const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
-        TimerScope t(c, F_TRACK, (double)npairs * n * (foot * 2 * first->nlev + 32), c->tstream);
-        if (launch_track(c->tstream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
+        TimerScope t(c, F_TRACK, (double)npairs * n * (foot * 2 * first->nlev + 32), c->stream);
+        if (launch_track(c->stream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
     }
     if (c->collect_stats)
-        for (int i = 0; i < npairs; i++) launch_track_stats(c->tstream, table[i].in, table[i].out, n, first->nlev, c->stats_d);
-    if (int rc = tracker_end(c, used.data(), (int)used.size())) return rc;
+        for (int i = 0; i < npairs; i++) launch_track_stats(c->stream, table[i].in, table[i].out, n, first->nlev, c->stats_d);
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -1502,7 +1411,6 @@ int klt_affine_alloc(klt_ctx *c, int state, int n)
         a.n = n;
         a.tn = tn;
     }
-    if (int rc = wait_tracker(c)) return rc;
     launch_affine_reset(c->stream, a.rec, a.n);
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
@@ -1513,7 +1421,6 @@ int klt_affine_download(klt_ctx *c, int state, klt_affine_rec *dst, int n)
     if (!c || !dst || state < 0 || (size_t)state >= c->aff.size() || !c->aff[state].rec || c->aff[state].n < n)
         return fail(c, KLT_ERR_STATE, "affine state not allocated (or smaller than requested)");
     HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = wait_tracker(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(dst, c->aff[state].rec, (size_t)n * sizeof(klt_affine_rec), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return KLT_OK;
@@ -1539,11 +1446,9 @@ int klt_track_affine_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_o
     a.step = c->p.step_factor; a.small = c->p.min_determinant; a.th = c->p.min_displacement;
     a.th_aff = c->ap.min_displacement; a.max_residue = c->ap.max_residue; a.max_differ = c->ap.max_displacement_differ;
     {
-        TimerScope t(c, F_AFFINE, (double)n * 12.0 * (a.width + 1) * (a.height + 1) * 3, c->tstream);
-        launch_affine(c->tstream, a);
+        TimerScope t(c, F_AFFINE, (double)n * 12.0 * (a.width + 1) * (a.height + 1) * 3, c->stream);
+        launch_affine(c->stream, a);
     }
-    Slot *both[2] = {s1, s2};
-    if (int rc = tracker_end(c, both, 2)) return rc;
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -1575,13 +1480,116 @@ int klt_track_stats_read(klt_ctx *c, klt_track_stats *out)
 {
     if (!c || !out) return fail(c, KLT_ERR_ARG, "null argument");
     unsigned long long h[1 + 2 * KLT_MAX_LEVELS];
-    if (int rc = wait_tracker(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(h, c->stats_d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->collect_stats = false;
     out->features = h[0];
     for (int l = 0; l < KLT_MAX_LEVELS; l++) { out->level_visits[l] = h[1 + l]; out->iterations[l] = h[1 + KLT_MAX_LEVELS + l]; }
     return KLT_OK;
+}
+
+// ------------------------------------------------------------------------------------- multi-GPU
+static std::string g_comm_error;      // klt_comm_unique_id has no context to report into
+
+int klt_comm_unique_id(void *out128)
+{
+    const int rc = comm_unique_id(out128, g_comm_error);
+    if (rc) g_create_error = g_comm_error;          // readable through klt_last_error(NULL)
+    return rc;
+}
+
+int klt_comm_init_rank(klt_ctx *c, int nranks, int rank, const void *unique_id)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (c->comm) return fail(c, KLT_ERR_STATE, "the context already has a communicator");
+    std::string err;
+    if (int rc = comm_create(c->device, nranks, rank, unique_id, &c->comm, err)) return fail(c, rc, err);
+    return KLT_OK;
+}
+
+int klt_comm_destroy(klt_ctx *c)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
+    return KLT_OK;
+}
+
+int klt_comm_info(klt_ctx *c, int *nranks, int *rank)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (nranks) *nranks = comm_nranks(c->comm);
+    if (rank) *rank = comm_rank(c->comm);
+    return KLT_OK;
+}
+
+static int gather_common(klt_ctx *c, int fb_src, int fb_dst, int n, int root /* -1: all-gather */)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (!c->comm) return fail(c, KLT_ERR_STATE, "klt_comm_init_rank has not been called");
+    if (n <= 0 || fb_src == fb_dst) return fail(c, KLT_ERR_ARG, "bad gather arguments");
+    if (fb_src < 0 || (size_t)fb_src >= c->fbs.size() || c->fbs[fb_src].cap < n) return fail(c, KLT_ERR_STATE, "source feature buffer not that large");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nranks = comm_nranks(c->comm), rank = comm_rank(c->comm);
+    const bool need_dst = root < 0 || rank == root;
+    if ((long long)n * nranks > 0x7fffffffLL) return fail(c, KLT_ERR_ARG, "gathered table too large");
+    klt_feat *dst = nullptr;
+    if (need_dst) {
+        FeatBuf *bd;
+        if (int rc = get_fb(c, fb_dst, n * nranks, &bd)) return rc;      // may grow c->fbs: take the source pointer afterwards
+        dst = bd->d;
+    }
+    const klt_feat *src = c->fbs[fb_src].d;
+    std::string err;
+    const size_t bytes = (size_t)n * sizeof(klt_feat);
+    const int rc = root < 0 ? comm_allgather(c->comm, c->stream, src, dst, bytes, err)
+                            : comm_gather(c->comm, c->stream, src, dst, bytes, root, err);
+    if (rc) return fail(c, rc, err);
+    c->fbs[fb_src].comm_done = comm_last_done(c->comm);
+    if (need_dst) c->fbs[fb_dst].comm_done = c->fbs[fb_src].comm_done;
+    return KLT_OK;
+}
+
+int klt_comm_fence_featbuf_async(klt_ctx *c, int fb)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (fb < 0 || (size_t)fb >= c->fbs.size() || !c->fbs[fb].comm_done) return KLT_OK;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->fbs[fb].comm_done, 0));
+    return KLT_OK;
+}
+
+int klt_allgather_featbuf_async(klt_ctx *c, int fb_src, int fb_dst, int n) { return gather_common(c, fb_src, fb_dst, n, -1); }
+
+int klt_gather_featbuf_async(klt_ctx *c, int fb_src, int fb_dst, int n, int root)
+{
+    if (c && c->comm && (root < 0 || root >= comm_nranks(c->comm))) return fail(c, KLT_ERR_ARG, "gather root out of range");
+    return gather_common(c, fb_src, fb_dst, n, root < 0 ? 0 : root);
+}
+
+int klt_comm_fence_async(klt_ctx *c)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (!c->comm) return KLT_OK;
+    std::string err;
+    const int rc = comm_fence(c->comm, c->stream, err);
+    return rc ? fail(c, rc, err) : KLT_OK;
+}
+
+int klt_comm_wait(klt_ctx *c)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (!c->comm) return KLT_OK;
+    std::string err;
+    const int rc = comm_wait(c->comm, err);
+    return rc ? fail(c, rc, err) : KLT_OK;
+}
+
+int klt_comm_allreduce_max(klt_ctx *c, double *inout, int n)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (!c->comm) return fail(c, KLT_ERR_STATE, "klt_comm_init_rank has not been called");
+    std::string err;
+    const int rc = comm_allreduce_max(c->comm, inout, n, err);
+    return rc ? fail(c, rc, err) : KLT_OK;
 }
 
 // -------------------------------------------------------------------------------------- inspection

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "klt_gpu.h"
 
 // FP64 taps in the order scipy.ndimage.correlate1d consumes them (i.e. the convolve.py taps reversed,
@@ -63,7 +65,7 @@ struct TrackArgs {
     klt_feat *out;
     const TrackPairDesc *pairs;         // batched launch: npairs descriptors (lv / in / out above unused)
     int npairs;
-    uint32_t *order;                    // single-pair launch, optional: scratch [n] for the XCD-aware feature order (see track_order_kernel)
+    uint32_t *order;                    // optional: scratch [npairs][n] for the XCD-aware feature order, one permutation per pair (see track_order_kernel)
     int order_chunk;                    // ceil(n / 8): features per XCD
     int order_refresh;                  // 1: sort before this launch; 0: reuse the order of an earlier launch on the same buffer (any
                                         // permutation of 0..n-1 is correct; an old one is only a little less local)
@@ -129,9 +131,7 @@ void launch_hconv_f32(hipStream_t s, const float *in, int ncols, int nrows, floa
 void launch_vconv(hipStream_t s, const float *inA, const float *inB, int ncols, int nrows, float *outA, float *outB,
                   int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb);
 
-extern int g_smooth_grad_variant;   // test hook: 0 register-blocked, 1 one-sample-per-thread
-extern int g_track_variant;         // tracker kernel for 7x7 windows: 4 (default) track_kernel_qv, 0 track_kernel, 1 _pf, 2 _q, 3 <GRID>
-extern int g_pyr_reduce_variant;    // test hook: 0 1024-thread reduce (default), 1 512-thread all-f32 reduce
+extern int g_track_variant;         // tracker kernels: 4 (default) quad-load kernels where they apply, 0 always track_kernel
 size_t smooth_grad_lds_bytes(int smooth_radius /* -1: no smoothing stage */, int R);
 size_t pyr_reduce_lds_bytes(int ss, int ntaps);
 // kind: 0 = u8 frame + smoothing, 1 = f32 frame + smoothing, 2 = f32 image gradients only, 3 = u8 image gradients only
@@ -140,7 +140,6 @@ bool smooth_grad_hred_ok(const SmoothGradArgs &a, int batch, int kind, const Tap
 int launch_pyr_vreduce(hipStream_t s, const PyrReduceArgs &a, int batch);
 int launch_pyr_level(hipStream_t s, const LevelArgs &a, int batch, bool emit_hnext);   // subsampling 4, 21 / 7 / 7 taps   // level 1 from the H1 planes (src = H1, src_nr rows x dst_nc columns)
 int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch);
-int launch_smooth_only(hipStream_t s, const SmoothGradArgs &a, int batch, bool u8_input);   // 1: no specialised kernel
 
 void launch_sat_rows(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows);
 void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows);
@@ -174,3 +173,17 @@ void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, 
 int launch_track(hipStream_t s, const TrackArgs &a);
 void launch_affine(hipStream_t s, const AffineArgs &a);
 void launch_affine_reset(hipStream_t s, klt_affine_rec *rec, int n);   // returns 0, or -1 for an unsupported window
+
+// ---- multi-GPU (comm.hip): RCCL communicator + side stream; every function returns 0 or a klt_status and fills `err` ----
+struct KltComm;
+int  comm_unique_id(void *out128, std::string &err);
+int  comm_create(int device, int nranks, int rank, const void *unique_id, KltComm **out, std::string &err);
+void comm_destroy(KltComm *k);
+int  comm_nranks(const KltComm *k);
+hipEvent_t comm_last_done(const KltComm *k);   // end of the most recent collective (an event of the communicator's ring)
+int  comm_rank(const KltComm *k);
+int  comm_allgather(KltComm *k, hipStream_t producer, const void *src, void *dst, size_t bytes, std::string &err);
+int  comm_gather(KltComm *k, hipStream_t producer, const void *src, void *dst, size_t bytes, int root, std::string &err);
+int  comm_fence(KltComm *k, hipStream_t consumer, std::string &err);
+int  comm_wait(KltComm *k, std::string &err);
+int  comm_allreduce_max(KltComm *k, double *inout, int n, std::string &err);

@@ -54,7 +54,6 @@ constexpr int OW = 32, OH = 8;         // output tile of pyr_reduce_kernel
 }
 constexpr int OW_DEFAULT = 32, OH_DEFAULT = 8;
 namespace {
-constexpr int FTH = 16;                // tile height of the compile-time specialised smooth_grad kernels
 
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
@@ -228,93 +227,6 @@ __device__ __forceinline__ void load_taps(TapRegs<NT> &r, const Taps &t)
     for (int i = 0; i < NT; i++) r.k[i] = t.k[i];
 }
 
-// SYM = +1: acc = c0*k0; acc += (c[-j] + c[+j]) * k[-j], j = r..1     (scipy correlate1d, symmetric branch)
-// SYM = -1: acc = c0*k0; acc += (c[-j] - c[+j]) * k[-j]              (antisymmetric branch)
-template <int NT, int SYM, int STRIDE>
-__device__ __forceinline__ float correlate_ct(const float *c, const TapRegs<NT> &t)
-{
-    constexpr int H = NT / 2;
-    double acc = (double)c[0] * t.k[H];
-#pragma unroll
-    for (int jj = -H; jj < 0; jj++) {
-        const double lo = (double)c[jj * STRIDE], hi = (double)c[-jj * STRIDE];
-        const double pr = SYM > 0 ? lo + hi : lo - hi;
-        acc = acc + pr * t.k[H + jj];
-    }
-    return (float)acc;
-}
-
-// (An f64-in-LDS variant of this kernel -- widening each sample once when produced -- was measured 20 % slower:
-// twice the LDS bytes and half the resident blocks cost more than the saved conversions.  profiles/r01_v4.)
-template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_>
-__global__ __launch_bounds__(256) void smooth_grad_fast(SmoothGradArgs a)
-{
-    constexpr int rs = SMOOTH ? NS / 2 : 0;
-    constexpr int R = (NG > ND ? NG : ND) / 2;
-    constexpr int IW = TW + 2 * R, IH = TH_ + 2 * R, RW = IW + 2 * rs, RH = IH + 2 * rs;
-    constexpr int AB = SMOOTH ? RH * RW + RH * IW : 0, DE = 2 * IH * TW;
-    constexpr int OFF_C = AB > DE ? AB : DE;
-    __shared__ float lds[OFF_C + IH * IW];
-    float *const A = lds, *const B = lds + RH * RW, *const D = lds, *const E = lds + IH * TW, *const C = lds + OFF_C;
-    const int tid = threadIdx.x, b = blockIdx.z;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
-    const int nc = a.ncols, nr = a.nrows;
-    const TIn *__restrict__ raw = (const TIn *)a.raw[b];
-    TapRegs<NG> kg;
-    TapRegs<ND> kd;
-    load_taps(kg, a.ggauss);
-    load_taps(kd, a.gderiv);
-
-    if (SMOOTH) {
-        TapRegs<NS> ks;
-        load_taps(ks, a.smooth);
-        for (int i = tid; i < RH * RW; i += 256) {
-            const int r = i / RW, c = i % RW;
-            const int gy = reflect_fast(ty0 - R - rs + r, nr), gx = reflect_fast(tx0 - R - rs + c, nc);
-            A[i] = (float)raw[(size_t)gy * nc + gx];
-        }
-        __syncthreads();
-        for (int i = tid; i < RH * IW; i += 256) {
-            const int r = i / IW, c = i % IW;
-            B[i] = correlate_ct<NS, 1, 1>(A + r * RW + c + rs, ks);
-        }
-        __syncthreads();
-        float *__restrict__ img = a.img[b];
-        for (int i = tid; i < IH * IW; i += 256) {
-            const int r = i / IW, c = i % IW;
-            const float v = correlate_ct<NS, 1, IW>(B + (r + rs) * IW + c, ks);
-            C[i] = v;
-            const int y = ty0 - R + r, x = tx0 - R + c;
-            if (r >= R && r < R + TH_ && c >= R && c < R + TW && y < nr && x < nc) img[(size_t)y * nc + x] = v;
-        }
-    } else {
-        for (int i = tid; i < IH * IW; i += 256) {
-            const int r = i / IW, c = i % IW;
-            const int gy = reflect_fast(ty0 - R + r, nr), gx = reflect_fast(tx0 - R + c, nc);
-            C[i] = (float)raw[(size_t)gy * nc + gx];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < IH * TW; i += 256) {
-        const int r = i / TW, x = i % TW;
-        const float *c = C + r * IW + x + R;
-        D[i] = correlate_ct<ND, -1, 1>(c, kd);
-        E[i] = correlate_ct<NG, 1, 1>(c, kg);
-    }
-    __syncthreads();
-    float *__restrict__ gxo = a.gx[b];
-    float *__restrict__ gyo = a.gy[b];
-    for (int i = tid; i < TH_ * TW; i += 256) {
-        const int r = i / TW, x = i % TW;
-        const int y = ty0 + r, xx = tx0 + x;
-        if (y < nr && xx < nc) {
-            gxo[(size_t)y * nc + xx] = correlate_ct<NG, 1, TW>(D + (r + R) * TW + x, kg);
-            gyo[(size_t)y * nc + xx] = correlate_ct<ND, -1, TW>(E + (r + R) * TW + x, kd);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // Register-blocked variant (the one dispatched for the default sigmas).  Every thread produces 4 horizontally
 // adjacent samples per step: LDS is read 16 bytes at a time (ds_read_b128, one aligned quad per lane), each
 // sample is widened to f64 once per quad instead of once per tap, and the integer index math is amortised over
@@ -620,85 +532,6 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
     STAGE_MARK(5);
 }
 
-// Smoothing only (frame -> level-0 image), register-blocked like smooth_grad_rb.  Used when the level-0 gradients are
-// computed by a separate launch that overlaps the pyramid reduction on a second stream (KLT_OPT_SPLIT_L0).
-template <typename TIn, int NS, int TH_>
-__global__ __launch_bounds__(256) void smooth_only_rb(SmoothGradArgs a)
-{
-    constexpr int rs = NS / 2;
-    static_assert(rs <= 4, "needs a tap radius <= 4");
-    constexpr int AW = TW + 8, BW = TW, AQ = AW / 4, BQ = BW / 4;
-    constexpr int RH = TH_ + 2 * rs;
-    __shared__ __attribute__((aligned(16))) float lds[RH * AW + RH * BW];
-    float *const A = lds, *const B = lds + RH * AW;
-    const int tid = threadIdx.x, b = blockIdx.z;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
-    const int nc = a.ncols, nr = a.nrows;
-    const TIn *__restrict__ raw = (const TIn *)a.raw[b];
-    TapRegs<NS> ks;
-    load_taps(ks, a.smooth);
-    for (int i = tid; i < RH * AQ; i += 256) {
-        const int r = i / AQ, q = i % AQ;
-        const int gy = reflect_fast(ty0 - rs + r, nr);
-        const int x = tx0 - 4 + 4 * q;
-        const TIn *row = raw + (size_t)gy * nc;
-        float4 v;
-        if (x >= 0 && x + 3 < nc && (nc & 3) == 0) {
-            if (sizeof(TIn) == 1) {
-                const uint32_t wq = *reinterpret_cast<const uint32_t *>(row + x);
-                v.x = (float)(wq & 0xffu); v.y = (float)((wq >> 8) & 0xffu);
-                v.z = (float)((wq >> 16) & 0xffu); v.w = (float)(wq >> 24);
-            } else {
-                v = *reinterpret_cast<const float4 *>(row + x);
-            }
-        } else {
-            v.x = (float)row[reflect_fast(x, nc)]; v.y = (float)row[reflect_fast(x + 1, nc)];
-            v.z = (float)row[reflect_fast(x + 2, nc)]; v.w = (float)row[reflect_fast(x + 3, nc)];
-        }
-        *reinterpret_cast<float4 *>(A + (size_t)i * 4) = v;
-    }
-    __syncthreads();
-    for (int i = tid; i < RH * BQ; i += 256) {               // horizontal pass (B column c = A column c + 4)
-        const int r = i / BQ, q = i % BQ;
-        const float4 *src = reinterpret_cast<const float4 *>(A + r * AW + 4 * q);
-        double v[12];
-        widen4(src[0], v); widen4(src[1], v + 4); widen4(src[2], v + 8);
-        float4 o;
-        o.x = corr_regs<NS, 1>(v + 4, ks); o.y = corr_regs<NS, 1>(v + 5, ks);
-        o.z = corr_regs<NS, 1>(v + 6, ks); o.w = corr_regs<NS, 1>(v + 7, ks);
-        *reinterpret_cast<float4 *>(B + r * BW + 4 * q) = o;
-    }
-    __syncthreads();
-    float *__restrict__ img = a.img[b];
-    static_assert(TH_ % 2 == 0, "tile height must be even");
-    for (int i = tid; i < (TH_ / 2) * BQ; i += 256) {        // vertical pass, quad x two rows per thread
-        const int r = 2 * (i / BQ), q = i % BQ;
-        const int x = tx0 + 4 * q;
-        if (ty0 + r >= nr || x >= nc) continue;
-        double v[4][NS + 1];
-#pragma unroll
-        for (int j = 0; j < NS + 1; j++) {
-            const float4 t = *reinterpret_cast<const float4 *>(B + (r + j) * BW + 4 * q);
-            v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
-        }
-#pragma unroll
-        for (int dr = 0; dr < 2; dr++) {
-            const int y = ty0 + r + dr;
-            if (y >= nr) break;
-            float4 o;
-            o.x = corr_regs<NS, 1>(v[0] + rs + dr, ks); o.y = corr_regs<NS, 1>(v[1] + rs + dr, ks);
-            o.z = corr_regs<NS, 1>(v[2] + rs + dr, ks); o.w = corr_regs<NS, 1>(v[3] + rs + dr, ks);
-            float *dstp = img + (size_t)y * nc + x;
-            if (x + 3 < nc) { dstp[0] = o.x; dstp[1] = o.y; dstp[2] = o.z; dstp[3] = o.w; }
-            else {
-                dstp[0] = o.x;
-                if (x + 1 < nc) dstp[1] = o.y;
-                if (x + 2 < nc) dstp[2] = o.z;
-            }
-        }
-    }
-}
-
 // The f32-rounded horizontal result is kept in LDS as the double it widens to (one widening per sample instead of one
 // per tap of the vertical pass); the source tile stays f32 (an f64 tile was measured slower: half the LDS matters more).
 template <int NT, int STRIDE>
@@ -820,102 +653,6 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
             a.dst[b][(size_t)oy * a.dst_nc + ox] = correlate_sym_f64<NT, OW>(Hd + (ys * SS + r) * OW + xs, k);
     }
     STAGE_MARK(5);
-}
-
-// Variant of the fused reduce (KLT_OPT_PYR_REDUCE_VARIANT = 1, measured slower, kept for the comparison): 512 threads and f32 everywhere in LDS (35 KB for ss 4 / 21 taps), so that four
-// workgroups fit a CU and all tiles of a 1080p pair are resident at once; the tile load of an interior tile is a batch of
-// unconditional aligned quads (a guarded load is a branch, and every join drains vmcnt); the vertical pass widens per tap.
-template <int NT, int STRIDE>
-__device__ __forceinline__ float correlate_sym_f32src(const float *c, const TapRegs<NT> &t)
-{
-    constexpr int H = NT / 2;
-    double acc = (double)c[0] * t.k[H];
-#pragma unroll
-    for (int jj = -H; jj < 0; jj++) acc = acc + ((double)c[jj * STRIDE] + (double)c[-jj * STRIDE]) * t.k[H + jj];
-    return (float)acc;
-}
-
-template <int SS, int NT, int NTHR, int OW, int OH>
-__global__ __launch_bounds__(NTHR) void pyr_reduce_v2(PyrReduceArgs a)
-{
-    constexpr int r = NT / 2;
-    constexpr int SW = (OW - 1) * SS + 2 * r + 1, SH = (OH - 1) * SS + 2 * r + 1;
-    constexpr int PW = (SW + SS - 1) / SS, ROWLEN = PW * SS;
-    constexpr int SQ = (SW + 3) / 4, NQ = SH * SQ, QPT = (NQ + NTHR - 1) / NTHR;
-    extern __shared__ __attribute__((aligned(16))) float flds[];
-    float *const Hf = flds;                                      // [SH][OW]   horizontal results (f32, as between the passes)
-    float *const S = flds + SH * OW;                             // [SH][SS planes][PW]
-    const int tid = threadIdx.x, b = blockIdx.z;
-    const int xs0 = blockIdx.x * OW, ys0 = blockIdx.y * OH;
-    const int gx0 = xs0 * SS + SS / 2 - r, gy0 = ys0 * SS + SS / 2 - r;
-    const float *__restrict__ src = a.src[b];
-    const int nc = a.src_nc, nr = a.src_nr;
-    TapRegs<NT> k;
-    load_taps(k, a.taps);
-
-    // gx0 is a multiple of 4 columns for SS = 4 (and even for SS = 2): interior tiles load whole aligned quads
-    const bool interior = (nc & 3) == 0 && (gx0 & 3) == 0 && gx0 >= 0 && gy0 >= 0 && gx0 + 4 * SQ <= nc && gy0 + SH <= nr;
-    if (interior) {
-        float4 v[QPT];
-#pragma unroll
-        for (int u = 0; u < QPT; u++) {
-            const int i = min(tid + u * NTHR, NQ - 1);                    // clamped: the last threads repeat the last quad
-            const int rr = i / SQ, q = i - rr * SQ;
-            v[u] = *reinterpret_cast<const float4 *>(src + (size_t)(gy0 + rr) * nc + gx0 + 4 * q);
-        }
-#pragma unroll
-        for (int u = 0; u < QPT; u++) {
-            const int i = tid + u * NTHR;
-            if (i < NQ) {
-                const int rr = i / SQ, q = i - rr * SQ;
-                float *dst = S + rr * ROWLEN;
-                const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const int c = 4 * q + w;
-                    if (c < SW) dst[(c % SS) * PW + c / SS] = e[w];
-                }
-            }
-        }
-    } else {
-        for (int i = tid; i < SH * SW; i += NTHR) {
-            const int rr = i / SW, c = i - rr * SW;
-            S[rr * ROWLEN + (c % SS) * PW + c / SS] = src[(size_t)reflect_fast(gy0 + rr, nr) * nc + reflect_fast(gx0 + c, nc)];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < SH * OW; i += NTHR) {
-        const int rr = i / OW, xs = i % OW;
-        const float *row = S + rr * ROWLEN + xs;         // column xs*SS + r + j lives at plane (r+j)%SS, index xs + (r+j)/SS
-        double acc = (double)row[(r % SS) * PW + r / SS] * k.k[r];
-#pragma unroll
-        for (int jj = -r; jj < 0; jj++) {
-            const double lo = (double)row[((r + jj) % SS) * PW + (r + jj) / SS];
-            const double hi = (double)row[((r - jj) % SS) * PW + (r - jj) / SS];
-            acc = acc + (lo + hi) * k.k[r + jj];
-        }
-        Hf[i] = (float)acc;                              // the f32 rounding between the passes
-    }
-    __syncthreads();
-    if (tid < OW * OH) {
-        const int xs = tid % OW, ys = tid / OW;
-        const int ox = xs0 + xs, oy = ys0 + ys;
-        if (ox < a.dst_nc && oy < a.dst_nr)
-            a.dst[b][(size_t)oy * a.dst_nc + ox] = correlate_sym_f32src<NT, OW>(Hf + (ys * SS + r) * OW + xs, k);
-    }
-}
-
-template <int SS, int NT, int NTHR, int OW, int OH>
-static int launch_pyr_reduce_v2(hipStream_t s, const PyrReduceArgs &a, int batch)
-{
-    constexpr int r = NT / 2;
-    constexpr int SW = (OW - 1) * SS + 2 * r + 1, SH = (OH - 1) * SS + 2 * r + 1;
-    constexpr int PW = (SW + SS - 1) / SS;
-    constexpr size_t l = sizeof(float) * (size_t)(SH * OW + SH * PW * SS);
-    if (int e = set_lds(pyr_reduce_v2<SS, NT, NTHR, OW, OH>, l)) return e;
-    const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch);
-    hipLaunchKernelGGL((pyr_reduce_v2<SS, NT, NTHR, OW, OH>), grid, dim3(NTHR), l, s, a);
-    return 0;
 }
 
 template <int SS, int NT, typename TS, int OW, int OH>
@@ -1216,9 +953,6 @@ __global__ __launch_bounds__(NTHR) void pyr_level_kernel(LevelArgs a)
 
 }  // namespace
 
-int g_smooth_grad_variant = 0;     // 0 = register-blocked (default), 1 = one-sample-per-thread LDS kernels
-int g_pyr_reduce_variant = 0;      // 0 = 1024-thread kernel, f64 horizontal intermediate (default), 1 = 512-thread all-f32 kernel
-
 size_t smooth_grad_lds_bytes(int rs, int R)
 {
     const int IW = TW + 2 * R, IH = TH + 2 * R, RW = IW + 2 * rs, RH = IH + 2 * rs;
@@ -1251,7 +985,7 @@ bool smooth_grad_hred_ok(const SmoothGradArgs &a, int batch, int kind, const Tap
 {
     static const int force_th = getenv("KLT_RB_TH") ? atoi(getenv("KLT_RB_TH")) : 0;
     const bool tall = force_th ? force_th == 32 : (long long)a.ncols * a.nrows * batch >= 1000000;
-    return g_smooth_grad_variant == 0 && tall && kind < 2 && a.smooth.sym == 1 && (a.smooth.n == 5 || a.smooth.n == 9) &&
+    return tall && kind < 2 && a.smooth.sym == 1 && (a.smooth.n == 5 || a.smooth.n == 9) &&
            a.ggauss.sym == 1 && a.gderiv.sym == -1 && a.ggauss.n == 7 && a.gderiv.n == 7 && ss == 4 && reduce.sym == 1 && reduce.n == 21 &&
            a.nrows >= 64 && a.ncols >= 64;
 }
@@ -1277,41 +1011,31 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
     // compile-time specialisations: Gaussian smoothing (symmetric), Gaussian / derivative gradient taps
     if (a.ggauss.sym == 1 && a.gderiv.sym == -1 && a.ggauss.n == 7 && a.gderiv.n == 7 && (!smooth || a.smooth.sym == 1)) {
         const dim3 blk(256);
-        if (g_smooth_grad_variant == 0) {
-            // register-blocked kernels; small frames take the shorter tile so that the grid still covers the chip
-            static const int force_th = getenv("KLT_RB_TH") ? atoi(getenv("KLT_RB_TH")) : 0;   // experiment hook
-            const bool tall = force_th ? force_th == 32 : (long long)a.ncols * a.nrows * batch >= 1000000;
-            const int th = tall ? 32 : 16;
-            const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + th - 1) / th, batch);
+        // register-blocked kernels; small frames take the shorter tile so that the grid still covers the chip
+        static const int force_th = getenv("KLT_RB_TH") ? atoi(getenv("KLT_RB_TH")) : 0;   // experiment hook
+        const bool tall = force_th ? force_th == 32 : (long long)a.ncols * a.nrows * batch >= 1000000;
+        const int th = tall ? 32 : 16;
+        const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + th - 1) / th, batch);
 #define KLT_RB(T, SM, NSV)                                                                                        \
     do {                                                                                                          \
-        if (tall) hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 32>), g, blk, pad_lds, s, a);             \
+        if (tall) hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 32>), g, blk, 0, s, a);                   \
         else hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 16>), g, blk, 0, s, a);                        \
         return 0;                                                                                                 \
     } while (0)
-            static const size_t pad_lds = getenv("KLT_RB_PAD_LDS") ? (size_t)atoi(getenv("KLT_RB_PAD_LDS")) : 0;   // occupancy experiment
-            if (hred) {
-                if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 5, 7, 7, 32, 256, true>), g, blk, pad_lds, s, a); return 0; }
-                if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
-                if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
-                if (kind == 1 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
-                return -1;
-            }
-            if (kind == 0 && a.smooth.n == 5) KLT_RB(uint8_t, true, 5);
-            if (kind == 1 && a.smooth.n == 5) KLT_RB(float, true, 5);
-            if (kind == 0 && a.smooth.n == 9) KLT_RB(uint8_t, true, 9);
-            if (kind == 1 && a.smooth.n == 9) KLT_RB(float, true, 9);
-            if (kind == 2) KLT_RB(float, false, 1);
-            if (kind == 3) KLT_RB(uint8_t, false, 1);
-#undef KLT_RB
+        if (hred) {
+            if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+            if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+            if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+            if (kind == 1 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+            return -1;
         }
-        const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + FTH - 1) / FTH, batch);
-        if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 5, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
-        if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_fast<float, true, 5, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
-        if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, true, 9, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
-        if (kind == 1 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_fast<float, true, 9, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
-        if (kind == 2) { hipLaunchKernelGGL((smooth_grad_fast<float, false, 1, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
-        if (kind == 3) { hipLaunchKernelGGL((smooth_grad_fast<uint8_t, false, 1, 7, 7, FTH>), g, blk, 0, s, a); return 0; }
+        if (kind == 0 && a.smooth.n == 5) KLT_RB(uint8_t, true, 5);
+        if (kind == 1 && a.smooth.n == 5) KLT_RB(float, true, 5);
+        if (kind == 0 && a.smooth.n == 9) KLT_RB(uint8_t, true, 9);
+        if (kind == 1 && a.smooth.n == 9) KLT_RB(float, true, 9);
+        if (kind == 2) KLT_RB(float, false, 1);
+        if (kind == 3) KLT_RB(uint8_t, false, 1);
+#undef KLT_RB
     }
     const size_t lds = smooth_grad_lds_bytes(smooth ? a.smooth.n / 2 : -1, a.R);
     const dim3 grid((a.ncols + TW - 1) / TW, (a.nrows + TH - 1) / TH, batch), block(256);
@@ -1329,18 +1053,6 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
     return 0;
 }
 
-// smoothing only (u8 or f32 frame -> level-0 image); returns 1 if there is no compile-time kernel for these taps
-int launch_smooth_only(hipStream_t s, const SmoothGradArgs &a, int batch, bool u8_input)
-{
-    if (a.smooth.sym != 1 || (a.smooth.n != 5 && a.smooth.n != 9)) return 1;
-    const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + 31) / 32, batch), blk(256);
-    if (u8_input && a.smooth.n == 5) hipLaunchKernelGGL((smooth_only_rb<uint8_t, 5, 32>), g, blk, 0, s, a);
-    else if (u8_input) hipLaunchKernelGGL((smooth_only_rb<uint8_t, 9, 32>), g, blk, 0, s, a);
-    else if (a.smooth.n == 5) hipLaunchKernelGGL((smooth_only_rb<float, 5, 32>), g, blk, 0, s, a);
-    else hipLaunchKernelGGL((smooth_only_rb<float, 9, 32>), g, blk, 0, s, a);
-    return 0;
-}
-
 int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch)
 {
     const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch), block(256);
@@ -1348,16 +1060,7 @@ int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch)
         // measured at cfg-2 (us per launch, two frames, both levels averaged): f32 tile / 1024 threads 11.6,
         // f64 tile / 1024 threads 12.4, f32 / 512 14.1, f64 / 512 15.4 (profiles/README.md)
         // tile shapes 64x8, 32x16, 32x4 and 16x16 were measured too: 32x8 is the fastest (profiles/README.md)
-        if (g_pyr_reduce_variant == 1) {      // measured slower at cfg-2: 13.8 vs 11.7 us per launch (profiles/README.md)
-            if (a.ss == 4 && a.taps.n == 21) return launch_pyr_reduce_v2<4, 21, 512, 32, 8>(s, a, batch);
-            if (a.ss == 2 && a.taps.n == 11) return launch_pyr_reduce_v2<2, 11, 512, 32, 8>(s, a, batch);
-        }
-        if (a.ss == 4 && a.taps.n == 21) {
-            static const int oh = getenv("KLT_PYR_OH") ? atoi(getenv("KLT_PYR_OH")) : 8;      // experiment hook
-            if (oh == 16) return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 16>(s, a, batch);
-            if (oh == 12) return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 12>(s, a, batch);
-            return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 8>(s, a, batch);
-        }
+        if (a.ss == 4 && a.taps.n == 21) return launch_pyr_reduce_fast<4, 21, 1024, float, 32, 8>(s, a, batch);
         if (a.ss == 2 && a.taps.n == 11) return launch_pyr_reduce_fast<2, 11, 512, float, 32, 8>(s, a, batch);
     }
     const size_t lds = pyr_reduce_lds_bytes(a.ss, a.taps.n);

@@ -110,51 +110,16 @@ __device__ float pairwise_sum<0>(const float *a, int n, int lane)
     return pairwise_block_wave(a, n < 128 ? n : 128, lane);
 }
 
-// One footprint = the (w+1) x (w+1) pixels under a window; lane (r, c) of a (w+1)-wide grid loads pixel (r, c) of each of the
-// three images ONCE (for 7x7 windows the grid is exactly the 64 lanes) and gets its right / lower / diagonal neighbours
-// from the lanes that loaded them (ds_bpermute), instead of every lane loading its own four pixels of every image: 3 vector
-// loads per footprint instead of 12.  Vector-memory issue (64 scattered addresses per instruction through the address
-// unit) is what the tracker spends its time on after the round trips.
-struct Px3 { float i, gx, gy; };
-
-__device__ __forceinline__ void load_px3(const float *__restrict__ pi, const float *__restrict__ pgx, const float *__restrict__ pgy,
-                                         unsigned q, Px3 &o)
-{
-    o.i = pi[q]; o.gx = pgx[q]; o.gy = pgy[q];
-}
-
-// sample() on the 2x2 neighbourhood {v, right, below, diagonal} (same expression, same order)
-__device__ __forceinline__ float sample_nb(float v, int G, const Bilinear &b)
-{
-    const float v01 = __shfl_down(v, 1), v10 = __shfl_down(v, G), v11 = __shfl_down(v, G + 1);
-    const float t4 = b.w11 * v11;
-    double d = b.w00 * (double)v;
-    d = d + b.w01 * (double)v01;
-    d = d + b.w10 * (double)v10;
-    d = d + (double)t4;
-    return (float)d;
-}
-
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // _trackFeature for one level.  Returns the status; x2/y2 updated in place; `iters` = Newton iterations.
 // WCT > 0: window size known at compile time (index math folds, the summation loops unroll and read LDS
 // 16 bytes at a time); WCT == 0: any odd window up to 31.
-// GRID (windows of at most 7x7, MAXK = 1): lane (r, c) of a (w+1)-wide grid loads ONE pixel of each image per footprint and takes its
-// three neighbours from the lanes that loaded them, instead of every lane loading its own four pixels: half the L1 line accesses
-// (a footprint row is touched once, not once for y and once for y + 1) and a quarter of the vector-load lanes.
-template <int MAXK, int WCT, bool GRID = false>
+template <int MAXK, int WCT>
 __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, float y1, float &x2r, float &y2r,
                            float *lds, int lane, int &iters, int clk0 = 0)
 {
-    static_assert(!GRID || MAXK == 1, "grid sampling handles one sample per lane");
     const int w = WCT > 0 ? WCT : a.window, n = w * w, hw = w / 2;
-    const int G = w + 1;
-    const bool in_grid = lane < G * G;
-    const int gr = in_grid ? lane / G : 0, gc = in_grid ? lane % G : 0;
-    const bool mine = in_grid && gr < w && gc < w;
-    const int ks = gr * w + gc;                          // row-major index of this lane's window sample (GRID)
-    const int goff = gr * lv.nc + gc;                    // its pixel relative to the footprint's top-left corner
     const int npad = (n + 3) & ~3;                       // 16-byte aligned sub-arrays
     const int nc = lv.nc, nr = lv.nr;
     float *l_diff = lds;                                 // residue scratch (aliases product array 0)
@@ -166,13 +131,6 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
         return KLT_OOB;      // the reference asserts here (trackFeaturesUtils.pyx:35); see DESIGN.md
     float t_i[MAXK], t_gx[MAXK], t_gy[MAXK];
     int off[MAXK];           // sample offset relative to the window's top-left footprint pixel
-    if (GRID) {
-        const size_t q = (size_t)(b1.iy - hw) * nc + (b1.ix - hw) + goff;
-        t_i[0] = sample_nb(lv.i1[q], G, b1);
-        t_gx[0] = sample_nb(lv.gx1[q], G, b1);
-        t_gy[0] = sample_nb(lv.gy1[q], G, b1);
-        off[0] = 0;
-    } else
 #pragma unroll
     for (int kk = 0; kk < MAXK; kk++) {
         const int k = lane + 64 * kk;
@@ -202,19 +160,6 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
         const size_t base = (size_t)(b2.iy - hw) * nc + (b2.ix - hw);
         // every lane forms the five products of its samples (each product is one rounded f32 multiply, exactly the
         // term the reference adds); LDS then holds five arrays of n terms
-        if (GRID) {
-            const size_t q = base + goff;
-            const float diff = t_i[0] - sample_nb(lv.i2[q], G, b2);
-            const float sx = t_gx[0] + sample_nb(lv.gx2[q], G, b2);
-            const float sy = t_gy[0] + sample_nb(lv.gy2[q], G, b2);
-            if (mine) {
-                lds[ks] = sx * sx;
-                lds[npad + ks] = sx * sy;
-                lds[2 * npad + ks] = sy * sy;
-                lds[3 * npad + ks] = diff * sx;
-                lds[4 * npad + ks] = diff * sy;
-            }
-        } else
 #pragma unroll
         for (int kk = 0; kk < MAXK; kk++) {
             const int k = lane + 64 * kk;
@@ -280,10 +225,6 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
     if (status == KLT_TRACKED && a.use_max_residue) {
         const Bilinear b2 = make_bilinear(x2, y2);
         const size_t base = (size_t)(b2.iy - hw) * nc + (b2.ix - hw);
-        if (GRID) {
-            const float ad = fabsf(t_i[0] - sample_nb(lv.i2[base + goff], G, b2));
-            if (mine) l_diff[ks] = ad;
-        } else
 #pragma unroll
         for (int kk = 0; kk < MAXK; kk++) {
             const int k = lane + 64 * kk;
@@ -303,17 +244,18 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
     return KLT_TRACKED;
 }
 
-template <int MAXK, int WCT, bool BATCH, bool GRID = false>
+template <int MAXK, int WCT, bool BATCH>
 __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int f = blockIdx.x;
-    if (!BATCH && a.order) {
-        // XCD-aware order: workgroup b runs on XCD b % 8; XCD c takes the c-th eighth of the features sorted by row, so that
-        // the eight L2s each see one band of the pyramids instead of all of every plane
+    if (a.order) {
+        // XCD-aware order: workgroup (x, y) runs on XCD x % 8 (gridDim.x is a multiple of 8); XCD c takes the c-th eighth of the
+        // features sorted by row, so that the eight L2s each see one band of the pyramids instead of all of every plane
+        const uint32_t *ord = a.order + (BATCH ? (size_t)blockIdx.y * a.n : (size_t)0);
         const int c = blockIdx.x & 7, j = blockIdx.x >> 3, pos = c * a.order_chunk + j;
         if (j >= a.order_chunk || pos >= a.n) return;
-        f = (int)a.order[pos];
+        f = (int)ord[pos];
     }
     const int lane = threadIdx.x;
     if (f >= a.n) return;
@@ -336,7 +278,7 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     for (int r = L - 1; r >= 0; r--) {
         xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss;
         int it = 0;
-        val = track_level<MAXK, WCT, GRID>(a, levels[r], xloc, yloc, xout, yout, lds, lane, it, 1 + 9 * (L - 1 - r));
+        val = track_level<MAXK, WCT>(a, levels[r], xloc, yloc, xout, yout, lds, lane, it, 1 + 9 * (L - 1 - r));
         aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);      // visited level r with `it` Newton iterations
         if (val == KLT_SMALL_DET || val == KLT_OOB) break;             // :284-285
     }
@@ -355,242 +297,7 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Prefetching variant for windows of at most 64 samples (one sample per lane), the default for them.
-//
-// A feature is a chain of dependent global-memory round trips: per level the template footprint, then one footprint per
-// Newton iteration (each position depends on the previous solve), then the footprint of the final position for the
-// residue.  At cfg-2 that is ~10 round trips of 1-2 us each, and the whole launch lasts as long as the slowest chains.
-// The arithmetic below is track_level's, statement for statement; only the *loads* move:
-//   * the image-1 footprint of level r-1 is requested when level r starts (the template position is known up front);
-//   * after every position update the image-2 footprint of the new position is requested at once -- it is what the next
-//     iteration samples, or, if the loop ends here, what the residue test samples (same position, same weights);
-//   * when the loop ends, the image-2 footprint of the first iteration of level r-1 (position * subsampling) is requested
-//     together with it.
-// Round trips per feature: (Newton iterations + 1) instead of (iterations + 2 * levels).  Loads are unconditional with
-// clamped addresses (a guarded load is a branch, and the wait-count model drains every outstanding load at the join); the
-// single wavefront of the workgroup orders its LDS traffic with s_waitcnt lgkmcnt(0) instead of __syncthreads(), which
-// would also wait for the prefetches.
-// Every decision below is wave-uniform (positions come out of wave shuffles); saying so keeps the branches scalar and the
-// level index and the positions in SGPRs -- otherwise the level descriptors are fetched with vector loads (and waiting for
-// those drains the prefetches) and every position costs vector registers (the kernel must stay under 96 VGPRs: 5 wavefronts
-// per SIMD keep all 5000 features of a cfg-2 pair resident at once).
-__device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
-__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-
-#ifndef KLT_TRACK_WAVES
-#define KLT_TRACK_WAVES 4
-#endif
-template <int WCT, bool BATCH>
-__global__ __launch_bounds__(64, KLT_TRACK_WAVES) void track_kernel_pf(TrackArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int f = blockIdx.x;
-    const int lane = threadIdx.x;
-    if (f >= a.n) return;
-    const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
-    const klt_feat *fin = BATCH ? a.pairs[blockIdx.y].in : a.in;
-    klt_feat *fout = BATCH ? a.pairs[blockIdx.y].out : a.out;
-    const klt_feat ft = fin[f];
-    if (ft.val < 0) {                       // only live features are tracked, trackFeatures.py:253
-        if (lane == 0) fout[f] = ft;
-        return;
-    }
-    const int L = a.nlevels;
-    const int w = WCT > 0 ? WCT : a.window, n = w * w, hw = w / 2;
-    const int npad = (n + 3) & ~3;
-    const int G = w + 1;                                               // footprint grid (w+1) x (w+1), lane = r * G + c
-    const bool in_grid = lane < G * G;
-    const int kr = in_grid ? lane / G : 0, kc = in_grid ? lane % G : 0; // lanes beyond the grid shadow pixel (0, 0)
-    const bool mine = in_grid && kr < w && kc < w;                     // grid lanes with r, c < w own window sample (r, c)
-    const int ks = kr * w + kc;                                        // its row-major index (order of the reference's sums)
-    const float one_plus_eps = 1.001f;
-
-    auto tmpl_inside = [&](const TrackLevel &lv, float x, float y) {
-        const int ix = (int)x, iy = (int)y;
-        return uni(ix - hw >= 0 && iy - hw >= 0 && ix + hw + 2 <= lv.nc && iy + hw + 2 <= lv.nr);
-    };
-    auto inloop_oob = [&](const TrackLevel &lv, float x2, float y2) {        // trackFeaturesUtils.pyx:428-431
-        return uni((double)(x2 - (float)hw) < 0. || (float)lv.nc - (x2 + (float)hw) < one_plus_eps ||
-                   (double)(y2 - (float)hw) < 0. || (float)lv.nr - (y2 + (float)hw) < one_plus_eps);
-    };
-    // element offset of my sample's footprint for a window centred at (x, y); 0 (a valid address) when it must not be read
-    auto footprint = [&](const TrackLevel &lv, float x, float y, bool ok) -> unsigned {
-        return ok ? (unsigned)(((int)y - hw + kr) * lv.nc + ((int)x - hw + kc)) : 0u;
-    };
-
-    // trackFeatures.py:255-265
-    float xloc = ft.x, yloc = ft.y;
-    for (int r = 0; r < L; r++) { xloc = xloc * a.inv_ss; yloc = yloc * a.inv_ss; }
-    float xout = xloc, yout = yloc;
-    int val = KLT_TRACKED;
-    uint32_t aux = 0;
-
-    int r = L - 1;
-    xloc = unif(xloc * a.ss); yloc = unif(yloc * a.ss); xout = unif(xout * a.ss); yout = unif(yout * a.ss);
-    bool t_ok = tmpl_inside(levels[r], xloc, yloc);
-    bool have2 = !inloop_oob(levels[r], xout, yout);
-    Px3 rt, r2;
-    load_px3(levels[r].i1, levels[r].gx1, levels[r].gy1, footprint(levels[r], xloc, yloc, t_ok), rt);
-    load_px3(levels[r].i2, levels[r].gx2, levels[r].gy2, footprint(levels[r], xout, yout, have2), r2);
-
-    for (;;) {
-        r = __builtin_amdgcn_readfirstlane(r);
-        const TrackLevel &lv = levels[r];
-        const TrackLevel &ln = levels[r > 0 ? r - 1 : 0];
-        const int nc = lv.nc, nr = lv.nr;
-        const float xloc_n = unif(xloc * a.ss), yloc_n = unif(yloc * a.ss);     // template position at the next finer level
-        int it = 0, status = KLT_OOB;
-        float x2 = xout, y2 = yout;
-        bool pref = false, have2n = false, tn_ok = false;
-        Px3 rtn = rt, r2n = r2;
-        if (!t_ok) {
-            val = KLT_OOB;       // the reference asserts here (trackFeaturesUtils.pyx:35); see DESIGN.md
-        } else {
-            float t_i, t_gx, t_gy;
-            {
-                const Bilinear b1 = make_bilinear(xloc, yloc);
-                t_i = sample_nb(rt.i, G, b1); t_gx = sample_nb(rt.gx, G, b1); t_gy = sample_nb(rt.gy, G, b1);
-            }
-            for (;;) {
-                if (!have2) { status = KLT_OOB; break; }
-                {
-                    const Bilinear b2 = make_bilinear(x2, y2);
-                    const float diff = t_i - sample_nb(r2.i, G, b2);
-                    const float sx = t_gx + sample_nb(r2.gx, G, b2);
-                    const float sy = t_gy + sample_nb(r2.gy, G, b2);
-                    if (mine) {
-                        lds[ks] = sx * sx;
-                        lds[npad + ks] = sx * sy;
-                        lds[2 * npad + ks] = sy * sy;
-                        lds[3 * npad + ks] = diff * sx;
-                        lds[4 * npad + ks] = diff * sy;
-                    }
-                }
-                wave_lds_sync();
-                float acc = 0.f;
-                if (lane < 5) {
-                    const float *T = lds + lane * npad;
-                    if (WCT > 0) {
-                        // (quads are read in groups of four: the whole array in flight at once costs 52 VGPRs, and the
-                        // kernel has to fit 96)
-                        const float4 *T4 = reinterpret_cast<const float4 *>(T);
-                        constexpr int NQ = (WCT * WCT + 3) / 4;
-#pragma unroll
-                        for (int q0 = 0; q0 < NQ; q0 += 4) {
-                            float4 v[4];
-#pragma unroll
-                            for (int u = 0; u < 4; u++) v[u] = T4[q0 + u < NQ ? q0 + u : NQ - 1];
-                            asm volatile("" ::: "memory");
-#pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const int q = q0 + u;
-                                if (q < NQ) {
-                                    acc = acc + v[u].x;
-                                    if (4 * q + 1 < WCT * WCT) acc = acc + v[u].y;
-                                    if (4 * q + 2 < WCT * WCT) acc = acc + v[u].z;
-                                    if (4 * q + 3 < WCT * WCT) acc = acc + v[u].w;
-                                }
-                            }
-                        }
-                    } else {
-                        for (int k = 0; k < n; k++) acc = acc + T[k];
-                    }
-                }
-                wave_lds_sync();
-                const float gxx = __shfl(acc, 0), gxy = __shfl(acc, 1), gyy = __shfl(acc, 2);
-                const float ex = __shfl(acc, 3) * a.step, ey = __shfl(acc, 4) * a.step;
-                const float p1 = gxx * gyy, p2 = gxy * gxy;
-                const float det = p1 - p2;
-                if (uni(det < a.small)) { status = KLT_SMALL_DET; break; }
-                const float n1 = gyy * ex, n2 = gxy * ey, n3 = gxx * ey, n4 = gxy * ex;
-                const float dx = (n1 - n2) / det;
-                const float dy = (n3 - n4) / det;
-                status = KLT_TRACKED;
-                x2 = unif(x2 + dx);
-                y2 = unif(y2 + dy);
-                it++;
-                const bool more = uni((fabsf(dx) >= a.th || fabsf(dy) >= a.th) && it < a.max_iterations);
-                // the footprint of the new position: the next iteration's, or the residue test's
-                have2 = !inloop_oob(lv, x2, y2);
-                load_px3(lv.i2, lv.gx2, lv.gy2, footprint(lv, x2, y2, have2), r2);
-                if (!more) {
-                    // ... and, the loop ending here, the template and the first footprint of the next finer level
-                    const float x2n = unif(x2 * a.ss), y2n = unif(y2 * a.ss);
-                    tn_ok = r > 0 && tmpl_inside(ln, xloc_n, yloc_n);
-                    have2n = r > 0 && !inloop_oob(ln, x2n, y2n);
-                    load_px3(ln.i1, ln.gx1, ln.gy1, footprint(ln, xloc_n, yloc_n, tn_ok), rtn);
-                    load_px3(ln.i2, ln.gx2, ln.gy2, footprint(ln, x2n, y2n, have2n), r2n);
-                    pref = true;
-                    break;
-                }
-            }
-            // trackFeatures.py:110 -- Python floats: half-window 3.5, eps 1.001 as doubles
-            const double x2d = (double)x2, y2d = (double)y2, hwd = a.half_window;
-            if (uni(x2d - hwd < 0.0 || (double)nc - (x2d + hwd) < 1.001 || y2d - hwd < 0.0 || (double)nr - (y2d + hwd) < 1.001))
-                status = KLT_OOB;
-            // residue, trackFeatures.py:118-125 (status TRACKED here implies the final position passed the in-loop
-            // bounds test, so r2 holds its footprint)
-            if (status == KLT_TRACKED && a.use_max_residue) {
-                {
-                    const Bilinear b2 = make_bilinear(x2, y2);
-                    const float ad = fabsf(t_i - sample_nb(r2.i, G, b2));
-                    if (mine) lds[ks] = ad;
-                }
-                wave_lds_sync();
-                float sres = pairwise_sum<3>(lds, n, lane);
-                wave_lds_sync();
-                sres = __shfl(sres, 0);
-                if (uni(sres / (float)n > a.max_residue)) status = KLT_LARGE_RESIDUE;
-            }
-            if (a.retain) val = KLT_TRACKED;                                   // :127-129
-            else if (status == KLT_SMALL_DET || status == KLT_OOB || status == KLT_LARGE_RESIDUE) val = status;
-            else if (it >= a.max_iterations) val = KLT_MAX_ITERATIONS;
-            else val = KLT_TRACKED;
-            xout = x2;
-            yout = y2;
-        }
-        aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);
-        val = __builtin_amdgcn_readfirstlane(val);
-        if (val == KLT_SMALL_DET || val == KLT_OOB) break;             // :284-285
-        if (r == 0) break;
-        // next finer level
-        r--;
-        xloc = xloc_n; yloc = yloc_n;
-        xout = unif(xout * a.ss); yout = unif(yout * a.ss);
-        if (pref) { t_ok = tn_ok; have2 = have2n; rt = rtn; r2 = r2n; }
-        else {      // (retainTrackers after a failed level: nothing was requested ahead)
-            t_ok = tmpl_inside(levels[r], xloc, yloc);
-            have2 = !inloop_oob(levels[r], xout, yout);
-            load_px3(levels[r].i1, levels[r].gx1, levels[r].gy1, footprint(levels[r], xloc, yloc, t_ok), rt);
-            load_px3(levels[r].i2, levels[r].gx2, levels[r].gy2, footprint(levels[r], xout, yout, have2), r2);
-        }
-    }
-    if (lane == 0) {
-        klt_feat o;
-        o.aux = (int32_t)aux;
-        const double xd = (double)xout, yd = (double)yout;
-        const bool oob = val == KLT_OOB ||
-                         xd < a.borderx || xd > (double)(a.ncols - 1) - a.borderx ||
-                         yd < a.bordery || yd > (double)(a.nrows - 1) - a.bordery;   // :288-308
-        if (oob) { o.x = -1.f; o.y = -1.f; o.val = KLT_OOB; }
-        else if (val == KLT_SMALL_DET || val == KLT_LARGE_RESIDUE || val == KLT_MAX_ITERATIONS) {
-            o.x = -1.f; o.y = -1.f; o.val = val;
-        } else { o.x = xout; o.y = yout; o.val = KLT_TRACKED; }
-        fout[f] = o;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Four features per wavefront (windows of at most 64 samples): KLT_OPT_TRACK_VARIANT = 2.
-//
-// With several frame pairs in flight the tracker is bound by instruction issue, not by latency (tools/stage_throughput.py: it
-// reaches exactly its VALU issue time), and most of a Newton iteration is work that one feature cannot spread over a wavefront:
-// the five sequential 49-term sums occupy 5 lanes, the bounds tests, bilinear weights and the 2x2 solve are the same in every
-// lane.  Here a feature owns 16 lanes (sample k of its window -> lane k % 16, round k / 16), so those instructions serve four
-// features at once; only the sampling rounds cost the same per feature as before.  The four features of a wavefront iterate in
-// lock step under per-feature predicates (a finished feature keeps its state and idles), so a wavefront runs as many Newton
-// iterations as its slowest feature.  Every feature's arithmetic is track_level's, operation for operation.
+// numpy pairwise f32 sum of one 16-lane group (four features per wavefront): pairwise_block_wave with the group lane s
 __device__ __forceinline__ float pairwise_block_group(const float *a, int n, int s)      // result in the group's lane s == 0
 {
     if (n < 8) {
@@ -609,174 +316,6 @@ __device__ __forceinline__ float pairwise_block_group(const float *a, int n, int
     float res = r + __shfl_down(r, 4);
     for (int i = nn; i < n; i++) res = res + a[i];
     return res;
-}
-
-template <int WCT, bool BATCH>
-__global__ __launch_bounds__(64) void track_kernel_q(TrackArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int MAXK = 4;                                  // 16 lanes x 4 rounds >= 64 samples
-    const int lane = threadIdx.x, g = lane >> 4, s = lane & 15, glead = lane & 48;
-    const int f = 4 * blockIdx.x + g;
-    const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
-    const klt_feat *fin = BATCH ? a.pairs[blockIdx.y].in : a.in;
-    klt_feat *fout = BATCH ? a.pairs[blockIdx.y].out : a.out;
-    const bool valid = f < a.n;
-    const klt_feat ft = fin[valid ? f : a.n - 1];
-    const bool tracked_feature = valid && ft.val >= 0;       // only live features are tracked, trackFeatures.py:253
-    if (valid && ft.val < 0 && s == 0) fout[f] = ft;
-    if (!__any(tracked_feature)) return;
-    const int L = a.nlevels;
-    const int w = WCT > 0 ? WCT : a.window, n = w * w, hw = w / 2;
-    const int npad = (n + 3) & ~3;
-    float *const gl = lds + g * 5 * npad;                    // this feature's five product arrays
-    const float one_plus_eps = 1.001f;
-
-    // trackFeatures.py:255-265
-    float xloc = ft.x, yloc = ft.y;
-    for (int r = 0; r < L; r++) { xloc = xloc * a.inv_ss; yloc = yloc * a.inv_ss; }
-    float xout = xloc, yout = yloc;
-    int val = KLT_TRACKED;
-    uint32_t aux = 0;
-    bool alive = tracked_feature;                            // still descending the pyramid
-
-    for (int r = L - 1; r >= 0; r--) {
-        if (!__any(alive)) break;
-        const TrackLevel &lv = levels[r];
-        const int nc = lv.nc, nr = lv.nr;
-        if (alive) { xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss; }
-
-        // image-1 template (trackFeatures.py:102-104); a window that leaves image 1 ends the feature
-        const Bilinear b1 = make_bilinear(xloc, yloc);
-        const bool t_ok = b1.ix - hw >= 0 && b1.iy - hw >= 0 && b1.ix + hw + 2 <= nc && b1.iy + hw + 2 <= nr;
-        const bool run = alive && t_ok;
-        float t_i[MAXK], t_gx[MAXK], t_gy[MAXK];
-        int off[MAXK];
-#pragma unroll
-        for (int m = 0; m < MAXK; m++) {
-            const int k = s + 16 * m;
-            t_i[m] = t_gx[m] = t_gy[m] = 0.f;
-            off[m] = 0;
-            if (k < n) {
-                off[m] = (k / w) * nc + (k % w);
-                const size_t q = run ? (size_t)(b1.iy - hw) * nc + (b1.ix - hw) + off[m] : (size_t)0;
-                t_i[m] = sample(lv.i1 + q, nc, b1);
-                t_gx[m] = sample(lv.gx1 + q, nc, b1);
-                t_gy[m] = sample(lv.gy1 + q, nc, b1);
-            }
-        }
-
-        int it = 0, status = KLT_OOB;
-        float x2 = xout, y2 = yout;
-        bool iterating = run;
-        while (__any(iterating)) {
-            // trackFeaturesUtils.pyx:428-431
-            const bool oob = (double)(x2 - (float)hw) < 0. || (float)nc - (x2 + (float)hw) < one_plus_eps ||
-                             (double)(y2 - (float)hw) < 0. || (float)nr - (y2 + (float)hw) < one_plus_eps;
-            if (iterating && oob) { status = KLT_OOB; iterating = false; }
-            const bool act = iterating;
-            const Bilinear b2 = make_bilinear(x2, y2);
-            const size_t base = act ? (size_t)(b2.iy - hw) * nc + (b2.ix - hw) : (size_t)0;
-#pragma unroll
-            for (int m = 0; m < MAXK; m++) {
-                const int k = s + 16 * m;
-                if (k < n) {
-                    const size_t q = act ? base + off[m] : (size_t)0;
-                    const float diff = t_i[m] - sample(lv.i2 + q, nc, b2);
-                    const float sx = t_gx[m] + sample(lv.gx2 + q, nc, b2);
-                    const float sy = t_gy[m] + sample(lv.gy2 + q, nc, b2);
-                    gl[k] = sx * sx;
-                    gl[npad + k] = sx * sy;
-                    gl[2 * npad + k] = sy * sy;
-                    gl[3 * npad + k] = diff * sx;
-                    gl[4 * npad + k] = diff * sy;
-                }
-            }
-            wave_lds_sync();
-            float acc = 0.f;
-            if (s < 5) {
-                const float *T = gl + s * npad;
-                if (WCT > 0) {
-                    const float4 *T4 = reinterpret_cast<const float4 *>(T);
-#pragma unroll
-                    for (int q = 0; q < (WCT * WCT + 3) / 4; q++) {
-                        const float4 v = T4[q];
-                        acc = acc + v.x;
-                        if (4 * q + 1 < WCT * WCT) acc = acc + v.y;
-                        if (4 * q + 2 < WCT * WCT) acc = acc + v.z;
-                        if (4 * q + 3 < WCT * WCT) acc = acc + v.w;
-                    }
-                } else {
-                    for (int k = 0; k < n; k++) acc = acc + T[k];
-                }
-            }
-            wave_lds_sync();
-            const float gxx = __shfl(acc, glead), gxy = __shfl(acc, glead + 1), gyy = __shfl(acc, glead + 2);
-            const float ex = __shfl(acc, glead + 3) * a.step, ey = __shfl(acc, glead + 4) * a.step;
-            const float p1 = gxx * gyy, p2 = gxy * gxy;
-            const float det = p1 - p2;
-            const bool small_det = det < a.small;
-            if (act && small_det) { status = KLT_SMALL_DET; iterating = false; }
-            const float n1 = gyy * ex, n2 = gxy * ey, n3 = gxx * ey, n4 = gxy * ex;
-            const float dx = (n1 - n2) / det;
-            const float dy = (n3 - n4) / det;
-            if (act && !small_det) {
-                status = KLT_TRACKED;
-                x2 = x2 + dx;
-                y2 = y2 + dy;
-                it++;
-                iterating = (fabsf(dx) >= a.th || fabsf(dy) >= a.th) && it < a.max_iterations;
-            }
-        }
-        if (run) { xout = x2; yout = y2; }
-
-        // trackFeatures.py:110 -- Python floats: half-window 3.5, eps 1.001 as doubles
-        const double x2d = (double)x2, y2d = (double)y2, hwd = a.half_window;
-        if (run && (x2d - hwd < 0.0 || (double)nc - (x2d + hwd) < 1.001 || y2d - hwd < 0.0 || (double)nr - (y2d + hwd) < 1.001))
-            status = KLT_OOB;
-
-        // residue, trackFeatures.py:118-125
-        const bool need_res = run && status == KLT_TRACKED && a.use_max_residue;
-        if (__any(need_res)) {
-            const Bilinear b2 = make_bilinear(x2, y2);
-            const size_t base = need_res ? (size_t)(b2.iy - hw) * nc + (b2.ix - hw) : (size_t)0;
-#pragma unroll
-            for (int m = 0; m < MAXK; m++) {
-                const int k = s + 16 * m;
-                if (k < n) gl[k] = fabsf(t_i[m] - sample(lv.i2 + (need_res ? base + off[m] : (size_t)0), nc, b2));
-            }
-            wave_lds_sync();
-            float sres = pairwise_block_group(gl, n, s);
-            wave_lds_sync();
-            sres = __shfl(sres, glead);
-            if (need_res && sres / (float)n > a.max_residue) status = KLT_LARGE_RESIDUE;
-        }
-
-        int lvl_val;
-        if (!t_ok) lvl_val = KLT_OOB;
-        else if (a.retain) lvl_val = KLT_TRACKED;                                               // :127-129
-        else if (status == KLT_SMALL_DET || status == KLT_OOB || status == KLT_LARGE_RESIDUE) lvl_val = status;
-        else if (it >= a.max_iterations) lvl_val = KLT_MAX_ITERATIONS;
-        else lvl_val = KLT_TRACKED;
-        if (alive) {
-            val = lvl_val;
-            aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);
-            alive = !(val == KLT_SMALL_DET || val == KLT_OOB);                                  // :284-285
-        }
-    }
-    if (tracked_feature && s == 0) {
-        klt_feat o;
-        o.aux = (int32_t)aux;
-        const double xd = (double)xout, yd = (double)yout;
-        const bool oob = val == KLT_OOB ||
-                         xd < a.borderx || xd > (double)(a.ncols - 1) - a.borderx ||
-                         yd < a.bordery || yd > (double)(a.nrows - 1) - a.bordery;   // :288-308
-        if (oob) { o.x = -1.f; o.y = -1.f; o.val = KLT_OOB; }
-        else if (val == KLT_SMALL_DET || val == KLT_LARGE_RESIDUE || val == KLT_MAX_ITERATIONS) {
-            o.x = -1.f; o.y = -1.f; o.val = val;
-        } else { o.x = xout; o.y = yout; o.val = KLT_TRACKED; }
-        fout[f] = o;
-    }
 }
 
 // Four 7x7 features per wavefront with QUAD loads (KLT_OPT_TRACK_VARIANT = 4).  The 8x8 footprint of a feature is 16 quads of four
@@ -818,11 +357,13 @@ __global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x, g = lane >> 4, s = lane & 15, glead = lane & 48;
     int f = 4 * blockIdx.x + g;
-    if (!BATCH && a.order) {
-        // XCD-aware order (KLT_OPT_TRACK_XCD_ORDER): workgroup b runs on XCD b % 8 and takes four consecutive features of that
-        // XCD's band of the row-sorted list
+    if (a.order) {
+        // XCD-aware order (KLT_OPT_TRACK_XCD_ORDER): workgroups go to the XCDs round-robin in linear order and gridDim.x is a
+        // multiple of 8, so workgroup (x, y) runs on XCD x % 8; it takes four consecutive features of that XCD's band of the
+        // row-sorted list of its pair (batched launches: pair blockIdx.y, permutation blockIdx.y of the table)
+        const uint32_t *ord = a.order + (BATCH ? (size_t)blockIdx.y * a.n : (size_t)0);
         const int c = blockIdx.x & 7, pos = c * a.order_chunk + 4 * (blockIdx.x >> 3) + g;
-        f = (4 * (blockIdx.x >> 3) + g < a.order_chunk && pos < a.n) ? (int)a.order[pos] : a.n;
+        f = (4 * (blockIdx.x >> 3) + g < a.order_chunk && pos < a.n) ? (int)ord[pos] : a.n;
     }
     const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
     const klt_feat *fin = BATCH ? a.pairs[blockIdx.y].in : a.in;
@@ -986,8 +527,11 @@ __global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
 // features go last.  The order within a row is whatever the atomics give -- every feature is still tracked exactly once and
 // written to its own slot, so the result does not depend on it.
 constexpr int ORDER_BINS = 4096, ORDER_T = 1024;
-__global__ __launch_bounds__(ORDER_T) void track_order_kernel(const klt_feat *__restrict__ in, int n, uint32_t *__restrict__ order)
+__global__ __launch_bounds__(ORDER_T) void track_order_kernel(const klt_feat *__restrict__ in_single, const TrackPairDesc *__restrict__ pairs,
+                                                              int n, uint32_t *__restrict__ order_base)
 {
+    const klt_feat *__restrict__ in = pairs ? pairs[blockIdx.x].in : in_single;      // batched launches: one workgroup per pair
+    uint32_t *__restrict__ order = order_base + (size_t)blockIdx.x * n;
     __shared__ unsigned hist[ORDER_BINS], start[ORDER_BINS];
     __shared__ unsigned wsum[ORDER_T / 64];
     const int tid = threadIdx.x;
@@ -1054,72 +598,38 @@ void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, 
     hipLaunchKernelGGL(track_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, nlevels, stats);
 }
 
-// Tracker kernel for 7x7 windows (other windows always take track_kernel, or 1 / 2 / 3 where they apply):
-//   4 (default)  track_kernel_qv  four features per wavefront, one 16-byte load per lane, image and footprint;
-//   0            track_kernel     one feature per wavefront (the fastest on ONE stream: 17.6 vs 18.6 us per 5000 features);
-//   1            track_kernel_pf  footprints requested ahead, one pixel per lane;
-//   2            track_kernel_q   four features per wavefront, per-sample loads;
-//   3            track_kernel<GRID>  one feature per wavefront, one pixel per lane.
-// All give bit-identical records.  With pairs in flight 0-3 share one throughput floor (1.93 ns per feature: 0 is bound by VALU
-// issue, 2 -- with 42 % fewer VALU instructions -- by the address / L1 path; nor does halving the HBM traffic help,
-// KLT_OPT_TRACK_XCD_ORDER); 4 removes both and reaches 1.62 ns (tools/track_scaling.py).  KLT_TRACK_VARIANT in the environment
-// sets the initial value.
+// Tracker kernels: track_kernel_qv (7x7 windows, lists of 2048 features and more: four features per wavefront, one 16-byte
+// load per lane, image and footprint), track_kernel (one feature per wavefront: every other window, short lists -- with a few
+// hundred features the launch is pure latency, which four features in lock step lengthen).  Both give bit-identical records.
+// KLT_OPT_TRACK_VARIANT = 0 (or KLT_TRACK_VARIANT=0 in the environment) forces track_kernel: the plain fallback the parity
+// tests compare the quad kernel with.  The measured-slower generations in between (prefetching, per-sample loads with four
+// features per wavefront, one pixel per lane) are recorded in profiles/README.md and live in the git history.
 int g_track_variant = getenv("KLT_TRACK_VARIANT") ? atoi(getenv("KLT_TRACK_VARIANT")) : 4;
 
 template <bool BATCH>
 static int launch_track_t(hipStream_t s, const TrackArgs &a)
 {
     const int n = a.window * a.window;
+    if (n > 1024) return -1;
     const size_t lds = 5 * (size_t)((n + 3) & ~3) * sizeof(float);
-    const dim3 grid(a.n, BATCH ? a.npairs : 1), block(64);
-    if (g_track_variant == 3 && a.window <= 7) {
-        if (!BATCH && a.order) {
-            if (a.order_refresh) hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
-            const dim3 gx(8 * a.order_chunk);
-            if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH, true>), gx, block, lds, s, a);
-            else hipLaunchKernelGGL((track_kernel<1, 0, BATCH, true>), gx, block, lds, s, a);
-            return 0;
-        }
-        if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((track_kernel<1, 0, BATCH, true>), grid, block, lds, s, a);
-        return 0;
-    }
-    // (short lists keep one feature per wavefront: with a few hundred features the launch is pure latency, which four features
-    // in lock step lengthen)
-    if (g_track_variant == 4 && a.window == 7 && (long long)a.n * (BATCH ? a.npairs : 1) >= 2048) {
-        if (!BATCH && a.order) {
-            if (a.order_refresh) hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
-            hipLaunchKernelGGL((track_kernel_qv<BATCH>), dim3(8 * ((a.order_chunk + 3) / 4)), block, 4 * lds, s, a);
-            return 0;
-        }
-        const dim3 gq((a.n + 3) / 4, BATCH ? a.npairs : 1);
+    const unsigned ny = BATCH ? a.npairs : 1;
+    const dim3 block(64);
+    // the permutation is (re)computed here whenever the caller asks for it, whichever kernel consumes it
+    if (a.order && a.order_refresh)
+        hipLaunchKernelGGL(track_order_kernel, dim3(ny), dim3(ORDER_T), 0, s, a.in, BATCH ? a.pairs : nullptr, a.n, a.order);
+    if (g_track_variant != 0 && a.window == 7 && (long long)a.n * ny >= 2048) {
+        const dim3 gq(a.order ? 8 * ((a.order_chunk + 3) / 4) : (a.n + 3) / 4, ny);
         hipLaunchKernelGGL((track_kernel_qv<BATCH>), gq, block, 4 * lds, s, a);
         return 0;
     }
-    if (g_track_variant == 2 && n <= 64) {
-        const dim3 gq((a.n + 3) / 4, BATCH ? a.npairs : 1);
-        if (a.window == 7) hipLaunchKernelGGL((track_kernel_q<7, BATCH>), gq, block, 4 * lds, s, a);
-        else hipLaunchKernelGGL((track_kernel_q<0, BATCH>), gq, block, 4 * lds, s, a);
-        return 0;
-    }
-    if (g_track_variant == 1 && n <= 64) {
-        if (a.window == 7) hipLaunchKernelGGL((track_kernel_pf<7, BATCH>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((track_kernel_pf<0, BATCH>), grid, block, lds, s, a);
-        return 0;
-    }
-    if (!BATCH && a.order) {                 // (the API sets `order` for 7x7 windows only)
-        if (a.order_refresh) hipLaunchKernelGGL(track_order_kernel, dim3(1), dim3(ORDER_T), 0, s, a.in, a.n, a.order);
-        const dim3 gx(8 * a.order_chunk);
-        if (a.window == 7) { hipLaunchKernelGGL((track_kernel<1, 7, BATCH>), gx, block, lds, s, a); return 0; }
-    }
+    const dim3 grid(a.order ? 8 * a.order_chunk : a.n, ny);
     if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH>), grid, block, lds, s, a);
     else if (a.window == 15) hipLaunchKernelGGL((track_kernel<4, 15, BATCH>), grid, block, lds, s, a);
     else if (n <= 64) hipLaunchKernelGGL((track_kernel<1, 0, BATCH>), grid, block, lds, s, a);
     else if (n <= 128) hipLaunchKernelGGL((track_kernel<2, 0, BATCH>), grid, block, lds, s, a);
     else if (n <= 256) hipLaunchKernelGGL((track_kernel<4, 0, BATCH>), grid, block, lds, s, a);
     else if (n <= 512) hipLaunchKernelGGL((track_kernel<8, 0, BATCH>), grid, block, lds, s, a);
-    else if (n <= 1024) hipLaunchKernelGGL((track_kernel<16, 0, BATCH>), grid, block, lds, s, a);
-    else return -1;
+    else hipLaunchKernelGGL((track_kernel<16, 0, BATCH>), grid, block, lds, s, a);
     return 0;
 }
 

@@ -84,7 +84,8 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
     slots = _slots_of(tc)
     if featurelist is None:
         featurelist = [KLT_Feature() for _ in range(nFeatures)]
-    reuse = (mode == selectionMode.REPLACING_SOME and tc.sequentialMode and tc.pyramid_last is not None)
+    reuse = (mode == selectionMode.REPLACING_SOME and tc.sequentialMode and tc.pyramid_last is not None
+             and ctx.pyramids_valid(slots[0]))
     if reuse:
         slot = slots[0]            # selectGoodFeatures.py:176-181: level 0 of the pyramids kept from the last track
     else:

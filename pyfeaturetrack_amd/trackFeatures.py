@@ -58,6 +58,10 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
     ctx.configure(tc)
     s1, s2, _ = _slots_of(tc)
     resident = tc.sequentialMode and tc.pyramid_last is not None
+    if resident and not ctx.pyramids_valid(s1):
+        # the pyramid geometry / taps changed since the last call (or another tracking context rebuilt the slot):
+        # the reference would go on with the stale pyramid_last; rebuilding frame 1 from img1 is the useful reading
+        resident = False
     if resident:
         if tc.pyramid_last.ncols[0] != ncols or tc.pyramid_last.nrows[0] != nrows:
             from .error import KLTError

@@ -68,7 +68,9 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
 
     ingest(s[0], first, 0)
     ctx.build_pyramids(s[0], sync=False)
-    ctx.select_async(s[0], SELECTING_ALL, True, row_fb(0), nFeatures)
+    # the initial selection follows KLTSelectGoodFeatures: the smoothed level-0 image when tc.smoothBeforeSelecting, the raw
+    # frame otherwise (selectGoodFeatures.py:183-197) -- level 0 of the pyramid is always smoothed
+    ctx.select_async(s[0], SELECTING_ALL, bool(tc.smoothBeforeSelecting), row_fb(0), nFeatures)
     state = None
     if affine:
         state = getattr(ctx, "_next_affine_state", 0)

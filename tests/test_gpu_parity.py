@@ -170,62 +170,6 @@ def test_unusual_sigmas_take_the_runtime_sized_kernels(ctx, ko, attrs, window, l
         assert_feats(out, *oracle_feats(ofl), what="%s track" % attrs)
 
 
-def test_split_level0_fork_join_build(cfg1, img0, img1):
-    """KLT_OPT_SPLIT_L0: smoothing alone, then level-0 gradients and the reductions on two streams; same pyramids."""
-    from pyfeaturetrack_amd.backend import Context
-    c = Context(0)
-    try:
-        c.configure(make_tc(max_residue=10.0))
-        c.set_option(7, 1)
-        c.upload(0, img0)
-        c.upload(1, img1)
-        for _ in range(3):
-            c.build_pyramids_batch([0, 1])
-        c.sync()
-        for slot, name in ((0, "p0"), (1, "p1")):
-            for l in range(2):
-                for pi, w in enumerate(("img", "gx", "gy")):
-                    assert_same(c.download_level(slot, pi, l), cfg1["%s_%s_%d" % (name, w, l)], "split %s %s %d" % (name, w, l))
-        fl, _ = c.select(0, 100, use_pyramid=True)
-        out, _ = c.track(0, 1, fl)
-        assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "track after a split build")
-    finally:
-        c.close()
-
-
-def test_one_sample_per_thread_variant(ctx, cfg1, img0):
-    """KLT_OPT_SMOOTH_GRAD_VARIANT=1: the non-register-blocked LDS kernels stay bit-identical too."""
-    ctx.configure(make_tc())
-    ctx.upload(0, img0)
-    try:
-        ctx.set_option(2, 1)
-        ctx.build_pyramids(0)
-        for l in range(2):
-            for pi, w in enumerate(("img", "gx", "gy")):
-                assert_same(ctx.download_level(0, pi, l), cfg1["p0_%s_%d" % (w, l)], "variant 1 %s %d" % (w, l))
-    finally:
-        ctx.set_option(2, 0)
-
-
-@pytest.mark.parametrize("levels,ss,shape", [(3, 4, (1080, 1920)), (3, 2, (240, 320)), (2, 4, (187, 251))])
-def test_pyramid_reduce_variant(ctx, ko, levels, ss, shape):
-    """KLT_OPT_PYR_REDUCE_VARIANT=1 (512 threads, all-f32 LDS, batched interior loads): bit-identical pyramids."""
-    from pyfeaturetrack_amd import synth
-    img = synth.synth_frame(shape[1], shape[0], 9, 0)
-    tc = make_tc(levels=levels, ss=ss)
-    ctx.configure(tc)
-    P = ko.Pyramids(params_from_tc(tc), img.astype(np.float32))
-    try:
-        ctx.set_option(9, 1)
-        ctx.upload(0, img)
-        ctx.build_pyramids(0)
-        for l in range(levels):
-            for pi, w in enumerate(("img", "gx", "gy")):
-                assert_same(ctx.download_level(0, pi, l), P.level(w, l), "reduce variant 1 ss%d %s level %d" % (ss, w, l))
-    finally:
-        ctx.set_option(9, 0)
-
-
 @pytest.mark.parametrize("shape,f32_input", [((1080, 1920), False), ((1080, 1920), True), ((1013, 1250), False), ((2160, 3840), False),
                                              ((1100, 1001), False)])
 def test_fused_first_reduction_on_and_off(ctx, ko, shape, f32_input):
@@ -456,13 +400,11 @@ def test_track_retain(ctx, cfg1, img0, img1):
     assert_feats(out, cfg1["trk100_retain_x"], cfg1["trk100_retain_y"], cfg1["trk100_retain_val"], "track retainTrackers")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("window,levels,ss,retain,mr", [(7, 2, 4, False, 10.0), (7, 2, 4, True, 10.0), (7, 3, 2, False, None),
                                                         (5, 2, 4, False, 10.0), (3, 2, 2, False, 5.0)])
-def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, retain, mr, variant):
-    """KLT_OPT_TRACK_VARIANT=1 (footprints requested ahead, one pixel per lane + lane shuffles) and =2 (four features per
-    wavefront), =3 (one pixel per lane), =4 (four features per wavefront with quad loads, the default for 7x7): same records as
-    the plain kernel (=0) and the oracle, and for the default context as the reference's goldens."""
+def test_track_default_vs_plain_kernel(ctx, ko, cfg1, img0, img1, window, levels, ss, retain, mr):
+    """KLT_OPT_TRACK_VARIANT=4 (the default kernel selection) gives the same records as the plain one-feature-per-wavefront
+    kernel (=0) and the oracle, and for the default context as the reference's goldens."""
     tc = make_tc(levels=levels, ss=ss, window=window, max_residue=mr, retainTrackers=retain)
     p = params_from_tc(tc)
     ctx.configure(tc)
@@ -472,7 +414,7 @@ def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, r
     ctx.build_pyramids(1)
     fl, _ = ctx.select(0, 100)
     try:
-        ctx.set_option(11, variant)
+        ctx.set_option(11, 4)
         out, _ = ctx.track(0, 1, fl)
         ctx.set_option(11, 0)
         ref, _ = ctx.track(0, 1, fl)
@@ -482,9 +424,9 @@ def test_track_prefetch_variant(ctx, ko, cfg1, img0, img1, window, levels, ss, r
     a0, a1 = np.asarray(img0, np.float32), np.asarray(img1, np.float32)
     ofl = ko.select_good_features(p, a0, 100)
     ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), ofl)
-    assert_feats(out, *oracle_feats(ofl), what="prefetching tracker, window %d" % window)
+    assert_feats(out, *oracle_feats(ofl), what="tracker, window %d" % window)
     if (window, levels, ss, retain, mr) == (7, 2, 4, False, 10.0):
-        assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "prefetching tracker vs golden")
+        assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "tracker vs golden")
 
 
 @pytest.mark.parametrize("mr,retain", [(10.0, False), (None, False), (10.0, True)])
@@ -533,7 +475,7 @@ def test_track_xcd_aware_order(ctx, ko):
     fl["val"][::7] = -3                     # some lost features in the list
     ref = None
     try:
-        for variant in (0, 3, 4):
+        for variant in (0, 4):
             ctx.set_option(11, variant)
             ctx.set_option(13, 0)
             ref, _ = ctx.track(0, 1, fl)
@@ -746,20 +688,74 @@ def test_cfg5_shape_4k_sequence_with_replacement(ctx, ko):
         P_prev = P_cur
 
 
-def test_rccl_path_on_one_gpu(tmp_path):
-    """bench.py's N > 1 code path (process group, zero-copy tensor view of the feature buffer, RCCL all-gather on the
-    tracker's stream) with a single rank."""
+def _run_bench(extra_args, **env_kw):
     import json
     import subprocess
     import sys
     from conftest import REPO
-    env = dict(os.environ, KLT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0",
-               WORLD_SIZE="1")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KLT_RDZV_FILE")}
+    env.update(env_kw)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + extra_args, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 code path -- rendezvous file, klt_comm_init_rank, the all-gather of the device-side record table on
+    libkltgpu's side stream, barrier / max over ranks through klt_comm_allreduce_max -- with a single rank (no torch)."""
+    line = _run_bench(["--gpus", "1", "--steps", "6", "--warmup", "2", "--repeats", "5", "--no-cpu-baseline"],
+                      KLT_FORCE_DIST="1", KLT_RDZV_FILE=str(tmp_path / "ids"))
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["tracked"] > 4500
+    assert line["config"]["rccl_ranks"] == 1 and line["parity_checked"] is True and line["max_abs_dx"] <= 1e-3
+
+
+def test_cfg4_sharded_bench_with_native_gather(tmp_path):
+    """`--config cfg4` on one rank with the RCCL path forced: batched build, one tracker launch, one gather of the table."""
+    line = _run_bench(["--config", "cfg4", "--gpus", "1", "--pairs", "4", "--steps", "3", "--warmup", "1", "--repeats", "5"],
+                      KLT_FORCE_DIST="1", KLT_RDZV_FILE=str(tmp_path / "ids"))
+    assert line["config"]["pairs_per_step"] == 4 and line["config"]["rccl_ranks"] == 1 and line["config"]["gathered_table_ok"] is True
+    assert line["parity_checked"] is True and line["scaling"] == "strong" and line["value"] > 0
+
+
+def test_native_gather_entry_points(tmp_path):
+    """klt_comm_* / klt_(all)gather_featbuf_async through the C ABI on a one-rank communicator: the gathered table equals the
+    source, the per-buffer fence orders a later overwrite behind the collective, errors come back as codes."""
+    import ctypes as C
+    from pyfeaturetrack_amd._abi import load_library
+    from pyfeaturetrack_amd.backend import Context, FEAT_DTYPE, KltBackendError
+    lib = load_library()
+    c = Context(0)
+    try:
+        assert c.comm_info() == (1, 0)
+        with pytest.raises(KltBackendError, match="klt_comm_init_rank"):
+            c.allgather_featbuf_async(0, 1, 4)
+        uid = (C.c_uint8 * 128)()
+        assert lib.klt_comm_unique_id(uid) == 0 and any(bytes(uid))
+        c.comm_init(1, 0, bytes(uid))
+        with pytest.raises(KltBackendError, match="already"):
+            c.comm_init(1, 0, bytes(uid))
+        n = 3000
+        fl = np.zeros(n, FEAT_DTYPE)
+        fl["x"] = np.arange(n)
+        fl["y"] = -np.arange(n)
+        fl["val"] = np.arange(n) % 7 - 3
+        c.featbuf_upload(0, fl)
+        c.allgather_featbuf_async(0, 1, n)
+        c.gather_featbuf_async(0, 2, n, root=0)
+        c.comm_fence_featbuf(0)                        # the overwrite below waits for both collectives on the device
+        c.featbuf_upload(0, np.zeros(n, FEAT_DTYPE))
+        assert np.array_equal(c.featbuf_download(1, n), fl) and np.array_equal(c.featbuf_download(2, n), fl)
+        assert c.comm_allreduce_max([1.5, -2.0]) == [1.5, -2.0]
+        with pytest.raises(KltBackendError, match="root"):
+            c.gather_featbuf_async(0, 2, n, root=3)
+        c.comm_wait()
+        c.comm_destroy()
+        assert c.comm_info() == (1, 0)
+    finally:
+        c.close()
 
 
 def test_topk_prefilter_and_its_fallback(ctx, ko):
@@ -823,37 +819,6 @@ def test_abi_error_reporting(ctx, img0):
             c.configure(make_tc(levels=4, ss=8))
             c.upload(3, img0[:40, :40].copy())
             c.build_pyramids(3)
-    finally:
-        c.close()
-
-
-def test_track_stream_overlap_keeps_results(cfg1, img0, img1):
-    """KLT_OPT_TRACK_STREAM: tracker launches on a second stream, slots rebuilt while earlier launches may still run;
-    every step must still produce the golden result (ordering by events)."""
-    from pyfeaturetrack_amd.backend import Context
-    c = Context(0)
-    try:
-        c.configure(make_tc(max_residue=10.0))
-        c.set_option(3, 1)
-        for s0 in (0, 2):
-            c.upload(s0, img0)
-            c.upload(s0 + 1, img1)
-        c.build_pyramids(0)
-        fl, _ = c.select(0, 100, use_pyramid=True)
-        c.featbuf_upload(0, fl)
-        for i in range(40):
-            a = 0 if i % 2 == 0 else 2
-            if i % 5 == 4:                                   # overwrite frame 1 with garbage, then restore it
-                c.upload(a + 1, (255 - img1))
-            c.upload(a + 1, img1)
-            c.build_pyramids_batch([a, a + 1])
-            c.track_async(a, a + 1, 0, 1 + i % 3, 100)
-        for k in range(3):
-            out = c.featbuf_download(1 + k, 100)
-            assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "two-stream step, buffer %d" % k)
-        c.set_option(3, 0)
-        out, _ = c.track(0, 1, fl)
-        assert_feats(out, cfg1["trk100_r10_x"], cfg1["trk100_r10_y"], cfg1["trk100_r10_val"], "back to one stream")
     finally:
         c.close()
 
