@@ -26,13 +26,84 @@ def KLTWriteFeatureListToPPM(featurelist, greyimg, filename):
     Image.fromarray(rgb, "RGB").save(filename)
 
 
+_BINHEADER_FL = b"KLTFL1"
+_VAL_WIDTH = 5
+
+
+def _format_width(fmt):
+    """Printed width of one `(x,y)=val ` group (upstream _findStringWidth: the digits of every conversion plus the literals)."""
+    import re
+    group = "(%s,%s)=%%%dd " % (fmt, fmt, _VAL_WIDTH)
+    width = 0
+    for lit, w in re.findall(r"([^%]+)|%(\d*)(?:\.\d+)?[a-zA-Z]", group):
+        width += len(lit) if lit else int(w or 1)
+    return width
+
+
 def KLTWriteFeatureList(featurelist, filename, fmt="%5.1f"):
-    """Text dump of a feature list.  The reference's version (writeFeatures.py:53-82) references
-    undefined helpers and cannot run; this writes one `index x y val` line per feature."""
+    """Feature list to a text file (fmt such as "%5.1f" or "%3d") or, with fmt None, to a binary file.
+
+    The reference's function (writeFeatures.py:53-82) calls helpers it never defines (_printSetupTxt, _printHeader,
+    FEATURE_LIST ...) and cannot run; the layout here is upstream KLT 1.3.4's: a comment area, the "do not modify" line, the
+    `KLT Feature List` banner, `nFeatures = n`, one `%7d | (x,y)=val ` row per feature; an integer format prints the
+    rounded position.  Binary: b"KLTFL1", int32 nFeatures, then (float32 x, float32 y, int32 val) per feature."""
+    fmt_str = "binary" if fmt is None else "text"
+    if _sgf.KLT_verbose >= 1 and filename is not None:
+        print("(KLT) Writing feature list to {0} file: '{1}'".format(fmt_str, filename))
+    n = len(featurelist)
+    if fmt is None:
+        rec = np.zeros(n, np.dtype([("x", "<f4"), ("y", "<f4"), ("val", "<i4")]))
+        rec["x"] = [f.x for f in featurelist]
+        rec["y"] = [f.y for f in featurelist]
+        rec["val"] = [f.val for f in featurelist]
+        with open(filename, "wb") as f:
+            f.write(_BINHEADER_FL)
+            f.write(np.int32(n).tobytes())
+            f.write(rec.tobytes())
+        return
+    integer = fmt.rstrip()[-1] == "d"
+    if not integer and fmt.rstrip()[-1] != "f":
+        from .error import KLTError
+        KLTError("(KLTWriteFeatureList) Bad format: {0}".format(fmt))
+    group = "(%s,%s)=%%%dd " % (fmt, fmt, _VAL_WIDTH)
     with open(filename, "w") as f:
-        f.write("# KLT feature list: %d features\n" % len(featurelist))
+        f.write("Feel free to place comments here.\n\n\n")
+        f.write("!!! Warning:  This is a KLT data file.  Do not modify below this line !!!\n")
+        f.write("\n------------------------------\nKLT Feature List\n------------------------------\n\n")
+        f.write("nFeatures = %d\n\n" % n)
+        f.write("feature | (x,y)=val\n--------+-" + "-" * _format_width(fmt) + "\n")
         for i, feat in enumerate(featurelist):
-            f.write("%d %s %s %d\n" % (i, fmt % feat.x, fmt % feat.y, feat.val))
+            if integer:
+                x, y = int(feat.x + 0.5), int(feat.y + 0.5)      # upstream rounds for integer formats
+            else:
+                x, y = feat.x, feat.y
+            f.write("%7d | " % i + group % (x, y, feat.val) + "\n")
+
+
+def KLTReadFeatureList(filename):
+    """Reads what KLTWriteFeatureList wrote (either form) back into a list of KLT_Feature."""
+    import re
+    from .klt import KLT_Feature
+    with open(filename, "rb") as f:
+        data = f.read()
+    out = []
+    if data.startswith(_BINHEADER_FL):
+        n = int(np.frombuffer(data, "<i4", 1, len(_BINHEADER_FL))[0])
+        rec = np.frombuffer(data, np.dtype([("x", "<f4"), ("y", "<f4"), ("val", "<i4")]), n, len(_BINHEADER_FL) + 4)
+        rows = zip(rec["x"].tolist(), rec["y"].tolist(), rec["val"].tolist())
+    else:
+        text = data.decode()
+        if "KLT Feature List" not in text:
+            from .error import KLTError
+            KLTError("(KLTReadFeatureList) File '{0}' does not contain a feature list".format(filename))
+        body = text[text.index("--------+-"):]
+        rows = [(float(m.group(1)), float(m.group(2)), int(m.group(3)))
+                for m in re.finditer(r"^\s*\d+ \| \(\s*([-\d.]+),\s*([-\d.]+)\)=\s*(-?\d+)", body, flags=re.M)]
+    for x, y, v in rows:
+        feat = KLT_Feature()
+        feat.x, feat.y, feat.val = x, y, int(v)
+        out.append(feat)
+    return out
 
 
 def KLTWriteFeatureTable(ft, filename, fmt="%5.1f"):

@@ -320,6 +320,86 @@ def main():
     out["w15_trk_x"], out["w15_trk_y"], out["w15_trk_val"] = feats_to_arrays(fl)
     np.savez_compressed(os.path.join(HERE, "synth251.npz"), **out)
 
+    # ------------------------------------------------------------------------------------------------------------
+    # BASELINE sizes (cfg-2 ... cfg-5), run through the reference itself: selected and tracked lists in full, the big
+    # planes as sha256 (eigenvalue map, every pyramid plane).  The f32 SAT noise that decides int(val) and the top-K set
+    # only exists at this scale, so the oracle is pinned here too, not only at 320x240.
+    def big_case(tag, frames, tc, nfeat, planes=True):
+        o = {}
+        pil = [Image.fromarray(f, "L") for f in frames]
+        W, H = pil[0].size
+        for k, f in enumerate(frames):
+            o["frame%d_sha" % k] = np.frombuffer(bytes.fromhex(sha(f)), np.uint8)
+        fimg, gx, gy, px, py, pv, pl = selection_internals(tc, pil[0])
+        o["eig_sha"] = np.frombuffer(bytes.fromhex(sha(np.array(pv, np.float32))), np.uint8)
+        o["eig_count"] = np.array([len(pv)], np.int64)
+        o["sorted_val"] = np.array([p[0] for p in pl[:4096]], np.float32)
+        o["sorted_x"] = np.array([p[1] for p in pl[:4096]], np.int32)
+        o["sorted_y"] = np.array([p[2] for p in pl[:4096]], np.int32)
+        del fimg, gx, gy, px, py, pv, pl
+        fl = sgf.KLTSelectGoodFeatures(tc, pil[0], nfeat)
+        x, y, v = feats_to_arrays(fl)
+        o["sel_x"], o["sel_y"], o["sel_val"] = x.astype(np.float32), y.astype(np.float32), v.astype(np.int32)
+        assert np.array_equal(o["sel_x"].astype(np.float64), x)
+        if planes:
+            for k in (0, 1):
+                imgs, gxs, gys = pyramids_of(tc, pil[k])
+                for l in range(tc.nPyramidLevels):
+                    for nm, arr in (("img", imgs[l]), ("gx", gxs[l]), ("gy", gys[l])):
+                        o["p%d_%s_%d_sha" % (k, nm, l)] = np.frombuffer(bytes.fromhex(sha(np.asarray(arr, np.float32))), np.uint8)
+        run_track(tc, pil[0], pil[1], fl)
+        x, y, v = feats_to_arrays(fl)
+        o["trk_x"], o["trk_y"], o["trk_val"] = x.astype(np.float32), y.astype(np.float32), v.astype(np.int32)
+        assert np.array_equal(o["trk_x"].astype(np.float64), x) and np.array_equal(o["trk_y"].astype(np.float64), y)
+        o["border"] = np.array([tc.borderx, tc.bordery], np.float64)
+        return {"%s_%s" % (tag, k): v for k, v in o.items()}
+
+    def ctx(levels, ss, window=7, **kw):
+        tc = klt.KLT_TrackingContext()
+        tc.window_width = tc.window_height = window
+        tc.nPyramidLevels, tc.subsampling = levels, ss
+        tc.KLTUpdateTCBorder()
+        for k, v in kw.items():
+            setattr(tc, k, v)
+        return tc
+
+    big = {}
+    # cfg-2: 1920x1080, seed 1, shift (3.3, -2.1), 5000 features, 7x7, L3 / ss4 (border 120)
+    big.update(big_case("cfg2", list(synth.synth_pair(1920, 1080, seed=1)), ctx(3, 4), 5000))
+    # cfg-4: one pair of the batch (1280x720, seed 0), 2000 features
+    big.update(big_case("cfg4", list(synth.synth_pair(1280, 720, seed=0)), ctx(3, 4), 2000))
+    # cfg-3, translation part: 15x15, L4 / ss2 (border 108), 5000 features, frames 0 -> 1 of the bench sequence
+    base3 = synth.synth_base(1920, 1080, 1)
+    fr3 = [synth.synth_frame(1920, 1080, 1, k, shift=(1.1, -0.7), base=base3) for k in range(2)]
+    big.update(big_case("cfg3", fr3, ctx(4, 2, window=15), 5000))
+    # cfg-5: first step of the 3840x2160 sequence (seed 4), 20000 features, max_residue 10 as in the bench
+    base5 = synth.synth_base(3840, 2160, 4)
+    fr5 = [synth.synth_frame(3840, 2160, 4, k, base=base5) for k in range(2)]
+    big.update(big_case("cfg5", fr5, ctx(3, 4, max_residue=10.0), 20000))
+    np.savez_compressed(os.path.join(HERE, "baseline_sizes.npz"), **big)
+
+    # ------------------------------------------------ example1: feat1.ppm bytes, end state of the 200-call ping-pong
+    ex = {}
+    tc = klt.KLT_TrackingContext()
+    tc.nSkippedPixels = 0
+    tc.max_residue = 10.0
+    fl = sgf.KLTSelectGoodFeatures(tc, img0, 50)
+    import writeFeatures as wf
+    wf.KLT_verbose = 0
+    ppm = os.path.join(refdir, "feat1.ppm")
+    wf.KLTWriteFeatureListToPPM(fl, img0, ppm)
+    ex["feat1_ppm_sha"] = np.frombuffer(hashlib.sha256(open(ppm, "rb").read()).digest(), np.uint8)
+    ex["feat1_ppm_size"] = np.array([os.path.getsize(ppm)], np.int64)
+    for k in range(100):                                     # example1.py:53-56
+        run_track(tc, img0, img1, fl)
+        run_track(tc, img1, img0, fl)
+        if k in (0, 9, 49, 99):
+            x, y, v = feats_to_arrays(fl)
+            ex["pp_after_%d_x" % (2 * k + 2)], ex["pp_after_%d_y" % (2 * k + 2)], ex["pp_after_%d_val" % (2 * k + 2)] = x, y, v
+    wf.KLTWriteFeatureListToPPM(fl, img1, os.path.join(refdir, "feat2.ppm"))
+    ex["feat2_ppm_sha"] = np.frombuffer(hashlib.sha256(open(os.path.join(refdir, "feat2.ppm"), "rb").read()).digest(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "example1.npz"), **ex)
+
     with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1)
     shutil.rmtree(refdir, ignore_errors=True)

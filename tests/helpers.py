@@ -38,3 +38,30 @@ def feats_equal(fl, gx, gy, gv):
 
 
 __all__ = ["sha_bytes", "make_tc", "synth251_frames", "feats_equal", "params_from_tc"]
+
+
+# ---- BASELINE-size cases pinned by tests/golden/baseline_sizes.npz (generated from the reference itself, gen_golden.py) ----
+def baseline_case(tag):
+    """(frames [2 x uint8], tracking context, nFeatures) of the cfg-2 / cfg-3 / cfg-4 / cfg-5 golden cases."""
+    if tag == "cfg2":
+        return list(synth.synth_pair(1920, 1080, seed=1)), make_tc(levels=3, ss=4), 5000
+    if tag == "cfg4":
+        return list(synth.synth_pair(1280, 720, seed=0)), make_tc(levels=3, ss=4), 2000
+    if tag == "cfg3":
+        base = synth.synth_base(1920, 1080, 1)
+        return ([synth.synth_frame(1920, 1080, 1, k, shift=(1.1, -0.7), base=base) for k in range(2)],
+                make_tc(levels=4, ss=2, window=15), 5000)
+    if tag == "cfg5":
+        base = synth.synth_base(3840, 2160, 4)
+        return ([synth.synth_frame(3840, 2160, 4, k, base=base) for k in range(2)],
+                make_tc(levels=3, ss=4, max_residue=10.0), 20000)
+    raise KeyError(tag)
+
+
+def golden_feats_equal(fl, g, tag, what):
+    """feature records vs the golden (x, y stored as f32: every value the reference produces is f32-valued)"""
+    return (np.array_equal(fl["val"], g["%s_%s_val" % (tag, what)])
+            and np.array_equal(fl["x"], g["%s_%s_x" % (tag, what)]) and np.array_equal(fl["y"], g["%s_%s_y" % (tag, what)]))
+
+
+__all__ += ["baseline_case", "golden_feats_equal"]
