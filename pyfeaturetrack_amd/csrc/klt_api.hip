@@ -1021,7 +1021,9 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     const int R = d >= 0 ? d / step : -1;                 // exclusion radius in candidate cells
     const bool parallel_nms = c->use_mis && ncand > 0 && mis_stage_bytes(R) <= 120 * 1024;
     const uint8_t *seed = nullptr;
-    if (mode == KLT_REPLACING_SOME && d >= 0 && !parallel_nms) {
+    // REPLACING_SOME: the squares of the live features are marked first; the eigenvalue kernels skip marked pixels, so neither the
+    // scoring nor the minimum-distance stage ever sees them
+    if (mode == KLT_REPLACING_SOME && d >= 0) {
         if (int rc = ensure(c, c->seedmap, c->seed_cap, N)) return rc;
         HIPCHK(c, hipMemsetAsync(c->seedmap, 0, N, c->stream));
         TimerScope t(c, F_SEED, (double)n * 16);
@@ -1032,7 +1034,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     SelectArgs sa;
     sa.sat = c->sat; sa.valmap = c->valmap; sa.keys = c->keys; sa.seedmap = seed;
     sa.val_in = nullptr;
-    sa.hist = sa.ticket = sa.info = nullptr; sa.hist_target = 0;
+    sa.hist = sa.ticket = sa.info = nullptr; sa.hist_target = 0; sa.hist_slots = nullptr; sa.hist_per_slot = 0;
     if (c->score_override_n) {
         const int given = c->score_override_n;
         c->score_override_n = 0;
@@ -1130,6 +1132,11 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
             if (attempt == 0) {
                 launch_mis_prepare(c->stream, b->d, n, pa.overwrite_all, pa.slots, nfill_d, c->fl_snapshot, c->mis_cnt + off_rem, n_cnt - off_rem);
                 if (filtered) { sa.hist = c->mis_cnt + off_hist; sa.ticket = c->mis_cnt + off_ticket; sa.info = info_d; sa.hist_target = (unsigned)((target + 3) / 4); }
+                if (filtered && mode == KLT_REPLACING_SOME) {
+                    // only the lost features' slots are filled and the live features' squares are not scored at all: 64 candidates per
+                    // LOST feature (at least 65536) instead of 64 per list entry -- most of a frame's candidates never enter the passes
+                    sa.hist_target = 65536 / 4; sa.hist_slots = nfill_d; sa.hist_per_slot = 64 / 4;
+                }
                 TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8));
                 launch_eigen_hist(c->stream, sa);
             } else {
@@ -1140,7 +1147,6 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
             {
                 TimerScope t(c, F_NMS, (double)ncand * 12);
                 launch_mis_init(c->stream, ma);
-                if (mode == KLT_REPLACING_SOME && d >= 0) launch_mis_seed(c->stream, c->fl_snapshot, n, ma, d);
             }
             unsigned left = 0;
             for (;;) {
@@ -1169,6 +1175,9 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
                     int needed = look;                                           // learn how many passes were needed
                     while (needed > 1 && rem[needed - 2] == 0u) needed--;
                     needed += round - look;
+                    // replacement runs frame after frame: one spare pass, because a frame that needs one pass more than the last
+                    // one costs a host round trip and another batch of passes, an idle pass 2-5 us
+                    if (mode == KLT_REPLACING_SOME) needed += 1;
                     c->mis_rounds_hint = needed < 2 ? 2 : (needed > 32 ? 32 : needed);
                     break;
                 }

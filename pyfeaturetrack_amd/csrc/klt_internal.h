@@ -93,6 +93,8 @@ struct SelectArgs {
     const float *val_in;     // test hook: eigenvalues given instead of computed (may be null)
     unsigned *hist, *ticket, *info;   // eigen_hist_kernel: 8192 bins, workgroup ticket, threshold info (hist may be null)
     unsigned hist_target;
+    const int *hist_slots;            // optional (device): number of free slots; the cut keeps max(hist_target, hist_per_slot * *hist_slots) keys
+    unsigned hist_per_slot;           // (both in units of the sampled histogram: every 4th workgroup counts)
     double min_eig;
     int ncols, nrows, bx, by, step, nx, ny, hw, hh, npow2;
 };
@@ -162,7 +164,6 @@ int  mis_tile_capacity(int R);
 void launch_zero_words(hipStream_t s, unsigned *p, size_t n);
 void launch_mis_prepare(hipStream_t s, const klt_feat *fl, int nfeat, int overwrite_all, int *slots, int *nfill_out, klt_feat *snapshot,
                         unsigned *zero, size_t zero_n);
-void launch_mis_seed(hipStream_t s, const klt_feat *fl, int nfeat, const MisArgs &a, int d);
 void launch_eigen_hist(hipStream_t s, const SelectArgs &a);
 void launch_mis_results(hipStream_t s, unsigned *host_out, const unsigned *rem, int look, const unsigned *info, const int *placed);
 void launch_mis_place(hipStream_t s, const NmsArgs &a, const unsigned *count, unsigned *rank, const int *nfill, int bound,

@@ -285,10 +285,15 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
     constexpr int AW = TW + 2 * HB + 8, BW = TW + 2 * HB, DW = TW;   // floats per row (A starts at column -HB-4, B / C at -HB, D / E at 0)
     constexpr int AQ = AW / 4, BQ = BW / 4, DQ = DW / 4;        // quads per row
     constexpr int IH = TH_ + 2 * R, RH = IH + 2 * rs;
-    constexpr int AB = SMOOTH ? RH * AW + RH * BW : 0, DE = 2 * IH * DW;
-    constexpr int OFF_C = AB > DE ? AB : DE;
-    __shared__ __attribute__((aligned(16))) float lds[OFF_C + IH * BW];
-    float *const A = lds, *const B = lds + RH * AW, *const D = lds, *const E = lds + IH * DW, *const C = lds + OFF_C;
+    // LDS regions.  With smoothing: [A | C] then [B | D E] -- the raw tile A is dead once B exists and the smoothed tile C takes its
+    // place; B is dead once C exists and the two gradient intermediates D, E take its place (they are written while C is read,
+    // so they cannot share C's region).  35.6 KB for the 32-row tile with the fused reduction: four workgroups per CU, and the
+    // 2040 tiles of a 1080p pair are two full rounds of the 1024 slots (44 KB / three per CU before: 2.66 rounds).
+    // Without smoothing (gradients of levels >= 1): C, then D E.
+    constexpr int AC = SMOOTH ? (RH * AW > IH * BW ? RH * AW : IH * BW) : IH * BW;
+    constexpr int BDE = SMOOTH ? (RH * BW > 2 * IH * DW ? RH * BW : 2 * IH * DW) : 2 * IH * DW;
+    __shared__ __attribute__((aligned(16))) float lds[AC + BDE];
+    float *const A = lds, *const C = lds, *const B = lds + AC, *const D = lds + AC, *const E = lds + AC + IH * DW;
     const int tid = threadIdx.x, b = blockIdx.z;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
     const int nc = a.dim_c[b] ? a.dim_c[b] : a.ncols, nr = a.dim_r[b] ? a.dim_r[b] : a.nrows;

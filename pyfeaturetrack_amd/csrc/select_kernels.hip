@@ -230,6 +230,9 @@ __device__ __forceinline__ unsigned long long eigen_key(const SelectArgs &a, int
 {
     const int xi = k % a.nx, yi = k / a.nx;
     const int x = a.bx + xi * a.step, y = a.by + yi * a.step;
+    // REPLACING_SOME: a pixel inside the exclusion square of a live feature can never be placed (selectGoodFeatures.py:64-69 marks
+    // the feature map before the walk), so it is not scored at all -- most of the frame when few features were lost
+    if (a.seedmap && a.seedmap[(size_t)y * a.ncols + x] != 0) { a.valmap[k] = 0.f; return 0ull; }
     const size_t plane = (size_t)a.ncols * a.nrows;
     const float gxx = window_sum(a.sat, a.ncols, x, y, a.hw, a.hh);
     const float gxy = window_sum(a.sat + plane, a.ncols, x, y, a.hw, a.hh);
@@ -244,8 +247,7 @@ __device__ __forceinline__ unsigned long long eigen_key(const SelectArgs &a, int
     const float num = sum - s;
     const float val = a.val_in ? a.val_in[k] : (float)((double)num / 2.0);
     a.valmap[k] = val;
-    bool ok = (double)val >= a.min_eig;                // val >= max(min_eigenvalue, 1) > 0
-    if (ok && a.seedmap) ok = a.seedmap[(size_t)y * a.ncols + x] == 0;
+    const bool ok = (double)val >= a.min_eig;          // val >= max(min_eigenvalue, 1) > 0
     return ok ? (((unsigned long long)__float_as_uint(val) << 32) | ((unsigned long long)x << 16) | (unsigned long long)y) : 0ull;
 }
 
@@ -281,10 +283,17 @@ __global__ __launch_bounds__(256) void key_hist_kernel(const unsigned long long 
 }
 
 // info[0] = threshold bin, info[1] = number of keys in bins >= threshold, info[2] = number of valid keys
-__global__ __launch_bounds__(1024) void key_threshold_kernel(const unsigned *__restrict__ hist, unsigned target, unsigned *__restrict__ info)
+// slots != nullptr: target = max(target, per_slot * *slots) -- REPLACING_SOME sizes the cut by the number of lost features, which
+// only the device knows (mis_prepare_kernel)
+__global__ __launch_bounds__(1024) void key_threshold_kernel(const unsigned *__restrict__ hist, unsigned target, unsigned *__restrict__ info,
+                                                             const int *__restrict__ slots, unsigned per_slot)
 {
     __shared__ unsigned suf[1025];
     const int t = threadIdx.x;
+    if (slots) {
+        const unsigned want = per_slot * (unsigned)max(*slots, 0);
+        target = want > target ? want : target;
+    }
     unsigned mine = 0;
     for (int b = 0; b < 8; b++) mine += hist[8 * t + b];
     suf[t] = mine;
@@ -668,6 +677,10 @@ __global__ __launch_bounds__(MIS_T) void mis_init_kernel(MisArgs a)
     if (threadIdx.x == 0) a.cnt[blockIdx.x] = s_cursor;
 }
 
+// (Several passes per launch -- every tile looping over re-staged states read with agent-scope loads, so that decisions of
+// other XCDs are seen inside the launch -- were measured in round 2: 2 launches x 41 us instead of 6 x 13 us at 1080p, i.e. the
+// same; at 4K, where the 5700 tiles are not all resident, the early tiles spin on neighbours that have not started: 218 vs 99 us.
+// A pass costs what it computes (staging + window maxima of every active tile, ~4.6 M wavefront-instructions), not its launch.)
 __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
 {
     // staged tiles: S = states of the tile + halo ((32 + 2R)^2 u32), H = per row of S and interior column the maximum
@@ -686,6 +699,9 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int R = a.R, W = MIS_TILE + 2 * R, L = 2 * R + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (Deciding the last few candidates of a tile without staging it -- a wavefront reading each candidate's window straight from
+    // the states -- was measured in round 2: every pass got slower, 11.3 vs 7.4 us for the late ones; the dependent L2 round trips
+    // per candidate cost more than staging the tile once.)
     const bool staged = a.stage && R > 0;
     uint32_t *H = lds32;                      // [W][32]
     uint32_t *S = lds32 + W * MIS_TILE;       // [W][W]
@@ -831,98 +847,100 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
         const int q = (int)acc_local[i];
         const int xi = tx * MIS_TILE + q % MIS_TILE, yi = ty * MIS_TILE + q / MIS_TILE;
         const uint32_t sp = staged ? S[(q / MIS_TILE + R) * W + q % MIS_TILE + R] : a.st[(size_t)yi * a.nx + xi] & 0x7fffffffu;
-        a.acc_keys[s_base + i] = ((unsigned long long)sp << 32) | ((unsigned long long)(a.bx + xi * a.step) << 16) |
-                                 (unsigned long long)(a.by + yi * a.step);
+        const unsigned long long key = ((unsigned long long)sp << 32) | ((unsigned long long)(a.bx + xi * a.step) << 16) |
+                                       (unsigned long long)(a.by + yi * a.step);
+        a.acc_keys[s_base + i] = key;
     }
 }
 
-// accepted candidates of all tiles -> one dense array (tile order) + their number
-__global__ __launch_bounds__(1024) void mis_compact_kernel(const unsigned long long *__restrict__ tile_keys, const unsigned *__restrict__ acc_cnt,
-                                                           int tiles, int cap, unsigned long long *__restrict__ out, unsigned *__restrict__ out_count)
+// block-wide helpers (256 threads): sum, and inclusive scan, of one unsigned per thread
+__device__ __forceinline__ unsigned block_sum_256(unsigned v, unsigned *red /* [4] */)
 {
-    __shared__ unsigned scan[1024];
-    __shared__ unsigned s_running;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_running = 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int t0 = 0; t0 < tiles; t0 += 1024) {
-        const int t = t0 + tid;
-        const unsigned c = t < tiles ? acc_cnt[t] : 0u;
-        scan[tid] = c;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const unsigned v = tid >= off ? scan[tid - off] : 0u;
-            __syncthreads();
-            scan[tid] += v;
-            __syncthreads();
-        }
-        const unsigned running = s_running;
-        {                                                                  // thread = tile; 8 loads in flight at a time
-            const unsigned long long *src = tile_keys + (size_t)t * cap;
-            unsigned long long *dst = out + running + scan[tid] - c;
-            for (unsigned k0 = 0; k0 < c; k0 += 8) {
-                unsigned long long v[8];
+    const unsigned t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ unsigned block_scan_256(unsigned v, unsigned *red /* [4] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = k0 + u < c ? src[k0 + u] : 0ull;
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (k0 + u < c) dst[k0 + u] = v[u];
-            }
-        }
-        __syncthreads();
-        if (tid == 1023) s_running = running + scan[1023];
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
     }
-    if (tid == 0) *out_count = s_running;
+    if (lane == 63) red[wave] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; w++) base += red[w];
+    __syncthreads();
+    return base + inc;
+}
+
+// accepted candidates of all tiles -> one dense array (tile order) + their number.  One thread per tile, any number of
+// workgroups: a workgroup first adds up the counts of the tiles before its own 256 (a few thousand words from L2), scans its
+// own, and every thread copies its tile's keys.  (The single-workgroup version took 10.7 us at 1080p and 30.7 us at 4K.
+// Keeping only the keys that can reach a free slot -- a histogram of the accepted keys, the bin that leaves `free slots` above
+// it -- would shrink the O(n^2) ranking behind it, but building that histogram costs more than it saves: 1.4 us per pass with
+// one global atomic per accepted key, 16 / 37 us with every compaction workgroup histogramming all keys in LDS.)
+__global__ __launch_bounds__(256) void mis_compact_kernel(const unsigned long long *__restrict__ tile_keys, const unsigned *__restrict__ acc_cnt,
+                                                          int tiles, int cap, unsigned long long *__restrict__ out, unsigned *__restrict__ out_count)
+{
+    __shared__ unsigned red[4];
+    const int tid = threadIdx.x, t0 = blockIdx.x * 256, t = t0 + tid;
+    unsigned before = 0;
+    for (int i = tid; i < t0; i += 256) before += acc_cnt[i];
+    const unsigned base = block_sum_256(before, red);
+    const unsigned c = t < tiles ? acc_cnt[t] : 0u;
+    const unsigned incl = block_scan_256(c, red);
+    {                                                                      // thread = tile; 8 loads in flight at a time
+        const unsigned long long *src = tile_keys + (size_t)t * cap;
+        unsigned long long *dst = out + base + incl - c;
+        for (unsigned k0 = 0; k0 < c; k0 += 8) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = k0 + u < c ? src[k0 + u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (k0 + u < c) dst[k0 + u] = v[u];
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) *out_count = base + incl;
 }
 
 // ---- placement of the accepted candidates: rank by counting, then the first `free slots` fill the list
 // free slots in list order (selectGoodFeatures.py:109-110): every slot when overwriting, else the lost features
-// one launch before the passes: workgroup 0 lists the free slots and keeps a copy of the list (a repeated attempt starts
-// from it), the other workgroups clear the counters
-__global__ __launch_bounds__(1024) void mis_prepare_kernel(const klt_feat *__restrict__ fl, int nfeat, int overwrite_all, int *__restrict__ slots,
-                                                           int *__restrict__ nfill_out, klt_feat *__restrict__ snapshot,
-                                                           unsigned *__restrict__ zero, size_t zero_n)
+// one launch before the passes: the first workgroups list the free slots and keep a copy of the list (a repeated attempt
+// starts from it), the others clear the counters
+__global__ __launch_bounds__(256) void mis_prepare_kernel(const klt_feat *__restrict__ fl, int nfeat, int overwrite_all, int *__restrict__ slots,
+                                                          int *__restrict__ nfill_out, klt_feat *__restrict__ snapshot,
+                                                          unsigned *__restrict__ zero, size_t zero_n, int feat_blocks)
 {
-    if (blockIdx.x > 0) {
-        for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < zero_n; i += (size_t)(gridDim.x - 1) * 1024) zero[i] = 0u;
+    if ((int)blockIdx.x >= feat_blocks) {
+        const size_t zb = blockIdx.x - feat_blocks, nz = gridDim.x - feat_blocks;
+        for (size_t i = zb * 256 + threadIdx.x; i < zero_n; i += nz * 256) zero[i] = 0u;
         return;
     }
-    __shared__ int scan[1024];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < nfeat; i += 1024) snapshot[i] = fl[i];
-    if (overwrite_all) { if (tid == 0) *nfill_out = nfeat; return; }
-    const int per = (nfeat + 1023) / 1024, lo = tid * per, hi = min(lo + per, nfeat);
-    int cnt = 0;
-    for (int i = lo; i < hi; i++) cnt += fl[i].val < 0;
-    scan[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? scan[tid - off] : 0;
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
-    }
-    int k = scan[tid] - cnt;
-    for (int i = lo; i < hi; i++)
-        if (fl[i].val < 0) slots[k++] = i;
-    if (tid == 1023) *nfill_out = scan[tid];
-}
-
-// REPLACING_SOME (selectGoodFeatures.py:64-69): every live feature clears the candidates within its exclusion square
-__global__ void mis_seed_kernel(const klt_feat *__restrict__ fl, int nfeat, MisArgs a, int d)
-{
-    const int f = blockIdx.x;
-    if (f >= nfeat) return;
-    const klt_feat ft = fl[f];
-    if (ft.val < 0) return;
-    const int cx = (int)ft.x, cy = (int)ft.y, side = 2 * d + 1;
-    for (int k = threadIdx.x; k < side * side; k += blockDim.x) {
-        const int px = cx - d + k % side - a.bx, py = cy - d + k / side - a.by;      // pixel offset from the first candidate
-        if (px < 0 || py < 0 || px % a.step || py % a.step) continue;
-        const int xi = px / a.step, yi = py / a.step;
-        if (xi < a.nx && yi < a.ny) a.st[(size_t)yi * a.nx + xi] = 0u;
-    }
+    // workgroup b owns features [256 b, 256 b + 256): copies them, and (REPLACING_SOME) lists the lost ones among them behind
+    // the lost ones of all earlier features, which it counts itself
+    __shared__ unsigned red[4];
+    const int tid = threadIdx.x, f0 = blockIdx.x * 256, f = f0 + tid;
+    klt_feat ft;
+    ft.val = 0;
+    if (f < nfeat) { ft = fl[f]; snapshot[f] = ft; }
+    if (overwrite_all) { if (f == 0) *nfill_out = nfeat; return; }
+    unsigned before = 0;
+    for (int i = tid; i < f0; i += 256) before += fl[i].val < 0 ? 1u : 0u;
+    const unsigned base = block_sum_256(before, red);
+    const unsigned lost = (f < nfeat && ft.val < 0) ? 1u : 0u;
+    const unsigned incl = block_scan_256(lost, red);
+    if (lost) slots[base + incl - 1] = f;
+    if ((int)blockIdx.x == feat_blocks - 1 && tid == 255) *nfill_out = (int)(base + incl);
 }
 
 // the few words the host looks at, written straight into pinned host memory: [0, look) "undecided left" flags of the
@@ -939,23 +957,28 @@ __global__ void mis_results_kernel(unsigned *host_out, const unsigned *rem, int 
     write_results(host_out, rem, look, info, placed[0], placed[1]);
 }
 
-// rank[i] += number of accepted keys in chunk blockIdx.y that are greater than key i (keys are distinct)
-constexpr int RANK_T = 256;
+// rank[i] = number of accepted keys greater than key i (keys are distinct).  The number of accepted keys is only known on the
+// device, so the grid is fixed and every workgroup walks the (i-chunk, j-chunk) pairs with its stride: a REPLACING_SOME pass that
+// accepted a few hundred candidates does one pair, where a grid sized for the worst case launched 73 000 empty workgroups at 4K.
+constexpr int RANK_T = 256, RANK_GX = 96, RANK_GY = 96;
 __global__ __launch_bounds__(RANK_T) void mis_rank_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ count,
                                                           unsigned *__restrict__ rank)
 {
     __shared__ unsigned long long other[RANK_T];
-    const unsigned n = *count;
-    const unsigned i = blockIdx.x * RANK_T + threadIdx.x, j0 = blockIdx.y * RANK_T;
-    if (blockIdx.x * RANK_T >= n || j0 >= n) return;
-    other[threadIdx.x] = j0 + threadIdx.x < n ? keys[j0 + threadIdx.x] : 0ull;
-    __syncthreads();
-    if (i >= n) return;
-    const unsigned long long key = keys[i];
-    unsigned greater = 0;
+    const unsigned n = *count, nchunks = (n + RANK_T - 1) / RANK_T;
+    for (unsigned ic = blockIdx.x; ic < nchunks; ic += gridDim.x) {
+        const unsigned i = ic * RANK_T + threadIdx.x;
+        const unsigned long long key = i < n ? keys[i] : ~0ull;
+        unsigned greater = 0;
+        for (unsigned jc = blockIdx.y; jc < nchunks; jc += gridDim.y) {
+            __syncthreads();
+            other[threadIdx.x] = jc * RANK_T + threadIdx.x < n ? keys[jc * RANK_T + threadIdx.x] : 0ull;
+            __syncthreads();
 #pragma unroll 8
-    for (int j = 0; j < RANK_T; j++) greater += other[j] > key ? 1u : 0u;
-    if (greater) atomicAdd(&rank[i], greater);
+            for (int j = 0; j < RANK_T; j++) greater += other[j] > key ? 1u : 0u;
+        }
+        if (i < n && greater) atomicAdd(&rank[i], greater);
+    }
 }
 
 __global__ __launch_bounds__(256) void mis_place_kernel(NmsArgs a, const unsigned *__restrict__ count, const unsigned *__restrict__ rank,
@@ -1035,7 +1058,7 @@ void launch_topk_prefilter(hipStream_t s, const unsigned long long *keys, int n,
                            unsigned *info /* [0..2] + counter at [3] */, unsigned long long *out)
 {
     hipLaunchKernelGGL(key_hist_kernel, dim3(256), dim3(256), 0, s, keys, n, hist, 1);
-    hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, hist, target, info);
+    hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, hist, target, info, (const int *)nullptr, 0u);
     hipLaunchKernelGGL(key_compact_kernel, dim3(512), dim3(256), 0, s, keys, n, info, out, info + 3);
 }
 
@@ -1043,7 +1066,7 @@ void launch_topk_prefilter(hipStream_t s, const unsigned long long *keys, int n,
 void launch_key_threshold(hipStream_t s, const unsigned long long *keys, int n, unsigned target, unsigned *hist, unsigned *info)
 {
     hipLaunchKernelGGL(key_hist_kernel, dim3(256), dim3(256), 0, s, keys, n, hist, 4);
-    hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, hist, (target + 3u) / 4u, info);
+    hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, hist, (target + 3u) / 4u, info, (const int *)nullptr, 0u);
 }
 
 __global__ __launch_bounds__(256) void zero_words_kernel(unsigned *__restrict__ p, size_t n)
@@ -1083,7 +1106,8 @@ int launch_mis_round(hipStream_t s, const MisArgs &a, int round)
 
 void launch_mis_compact(hipStream_t s, const MisArgs &a, unsigned long long *out, unsigned *out_count)
 {
-    hipLaunchKernelGGL(mis_compact_kernel, dim3(1), dim3(1024), 0, s, a.acc_keys, a.acc_cnt, mis_tiles(a.nx, a.ny), a.acc_cap, out, out_count);
+    const int tiles = mis_tiles(a.nx, a.ny);
+    hipLaunchKernelGGL(mis_compact_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, a.acc_keys, a.acc_cnt, tiles, a.acc_cap, out, out_count);
 }
 
 int mis_tile_capacity(int R)
@@ -1097,20 +1121,16 @@ void launch_mis_prepare(hipStream_t s, const klt_feat *fl, int nfeat, int overwr
                         unsigned *zero, size_t zero_n)
 {
     const size_t zb = (zero_n + 1023) / 1024;
-    hipLaunchKernelGGL(mis_prepare_kernel, dim3(1 + (unsigned)(zb < 1 ? 1 : (zb > 64 ? 64 : zb))), dim3(1024), 0, s, fl, nfeat, overwrite_all, slots,
-                       nfill_out, snapshot, zero, zero_n);
-}
-
-void launch_mis_seed(hipStream_t s, const klt_feat *fl, int nfeat, const MisArgs &a, int d)
-{
-    hipLaunchKernelGGL(mis_seed_kernel, dim3(nfeat), dim3(128), 0, s, fl, nfeat, a, d);
+    const int feat_blocks = nfeat > 0 ? (nfeat + 255) / 256 : 1;
+    hipLaunchKernelGGL(mis_prepare_kernel, dim3(feat_blocks + (unsigned)(zb < 1 ? 1 : (zb > 64 ? 64 : zb))), dim3(256), 0, s, fl, nfeat, overwrite_all,
+                       slots, nfill_out, snapshot, zero, zero_n, feat_blocks);
 }
 
 void launch_eigen_hist(hipStream_t s, const SelectArgs &a)
 {
     const int blocks = (a.nx * a.ny + 255) / 256;
     hipLaunchKernelGGL(eigen_hist_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, a);
-    if (a.hist) hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, a.hist, a.hist_target, a.info);
+    if (a.hist) hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, a.hist, a.hist_target, a.info, a.hist_slots, a.hist_per_slot);
 }
 
 void launch_mis_results(hipStream_t s, unsigned *host_out, const unsigned *rem, int look, const unsigned *info, const int *placed)
@@ -1123,7 +1143,8 @@ void launch_mis_place(hipStream_t s, const NmsArgs &a, const unsigned *count, un
                       unsigned *host_out, const unsigned *rem, int look, const unsigned *info)
 {
     const int chunks = (bound + RANK_T - 1) / RANK_T;
-    hipLaunchKernelGGL(mis_rank_kernel, dim3(chunks, chunks), dim3(RANK_T), 0, s, a.keys, count, rank);
+    hipLaunchKernelGGL(mis_rank_kernel, dim3(chunks < RANK_GX ? chunks : RANK_GX, chunks < RANK_GY ? chunks : RANK_GY), dim3(RANK_T), 0, s,
+                       a.keys, count, rank);
     hipLaunchKernelGGL(mis_place_kernel, dim3((bound + 255) / 256), dim3(256), 0, s, a, count, rank, nfill, host_out, rem, look, info);
 }
 

@@ -297,8 +297,23 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     }
 }
 
-// numpy pairwise f32 sum of one 16-lane group (four features per wavefront): pairwise_block_wave with the group lane s
-__device__ __forceinline__ float pairwise_block_group(const float *a, int n, int s)      // result in the group's lane s == 0
+// ------------------------------------------------------------------------------------------------------
+// Quad-load tracker kernels.  The (w+1) x (w+1) footprint of a window is loaded as QUADS of four pixels, one 16-byte load per
+// lane and image:
+//   7x7   the 8x8 footprint is 16 quads -> a feature owns 16 lanes and a wavefront tracks FOUR features in lock step under
+//         per-feature predicates (a finished feature keeps its state and idles);
+//   15x15 the 16x16 footprint is exactly 64 quads -> one feature per wavefront.
+// Lane (row r, quad h) of a feature loads pixels (r, 4h .. 4h + 3) and computes the window samples (r, 4h .. 4h + 3) from its own
+// quad, the quad below (lane + quads-per-row) and the first pixels of the quads to the right (lane + 1, lane + quads-per-row + 1):
+// 3 vector loads per footprint and wavefront, where the one-sample-per-lane kernel issues 12 (7x7) or 48 (15x15).  The bounds test
+// and the footprint of the NEXT Newton iteration are issued as soon as the position is known -- for the first iteration of a
+// level together with the template's loads -- so a level costs one memory round trip per iteration instead of one more.
+// Every feature's arithmetic is track_level's, operation for operation: same bilinear expression, the five product arrays in
+// LDS added by lanes 0..4 of the feature in the reference's row-major sequential f32 order, numpy's pairwise sum for the residue.
+
+// numpy's pairwise f32 sum of a block of n <= 128 floats, by the lanes s = 0..7 of a feature's lane group (pairwise_block_wave
+// with the group lane); the result is valid in the group's lane s == 0
+__device__ __forceinline__ float pairwise_block_group(const float *a, int n, int s)
 {
     if (n < 8) {
         float res = 0.f;
@@ -318,11 +333,21 @@ __device__ __forceinline__ float pairwise_block_group(const float *a, int n, int
     return res;
 }
 
-// Four 7x7 features per wavefront with QUAD loads (KLT_OPT_TRACK_VARIANT = 4).  The 8x8 footprint of a feature is 16 quads of four
-// pixels; lane (row r = s / 2, half h = s % 2) of the feature's 16 lanes loads quad (r, 4h .. 4h + 3) of each image with one
-// 16-byte load -- 3 vector loads per footprint for four features, where track_kernel_q issues 24 and track_kernel 6 per feature --
-// and computes the window samples (r, 4h .. 4h + 3) from its own quad, the quad below (lane s + 2) and the first pixels of the two
-// quads to the right (lanes s + 1, s + 3).  Instruction count of track_kernel_q, a sixth of its L1 accesses.
+// ... of any n: numpy halves blocks of more than 128 elements (n2 = n / 2 rounded down to a multiple of 8)
+template <int DEPTH>
+__device__ __forceinline__ float pairwise_group(const float *a, int n, int s)
+{
+    if (n <= 128) return pairwise_block_group(a, n, s);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_group<DEPTH - 1>(a, n2, s) + pairwise_group<DEPTH - 1>(a + n2, n - n2, s);
+}
+template <>
+__device__ __forceinline__ float pairwise_group<0>(const float *a, int n, int s)
+{
+    return pairwise_block_group(a, n < 128 ? n : 128, s);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 load_quad(const float *p)      // 4-byte aligned 16-byte load
@@ -332,12 +357,13 @@ __device__ __forceinline__ f32x4 load_quad(const float *p)      // 4-byte aligne
 }
 
 // the four window samples of a lane from its quad `a`: pairs (a.x,a.y), (a.y,a.z), (a.z,a.w), (a.w, right neighbour) and the same
-// pairs of the row below
+// pairs of the row below (QPR = quads per footprint row: the lane holding the quad below is QPR lanes up)
+template <int QPR>
 __device__ __forceinline__ void sample_quad(const f32x4 a, const Bilinear &b, float out[4])
 {
     f32x4 lo;
-    lo.x = __shfl_down(a.x, 2); lo.y = __shfl_down(a.y, 2); lo.z = __shfl_down(a.z, 2); lo.w = __shfl_down(a.w, 2);
-    const float rx = __shfl_down(a.x, 1), dx = __shfl_down(a.x, 3);
+    lo.x = __shfl_down(a.x, QPR); lo.y = __shfl_down(a.y, QPR); lo.z = __shfl_down(a.z, QPR); lo.w = __shfl_down(a.w, QPR);
+    const float rx = __shfl_down(a.x, 1), dx = __shfl_down(a.x, QPR + 1);
     const float v00[4] = {a.x, a.y, a.z, a.w}, v01[4] = {a.y, a.z, a.w, rx};
     const float v10[4] = {lo.x, lo.y, lo.z, lo.w}, v11[4] = {lo.y, lo.z, lo.w, dx};
 #pragma unroll
@@ -351,19 +377,25 @@ __device__ __forceinline__ void sample_quad(const f32x4 a, const Bilinear &b, fl
     }
 }
 
-template <bool BATCH>
-__global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
+template <bool BATCH, int W>
+__global__ __launch_bounds__(64) void track_kernel_quad(TrackArgs a)
 {
+    static_assert(W == 7 || W == 15, "quad kernels exist for 7x7 and 15x15 windows");
+    constexpr int FPW = W == 7 ? 4 : 1;                      // features per wavefront
+    constexpr int LPF = 64 / FPW;                            // lanes per feature = quads of its footprint
+    constexpr int QPR = (W + 1) / 4;                         // quads per footprint row
+    constexpr int w = W, n = W * W, hw = W / 2, npad = (n + 3) & ~3;
+    static_assert((W + 1) * QPR == LPF, "one quad per lane");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x, g = lane >> 4, s = lane & 15, glead = lane & 48;
-    int f = 4 * blockIdx.x + g;
+    const int lane = threadIdx.x, g = lane / LPF, s = lane % LPF, glead = lane - s;
+    int f = FPW * blockIdx.x + g;
     if (a.order) {
         // XCD-aware order (KLT_OPT_TRACK_XCD_ORDER): workgroups go to the XCDs round-robin in linear order and gridDim.x is a
-        // multiple of 8, so workgroup (x, y) runs on XCD x % 8; it takes four consecutive features of that XCD's band of the
+        // multiple of 8, so workgroup (x, y) runs on XCD x % 8; it takes FPW consecutive features of that XCD's band of the
         // row-sorted list of its pair (batched launches: pair blockIdx.y, permutation blockIdx.y of the table)
         const uint32_t *ord = a.order + (BATCH ? (size_t)blockIdx.y * a.n : (size_t)0);
-        const int c = blockIdx.x & 7, pos = c * a.order_chunk + 4 * (blockIdx.x >> 3) + g;
-        f = (4 * (blockIdx.x >> 3) + g < a.order_chunk && pos < a.n) ? (int)ord[pos] : a.n;
+        const int c = blockIdx.x & 7, j = FPW * (blockIdx.x >> 3) + g, pos = c * a.order_chunk + j;
+        f = (j < a.order_chunk && pos < a.n) ? (int)ord[pos] : a.n;
     }
     const TrackLevel *levels = BATCH ? a.pairs[blockIdx.y].lv : a.lv;
     const klt_feat *fin = BATCH ? a.pairs[blockIdx.y].in : a.in;
@@ -374,10 +406,8 @@ __global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
     if (valid && ft.val < 0 && s == 0) fout[f] = ft;
     if (!__any(tracked_feature)) return;
     const int L = a.nlevels;
-    constexpr int WCT = 7, w = 7, n = 49, hw = 3;
-    constexpr int npad = (n + 3) & ~3;
     float *const gl = lds + g * 5 * npad;                    // this feature's five product arrays
-    const int qr = s >> 1, qh = s & 1;                       // my quad: footprint row qr, columns 4 qh .. 4 qh + 3
+    const int qr = s / QPR, qh = s % QPR;                    // my quad: footprint row qr, columns 4 qh .. 4 qh + 3
     const int k0 = qr * w + 4 * qh;                          // window index of my first sample (qr, 4 qh)
     const float one_plus_eps = 1.001f;
 
@@ -399,29 +429,37 @@ __global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
         const Bilinear b1 = make_bilinear(xloc, yloc);
         const bool t_ok = b1.ix - hw >= 0 && b1.iy - hw >= 0 && b1.ix + hw + 2 <= nc && b1.iy + hw + 2 <= nr;
         const bool run = alive && t_ok;
-        float t_i[4], t_gx[4], t_gy[4];
-        {
-            const size_t q = run ? (size_t)(b1.iy - hw + qr) * nc + (b1.ix - hw + 4 * qh) : (size_t)0;
-            sample_quad(load_quad(lv.i1 + q), b1, t_i);
-            sample_quad(load_quad(lv.gx1 + q), b1, t_gx);
-            sample_quad(load_quad(lv.gy1 + q), b1, t_gy);
-        }
+        const size_t q1 = run ? (size_t)(b1.iy - hw + qr) * nc + (b1.ix - hw + 4 * qh) : (size_t)0;
+        const f32x4 t_qi = load_quad(lv.i1 + q1), t_qgx = load_quad(lv.gx1 + q1), t_qgy = load_quad(lv.gy1 + q1);
 
+        // the first Newton iteration starts from a position that is already known: its bounds test (trackFeaturesUtils.pyx:428-431)
+        // and its footprint loads go out now, behind the template's
         int it = 0, status = KLT_OOB;
         float x2 = xout, y2 = yout;
         bool iterating = run;
-        while (__any(iterating)) {
-            // trackFeaturesUtils.pyx:428-431
+        Bilinear b2;
+        f32x4 s_qi, s_qgx, s_qgy;
+        auto request_footprint = [&]() {
             const bool oob = (double)(x2 - (float)hw) < 0. || (float)nc - (x2 + (float)hw) < one_plus_eps ||
                              (double)(y2 - (float)hw) < 0. || (float)nr - (y2 + (float)hw) < one_plus_eps;
             if (iterating && oob) { status = KLT_OOB; iterating = false; }
+            b2 = make_bilinear(x2, y2);
+            const size_t q = iterating ? (size_t)(b2.iy - hw + qr) * nc + (b2.ix - hw + 4 * qh) : (size_t)0;
+            s_qi = load_quad(lv.i2 + q); s_qgx = load_quad(lv.gx2 + q); s_qgy = load_quad(lv.gy2 + q);
+        };
+        request_footprint();
+
+        float t_i[4], t_gx[4], t_gy[4];
+        sample_quad<QPR>(t_qi, b1, t_i);
+        sample_quad<QPR>(t_qgx, b1, t_gx);
+        sample_quad<QPR>(t_qgy, b1, t_gy);
+
+        while (__any(iterating)) {
             const bool act = iterating;
-            const Bilinear b2 = make_bilinear(x2, y2);
-            const size_t q = act ? (size_t)(b2.iy - hw + qr) * nc + (b2.ix - hw + 4 * qh) : (size_t)0;
             float s_i[4], s_gx[4], s_gy[4];
-            sample_quad(load_quad(lv.i2 + q), b2, s_i);
-            sample_quad(load_quad(lv.gx2 + q), b2, s_gx);
-            sample_quad(load_quad(lv.gy2 + q), b2, s_gy);
+            sample_quad<QPR>(s_qi, b2, s_i);
+            sample_quad<QPR>(s_qgx, b2, s_gx);
+            sample_quad<QPR>(s_qgy, b2, s_gy);
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 if (qr < w && 4 * qh + m < w) {
@@ -439,19 +477,14 @@ __global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
             wave_lds_sync();
             float acc = 0.f;
             if (s < 5) {
-                const float *T = gl + s * npad;
-                if (WCT > 0) {
-                    const float4 *T4 = reinterpret_cast<const float4 *>(T);
-#pragma unroll
-                    for (int q = 0; q < (WCT * WCT + 3) / 4; q++) {
-                        const float4 v = T4[q];
-                        acc = acc + v.x;
-                        if (4 * q + 1 < WCT * WCT) acc = acc + v.y;
-                        if (4 * q + 2 < WCT * WCT) acc = acc + v.z;
-                        if (4 * q + 3 < WCT * WCT) acc = acc + v.w;
-                    }
-                } else {
-                    for (int k = 0; k < n; k++) acc = acc + T[k];
+                const float4 *T4 = reinterpret_cast<const float4 *>(gl + s * npad);
+#pragma unroll W <= 8 ? 16 : 4
+                for (int q = 0; q < (n + 3) / 4; q++) {
+                    const float4 v = T4[q];
+                    acc = acc + v.x;
+                    if (4 * q + 1 < n) acc = acc + v.y;
+                    if (4 * q + 2 < n) acc = acc + v.z;
+                    if (4 * q + 3 < n) acc = acc + v.w;
                 }
             }
             wave_lds_sync();
@@ -471,6 +504,7 @@ __global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
                 it++;
                 iterating = (fabsf(dx) >= a.th || fabsf(dy) >= a.th) && it < a.max_iterations;
             }
+            if (__any(iterating)) request_footprint();
         }
         if (run) { xout = x2; yout = y2; }
 
@@ -482,15 +516,15 @@ __global__ __launch_bounds__(64) void track_kernel_qv(TrackArgs a)
         // residue, trackFeatures.py:118-125
         const bool need_res = run && status == KLT_TRACKED && a.use_max_residue;
         if (__any(need_res)) {
-            const Bilinear b2 = make_bilinear(x2, y2);
-            const size_t q = need_res ? (size_t)(b2.iy - hw + qr) * nc + (b2.ix - hw + 4 * qh) : (size_t)0;
+            const Bilinear br = make_bilinear(x2, y2);
+            const size_t q = need_res ? (size_t)(br.iy - hw + qr) * nc + (br.ix - hw + 4 * qh) : (size_t)0;
             float s_i[4];
-            sample_quad(load_quad(lv.i2 + q), b2, s_i);
+            sample_quad<QPR>(load_quad(lv.i2 + q), br, s_i);
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 if (qr < w && 4 * qh + m < w) gl[k0 + m] = fabsf(t_i[m] - s_i[m]);
             wave_lds_sync();
-            float sres = pairwise_block_group(gl, n, s);
+            float sres = pairwise_group<3>(gl, n, s);
             wave_lds_sync();
             sres = __shfl(sres, glead);
             if (need_res && sres / (float)n > a.max_residue) status = KLT_LARGE_RESIDUE;
@@ -598,9 +632,9 @@ void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, 
     hipLaunchKernelGGL(track_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, nlevels, stats);
 }
 
-// Tracker kernels: track_kernel_qv (7x7 windows, lists of 2048 features and more: four features per wavefront, one 16-byte
-// load per lane, image and footprint), track_kernel (one feature per wavefront: every other window, short lists -- with a few
-// hundred features the launch is pure latency, which four features in lock step lengthen).  Both give bit-identical records.
+// Tracker kernels: track_kernel_quad (7x7 windows with lists of 2048 features and more: four features per wavefront; 15x15
+// windows: one feature per wavefront; one 16-byte load per lane, image and footprint), track_kernel (one feature per wavefront,
+// one sample per lane and round: every other window, short 7x7 lists).  All give bit-identical records.
 // KLT_OPT_TRACK_VARIANT = 0 (or KLT_TRACK_VARIANT=0 in the environment) forces track_kernel: the plain fallback the parity
 // tests compare the quad kernel with.  The measured-slower generations in between (prefetching, per-sample loads with four
 // features per wavefront, one pixel per lane) are recorded in profiles/README.md and live in the git history.
@@ -617,9 +651,16 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     // the permutation is (re)computed here whenever the caller asks for it, whichever kernel consumes it
     if (a.order && a.order_refresh)
         hipLaunchKernelGGL(track_order_kernel, dim3(ny), dim3(ORDER_T), 0, s, a.in, BATCH ? a.pairs : nullptr, a.n, a.order);
+    // (short 7x7 lists keep one feature per wavefront: with a few hundred features the launch is pure latency, which four
+    // features in lock step lengthen)
     if (g_track_variant != 0 && a.window == 7 && (long long)a.n * ny >= 2048) {
         const dim3 gq(a.order ? 8 * ((a.order_chunk + 3) / 4) : (a.n + 3) / 4, ny);
-        hipLaunchKernelGGL((track_kernel_qv<BATCH>), gq, block, 4 * lds, s, a);
+        hipLaunchKernelGGL((track_kernel_quad<BATCH, 7>), gq, block, 4 * lds, s, a);
+        return 0;
+    }
+    if (g_track_variant != 0 && a.window == 15) {
+        const dim3 gq(a.order ? 8 * a.order_chunk : a.n, ny);
+        hipLaunchKernelGGL((track_kernel_quad<BATCH, 15>), gq, block, lds, s, a);
         return 0;
     }
     const dim3 grid(a.order ? 8 * a.order_chunk : a.n, ny);

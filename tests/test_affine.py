@@ -122,17 +122,17 @@ def test_gpu_affine_matches_oracle(mode):
     frames = warped_sequence(A_step, (0.9, -0.6), 4)
     tc = tc_affine(mode)
     g, o = run_gpu(frames, tc), run_oracle(frames, tc)
+    # Exact: the affine check's window sums follow one stated order (per-lane partial sums + butterfly, DESIGN.md section 8;
+    # oracle/klt_oracle.c am_fold), so every status code, position and A matrix is bit-identical -- integer work is not
+    # allowed to be "mostly right".
     for k, ((gfl, grec), (ofl, orec)) in enumerate(zip(g, o)):
-        same = gfl["val"] == ofl["val"]
-        assert same.mean() > 0.99, "call %d: status agreement %.3f" % (k, same.mean())
-        both = same & (ofl["val"] == 0)
-        assert np.array_equal(gfl["x"][both], ofl["x"][both]) and np.array_equal(gfl["y"][both], ofl["y"][both])
-        assert np.array_equal(grec["valid"][same], orec["valid"][same])
-        for name in ("aff_x", "aff_y"):
-            assert np.array_equal(grec[name][both], orec[name][both]), name
-        for name in ("Axx", "Ayx", "Axy", "Ayy"):
-            d = np.abs(grec[name][both] - orec[name][both])
-            assert np.percentile(d, 99) < 2e-3, (k, name, d.max())
+        assert np.array_equal(gfl["val"], ofl["val"]), "call %d: %d status codes differ" % (k, int((gfl["val"] != ofl["val"]).sum()))
+        assert np.array_equal(gfl["x"], ofl["x"]) and np.array_equal(gfl["y"], ofl["y"]), "call %d: positions" % k
+        for name in ("valid", "aff_x", "aff_y", "Axx", "Ayx", "Axy", "Ayy"):
+            live = orec["valid"] != 0                    # the A entries of a freed template are don't-cares upstream too; keep them equal anyway
+            assert np.array_equal(grec[name][live], orec[name][live]), (k, name)
+            assert np.array_equal(grec[name], orec[name]), (k, name, "freed templates")
+    assert (g[-1][0]["val"] == 0).sum() > 0.5 * NF
 
 
 @pytest.mark.gpu

@@ -401,7 +401,8 @@ def test_track_retain(ctx, cfg1, img0, img1):
 
 
 @pytest.mark.parametrize("window,levels,ss,retain,mr", [(7, 2, 4, False, 10.0), (7, 2, 4, True, 10.0), (7, 3, 2, False, None),
-                                                        (5, 2, 4, False, 10.0), (3, 2, 2, False, 5.0)])
+                                                        (5, 2, 4, False, 10.0), (3, 2, 2, False, 5.0), (15, 2, 2, False, 12.0),
+                                                        (15, 3, 2, True, None), (15, 2, 2, False, None)])
 def test_track_default_vs_plain_kernel(ctx, ko, cfg1, img0, img1, window, levels, ss, retain, mr):
     """KLT_OPT_TRACK_VARIANT=4 (the default kernel selection) gives the same records as the plain one-feature-per-wavefront
     kernel (=0) and the oracle, and for the default context as the reference's goldens."""
