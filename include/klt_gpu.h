@@ -125,6 +125,9 @@ int klt_build_pyramids(klt_ctx *ctx, int slot);
 /* bit 0: the slot holds a frame; bit 1: its pyramids are built and match the current parameters / taps (what
  * `tc.pyramid_last is not None` means in the reference, trackFeatures.py:152); 0 for a slot never used */
 int klt_slot_state(klt_ctx *ctx, int slot);
+/* releases the slot's device memory (raw frames, pyramids); the index can be used again.  The reference frees images and
+ * pyramids when the Python objects die; the host layer calls this from a finalizer of the tracking context. */
+int klt_slot_free(klt_ctx *ctx, int slot);
 /* sequentialMode: the frame-2 pyramids become frame 1 (trackFeatures.py:152-161, :401-404) */
 int klt_swap_slots(klt_ctx *ctx, int a, int b);
 
@@ -170,6 +173,7 @@ typedef struct { float aff_x, aff_y, Axx, Ayx, Axy, Ayy; int32_t valid, pad; } k
 int klt_set_affine_params(klt_ctx *ctx, const klt_affine_params *p);
 int klt_affine_alloc(klt_ctx *ctx, int state, int n);          /* n feature slots, no templates yet */
 int klt_affine_download(klt_ctx *ctx, int state, klt_affine_rec *dst, int n);
+int klt_affine_free(klt_ctx *ctx, int state);                  /* releases records + templates; the id can be allocated again */
 /* klt_track_async followed by the consistency check of the features it tracked; fb_in != fb_out.  `state` travels
  * with the feature list (same index = same feature). */
 int klt_track_affine_async(klt_ctx *ctx, int slot1, int slot2, int fb_in, int fb_out, int n, int state);

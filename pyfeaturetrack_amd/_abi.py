@@ -74,6 +74,7 @@ SYMBOLS = {
     "klt_set_option": (_I, [_P, _I, _I]),
     "klt_build_pyramids": (_I, [_P, _I]),
     "klt_slot_state": (_I, [_P, _I]),
+    "klt_slot_free": (_I, [_P, _I]),
     "klt_swap_slots": (_I, [_P, _I, _I]),
     "klt_featbuf_upload": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_download": (_I, [_P, _I, _P, _I]),
@@ -88,6 +89,7 @@ SYMBOLS = {
     "klt_set_affine_params": (_I, [_P, C.POINTER(KltAffineParams)]),
     "klt_affine_alloc": (_I, [_P, _I, _I]),
     "klt_affine_download": (_I, [_P, _I, _P, _I]),
+    "klt_affine_free": (_I, [_P, _I]),
     "klt_track_affine_async": (_I, [_P, _I, _I, _I, _I, _I, _I]),
     "klt_track_affine": (_I, [_P, _I, _I, _P, _I, _I, _PI]),
     "klt_track_stats_reset": (_I, [_P]),

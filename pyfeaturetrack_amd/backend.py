@@ -93,6 +93,47 @@ class Context:
     def affine_alloc(self, state, n):
         self._check(self._lib.klt_affine_alloc(self._h, state, n))
 
+    def affine_free(self, state):
+        if getattr(self, "_h", None):
+            self._check(self._lib.klt_affine_free(self._h, state))
+
+    def slot_free(self, slot):
+        if getattr(self, "_h", None):
+            self._check(self._lib.klt_slot_free(self._h, slot))
+
+    # ids handed to the reference-shaped API objects (tracking contexts: 3 slots; feature lists: affine state) are recycled
+    # when those objects die (weakref finalizers in selectGoodFeatures.py / trackFeatures.py)
+    def take_slots(self, count=3):
+        free = self.__dict__.setdefault("_free_slot_bases", [])
+        if free:
+            return free.pop()
+        base = getattr(self, "_next_slot", 0)
+        self._next_slot = base + count
+        return base
+
+    def release_slots(self, base, count=3):
+        try:
+            for k in range(count):
+                self.slot_free(base + k)
+        except KltBackendError:
+            return
+        self.__dict__.setdefault("_free_slot_bases", []).append(base)
+
+    def take_affine_state(self):
+        free = self.__dict__.setdefault("_free_affine_states", [])
+        if free:
+            return free.pop()
+        sid = getattr(self, "_next_affine_state", 0)
+        self._next_affine_state = sid + 1
+        return sid
+
+    def release_affine_state(self, sid):
+        try:
+            self.affine_free(sid)
+        except KltBackendError:
+            return
+        self.__dict__.setdefault("_free_affine_states", []).append(sid)
+
     def affine_download(self, state, n):
         out = np.empty(n, AFFINE_DTYPE)
         self._check(self._lib.klt_affine_download(self._h, state, out.ctypes.data, n))

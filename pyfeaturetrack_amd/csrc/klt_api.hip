@@ -34,6 +34,7 @@ struct Slot {
     bool pyr_valid = false;
     hipEvent_t ev_upload = nullptr;   // asynchronous ingest: frame copy finished (the build waits for it)
     hipEvent_t ev_consumed = nullptr; // last kernel on `stream` that read the raw frame u8
+    uint64_t upload_serial = 0, consumed_serial = 0, consumed_alt_serial = 0;   // when the ring handed those events out (event_live)
     bool upload_pending = false, consumed_valid = false;
     // asynchronous ingest alternates between two raw buffers so that a copy never has to wait (on the device) for
     // kernels still reading the previous frame: making the copy stream wait on a compute-stream event blocks the
@@ -65,6 +66,7 @@ struct klt_ctx {
     // 400-800 us per step).  256 events ~ 25 steps of history.
     std::vector<hipEvent_t> ring;
     size_t ring_next = 0;
+    uint64_t ring_serial = 0;         // events handed out so far
     std::string err;
     klt_params p{};
     bool have_params = false;
@@ -259,10 +261,15 @@ int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
 }
 
 // ordering events for the asynchronous ingest come from a ring (see klt_ctx::ring)
-int fresh_event(klt_ctx *c, hipEvent_t *out)
+constexpr size_t kEventRing = 256;
+
+// `serial` (optional) receives the running number of the hand-out: an event pointer kept by a slot is only meaningful while
+// fewer than kEventRing events have been handed out since (event_live); after that the ring has re-recorded it elsewhere.
+int fresh_event(klt_ctx *c, hipEvent_t *out, uint64_t *serial = nullptr)
 {
-    constexpr size_t kRing = 256;
-    if (c->ring.size() < kRing) {
+    if (serial) *serial = c->ring_serial;
+    c->ring_serial++;
+    if (c->ring.size() < kEventRing) {
         hipEvent_t e = nullptr;
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->ring.push_back(e);
@@ -270,7 +277,32 @@ int fresh_event(klt_ctx *c, hipEvent_t *out)
         return 0;
     }
     *out = c->ring[c->ring_next];
-    c->ring_next = (c->ring_next + 1) % kRing;
+    c->ring_next = (c->ring_next + 1) % kEventRing;
+    return 0;
+}
+
+bool event_live(const klt_ctx *c, uint64_t serial) { return c->ring_serial - serial < kEventRing; }
+
+// The frame copied by klt_upload_u8_async has landed before anything enqueued on `stream` after this call reads it.  A slot
+// left alone for more than a ring's worth of events no longer owns its event: the host waits for the copy stream instead.
+int wait_upload(klt_ctx *c, Slot *s)
+{
+    if (!s->upload_pending) return 0;
+    if (event_live(c, s->upload_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_upload, 0));
+    else HIPCHK(c, hipStreamSynchronize(c->cstream));
+    s->upload_pending = false;
+    return 0;
+}
+
+// everything enqueued on `stream` so far has read the raw frames of these slots: the next asynchronous copy into them waits for it
+int mark_consumed(klt_ctx *c, Slot *const *slots, int n)
+{
+    if (!c->cstream) return 0;
+    hipEvent_t e;
+    uint64_t serial;
+    if (int rc = fresh_event(c, &e, &serial)) return rc;
+    HIPCHK(c, hipEventRecord(e, c->stream));
+    for (int i = 0; i < n; i++) { slots[i]->ev_consumed = e; slots[i]->consumed_serial = serial; slots[i]->consumed_valid = true; }
     return 0;
 }
 
@@ -470,10 +502,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         for (int j = 0; j < i; j++)
             if (sl[j] == sl[i]) return fail(c, KLT_ERR_ARG, "slot listed twice");
         if (int rc = layout_pyramid(c, sl[i])) return rc;
-        if (sl[i]->upload_pending) {                        // asynchronous ingest: the frame must have landed
-            HIPCHK(c, hipStreamWaitEvent(c->stream, sl[i]->ev_upload, 0));
-            sl[i]->upload_pending = false;
-        }
+        if (int rc = wait_upload(c, sl[i])) return rc;      // asynchronous ingest: the frame must have landed
     }
     const int ss = c->p.subsampling;
     // groups of frames with the same geometry and input type share launches
@@ -606,12 +635,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         for (Slot *s : g) s->pyr_valid = true;
     }
     // the next asynchronous copy into these slots waits for this build
-    if (c->cstream) {
-        hipEvent_t e;
-        if (int rc = fresh_event(c, &e)) return rc;
-        HIPCHK(c, hipEventRecord(e, c->stream));
-        for (Slot *s : sl) { s->ev_consumed = e; s->consumed_valid = true; }
-    }
+    if (int rc = mark_consumed(c, sl.data(), n)) return rc;
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -790,17 +814,22 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
     std::swap(s->u8, s->u8_alt);
     std::swap(s->u8_cap, s->u8_alt_cap);
     std::swap(s->ev_consumed, s->ev_consumed_alt);
+    std::swap(s->consumed_serial, s->consumed_alt_serial);
     std::swap(s->consumed_valid, s->consumed_alt_valid);
     if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc;
     if (s->consumed_valid) {
-        const hipError_t q = hipEventQuery(s->ev_consumed);
-        if (q == hipErrorNotReady) HIPCHK(c, hipEventSynchronize(s->ev_consumed));
-        else if (q != hipSuccess) return fail(c, KLT_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        if (!event_live(c, s->consumed_serial)) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));       // the event has been re-used since: wait for the reading stream itself
+        } else {
+            const hipError_t q = hipEventQuery(s->ev_consumed);
+            if (q == hipErrorNotReady) HIPCHK(c, hipEventSynchronize(s->ev_consumed));
+            else if (q != hipSuccess) return fail(c, KLT_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        }
         s->consumed_valid = false;
     }
     if (pitch == ncols) HIPCHK(c, hipMemcpyAsync(s->u8, px, px_count, hipMemcpyHostToDevice, c->cstream));
     else HIPCHK(c, hipMemcpy2DAsync(s->u8, (size_t)ncols, px, (size_t)pitch, (size_t)ncols, nrows, hipMemcpyHostToDevice, c->cstream));
-    if (int rc = fresh_event(c, &s->ev_upload)) return rc;
+    if (int rc = fresh_event(c, &s->ev_upload, &s->upload_serial)) return rc;
     HIPCHK(c, hipEventRecord(s->ev_upload, c->cstream));
     s->upload_pending = true;
     s->nc = ncols;
@@ -853,6 +882,18 @@ int klt_slot_state(klt_ctx *c, int slot)
     if (slot < 0 || (size_t)slot >= c->slots.size()) return 0;
     const Slot &s = c->slots[slot];
     return (s.raw_kind != 0 ? 1 : 0) | (s.pyr_valid ? 2 : 0);
+}
+
+int klt_slot_free(klt_ctx *c, int slot)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (slot < 0 || (size_t)slot >= c->slots.size()) return KLT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = sync_all(c)) return rc;
+    Slot &s = c->slots[slot];
+    hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes);
+    s = Slot();
+    return KLT_OK;
 }
 
 int klt_swap_slots(klt_ctx *c, int a, int b)
@@ -972,7 +1013,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
         img = s->lv[0].img; gx = s->lv[0].gx; gy = s->lv[0].gy;
     } else {
         if (s->raw_kind == 0) return fail(c, KLT_ERR_STATE, "slot has no frame");
-        if (s->upload_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_upload, 0)); s->upload_pending = false; }
+        if (int rc = wait_upload(c, s)) return rc;
         bool grads_done = false;
         if (p.smoothBeforeSelecting && fused_smooth_ok(c)) {
             const void *raw = s->raw_kind == 1 ? (const void *)s->u8 : (const void *)s->f32;
@@ -997,6 +1038,8 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
             else enqueue_gradients(c, img, nc, nr, c->sel_gx, c->sel_gy);
         }
         gx = c->sel_gx; gy = c->sel_gy;
+        // the kernels above read the raw frame: the second-next asynchronous copy into this slot (its raw buffers alternate) waits
+        if (int rc = mark_consumed(c, &s, 1)) return rc;
     }
     c->last_sel[0] = img; c->last_sel[1] = gx; c->last_sel[2] = gy;
     c->sel_nc = nc; c->sel_nr = nr; c->sel_nx = nx; c->sel_ny = ny; c->sel_npow2 = (int)npow2;
@@ -1422,6 +1465,19 @@ int klt_affine_alloc(klt_ctx *c, int state, int n)
     }
     launch_affine_reset(c->stream, a.rec, a.n);
     HIPCHK(c, hipGetLastError());
+    return KLT_OK;
+}
+
+int klt_affine_free(klt_ctx *c, int state)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (state < 0 || (size_t)state >= c->aff.size() || !c->aff[state].rec) return KLT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = sync_all(c)) return rc;
+    AffState &a = c->aff[state];
+    hipFree(a.rec); hipFree(a.tpl);
+    a = AffState();
+    if (c->select_aff_state == state) c->select_aff_state = -1;
     return KLT_OK;
 }
 

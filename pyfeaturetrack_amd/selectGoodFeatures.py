@@ -51,10 +51,11 @@ def _slots_of(tc):
     """Two device slots per tracking context: [frame 1, frame 2]; a third for selection frames."""
     s = getattr(tc, "_klt_slots", None)
     if s is None:
+        import weakref
         ctx = default_context()
-        base = getattr(ctx, "_next_slot", 0)
-        ctx._next_slot = base + 3
+        base = ctx.take_slots(3)
         s = tc._klt_slots = (base, base + 1, base + 2)
+        weakref.finalize(tc, ctx.release_slots, base, 3)      # the device memory goes when the tracking context does
     return s
 
 
@@ -92,7 +93,8 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
         slot = slots[2]
         ctx.upload(slot, image_to_array(img))
     fl_in = features_to_array(featurelist) if mode == selectionMode.REPLACING_SOME else None
-    aff = getattr(tc, "_klt_affine_states", {}).get(id(featurelist))
+    from .trackFeatures import affine_state_lookup
+    aff = affine_state_lookup(ctx, featurelist)
     if aff is not None and aff[1] == len(featurelist):
         ctx.set_option(4, aff[0])       # newly placed features lose their affine templates (:120-128)
     try:

@@ -26,18 +26,49 @@ class _ResidentPyramids:
 _DEVICE_TEMPLATE = "<template on device>"      # what feat.aff_img* hold while the device keeps the templates
 
 
+class _ListRef:
+    """Weak handle on a feature list (plain lists cannot be weakly referenced): the list's first feature object stands in for it.
+    The reference keeps the affine state in the KLT_Feature objects themselves, so the state dies with them."""
+    def __init__(self, featurelist):
+        import weakref
+        self.ident = id(featurelist)
+        self.first = weakref.ref(featurelist[0]) if len(featurelist) else None
+
+    def matches(self, featurelist):
+        return (self.first is not None and len(featurelist) > 0 and self.first() is featurelist[0]
+                and self.ident == id(featurelist))
+
+
+def affine_state_lookup(ctx, featurelist):
+    """(state id, length) of the device affine state that travels with this feature list, or None."""
+    entry = ctx.__dict__.setdefault("_affine_states", {}).get(id(featurelist))
+    if entry is None or not entry[0].matches(featurelist):
+        return None
+    return entry[1], entry[2]
+
+
 def _affine_state_of(tc, ctx, featurelist):
-    """Device affine-state id of a feature list (allocated on first use; the list object is the key, as the
-    reference keeps the state in the KLT_Feature objects of the list)."""
-    table = tc.__dict__.setdefault("_klt_affine_states", {})
+    """Device affine-state id of a feature list (allocated on first use).  The table is keyed by the list's id but every entry
+    carries a weak reference to the list's first feature: an id that CPython re-uses for another list never inherits stale
+    templates, and the device state is released when the features die."""
+    import weakref
+    table = ctx.__dict__.setdefault("_affine_states", {})
     key = id(featurelist)
     entry = table.get(key)
-    if entry is None or entry[1] != len(featurelist):
-        sid = getattr(ctx, "_next_affine_state", 0)
-        ctx._next_affine_state = sid + 1
+    if entry is not None and (not entry[0].matches(featurelist) or entry[2] != len(featurelist)):
+        ctx.release_affine_state(entry[1])
+        entry = None
+    if entry is None:
+        sid = ctx.take_affine_state()
         ctx.affine_alloc(sid, len(featurelist))
-        entry = table[key] = (sid, len(featurelist))
-    return entry[0]
+        entry = table[key] = (_ListRef(featurelist), sid, len(featurelist))
+        if len(featurelist):
+            def _drop(table=table, key=key, sid=sid, ctx=ctx):
+                if key in table and table[key][1] == sid:
+                    del table[key]
+                    ctx.release_affine_state(sid)
+            weakref.finalize(featurelist[0], _drop)
+    return entry[1]
 
 
 def _outOfBounds(x, y, ncols, nrows, borderx, bordery):

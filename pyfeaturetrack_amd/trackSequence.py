@@ -73,8 +73,7 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
     ctx.select_async(s[0], SELECTING_ALL, bool(tc.smoothBeforeSelecting), row_fb(0), nFeatures)
     state = None
     if affine:
-        state = getattr(ctx, "_next_affine_state", 0)
-        ctx._next_affine_state = state + 1
+        state = ctx.take_affine_state()
         ctx.affine_alloc(state, nFeatures)
     k = 0
     try:
@@ -93,6 +92,7 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
     finally:
         if affine:
             ctx.set_option(_OPT_SELECT_AFFINE_STATE, -1)
+            ctx.release_affine_state(state)
     nframes = k + 1
     ft = KLT_FeatureTable(nframes, nFeatures)
     for ci, base in enumerate(tables):

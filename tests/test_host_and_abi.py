@@ -173,3 +173,54 @@ def test_features_to_array_columns():
     assert a["val"].tolist() == [-1, 1234567, 0] and a["aux"].tolist() == [0, 0, 0]
     assert a["x"].tolist() == [-1.0, 3.0, float(np.float32(0.1))] and a["y"][2] == np.float32(1e-3)
     assert features_to_array([]).shape == (0,)
+
+
+def test_no_fma_contraction_in_the_device_code(tmp_path):
+    """The parity spec forbids fused multiply-adds (scipy / Cython / numpy round every product and every sum):
+    disassemble the gfx950 code objects of libkltgpu.so and check where FMA instructions occur.  The convolution, pyramid and
+    summed-area kernels must contain none; the only ones allowed are the compiler's own expansions of IEEE f32 division (tracker /
+    affine solve, residue mean) and of the f64 square root (eigenvalue), which are correctly rounded as a whole."""
+    import collections
+    import shutil
+    import subprocess
+    from pyfeaturetrack_amd import _abi
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    if not os.path.exists(_abi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = tmp_path / "libkltgpu.so"
+    shutil.copy(_abi.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", lib.name], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = sorted(p for p in tmp_path.iterdir() if p.name.endswith("gfx950"))
+    assert objs, "no gfx950 code object found in libkltgpu.so"
+    fma = re.compile(r"\b(v_(?:pk_)?fm(?:a|ac|amk|aak)_(?:f16|f32|f64|legacy_f32)|v_mad_(?:f32|f16|legacy_f32)|v_mac_f32|v_fma_mix\w*|v_dot\w*|v_mfma\w*)\b")
+    per_kernel = collections.defaultdict(collections.Counter)
+    nkernels = 0
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", str(o)], check=True, capture_output=True, text=True).stdout
+        cur = None
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            if m:
+                cur = m.group(1)
+                nkernels += 1
+                continue
+            m = fma.search(line)
+            if m and cur:
+                per_kernel[cur][m.group(1)] += 1
+    assert nkernels > 40
+    for name, ops in per_kernel.items():
+        if "eigen" in name:
+            assert set(ops) == {"v_fma_f64"} and ops["v_fma_f64"] <= 4, (name, dict(ops))          # sqrt(double)
+        elif "track_kernel" in name:
+            assert set(ops) == {"v_fma_f32"} and ops["v_fma_f32"] <= 9, (name, dict(ops))          # dx, dy, residue mean: three divisions
+        elif "affine_kernel" in name:
+            assert set(ops) == {"v_fma_f32"} and ops["v_fma_f32"] <= 16, (name, dict(ops))         # 2x2 solve, 1 / pivot, residue mean
+        elif "mis_round" in name:
+            assert set(ops) <= {"v_fmamk_f32"}, (name, dict(ops))                                  # integer division helper, no image data
+        else:
+            raise AssertionError("FMA in %s: %r" % (name, dict(ops)))
+    # the kernels that carry the reference's FP64 convolution arithmetic are FMA-free
+    assert not [k for k in per_kernel if re.search(r"smooth_grad|pyr_|hconv|vconv|sat_", k)]

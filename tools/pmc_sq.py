@@ -15,7 +15,7 @@ import json
 import os
 import sys
 
-from pmc_traffic import family_of
+from pmc_traffic import family_of, provenance
 
 
 def main():
@@ -33,7 +33,8 @@ def main():
                     fam_of[r["Dispatch_Id"]] = fam
             for (disp, counter), v in per_dispatch.items():
                 acc[fam_of[disp]][counter].append(v)
-    out = {"_unit": "counter value per launch, summed over the device (largest launch of the family)"}
+    out = {"_unit": "counter value per launch, summed over the device (largest launch of the family)",
+           "_meta": provenance("SQ counter passes of bench.py --inflight 1")}
     for fam in sorted(acc):
         out[fam] = {c: max(v) for c, v in sorted(acc[fam].items())}
         out[fam]["_launches"] = max(len(v) for v in acc[fam].values())

@@ -21,8 +21,7 @@ import os
 import sys
 
 FAMILY = [("smooth_grad_rb<unsigned char, true", "smooth_grad_l0"), ("smooth_grad_rb<float, true", "smooth_grad_l0"),
-          ("smooth_grad_rb<float, false", "gradients"), ("smooth_grad_fast<unsigned char, true", "smooth_grad_l0"), ("smooth_grad_fast<float, true", "smooth_grad_l0"),
-          ("smooth_grad_fast<float, false", "gradients"), ("smooth_grad_kernel", "smooth_grad_l0"),
+          ("smooth_grad_rb<float, false", "gradients"), ("smooth_grad_kernel", "smooth_grad_l0"),
           ("pyr_reduce", "pyramid_reduce"), ("pyr_vreduce", "pyramid_reduce"), ("track_kernel", "track"), ("sat_rows", "sat_rows"), ("sat_cols", "sat_cols"),
           ("eigen_kernel", "eigen_keys"), ("eigen_hist_kernel", "eigen_keys"), ("nms_kernel", "nms"), ("mis_init", "min_distance_init"),
           ("mis_round", "min_distance_pass"), ("mis_compact", "min_distance_compact"), ("mis_rank", "min_distance_rank"),
@@ -47,10 +46,32 @@ def read(dirname, counter):
     return acc
 
 
+KERNEL_SOURCES = ["pyfeaturetrack_amd/csrc/pyramid_kernels.hip", "pyfeaturetrack_amd/csrc/track_kernels.hip",
+                  "pyfeaturetrack_amd/csrc/select_kernels.hip", "pyfeaturetrack_amd/csrc/sat_pipeline.hip"]
+
+
+def provenance(what):
+    """`_meta` record bench.py checks before it quotes a committed counter: where the numbers come from and the hash of the
+    kernel sources they were collected for (a counter of an older kernel is dropped, not quoted)."""
+    import hashlib
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = {}
+    for rel in KERNEL_SOURCES:
+        try:
+            shas[rel] = hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest()[:16]
+        except OSError:
+            pass
+    return {"source": "%s, builder gpurun (rocprofv3 --pmc, kernel-trace only), tag %s, %s" %
+                      (what, os.environ.get("KLT_PROFILE_TAG", "?"), time.strftime("%Y-%m-%d")),
+            "kernel_source_sha16": shas}
+
+
 def main():
     fetch = read(sys.argv[1], "FETCH_SIZE")
     write = read(sys.argv[2], "WRITE_SIZE")
-    out = {"_unit": "bytes per launch (largest launch of the family)", "_formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+    out = {"_unit": "bytes per launch (largest launch of the family)", "_formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024",
+           "_meta": provenance("FETCH_SIZE / WRITE_SIZE passes of bench.py --inflight 1")}
     if "sat_cols" in fetch and "sat_cols" in write:
         out["_calibration"] = {"kernel": "SAT column pass (reads == writes == 3*ncols*nrows*4 bytes)",
                                "WRITE_SIZE_KiB": max(write["sat_cols"]), "FETCH_SIZE_KiB": max(fetch["sat_cols"]),
