@@ -125,7 +125,7 @@ class KLT_Feature:
     created and updated in Python on every selection, so the constructor stays small)."""
 
     __slots__ = ("x", "y", "val", "aff_img", "aff_img_gradx", "aff_img_grady",
-                 "aff_x", "aff_y", "aff_Axx", "aff_Ayx", "aff_Axy", "aff_Ayy")
+                 "aff_x", "aff_y", "aff_Axx", "aff_Ayx", "aff_Axy", "aff_Ayy", "__weakref__")
     _AFF_DEFAULTS = {"aff_img": None, "aff_img_gradx": None, "aff_img_grady": None, "aff_x": -1.0, "aff_y": -1.0,
                      "aff_Axx": 1.0, "aff_Ayx": 0.0, "aff_Axy": 0.0, "aff_Ayy": 1.0}
 
