@@ -9,9 +9,10 @@
 //   * later calls: Newton iterations on [dAxx dAyx dAxy dAyy dx dy] (6x6 normal equations; 4x4 for the
 //     similarity model; 2x2 for translation only) of the template against level 0 of frame 2; the feature
 //     is lost unless this returns KLT_TRACKED; on success the translation result is kept.
-// Window sums: every lane accumulates its own samples, then a 6-step butterfly (wave shuffles) -- there is
-// no reference summation order to reproduce here.  The test oracle restates the same algorithm with
-// sequential sums; tests compare within a tolerance and against synthetic known warps.
+// Window sums: there is no reference summation order to reproduce here, so the order is part of the behaviour
+// specification and the test oracle restates it exactly (oracle/klt_oracle.c am_fold): term k
+// (row-major window index) is added, in increasing k, to the partial sum of lane k mod 64; the 64 partials are folded by
+// the butterfly p[l] + p[l ^ m], m = 32 .. 1.  Statuses, positions and A matrices are bit-identical to the oracle's.
 #include "klt_internal.h"
 
 #pragma clang fp contract(off)
@@ -24,11 +25,13 @@ __device__ __forceinline__ float bilinear_at(const float *__restrict__ img, int 
     const float ax = (float)((double)x - (double)ix), ay = (float)((double)y - (double)iy);
     const double w00 = (1. - (double)ax) * (1. - (double)ay), w01 = (double)ax * (1. - (double)ay), w10 = (1. - (double)ax) * (double)ay;
     const float w11 = ax * ay;
-    const float *q = img + (size_t)iy * nc + ix;
-    const float t4 = w11 * q[nc + 1];
-    double v = w00 * (double)q[0];
-    v = v + w01 * (double)q[1];
-    v = v + w10 * (double)q[nc];
+    // 32-bit element offsets from the (wave-uniform) plane pointer: the loads take the scalar-base + vector-offset form, one VGPR
+    // per address instead of a 64-bit pointer pair (the model-2 kernel has 48 of them in flight and was at 200+ VGPRs)
+    const unsigned o = (unsigned)iy * (unsigned)nc + (unsigned)ix;
+    const float t4 = w11 * img[o + (unsigned)nc + 1u];
+    double v = w00 * (double)img[o];
+    v = v + w01 * (double)img[o + 1u];
+    v = v + w10 * (double)img[o + (unsigned)nc];
     v = v + (double)t4;
     return (float)v;
 }
@@ -38,6 +41,47 @@ __device__ __forceinline__ float wave_sum(float v)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m);
     return v;
+}
+
+// N (a power of two <= 32) sums over the wavefront at once.  Same additions as N calls of wave_sum -- value j goes through
+// p[l] + p[l ^ 32], then ^ 16, ^ 8, ... -- but at every step a lane keeps only the half of the values its bit selects and hands the
+// other half to its partner, so the step costs N/2, N/4, ... shuffles instead of N: 31 + 1 instead of 32 x 6 for N = 32.  On return
+// v[0] of lane l holds the total of value (l >> s) & (N - 1), s = 6 - log2(N) (every total sits on 2^s adjacent lanes).
+template <int N>
+__device__ __forceinline__ void wave_sum_scatter(float (&v)[N], int lane)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    int m = 32, h = N / 2;
+    // m = 32 and m = 16 with gfx950's row swaps: v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of
+    // its second, so first + second is value i summed over (l, l ^ 32) in the lower half of the wavefront and value i + h in the
+    // upper half -- one swap and one add per pair of values, no selects (v_permlane16_swap: the same with rows of 16 lanes)
+    if (h >= 1) {
+#pragma unroll
+        for (int i = 0; i < h; i++) {
+            const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + h]), false, false);
+            v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+        }
+        h >>= 1; m >>= 1;
+    }
+    if (h >= 1) {
+#pragma unroll
+        for (int i = 0; i < h; i++) {
+            const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + h]), false, false);
+            v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+        }
+        h >>= 1; m >>= 1;
+    }
+#pragma unroll
+    for (; h >= 1; h >>= 1, m >>= 1) {
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < h; i++) {
+            const float send = up ? v[i] : v[i + h];
+            const float keep = up ? v[i + h] : v[i];
+            v[i] = keep + __shfl_xor(send, m);
+        }
+    }
+    for (; m >= 1; m >>= 1) v[0] = v[0] + __shfl_xor(v[0], m);
 }
 
 // Numerical Recipes' gaussj with full pivoting, as upstream's _am_gauss_jordan_elimination, spread over the wavefront:
@@ -81,6 +125,9 @@ __device__ __forceinline__ int gauss_jordan_wave(float &val, int n, int lane)
     return KLT_TRACKED;
 }
 
+// MODE = tc.affineConsistencyCheck (0 translation, 1 similarity, 2 affine): one instantiation per model keeps the other
+// models' accumulators out of the register file
+template <int MODE>
 __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
 {
     const int f = blockIdx.x, lane = threadIdx.x;
@@ -124,39 +171,23 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
     const float old_x2 = x2, old_y2 = y2;
     float Axx = st.Axx, Ayx = st.Ayx, Axy = st.Axy, Ayy = st.Ayy;
     const float *t_img = tpl, *t_gx = tpl + tn, *t_gy = tpl + 2 * tn;
-    // The template is sampled at (x1 + i, y1 + j), the same positions in every iteration: each lane keeps the samples of
-    // its (up to four) window pixels in registers.  Windows of more than 256 pixels sample inside the loops.
-    const bool hoist = n <= 256;
-    float ts_i[4] = {0.f, 0.f, 0.f, 0.f}, ts_gx[4] = {0.f, 0.f, 0.f, 0.f}, ts_gy[4] = {0.f, 0.f, 0.f, 0.f};
-    if (hoist) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int k = lane + 64 * q;
-            if (k < n) {
-                const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);
-                ts_i[q] = bilinear_at(t_img, tw, x1 + fi, y1 + fj);
-                if (a.mode == 0) {
-                    ts_gx[q] = bilinear_at(t_gx, tw, x1 + fi, y1 + fj);
-                    ts_gy[q] = bilinear_at(t_gy, tw, x1 + fi, y1 + fj);
-                }
-            }
+    // The template is sampled at (x1 + i, y1 + j), the same positions in every iteration: sampled once into LDS (lane l owns window
+    // pixels l, l + 64, ...).  The window loops below are NOT unrolled: four samples at a time with their 48 bilinear reads and 27
+    // accumulators in flight needed 250+ VGPRs (one wavefront per SIMD); one sample at a time needs under 100 and five wavefronts
+    // per SIMD hide the latency instead.
+    extern __shared__ float tsamp[];                      // [n] image (+ [n] gradx, [n] grady for the translation model)
+    for (int k = lane; k < n; k += 64) {
+        const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);
+        tsamp[k] = bilinear_at(t_img, tw, x1 + fi, y1 + fj);
+        if (MODE == 0) {
+            tsamp[n + k] = bilinear_at(t_gx, tw, x1 + fi, y1 + fj);
+            tsamp[2 * n + k] = bilinear_at(t_gy, tw, x1 + fi, y1 + fj);
         }
     }
-    // body(k, template image, template gradx, template grady) for every window pixel of this lane
+    // body(k, template image, template gradx, template grady) for every window pixel of this lane, in increasing k
     auto for_samples = [&](auto body) {
-        if (hoist) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int k = lane + 64 * q;
-                if (k < n) body(k, ts_i[q], ts_gx[q], ts_gy[q]);
-            }
-        } else {
-            for (int k = lane; k < n; k += 64) {
-                const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);
-                body(k, bilinear_at(t_img, tw, x1 + fi, y1 + fj), a.mode == 0 ? bilinear_at(t_gx, tw, x1 + fi, y1 + fj) : 0.f,
-                     a.mode == 0 ? bilinear_at(t_gy, tw, x1 + fi, y1 + fj) : 0.f);
-            }
-        }
+#pragma unroll 1
+        for (int k = lane; k < n; k += 64) body(k, tsamp[k], MODE == 0 ? tsamp[n + k] : 0.f, MODE == 0 ? tsamp[2 * n + k] : 0.f);
     };
     const float sxs[4] = {-(float)hw, -(float)hw, (float)hw, (float)hw};
     const float sys[4] = {(float)hh, -(float)hh, (float)hh, -(float)hh};
@@ -164,7 +195,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
     bool convergence = false;
     do {
         float dx = 0.f, dy = 0.f;
-        if (a.mode == 0) {
+        if (MODE == 0) {
             if (x1 - hw < 0.0f || tw - (x1 + hw) < one_plus_eps || x2 - hw < 0.0f || nc - (x2 + hw) < one_plus_eps ||
                 y1 - hh < 0.0f || th - (y1 + hh) < one_plus_eps || y2 - hh < 0.0f || nr - (y2 + hh) < one_plus_eps) {
                 status = KLT_OOB;
@@ -198,7 +229,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
             if (oob) { status = KLT_OOB; break; }
             float T[6][6], e[6];
             for (int r = 0; r < 6; r++) { e[r] = 0.f; for (int q = 0; q < 6; q++) T[r][q] = 0.f; }
-            const int nn = a.mode == 1 ? 4 : 6;
+            const int nn = MODE == 1 ? 4 : 6;
             for_samples([&](int k, float ti, float, float) {
                 const int i = k % width - hw, j = k / width - hh;
                 const float x = (float)i, y = (float)j;
@@ -206,7 +237,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
                 const float d = ti - bilinear_at(a.i2, nc, x2 + mi, y2 + mj);
                 const float g1 = bilinear_at(a.gx2, nc, x2 + mi, y2 + mj);
                 const float g2 = bilinear_at(a.gy2, nc, x2 + mi, y2 + mj);
-                if (a.mode == 1) {
+                if (MODE == 1) {
                     const float u = x * g1 + y * g2, v = x * g2 - y * g1;
                     e[0] = e[0] + (d * g1 * x + d * g2 * y); e[1] = e[1] + (d * g2 * x - d * g1 * y);
                     e[2] = e[2] + d * g1; e[3] = e[3] + d * g2;
@@ -227,21 +258,46 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
                     T[4][4] = T[4][4] + gxx; T[4][5] = T[4][5] + gxy; T[5][5] = T[5][5] + gyy;
                 }
             });
-            float mine = 0.f;                                // this lane's element of the normal equations
+            // the wave-wide sums of e[] and of the upper triangle of T (27 values; 14 for the similarity model), then every lane
+            // fetches its element of the normal equations: lane r * 6 + c holds T[r][c], lane 36 + r holds 0.5 e[r]
+            const int lr = lane < 36 ? lane / 6 : lane - 36, lc = lane < 36 ? lane % 6 : 0;
+            const int tr = lr < lc ? lr : lc, tc = lr < lc ? lc : lr;             // upper-triangle coordinates of my element
+            float mine;
+            if (MODE == 1) {
+                float v[16];
+                int k = 0;
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const float er = wave_sum(e[r]) * 0.5f;
-                if (lane == 36 + r) mine = er;
+                for (int r = 0; r < 4; r++) v[k++] = e[r];
 #pragma unroll
-                for (int q = r; q < 6; q++) {
-                    const float t = wave_sum(T[r][q]);
-                    if (lane == r * 6 + q || lane == q * 6 + r) mine = t;
-                }
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int q = r; q < 4; q++) v[k++] = T[r][q];
+                v[14] = v[15] = 0.f;
+                wave_sum_scatter<16>(v, lane);
+                // value index of (tr, tc) in the order above: 4 + tr * 4 - tr (tr - 1) / 2 + (tc - tr)
+                const int idx = lane >= 36 ? lr : 4 + tr * 4 - (tr * (tr - 1)) / 2 + (tc - tr);
+                mine = __shfl(v[0], (idx & 15) << 2);
+            } else {
+                float v[32];
+                int k = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) v[k++] = e[r];
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int q = r; q < 6; q++) v[k++] = T[r][q];
+#pragma unroll
+                for (int z = 27; z < 32; z++) v[z] = 0.f;
+                wave_sum_scatter<32>(v, lane);
+                const int idx = lane >= 36 ? lr : 6 + tr * 6 - (tr * (tr - 1)) / 2 + (tc - tr);
+                mine = __shfl(v[0], (idx & 31) << 1);
             }
+            if (lane >= 36) mine = mine * 0.5f;
+            if (lane >= 42 || (lane < 36 && (lr >= nn || lc >= nn)) || (lane >= 36 && lr >= nn)) mine = 0.f;
             status = gauss_jordan_wave(mine, nn, lane);
 #pragma unroll
             for (int r = 0; r < 6; r++) e[r] = __shfl(mine, 36 + r);
-            if (a.mode == 1) { Axx = Axx + e[0]; Ayx = Ayx + e[1]; Ayy = Axx; Axy = -Ayx; dx = e[2]; dy = e[3]; }
+            if (MODE == 1) { Axx = Axx + e[0]; Ayx = Ayx + e[1]; Ayy = Axx; Axy = -Ayx; dx = e[2]; dy = e[3]; }
             else { Axx = Axx + e[0]; Ayx = Ayx + e[1]; Axy = Axy + e[2]; Ayy = Ayy + e[3]; dx = e[4]; dy = e[5]; }
             x2 = x2 + dx; y2 = y2 + dy;
             convergence = fabsf(dx) < a.th && fabsf(dy) < a.th;
@@ -261,7 +317,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
         float s = 0.f;
         for_samples([&](int k, float ti, float, float) {
             const float x = (float)(k % width - hw), y = (float)(k / width - hh);
-            const float mi = a.mode ? Axx * x + Axy * y : x, mj = a.mode ? Ayx * x + Ayy * y : y;
+            const float mi = MODE ? Axx * x + Axy * y : x, mj = MODE ? Ayx * x + Ayy * y : y;
             s = s + fabsf(ti - bilinear_at(a.i2, nc, x2 + mi, y2 + mj));
         });
         s = wave_sum(s);
@@ -293,7 +349,10 @@ __global__ void affine_reset_kernel(klt_affine_rec *rec, int n)
 void launch_affine(hipStream_t s, const AffineArgs &a)
 {
     if (a.n <= 0) return;
-    hipLaunchKernelGGL(affine_kernel, dim3(a.n), dim3(64), 0, s, a);
+    const size_t n = (size_t)a.width * a.height;
+    if (a.mode == 0) hipLaunchKernelGGL(affine_kernel<0>, dim3(a.n), dim3(64), 3 * n * sizeof(float), s, a);
+    else if (a.mode == 1) hipLaunchKernelGGL(affine_kernel<1>, dim3(a.n), dim3(64), n * sizeof(float), s, a);
+    else hipLaunchKernelGGL(affine_kernel<2>, dim3(a.n), dim3(64), n * sizeof(float), s, a);
 }
 
 void launch_affine_reset(hipStream_t s, klt_affine_rec *rec, int n)

@@ -407,33 +407,31 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
         __syncthreads();
         STAGE_MARK(2);
         // ---- stage 2: vertical smoothing, B -> C (+ store the tile interior of the smoothed image).
-        // A thread produces a quad on two consecutive rows: NS+1 rows are read and widened for 8 outputs.
+        // A thread produces two adjacent columns on FOUR consecutive rows: NS + 3 rows of two samples are read (ds_read_b64) and
+        // widened for 8 outputs -- 2 widenings per output (a quad on two rows: 3).
         float *__restrict__ img = a.img[b];
-        static_assert(IH % 2 == 0, "tile height must be even");
-        for (int i = tid; i < (IH / 2) * BQ; i += NTHR) {
-            const int r = 2 * (i / BQ), q = i % BQ;
-            double v[4][NS + 1];
+        constexpr int BH = BW / 2, G2 = (IH + 3) / 4;           // half-quads per row, groups of four rows (the last one may be partial)
+        for (int i = tid; i < G2 * BH; i += NTHR) {
+            const int r = 4 * (i / BH), h = i % BH;
+            double v[2][NS + 3];
 #pragma unroll
-            for (int j = 0; j < NS + 1; j++) {
-                const float4 t = *reinterpret_cast<const float4 *>(B + (r + j) * BW + 4 * q);
-                v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
+            for (int j = 0; j < NS + 3; j++) {
+                const int rj = min(r + j, RH - 1);              // rows past the tile only feed outputs that are not stored
+                const float2 t = *reinterpret_cast<const float2 *>(B + rj * BW + 2 * h);
+                v[0][j] = (double)t.x; v[1][j] = (double)t.y;
             }
 #pragma unroll
-            for (int dr = 0; dr < 2; dr++) {
-                float4 o;
-                o.x = corr_regs<NS, 1>(v[0] + rs + dr, ks); o.y = corr_regs<NS, 1>(v[1] + rs + dr, ks);
-                o.z = corr_regs<NS, 1>(v[2] + rs + dr, ks); o.w = corr_regs<NS, 1>(v[3] + rs + dr, ks);
+            for (int dr = 0; dr < 4; dr++) {
                 const int rr = r + dr;
-                *reinterpret_cast<float4 *>(C + rr * BW + 4 * q) = o;
-                const int y = ty0 - R + rr, x = tx0 - HB + 4 * q;
-                if (rr >= R && rr < R + TH_ && q >= HB / 4 && q < HB / 4 + DQ && y < nr) {
+                if (rr >= IH) break;
+                float2 o;
+                o.x = corr_regs<NS, 1>(v[0] + rs + dr, ks); o.y = corr_regs<NS, 1>(v[1] + rs + dr, ks);
+                *reinterpret_cast<float2 *>(C + rr * BW + 2 * h) = o;
+                const int y = ty0 - R + rr, x = tx0 - HB + 2 * h;
+                if (rr >= R && rr < R + TH_ && h >= HB / 2 && h < HB / 2 + DW / 2 && y < nr) {
                     float *dstp = img + (size_t)y * nc + x;
-                    if (x + 3 < nc) { dstp[0] = o.x; dstp[1] = o.y; dstp[2] = o.z; dstp[3] = o.w; }
-                    else {
-                        if (x < nc) dstp[0] = o.x;
-                        if (x + 1 < nc) dstp[1] = o.y;
-                        if (x + 2 < nc) dstp[2] = o.z;
-                    }
+                    if (x < nc) dstp[0] = o.x;
+                    if (x + 1 < nc) dstp[1] = o.y;
                 }
             }
         }
@@ -464,74 +462,78 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
         for (int t = 0; t <= HR; t++) kr.k[t] = a.reduce.k[t];
         float *__restrict__ h1 = a.h1[b];
         const int h1_nc = a.h1_nc;
-        for (int i = tid; i < TH_ * DQ; i += NTHR) {
-            const int r = i / DQ, xs = i % DQ;
+        // a thread makes TWO adjacent outputs (columns 4 xs + 2 and 4 xs + 6 of the tile): their 21-sample windows share 17
+        // samples, so 28 samples are read and widened for two outputs instead of 24 for each
+        static_assert(DQ % 2 == 0, "tile width must be a multiple of eight");
+        for (int i = tid; i < TH_ * (DQ / 2); i += NTHR) {
+            const int r = i / (DQ / 2), xs = 2 * (i % (DQ / 2));
             // centre = image column 4 xs + 2 = C index HB + 4 xs + 2; samples -10 .. +10 start at C index 4 xs + HB - 8 (a quad)
             typedef const volatile __attribute__((address_space(3))) f32x4 *lds_quad_ptr;
             const lds_quad_ptr p = (lds_quad_ptr)(C + (r + R) * BW + 4 * xs + (HB - 8));
-            double v[24];
+            double v[28];
 #pragma unroll
-            for (int u = 0; u < 6; u++) {
+            for (int u = 0; u < 7; u++) {
                 const f32x4 t = p[u];
                 v[4 * u] = (double)t.x; v[4 * u + 1] = (double)t.y; v[4 * u + 2] = (double)t.z; v[4 * u + 3] = (double)t.w;
             }
-            double acc = v[HR] * kr.k[HR];
+            const int y = ty0 + r;
 #pragma unroll
-            for (int jj = -HR; jj < 0; jj++) acc = acc + (v[HR + jj] + v[HR - jj]) * kr.k[HR + jj];
-            const int y = ty0 + r, xg = tx0 / 4 + xs;
-            if (y < nr && xg < h1_nc) h1[(size_t)y * h1_nc + xg] = (float)acc;
+            for (int o = 0; o < 2; o++) {
+                const double *c = v + HR + 4 * o;                    // centre sample of output o
+                double acc = c[0] * kr.k[HR];
+#pragma unroll
+                for (int jj = -HR; jj < 0; jj++) acc = acc + (c[jj] + c[-jj]) * kr.k[HR + jj];
+                const int xg = tx0 / 4 + xs + o;
+                if (y < nr && xg < h1_nc) h1[(size_t)y * h1_nc + xg] = (float)acc;
+            }
         }
     }
     __syncthreads();
     STAGE_MARK(4);
-    // ---- stage 4: vertical pass, D -> gradx (Gaussian taps), E -> grady (derivative taps); quad x two rows per thread
+    // ---- stage 4: vertical pass, D -> gradx (Gaussian taps), E -> grady (derivative taps).  A thread makes two adjacent columns on
+    // FOUR consecutive rows: NG + 3 rows of two samples are read (ds_read_b64) and widened once for 8 outputs per plane -- 2.5
+    // widenings per output where a quad on two rows needs 4 (the widening is an FP64-rate instruction like the adds and multiplies).
     float *__restrict__ gxo = a.gx[b];
     float *__restrict__ gyo = a.gy[b];
-    static_assert(TH_ % 2 == 0, "tile height must be even");
-    for (int i = tid; i < (TH_ / 2) * DQ; i += NTHR) {
-        const int r = 2 * (i / DQ), q = i % DQ;
-        const int x = tx0 + 4 * q;
+    static_assert(TH_ % 4 == 0, "tile height must be a multiple of four");
+    static_assert(NG == ND, "the vertical pass shares its row window between the two planes");
+    constexpr int DH = DW / 2;                                   // half-quads per row
+    for (int i = tid; i < (TH_ / 4) * DH; i += NTHR) {
+        const int r = 4 * (i / DH), h = i % DH;
+        const int x = tx0 + 2 * h;
         if (ty0 + r >= nr || x >= nc) continue;
-        float4 ox[2], oy[2];
+        float2 ox[4], oy[4];
         {
-            double v[4][NG + 1];
+            double v[2][NG + 3];
 #pragma unroll
-            for (int j = 0; j < NG + 1; j++) {
-                const float4 t = *reinterpret_cast<const float4 *>(D + (r + R - NG / 2 + j) * DW + 4 * q);
-                v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
+            for (int j = 0; j < NG + 3; j++) {
+                const float2 t = *reinterpret_cast<const float2 *>(D + (r + R - NG / 2 + j) * DW + 2 * h);
+                v[0][j] = (double)t.x; v[1][j] = (double)t.y;
             }
 #pragma unroll
-            for (int dr = 0; dr < 2; dr++) {
+            for (int dr = 0; dr < 4; dr++) {
                 ox[dr].x = corr_regs<NG, 1>(v[0] + NG / 2 + dr, kg); ox[dr].y = corr_regs<NG, 1>(v[1] + NG / 2 + dr, kg);
-                ox[dr].z = corr_regs<NG, 1>(v[2] + NG / 2 + dr, kg); ox[dr].w = corr_regs<NG, 1>(v[3] + NG / 2 + dr, kg);
             }
         }
         {
-            double v[4][ND + 1];
+            double v[2][ND + 3];
 #pragma unroll
-            for (int j = 0; j < ND + 1; j++) {
-                const float4 t = *reinterpret_cast<const float4 *>(E + (r + R - ND / 2 + j) * DW + 4 * q);
-                v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
+            for (int j = 0; j < ND + 3; j++) {
+                const float2 t = *reinterpret_cast<const float2 *>(E + (r + R - ND / 2 + j) * DW + 2 * h);
+                v[0][j] = (double)t.x; v[1][j] = (double)t.y;
             }
 #pragma unroll
-            for (int dr = 0; dr < 2; dr++) {
+            for (int dr = 0; dr < 4; dr++) {
                 oy[dr].x = corr_regs<ND, -1>(v[0] + ND / 2 + dr, kd); oy[dr].y = corr_regs<ND, -1>(v[1] + ND / 2 + dr, kd);
-                oy[dr].z = corr_regs<ND, -1>(v[2] + ND / 2 + dr, kd); oy[dr].w = corr_regs<ND, -1>(v[3] + ND / 2 + dr, kd);
             }
         }
 #pragma unroll
-        for (int dr = 0; dr < 2; dr++) {
+        for (int dr = 0; dr < 4; dr++) {
             const int y = ty0 + r + dr;
             if (y >= nr) break;
             float *px = gxo + (size_t)y * nc + x, *py = gyo + (size_t)y * nc + x;
-            if (x + 3 < nc) {
-                px[0] = ox[dr].x; px[1] = ox[dr].y; px[2] = ox[dr].z; px[3] = ox[dr].w;
-                py[0] = oy[dr].x; py[1] = oy[dr].y; py[2] = oy[dr].z; py[3] = oy[dr].w;
-            } else {
-                px[0] = ox[dr].x; py[0] = oy[dr].x;
-                if (x + 1 < nc) { px[1] = ox[dr].y; py[1] = oy[dr].y; }
-                if (x + 2 < nc) { px[2] = ox[dr].z; py[2] = oy[dr].z; }
-            }
+            px[0] = ox[dr].x; py[0] = oy[dr].x;
+            if (x + 1 < nc) { px[1] = ox[dr].y; py[1] = oy[dr].y; }
         }
     }
     STAGE_MARK(5);

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64) void track_kernel_quad(TrackArgs a)
         const Bilinear b1 = make_bilinear(xloc, yloc);
         const bool t_ok = b1.ix - hw >= 0 && b1.iy - hw >= 0 && b1.ix + hw + 2 <= nc && b1.iy + hw + 2 <= nr;
         const bool run = alive && t_ok;
-        const size_t q1 = run ? (size_t)(b1.iy - hw + qr) * nc + (b1.ix - hw + 4 * qh) : (size_t)0;
+        const unsigned q1 = run ? (unsigned)(b1.iy - hw + qr) * (unsigned)nc + (unsigned)(b1.ix - hw + 4 * qh) : 0u;   // 32-bit element offsets: scalar base + vector offset loads
         const f32x4 t_qi = load_quad(lv.i1 + q1), t_qgx = load_quad(lv.gx1 + q1), t_qgy = load_quad(lv.gy1 + q1);
 
         // the first Newton iteration starts from a position that is already known: its bounds test (trackFeaturesUtils.pyx:428-431)
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64) void track_kernel_quad(TrackArgs a)
                              (double)(y2 - (float)hw) < 0. || (float)nr - (y2 + (float)hw) < one_plus_eps;
             if (iterating && oob) { status = KLT_OOB; iterating = false; }
             b2 = make_bilinear(x2, y2);
-            const size_t q = iterating ? (size_t)(b2.iy - hw + qr) * nc + (b2.ix - hw + 4 * qh) : (size_t)0;
+            const unsigned q = iterating ? (unsigned)(b2.iy - hw + qr) * (unsigned)nc + (unsigned)(b2.ix - hw + 4 * qh) : 0u;
             s_qi = load_quad(lv.i2 + q); s_qgx = load_quad(lv.gx2 + q); s_qgy = load_quad(lv.gy2 + q);
         };
         request_footprint();
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64) void track_kernel_quad(TrackArgs a)
         const bool need_res = run && status == KLT_TRACKED && a.use_max_residue;
         if (__any(need_res)) {
             const Bilinear br = make_bilinear(x2, y2);
-            const size_t q = need_res ? (size_t)(br.iy - hw + qr) * nc + (br.ix - hw + 4 * qh) : (size_t)0;
+            const unsigned q = need_res ? (unsigned)(br.iy - hw + qr) * (unsigned)nc + (unsigned)(br.ix - hw + 4 * qh) : 0u;
             float s_i[4];
             sample_quad<QPR>(load_quad(lv.i2 + q), br, s_i);
 #pragma unroll
@@ -556,6 +556,11 @@ __global__ __launch_bounds__(64) void track_kernel_quad(TrackArgs a)
         fout[f] = o;
     }
 }
+
+// (15x15, measured and not kept -- round 2: several features per workgroup with ONE wavefront adding the five 225-term chains of
+// all of them (5 NW lanes busy instead of 5; the chains are 40 % of an iteration's instructions): 68.4 us (8 features) / 62.7 (4)
+// against 59.8 for one independent wavefront per feature at cfg-3.  The barriers and the lock step cost more than the saved issue
+// slots.)
 
 // Features sorted by image row (counting sort, one workgroup): order[0..n) = feature indices by ascending (int)y; lost
 // features go last.  The order within a row is whatever the atomics give -- every feature is still tracked exactly once and

@@ -1087,3 +1087,96 @@ def test_min_distance_on_given_scores(ctx, ko, case):
             assert_feats(got, *oracle_feats(want), what="%s algo %d" % (case, algo))
     finally:
         ctx.set_option(8, 1)
+
+
+def test_track_sequence_without_presmoothing():
+    """tc.smoothBeforeSelecting = False: KLTTrackSequence's initial selection uses the raw frame, as KLTSelectGoodFeatures does
+    (selectGoodFeatures.py:183-197) -- not level 0 of the pyramid, which is always smoothed."""
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.trackSequence import KLTTrackSequence
+    w, h, n = 320, 240, 120
+    base = synth.synth_base(w, h, 5)
+    frames = [synth.synth_frame(w, h, 5, k, shift=(1.7, 0.9), base=base) for k in range(3)]
+
+    def make():
+        tc = KLT_TrackingContext()
+        tc.sequentialMode = True
+        tc.smoothBeforeSelecting = False
+        return tc
+
+    sgf.KLT_verbose = 0
+    try:
+        want = _host_api_sequence(make(), frames, n, True)
+        got = KLTTrackSequence(make(), frames, n, replace_lost=True)
+        assert np.array_equal(got.val, want.val) and np.array_equal(got.x, want.x) and np.array_equal(got.y, want.y)
+        smoothed = make()
+        smoothed.smoothBeforeSelecting = True
+        other = KLTTrackSequence(smoothed, frames, n, replace_lost=True)
+        assert not np.array_equal(other.x[0], got.x[0])          # the two settings really select different features
+    finally:
+        sgf.KLT_verbose = 1
+
+
+def test_sequential_mode_survives_parameter_changes(img0, img1, cfg1):
+    """sequentialMode keeps tc.pyramid_last across calls (trackFeatures.py:152-161).  Changing a field that does not enter the
+    pyramids (mindist, max_residue, min_eigenvalue) between two calls must keep the resident pyramids; a second tracking
+    context with other parameters on the same device context must not break the first one either."""
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd.backend import default_context
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures
+    sgf.KLT_verbose = 0
+    try:
+        tc = KLT_TrackingContext()
+        tc.sequentialMode = True
+        tc.max_residue = 10.0
+        fl = sgf.KLTSelectGoodFeatures(tc, img0, 50)
+        KLTTrackFeatures(tc, img0, img1, fl)
+        assert [f.val for f in fl] == cfg1["seq50_0_val"].tolist()
+        s1 = tc._klt_slots[0]
+        assert default_context().pyramids_valid(s1)
+        tc.mindist = 12                                              # not a pyramid parameter
+        tc.min_eigenvalue = 2
+        default_context().configure(tc)
+        assert default_context().pyramids_valid(s1), "resident pyramids were invalidated by a mindist change"
+        tc.mindist, tc.min_eigenvalue = 10, 1
+        other = KLT_TrackingContext()                                # another context, other taps, same device context
+        other.grad_sigma = 1.5
+        sgf.KLTSelectGoodFeatures(other, img1, 20)
+        # the taps changed under tc's resident pyramids: the next call rebuilds frame 1 from the image it is given
+        # instead of failing ("pyramids of both slots must be built")
+        KLTTrackFeatures(tc, img1, img0, fl)
+        assert [f.val for f in fl] == cfg1["seq50_1_val"].tolist()
+        assert [f.x for f in fl] == cfg1["seq50_1_x"].tolist()
+    finally:
+        sgf.KLT_verbose = 1
+
+
+def test_slots_and_affine_states_are_recycled():
+    """Tracking contexts and feature lists that die give their device slots / affine states back (weakref finalizers)."""
+    import gc
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.backend import default_context
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures
+    ctx = default_context()
+    f0, f1 = synth.synth_pair(320, 240, seed=3)
+    sgf.KLT_verbose = 0
+    try:
+        bases, states = set(), set()
+        for _ in range(6):
+            tc = KLT_TrackingContext()
+            tc.affineConsistencyCheck = 2
+            fl = sgf.KLTSelectGoodFeatures(tc, f0, 40)
+            KLTTrackFeatures(tc, f0, f1, fl)
+            bases.add(tc._klt_slots[0])
+            states.update(e[1] for e in ctx.__dict__.get("_affine_states", {}).values())
+            del tc, fl
+            gc.collect()
+        assert len(bases) <= 2 and len(states) <= 2, (bases, states)
+        assert not ctx.__dict__.get("_affine_states")
+    finally:
+        sgf.KLT_verbose = 1
