@@ -10,7 +10,7 @@
 //     similarity model; 2x2 for translation only) of the template against level 0 of frame 2; the feature
 //     is lost unless this returns KLT_TRACKED; on success the translation result is kept.
 // Window sums: there is no reference summation order to reproduce here, so the order is part of the behaviour
-// specification and the test oracle restates it exactly (oracle/klt_oracle.c am_fold): term k
+// specification and the CPU checker under oracle/ restates it exactly (its am_fold): term k
 // (row-major window index) is added, in increasing k, to the partial sum of lane k mod 64; the 64 partials are folded by
 // the butterfly p[l] + p[l ^ m], m = 32 .. 1.  Statuses, positions and A matrices are bit-identical to the oracle's.
 #include "klt_internal.h"
