@@ -196,31 +196,46 @@ def test_no_fma_contraction_in_the_device_code(tmp_path):
     objs = sorted(p for p in tmp_path.iterdir() if p.name.endswith("gfx950"))
     assert objs, "no gfx950 code object found in libkltgpu.so"
     fma = re.compile(r"\b(v_(?:pk_)?fm(?:a|ac|amk|aak)_(?:f16|f32|f64|legacy_f32)|v_mad_(?:f32|f16|legacy_f32)|v_mac_f32|v_fma_mix\w*|v_dot\w*|v_mfma\w*)\b")
+    expansion = re.compile(r"\b(v_div_scale_f(?:32|64)|v_div_fmas_f(?:32|64)|v_div_fixup_f(?:32|64)|v_rcp_f(?:32|64)|v_rsq_f64|v_sqrt_f64)\b")
     per_kernel = collections.defaultdict(collections.Counter)
+    stray = []                  # FMAs that are not part of a division / square-root expansion
     nkernels = 0
     for o in objs:
         asm = subprocess.run([objdump, "-d", str(o)], check=True, capture_output=True, text=True).stdout
-        cur = None
+        cur, lines = None, []
+
+        def close(cur, lines):
+            for k, line in enumerate(lines):
+                m = fma.search(line)
+                if not m:
+                    continue
+                per_kernel[cur][m.group(1)] += 1
+                window = lines[max(0, k - 16):k + 17]
+                if not any(expansion.search(w) for w in window):
+                    stray.append((cur, line.strip()))
+
         for line in asm.splitlines():
             m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
             if m:
-                cur = m.group(1)
+                if cur:
+                    close(cur, lines)
+                cur, lines = m.group(1), []
                 nkernels += 1
                 continue
-            m = fma.search(line)
-            if m and cur:
-                per_kernel[cur][m.group(1)] += 1
+            lines.append(line)
+        if cur:
+            close(cur, lines)
     assert nkernels > 40
     for name, ops in per_kernel.items():
         if "eigen" in name:
-            assert set(ops) == {"v_fma_f64"} and ops["v_fma_f64"] <= 4, (name, dict(ops))          # sqrt(double)
-        elif "track_kernel" in name:
-            assert set(ops) == {"v_fma_f32"} and ops["v_fma_f32"] <= 9, (name, dict(ops))          # dx, dy, residue mean: three divisions
-        elif "affine_kernel" in name:
-            assert set(ops) == {"v_fma_f32"} and ops["v_fma_f32"] <= 16, (name, dict(ops))         # 2x2 solve, 1 / pivot, residue mean
+            assert set(ops) == {"v_fma_f64"}, (name, dict(ops))                                    # sqrt(double)
+        elif "track_kernel" in name or "affine_kernel" in name:
+            assert set(ops) == {"v_fma_f32"}, (name, dict(ops))         # IEEE f32 divisions: 2x2 solve, 1 / pivot, residue mean
         elif "mis_round" in name:
             assert set(ops) <= {"v_fmamk_f32"}, (name, dict(ops))                                  # integer division helper, no image data
         else:
             raise AssertionError("FMA in %s: %r" % (name, dict(ops)))
+    stray = [x for x in stray if "mis_round" not in x[0]]
+    assert not stray, "fused multiply-adds outside division / sqrt expansions: %r" % stray[:5]
     # the kernels that carry the reference's FP64 convolution arithmetic are FMA-free
     assert not [k for k in per_kernel if re.search(r"smooth_grad|pyr_|hconv|vconv|sat_", k)]
