@@ -377,8 +377,8 @@ __device__ __forceinline__ void sample_quad(const f32x4 a, const Bilinear &b, fl
     }
 }
 
-template <bool BATCH, int W>
-__global__ __launch_bounds__(64) void track_kernel_quad(TrackArgs a)
+template <bool BATCH, int W, int WAVES = 1>
+__global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
 {
     static_assert(W == 7 || W == 15, "quad kernels exist for 7x7 and 15x15 windows");
     constexpr int FPW = W == 7 ? 4 : 1;                      // features per wavefront
@@ -665,7 +665,10 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     }
     if (g_track_variant != 0 && a.window == 15) {
         const dim3 gq(a.order ? 8 * a.order_chunk : a.n, ny);
-        hipLaunchKernelGGL((track_kernel_quad<BATCH, 15>), gq, block, lds, s, a);
+        // occupancy target 5 (96 VGPRs, 40 bytes of scratch per lane instead of 107 VGPRs): the 5000 wavefronts of cfg-3 are then
+        // resident at once instead of in two rounds -- 57.9 -> 49.3 us.  (The 7x7 kernel loses from the same cap: its spills land
+        // in the Newton loop -- 143 -> 211 us at cfg-4.)
+        hipLaunchKernelGGL((track_kernel_quad<BATCH, 15, 5>), gq, block, lds, s, a);
         return 0;
     }
     const dim3 grid(a.order ? 8 * a.order_chunk : a.n, ny);

@@ -118,35 +118,141 @@ class KLT_TrackingContext:
         self.bordery = border
 
 
+class _FeatureStore:
+    """Column storage behind the KLT_Feature objects of one feature list.
+
+    The reference keeps x / y / val (and the affine fields) as attributes of 5000 separate Python objects and touches every one of
+    them on every call (selectGoodFeatures.py:116-128, trackFeatures.py:288-399).  Here the objects are thin views of rows of
+    shared numpy columns, so KLTSelectGoodFeatures / KLTTrackFeatures / KLTReplaceLostFeatures move whole columns to and from the
+    16-byte device records instead of looping over features; a feature object reads its row when somebody looks at it.
+    x / y are kept as float64 (exact for the reference's values: integers after selection, f32-valued after tracking) plus a flag
+    that remembers whether the reference would hold a Python int there (`print` shows 86, not 86.0)."""
+
+    __slots__ = ("x", "y", "val", "xint", "yint", "aff", "aff_img", "features", "__weakref__")
+    _AFF_DEFAULTS = (("aff_x", -1.0), ("aff_y", -1.0), ("aff_Axx", 1.0), ("aff_Ayx", 0.0), ("aff_Axy", 0.0), ("aff_Ayy", 1.0))
+
+    def __init__(self, n):
+        self.x = np.full(n, -1.0)
+        self.y = np.full(n, -1.0)
+        self.val = np.full(n, kltState.KLT_NOT_FOUND, np.int64)
+        self.xint = np.ones(n, bool)
+        self.yint = np.ones(n, bool)
+        self.aff = None               # {name: float64 column}, created when an affine field is first written
+        self.aff_img = None           # {name: object column} for aff_img / aff_img_gradx / aff_img_grady
+        self.features = None          # the KLT_Feature objects of rows 0 .. n-1 (new_feature_list)
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def aff_columns(self):
+        if self.aff is None:
+            n = len(self)
+            self.aff = {name: np.full(n, dflt) for name, dflt in self._AFF_DEFAULTS}
+            self.aff_img = {name: np.full(n, None, object) for name in ("aff_img", "aff_img_gradx", "aff_img_grady")}
+        return self.aff
+
+    def reset_affine(self, rows):
+        """rows (index array / mask) back to the state of newly placed features (selectGoodFeatures.py:120-128)"""
+        if self.aff is None:
+            return
+        for name, dflt in self._AFF_DEFAULTS:
+            self.aff[name][rows] = dflt
+        for col in self.aff_img.values():
+            col[rows] = None
+
+
+def _coord_property(col, flag):
+    def get(self):
+        s, i = self._s, self._i
+        v = getattr(s, col)[i]
+        return int(v) if getattr(s, flag)[i] else float(v)
+
+    def put(self, value):
+        s, i = self._s, self._i
+        getattr(s, col)[i] = value
+        getattr(s, flag)[i] = isinstance(value, (int, np.integer)) and not isinstance(value, bool)
+    return property(get, put)
+
+
+def _aff_property(name, dflt):
+    def get(self):
+        s = self._s
+        return dflt if s.aff is None else float(s.aff[name][self._i])
+
+    def put(self, value):
+        self._s.aff_columns()[name][self._i] = value
+    return property(get, put)
+
+
+def _aff_img_property(name):
+    def get(self):
+        s = self._s
+        return None if s.aff is None else s.aff_img[name][self._i]
+
+    def put(self, value):
+        s = self._s
+        s.aff_columns()
+        s.aff_img[name][self._i] = value
+    return property(get, put)
+
+
 class KLT_Feature:
-    """klt.py:249-263.  The reference's __init__ assigns locals only; real attributes are set on
-    first placement (selectGoodFeatures.py:117-128).  Here they always exist: x, y, val are set by __init__, the
-    affine-consistency fields read as their defaults until something assigns them (a list of 20 000 features is
-    created and updated in Python on every selection, so the constructor stays small)."""
+    """klt.py:249-263.  The reference's __init__ assigns locals only; real attributes are set on first placement
+    (selectGoodFeatures.py:117-128).  Here x, y, val and the affine-consistency fields always exist; the object is a view of
+    row `_i` of a _FeatureStore (its own one-row store when created on its own, the list's shared store when it comes from
+    KLTSelectGoodFeatures / KLTCreateFeatureList)."""
 
-    __slots__ = ("x", "y", "val", "aff_img", "aff_img_gradx", "aff_img_grady",
-                 "aff_x", "aff_y", "aff_Axx", "aff_Ayx", "aff_Axy", "aff_Ayy", "__weakref__")
-    _AFF_DEFAULTS = {"aff_img": None, "aff_img_gradx": None, "aff_img_grady": None, "aff_x": -1.0, "aff_y": -1.0,
-                     "aff_Axx": 1.0, "aff_Ayx": 0.0, "aff_Axy": 0.0, "aff_Ayy": 1.0}
+    __slots__ = ("_s", "_i", "__weakref__")
 
-    def __init__(self):
-        self.x = -1
-        self.y = -1
-        self.val = kltState.KLT_NOT_FOUND
+    def __init__(self, _store=None, _index=0):
+        self._s = _FeatureStore(1) if _store is None else _store
+        self._i = _index
 
-    def __getattr__(self, name):                  # only reached for a slot that was never assigned
-        try:
-            return KLT_Feature._AFF_DEFAULTS[name]
-        except KeyError:
-            raise AttributeError(name)
+    x = _coord_property("x", "xint")
+    y = _coord_property("y", "yint")
+
+    @property
+    def val(self):
+        return int(self._s.val[self._i])
+
+    @val.setter
+    def val(self, value):
+        self._s.val[self._i] = value
+
+    aff_x = _aff_property("aff_x", -1.0)
+    aff_y = _aff_property("aff_y", -1.0)
+    aff_Axx = _aff_property("aff_Axx", 1.0)
+    aff_Ayx = _aff_property("aff_Ayx", 0.0)
+    aff_Axy = _aff_property("aff_Axy", 0.0)
+    aff_Ayy = _aff_property("aff_Ayy", 1.0)
+    aff_img = _aff_img_property("aff_img")
+    aff_img_gradx = _aff_img_property("aff_img_gradx")
+    aff_img_grady = _aff_img_property("aff_img_grady")
 
     def _reset_affine(self):
         """Back to the state of a newly placed feature (selectGoodFeatures.py:120-128)."""
-        for name in KLT_Feature._AFF_DEFAULTS:
-            try:
-                delattr(self, name)
-            except AttributeError:
-                pass
+        self._s.reset_affine(self._i)
+
+
+def new_feature_list(n):
+    """n lost features sharing one column store (what KLTSelectGoodFeatures / KLTCreateFeatureList hand out)."""
+    store = _FeatureStore(n)
+    fl = [KLT_Feature(store, i) for i in range(n)]
+    store.features = list(fl)         # a private copy: the caller's list may be edited
+    return fl
+
+
+def shared_store(featurelist):
+    """The _FeatureStore whose rows 0 .. n-1 are exactly this list's features, in order -- or None (a list assembled by hand,
+    re-ordered, or mixing features of several lists), in which case callers fall back to per-feature access.  The test is one
+    C-level list comparison (identity of every element)."""
+    try:
+        s = featurelist[0]._s
+    except (IndexError, AttributeError):
+        return None
+    if s.features is None or len(featurelist) != len(s.features):
+        return None
+    return s if featurelist == s.features else None
 
 
 _REC_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("val", np.int32), ("aux", np.int32)])   # == klt_feat
@@ -218,4 +324,7 @@ def KLTPrintTrackingContext(tc):
 
 def KLTCountRemainingFeatures(fl):
     """klt.py:319-325"""
+    s = shared_store(fl)
+    if s is not None:
+        return int(np.count_nonzero(s.val >= 0))
     return sum(1 for feat in fl if feat.val >= 0)

@@ -10,7 +10,7 @@ from __future__ import print_function
 import numpy as np
 
 from .backend import FEAT_DTYPE, REPLACING_SOME, SELECTING_ALL, default_context
-from .klt import KLT_Feature, KLTCountRemainingFeatures, kltState
+from .klt import KLT_Feature, KLTCountRemainingFeatures, kltState, new_feature_list, shared_store
 from .error import KLTWarning
 
 
@@ -38,9 +38,13 @@ def _image_size(img):
 
 
 def features_to_array(featurelist):
-    """KLT_Feature list -> record array (column-wise: three list comprehensions, no per-record numpy calls)."""
+    """KLT_Feature list -> record array.  A list whose features share one column store (every list this package hands out)
+    is converted column by column; anything else feature by feature."""
     fl = np.zeros(len(featurelist), FEAT_DTYPE)
-    if len(featurelist):
+    store = shared_store(featurelist)
+    if store is not None:
+        fl["x"], fl["y"], fl["val"] = store.x, store.y, store.val
+    elif len(featurelist):
         fl["x"] = [f.x for f in featurelist]
         fl["y"] = [f.y for f in featurelist]
         fl["val"] = [f.val for f in featurelist]
@@ -84,7 +88,7 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
     ctx.configure(tc)
     slots = _slots_of(tc)
     if featurelist is None:
-        featurelist = [KLT_Feature() for _ in range(nFeatures)]
+        featurelist = new_feature_list(nFeatures)
     reuse = (mode == selectionMode.REPLACING_SOME and tc.sequentialMode and tc.pyramid_last is not None
              and ctx.pyramids_valid(slots[0]))
     if reuse:
@@ -103,8 +107,32 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
         if aff is not None:
             ctx.set_option(4, -1)
     affine_used = aff is not None or tc.affineConsistencyCheck >= 0     # otherwise the affine fields were never assigned
-    xs, ys, vals = fl["x"].tolist(), fl["y"].tolist(), fl["val"].tolist()
-    olds = fl_in["val"].tolist() if mode == selectionMode.REPLACING_SOME else None
+    vals = fl["val"]
+    olds = fl_in["val"] if mode == selectionMode.REPLACING_SOME else None
+    store = shared_store(featurelist)
+    if store is not None:
+        # whole columns at once (selectGoodFeatures.py:109-128 touches every feature object in a Python loop)
+        free = np.ones(len(featurelist), bool) if olds is None else olds < 0      # live features are left untouched (:109-110)
+        placed = free & (vals >= 0)
+        store.x[placed] = fl["x"][placed]                                     # integer positions (:116-119)
+        store.y[placed] = fl["y"][placed]
+        store.val[placed] = vals[placed]
+        store.xint[placed] = True
+        store.yint[placed] = True
+        touched = placed
+        if mode == selectionMode.SELECTING_ALL:
+            missing = free & (vals < 0)
+            store.x[missing] = -1
+            store.y[missing] = -1
+            store.val[missing] = kltState.KLT_NOT_FOUND
+            store.xint[missing] = True
+            store.yint[missing] = True
+            touched = free
+        if affine_used:
+            store.reset_affine(touched)
+        return featurelist
+    xs, ys, vals = fl["x"].tolist(), fl["y"].tolist(), vals.tolist()
+    olds = olds.tolist() if olds is not None else None
     for i, feat in enumerate(featurelist):
         if olds is not None and olds[i] >= 0:
             continue                # live features are left untouched (:109-110)

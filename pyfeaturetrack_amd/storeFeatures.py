@@ -4,12 +4,12 @@ KLT_FeatureTable / KLT_FeatureHistory stubs at klt.py:272-283).  Host-side Pytho
 from __future__ import print_function
 
 from .error import KLTError
-from .klt import KLT_Feature, KLT_FeatureHistory, KLT_FeatureTable
+from .klt import KLT_FeatureHistory, KLT_FeatureTable, new_feature_list, shared_store
 from .selectGoodFeatures import features_to_array
 
 
 def KLTCreateFeatureList(nFeatures):
-    return [KLT_Feature() for _ in range(nFeatures)]
+    return new_feature_list(nFeatures)
 
 
 def KLTCreateFeatureHistory(nFrames):
@@ -46,6 +46,12 @@ def KLTExtractFeatureList(fl, ft, frame):
     if len(fl) != ft.nFeatures:
         KLTError("(KLTExtractFeatureList) FeatureList and FeatureTable must have the same number of features")
     row = ft.rec[frame]
+    store = shared_store(fl)
+    if store is not None:
+        store.x[:], store.y[:], store.val[:] = row["x"], row["y"], row["val"]
+        store.xint[:] = False
+        store.yint[:] = False
+        return
     for feat, x, y, v in zip(fl, row["x"].tolist(), row["y"].tolist(), row["val"].tolist()):
         feat.x, feat.y, feat.val = x, y, v
 

@@ -9,7 +9,7 @@ from __future__ import print_function
 
 from . import selectGoodFeatures as _sgf
 from .backend import default_context
-from .klt import KLTCountRemainingFeatures, kltState  # noqa: F401
+from .klt import KLTCountRemainingFeatures, kltState, shared_store  # noqa: F401
 from .selectGoodFeatures import _fix_window, _image_size, _slots_of, features_to_array, image_to_array
 
 
@@ -116,26 +116,53 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
         rec = ctx.affine_download(state, len(featurelist))
     else:
         fl_out, _ = ctx.track(s1, s2, fl_in)
-    olds = fl_in["val"].tolist()
-    xs, ys, vals = fl_out["x"].tolist(), fl_out["y"].tolist(), fl_out["val"].tolist()
-    if affine:
-        rcols = [rec[k].tolist() for k in ("aff_x", "aff_y", "Axx", "Ayx", "Axy", "Ayy", "valid")]
-    for i, feat in enumerate(featurelist):
-        if olds[i] < 0:
-            continue                                  # only live features are tracked (:253)
+    store = shared_store(featurelist)
+    if store is not None:
+        # whole columns at once (the reference walks the list: trackFeatures.py:288-399)
+        live = fl_in["val"] >= 0                          # only live features are tracked (:253)
+        ok = live & (fl_out["val"] == kltState.KLT_TRACKED)
+        lost = live & ~ok
+        store.x[ok] = fl_out["x"][ok]
+        store.y[ok] = fl_out["y"][ok]
+        store.val[ok] = kltState.KLT_TRACKED
+        store.x[lost] = -1.0
+        store.y[lost] = -1.0
+        store.val[lost] = fl_out["val"][lost]
+        store.xint[live] = False
+        store.yint[live] = False
         if affine:
-            feat.aff_x, feat.aff_y = rcols[0][i], rcols[1][i]
-            feat.aff_Axx, feat.aff_Ayx, feat.aff_Axy, feat.aff_Ayy = rcols[2][i], rcols[3][i], rcols[4][i], rcols[5][i]
-            feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = (_DEVICE_TEMPLATE if rcols[6][i] else None)
-        if vals[i] == kltState.KLT_TRACKED:
-            feat.x = xs[i]
-            feat.y = ys[i]
-            feat.val = kltState.KLT_TRACKED
-        else:
-            feat.x = -1.0
-            feat.y = -1.0
-            feat.val = vals[i]
-            feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = None
+            cols = store.aff_columns()
+            for name, key in (("aff_x", "aff_x"), ("aff_y", "aff_y"), ("aff_Axx", "Axx"), ("aff_Ayx", "Ayx"), ("aff_Axy", "Axy"),
+                              ("aff_Ayy", "Ayy")):
+                cols[name][live] = rec[key][live]
+            has_tpl = live & (rec["valid"] != 0) & ok
+            for col in store.aff_img.values():
+                col[live] = None
+                col[has_tpl] = _DEVICE_TEMPLATE
+        elif store.aff is not None:
+            for col in store.aff_img.values():
+                col[lost] = None
+    else:
+        olds = fl_in["val"].tolist()
+        xs, ys, vals = fl_out["x"].tolist(), fl_out["y"].tolist(), fl_out["val"].tolist()
+        if affine:
+            rcols = [rec[k].tolist() for k in ("aff_x", "aff_y", "Axx", "Ayx", "Axy", "Ayy", "valid")]
+        for i, feat in enumerate(featurelist):
+            if olds[i] < 0:
+                continue                                  # only live features are tracked (:253)
+            if affine:
+                feat.aff_x, feat.aff_y = rcols[0][i], rcols[1][i]
+                feat.aff_Axx, feat.aff_Ayx, feat.aff_Axy, feat.aff_Ayy = rcols[2][i], rcols[3][i], rcols[4][i], rcols[5][i]
+                feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = (_DEVICE_TEMPLATE if rcols[6][i] else None)
+            if vals[i] == kltState.KLT_TRACKED:
+                feat.x = xs[i]
+                feat.y = ys[i]
+                feat.val = kltState.KLT_TRACKED
+            else:
+                feat.x = -1.0
+                feat.y = -1.0
+                feat.val = vals[i]
+                feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = None
 
     if tc.sequentialMode:
         ctx.swap_slots(s1, s2)                        # frame-2 pyramids become frame 1 (:401-404)
