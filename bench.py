@@ -466,10 +466,21 @@ def run_cfg5(args, json_fd):
     ctx.featbuf_upload(0, fl)
     ctx.sync()
 
+    # the pyramids of frame k+1 are built on the context's build stream while frame k is tracked and its lost features are replaced
+    # (KLT_OPT_BUILD_STREAM; same results -- every frame has its own slot here)
+    prefetch = os.environ.get("KLT_BENCH_NO_PREFETCH") != "1"
+    if prefetch:
+        ctx.set_option(15, 1)
+
     def run_sequence(timed):
         t_sel = 0.0
+        if prefetch:
+            ctx.build_pyramids(10 + 1, sync=False)
         for k in range(1, nframes):
-            ctx.build_pyramids(10 + k, sync=False)
+            if not prefetch:
+                ctx.build_pyramids(10 + k, sync=False)
+            elif k + 1 < nframes:
+                ctx.build_pyramids(10 + k + 1, sync=False)
             ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)
             if timed:
                 ctx.sync()
@@ -496,8 +507,10 @@ def run_cfg5(args, json_fd):
     ctx.close()
     emit(json_fd, base_line(n * frames_done / el, 1, frames_done, 0, el / frames_done * 1e3, el / frames_done * 1e3,
                             "cfg-5 (one GPU): 3840x2160 sequence, 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost "
-                            "features replaced after every frame; per frame: pyramid of the new frame + track + replacement",
-                            extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3}))
+                            "features replaced after every frame; per frame: pyramid of the new frame + track + replacement"
+                            + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else ""),
+                            extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
+                                       "build_stream": bool(prefetch)}))
 
 
 # ================================================================================= launcher dry run

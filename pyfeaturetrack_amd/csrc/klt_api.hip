@@ -35,6 +35,9 @@ struct Slot {
     hipEvent_t ev_upload = nullptr;   // asynchronous ingest: frame copy finished (the build waits for it)
     hipEvent_t ev_consumed = nullptr; // last kernel on `stream` that read the raw frame u8
     uint64_t upload_serial = 0, consumed_serial = 0, consumed_alt_serial = 0;   // when the ring handed those events out (event_live)
+    hipEvent_t ev_built = nullptr;    // KLT_OPT_BUILD_STREAM: end of the build that filled this slot's pyramids (recorded on the build stream)
+    uint64_t built_serial = 0;
+    bool built_pending = false;       // the main stream has not waited for ev_built yet
     bool upload_pending = false, consumed_valid = false;
     // asynchronous ingest alternates between two raw buffers so that a copy never has to wait (on the device) for
     // kernels still reading the previous frame: making the copy stream wait on a compute-stream event blocks the
@@ -59,6 +62,9 @@ struct klt_ctx {
     int device = -1;
     hipStream_t stream = nullptr;     // uploads, pyramid build, selection, tracker
     hipStream_t cstream = nullptr;    // asynchronous frame ingest from pinned host memory (created on first use)
+    hipStream_t bstream = nullptr;    // KLT_OPT_BUILD_STREAM: pyramid builds run here, overlapping the tracker / selection of earlier frames
+    hipStream_t work = nullptr;       // stream the pyramid-build helpers enqueue on: `stream`, or `bstream` inside a build
+    bool build_stream_on = false;
     KltComm *comm = nullptr;          // RCCL communicator + side stream (klt_comm_init_rank), comm.hip
     std::vector<void *> pinned;       // klt_host_alloc allocations
     // Ordering events come from one ring and are never re-recorded while a waiter may still be queued on them
@@ -155,7 +161,7 @@ struct TimerScope {
     Timed t;
     bool on;
     hipStream_t st;
-    TimerScope(klt_ctx *c_, int fam, double bytes, hipStream_t st_ = nullptr) : c(c_), on(c_->timing), st(st_ ? st_ : c_->stream)
+    TimerScope(klt_ctx *c_, int fam, double bytes, hipStream_t st_ = nullptr) : c(c_), on(c_->timing), st(st_ ? st_ : c_->work)
     {
         if (!on) return;
         t.fam = fam;
@@ -178,6 +184,7 @@ int drain_timers(klt_ctx *c)
 {
     if (c->pending.empty()) return 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
     for (Timed &t : c->pending) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, t.a, t.b);
@@ -196,6 +203,7 @@ int sync_all(klt_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
+    if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
     return 0;
 }
 
@@ -285,24 +293,35 @@ bool event_live(const klt_ctx *c, uint64_t serial) { return c->ring_serial - ser
 
 // The frame copied by klt_upload_u8_async has landed before anything enqueued on `stream` after this call reads it.  A slot
 // left alone for more than a ring's worth of events no longer owns its event: the host waits for the copy stream instead.
-int wait_upload(klt_ctx *c, Slot *s)
+int wait_upload(klt_ctx *c, Slot *s, hipStream_t consumer)
 {
     if (!s->upload_pending) return 0;
-    if (event_live(c, s->upload_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_upload, 0));
+    if (event_live(c, s->upload_serial)) HIPCHK(c, hipStreamWaitEvent(consumer, s->ev_upload, 0));
     else HIPCHK(c, hipStreamSynchronize(c->cstream));
     s->upload_pending = false;
     return 0;
 }
 
 // everything enqueued on `stream` so far has read the raw frames of these slots: the next asynchronous copy into them waits for it
-int mark_consumed(klt_ctx *c, Slot *const *slots, int n)
+int mark_consumed(klt_ctx *c, Slot *const *slots, int n, hipStream_t reader)
 {
     if (!c->cstream) return 0;
     hipEvent_t e;
     uint64_t serial;
     if (int rc = fresh_event(c, &e, &serial)) return rc;
-    HIPCHK(c, hipEventRecord(e, c->stream));
+    HIPCHK(c, hipEventRecord(e, reader));
     for (int i = 0; i < n; i++) { slots[i]->ev_consumed = e; slots[i]->consumed_serial = serial; slots[i]->consumed_valid = true; }
+    return 0;
+}
+
+// KLT_OPT_BUILD_STREAM: work on the main stream that reads (or overwrites) a slot's frame / pyramids waits for the build that is
+// filling them on the build stream.  One wait per build: later main-stream work is ordered behind the first.
+int wait_built(klt_ctx *c, Slot *s)
+{
+    if (!s->built_pending) return 0;
+    if (event_live(c, s->built_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_built, 0));
+    else HIPCHK(c, hipStreamSynchronize(c->bstream));
+    s->built_pending = false;
     return 0;
 }
 
@@ -335,6 +354,7 @@ int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int p
     Slot *s;
     if (int rc = get_slot(c, slot, &s, true)) return rc;
     if (s->upload_pending) { HIPCHK(c, hipStreamSynchronize(c->cstream)); s->upload_pending = false; }
+    if (int rc = wait_built(c, s)) return rc;                 // a build on the build stream may still read the old frame
     const size_t px_count = (size_t)ncols * nrows;
     if (kind == 1) { if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc; }
     else { if (int rc = ensure(c, s->f32, s->f32_cap, px_count)) return rc; }
@@ -403,12 +423,12 @@ int enqueue_smooth_raw(klt_ctx *c, Slot *s, float *dst)
     const Taps &g = c->gauss[0];
     {
         TimerScope t(c, F_SMOOTH_H, N * ((s->raw_kind == 1 ? 1 : 4) + 4));
-        if (s->raw_kind == 1) launch_hconv_u8(c->stream, s->u8, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
-        else launch_hconv_f32(c->stream, s->f32, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+        if (s->raw_kind == 1) launch_hconv_u8(c->work, s->u8, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+        else launch_hconv_f32(c->work, s->f32, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
     }
     {
         TimerScope t(c, F_SMOOTH_V, N * 8);
-        launch_vconv(c->stream, c->tmpA, nullptr, nc, nr, dst, nullptr, nr, 1, 0, g, nullptr);
+        launch_vconv(c->work, c->tmpA, nullptr, nc, nr, dst, nullptr, nr, 1, 0, g, nullptr);
     }
     return 0;
 }
@@ -419,11 +439,11 @@ int enqueue_gradients(klt_ctx *c, const float *img, int nc, int nr, float *gx, f
     const double N = (double)nc * nr;
     {
         TimerScope t(c, F_GRAD_H, N * 12);
-        launch_hconv_f32(c->stream, img, nc, nr, c->tmpA, c->tmpB, nc, 1, 0, c->deriv[2], &c->gauss[2]);
+        launch_hconv_f32(c->work, img, nc, nr, c->tmpA, c->tmpB, nc, 1, 0, c->deriv[2], &c->gauss[2]);
     }
     {
         TimerScope t(c, F_GRAD_V, N * 16);
-        launch_vconv(c->stream, c->tmpA, c->tmpB, nc, nr, gx, gy, nr, 1, 0, c->gauss[2], &c->deriv[2]);
+        launch_vconv(c->work, c->tmpA, c->tmpB, nc, nr, gx, gy, nr, 1, 0, c->gauss[2], &c->deriv[2]);
     }
     return 0;
 }
@@ -470,7 +490,7 @@ int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int
     // launch also consumes the reduction stage's input (4 per pixel of level 0 -- the part of 4 (N0 + N1) that no longer
     // touches HBM); pyr_vreduce is charged the stage's output, so the step total is unchanged
     TimerScope t(c, F_SMOOTH_GRAD, N * ((raw_kind == 1 ? 1 : 4) + 4) + N * 12 + (hred ? 4.0 * N : 0.0));
-    if (int e = launch_smooth_grad(c->stream, a, batch, kind, hred))
+    if (int e = launch_smooth_grad(c->work, a, batch, kind, hred))
         return fail(c, KLT_ERR_DEVICE, std::string("smooth_grad launch: ") + hipGetErrorString((hipError_t)e));
     return 0;
 }
@@ -485,7 +505,7 @@ int enqueue_fused_grad(klt_ctx *c, int batch, const float *const *img, float *co
     a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
     a.ncols = nc; a.nrows = nr; a.R = grad_radius(c);
     TimerScope t(c, F_GRAD, (double)nc * nr * batch * 12);
-    if (int e = launch_smooth_grad(c->stream, a, batch, u8_input ? 3 : 2))
+    if (int e = launch_smooth_grad(c->work, a, batch, u8_input ? 3 : 2))
         return fail(c, KLT_ERR_DEVICE, std::string("gradient launch: ") + hipGetErrorString((hipError_t)e));
     return 0;
 }
@@ -495,6 +515,22 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
     if (int rc = check_ready(c)) return rc;
     if (!slot_ids || n <= 0) return fail(c, KLT_ERR_ARG, "empty slot list");
     HIPCHK(c, hipSetDevice(c->device));
+    // KLT_OPT_BUILD_STREAM: the whole build goes to the build stream, behind everything enqueued on the main stream so far (the
+    // earlier readers of these slots, synchronous uploads) -- one event each way per build.  The generic two-pass kernels share
+    // scratch with the selection, so they stay on the main stream.
+    struct WorkScope {
+        klt_ctx *c;
+        ~WorkScope() { c->work = c->stream; }
+    } work_scope{c};
+    const bool on_bstream = c->build_stream_on && c->use_fused && fused_smooth_ok(c) && fused_grad_ok(c) && fused_reduce_ok(c);
+    if (on_bstream) {
+        if (!c->bstream) HIPCHK(c, hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking));
+        hipEvent_t mark;
+        if (int rc = fresh_event(c, &mark)) return rc;
+        HIPCHK(c, hipEventRecord(mark, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->bstream, mark, 0));
+        c->work = c->bstream;
+    }
     std::vector<Slot *> sl((size_t)n);
     for (int i = 0; i < n; i++) {
         if (int rc = get_slot(c, slot_ids[i], &sl[i], false)) return rc;
@@ -502,7 +538,8 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         for (int j = 0; j < i; j++)
             if (sl[j] == sl[i]) return fail(c, KLT_ERR_ARG, "slot listed twice");
         if (int rc = layout_pyramid(c, sl[i])) return rc;
-        if (int rc = wait_upload(c, sl[i])) return rc;      // asynchronous ingest: the frame must have landed
+        if (int rc = wait_upload(c, sl[i], c->work)) return rc;      // asynchronous ingest: the frame must have landed
+        if (!on_bstream) { if (int rc = wait_built(c, sl[i])) return rc; }
     }
     const int ss = c->p.subsampling;
     // groups of frames with the same geometry and input type share launches
@@ -565,7 +602,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                 a.src_nr = ls.nr; a.nc = ld.nc; a.nr = ld.nr; a.hnext_nc = more ? s0->lv[l + 1].nc : 0;
                 // algorithmic bytes: the level's output (4 N_l) + its gradients (12 N_l) + the next reduction's input (4 N_l)
                 TimerScope t(c, F_PYR_REDUCE, (double)B * ld.nc * ld.nr * (4.0 + 12.0 + (more ? 4.0 : 0.0)));
-                if (int e = launch_pyr_level(c->stream, a, B, more))
+                if (int e = launch_pyr_level(c->work, a, B, more))
                     return fail(c, KLT_ERR_DEVICE, std::string("pyr_level launch: ") + hipGetErrorString((hipError_t)e));
                 hoff += plane * B;
             }
@@ -586,22 +623,22 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                     const size_t plane = (size_t)ls.nr * ld.nc;
                     for (int b = 0; b < B; b++) a.src[b] = c->h1 + plane * b;
                     TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ld.nc * ld.nr));
-                    if (int e = launch_pyr_vreduce(c->stream, a, B))
+                    if (int e = launch_pyr_vreduce(c->work, a, B))
                         return fail(c, KLT_ERR_DEVICE, std::string("pyr_vreduce launch: ") + hipGetErrorString((hipError_t)e));
                 } else {
                     TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ls.nc * ls.nr + (double)ld.nc * ld.nr));
-                    if (int e = launch_pyr_reduce(c->stream, a, B))
+                    if (int e = launch_pyr_reduce(c->work, a, B))
                         return fail(c, KLT_ERR_DEVICE, std::string("pyr_reduce launch: ") + hipGetErrorString((hipError_t)e));
                 }
             } else {
                 for (int b = 0; b < B; b++) {
                     {
                         TimerScope t(c, F_PYR_H, 4.0 * ((double)ls.nc * ls.nr + (double)ld.nc * ls.nr));
-                        launch_hconv_f32(c->stream, g[b]->lv[l - 1].img, ls.nc, ls.nr, c->tmpA, nullptr, ld.nc, ss, ss / 2, c->gauss[1], nullptr);
+                        launch_hconv_f32(c->work, g[b]->lv[l - 1].img, ls.nc, ls.nr, c->tmpA, nullptr, ld.nc, ss, ss / 2, c->gauss[1], nullptr);
                     }
                     {
                         TimerScope t(c, F_PYR_V, 4.0 * ((double)ld.nc * ls.nr + (double)ld.nc * ld.nr));
-                        launch_vconv(c->stream, c->tmpA, nullptr, ld.nc, ls.nr, g[b]->lv[l].img, nullptr, ld.nr, ss, ss / 2, c->gauss[1], nullptr);
+                        launch_vconv(c->work, c->tmpA, nullptr, ld.nc, ls.nr, g[b]->lv[l].img, nullptr, ld.nr, ss, ss / 2, c->gauss[1], nullptr);
                     }
                 }
             }
@@ -629,13 +666,20 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
             a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
             a.ncols = s0->lv[1].nc; a.nrows = s0->lv[1].nr; a.R = grad_radius(c);
             TimerScope t(c, F_GRAD, bytes);
-            if (int er = launch_smooth_grad(c->stream, a, e, 2))
+            if (int er = launch_smooth_grad(c->work, a, e, 2))
                 return fail(c, KLT_ERR_DEVICE, std::string("gradient launch: ") + hipGetErrorString((hipError_t)er));
         }
         for (Slot *s : g) s->pyr_valid = true;
     }
     // the next asynchronous copy into these slots waits for this build
-    if (int rc = mark_consumed(c, sl.data(), n)) return rc;
+    if (int rc = mark_consumed(c, sl.data(), n, c->work)) return rc;
+    if (on_bstream) {
+        hipEvent_t e;
+        uint64_t serial;
+        if (int rc = fresh_event(c, &e, &serial)) return rc;
+        HIPCHK(c, hipEventRecord(e, c->bstream));
+        for (Slot *s : sl) { s->ev_built = e; s->built_serial = serial; s->built_pending = true; }
+    }
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -681,6 +725,7 @@ int klt_create(int device, klt_ctx **out)
         delete c;
         return KLT_ERR_DEVICE;
     }
+    c->work = c->stream;
     if (const char *v = getenv("KLT_FUSED_HREDUCE")) c->fuse_hreduce = atoi(v) != 0;      // experiment hook (initial value of the option)
     if (const char *v = getenv("KLT_TRACK_XCD_ORDER")) c->track_xcd_order = atoi(v) != 0;
     if (const char *v = getenv("KLT_FUSED_LEVELS")) c->fuse_levels = atoi(v) != 0;
@@ -694,6 +739,7 @@ void klt_destroy(klt_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
+    if (c->bstream) { hipStreamSynchronize(c->bstream); hipStreamDestroy(c->bstream); }
     if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
     for (void *p : c->pinned) hipHostFree(p);
     for (hipEvent_t e : c->ring) hipEventDestroy(e);
@@ -716,6 +762,7 @@ int klt_sync(klt_ctx *c)
 {
     if (!c) return KLT_ERR_ARG;
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
+    if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->comm) { std::string err; if (int rc = comm_wait(c->comm, err)) return fail(c, rc, err); }
     return KLT_OK;
@@ -860,6 +907,11 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_FUSED_HREDUCE) { c->fuse_hreduce = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TRACK_XCD_ORDER) { c->track_xcd_order = value != 0; return KLT_OK; }
     if (option == KLT_OPT_FUSED_LEVELS) { c->fuse_levels = value != 0; return KLT_OK; }
+    if (option == KLT_OPT_BUILD_STREAM) {
+        if (!value && c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));      // pending builds finish; their events stay valid
+        c->build_stream_on = value != 0;
+        return KLT_OK;
+    }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_PARALLEL_NMS) { c->use_mis = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_AFFINE_STATE) {
@@ -1010,10 +1062,12 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     const float *img, *gx, *gy;
     if (use_pyramid) {
         if (!s->pyr_valid) return fail(c, KLT_ERR_STATE, "use_pyramid requested but the slot's pyramids are not built");
+        if (int rc = wait_built(c, s)) return rc;
         img = s->lv[0].img; gx = s->lv[0].gx; gy = s->lv[0].gy;
     } else {
         if (s->raw_kind == 0) return fail(c, KLT_ERR_STATE, "slot has no frame");
-        if (int rc = wait_upload(c, s)) return rc;
+        if (int rc = wait_upload(c, s, c->stream)) return rc;
+        if (int rc = wait_built(c, s)) return rc;              // a build of this slot may still read the raw frame's buffers
         bool grads_done = false;
         if (p.smoothBeforeSelecting && fused_smooth_ok(c)) {
             const void *raw = s->raw_kind == 1 ? (const void *)s->u8 : (const void *)s->f32;
@@ -1039,7 +1093,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
         }
         gx = c->sel_gx; gy = c->sel_gy;
         // the kernels above read the raw frame: the second-next asynchronous copy into this slot (its raw buffers alternate) waits
-        if (int rc = mark_consumed(c, &s, 1)) return rc;
+        if (int rc = mark_consumed(c, &s, 1, c->stream)) return rc;
     }
     c->last_sel[0] = img; c->last_sel[1] = gx; c->last_sel[2] = gy;
     c->sel_nc = nc; c->sel_nr = nr; c->sel_nx = nx; c->sel_ny = ny; c->sel_npow2 = (int)npow2;
@@ -1326,6 +1380,8 @@ static int check_pair(klt_ctx *c, int slot1, int slot2, Slot **p1, Slot **p2)
     if (int rc = get_slot(c, slot2, p2, false)) return rc;
     Slot *s1 = *p1, *s2 = *p2;
     if (!s1->pyr_valid || !s2->pyr_valid) return fail(c, KLT_ERR_STATE, "pyramids of both slots must be built before tracking");
+    if (int rc = wait_built(c, s1)) return rc;
+    if (int rc = wait_built(c, s2)) return rc;
     if (s1->nc != s2->nc || s1->nr != s2->nr || s1->nlev != s2->nlev || s1->ss != s2->ss)
         return fail(c, KLT_ERR_ARG, "the two frames differ in size");            // trackFeatures.py:156-159, :217
     return 0;
@@ -1678,6 +1734,7 @@ int klt_download_f32(klt_ctx *c, int slot, int pyramid, int level, float *dst)
     const Level &l = s->lv[level];
     const float *src = pyramid == 0 ? l.img : (pyramid == 1 ? l.gx : l.gy);
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = wait_built(c, s)) return rc;
     HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)l.nc * l.nr * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return KLT_OK;

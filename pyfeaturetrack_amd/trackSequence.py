@@ -20,16 +20,22 @@ _MAX_FRAMES = 65535 - _FB_ROW0
 _OPT_SELECT_AFFINE_STATE = 4
 
 
-def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True):
+_OPT_BUILD_STREAM = 15
+
+
+def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True, prefetch=True):
     """Track `nFeatures` features through `frames` (an iterable of equally sized 8-bit images) and return the
     KLT_FeatureTable: row 0 = the selected features, row k = the features after tracking frame k-1 -> k (and, with
     `replace_lost`, after replacing the lost ones on frame k: new features carry their eigenvalue in `val`, as after
-    KLTReplaceLostFeatures).  tc.affineConsistencyCheck >= 0 runs the affine check on every step."""
+    KLTReplaceLostFeatures).  tc.affineConsistencyCheck >= 0 runs the affine check on every step.
+    `prefetch`: the pyramids of frame k+1 are built on a second HIP stream (KLT_OPT_BUILD_STREAM) while frame k is tracked and its
+    lost features are replaced -- same results, the frames then live in a ring of three slots."""
     frames = iter(frames)
     _fix_window(tc)
     ctx = default_context()
     ctx.configure(tc)
-    s = list(_slots_of(tc)[:2])
+    s = list(_slots_of(tc))              # ring of three frame slots (the third is otherwise the per-frame API's selection slot)
+    ring = 3 if prefetch else 2
     first = image_to_array(next(frames))
     rows = [first]
     nrows, ncols = first.shape
@@ -51,7 +57,7 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
             tables.append(base)
         return tables[ci] + 1 + off
 
-    stage = ctx.staging((nrows, ncols)) if async_ingest and first.dtype == np.uint8 else None
+    stage = ctx.staging((nrows, ncols), count=ring) if async_ingest and first.dtype == np.uint8 else None
 
     def ingest(slot, img, k):
         if img.shape != (nrows, ncols):
@@ -61,7 +67,7 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
         if stage is None or img.dtype != np.uint8:
             ctx.upload(slot, img)
         else:
-            buf = stage[k % 2]
+            buf = stage[k % len(stage)]
             ctx.upload_wait()               # the copy that last read this staging buffer has finished (kernels keep running)
             buf[...] = img
             ctx.upload_async(slot, buf)
@@ -79,17 +85,33 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
     try:
         if affine:
             ctx.set_option(_OPT_SELECT_AFFINE_STATE, state)
-        for k, img in enumerate(frames, start=1):
-            cur, prev = s[k % 2], s[(k - 1) % 2]
-            ingest(cur, image_to_array(img), k)
-            ctx.build_pyramids(cur, sync=False)
+        if prefetch:
+            ctx.set_option(_OPT_BUILD_STREAM, 1)
+
+        def stage_frame(k, img):                     # upload + pyramid build of frame k (enqueued only)
+            ingest(s[k % ring], image_to_array(img), k)
+            ctx.build_pyramids(s[k % ring], sync=False)
+
+        nxt = next(frames, None)
+        if nxt is not None:
+            stage_frame(1, nxt)
+        while nxt is not None:
+            k += 1
+            nxt = next(frames, None)
+            if nxt is not None and prefetch:
+                stage_frame(k + 1, nxt)              # before frame k's tracker: the build stream overlaps it
+            cur, prev = s[k % ring], s[(k - 1) % ring]
             if affine:
                 ctx.track_affine_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures, state)
             else:
                 ctx.track_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures)
             if replace_lost:
                 ctx.select_async(cur, REPLACING_SOME, True, row_fb(k), nFeatures)
+            if nxt is not None and not prefetch:
+                stage_frame(k + 1, nxt)
     finally:
+        if prefetch:
+            ctx.set_option(_OPT_BUILD_STREAM, 0)
         if affine:
             ctx.set_option(_OPT_SELECT_AFFINE_STATE, -1)
             ctx.release_affine_state(state)
@@ -103,9 +125,9 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
     if tc.sequentialMode:
         # leave the context as the per-frame API would: the last frame's pyramids are "frame 1" of the next call
         from .trackFeatures import _ResidentPyramids
-        last = s[(nframes - 1) % 2]
+        last = s[(nframes - 1) % ring]
         if last != s[0]:
-            ctx.swap_slots(s[0], s[1])
+            ctx.swap_slots(s[0], last)
         tc.pyramid_last = _ResidentPyramids(s[0], ncols, nrows, "img")
         tc.pyramid_last_gradx = _ResidentPyramids(s[0], ncols, nrows, "gradx")
         tc.pyramid_last_grady = _ResidentPyramids(s[0], ncols, nrows, "grady")

@@ -1180,3 +1180,33 @@ def test_slots_and_affine_states_are_recycled():
         assert not ctx.__dict__.get("_affine_states")
     finally:
         sgf.KLT_verbose = 1
+
+
+def test_build_stream_prefetch_keeps_results(ko):
+    """KLT_OPT_BUILD_STREAM: pyramids of frame k+1 built on a second HIP stream while frame k is tracked and replaced (ring of three
+    slots, one event each way per frame) -- the same table as with everything on one stream, with and without asynchronous ingest,
+    and slots rewritten while earlier work may still be queued."""
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.trackSequence import KLTTrackSequence
+    w, h, n, nf = 640, 480, 800, 9
+    base = synth.synth_base(w, h, 21)
+    frames = [synth.synth_frame(w, h, 21, k, shift=(2.1, 1.2), base=base) for k in range(nf)]
+
+    def make():
+        tc = KLT_TrackingContext()
+        tc.sequentialMode = True
+        tc.max_residue = 10.0
+        return tc
+
+    sgf.KLT_verbose = 0
+    try:
+        ref = KLTTrackSequence(make(), frames, n, prefetch=False)
+        for ingest in (True, False):
+            for _ in range(2):
+                got = KLTTrackSequence(make(), (f for f in frames), n, prefetch=True, async_ingest=ingest)
+                assert np.array_equal(got.rec, ref.rec), "prefetching builds changed the feature table (ingest=%s)" % ingest
+        assert (ref.val[-1] >= 0).sum() > n // 2
+    finally:
+        sgf.KLT_verbose = 1
