@@ -194,6 +194,8 @@ class Ranks:
 
     def __init__(self, args):
         self.rank, self.local_rank, self.world = parallel.world_from_env()
+        if os.environ.get("KLT_RANKS_SHARE_DEVICE") is not None:      # test hook: several ranks on one GPU (a one-GPU box)
+            self.local_rank = int(os.environ["KLT_RANKS_SHARE_DEVICE"])
         if self.world != args.gpus and self.world > 1:
             print("warning: WORLD_SIZE=%d but --gpus %d" % (self.world, args.gpus), file=sys.stderr)
         self.distributed = self.world > 1 or os.environ.get("KLT_FORCE_DIST") == "1"   # the env var exercises the RCCL path on one GPU

@@ -93,7 +93,6 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
 #define KLT_OPT_TRACK_VARIANT 11         /* 4 (default): quad-load tracker kernels (7x7: four features per wavefront; 15x15: one 16-byte load per lane and image); 0: plain one-feature-per-wavefront kernel for every window (same records; process-wide) */
 #define KLT_OPT_FUSED_HREDUCE 12         /* 1 (default): the level-0 kernel also runs the horizontal pass of the first pyramid reduction (subsampling 4); 0: separate reduction kernel */
 #define KLT_OPT_TRACK_XCD_ORDER 13        /* 1 (default): features are handed to the tracker sorted by row, one band of the image per XCD (single-pair and batched launches; the order is refreshed every 64 launches); 0: list order */
-#define KLT_OPT_FUSED_LEVELS 14           /* 1: every pyramid level >= 1 is ONE launch (vertical reduction from the previous level's H planes + gradients + next H planes; needs KLT_OPT_FUSED_HREDUCE, subsampling 4); 0: separate reduction and gradient launches */
 /* 1: pyramid builds are enqueued on a second HIP stream of the context (a second hardware queue), behind everything enqueued on
  * the main stream so far; trackers / selections / uploads that touch a slot wait (on the device) for the build that fills it.
  * A sequence can then enqueue the build of frame t+1 BEFORE the tracker and the replacement pass of frame t and the GPU overlaps

@@ -85,7 +85,6 @@ struct klt_ctx {
     float *h1 = nullptr;                      // H1 planes of the fused first reduction (one per frame of a batch)
     size_t h1_cap = 0;
     bool fuse_hreduce = true;                 // KLT_OPT_FUSED_HREDUCE
-    bool fuse_levels = false;                 // KLT_OPT_FUSED_LEVELS
     bool track_xcd_order = true;              // KLT_OPT_TRACK_XCD_ORDER
     uint32_t *track_order = nullptr;
     size_t track_order_cap = 0;
@@ -468,7 +467,7 @@ bool fused_reduce_ok(const klt_ctx *c) { return c->use_fused && pyr_reduce_lds_b
 // *fused_h1 (optional, in/out): in = the caller wants the horizontal pass of the first reduction fused into this launch; out =
 // whether it was (then c->h1 holds one H1 plane of nr x (nc / ss) floats per frame)
 int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int raw_kind, float *const *img,
-                              float *const *gx, float *const *gy, int nc, int nr, bool *fused_h1 = nullptr, size_t h_extra = 0)
+                              float *const *gx, float *const *gy, int nc, int nr, bool *fused_h1 = nullptr)
 {
     SmoothGradArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -479,7 +478,7 @@ int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int
     bool hred = fused_h1 && *fused_h1 && c->fuse_hreduce && smooth_grad_hred_ok(a, batch, kind, c->gauss[1], c->p.subsampling);
     if (hred) {
         const size_t plane = (size_t)nr * (nc / c->p.subsampling);
-        if (int rc = ensure_h1(c, plane * batch + h_extra)) return rc;
+        if (int rc = ensure_h1(c, plane * batch)) return rc;
         a.reduce = c->gauss[1];
         a.h1_nc = nc / c->p.subsampling;
         for (int b = 0; b < batch; b++) a.h1[b] = c->h1 + plane * b;
@@ -561,20 +560,13 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
 
         // level 0: smoothed frame (trackFeatures.py:165-166) and its gradients (:171-172)
         bool h1_fused = false;              // level 1 comes from the H1 planes written by the level-0 kernel
-        bool levels_fused = false;          // ... and every level >= 1 is one pyr_level_kernel launch
         if (fused_smooth_ok(c)) {
             for (int b = 0; b < B; b++) {
                 raw[b] = g[b]->raw_kind == 1 ? (const void *)g[b]->u8 : (const void *)g[b]->f32;
                 img[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy;
             }
             h1_fused = s0->nlev > 1 && fused_reduce_ok(c);
-            // one launch per level >= 1 (pyr_level_kernel) needs the H planes of every further level behind H1
-            levels_fused = c->fuse_levels && merged_grad_ok(c) && ss == 4 && c->gauss[1].sym == 1 && c->gauss[1].n == 21;
-            size_t h_extra = 0;
-            if (levels_fused)
-                for (int l = 2; l < s0->nlev; l++) h_extra += (size_t)B * s0->lv[l - 1].nr * s0->lv[l].nc;
-            if (int rc = enqueue_fused_smooth_grad(c, B, raw, s0->raw_kind, img, gx, gy, s0->nc, s0->nr, &h1_fused, h_extra)) return rc;
-            levels_fused = levels_fused && h1_fused;
+            if (int rc = enqueue_fused_smooth_grad(c, B, raw, s0->raw_kind, img, gx, gy, s0->nc, s0->nr, &h1_fused)) return rc;
         } else {
             for (int b = 0; b < B; b++) {
                 enqueue_smooth_raw(c, g[b], g[b]->lv[0].img);
@@ -583,30 +575,6 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         }
         // levels 1..L-1: smooth with the pyramid sigma, keep pixel (ss*y + ss/2, ss*x + ss/2) (pyramid.py:59-72),
         // then the gradients of the new level.  Only surviving columns / rows are evaluated.
-        if (levels_fused) {
-            size_t hoff = 0;                                    // H planes of level l start here in c->h1
-            for (int l = 1; l < s0->nlev; l++) {
-                const Level &ls = s0->lv[l - 1];
-                const Level &ld = s0->lv[l];
-                const size_t plane = (size_t)ls.nr * ld.nc;
-                const bool more = l + 1 < s0->nlev;
-                const size_t plane_next = more ? (size_t)ld.nr * s0->lv[l + 1].nc : 0;
-                LevelArgs a;
-                std::memset(&a, 0, sizeof(a));
-                for (int b = 0; b < B; b++) {
-                    a.hsrc[b] = c->h1 + hoff + plane * b;
-                    a.img[b] = g[b]->lv[l].img; a.gx[b] = g[b]->lv[l].gx; a.gy[b] = g[b]->lv[l].gy;
-                    a.hnext[b] = more ? c->h1 + hoff + plane * B + plane_next * b : nullptr;
-                }
-                a.reduce = c->gauss[1]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
-                a.src_nr = ls.nr; a.nc = ld.nc; a.nr = ld.nr; a.hnext_nc = more ? s0->lv[l + 1].nc : 0;
-                // algorithmic bytes: the level's output (4 N_l) + its gradients (12 N_l) + the next reduction's input (4 N_l)
-                TimerScope t(c, F_PYR_REDUCE, (double)B * ld.nc * ld.nr * (4.0 + 12.0 + (more ? 4.0 : 0.0)));
-                if (int e = launch_pyr_level(c->work, a, B, more))
-                    return fail(c, KLT_ERR_DEVICE, std::string("pyr_level launch: ") + hipGetErrorString((hipError_t)e));
-                hoff += plane * B;
-            }
-        } else
         for (int l = 1; l < s0->nlev; l++) {
             const Level &ls = s0->lv[l - 1];
             const Level &ld = s0->lv[l];
@@ -651,7 +619,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                 for (int b = 0; b < B; b++) enqueue_gradients(c, g[b]->lv[l].img, ld.nc, ld.nr, g[b]->lv[l].gx, g[b]->lv[l].gy);
             }
         }
-        if (!levels_fused && s0->nlev > 1 && fused_grad_ok(c) && merged_grad_ok(c) && B * (s0->nlev - 1) <= KLT_MAX_BATCH && s0->nc / s0->ss <= 32767 && s0->nr / s0->ss <= 32767) {
+        if (s0->nlev > 1 && fused_grad_ok(c) && merged_grad_ok(c) && B * (s0->nlev - 1) <= KLT_MAX_BATCH && s0->nc / s0->ss <= 32767 && s0->nr / s0->ss <= 32767) {
             // one launch for the gradients of every level >= 1 of every frame: entry = (frame, level), per-entry geometry
             SmoothGradArgs a;
             std::memset(&a, 0, sizeof(a));
@@ -728,7 +696,6 @@ int klt_create(int device, klt_ctx **out)
     c->work = c->stream;
     if (const char *v = getenv("KLT_FUSED_HREDUCE")) c->fuse_hreduce = atoi(v) != 0;      // experiment hook (initial value of the option)
     if (const char *v = getenv("KLT_TRACK_XCD_ORDER")) c->track_xcd_order = atoi(v) != 0;
-    if (const char *v = getenv("KLT_FUSED_LEVELS")) c->fuse_levels = atoi(v) != 0;
     *out = c;
     return KLT_OK;
 }
@@ -906,7 +873,6 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_TRACK_VARIANT) { g_track_variant = value; return KLT_OK; }
     if (option == KLT_OPT_FUSED_HREDUCE) { c->fuse_hreduce = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TRACK_XCD_ORDER) { c->track_xcd_order = value != 0; return KLT_OK; }
-    if (option == KLT_OPT_FUSED_LEVELS) { c->fuse_levels = value != 0; return KLT_OK; }
     if (option == KLT_OPT_BUILD_STREAM) {
         if (!value && c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));      // pending builds finish; their events stay valid
         c->build_stream_on = value != 0;

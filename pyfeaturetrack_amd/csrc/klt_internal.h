@@ -37,16 +37,6 @@ struct PyrReduceArgs {
     int src_nc, src_nr, dst_nc, dst_nr, ss, log2ss;
 };
 
-// One pyramid level >= 1 in one launch (pyr_level_kernel): level image = vertical reduction of the H planes the previous level's
-// kernel wrote, its gradients, and (optionally) the H planes for the next level.
-struct LevelArgs {
-    const float *hsrc[KLT_MAX_BATCH];   // H planes of this level: [src_nr rows of the previous level][nc columns of this level]
-    float *img[KLT_MAX_BATCH], *gx[KLT_MAX_BATCH], *gy[KLT_MAX_BATCH];
-    float *hnext[KLT_MAX_BATCH];        // H planes for the next level: [nr][hnext_nc]; null: none
-    Taps reduce, ggauss, gderiv;
-    int src_nr, nc, nr, hnext_nc;
-};
-
 struct TrackLevel {
     const float *i1, *gx1, *gy1, *i2, *gx2, *gy2;
     int nc, nr;
@@ -140,7 +130,6 @@ size_t pyr_reduce_lds_bytes(int ss, int ntaps);
 int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int kind, bool hred = false);
 bool smooth_grad_hred_ok(const SmoothGradArgs &a, int batch, int kind, const Taps &reduce, int ss);
 int launch_pyr_vreduce(hipStream_t s, const PyrReduceArgs &a, int batch);
-int launch_pyr_level(hipStream_t s, const LevelArgs &a, int batch, bool emit_hnext);   // subsampling 4, 21 / 7 / 7 taps   // level 1 from the H1 planes (src = H1, src_nr rows x dst_nc columns)
 int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch);
 
 void launch_sat_rows(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows);

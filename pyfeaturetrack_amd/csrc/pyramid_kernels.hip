@@ -732,231 +732,9 @@ __global__ __launch_bounds__(256) void pyr_vreduce_kernel(PyrReduceArgs a)
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// One pyramid level >= 1 per launch (subsampling 4): image(y, x) = V(H)(4 y + 2, x) from the H planes the previous level's kernel
-// wrote (smooth_grad_rb<..., HRED> for level 1, this kernel for the others), then the level's gradients from the tile in LDS,
-// then -- HRED -- the horizontal pass of the NEXT reduction on the same tile.  Replaces pyr_vreduce / pyr_reduce_fast + the
-// separate gradient launch: a level costs one launch, and the level image is never re-read from HBM.
-// The tile is addressed in virtual coordinates; element (y, x) holds image[R(y)][R(x)] (R = the reflect map), which is what
-// scipy's `reflect` mode reads for the gradients and for the next reduction.  Same FP64 expressions and order as the separate
-// kernels.
-// (512 threads per 64x16 tile and at most 128 VGPRs: two workgroups fit a CU, so the 272 tiles of a 1080p pair's level 1 are all
-// resident at once -- with 1024 threads the last 16 tiles made a second round)
-template <bool HRED, int NTHR = 512>
-__global__ __launch_bounds__(NTHR) void pyr_level_kernel(LevelArgs a)
-{
-    constexpr int SS = 4, NR = 21, HR = NR / 2, NG = 7, ND = 7, R = 3, TH_ = 16;
-    constexpr int HB = HRED ? 12 : 4, BW = TW + 2 * HB, BQ = BW / 4, DW = TW, DQ = DW / 4;
-    constexpr int IH = TH_ + 2 * R;                              // 22 image rows per tile
-    constexpr int SH = (IH - 1) * SS + NR;                       // 105 H rows feed them
-    constexpr int DE = 2 * IH * DW;
-    __shared__ __attribute__((aligned(16))) float lds[SH * BW + IH * BW];
-    float *const S = lds, *const D = lds, *const E = lds + IH * DW, *const C = lds + SH * BW;
-    static_assert(DE <= SH * BW, "D / E overlay the staging tile");
-    const int tid = threadIdx.x, b = blockIdx.z;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
-    const int nc = a.nc, nr = a.nr, snr = a.src_nr;
-    const float *__restrict__ hs = a.hsrc[b];
-    TapRegs<HR + 1> kr;
-#pragma unroll
-    for (int t = 0; t <= HR; t++) kr.k[t] = a.reduce.k[t];
-
-    STAGE_MARK(0);
-    // image rows this tile really needs (after reflection) and the H rows under them
-    // Rows above the frame reflect to rows 0 .. R-1 (the tile then starts at row 0), rows below it -- as far as a stored output
-    // reads them, i.e. up to nr - 1 + R -- to rows nr - R .. nr - 1 >= ty0 - R: all inside [y_first, y_last].  Tile rows further
-    // out feed only outputs beyond the frame; they get 0.
-    const int y_first = max(min(ty0 - R, nr - 1), 0), y_last = min(ty0 + TH_ + R - 1, nr - 1);
-    const int srow0 = SS * y_first + SS / 2 - HR;                // first staged H row (virtual)
-    const int nstage = min(SS * (y_last - y_first) + NR, SH);    // staged H rows
-    // ---- stage 0: H rows -> LDS (rows and columns through the reflect maps)
-    __shared__ int ymap[IH];                                     // image row under each tile row (an integer division per entry)
-    if (tid < IH) ymap[tid] = reflect_idx(ty0 - R + tid, nr);
-    {
-        const bool interior = (nc & 3) == 0 && tx0 - HB >= 0 && tx0 - HB + BW <= nc && srow0 >= 0 && srow0 + nstage <= snr;
-        if (interior) {
-            constexpr int U = (SH * BQ + NTHR - 1) / NTHR;
-            const int nq = nstage * BQ;
-            float4 v[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = min(tid + u * NTHR, nq - 1);
-                v[u] = *reinterpret_cast<const float4 *>(hs + (size_t)(srow0 + i / BQ) * nc + (tx0 - HB) + 4 * (i % BQ));
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = tid + u * NTHR;
-                if (i < nq) *reinterpret_cast<float4 *>(S + (size_t)i * 4) = v[u];
-            }
-        } else {
-            // frame-edge tiles (every tile of a small level): reflected element loads, all of a thread's loads in flight
-            // together (a load -> store loop pays one memory round trip per iteration: 36 of them here)
-            constexpr int UE = (SH * BW + NTHR - 1) / NTHR;
-            const int ne = nstage * BW;
-            const bool single = nc >= 2 * BW && snr >= 2 * SH;
-            float v[UE];
-#pragma unroll
-            for (int u = 0; u < UE; u++) {
-                const int i = min(tid + u * NTHR, ne - 1);
-                const int sr = srow0 + i / BW, sc = tx0 - HB + i % BW;
-                // one reflection is enough for levels larger than the tile (the usual case): selects, no division
-                const int rr1 = single ? (sr < 0 ? -1 - sr : sr >= snr ? 2 * snr - 1 - sr : sr) : reflect_idx(sr, snr);
-                const int cc1 = single ? (sc < 0 ? -1 - sc : sc >= nc ? 2 * nc - 1 - sc : sc) : reflect_idx(sc, nc);
-                v[u] = hs[(size_t)rr1 * nc + cc1];
-            }
-#pragma unroll
-            for (int u = 0; u < UE; u++) {
-                const int i = tid + u * NTHR;
-                if (i < ne) S[i] = v[u];
-            }
-        }
-    }
-    __syncthreads();
-    STAGE_MARK(1);
-    // ---- stage 1: vertical pass -> image tile C (virtual coordinates), interior stored.  A thread makes two vertically adjacent
-    // elements of a column: where the second row is simply the next image row (everywhere but across a reflected border) the two
-    // windows share 17 of their 21 H rows, which are read and widened once.
-    {
-        float *__restrict__ img = a.img[b];
-        static_assert(IH % 2 == 0, "row pairs");
-        for (int i = tid; i < (IH / 2) * BW; i += NTHR) {
-            const int r = 2 * (i / BW), c = i % BW;
-            const int y0 = ymap[r], y1 = ymap[r + 1];
-            const bool ok0 = y0 >= y_first && y0 <= y_last, ok1 = y1 >= y_first && y1 <= y_last;
-            float val0 = 0.f, val1 = 0.f;
-            if (ok0 && ok1 && y1 == y0 + 1) {
-                const float *col = S + (SS * (y0 - y_first)) * BW + c;
-                double v[NR + SS];
-#pragma unroll
-                for (int j = 0; j < NR + SS; j++) v[j] = (double)col[j * BW];
-                double a0 = v[HR] * kr.k[HR], a1 = v[HR + SS] * kr.k[HR];
-#pragma unroll
-                for (int jj = -HR; jj < 0; jj++) {
-                    a0 = a0 + (v[HR + jj] + v[HR - jj]) * kr.k[HR + jj];
-                    a1 = a1 + (v[HR + SS + jj] + v[HR + SS - jj]) * kr.k[HR + jj];
-                }
-                val0 = (float)a0;
-                val1 = (float)a1;
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int y = h ? y1 : y0;
-                    if (h ? ok1 : ok0) {
-                        const float *col = S + (SS * (y - y_first)) * BW + c;
-                        double v[NR];
-#pragma unroll
-                        for (int j = 0; j < NR; j++) v[j] = (double)col[j * BW];
-                        double acc = v[HR] * kr.k[HR];
-#pragma unroll
-                        for (int jj = -HR; jj < 0; jj++) acc = acc + (v[HR + jj] + v[HR - jj]) * kr.k[HR + jj];
-                        (h ? val1 : val0) = (float)acc;
-                    }
-                }
-            }
-            C[r * BW + c] = val0;
-            C[(r + 1) * BW + c] = val1;
-            const int xx = tx0 - HB + c;
-            if (c >= HB && c < HB + TW && xx < nc) {
-                const int yy = ty0 - R + r;
-                if (r >= R && r < R + TH_ && yy < nr) img[(size_t)yy * nc + xx] = val0;
-                if (r + 1 >= R && r + 1 < R + TH_ && yy + 1 < nr) img[(size_t)(yy + 1) * nc + xx] = val1;
-            }
-        }
-    }
-    __syncthreads();
-    STAGE_MARK(2);
-    TapRegs<NG> kg;
-    TapRegs<ND> kd;
-    load_taps(kg, a.ggauss);
-    load_taps(kd, a.gderiv);
-    // ---- stage 3: horizontal pass of both gradients, C -> D, E (overlaying the staging tile), as in smooth_grad_rb
-    for (int i = tid; i < IH * DQ; i += NTHR) {
-        const int r = i / DQ, q = i % DQ;
-        double v[12];
-        widen12(C + r * BW + 4 * q + (HB - 4), v);
-        float4 d, e;
-        d.x = corr_regs<ND, -1>(v + 4, kd); d.y = corr_regs<ND, -1>(v + 5, kd);
-        d.z = corr_regs<ND, -1>(v + 6, kd); d.w = corr_regs<ND, -1>(v + 7, kd);
-        e.x = corr_regs<NG, 1>(v + 4, kg); e.y = corr_regs<NG, 1>(v + 5, kg);
-        e.z = corr_regs<NG, 1>(v + 6, kg); e.w = corr_regs<NG, 1>(v + 7, kg);
-        *reinterpret_cast<float4 *>(D + r * DW + 4 * q) = d;
-        *reinterpret_cast<float4 *>(E + r * DW + 4 * q) = e;
-    }
-    if (HRED) {
-        // ---- stage 3b: horizontal pass of the next reduction at the surviving columns 4 x + 2 of the tile's own rows
-        float *__restrict__ hn = a.hnext[b];
-        const int hn_nc = a.hnext_nc;
-        for (int i = tid; i < TH_ * DQ; i += NTHR) {
-            const int r = i / DQ, xs = i % DQ;
-            typedef const volatile __attribute__((address_space(3))) f32x4 *lds_quad_ptr;
-            const lds_quad_ptr p = (lds_quad_ptr)(C + (r + R) * BW + 4 * xs + (HB - 8));
-            double v[24];
-#pragma unroll
-            for (int u = 0; u < 6; u++) {
-                const f32x4 t = p[u];
-                v[4 * u] = (double)t.x; v[4 * u + 1] = (double)t.y; v[4 * u + 2] = (double)t.z; v[4 * u + 3] = (double)t.w;
-            }
-            double acc = v[HR] * kr.k[HR];
-#pragma unroll
-            for (int jj = -HR; jj < 0; jj++) acc = acc + (v[HR + jj] + v[HR - jj]) * kr.k[HR + jj];
-            const int y = ty0 + r, xg = tx0 / 4 + xs;
-            if (y < nr && xg < hn_nc) hn[(size_t)y * hn_nc + xg] = (float)acc;
-        }
-    }
-    __syncthreads();
-    STAGE_MARK(3);
-    STAGE_MARK(4);
-    // ---- stage 4: vertical pass, D -> gradx, E -> grady
-    float *__restrict__ gxo = a.gx[b];
-    float *__restrict__ gyo = a.gy[b];
-    for (int i = tid; i < (TH_ / 2) * DQ; i += NTHR) {
-        const int r = 2 * (i / DQ), q = i % DQ;
-        const int x = tx0 + 4 * q;
-        if (ty0 + r >= nr || x >= nc) continue;
-        float4 ox[2], oy[2];
-        {
-            double v[4][NG + 1];
-#pragma unroll
-            for (int j = 0; j < NG + 1; j++) {
-                const float4 t = *reinterpret_cast<const float4 *>(D + (r + R - NG / 2 + j) * DW + 4 * q);
-                v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
-            }
-#pragma unroll
-            for (int dr = 0; dr < 2; dr++) {
-                ox[dr].x = corr_regs<NG, 1>(v[0] + NG / 2 + dr, kg); ox[dr].y = corr_regs<NG, 1>(v[1] + NG / 2 + dr, kg);
-                ox[dr].z = corr_regs<NG, 1>(v[2] + NG / 2 + dr, kg); ox[dr].w = corr_regs<NG, 1>(v[3] + NG / 2 + dr, kg);
-            }
-        }
-        {
-            double v[4][ND + 1];
-#pragma unroll
-            for (int j = 0; j < ND + 1; j++) {
-                const float4 t = *reinterpret_cast<const float4 *>(E + (r + R - ND / 2 + j) * DW + 4 * q);
-                v[0][j] = (double)t.x; v[1][j] = (double)t.y; v[2][j] = (double)t.z; v[3][j] = (double)t.w;
-            }
-#pragma unroll
-            for (int dr = 0; dr < 2; dr++) {
-                oy[dr].x = corr_regs<ND, -1>(v[0] + ND / 2 + dr, kd); oy[dr].y = corr_regs<ND, -1>(v[1] + ND / 2 + dr, kd);
-                oy[dr].z = corr_regs<ND, -1>(v[2] + ND / 2 + dr, kd); oy[dr].w = corr_regs<ND, -1>(v[3] + ND / 2 + dr, kd);
-            }
-        }
-#pragma unroll
-        for (int dr = 0; dr < 2; dr++) {
-            const int y = ty0 + r + dr;
-            if (y >= nr) break;
-            float *px = gxo + (size_t)y * nc + x, *py = gyo + (size_t)y * nc + x;
-            if (x + 3 < nc) {
-                px[0] = ox[dr].x; px[1] = ox[dr].y; px[2] = ox[dr].z; px[3] = ox[dr].w;
-                py[0] = oy[dr].x; py[1] = oy[dr].y; py[2] = oy[dr].z; py[3] = oy[dr].w;
-            } else {
-                px[0] = ox[dr].x; py[0] = oy[dr].x;
-                if (x + 1 < nc) { px[1] = ox[dr].y; py[1] = oy[dr].y; }
-                if (x + 2 < nc) { px[2] = ox[dr].z; py[2] = oy[dr].z; }
-            }
-        }
-    }
-    STAGE_MARK(5);
-}
+// (A one-launch-per-level kernel -- vertical reduction from the previous level's H planes, the level's gradients and the next
+// level's H planes in one workgroup -- existed in round 1 as KLT_OPT_FUSED_LEVELS: bit-identical, 12 us per level against 5 + 5 + 5
+// for the three small launches, because its phases are serial and latency-bound inside a workgroup.  Removed in round 2.)
 
 }  // namespace
 
@@ -1001,14 +779,6 @@ int launch_pyr_vreduce(hipStream_t s, const PyrReduceArgs &a, int batch)
 {
     const dim3 grid((a.dst_nc + 63) / 64, (a.dst_nr + 15) / 16, batch);
     hipLaunchKernelGGL((pyr_vreduce_kernel<4, 21>), grid, dim3(256), 0, s, a);
-    return 0;
-}
-
-int launch_pyr_level(hipStream_t s, const LevelArgs &a, int batch, bool emit_hnext)
-{
-    const dim3 grid((a.nc + TW - 1) / TW, (a.nr + 15) / 16, batch);
-    if (emit_hnext) hipLaunchKernelGGL((pyr_level_kernel<true, 512>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((pyr_level_kernel<false, 512>), grid, dim3(512), 0, s, a);
     return 0;
 }
 
