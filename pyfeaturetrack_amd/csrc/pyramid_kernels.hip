@@ -802,6 +802,8 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
         if (hred) {
             // (28- / 24- / 20-row tiles -- 32.0 / 28.4 / 24.8 KB of LDS, five / five / six workgroups per CU -- were measured in
             // round 2: 29.9 / 29.9 / 30.4 us event-timed against 28.1 for the 32-row tile: the extra halo work outweighs the occupancy)
+            // (three / two workgroups per CU instead of four -- dynamic LDS padding, same kernel -- read 0.0379 / 0.0382 ms per pair with
+            // three pairs in flight against 0.0365, and 0.0576 against 0.0556 on one stream: round 2)
             if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
             if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
             if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
