@@ -474,6 +474,8 @@ def run_cfg5(args, json_fd):
     if prefetch:
         ctx.set_option(15, 1)
 
+    lost = []
+
     def run_sequence(timed):
         t_sel = 0.0
         if prefetch:
@@ -485,7 +487,7 @@ def run_cfg5(args, json_fd):
                 ctx.build_pyramids(10 + k + 1, sync=False)
             ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)
             if timed:
-                ctx.sync()
+                lost.append(int((ctx.featbuf_download(k % 2, n)["val"] < 0).sum()))      # (synchronises)
                 t = time.perf_counter()
             ctx.select_async(10 + k, 2, True, k % 2, n)       # KLTReplaceLostFeatures on the resident level-0 images
             if timed:
@@ -512,7 +514,7 @@ def run_cfg5(args, json_fd):
                             "features replaced after every frame; per frame: pyramid of the new frame + track + replacement"
                             + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else ""),
                             extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
-                                       "build_stream": bool(prefetch)}))
+                                       "lost_per_frame": lost, "build_stream": bool(prefetch)}))
 
 
 # ================================================================================= launcher dry run

@@ -1197,8 +1197,10 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
                 if (filtered) { sa.hist = c->mis_cnt + off_hist; sa.ticket = c->mis_cnt + off_ticket; sa.info = info_d; sa.hist_target = (unsigned)((target + 3) / 4); }
                 if (filtered && mode == KLT_REPLACING_SOME) {
                     // only the lost features' slots are filled and the live features' squares are not scored at all: 64 candidates per
-                    // LOST feature (at least 65536) instead of 64 per list entry -- most of a frame's candidates never enter the passes
-                    sa.hist_target = 65536 / 4; sa.hist_slots = nfill_d; sa.hist_per_slot = 64 / 4;
+                    // LOST feature (at least 4096) instead of 64 per list entry -- most of a frame's candidates never enter the passes.
+                    // (cfg-5, 50-95 lost of 20000 per frame: a floor of 65536 / 16384 / 4096 / 1024 candidates reads 0.424 / 0.387 /
+                    // 0.365 / 0.364 ms per frame; too tight a cut only costs the repeat below, never the result)
+                    sa.hist_target = 4096 / 4; sa.hist_slots = nfill_d; sa.hist_per_slot = 64 / 4;
                 }
                 TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8));
                 launch_eigen_hist(c->stream, sa);

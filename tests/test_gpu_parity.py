@@ -759,6 +759,32 @@ def test_topk_prefilter_and_its_fallback(ctx, ko):
         assert_feats(fl2, *oracle_feats(ofl), what="full-sort select mindist=%d n=%d" % (mindist, n))
 
 
+def test_replacement_cut_and_its_repeat(ctx, ko):
+    """REPLACING_SOME at 1080p keeps 64 candidates per LOST feature (at least 4096).  Few lost features: the cut holds.  Many lost
+    features under a large minimum distance: the kept candidates run out and the selection repeats with every candidate.  Either way
+    the list equals the reference walk's (selectGoodFeatures.py:45-135, :279-294)."""
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.backend import REPLACING_SOME
+    f0 = synth.synth_frame(1920, 1080, 6, 0)
+    for mindist, n, lose in ((10, 5000, 40), (40, 700, 450), (25, 1500, 1500)):
+        tc = make_tc(levels=3, ss=4, mindist=mindist)
+        ctx.configure(tc)
+        ctx.upload(0, f0)
+        p = params_from_tc(tc)
+        base = ko.select_good_features(p, f0.astype(np.float32), n)
+        live = np.flatnonzero(base["val"] >= 0)
+        rng = np.random.default_rng(mindist)
+        gone = rng.choice(live, min(lose, len(live)), replace=False)
+        fl = base.copy()
+        fl["val"][gone] = -1
+        fl["x"][gone] = -1.0
+        fl["y"][gone] = -1.0
+        want = ko.select_good_features(p, f0.astype(np.float32), n, mode=REPLACING_SOME, fl=fl.copy())
+        got, replaced = ctx.select(0, n, mode=REPLACING_SOME, fl=fl.copy())
+        assert replaced == int(np.count_nonzero((want["val"] >= 0) & (fl["val"] < 0)))
+        assert_feats(got, *oracle_feats(want), what="replace mindist=%d lost=%d of %d" % (mindist, len(gone), n))
+
+
 def test_nms_global_grid_path(ctx, ko):
     """mindist 2 at 1920x1080 -> the cell grid (960x540 u32) exceeds LDS and lives in global memory"""
     from pyfeaturetrack_amd import synth
