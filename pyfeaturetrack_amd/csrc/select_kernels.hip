@@ -689,9 +689,8 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     // equals the window maximum scans the window for an equal neighbour of higher rank (right of it, or below it in
     // the same column).
     extern __shared__ uint32_t lds32[];
-    __shared__ unsigned short acc_local[MIS_CAP], top_local[MIS_CAP];
-    __shared__ unsigned char top_blocked[MIS_CAP];
-    __shared__ unsigned s_cursor, s_acc, s_top;
+    __shared__ unsigned short top_local[MIS_CAP], wait_local[MIS_CAP];
+    __shared__ unsigned s_cursor, s_acc, s_top, s_left;
     const unsigned n = a.cnt[blockIdx.x];
     if (n == 0u) return;
     const unsigned have = a.acc_cnt[blockIdx.x];             // accepted candidates of this tile so far
@@ -705,10 +704,13 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     const bool staged = a.stage && R > 0;
     uint32_t *H = lds32;                      // [W][32]
     uint32_t *S = lds32 + W * MIS_TILE;       // [W][W]
+    // candidates accepted in this pass: at most a.acc_cap per tile (pairwise more than R cells apart), behind the staged tiles
+    // (eight workgroups per CU instead of seven -- 2048 slots for the tiles of a 1080p frame -- were measured this way: no change)
+    unsigned short *acc_local = reinterpret_cast<unsigned short *>(lds32 + (staged ? W * MIS_TILE + W * W : 0));
     const int ox = tx * MIS_TILE - R, oy = ty * MIS_TILE - R;
     uint32_t *list = a.list + (size_t)blockIdx.x * MIS_CAP;
     unsigned next_p = threadIdx.x < n ? list[threadIdx.x] : 0u;           // first batch, in flight during the staging
-    if (threadIdx.x == 0) { s_acc = 0u; s_cursor = 0u; s_top = 0u; }
+    if (threadIdx.x == 0) { s_acc = 0u; s_cursor = 0u; s_top = 0u; s_left = 0u; }
     if (staged) {
         for (int cx0 = 0; cx0 < W; cx0 += 64)
             for (int r0 = 0; r0 < W; r0 += 64) {            // 16 rows per wavefront in flight at once
@@ -726,6 +728,32 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
                 }
             }
         __syncthreads();
+        // H[r][c] = max of S[r][c .. c + 2R].  A thread makes 8 adjacent outputs of a row: their windows share the columns
+        // c0 + 7 .. c0 + L - 1 (one running maximum), output j adds the last 7 - j columns before and the first j columns after that
+        // range -- L + 7 LDS reads for 8 outputs instead of 8 L (the passes are bound by LDS traffic: this loop was 30400 of the
+        // ~37000 LDS accesses a tile costs).
+        if (L >= 8) {
+            for (int it = threadIdx.x; it < W * (MIS_TILE / 8); it += MIS_T) {
+                const int r = it % W, c0 = (it / W) * 8;
+                const uint32_t *row = S + r * W + c0;
+                uint32_t lo[7], hi[7];
+#pragma unroll
+                for (int j = 0; j < 7; j++) { lo[j] = row[j]; hi[j] = row[L + j]; }
+                uint32_t common = row[7];
+#pragma unroll 4
+                for (int k = 8; k < L; k++) common = max(common, row[k]);
+                uint32_t o[8];
+                o[7] = common;
+#pragma unroll
+                for (int j = 6; j >= 0; j--) o[j] = max(o[j + 1], lo[j]);           // + columns c0 + j .. c0 + 6
+                uint32_t m = 0u;
+#pragma unroll
+                for (int j = 1; j < 8; j++) { m = max(m, hi[j - 1]); o[j] = max(o[j], m); }      // + columns c0 + L .. c0 + L + j - 1
+                uint4 *dst = reinterpret_cast<uint4 *>(H + r * MIS_TILE + c0);
+                dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            }
+        } else
         for (int k = threadIdx.x; k < W * MIS_TILE; k += MIS_T) {
             const uint32_t *row = &S[(k / MIS_TILE) * W + (k % MIS_TILE)];     // window = columns c .. c + 2R of the row
             uint32_t m = row[0];
@@ -771,47 +799,43 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
         const bool reject = live && near_accepted;
         const bool wait = live && !near_accepted && blocked;
         const bool accept = live && !near_accepted && !blocked && !top;
+        const unsigned short q = (unsigned short)(ly * MIS_TILE + lx);
         if (reject) a.st[p] = 0u;
-        if (top) {                                       // decided after the loop, by the whole workgroup
-            const unsigned e = atomicAdd(&s_top, 1u);
-            top_local[e] = (unsigned short)(ly * MIS_TILE + lx);
-            top_blocked[e] = 0;
-        }
+        if (top) top_local[atomicAdd(&s_top, 1u)] = q;       // decided after the loop
         if (accept) {
             a.st[p] = sp | 0x80000000u;
-            acc_local[atomicAdd(&s_acc, 1u)] = (unsigned short)(ly * MIS_TILE + lx);
+            acc_local[atomicAdd(&s_acc, 1u)] = q;
         }
-        __syncthreads();                                 // every read of this batch of the list is done
+        // the candidates that stay undecided are collected in LDS and go back to the list once this pass's accepted ones are known
         const unsigned long long m = __ballot(wait);
         unsigned wbase = 0;
         if (lane == 0 && m) wbase = atomicAdd(&s_cursor, (unsigned)__popcll(m));
         wbase = __shfl(wbase, 0);
-        if (wait) list[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
+        if (wait) wait_local[wbase + __popcll(m & ((1ull << lane) - 1ull))] = q;
     }
     __syncthreads();
     const unsigned ntop = s_top;
     if (ntop) {
-        // equal eigenvalues inside one window are ranked by position; the workgroup shares each window's scan
+        // equal eigenvalues inside one window are ranked by position: a wavefront per candidate scans its window for an equal
+        // neighbour of higher rank (one candidate after the other with the whole workgroup, and a barrier each, before: 1.7 of
+        // the 11 us a dense tile lives)
         const unsigned magic = (unsigned)((1ull << 32) / (unsigned)L) + 1u;      // w / L for w < 65536
-        for (unsigned e = 0; e < ntop; e++) {
+        for (unsigned e = (unsigned)wave; e < ntop; e += MIS_T / 64) {
             const int q = (int)top_local[e], lx = q % MIS_TILE, ly = q / MIS_TILE;
             const uint32_t sp = S[(ly + R) * W + lx + R];
             bool outranked = false;
-            for (int w = threadIdx.x; w < L * L; w += MIS_T) {
+            for (int w = lane; w < L * L; w += 64) {
                 const int wy = (int)__umulhi((unsigned)w, magic), dx = w - wy * L - R, dy = wy - R;
                 outranked |= S[(ly + R + dy) * W + lx + R + dx] == sp && (dx > 0 || (dx == 0 && dy > 0));
             }
-            if (outranked) top_blocked[e] = 1;
-        }
-        __syncthreads();
-        for (unsigned e = threadIdx.x; e < ntop; e += MIS_T) {
-            const int q = (int)top_local[e], lx = q % MIS_TILE, ly = q / MIS_TILE;
-            const int p = (ty * MIS_TILE + ly) * a.nx + tx * MIS_TILE + lx;
-            if (top_blocked[e]) {
-                list[atomicAdd(&s_cursor, 1u)] = (uint32_t)p;
-            } else {
-                a.st[p] = S[(ly + R) * W + lx + R] | 0x80000000u;
-                acc_local[atomicAdd(&s_acc, 1u)] = (unsigned short)q;
+            const bool any = __ballot(outranked) != 0ull;
+            if (lane == 0) {
+                if (any) {
+                    wait_local[atomicAdd(&s_cursor, 1u)] = (unsigned short)q;
+                } else {
+                    a.st[(ty * MIS_TILE + ly) * a.nx + tx * MIS_TILE + lx] = sp | 0x80000000u;
+                    acc_local[atomicAdd(&s_acc, 1u)] = (unsigned short)q;
+                }
             }
         }
         __syncthreads();
@@ -820,8 +844,28 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     // atomics per microsecond chip-wide).  "Something is left" is a plain store of 1; the accepted candidates go to the
     // tile's own slots and are compacted once, after the last pass.
     unsigned nacc = s_acc;
-    const unsigned left = s_cursor;
+    const unsigned nwait = s_cursor;
     if (have + nacc > (unsigned)a.acc_cap) nacc = (unsigned)a.acc_cap - have;      // cannot happen (one per (R+1)^2 cells)
+    // back to the list: the undecided candidates outside the squares of the candidates accepted in this pass.  (The push below
+    // clears the squares in the state map; a candidate of this tile inside one used to stay listed until the next pass found it
+    // gone -- after the first pass that was 85 % of the list.)
+    for (unsigned i0 = 0; i0 < nwait; i0 += MIS_T) {
+        const unsigned i = i0 + threadIdx.x;
+        const int q = i < nwait ? (int)wait_local[i] : 0, lx = q % MIS_TILE, ly = q / MIS_TILE;
+        bool keep = i < nwait;
+        if (R > 0)
+            for (unsigned k = 0; k < nacc; k++) {
+                const int qa = (int)acc_local[k];
+                keep = keep && (abs(lx - qa % MIS_TILE) > R || abs(ly - qa / MIS_TILE) > R);
+            }
+        const unsigned long long m = __ballot(keep);
+        unsigned wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&s_left, (unsigned)__popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (keep) list[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)((ty * MIS_TILE + ly) * a.nx + tx * MIS_TILE + lx);
+    }
+    __syncthreads();
+    const unsigned left = s_left;
     if (threadIdx.x == 0) {
         a.cnt[blockIdx.x] = left;
         if (left) a.remaining[round] = 1u;
@@ -838,6 +882,7 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
             for (unsigned k = 0; k < nacc; k++) {
                 const int q = (int)acc_local[k];
                 const int gx = tx * MIS_TILE + (q % MIS_TILE) + dx, gy = ty * MIS_TILE + q / MIS_TILE + dy;
+                if (staged && S[(q / MIS_TILE + R + dy) * W + q % MIS_TILE + R + dx] == 0u) continue;
                 if (gx >= 0 && gy >= 0 && gx < a.nx && gy < a.ny) a.st[(size_t)gy * a.nx + gx] = 0u;
             }
         }
@@ -1095,7 +1140,7 @@ void launch_mis_init(hipStream_t s, const MisArgs &a)
 
 int launch_mis_round(hipStream_t s, const MisArgs &a, int round)
 {
-    const size_t lds = a.stage ? mis_stage_bytes(a.R) : 0;
+    const size_t lds = (a.stage ? mis_stage_bytes(a.R) : 0) + (((size_t)a.acc_cap * sizeof(unsigned short) + 15) & ~(size_t)15);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)mis_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
