@@ -329,6 +329,8 @@ __global__ __launch_bounds__(256) void eigen_hist_kernel(SelectArgs a)
 {
     __shared__ unsigned h[HIST_BINS];
     const int tid = threadIdx.x, ncand = a.nx * a.ny;
+    // (XCD-contiguous eighths of the candidates instead of this interleaved sweep -- the table rows shared by windows 2 hh + 1 rows
+    // apart then meet in one L2 -- were measured in round 2: no change, 14.6 us at 1080p either way)
     const bool sampler = a.hist != nullptr && (blockIdx.x & 3) == 0;
     if (sampler) {
         for (int i = tid; i < HIST_BINS; i += 256) h[i] = 0u;
@@ -649,16 +651,25 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(NmsArgs a)
 // Each workgroup owns one 32x32 tile of the candidate grid and the list of its undecided cells (compacted in place).
 constexpr int MIS_TILE = 32, MIS_CAP = MIS_TILE * MIS_TILE, MIS_T = 256;
 
+// Workgroup -> tile.  Workgroup b runs on XCD b % 8: XCD k takes the k-th contiguous eighth of the (row-major) tiles, so that the
+// halo cells a tile shares with its neighbours come out of the same L2.
+__device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned g)
+{
+    const unsigned k = b & 7u, i = b >> 3, base = g >> 3, rem = g & 7u;
+    return k * base + min(k, rem) + i;
+}
+
 __global__ __launch_bounds__(MIS_T) void mis_init_kernel(MisArgs a)
 {
     __shared__ unsigned s_cursor;
     const int tiles_x = (a.nx + MIS_TILE - 1) / MIS_TILE;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const unsigned thr = a.info[0];
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) s_cursor = 0u;
     __syncthreads();
-    uint32_t *list = a.list + (size_t)blockIdx.x * MIS_CAP;
+    uint32_t *list = a.list + (size_t)tile * MIS_CAP;
     for (int k0 = 0; k0 < MIS_CAP; k0 += MIS_T) {
         const int k = k0 + threadIdx.x;
         const int xi = tx * MIS_TILE + (k & (MIS_TILE - 1)), yi = ty * MIS_TILE + k / MIS_TILE;
@@ -674,13 +685,18 @@ __global__ __launch_bounds__(MIS_T) void mis_init_kernel(MisArgs a)
         if (keep) list[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
     }
     __syncthreads();
-    if (threadIdx.x == 0) a.cnt[blockIdx.x] = s_cursor;
+    if (threadIdx.x == 0) a.cnt[tile] = s_cursor;
 }
 
 // (Several passes per launch -- every tile looping over re-staged states read with agent-scope loads, so that decisions of
 // other XCDs are seen inside the launch -- were measured in round 2: 2 launches x 41 us instead of 6 x 13 us at 1080p, i.e. the
 // same; at 4K, where the 5700 tiles are not all resident, the early tiles spin on neighbours that have not started: 218 vs 99 us.
 // A pass costs what it computes (staging + window maxima of every active tile, ~4.6 M wavefront-instructions), not its launch.)
+// Timeline of one workgroup in the first pass (1080p cfg-2 frame, 1431 tiles, ~220 candidates each; medians, wall clock read by
+// thread 0 at the stage boundaries): list length 0.4 us, staging the tile 4.1, window maxima 1.3, decisions 2.2, tie checks 1.7, push
+// 1.0, keys 0.3 -- 11 us, and 16.8 us from the first workgroup's start to the last one's end; in the fifth pass (145 tiles, ~3
+// candidates) 0.4 / 2.0 / 0.8 / 0.9 / 0.2 / 0.1 / 0.1 -- 4.4 us in a 7.4 us launch.  Staging is state-map reads that missed the L2
+// (every kernel boundary invalidates it): hence the XCD-contiguous tile order below (-4 % on a 4K frame).
 __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
 {
     // staged tiles: S = states of the tile + halo ((32 + 2R)^2 u32), H = per row of S and interior column the maximum
@@ -691,11 +707,12 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     extern __shared__ uint32_t lds32[];
     __shared__ unsigned short top_local[MIS_CAP], wait_local[MIS_CAP];
     __shared__ unsigned s_cursor, s_acc, s_top, s_left;
-    const unsigned n = a.cnt[blockIdx.x];
+    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+    const unsigned n = a.cnt[tile];
     if (n == 0u) return;
-    const unsigned have = a.acc_cnt[blockIdx.x];             // accepted candidates of this tile so far
+    const unsigned have = a.acc_cnt[tile];             // accepted candidates of this tile so far
     const int tiles_x = (a.nx + MIS_TILE - 1) / MIS_TILE;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int R = a.R, W = MIS_TILE + 2 * R, L = 2 * R + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // (Deciding the last few candidates of a tile without staging it -- a wavefront reading each candidate's window straight from
@@ -708,7 +725,7 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     // (eight workgroups per CU instead of seven -- 2048 slots for the tiles of a 1080p frame -- were measured this way: no change)
     unsigned short *acc_local = reinterpret_cast<unsigned short *>(lds32 + (staged ? W * MIS_TILE + W * W : 0));
     const int ox = tx * MIS_TILE - R, oy = ty * MIS_TILE - R;
-    uint32_t *list = a.list + (size_t)blockIdx.x * MIS_CAP;
+    uint32_t *list = a.list + (size_t)tile * MIS_CAP;
     unsigned next_p = threadIdx.x < n ? list[threadIdx.x] : 0u;           // first batch, in flight during the staging
     if (threadIdx.x == 0) { s_acc = 0u; s_cursor = 0u; s_top = 0u; s_left = 0u; }
     if (staged) {
@@ -867,11 +884,11 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     __syncthreads();
     const unsigned left = s_left;
     if (threadIdx.x == 0) {
-        a.cnt[blockIdx.x] = left;
+        a.cnt[tile] = left;
         if (left) a.remaining[round] = 1u;
-        a.acc_cnt[blockIdx.x] = have + nacc;
+        a.acc_cnt[tile] = have + nacc;
     }
-    const size_t s_base = (size_t)blockIdx.x * a.acc_cap + have;
+    const size_t s_base = (size_t)tile * a.acc_cap + have;
     // push: every cell within the exclusion square of a newly accepted candidate is rejected right away.  None of them
     // can be accepted (two accepted candidates never lie within each other's square), so the whole square is cleared.
     if (R > 0 && nacc) {
