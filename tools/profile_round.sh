@@ -30,5 +30,10 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F64 --output-format csv -d $O/pmc_${TAG}_sq5 -o run -- python3 bench.py --inflight 1 --steps 20 --warmup 2 --repeats 5 --no-cpu-baseline > $O/pmc_${TAG}_sq5.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT32 SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_${TAG}_sq6 -o run -- python3 bench.py --inflight 1 --steps 20 --warmup 2 --repeats 5 --no-cpu-baseline > $O/pmc_${TAG}_sq6.log 2>&1
 python3 tools/pmc_sq.py $O/sq_counters_$TAG.json $O/pmc_${TAG}_sq1 $O/pmc_${TAG}_sq2 $O/pmc_${TAG}_sq3 $O/pmc_${TAG}_sq4 $O/pmc_${TAG}_sq5 $O/pmc_${TAG}_sq6 > /dev/null 2>> $O/bench_$TAG.err
+python3 bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_steps20.json 2>> $O/bench_$TAG.err
+python3 tools/api_probe.py > $O/api_probe_$TAG.json 2>> $O/bench_$TAG.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${TAG}_cfg4_fetch -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 10 --warmup 2 --repeats 3 > $O/pmc_${TAG}_cfg4_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${TAG}_cfg4_write -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 10 --warmup 2 --repeats 3 > $O/pmc_${TAG}_cfg4_write.log 2>&1
+python3 tools/pmc_traffic.py $O/pmc_${TAG}_cfg4_fetch $O/pmc_${TAG}_cfg4_write $O/traffic_${TAG}_cfg4.json > /dev/null 2>> $O/bench_$TAG.err
 find $O/prof_$TAG $O/prof_${TAG}_select -name "*kernel_stats.csv" | head
 tail -c 600 $O/bench_$TAG.json
