@@ -471,6 +471,7 @@ def run_cfg5(args, json_fd):
     # the pyramids of frame k+1 are built on the context's build stream while frame k is tracked and its lost features are replaced
     # (KLT_OPT_BUILD_STREAM; same results -- every frame has its own slot here)
     prefetch = os.environ.get("KLT_BENCH_NO_PREFETCH") != "1"
+    prepare = prefetch and os.environ.get("KLT_BENCH_NO_PREPARE") != "1"
     if prefetch:
         ctx.set_option(15, 1)
 
@@ -480,12 +481,16 @@ def run_cfg5(args, json_fd):
         t_sel = 0.0
         if prefetch:
             ctx.build_pyramids(10 + 1, sync=False)
+            if prepare:
+                ctx.select_prepare(10 + 1)
         for k in range(1, nframes):
             if not prefetch:
                 ctx.build_pyramids(10 + k, sync=False)
-            elif k + 1 < nframes:
+            ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)      # the chain first: the build stream waits for nothing on this one
+            if prefetch and k + 1 < nframes:
                 ctx.build_pyramids(10 + k + 1, sync=False)
-            ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)
+                if prepare:
+                    ctx.select_prepare(10 + k + 1)        # SAT + eigenvalues of the next frame, behind its build on the build stream
             if timed:
                 lost.append(int((ctx.featbuf_download(k % 2, n)["val"] < 0).sum()))      # (synchronises)
                 t = time.perf_counter()
@@ -512,9 +517,10 @@ def run_cfg5(args, json_fd):
     emit(json_fd, base_line(n * frames_done / el, 1, frames_done, 0, el / frames_done * 1e3, el / frames_done * 1e3,
                             "cfg-5 (one GPU): 3840x2160 sequence, 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost "
                             "features replaced after every frame; per frame: pyramid of the new frame + track + replacement"
-                            + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else ""),
+                            + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else "")
+                            + (", and so are its summed-area tables and eigenvalues (klt_select_prepare_async)" if prepare else ""),
                             extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
-                                       "lost_per_frame": lost, "build_stream": bool(prefetch)}))
+                                       "lost_per_frame": lost, "build_stream": bool(prefetch), "scores_prepared": bool(prepare)}))
 
 
 # ================================================================================= launcher dry run

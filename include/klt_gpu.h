@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 3
+#define KLT_ABI_VERSION 4
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -152,6 +152,13 @@ void *klt_featbuf_devptr(klt_ctx *ctx, int fb);             /* device address (f
  * level-0 image/gradients of the slot's pyramids are reused (selectGoodFeatures.py:176-181),
  * otherwise the slot's raw frame is smoothed/differentiated afresh (:183-197). */
 int klt_select_async(klt_ctx *ctx, int slot, int mode, int use_pyramid, int fb, int n);
+/* The list-independent half of a later klt_select_async(slot, KLT_REPLACING_SOME, use_pyramid = 1, ...): the summed-area tables and
+ * the eigenvalue of every candidate window (goodFeaturesUtils.pyx:17-73, called from selectGoodFeatures.py:199-232) of the slot's
+ * level-0 gradients, kept with the slot's contents (two sets per context; a set follows klt_swap_slots and dies with the next build
+ * of the slot or a change of the selection parameters).  With KLT_OPT_BUILD_STREAM it runs on the build stream, i.e. while the main
+ * stream tracks into the previous frame and replaces its lost features; the selection then only masks the live features'
+ * squares, cuts and runs the minimum-distance passes.  Same result with or without this call. */
+int klt_select_prepare_async(klt_ctx *ctx, int slot);
 int klt_select(klt_ctx *ctx, int slot, int mode, int use_pyramid, klt_feat *inout, int n, int *n_placed);
 
 /* ---- tracking: KLTTrackFeatures, trackFeatures.py:205-409 (translation model) -------------- */

@@ -254,6 +254,10 @@ class Context:
     def select_async(self, slot, mode, use_pyramid, fb, n):
         self._check(self._lib.klt_select_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))
 
+    def select_prepare(self, slot):
+        """Scores of the slot's level-0 images ahead of a REPLACING_SOME selection on it (klt_select_prepare_async); asynchronous."""
+        self._check(self._lib.klt_select_prepare_async(self._h, slot))
+
     def select_intermediate(self, what):
         nc, nr = C.c_int(), C.c_int()
         self._check(self._lib.klt_select_dims(self._h, what, C.byref(nc), C.byref(nr)))

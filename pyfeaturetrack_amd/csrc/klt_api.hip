@@ -32,12 +32,17 @@ struct Slot {
     Level lv[KLT_MAX_LEVELS];
     int nlev = 0, ss = 0;
     bool pyr_valid = false;
+    uint64_t gen = 0;                 // which build filled the pyramids (unique per build; travels with klt_swap_slots)
     hipEvent_t ev_upload = nullptr;   // asynchronous ingest: frame copy finished (the build waits for it)
     hipEvent_t ev_consumed = nullptr; // last kernel on `stream` that read the raw frame u8
     uint64_t upload_serial = 0, consumed_serial = 0, consumed_alt_serial = 0;   // when the ring handed those events out (event_live)
     hipEvent_t ev_built = nullptr;    // KLT_OPT_BUILD_STREAM: end of the build that filled this slot's pyramids (recorded on the build stream)
     uint64_t built_serial = 0;
     bool built_pending = false;       // the main stream has not waited for ev_built yet
+    bool built_on_bstream = false;    // which stream the last build of this slot ran on
+    hipEvent_t ev_read = nullptr;     // last tracker launch on the main stream that reads this slot's pyramids (a build on the build
+    uint64_t read_serial = 0;         // stream waits for it; selections synchronise before they return and need no mark)
+    bool read_valid = false;
     bool upload_pending = false, consumed_valid = false;
     // asynchronous ingest alternates between two raw buffers so that a copy never has to wait (on the device) for
     // kernels still reading the previous frame: making the copy stream wait on a compute-stream event blocks the
@@ -118,6 +123,23 @@ struct klt_ctx {
     size_t mis_tile_keys_cap = 0;
     unsigned *mis_cnt = nullptr;              // [tiles] + kMisRounds remaining counters + accepted counter
     size_t mis_st_cap = 0, mis_list_cap = 0, mis_cnt_cap = 0;
+    // klt_select_prepare_async: the list-independent half of a selection (summed-area tables, eigenvalue keys) of a slot's level 0, computed
+    // ahead of time (on the build stream when that is on).  Two entries: the next frame's keys are written while this frame's are read.
+    struct ScoreCache {
+        unsigned long long *keys = nullptr;
+        size_t cap = 0;
+        uint64_t gen = 0, stamp = 0;      // generation of the slot contents the keys were scored on (0 = empty); age
+        int nc = 0, nr = 0, bx = 0, by = 0, hw = 0, hh = 0, step = 0, nx = 0, ny = 0;
+        double min_eig = 0;
+        hipEvent_t ev = nullptr;
+        uint64_t ev_serial = 0;
+    } pre[2];
+    float *sat_pre = nullptr;
+    size_t sat_pre_cap = 0;
+    uint64_t gen_counter = 0, pre_stamp = 0;
+    int last_build_on_bstream = -1;           // -1: no build yet
+    hipEvent_t ev_bbuild = nullptr;           // end of the latest build on the build stream (shares the H1 scratch with main-stream builds)
+    uint64_t bbuild_serial = 0;
     const unsigned long long *sorted_keys = nullptr;   // what the last selection walked (test hook)
     int sorted_count = 0;
     TrackPairDesc *pair_table = nullptr;
@@ -310,6 +332,19 @@ int mark_consumed(klt_ctx *c, Slot *const *slots, int n, hipStream_t reader)
     if (int rc = fresh_event(c, &e, &serial)) return rc;
     HIPCHK(c, hipEventRecord(e, reader));
     for (int i = 0; i < n; i++) { slots[i]->ev_consumed = e; slots[i]->consumed_serial = serial; slots[i]->consumed_valid = true; }
+    return 0;
+}
+
+// the tracker launch just enqueued on the main stream reads the pyramids of these slots: the next build of any of them on the build
+// stream waits for it (and for nothing else on the main stream)
+int mark_read(klt_ctx *c, Slot *const *slots, int n)
+{
+    if (!c->build_stream_on) { for (int i = 0; i < n; i++) slots[i]->read_valid = false; return 0; }    // main-stream builds are in order
+    hipEvent_t e;
+    uint64_t serial;
+    if (int rc = fresh_event(c, &e, &serial)) return rc;
+    HIPCHK(c, hipEventRecord(e, c->stream));
+    for (int i = 0; i < n; i++) { slots[i]->ev_read = e; slots[i]->read_serial = serial; slots[i]->read_valid = true; }
     return 0;
 }
 
@@ -524,11 +559,17 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
     const bool on_bstream = c->build_stream_on && c->use_fused && fused_smooth_ok(c) && fused_grad_ok(c) && fused_reduce_ok(c);
     if (on_bstream) {
         if (!c->bstream) HIPCHK(c, hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking));
-        hipEvent_t mark;
-        if (int rc = fresh_event(c, &mark)) return rc;
-        HIPCHK(c, hipEventRecord(mark, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->bstream, mark, 0));
+        if (c->last_build_on_bstream != 1) {
+            // the first build over here: behind everything on the main stream (earlier builds there share the H1 scratch)
+            hipEvent_t mark;
+            if (int rc = fresh_event(c, &mark)) return rc;
+            HIPCHK(c, hipEventRecord(mark, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->bstream, mark, 0));
+        }
         c->work = c->bstream;
+    } else if (c->last_build_on_bstream == 1 && c->ev_bbuild) {
+        if (event_live(c, c->bbuild_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_bbuild, 0));
+        else HIPCHK(c, hipStreamSynchronize(c->bstream));
     }
     std::vector<Slot *> sl((size_t)n);
     for (int i = 0; i < n; i++) {
@@ -539,7 +580,15 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         if (int rc = layout_pyramid(c, sl[i])) return rc;
         if (int rc = wait_upload(c, sl[i], c->work)) return rc;      // asynchronous ingest: the frame must have landed
         if (!on_bstream) { if (int rc = wait_built(c, sl[i])) return rc; }
+        else if (sl[i]->read_valid) {
+            // a tracker on the main stream may still be reading the pyramids this build overwrites: wait for that launch only (a mark on
+            // the whole main stream would put the build behind a tracker enqueued just before it -- the overlap the stream is for)
+            if (event_live(c, sl[i]->read_serial)) HIPCHK(c, hipStreamWaitEvent(c->bstream, sl[i]->ev_read, 0));
+            else HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        sl[i]->read_valid = false;
     }
+    c->last_build_on_bstream = on_bstream ? 1 : 0;
     const int ss = c->p.subsampling;
     // groups of frames with the same geometry and input type share launches
     std::vector<bool> done((size_t)n, false);
@@ -637,7 +686,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
             if (int er = launch_smooth_grad(c->work, a, e, 2))
                 return fail(c, KLT_ERR_DEVICE, std::string("gradient launch: ") + hipGetErrorString((hipError_t)er));
         }
-        for (Slot *s : g) s->pyr_valid = true;
+        for (Slot *s : g) { s->pyr_valid = true; s->gen = ++c->gen_counter; }
     }
     // the next asynchronous copy into these slots waits for this build
     if (int rc = mark_consumed(c, sl.data(), n, c->work)) return rc;
@@ -647,7 +696,9 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         if (int rc = fresh_event(c, &e, &serial)) return rc;
         HIPCHK(c, hipEventRecord(e, c->bstream));
         for (Slot *s : sl) { s->ev_built = e; s->built_serial = serial; s->built_pending = true; }
+        c->ev_bbuild = e; c->bbuild_serial = serial;
     }
+    for (Slot *s : sl) s->built_on_bstream = on_bstream;
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -715,6 +766,7 @@ void klt_destroy(klt_ctx *c)
         if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1); hipFree(c->track_order);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
+    hipFree(c->pre[0].keys); hipFree(c->pre[1].keys); hipFree(c->sat_pre);
     hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
@@ -875,7 +927,8 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_TRACK_XCD_ORDER) { c->track_xcd_order = value != 0; return KLT_OK; }
     if (option == KLT_OPT_BUILD_STREAM) {
         if (!value && c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));      // pending builds finish; their events stay valid
-        c->build_stream_on = value != 0;
+        if (c->build_stream_on != (value != 0)) c->last_build_on_bstream = -1;   // trackers launched meanwhile carry no read marks: the next
+        c->build_stream_on = value != 0;                                          // build over there waits for the whole main stream
         return KLT_OK;
     }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
@@ -980,6 +1033,113 @@ void *klt_featbuf_devptr(klt_ctx *c, int fb)
 }
 
 // ---------------------------------------------------------------------------------------- selection
+namespace {
+// borders / half-windows as ScanImageForGoodFeatures receives them: Python floats truncated to C ints
+// (selectGoodFeatures.py:168-169, :215-221, goodFeaturesUtils.pyx:35-37)
+struct SelGeom { int bx, by, hw, hh, step, nx, ny; long long ncand, npow2; };
+int select_geometry(klt_ctx *c, int nc, int nr, SelGeom *g)
+{
+    const klt_params &p = c->p;
+    double bxd = p.borderx, byd = p.bordery;
+    if (bxd < p.window_width / 2.0) bxd = p.window_width / 2.0;
+    if (byd < p.window_height / 2.0) byd = p.window_height / 2.0;
+    g->bx = (int)bxd; g->by = (int)byd; g->hw = p.window_width / 2; g->hh = p.window_height / 2;
+    g->step = p.nSkippedPixels + 1;
+    if (g->bx - g->hw - 1 < 0 || g->by - g->hh - 1 < 0)
+        return fail(c, KLT_ERR_ARG, "border must be at least window/2 + 1 (the reference reads outside the image otherwise)");
+    g->nx = (nc - g->bx > g->bx) ? (nc - 2 * g->bx + g->step - 1) / g->step : 0;
+    g->ny = (nr - g->by > g->by) ? (nr - 2 * g->by + g->step - 1) / g->step : 0;
+    g->ncand = (long long)g->nx * g->ny;
+    g->npow2 = 2048;
+    while (g->npow2 < g->ncand) g->npow2 <<= 1;
+    if (g->npow2 > (1LL << 30)) return fail(c, KLT_ERR_ARG, "too many candidates");
+    return 0;
+}
+
+// summed-area tables of the gradient products (goodFeaturesUtils.pyx:49-51): step-synchronous wavefront pipelines (sat_pipeline.hip)
+// where whole aligned quads can be moved, else the barrier-coupled kernels of select_kernels.hip
+int enqueue_sat(klt_ctx *c, hipStream_t st, const float *gx, const float *gy, float *sat, int nc, int nr)
+{
+    const bool pipe = c->sat_variant == 1;
+    const double N = (double)nc * nr;
+    { TimerScope t(c, F_SAT_ROWS, N * (8 + 12));
+      const int e = pipe ? launch_sat_rows_pipe(st, gx, gy, sat, nc, nr) : -1;
+      if (e > 0) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e));
+      if (e < 0) launch_sat_rows(st, gx, gy, sat, nc, nr); }
+    { TimerScope t(c, F_SAT_COLS, N * 24);
+      const int e = pipe ? launch_sat_cols_pipe(st, sat, nc, nr) : -1;
+      if (e > 0) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e));
+      if (e < 0) launch_sat_cols(st, sat, nc, nr); }
+    return 0;
+}
+
+klt_ctx::ScoreCache *find_scores(klt_ctx *c, const Slot *s, const SelGeom &g, double min_eig)
+{
+    if (!s->pyr_valid || !s->gen) return nullptr;
+    for (auto &e : c->pre)
+        if (e.gen == s->gen && e.nc == s->nc && e.nr == s->nr && e.bx == g.bx && e.by == g.by && e.hw == g.hw && e.hh == g.hh &&
+            e.step == g.step && e.nx == g.nx && e.ny == g.ny && e.min_eig == min_eig)
+            return &e;
+    return nullptr;
+}
+}  // namespace
+
+// The half of a selection that depends on the pixels only -- summed-area tables and the eigenvalue of every candidate window
+// (goodFeaturesUtils.pyx:17-73) -- for the level-0 images of `slot`, ahead of the selection itself: on the build stream when
+// KLT_OPT_BUILD_STREAM is on, where it overlaps the tracker and the minimum-distance passes of the previous frame.
+int klt_select_prepare_async(klt_ctx *c, int slot)
+{
+    if (int rc = check_ready(c)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot *s;
+    if (int rc = get_slot(c, slot, &s, false)) return rc;
+    if (!s->pyr_valid) return fail(c, KLT_ERR_STATE, "klt_select_prepare_async: the slot's pyramids are not built");
+    const int nc = s->nc, nr = s->nr;
+    const size_t N = (size_t)nc * nr;
+    SelGeom g;
+    if (int rc = select_geometry(c, nc, nr, &g)) return rc;
+    if (g.ncand <= 0) return KLT_OK;
+    struct WorkScope {
+        klt_ctx *c;
+        ~WorkScope() { c->work = c->stream; }
+    } work_scope{c};
+    if (c->build_stream_on) {
+        if (!c->bstream) HIPCHK(c, hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking));
+        if (!s->built_on_bstream) {             // built on the main stream: behind everything there
+            hipEvent_t mark;
+            if (int rc = fresh_event(c, &mark)) return rc;
+            HIPCHK(c, hipEventRecord(mark, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->bstream, mark, 0));
+        }
+        // (the set being replaced was last read by a selection, and selections synchronise the main stream before they return)
+        c->work = c->bstream;
+    } else {
+        if (int rc = wait_built(c, s)) return rc;
+        for (auto &e : c->pre)                  // an earlier preparation on the build stream shares the table scratch
+            if (e.ev && event_live(c, e.ev_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, e.ev, 0));
+    }
+    klt_ctx::ScoreCache *e = &c->pre[0];
+    if (c->pre[0].gen != s->gen && (c->pre[1].gen == s->gen || c->pre[1].stamp < c->pre[0].stamp)) e = &c->pre[1];
+    if (int rc = ensure(c, c->sat_pre, c->sat_pre_cap, 3 * N)) return rc;
+    if (int rc = ensure(c, e->keys, e->cap, (size_t)g.npow2)) return rc;
+    e->gen = 0;
+    if (int rc = enqueue_sat(c, c->work, s->lv[0].gx, s->lv[0].gy, c->sat_pre, nc, nr)) return rc;
+    SelectArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.sat = c->sat_pre; sa.keys = e->keys;
+    sa.min_eig = c->p.min_eigenvalue < 1 ? 1.0 : c->p.min_eigenvalue;          // selectGoodFeatures.py:53
+    sa.ncols = nc; sa.nrows = nr; sa.bx = g.bx; sa.by = g.by; sa.step = g.step; sa.nx = g.nx; sa.ny = g.ny;
+    sa.hw = g.hw; sa.hh = g.hh; sa.npow2 = (int)g.npow2;
+    { TimerScope t(c, F_EIGEN, (double)g.ncand * (48 + 8)); launch_eigen_hist(c->work, sa); }
+    if (int rc = fresh_event(c, &e->ev, &e->ev_serial)) return rc;
+    HIPCHK(c, hipEventRecord(e->ev, c->work));
+    e->gen = s->gen; e->stamp = ++c->pre_stamp;
+    e->nc = nc; e->nr = nr; e->bx = g.bx; e->by = g.by; e->hw = g.hw; e->hh = g.hh; e->step = g.step; e->nx = g.nx; e->ny = g.ny;
+    e->min_eig = sa.min_eig;
+    HIPCHK(c, hipGetLastError());
+    return KLT_OK;
+}
+
 int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, int n)
 {
     if (int rc = check_ready(c)) return rc;
@@ -993,22 +1153,11 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     FeatBuf *b;
     if (int rc = get_fb(c, fb, n, &b)) return rc;
 
-    // borders / half-windows as ScanImageForGoodFeatures receives them: Python floats truncated to C ints
-    // (selectGoodFeatures.py:168-169, :215-221, goodFeaturesUtils.pyx:35-37)
     const klt_params &p = c->p;
-    double bxd = p.borderx, byd = p.bordery;
-    if (bxd < p.window_width / 2.0) bxd = p.window_width / 2.0;
-    if (byd < p.window_height / 2.0) byd = p.window_height / 2.0;
-    const int bx = (int)bxd, by = (int)byd, hw = p.window_width / 2, hh = p.window_height / 2;
-    const int step = p.nSkippedPixels + 1;
-    if (bx - hw - 1 < 0 || by - hh - 1 < 0)
-        return fail(c, KLT_ERR_ARG, "border must be at least window/2 + 1 (the reference reads outside the image otherwise)");
-    const int nx = (nc - bx > bx) ? (nc - 2 * bx + step - 1) / step : 0;
-    const int ny = (nr - by > by) ? (nr - 2 * by + step - 1) / step : 0;
-    const long long ncand = (long long)nx * ny;
-    long long npow2 = 2048;
-    while (npow2 < ncand) npow2 <<= 1;
-    if (npow2 > (1LL << 30)) return fail(c, KLT_ERR_ARG, "too many candidates");
+    SelGeom geom;
+    if (int rc = select_geometry(c, nc, nr, &geom)) return rc;
+    const int bx = geom.bx, by = geom.by, hw = geom.hw, hh = geom.hh, step = geom.step, nx = geom.nx, ny = geom.ny;
+    const long long ncand = geom.ncand, npow2 = geom.npow2;
 
     // scratch
     if (N > c->sel_cap) {
@@ -1064,25 +1213,28 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     c->last_sel[0] = img; c->last_sel[1] = gx; c->last_sel[2] = gy;
     c->sel_nc = nc; c->sel_nr = nr; c->sel_nx = nx; c->sel_ny = ny; c->sel_npow2 = (int)npow2;
 
-    // summed-area tables (goodFeaturesUtils.pyx:49-51)
-    {
-        // step-synchronous wavefront pipelines (sat_pipeline.hip) where whole aligned quads can be moved, else the
-        // barrier-coupled kernels of select_kernels.hip
-        const bool pipe = c->sat_variant == 1;
-        { TimerScope t(c, F_SAT_ROWS, (double)N * (8 + 12));
-          const int e = pipe ? launch_sat_rows_pipe(c->stream, gx, gy, c->sat, nc, nr) : -1;
-          if (e > 0) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e));
-          if (e < 0) launch_sat_rows(c->stream, gx, gy, c->sat, nc, nr); }
-        { TimerScope t(c, F_SAT_COLS, (double)N * 24);
-          const int e = pipe ? launch_sat_cols_pipe(c->stream, c->sat, nc, nr) : -1;
-          if (e > 0) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e));
-          if (e < 0) launch_sat_cols(c->stream, c->sat, nc, nr); }
-    }
-
     int mindist = p.mindist < 0 ? 0 : p.mindist;          // selectGoodFeatures.py:241-243
     const int d = mindist - 1;                            // :61
     const int R = d >= 0 ? d / step : -1;                 // exclusion radius in candidate cells
     const bool parallel_nms = c->use_mis && ncand > 0 && mis_stage_bytes(R) <= 120 * 1024;
+    long long target = 64LL * n;
+    if (target < 65536) target = 65536;
+    const bool prefilter = c->use_topk && ncand > 262144 && target < ncand / 2;
+    const double min_eig = p.min_eigenvalue < 1 ? 1.0 : p.min_eigenvalue;          // :53
+
+    // scores prepared ahead of time (klt_select_prepare_async) are used by the replacement pass of the parallel path; everything else
+    // computes them here
+    klt_ctx::ScoreCache *pre = nullptr;
+    if (mode == KLT_REPLACING_SOME && use_pyramid && parallel_nms && prefilter && d >= 0 && !c->score_override_n)
+        pre = find_scores(c, s, geom, min_eig);
+    if (pre) {
+        if (event_live(c, pre->ev_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, pre->ev, 0));
+        else if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
+    } else {
+        // summed-area tables (goodFeaturesUtils.pyx:49-51)
+        if (int rc = enqueue_sat(c, c->stream, gx, gy, c->sat, nc, nr)) return rc;
+    }
+
     const uint8_t *seed = nullptr;
     // REPLACING_SOME: the squares of the live features are marked first; the eigenvalue kernels skip marked pixels, so neither the
     // scoring nor the minimum-distance stage ever sees them
@@ -1104,7 +1256,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
         if (given != ncand) return fail(c, KLT_ERR_ARG, "score override does not match the candidate grid");
         sa.val_in = c->score_override;
     }
-    sa.min_eig = p.min_eigenvalue < 1 ? 1.0 : p.min_eigenvalue;          // :53
+    sa.min_eig = min_eig;
     sa.ncols = nc; sa.nrows = nr; sa.bx = bx; sa.by = by; sa.step = step; sa.nx = nx; sa.ny = ny;
     sa.hw = hw; sa.hh = hh; sa.npow2 = (int)npow2;
     if (!parallel_nms) { TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8)); launch_eigen(c->stream, sa); }
@@ -1140,10 +1292,6 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
         if (e) return fail(c, KLT_ERR_DEVICE, std::string("nms launch: ") + hipGetErrorString((hipError_t)e));
         return 0;
     };
-
-    long long target = 64LL * n;
-    if (target < 65536) target = 65536;
-    const bool prefilter = c->use_topk && ncand > 262144 && target < ncand / 2;
 
     // ---- parallel minimum distance (default): decide every candidate in a few passes, rank the accepted ones, and
     // fill the free slots with the best of them (same result as the sorted serial walk below)
@@ -1183,7 +1331,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
         unsigned *const acc_count_d = c->mis_cnt + off_acc;
         int *const nfill_d = c->placed_d + 2;
         MisArgs ma;
-        ma.keys = c->keys; ma.st = c->mis_st; ma.list = c->mis_list; ma.cnt = c->mis_cnt;
+        ma.keys = pre ? pre->keys : c->keys; ma.seed = pre ? seed : nullptr; ma.ncols = nc; ma.st = c->mis_st; ma.list = c->mis_list; ma.cnt = c->mis_cnt;
         ma.remaining = c->mis_cnt + off_rem; ma.acc_cnt = c->mis_cnt + off_tacc; ma.acc_cap = tile_cap;
         ma.acc_keys = c->mis_tile_keys; ma.info = info_d;
         ma.nx = nx; ma.ny = ny; ma.R = R; ma.stage = 1; ma.bx = bx; ma.by = by; ma.step = step;
@@ -1202,8 +1350,15 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
                     // 0.365 / 0.364 ms per frame; too tight a cut only costs the repeat below, never the result)
                     sa.hist_target = 4096 / 4; sa.hist_slots = nfill_d; sa.hist_per_slot = 64 / 4;
                 }
-                TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8));
-                launch_eigen_hist(c->stream, sa);
+                if (pre) {
+                    // scored ahead of time without the seed map: histogram of the keys outside it here, the mask itself in mis_init
+                    sa.keys = pre->keys;
+                    TimerScope t(c, F_EIGEN, (double)ncand * 2);
+                    launch_mask_hist(c->stream, sa);
+                } else {
+                    TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8));
+                    launch_eigen_hist(c->stream, sa);
+                }
             } else {
                 launch_zero_words(c->stream, c->mis_cnt + off_rem, n_cnt - off_rem);      // threshold bin 0: every candidate
             }
@@ -1386,6 +1541,10 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
         if (launch_track(c->stream, a)) return fail(c, KLT_ERR_ARG, "unsupported window size");
     }
     if (c->collect_stats) launch_track_stats(c->stream, a.in, a.out, n, s1->nlev, c->stats_d);
+    {
+        Slot *both[2] = {s1, s2};
+        if (int rc = mark_read(c, both, 2)) return rc;
+    }
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -1439,6 +1598,7 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
     }
     if (c->collect_stats)
         for (int i = 0; i < npairs; i++) launch_track_stats(c->stream, table[i].in, table[i].out, n, first->nlev, c->stats_d);
+    if (int rc = mark_read(c, used.data(), (int)used.size())) return rc;
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
 }
@@ -1537,6 +1697,10 @@ int klt_track_affine_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_o
     {
         TimerScope t(c, F_AFFINE, (double)n * 12.0 * (a.width + 1) * (a.height + 1) * 3, c->stream);
         launch_affine(c->stream, a);
+    }
+    {
+        Slot *both[2] = {s1, s2};
+        if (int rc = mark_read(c, both, 2)) return rc;
     }
     HIPCHK(c, hipGetLastError());
     return KLT_OK;

@@ -113,6 +113,8 @@ struct MisArgs {
     const unsigned *info;             // info[0] = lowest key bin that takes part (top-K prefilter)
     int nx, ny, R /* exclusion radius in cells */, stage /* 1: stage tile + halo in LDS */;
     int bx, by, step;                 // pixel position of cell (i, j) = (bx + i * step, by + j * step)
+    const uint8_t *seed;              // optional: [nrows][ncols] squares of the live features; keys were scored WITHOUT it (klt_select_prepare_async)
+    int ncols;
 };
 
 // ---- launchers (each enqueues on `s`; no synchronisation) ----
@@ -154,6 +156,8 @@ void launch_zero_words(hipStream_t s, unsigned *p, size_t n);
 void launch_mis_prepare(hipStream_t s, const klt_feat *fl, int nfeat, int overwrite_all, int *slots, int *nfill_out, klt_feat *snapshot,
                         unsigned *zero, size_t zero_n);
 void launch_eigen_hist(hipStream_t s, const SelectArgs &a);
+// histogram (every 4th block of 256 keys, as eigen_hist_kernel samples) of the keys outside the seed map, then the threshold
+void launch_mask_hist(hipStream_t s, const SelectArgs &a);
 void launch_mis_results(hipStream_t s, unsigned *host_out, const unsigned *rem, int look, const unsigned *info, const int *placed);
 void launch_mis_place(hipStream_t s, const NmsArgs &a, const unsigned *count, unsigned *rank, const int *nfill, int bound,
                       unsigned *host_out, const unsigned *rem, int look, const unsigned *info);

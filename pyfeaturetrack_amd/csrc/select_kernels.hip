@@ -232,7 +232,7 @@ __device__ __forceinline__ unsigned long long eigen_key(const SelectArgs &a, int
     const int x = a.bx + xi * a.step, y = a.by + yi * a.step;
     // REPLACING_SOME: a pixel inside the exclusion square of a live feature can never be placed (selectGoodFeatures.py:64-69 marks
     // the feature map before the walk), so it is not scored at all -- most of the frame when few features were lost
-    if (a.seedmap && a.seedmap[(size_t)y * a.ncols + x] != 0) { a.valmap[k] = 0.f; return 0ull; }
+    if (a.seedmap && a.seedmap[(size_t)y * a.ncols + x] != 0) { if (a.valmap) a.valmap[k] = 0.f; return 0ull; }
     const size_t plane = (size_t)a.ncols * a.nrows;
     const float gxx = window_sum(a.sat, a.ncols, x, y, a.hw, a.hh);
     const float gxy = window_sum(a.sat + plane, a.ncols, x, y, a.hw, a.hh);
@@ -246,7 +246,7 @@ __device__ __forceinline__ unsigned long long eigen_key(const SelectArgs &a, int
     const float sum = gxx + gyy;
     const float num = sum - s;
     const float val = a.val_in ? a.val_in[k] : (float)((double)num / 2.0);
-    a.valmap[k] = val;
+    if (a.valmap) a.valmap[k] = val;
     const bool ok = (double)val >= a.min_eig;          // val >= max(min_eigenvalue, 1) > 0
     return ok ? (((unsigned long long)__float_as_uint(val) << 32) | ((unsigned long long)x << 16) | (unsigned long long)y) : 0ull;
 }
@@ -347,6 +347,41 @@ __global__ __launch_bounds__(256) void eigen_hist_kernel(SelectArgs a)
         for (int i = tid; i < HIST_BINS; i += 256)
             if (h[i]) atomicAdd(&a.hist[i], h[i]);
     }
+}
+
+// Keys scored ahead of time without the seed map (klt_select_prepare_async): the histogram behind the cut counts the keys outside
+// the live features' squares, on a sample of every 16th block of 256 keys (the cut only saves work; its targets are scaled to the
+// sample).  A workgroup takes eight sampled blocks in one step: the seed-map loads, then the key loads of the cells outside the squares,
+// are in flight together, and only ~250 workgroups flush their bins (one block per step and every 4th block, as eigen_hist_kernel
+// samples, read 29-35 us for a 4K frame: two dependent round trips per block, then 1024 workgroups adding to the same few hundred words).
+constexpr int MASK_HIST_SAMPLE = 16;
+__global__ __launch_bounds__(256) void mask_hist_kernel(SelectArgs a)
+{
+    __shared__ unsigned h[HIST_BINS];
+    const int tid = threadIdx.x, ncand = a.nx * a.ny;
+    for (int i = tid; i < HIST_BINS; i += 256) h[i] = 0u;
+    __syncthreads();
+    constexpr int U = 8, S = MASK_HIST_SAMPLE;
+    for (int k0 = S * U * blockIdx.x * 256 + tid; k0 < ncand; k0 += S * U * gridDim.x * 256) {
+        unsigned long long key[U];
+        uint8_t masked[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = k0 + S * u * 256, xi = k % a.nx, yi = k / a.nx;
+            masked[u] = k < ncand ? a.seedmap[(size_t)(a.by + yi * a.step) * a.ncols + a.bx + xi * a.step] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            key[u] = masked[u] ? 0ull : a.keys[k0 + S * u * 256];
+            if (!key[u]) masked[u] = 1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (!masked[u]) atomicAdd(&h[key_bin(key[u])], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < HIST_BINS; i += 256)
+        if (h[i]) atomicAdd(&a.hist[i], h[i]);
 }
 
 // Order inside the kept set does not matter (it is sorted next), so every workgroup counts the keys it keeps in its
@@ -670,14 +705,28 @@ __global__ __launch_bounds__(MIS_T) void mis_init_kernel(MisArgs a)
     if (threadIdx.x == 0) s_cursor = 0u;
     __syncthreads();
     uint32_t *list = a.list + (size_t)tile * MIS_CAP;
-    for (int k0 = 0; k0 < MIS_CAP; k0 += MIS_T) {
-        const int k = k0 + threadIdx.x;
+    // the four cells of a thread: seed-map bytes first (keys scored ahead of time carry no mask), then the keys of the cells outside
+    // the live features' squares, each group of loads in flight together
+    constexpr int U = MIS_CAP / MIS_T;
+    bool inside[U];
+    int pcell[U];
+    unsigned long long key[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int k = u * MIS_T + threadIdx.x;
         const int xi = tx * MIS_TILE + (k & (MIS_TILE - 1)), yi = ty * MIS_TILE + k / MIS_TILE;
-        const bool inside = xi < a.nx && yi < a.ny;
-        const int p = yi * a.nx + xi;
-        const unsigned long long key = inside ? a.keys[p] : 0ull;
-        const bool keep = key != 0ull && key_bin(key) >= thr;
-        if (inside) a.st[p] = keep ? (uint32_t)(key >> 32) : 0u;
+        inside[u] = xi < a.nx && yi < a.ny;
+        pcell[u] = yi * a.nx + xi;
+        key[u] = 1ull;
+        if (inside[u] && a.seed) key[u] = a.seed[(size_t)(a.by + yi * a.step) * a.ncols + a.bx + xi * a.step] ? 0ull : 1ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) key[u] = inside[u] && key[u] ? a.keys[pcell[u]] : 0ull;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int p = pcell[u];
+        const bool keep = key[u] != 0ull && key_bin(key[u]) >= thr;
+        if (inside[u]) a.st[p] = keep ? (uint32_t)(key[u] >> 32) : 0u;
         const unsigned long long m = __ballot(keep);
         unsigned wbase = 0;
         if (lane == 0 && m) wbase = atomicAdd(&s_cursor, (unsigned)__popcll(m));
@@ -1193,6 +1242,18 @@ void launch_eigen_hist(hipStream_t s, const SelectArgs &a)
     const int blocks = (a.nx * a.ny + 255) / 256;
     hipLaunchKernelGGL(eigen_hist_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, a);
     if (a.hist) hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, a.hist, a.hist_target, a.info, a.hist_slots, a.hist_per_slot);
+}
+
+void launch_mask_hist(hipStream_t s, const SelectArgs &a)
+{
+    // a.hist_target / a.hist_per_slot arrive in units of eigen_hist_kernel's sample (every 4th block)
+    constexpr unsigned scale = MASK_HIST_SAMPLE / 4;
+    const int per_wg = MASK_HIST_SAMPLE * 8 * 256;
+    const int blocks = (a.nx * a.ny + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL(mask_hist_kernel, dim3(blocks < 1024 ? (blocks ? blocks : 1) : 1024), dim3(256), 0, s, a);
+    const unsigned per_slot = (a.hist_per_slot + scale - 1) / scale;
+    hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, a.hist, (a.hist_target + scale - 1) / scale, a.info, a.hist_slots,
+                       per_slot ? per_slot : 1u);
 }
 
 void launch_mis_results(hipStream_t s, unsigned *host_out, const unsigned *rem, int look, const unsigned *info, const int *placed)

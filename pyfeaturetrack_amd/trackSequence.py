@@ -91,6 +91,8 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
         def stage_frame(k, img):                     # upload + pyramid build of frame k (enqueued only)
             ingest(s[k % ring], image_to_array(img), k)
             ctx.build_pyramids(s[k % ring], sync=False)
+            if replace_lost and prefetch:            # ... and the list-independent half of its replacement pass, on the same stream
+                ctx.select_prepare(s[k % ring])
 
         nxt = next(frames, None)
         if nxt is not None:
@@ -98,13 +100,13 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
         while nxt is not None:
             k += 1
             nxt = next(frames, None)
-            if nxt is not None and prefetch:
-                stage_frame(k + 1, nxt)              # before frame k's tracker: the build stream overlaps it
             cur, prev = s[k % ring], s[(k - 1) % ring]
             if affine:
                 ctx.track_affine_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures, state)
             else:
                 ctx.track_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures)
+            if nxt is not None and prefetch:
+                stage_frame(k + 1, nxt)              # right behind the tracker's launch: the build stream overlaps it and the replacement
             if replace_lost:
                 ctx.select_async(cur, REPLACING_SOME, True, row_fb(k), nFeatures)
             if nxt is not None and not prefetch:

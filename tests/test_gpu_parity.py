@@ -785,6 +785,69 @@ def test_replacement_cut_and_its_repeat(ctx, ko):
         assert_feats(got, *oracle_feats(want), what="replace mindist=%d lost=%d of %d" % (mindist, len(gone), n))
 
 
+@pytest.mark.parametrize("build_stream", [0, 1])
+def test_select_prepare_gives_the_same_replacement(ko, build_stream):
+    """klt_select_prepare_async scores a slot ahead of its replacement pass (on the build stream when that is on).  Same list as the
+    inline path and as the reference walk; scores that no longer belong to the slot's contents or to the parameters are not used."""
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.backend import Context, REPLACING_SOME
+    n = 3000
+    base = synth.synth_base(1920, 1080, 7)
+    f0, f1 = synth.synth_frame(1920, 1080, 7, 0, base=base), synth.synth_frame(1920, 1080, 7, 3, base=base)
+    tc = make_tc(levels=3, ss=4)
+    p = params_from_tc(tc)
+    c = Context(0)
+    try:
+        c.configure(tc)
+        c.set_option(15, build_stream)
+
+        def lose(fl, seed):
+            rng = np.random.default_rng(seed)
+            gone = rng.choice(np.flatnonzero(fl["val"] >= 0), 120, replace=False)
+            fl = fl.copy()
+            fl["val"][gone] = -1
+            fl["x"][gone] = -1.0
+            fl["y"][gone] = -1.0
+            return fl
+
+        def check(slot, frame, fl, what):
+            want = ko.select_good_features(p, frame.astype(np.float32), n, mode=REPLACING_SOME, fl=fl.copy())
+            got, _ = c.select(slot, n, mode=REPLACING_SOME, fl=fl.copy(), use_pyramid=True)
+            assert_feats(got, *oracle_feats(want), what=what)
+            return got
+
+        c.upload(0, f0)
+        c.build_pyramids(0, sync=False)
+        first, placed = c.select(0, n, use_pyramid=True)
+        assert placed == n
+        fl = lose(first, 1)
+        inline = check(0, f0, fl, "inline replacement")
+        c.select_prepare(0)
+        prepared = check(0, f0, fl, "prepared replacement")
+        assert np.array_equal(inline, prepared)
+        # the scores follow the slot's contents through a swap ...
+        c.upload(1, f1)
+        c.build_pyramids(1, sync=False)
+        c.select_prepare(1)
+        c.swap_slots(0, 1)
+        check(0, f1, fl, "prepared, then swapped")
+        # ... and are dropped when the slot is rebuilt with another frame
+        c.select_prepare(0)
+        c.upload(0, f0)
+        c.build_pyramids(0, sync=False)
+        check(0, f0, lose(first, 2), "prepared, then rebuilt")
+        # ... or when the selection parameters change
+        c.select_prepare(0)
+        tc2 = make_tc(levels=3, ss=4, mindist=14)
+        tc2.min_eigenvalue = 40
+        c.configure(tc2)
+        p = params_from_tc(tc2)
+        c.build_pyramids(0, sync=False)                 # (set_params keeps the pyramids: same taps)
+        check(0, f0, lose(first, 3), "prepared, then other parameters")
+    finally:
+        c.close()
+
+
 def test_nms_global_grid_path(ctx, ko):
     """mindist 2 at 1920x1080 -> the cell grid (960x540 u32) exceeds LDS and lives in global memory"""
     from pyfeaturetrack_amd import synth
@@ -1215,6 +1278,61 @@ def test_build_stream_prefetch_keeps_results(ko):
         assert (ref.val[-1] >= 0).sum() > n // 2
     finally:
         sgf.KLT_verbose = 1
+
+
+def test_build_stream_waits_for_the_tracker_that_reads_the_slot():
+    """A build on the build stream is ordered behind the tracker launches that read the slot it overwrites (per-slot read marks), not
+    behind the whole main stream.  A long tracker launch (a million features) on a small frame, the slot refilled (asynchronous ingest +
+    build, both far shorter than the tracker) right behind it: that tracker's result is untouched, and the next tracker sees the new
+    pyramids -- the records of the same calls with a synchronisation after each (the tracker itself is pinned elsewhere)."""
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.backend import Context, FEAT_DTYPE
+    w, h, n = 320, 240, 1000000
+    base = synth.synth_base(w, h, 31)
+    frames = [synth.synth_frame(w, h, 31, k, shift=(1.3, 0.8), base=base) for k in range(3)]
+    tc = make_tc(levels=2, ss=4, max_residue=10.0)
+    rng = np.random.default_rng(5)
+    fl = np.zeros(n, FEAT_DTYPE)
+    fl["x"] = rng.uniform(40, w - 40, n).astype(np.float32)
+    fl["y"] = rng.uniform(40, h - 40, n).astype(np.float32)
+    fl["val"] = 1
+    c = Context(0)
+    try:
+        c.configure(tc)
+        c.set_option(15, 1)
+        stage = c.staging((h, w), count=1)
+        stage[0][...] = frames[2]
+
+        def run(step_sync):
+            def after():
+                if step_sync:
+                    c.sync()
+                    c.upload_wait()
+            c.upload(0, frames[0])
+            c.upload(1, frames[1])
+            c.build_pyramids_batch([0, 1], sync=True)
+            c.featbuf_upload(0, fl)
+            c.sync()
+            c.track_async(0, 1, 0, 1, n)                    # reads the pyramids of slots 0 and 1 ...
+            after()
+            c.upload_async(0, stage[0])                     # ... while slot 0 gets another frame
+            after()
+            c.build_pyramids(0, sync=False)                 # (build stream: must wait for the tracker above, and only for it)
+            after()
+            c.track_async(0, 1, 0, 2, n)
+            out = c.featbuf_download(1, n), c.featbuf_download(2, n)
+            c.upload_wait()
+            return out
+
+        want01, want21 = run(True)
+        assert np.count_nonzero(want01["val"] >= 0) > n // 2
+        assert not np.array_equal(want01["x"], want21["x"])
+        for rep in range(4):
+            got01, got21 = run(False)
+            assert np.array_equal(got01, want01), "the tracker whose slot was refilled behind it read the new pyramids (rep %d)" % rep
+            assert np.array_equal(got21, want21), "the tracker on the refilled slot did not see the new pyramids (rep %d)" % rep
+    finally:
+        c.close()
 
 
 def test_two_rank_launch_reaches_rccl_on_one_gpu():
