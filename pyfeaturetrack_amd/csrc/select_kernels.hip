@@ -1046,7 +1046,18 @@ __global__ __launch_bounds__(256) void mis_prepare_kernel(const klt_feat *__rest
     if (f < nfeat) { ft = fl[f]; snapshot[f] = ft; }
     if (overwrite_all) { if (f == 0) *nfill_out = nfeat; return; }
     unsigned before = 0;
-    for (int i = tid; i < f0; i += 256) before += fl[i].val < 0 ? 1u : 0u;
+    {
+        // (eight loads in flight: the last workgroup of a 20 000-feature list walks 78 strides of 256 records)
+        int i = tid;
+        for (; i + 7 * 256 < f0; i += 8 * 256) {
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = fl[i + u * 256].val;
+#pragma unroll
+            for (int u = 0; u < 8; u++) before += v[u] < 0 ? 1u : 0u;
+        }
+        for (; i < f0; i += 256) before += fl[i].val < 0 ? 1u : 0u;
+    }
     const unsigned base = block_sum_256(before, red);
     const unsigned lost = (f < nfeat && ft.val < 0) ? 1u : 0u;
     const unsigned incl = block_scan_256(lost, red);
