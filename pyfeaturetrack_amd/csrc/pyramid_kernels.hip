@@ -735,6 +735,11 @@ __global__ __launch_bounds__(256) void pyr_vreduce_kernel(PyrReduceArgs a)
 // (A one-launch-per-level kernel -- vertical reduction from the previous level's H planes, the level's gradients and the next
 // level's H planes in one workgroup -- existed in round 1 as KLT_OPT_FUSED_LEVELS: bit-identical, 12 us per level against 5 + 5 + 5
 // for the three small launches, because its phases are serial and latency-bound inside a workgroup.  Removed in round 2.)
+// (The last level's reduction inside the merged gradient launch -- 1024-thread workgroups, a 32x8 tile + halo of 3 reduced into LDS, halo
+// positions beyond the frame reflected there, gradient passes on it; the gradients of the levels in between as further workgroups of
+// the same launch -- was built and measured in round 2 as well: bit-identical (all parity tests), 10.5 us per launch against 4.9 + 5.3 for
+// the two launches it replaces, 0.0567 vs 0.0557 ms per pair on one stream.  The launch boundary it saves (1.5-2 us) is less than
+// what the longer serial chain of a workgroup costs; not kept.)
 
 }  // namespace
 
