@@ -100,7 +100,8 @@ struct klt_ctx {
     unsigned long long *keys = nullptr;
     size_t keys_cap = 0;
     uint8_t *seedmap = nullptr;
-    size_t seed_cap = 0;
+    size_t seed_cap = 0, seed_n = 0;          // pixels the stamps in the map are valid for
+    uint8_t seed_stamp = 0;                   // stamp of the latest replacement pass (1..255)
     uint32_t *grid = nullptr;
     size_t grid_cap = 0;
     int *nms_slots = nullptr;
@@ -1239,15 +1240,21 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     // REPLACING_SOME: the squares of the live features are marked first; the eigenvalue kernels skip marked pixels, so neither the
     // scoring nor the minimum-distance stage ever sees them
     if (mode == KLT_REPLACING_SOME && d >= 0) {
+        const uint8_t *before = c->seedmap;
         if (int rc = ensure(c, c->seedmap, c->seed_cap, N)) return rc;
-        HIPCHK(c, hipMemsetAsync(c->seedmap, 0, N, c->stream));
+        if (c->seedmap != before || c->seed_n != N || c->seed_stamp == 255) {       // new map, other frame size, or the stamps wrapped
+            HIPCHK(c, hipMemsetAsync(c->seedmap, 0, N, c->stream));
+            c->seed_n = N;
+            c->seed_stamp = 0;
+        }
+        c->seed_stamp++;
         TimerScope t(c, F_SEED, (double)n * 16);
-        launch_seed_fill(c->stream, b->d, n, c->seedmap, nc, nr, d);
+        launch_seed_fill(c->stream, b->d, n, c->seedmap, nc, nr, d, c->seed_stamp);
         seed = c->seedmap;
     }
 
     SelectArgs sa;
-    sa.sat = c->sat; sa.valmap = c->valmap; sa.keys = c->keys; sa.seedmap = seed;
+    sa.sat = c->sat; sa.valmap = c->valmap; sa.keys = c->keys; sa.seedmap = seed; sa.seed_stamp = c->seed_stamp;
     sa.val_in = nullptr;
     sa.hist = sa.ticket = sa.info = nullptr; sa.hist_target = 0; sa.hist_slots = nullptr; sa.hist_per_slot = 0;
     if (c->score_override_n) {
@@ -1331,7 +1338,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
         unsigned *const acc_count_d = c->mis_cnt + off_acc;
         int *const nfill_d = c->placed_d + 2;
         MisArgs ma;
-        ma.keys = pre ? pre->keys : c->keys; ma.seed = pre ? seed : nullptr; ma.ncols = nc; ma.st = c->mis_st; ma.list = c->mis_list; ma.cnt = c->mis_cnt;
+        ma.keys = pre ? pre->keys : c->keys; ma.seed = pre ? seed : nullptr; ma.seed_stamp = c->seed_stamp; ma.ncols = nc; ma.st = c->mis_st; ma.list = c->mis_list; ma.cnt = c->mis_cnt;
         ma.remaining = c->mis_cnt + off_rem; ma.acc_cnt = c->mis_cnt + off_tacc; ma.acc_cap = tile_cap;
         ma.acc_keys = c->mis_tile_keys; ma.info = info_d;
         ma.nx = nx; ma.ny = ny; ma.R = R; ma.stage = 1; ma.bx = bx; ma.by = by; ma.step = step;

@@ -79,7 +79,8 @@ struct SelectArgs {
     const float *sat;        // 3 planes (gxx, gxy, gyy), each ncols*nrows
     float *valmap;           // [ny][nx]
     unsigned long long *keys;
-    const uint8_t *seedmap;  // may be null
+    const uint8_t *seedmap;  // may be null; a pixel is blocked when it holds seed_stamp
+    uint8_t seed_stamp;
     const float *val_in;     // test hook: eigenvalues given instead of computed (may be null)
     unsigned *hist, *ticket, *info;   // eigen_hist_kernel: 8192 bins, workgroup ticket, threshold info (hist may be null)
     unsigned hist_target;
@@ -113,7 +114,8 @@ struct MisArgs {
     const unsigned *info;             // info[0] = lowest key bin that takes part (top-K prefilter)
     int nx, ny, R /* exclusion radius in cells */, stage /* 1: stage tile + halo in LDS */;
     int bx, by, step;                 // pixel position of cell (i, j) = (bx + i * step, by + j * step)
-    const uint8_t *seed;              // optional: [nrows][ncols] squares of the live features; keys were scored WITHOUT it (klt_select_prepare_async)
+    const uint8_t *seed;              // optional: [nrows][ncols] squares of the live features (pixels holding seed_stamp); keys were scored WITHOUT it
+    uint8_t seed_stamp;               // (klt_select_prepare_async)
     int ncols;
 };
 
@@ -139,7 +141,7 @@ void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows);
 // step-synchronous wavefront pipelines (sat_pipeline.hip); return 0 or a hipError_t
 int  launch_sat_rows_pipe(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows);
 int  launch_sat_cols_pipe(hipStream_t s, float *sat, int ncols, int nrows);
-void launch_seed_fill(hipStream_t s, const klt_feat *fl, int nfeat, uint8_t *seedmap, int ncols, int nrows, int d);
+void launch_seed_fill(hipStream_t s, const klt_feat *fl, int nfeat, uint8_t *seedmap, int ncols, int nrows, int d, uint8_t stamp);
 void launch_eigen(hipStream_t s, const SelectArgs &a);
 void launch_sort_desc(hipStream_t s, unsigned long long *keys, int npow2);
 void launch_topk_prefilter(hipStream_t s, const unsigned long long *keys, int n, unsigned target, unsigned *hist,

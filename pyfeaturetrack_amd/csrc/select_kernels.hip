@@ -201,8 +201,10 @@ __global__ __launch_bounds__(SC_T) void sat_cols_kernel(float *__restrict__ sat,
 
 // ------------------------------------------------------------------ seed map for REPLACING_SOME
 // selectGoodFeatures.py:64-69: every live feature blocks the square of half-size d around (int(x), int(y))
+// The map is stamped, not cleared: a pixel is blocked when it carries THIS selection's stamp (1..255; the host clears the map when the
+// stamps wrap or the frame size changes), so that a replacement pass does not begin by zeroing a frame-sized map.
 __global__ void seed_fill_kernel(const klt_feat *__restrict__ fl, int nfeat, uint8_t *__restrict__ seedmap,
-                                 int ncols, int nrows, int d)
+                                 int ncols, int nrows, int d, uint8_t stamp)
 {
     const int f = blockIdx.x;
     if (f >= nfeat) return;
@@ -211,7 +213,7 @@ __global__ void seed_fill_kernel(const klt_feat *__restrict__ fl, int nfeat, uin
     const int cx = (int)ft.x, cy = (int)ft.y, side = 2 * d + 1;
     for (int k = threadIdx.x; k < side * side; k += blockDim.x) {
         const int ix = cx - d + k % side, iy = cy - d + k / side;
-        if (ix >= 0 && ix < ncols && iy >= 0 && iy < nrows) seedmap[(size_t)iy * ncols + ix] = 1;
+        if (ix >= 0 && ix < ncols && iy >= 0 && iy < nrows) seedmap[(size_t)iy * ncols + ix] = stamp;
     }
 }
 
@@ -232,7 +234,7 @@ __device__ __forceinline__ unsigned long long eigen_key(const SelectArgs &a, int
     const int x = a.bx + xi * a.step, y = a.by + yi * a.step;
     // REPLACING_SOME: a pixel inside the exclusion square of a live feature can never be placed (selectGoodFeatures.py:64-69 marks
     // the feature map before the walk), so it is not scored at all -- most of the frame when few features were lost
-    if (a.seedmap && a.seedmap[(size_t)y * a.ncols + x] != 0) { if (a.valmap) a.valmap[k] = 0.f; return 0ull; }
+    if (a.seedmap && a.seedmap[(size_t)y * a.ncols + x] == a.seed_stamp) { if (a.valmap) a.valmap[k] = 0.f; return 0ull; }
     const size_t plane = (size_t)a.ncols * a.nrows;
     const float gxx = window_sum(a.sat, a.ncols, x, y, a.hw, a.hh);
     const float gxy = window_sum(a.sat + plane, a.ncols, x, y, a.hw, a.hh);
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(256) void mask_hist_kernel(SelectArgs a)
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int k = k0 + S * u * 256, xi = k % a.nx, yi = k / a.nx;
-            masked[u] = k < ncand ? a.seedmap[(size_t)(a.by + yi * a.step) * a.ncols + a.bx + xi * a.step] : (uint8_t)1;
+            masked[u] = k < ncand ? (uint8_t)(a.seedmap[(size_t)(a.by + yi * a.step) * a.ncols + a.bx + xi * a.step] == a.seed_stamp) : (uint8_t)1;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(MIS_T) void mis_init_kernel(MisArgs a)
         inside[u] = xi < a.nx && yi < a.ny;
         pcell[u] = yi * a.nx + xi;
         key[u] = 1ull;
-        if (inside[u] && a.seed) key[u] = a.seed[(size_t)(a.by + yi * a.step) * a.ncols + a.bx + xi * a.step] ? 0ull : 1ull;
+        if (inside[u] && a.seed) key[u] = a.seed[(size_t)(a.by + yi * a.step) * a.ncols + a.bx + xi * a.step] == a.seed_stamp ? 0ull : 1ull;
     }
 #pragma unroll
     for (int u = 0; u < U; u++) key[u] = inside[u] && key[u] ? a.keys[pcell[u]] : 0ull;
@@ -1165,10 +1167,10 @@ void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows)
     hipLaunchKernelGGL(sat_cols_kernel, dim3((ncols + SC_COLS - 1) / SC_COLS, 3), dim3(SC_T), 0, s, sat, ncols, nrows);
 }
 
-void launch_seed_fill(hipStream_t s, const klt_feat *fl, int nfeat, uint8_t *seedmap, int ncols, int nrows, int d)
+void launch_seed_fill(hipStream_t s, const klt_feat *fl, int nfeat, uint8_t *seedmap, int ncols, int nrows, int d, uint8_t stamp)
 {
     if (nfeat <= 0 || d < 0) return;
-    hipLaunchKernelGGL(seed_fill_kernel, dim3(nfeat), dim3(64), 0, s, fl, nfeat, seedmap, ncols, nrows, d);
+    hipLaunchKernelGGL(seed_fill_kernel, dim3(nfeat), dim3(64), 0, s, fl, nfeat, seedmap, ncols, nrows, d, stamp);
 }
 
 void launch_eigen(hipStream_t s, const SelectArgs &a)

@@ -848,6 +848,34 @@ def test_select_prepare_gives_the_same_replacement(ko, build_stream):
         c.close()
 
 
+def test_replacement_seed_map_stamps_wrap(ctx, cfg1, img1, ko):
+    """The map of the live features' squares is stamped per replacement pass and cleared only when the 255 stamps wrap (or the frame
+    size changes): more than 255 passes in one context, other frame sizes in between, still the reference walk's list."""
+    from pyfeaturetrack_amd.backend import REPLACING_SOME
+    tc = make_tc(max_residue=10.0)
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    ctx.upload(2, img1)
+    small = np.ascontiguousarray(img1[:200, :300])
+    ctx.upload(3, small)
+    base = ko.select_good_features(p, img1.astype(np.float32), 100)
+    rng = np.random.default_rng(9)
+    for it in range(300):
+        fl = base.copy()
+        gone = rng.choice(100, 1 + it % 37, replace=False)
+        fl["val"][gone] = -1
+        fl["x"][gone] = -1.0
+        fl["y"][gone] = -1.0
+        frame, slot = (small, 3) if it % 50 == 49 else (img1, 2)
+        if slot == 3:
+            keep = (fl["x"] < 290) & (fl["y"] < 190)
+            fl["val"][~keep] = -1
+        got, _ = ctx.select(slot, 100, mode=REPLACING_SOME, fl=fl.copy())
+        if it % 50 == 49 or it >= 250 or it < 3:
+            want = ko.select_good_features(p, frame.astype(np.float32), 100, mode=REPLACING_SOME, fl=fl.copy())
+            assert_feats(got, *oracle_feats(want), what="replacement pass %d" % it)
+
+
 def test_nms_global_grid_path(ctx, ko):
     """mindist 2 at 1920x1080 -> the cell grid (960x540 u32) exceeds LDS and lives in global memory"""
     from pyfeaturetrack_amd import synth
