@@ -236,7 +236,8 @@ int klt_level_dims(klt_ctx *ctx, int slot, int level, int *ncols, int *nrows);
 int klt_download_f32(klt_ctx *ctx, int slot, int pyramid, int level, float *dst);
 /* selection intermediates of the last klt_select*: 0 = smoothed image, 1 = gradx, 2 = grady (full frame),
  * 3 = eigenvalue map [ny][nx] (scan order, goodFeaturesUtils.pyx:53-54; after a KLT_REPLACING_SOME selection the pixels inside
- * the exclusion squares of the live features read 0: they can never be placed and are not scored).  dims via klt_select_dims. */
+ * the exclusion squares of the live features read 0: they can never be placed and are not scored; a selection that used the
+ * scores of klt_select_prepare_async writes no map, and 3 is refused after it).  dims via klt_select_dims. */
 int klt_select_dims(klt_ctx *ctx, int what, int *ncols, int *nrows);
 int klt_download_select_f32(klt_ctx *ctx, int what, float *dst);
 /* the NEXT klt_select* takes `count` = nx*ny eigenvalues from `val` (scan order, as what = 3 above returns them) instead

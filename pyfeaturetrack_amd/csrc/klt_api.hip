@@ -152,6 +152,7 @@ struct klt_ctx {
     int *placed_d = nullptr;
     const float *last_sel[3] = {nullptr, nullptr, nullptr};
     int sel_nc = 0, sel_nr = 0, sel_nx = 0, sel_ny = 0, sel_npow2 = 0;
+    bool sel_valmap = false;          // the last selection wrote the eigenvalue map (one that used prepared scores did not)
     unsigned long long *stats_d = nullptr;
     bool collect_stats = false;
     bool use_fused = true;            // LDS-tiled fused kernels (pyramid_kernels.hip); off = generic two-pass kernels
@@ -1228,6 +1229,7 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     klt_ctx::ScoreCache *pre = nullptr;
     if (mode == KLT_REPLACING_SOME && use_pyramid && parallel_nms && prefilter && d >= 0 && !c->score_override_n)
         pre = find_scores(c, s, geom, min_eig);
+    c->sel_valmap = !pre;
     if (pre) {
         if (event_live(c, pre->ev_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, pre->ev, 0));
         else if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
@@ -1892,6 +1894,7 @@ int klt_download_select_f32(klt_ctx *c, int what, float *dst)
 {
     if (!c || !dst || what < 0 || what > 3) return fail(c, KLT_ERR_ARG, "bad argument");
     if (c->sel_nc == 0) return fail(c, KLT_ERR_STATE, "no selection has run");
+    if (what == 3 && !c->sel_valmap) return fail(c, KLT_ERR_STATE, "the last selection used prepared scores: no eigenvalue map was written");
     const float *src = what == 3 ? c->valmap : c->last_sel[what];
     const size_t cnt = what == 3 ? (size_t)c->sel_nx * c->sel_ny : (size_t)c->sel_nc * c->sel_nr;
     HIPCHK(c, hipSetDevice(c->device));

@@ -825,6 +825,9 @@ def test_select_prepare_gives_the_same_replacement(ko, build_stream):
         c.select_prepare(0)
         prepared = check(0, f0, fl, "prepared replacement")
         assert np.array_equal(inline, prepared)
+        from pyfeaturetrack_amd.backend import KltBackendError
+        with pytest.raises(KltBackendError, match="prepared scores"):
+            c.select_intermediate(3)                    # that selection wrote no eigenvalue map
         # the scores follow the slot's contents through a swap ...
         c.upload(1, f1)
         c.build_pyramids(1, sync=False)
