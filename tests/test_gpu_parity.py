@@ -879,6 +879,38 @@ def test_replacement_seed_map_stamps_wrap(ctx, cfg1, img1, ko):
             assert_feats(got, *oracle_feats(want), what="replacement pass %d" % it)
 
 
+def test_8k_frame_select_replace_and_track(ko):
+    """Twice the width and height of the largest BASELINE frame (7680x4320, 33 Mpixel; 32 400 minimum-distance tiles, candidate
+    indices past 2^24): selection, tracking into a shifted frame and replacement equal the oracle -- no index arithmetic overflows."""
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.backend import Context, REPLACING_SOME
+    W, H, NF = 7680, 4320, 30000
+    base = synth.synth_base(W, H, 11)
+    f0, f1 = synth.synth_frame(W, H, 11, 0, base=base), synth.synth_frame(W, H, 11, 1, base=base)
+    tc = make_tc(levels=3, ss=4, max_residue=10.0)
+    p = params_from_tc(tc)
+    c = Context(0)
+    try:
+        c.configure(tc)
+        c.upload(0, f0)
+        c.upload(1, f1)
+        c.build_pyramids_batch([0, 1], sync=False)
+        fl, placed = c.select(0, NF, use_pyramid=True)
+        ofl = ko.select_good_features(p, f0.astype(np.float32), NF)
+        assert placed == NF
+        assert_feats(fl, *oracle_feats(ofl), what="8K select")
+        fl, _ = c.track(0, 1, fl)
+        ko.track_features(p, ko.Pyramids(p, f0.astype(np.float32)), ko.Pyramids(p, f1.astype(np.float32)), ofl)
+        assert_feats(fl, *oracle_feats(ofl), what="8K track")
+        assert int(np.count_nonzero(fl["val"] >= 0)) > NF * 0.9
+        c.select_prepare(1)
+        fl, _ = c.select(1, NF, mode=REPLACING_SOME, fl=fl, use_pyramid=True)
+        ofl = ko.select_good_features(p, f1.astype(np.float32), NF, mode=REPLACING_SOME, fl=ofl)
+        assert_feats(fl, *oracle_feats(ofl), what="8K replacement (prepared scores)")
+    finally:
+        c.close()
+
+
 def test_nms_global_grid_path(ctx, ko):
     """mindist 2 at 1920x1080 -> the cell grid (960x540 u32) exceeds LDS and lives in global memory"""
     from pyfeaturetrack_amd import synth
