@@ -454,6 +454,9 @@ def run_cfg3(args, json_fd):
 def run_cfg5(args, json_fd):
     """BASELINE cfg-5 (single GPU): 3840x2160 sequence, 20000 features, sequential mode, lost features replaced after every
     frame.  Per step: upload is excluded (frames resident), pyramid of the new frame, track, REPLACING_SOME selection."""
+    ranks = Ranks(args)
+    if ranks.distributed:
+        return run_cfg5_blocks(args, json_fd, ranks)
     w, h, n = 3840, 2160, 20000
     nframes = 8
     tc = cfg2_context()
@@ -521,6 +524,81 @@ def run_cfg5(args, json_fd):
                             + (", and so are its summed-area tables and eigenvalues (klt_select_prepare_async)" if prepare else ""),
                             extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
                                        "lost_per_frame": lost, "build_stream": bool(prefetch), "scores_prepared": bool(prepare)}))
+
+
+def run_cfg5_blocks(args, json_fd, ranks):
+    """cfg-5 on N GPUs: ONE 3840x2160 sequence cut into blocks of 7 tracking steps, block r on rank r.  The tracker and
+    the replacement pass are a serial chain, so the feature list travels from rank to rank as a baton (klt_sendrecv_featbuf_async,
+    320 KB); what depends on the pixels only -- the pyramids and the selection scores of the block's frames -- is enqueued on the
+    owner's build stream at once and is ready (ranks > 0) long before the baton arrives.  Per-GPU work is fixed: weak scaling; the
+    serial chain bounds it.  With one rank (KLT_FORCE_DIST=1) this is the single-GPU sequence with all pixel
+    work enqueued ahead, and the baton a device copy."""
+    w, h, n, B = 3840, 2160, 20000, 7
+    rank, world = ranks.rank, ranks.world
+    tc = cfg2_context()
+    tc.max_residue = 10.0
+    ctx = Context(ranks.local_rank)
+    ctx.configure(tc)
+    base = synth.synth_base(w, h, 4)
+    first = rank * B                                       # global index of the block's frame 0 (= the previous block's last frame)
+    for j in range(B + 1):
+        ctx.upload(10 + j, synth.synth_frame(w, h, 4, first + j, base=base))
+    fl = None
+    if rank == 0:
+        ctx.build_pyramids(10)
+        fl, placed = ctx.select(10, n, use_pyramid=True)
+    ctx.set_option(15, 1)                                  # KLT_OPT_BUILD_STREAM
+    ctx.set_option(16, B + 1)                              # KLT_OPT_SCORE_SETS: one per frame of the block
+    ranks.attach([ctx])
+    FB_A, FB_B, FB_BATON, FB_ALL = 0, 1, 2, 3
+
+    def block():
+        ctx.comm_fence_featbuf(FB_B if B % 2 else FB_A)    # the baton sent at the end of the previous block has left its buffer
+        for j in range(B + 1):                             # the block's pixel work: build stream, nothing to wait for
+            ctx.build_pyramids(10 + j, sync=False)
+            if j:
+                ctx.select_prepare(10 + j)
+        if rank == 0:
+            ctx.featbuf_upload(FB_A, fl)
+        else:
+            ctx.sendrecv_featbuf(-1, -1, FB_A, rank - 1, n)             # the baton: the list after the previous block's last frame
+        for j in range(1, B + 1):
+            ctx.track_async(10 + j - 1, 10 + j, (FB_A, FB_B)[(j - 1) % 2], (FB_A, FB_B)[j % 2], n)
+            ctx.select_async(10 + j, 2, True, (FB_A, FB_B)[j % 2], n)
+        last = (FB_A, FB_B)[B % 2]
+        if world > 1 and rank + 1 < world:
+            ctx.sendrecv_featbuf(last, rank + 1, -1, -1, n)
+        elif world == 1:
+            ctx.sendrecv_featbuf(last, 0, FB_BATON, 0, n)                # one rank: the baton path as a device copy
+        return last
+
+    last = block()                                         # warm-up (allocations, RCCL's lazy connections)
+    ranks.fence()
+    reps = max(1, args.steps // B)
+
+    def region():
+        for _ in range(reps):
+            block()
+
+    el, regions, enq = timed_regions(ranks, region, reps, min(args.repeats, 7))
+    # the list after the last frame of every block, gathered on rank 0 (rank order = frame order)
+    ctx.gather_featbuf_async(last, FB_ALL, n, 0)
+    ctx.comm_wait()
+    ctx.sync()
+    if rank == 0:
+        table = ctx.featbuf_download(FB_ALL, n * world).reshape(world, n)
+        baton_ok = None
+        if world == 1:
+            baton_ok = bool(np.array_equal(ctx.featbuf_download(FB_BATON, n), table[0]))
+        frames_done = reps * B * world
+        emit(json_fd, base_line(n * frames_done / el, world, frames_done, 0, el / frames_done * 1e3, el / (reps * B) * 1e3,
+                                "cfg-5 on %d GPU(s): ONE 3840x2160 sequence in blocks of %d frames per GPU, 20000 features, sequential "
+                                "mode, lost features replaced after every frame; the feature list is the baton between the blocks (RCCL "
+                                "send / receive), the blocks' pyramids and selection scores are prepared on the owners' build streams" % (world, B),
+                                extra_cfg={"rccl_ranks": world, "live_after_each_block": [int((t["val"] >= 0).sum()) for t in table],
+                                           "ms_per_frame_of_the_chain": el / (reps * B * world) * 1e3, "baton_copy_ok": baton_ok,
+                                           "region_ms": {"median": el * 1e3, "min": min(regions) * 1e3, "max": max(regions) * 1e3}}))
+    ctx.close()
 
 
 # ================================================================================= launcher dry run

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 4
+#define KLT_ABI_VERSION 5
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -99,6 +99,7 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
  * them (one event each way per frame).  0 (default): one stream.  The caller must give frame t+1 a slot that no call still to be
  * enqueued reads (a ring of three slots for a sequence). */
 #define KLT_OPT_BUILD_STREAM 15
+#define KLT_OPT_SCORE_SETS 16            /* how many sets of prepared selection scores (klt_select_prepare_async) the context keeps: 2 (default) .. 256; a selection frees the set it uses */
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
 /* ---- parameters and taps ------------------------------------------------------------------- */
@@ -154,7 +155,8 @@ void *klt_featbuf_devptr(klt_ctx *ctx, int fb);             /* device address (f
 int klt_select_async(klt_ctx *ctx, int slot, int mode, int use_pyramid, int fb, int n);
 /* The list-independent half of a later klt_select_async(slot, KLT_REPLACING_SOME, use_pyramid = 1, ...): the summed-area tables and
  * the eigenvalue of every candidate window (goodFeaturesUtils.pyx:17-73, called from selectGoodFeatures.py:199-232) of the slot's
- * level-0 gradients, kept with the slot's contents (two sets per context; a set follows klt_swap_slots and dies with the next build
+ * level-0 gradients, kept with the slot's contents (KLT_OPT_SCORE_SETS sets per context; a set follows klt_swap_slots, is used by one
+ * selection, and dies with the next build
  * of the slot or a change of the selection parameters).  With KLT_OPT_BUILD_STREAM it runs on the build stream, i.e. while the main
  * stream tracks into the previous frame and replaces its lost features; the selection then only masks the live features'
  * squares, cuts and runs the minimum-distance passes.  Same result with or without this call. */
@@ -221,6 +223,12 @@ int klt_comm_info(klt_ctx *ctx, int *nranks, int *rank);       /* 1 / 0 when the
  * whole device-side [pairs x features] table (klt_featbuf_view). */
 int klt_allgather_featbuf_async(klt_ctx *ctx, int fb_src, int fb_dst, int n);
 int klt_gather_featbuf_async(klt_ctx *ctx, int fb_src, int fb_dst, int n, int root);
+/* The feature list as the baton of ONE temporal sequence cut into blocks of frames, one block per GPU (the tracker and the
+ * replacement pass are a serial chain, trackFeatures.py:250-346 / selectGoodFeatures.py:45-135; everything that depends on the pixels
+ * only is prepared by the block's owner meanwhile): n records of fb_send go to rank `to` and / or n records from rank `from` arrive in
+ * fb_recv (-1: no such side; to == from == own rank: a device copy), on the side stream behind everything enqueued on the context's
+ * stream so far; the context's stream then waits for the arrival.  fb_send must stay untouched until klt_comm_fence_featbuf_async. */
+int klt_sendrecv_featbuf_async(klt_ctx *ctx, int fb_send, int to, int fb_recv, int from, int n);
 int klt_comm_fence_async(klt_ctx *ctx);    /* the context's stream waits (on the device) for the collectives issued so far */
 /* ... only for the last collective that read or wrote feature buffer fb (call it before overwriting a table whose
  * gather may still be in flight; collectives on other tables keep overlapping) */

@@ -109,6 +109,7 @@ SYMBOLS = {
     "klt_comm_info": (_I, [_P, _PI, _PI]),
     "klt_allgather_featbuf_async": (_I, [_P, _I, _I, _I]),
     "klt_gather_featbuf_async": (_I, [_P, _I, _I, _I, _I]),
+    "klt_sendrecv_featbuf_async": (_I, [_P, _I, _I, _I, _I, _I]),
     "klt_comm_fence_async": (_I, [_P]),
     "klt_comm_fence_featbuf_async": (_I, [_P, _I]),
     "klt_comm_wait": (_I, [_P]),

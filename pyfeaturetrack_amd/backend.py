@@ -324,6 +324,11 @@ class Context:
     def gather_featbuf_async(self, fb_src, fb_dst, n, root=0):
         self._check(self._lib.klt_gather_featbuf_async(self._h, fb_src, fb_dst, n, root))
 
+    def sendrecv_featbuf(self, fb_send, to, fb_recv, frm, n):
+        """The feature list as a baton (klt_sendrecv_featbuf_async): n records of fb_send to rank `to` and / or from rank `frm` into
+        fb_recv (-1: no such side); the context's stream waits for the arrival."""
+        self._check(self._lib.klt_sendrecv_featbuf_async(self._h, fb_send, to, fb_recv, frm, n))
+
     def comm_fence(self):
         """The context's stream waits (on the device) for the collectives issued so far."""
         self._check(self._lib.klt_comm_fence_async(self._h))

@@ -209,6 +209,26 @@ int comm_gather(KltComm *k, hipStream_t producer, const void *src, void *dst, si
     return comm_mark_done(k, err);
 }
 
+// point to point, one group: `bytes` at src go to rank `to` and / or `bytes` from rank `from` arrive at dst (-1: no such side).
+// Sending to oneself (to == from == own rank) is a device copy.
+int comm_sendrecv(KltComm *k, hipStream_t producer, const void *src, int to, void *dst, int from, size_t bytes, std::string &err)
+{
+    if (to >= k->nranks || from >= k->nranks || (to < 0 && from < 0)) { err = "send / receive peer out of range"; return KLT_ERR_ARG; }
+    if ((to >= 0 && !src) || (from >= 0 && !dst)) { err = "send / receive buffer missing"; return KLT_ERR_ARG; }
+    if ((to == k->rank) != (from == k->rank)) { err = "a rank can only send to itself what it receives from itself"; return KLT_ERR_ARG; }
+    COMM_HIP(hipSetDevice(k->device));
+    if (int rc = comm_order_behind(k, producer, err)) return rc;
+    if (to == k->rank) {
+        COMM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, k->side));
+    } else {
+        COMM_NCCL(g_rccl.GroupStart());
+        if (to >= 0) COMM_NCCL(g_rccl.Send(src, bytes, ncclUint8, to, k->comm, k->side));
+        if (from >= 0) COMM_NCCL(g_rccl.Recv(dst, bytes, ncclUint8, from, k->comm, k->side));
+        COMM_NCCL(g_rccl.GroupEnd());
+    }
+    return comm_mark_done(k, err);
+}
+
 // `consumer` waits (on the device) for every collective issued so far
 int comm_fence(KltComm *k, hipStream_t consumer, std::string &err)
 {

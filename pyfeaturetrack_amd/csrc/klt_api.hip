@@ -125,7 +125,8 @@ struct klt_ctx {
     unsigned *mis_cnt = nullptr;              // [tiles] + kMisRounds remaining counters + accepted counter
     size_t mis_st_cap = 0, mis_list_cap = 0, mis_cnt_cap = 0;
     // klt_select_prepare_async: the list-independent half of a selection (summed-area tables, eigenvalue keys) of a slot's level 0, computed
-    // ahead of time (on the build stream when that is on).  Two entries: the next frame's keys are written while this frame's are read.
+    // ahead of time (on the build stream when that is on).  Two sets by default: the next frame's keys are written while this frame's are read;
+    // a rank that prepares a whole block of frames while it waits for the feature list of the previous block keeps one per frame.
     struct ScoreCache {
         unsigned long long *keys = nullptr;
         size_t cap = 0;
@@ -134,7 +135,8 @@ struct klt_ctx {
         double min_eig = 0;
         hipEvent_t ev = nullptr;
         uint64_t ev_serial = 0;
-    } pre[2];
+    };
+    std::vector<ScoreCache> pre = std::vector<ScoreCache>(2);      // KLT_OPT_SCORE_SETS
     float *sat_pre = nullptr;
     size_t sat_pre_cap = 0;
     uint64_t gen_counter = 0, pre_stamp = 0;
@@ -768,7 +770,8 @@ void klt_destroy(klt_ctx *c)
         if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1); hipFree(c->track_order);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
-    hipFree(c->pre[0].keys); hipFree(c->pre[1].keys); hipFree(c->sat_pre);
+    for (auto &e : c->pre) hipFree(e.keys);
+    hipFree(c->sat_pre);
     hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
@@ -931,6 +934,13 @@ int klt_set_option(klt_ctx *c, int option, int value)
         if (!value && c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));      // pending builds finish; their events stay valid
         if (c->build_stream_on != (value != 0)) c->last_build_on_bstream = -1;   // trackers launched meanwhile carry no read marks: the next
         c->build_stream_on = value != 0;                                          // build over there waits for the whole main stream
+        return KLT_OK;
+    }
+    if (option == KLT_OPT_SCORE_SETS) {
+        if (value < 2 || value > 256) return fail(c, KLT_ERR_ARG, "KLT_OPT_SCORE_SETS takes 2..256");
+        if (int rc = sync_all(c)) return rc;
+        for (size_t i = (size_t)value; i < c->pre.size(); i++) hipFree(c->pre[i].keys);
+        c->pre.resize((size_t)value);
         return KLT_OK;
     }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
@@ -1120,8 +1130,11 @@ int klt_select_prepare_async(klt_ctx *c, int slot)
         for (auto &e : c->pre)                  // an earlier preparation on the build stream shares the table scratch
             if (e.ev && event_live(c, e.ev_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, e.ev, 0));
     }
-    klt_ctx::ScoreCache *e = &c->pre[0];
-    if (c->pre[0].gen != s->gen && (c->pre[1].gen == s->gen || c->pre[1].stamp < c->pre[0].stamp)) e = &c->pre[1];
+    // the set that already belongs to these contents, else a free one, else the oldest
+    klt_ctx::ScoreCache *e = nullptr;
+    for (auto &x : c->pre) if (x.gen == s->gen) { e = &x; break; }
+    if (!e) for (auto &x : c->pre) if (!x.gen) { e = &x; break; }
+    if (!e) { e = &c->pre[0]; for (auto &x : c->pre) if (x.stamp < e->stamp) e = &x; }
     if (int rc = ensure(c, c->sat_pre, c->sat_pre_cap, 3 * N)) return rc;
     if (int rc = ensure(c, e->keys, e->cap, (size_t)g.npow2)) return rc;
     e->gen = 0;
@@ -1230,6 +1243,10 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     if (mode == KLT_REPLACING_SOME && use_pyramid && parallel_nms && prefilter && d >= 0 && !c->score_override_n)
         pre = find_scores(c, s, geom, min_eig);
     c->sel_valmap = !pre;
+    struct Consume {                                       // a set is used once: the selection frees it when it is through with it
+        klt_ctx::ScoreCache *e;
+        ~Consume() { if (e) e->gen = 0; }
+    } consume{pre};
     if (pre) {
         if (event_live(c, pre->ev_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, pre->ev, 0));
         else if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
@@ -1825,6 +1842,37 @@ int klt_gather_featbuf_async(klt_ctx *c, int fb_src, int fb_dst, int n, int root
 {
     if (c && c->comm && (root < 0 || root >= comm_nranks(c->comm))) return fail(c, KLT_ERR_ARG, "gather root out of range");
     return gather_common(c, fb_src, fb_dst, n, root < 0 ? 0 : root);
+}
+
+// The feature list as a baton between the GPUs of one temporal sequence: n records of fb_send go to rank `to` and / or
+// n records arrive in fb_recv from rank `from` (-1: no such side), on the communicator's side stream behind everything enqueued on the
+// main stream so far; the main stream then waits for the arrival, so whatever is enqueued next reads the received list.
+int klt_sendrecv_featbuf_async(klt_ctx *c, int fb_send, int to, int fb_recv, int from, int n)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (!c->comm) return fail(c, KLT_ERR_STATE, "klt_comm_init_rank has not been called");
+    if (n <= 0 || (to < 0 && from < 0)) return fail(c, KLT_ERR_ARG, "bad send / receive arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    klt_feat *dst = nullptr;
+    if (from >= 0) {
+        if (fb_recv == fb_send && to >= 0) return fail(c, KLT_ERR_ARG, "send and receive buffers must differ");
+        FeatBuf *bd;
+        if (int rc = get_fb(c, fb_recv, n, &bd)) return rc;             // may grow c->fbs: take the source pointer afterwards
+        dst = bd->d;
+    }
+    const klt_feat *src = nullptr;
+    if (to >= 0) {
+        if (fb_send < 0 || (size_t)fb_send >= c->fbs.size() || c->fbs[fb_send].cap < n) return fail(c, KLT_ERR_STATE, "source feature buffer not that large");
+        src = c->fbs[fb_send].d;
+    }
+    std::string err;
+    if (const int rc = comm_sendrecv(c->comm, c->stream, src, to, dst, from, (size_t)n * sizeof(klt_feat), err)) return fail(c, rc, err);
+    if (to >= 0) c->fbs[fb_send].comm_done = comm_last_done(c->comm);
+    if (from >= 0) {
+        c->fbs[fb_recv].comm_done = comm_last_done(c->comm);
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->fbs[fb_recv].comm_done, 0));
+    }
+    return KLT_OK;
 }
 
 int klt_comm_fence_async(klt_ctx *c)

@@ -700,6 +700,47 @@ def test_cfg4_sharded_bench_with_native_gather(tmp_path):
     assert line["parity_checked"] is True and line["scaling"] == "strong" and line["value"] > 0
 
 
+def test_cfg5_blocks_with_the_baton_on_one_rank(tmp_path):
+    """`bench.py --config cfg5 --gpus N`: one 4K sequence in blocks of frames, the feature list handed from rank to rank
+    (klt_sendrecv_featbuf_async), every block's pyramids and selection scores enqueued ahead on its owner's build stream
+    (KLT_OPT_SCORE_SETS).  With one rank the baton is a device copy through the same entry point; the sequence keeps all its
+    features alive, as the un-blocked sequence does."""
+    line = _run_bench(["--config", "cfg5", "--gpus", "1", "--steps", "7", "--repeats", "5"], KLT_FORCE_DIST="1",
+                      KLT_RDZV_FILE=str(tmp_path / "ids"))
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["rccl_ranks"] == 1 and line["value"] > 0
+    assert cfg["baton_copy_ok"] is True and cfg["live_after_each_block"] == [20000]
+    plain = _run_bench(["--config", "cfg5", "--steps", "7"])
+    assert plain["config"]["live_at_end"] == 20000 and plain["config"]["scores_prepared"] is True
+
+
+def test_sendrecv_featbuf_to_oneself():
+    """klt_sendrecv_featbuf_async on a one-rank communicator: the device copy, the wait of the context's stream for the arrival,
+    argument checks."""
+    from pyfeaturetrack_amd.backend import Context, FEAT_DTYPE, KltBackendError
+    c = Context(0)
+    try:
+        with pytest.raises(KltBackendError, match="klt_comm_init_rank"):
+            c.sendrecv_featbuf(0, 0, 1, 0, 4)
+        import ctypes as C
+        from pyfeaturetrack_amd._abi import load_library
+        uid = (C.c_uint8 * 128)()
+        assert load_library().klt_comm_unique_id(uid) == 0
+        c.comm_init(1, 0, bytes(uid))
+        fl = np.zeros(1000, FEAT_DTYPE)
+        fl["x"] = np.arange(1000)
+        fl["val"] = 7
+        c.featbuf_upload(0, fl)
+        c.sendrecv_featbuf(0, 0, 1, 0, 1000)
+        assert np.array_equal(c.featbuf_download(1, 1000), fl)
+        with pytest.raises(KltBackendError, match="out of range"):
+            c.sendrecv_featbuf(0, 1, -1, -1, 10)            # there is no rank 1
+        with pytest.raises(KltBackendError, match="itself"):
+            c.sendrecv_featbuf(0, 0, -1, -1, 10)            # a send to oneself needs its receive
+    finally:
+        c.close()
+
+
 def test_native_gather_entry_points(tmp_path):
     """klt_comm_* / klt_(all)gather_featbuf_async through the C ABI on a one-rank communicator: the gathered table equals the
     source, the per-buffer fence orders a later overwrite behind the collective, errors come back as codes."""
