@@ -574,13 +574,10 @@ def run_cfg5_blocks(args, json_fd, ranks):
 
     last = block()                                         # warm-up (allocations, RCCL's lazy connections)
     ranks.fence()
-    reps = max(1, args.steps // B)
-
-    def region():
-        for _ in range(reps):
-            block()
-
-    el, regions, enq = timed_regions(ranks, region, reps, min(args.repeats, 7))
+    # a timed region is ONE pass of the sequence over the ranks (a second pass inside the region would let rank 0 start it while the
+    # others still work on the first: N pipelined replicas, not one sequence)
+    reps = 1
+    el, regions, enq = timed_regions(ranks, block, B * world, max(5, min(args.repeats, 15)))
     # the list after the last frame of every block, gathered on rank 0 (rank order = frame order)
     ctx.gather_featbuf_async(last, FB_ALL, n, 0)
     ctx.comm_wait()
