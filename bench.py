@@ -490,10 +490,15 @@ def run_cfg5(args, json_fd):
             if not prefetch:
                 ctx.build_pyramids(10 + k, sync=False)
             ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)      # the chain first: the build stream waits for nothing on this one
+            if prefetch and not timed:
+                ctx.select_begin(10 + k, 2, True, k % 2, n)   # ... KLTReplaceLostFeatures on the resident level-0 images, up to the host's look
             if prefetch and k + 1 < nframes:
                 ctx.build_pyramids(10 + k + 1, sync=False)
                 if prepare:
                     ctx.select_prepare(10 + k + 1)        # SAT + eigenvalues of the next frame, behind its build on the build stream
+            if prefetch and not timed:
+                ctx.select_finish()
+                continue
             if timed:
                 lost.append(int((ctx.featbuf_download(k % 2, n)["val"] < 0).sum()))      # (synchronises)
                 t = time.perf_counter()
@@ -564,7 +569,7 @@ def run_cfg5_blocks(args, json_fd, ranks):
             ctx.sendrecv_featbuf(-1, -1, FB_A, rank - 1, n)             # the baton: the list after the previous block's last frame
         for j in range(1, B + 1):
             ctx.track_async(10 + j - 1, 10 + j, (FB_A, FB_B)[(j - 1) % 2], (FB_A, FB_B)[j % 2], n)
-            ctx.select_async(10 + j, 2, True, (FB_A, FB_B)[j % 2], n)
+            ctx.select_async(10 + j, 2, True, (FB_A, FB_B)[j % 2], n)        # (nothing to enqueue in between: the pixel work is ahead)
         last = (FB_A, FB_B)[B % 2]
         if world > 1 and rank + 1 < world:
             ctx.sendrecv_featbuf(last, rank + 1, -1, -1, n)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 5
+#define KLT_ABI_VERSION 6
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -153,6 +153,13 @@ void *klt_featbuf_devptr(klt_ctx *ctx, int fb);             /* device address (f
  * level-0 image/gradients of the slot's pyramids are reused (selectGoodFeatures.py:176-181),
  * otherwise the slot's raw frame is smoothed/differentiated afresh (:183-197). */
 int klt_select_async(klt_ctx *ctx, int slot, int mode, int use_pyramid, int fb, int n);
+/* klt_select_async in two halves.  klt_select_begin_async enqueues everything up to the point where the host has to look at the
+ * outcome (how many passes the minimum-distance stage needed, whether the candidate cut held); klt_select_finish waits, looks and --
+ * rarely -- enqueues more passes or the repeat with every candidate.  Between the two the caller may enqueue other work that does not
+ * touch the list or select again: the next frame's upload, build and klt_select_prepare_async (a sequence overlaps the host side of
+ * frame t+1 with the GPU side of frame t's replacement this way).  klt_select_finish without a pending selection returns KLT_OK. */
+int klt_select_begin_async(klt_ctx *ctx, int slot, int mode, int use_pyramid, int fb, int n);
+int klt_select_finish(klt_ctx *ctx);
 /* The list-independent half of a later klt_select_async(slot, KLT_REPLACING_SOME, use_pyramid = 1, ...): the summed-area tables and
  * the eigenvalue of every candidate window (goodFeaturesUtils.pyx:17-73, called from selectGoodFeatures.py:199-232) of the slot's
  * level-0 gradients, kept with the slot's contents (KLT_OPT_SCORE_SETS sets per context; a set follows klt_swap_slots, is used by one

@@ -82,6 +82,8 @@ SYMBOLS = {
     "klt_featbuf_view": (_I, [_P, _I, _I, _I, _I]),
     "klt_featbuf_devptr": (_P, [_P, _I]),
     "klt_select_async": (_I, [_P, _I, _I, _I, _I, _I]),
+    "klt_select_begin_async": (_I, [_P, _I, _I, _I, _I, _I]),
+    "klt_select_finish": (_I, [_P]),
     "klt_select_prepare_async": (_I, [_P, _I]),
     "klt_select": (_I, [_P, _I, _I, _I, _P, _I, _PI]),
     "klt_track_async": (_I, [_P, _I, _I, _I, _I, _I]),

@@ -254,6 +254,14 @@ class Context:
     def select_async(self, slot, mode, use_pyramid, fb, n):
         self._check(self._lib.klt_select_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))
 
+    def select_begin(self, slot, mode, use_pyramid, fb, n):
+        """First half of select_async: everything enqueued up to the host's look at the outcome (klt_select_begin_async)."""
+        self._check(self._lib.klt_select_begin_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))
+
+    def select_finish(self):
+        """Second half: waits, and completes the selection (klt_select_finish)."""
+        self._check(self._lib.klt_select_finish(self._h))
+
     def select_prepare(self, slot):
         """Scores of the slot's level-0 images ahead of a REPLACING_SOME selection on it (klt_select_prepare_async); asynchronous."""
         self._check(self._lib.klt_select_prepare_async(self._h, slot))

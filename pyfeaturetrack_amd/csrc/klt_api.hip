@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -62,6 +63,36 @@ struct Timed { int fam; hipEvent_t a, b; double bytes; };
 std::string g_create_error;
 
 }  // namespace
+
+// one set of prepared selection scores (klt_select_prepare_async)
+struct ScoreCache {
+    unsigned long long *keys = nullptr;
+    size_t cap = 0;
+    uint64_t gen = 0, stamp = 0;      // generation of the slot contents the keys were scored on (0 = empty); age
+    int nc = 0, nr = 0, bx = 0, by = 0, hw = 0, hh = 0, step = 0, nx = 0, ny = 0;
+    double min_eig = 0;
+    hipEvent_t ev = nullptr;
+    uint64_t ev_serial = 0;
+};
+
+// The parallel minimum-distance selection in two halves: everything up to the point where the host has to look at the outcome
+// (klt_select_begin_async) and the rest (klt_select_finish: wait, look, and -- rarely -- more passes or the repeat with every
+// candidate).  Between the two the caller may enqueue other work (the next frame's upload, build and score preparation).
+struct SelectJob {
+    static constexpr int kMaxRounds = 512;
+    MisArgs ma;
+    NmsArgs pa;
+    SelectArgs sa;
+    klt_feat *fl = nullptr;
+    ScoreCache *pre = nullptr;
+    unsigned *zero_from = nullptr, *hist_d = nullptr, *ticket_d = nullptr, *info_d = nullptr, *rank_d = nullptr, *acc_count_d = nullptr;
+    int *nfill_d = nullptr;
+    size_t zero_n = 0;
+    long long bound = 0, np2 = 0, ncand = 0, target = 0;
+    int n = 0, mode = 0, rounds_per_look = 0, attempt = 0, round = 0, look = 0;
+    bool by_rank = false, prefilter = false, filtered = false;
+};
+
 
 struct klt_ctx {
     int device = -1;
@@ -127,16 +158,8 @@ struct klt_ctx {
     // klt_select_prepare_async: the list-independent half of a selection (summed-area tables, eigenvalue keys) of a slot's level 0, computed
     // ahead of time (on the build stream when that is on).  Two sets by default: the next frame's keys are written while this frame's are read;
     // a rank that prepares a whole block of frames while it waits for the feature list of the previous block keeps one per frame.
-    struct ScoreCache {
-        unsigned long long *keys = nullptr;
-        size_t cap = 0;
-        uint64_t gen = 0, stamp = 0;      // generation of the slot contents the keys were scored on (0 = empty); age
-        int nc = 0, nr = 0, bx = 0, by = 0, hw = 0, hh = 0, step = 0, nx = 0, ny = 0;
-        double min_eig = 0;
-        hipEvent_t ev = nullptr;
-        uint64_t ev_serial = 0;
-    };
     std::vector<ScoreCache> pre = std::vector<ScoreCache>(2);      // KLT_OPT_SCORE_SETS
+    std::unique_ptr<SelectJob> sel_job;       // a selection between klt_select_begin_async and klt_select_finish
     float *sat_pre = nullptr;
     size_t sat_pre_cap = 0;
     uint64_t gen_counter = 0, pre_stamp = 0;
@@ -1046,6 +1069,105 @@ void *klt_featbuf_devptr(klt_ctx *c, int fb)
 
 // ---------------------------------------------------------------------------------------- selection
 namespace {
+// start of an attempt: free slots + snapshot of the list, scores / histogram / cut (attempt 0) or "every candidate" (attempt 1), tile lists
+int select_job_start(klt_ctx *c, SelectJob &j)
+{
+    j.filtered = j.prefilter && j.attempt == 0;
+    SelectArgs &sa = j.sa;
+    if (j.attempt == 0) {
+        launch_mis_prepare(c->stream, j.fl, j.n, j.pa.overwrite_all, j.pa.slots, j.nfill_d, c->fl_snapshot, j.zero_from, j.zero_n);
+        if (j.filtered) { sa.hist = j.hist_d; sa.ticket = j.ticket_d; sa.info = j.info_d; sa.hist_target = (unsigned)((j.target + 3) / 4); }
+        if (j.filtered && j.mode == KLT_REPLACING_SOME) {
+            // only the lost features' slots are filled and the live features' squares are not scored at all: 64 candidates per
+            // LOST feature (at least 4096) instead of 64 per list entry -- most of a frame's candidates never enter the passes.
+            // (cfg-5, 50-95 lost of 20000 per frame: a floor of 65536 / 16384 / 4096 / 1024 candidates reads 0.424 / 0.387 /
+            // 0.365 / 0.364 ms per frame; too tight a cut only costs the repeat below, never the result)
+            sa.hist_target = 4096 / 4; sa.hist_slots = j.nfill_d; sa.hist_per_slot = 64 / 4;
+        }
+        if (j.pre) {
+            // scored ahead of time without the seed map: histogram of the keys outside it here, the mask itself in mis_init
+            sa.keys = j.pre->keys;
+            TimerScope t(c, F_EIGEN, (double)j.ncand * 2);
+            launch_mask_hist(c->stream, sa);
+        } else {
+            TimerScope t(c, F_EIGEN, (double)j.ncand * (48 + 4 + 8));
+            launch_eigen_hist(c->stream, sa);
+        }
+    } else {
+        launch_zero_words(c->stream, j.zero_from, j.zero_n);      // threshold bin 0: every candidate
+    }
+    if (!j.by_rank) HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)j.np2 * sizeof(unsigned long long), c->stream));
+    j.round = 0;
+    TimerScope t(c, F_NMS, (double)j.ncand * 12);
+    launch_mis_init(c->stream, j.ma);
+    return 0;
+}
+
+// a batch of passes, then the accepted candidates ranked and placed, and the few words the host looks at written to pinned memory
+int select_job_rounds(klt_ctx *c, SelectJob &j)
+{
+    {
+        TimerScope t(c, F_NMS, (double)j.n * 16);
+        for (int r = 0; r < j.rounds_per_look; r++, j.round++)
+            if (const int e = launch_mis_round(c->stream, j.ma, j.round))
+                return fail(c, KLT_ERR_DEVICE, std::string("minimum-distance pass: ") + hipGetErrorString((hipError_t)e));
+    }
+    j.look = j.round < 64 ? j.round : 64;                        // the last `look` passes
+    const unsigned *rem_d = j.ma.remaining + j.round - j.look;
+    launch_mis_compact(c->stream, j.ma, c->keys2, j.acc_count_d);
+    if (j.by_rank) {
+        TimerScope t(c, F_NMS, (double)j.n * 16);
+        launch_mis_place(c->stream, j.pa, j.acc_count_d, j.rank_d, j.nfill_d, (int)j.bound, c->readback, rem_d, j.look, j.info_d);
+    } else {
+        { TimerScope t(c, F_SORT, (double)j.np2 * 16); launch_sort_desc(c->stream, c->keys2, (int)j.np2); }
+        TimerScope t(c, F_NMS, (double)j.n * 16);
+        const int e = launch_nms(c->stream, j.pa);
+        if (e) return fail(c, KLT_ERR_DEVICE, std::string("nms launch: ") + hipGetErrorString((hipError_t)e));
+        launch_mis_results(c->stream, c->readback, rem_d, j.look, j.info_d, c->placed_d);
+    }
+    return 0;
+}
+
+// the host's look at the outcome, and whatever it asks for; returns when the selection is complete
+int select_job_finish(klt_ctx *c, SelectJob &j)
+{
+    const unsigned *const rem = c->readback, *const info = c->readback + 64, *const res = c->readback + 72;
+    for (;;) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (rem[j.look - 1] != 0u) {
+            // a dependency chain longer than the passes run so far: put the list back and keep going
+            if (j.round + j.rounds_per_look > SelectJob::kMaxRounds) return fail(c, KLT_ERR_DEVICE, "minimum-distance passes did not settle");
+            HIPCHK(c, hipMemcpyAsync(j.fl, c->fl_snapshot, (size_t)j.n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+            if (j.by_rank) launch_zero_words(c->stream, j.rank_d, (size_t)j.bound);
+            else HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)j.np2 * sizeof(unsigned long long), c->stream));
+            if (int rc = select_job_rounds(c, j)) return rc;
+            continue;
+        }
+        int needed = j.look;                                         // learn how many passes were needed
+        while (needed > 1 && rem[needed - 2] == 0u) needed--;
+        needed += j.round - j.look;
+        // replacement runs frame after frame: one spare pass, because a frame that needs one pass more than the last
+        // one costs a host round trip and another batch of passes, an idle pass 2-5 us
+        if (j.mode == KLT_REPLACING_SOME) needed += 1;
+        c->mis_rounds_hint = needed < 2 ? 2 : (needed > 32 ? 32 : needed);
+        c->sorted_keys = j.by_rank ? nullptr : c->keys2; c->sorted_count = j.by_rank ? 0 : (int)j.np2;
+        // ran out of accepted candidates although the prefilter dropped some: repeat with every candidate
+        if (j.filtered && res[1] && info[1] < info[2]) {
+            HIPCHK(c, hipMemcpyAsync(j.fl, c->fl_snapshot, (size_t)j.n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+            j.attempt = 1;
+            if (int rc = select_job_start(c, j)) return rc;
+            if (int rc = select_job_rounds(c, j)) return rc;
+            continue;
+        }
+        break;
+    }
+    if (j.pre) j.pre->gen = 0;                                       // a score set is used once
+    HIPCHK(c, hipGetLastError());
+    return KLT_OK;
+}
+}  // namespace
+
+namespace {
 // borders / half-windows as ScanImageForGoodFeatures receives them: Python floats truncated to C ints
 // (selectGoodFeatures.py:168-169, :215-221, goodFeaturesUtils.pyx:35-37)
 struct SelGeom { int bx, by, hw, hh, step, nx, ny; long long ncand, npow2; };
@@ -1085,7 +1207,7 @@ int enqueue_sat(klt_ctx *c, hipStream_t st, const float *gx, const float *gy, fl
     return 0;
 }
 
-klt_ctx::ScoreCache *find_scores(klt_ctx *c, const Slot *s, const SelGeom &g, double min_eig)
+ScoreCache *find_scores(klt_ctx *c, const Slot *s, const SelGeom &g, double min_eig)
 {
     if (!s->pyr_valid || !s->gen) return nullptr;
     for (auto &e : c->pre)
@@ -1131,10 +1253,13 @@ int klt_select_prepare_async(klt_ctx *c, int slot)
             if (e.ev && event_live(c, e.ev_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, e.ev, 0));
     }
     // the set that already belongs to these contents, else a free one, else the oldest
-    klt_ctx::ScoreCache *e = nullptr;
+    ScoreCache *e = nullptr;
     for (auto &x : c->pre) if (x.gen == s->gen) { e = &x; break; }
     if (!e) for (auto &x : c->pre) if (!x.gen) { e = &x; break; }
-    if (!e) { e = &c->pre[0]; for (auto &x : c->pre) if (x.stamp < e->stamp) e = &x; }
+    if (!e) {
+        const ScoreCache *busy = c->sel_job ? c->sel_job->pre : nullptr;      // (a pending selection still reads its set)
+        for (auto &x : c->pre) if (&x != busy && (!e || x.stamp < e->stamp)) e = &x;
+    }
     if (int rc = ensure(c, c->sat_pre, c->sat_pre_cap, 3 * N)) return rc;
     if (int rc = ensure(c, e->keys, e->cap, (size_t)g.npow2)) return rc;
     e->gen = 0;
@@ -1155,9 +1280,10 @@ int klt_select_prepare_async(klt_ctx *c, int slot)
     return KLT_OK;
 }
 
-int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, int n)
+int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, int n)
 {
     if (int rc = check_ready(c)) return rc;
+    if (c->sel_job) return fail(c, KLT_ERR_STATE, "a selection is pending: klt_select_finish first");
     if (mode != KLT_SELECTING_ALL && mode != KLT_REPLACING_SOME) return fail(c, KLT_ERR_ARG, "bad selection mode");
     if (n <= 0) return fail(c, KLT_ERR_ARG, "nFeatures must be positive");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1239,12 +1365,12 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
 
     // scores prepared ahead of time (klt_select_prepare_async) are used by the replacement pass of the parallel path; everything else
     // computes them here
-    klt_ctx::ScoreCache *pre = nullptr;
+    ScoreCache *pre = nullptr;
     if (mode == KLT_REPLACING_SOME && use_pyramid && parallel_nms && prefilter && d >= 0 && !c->score_override_n)
         pre = find_scores(c, s, geom, min_eig);
     c->sel_valmap = !pre;
     struct Consume {                                       // a set is used once: the selection frees it when it is through with it
-        klt_ctx::ScoreCache *e;
+        ScoreCache *e;
         ~Consume() { if (e) e->gen = 0; }
     } consume{pre};
     if (pre) {
@@ -1322,23 +1448,24 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     // ---- parallel minimum distance (default): decide every candidate in a few passes, rank the accepted ones, and
     // fill the free slots with the best of them (same result as the sorted serial walk below)
     if (parallel_nms) {
-        constexpr int kMaxRounds = 512;
+        auto job = std::make_unique<SelectJob>();
+        SelectJob &j = *job;
         // passes enqueued before the host looks at the outcome: what the previous selection needed (frames of a sequence
         // behave alike); an idle pass costs 5 us, a second look costs a host round trip
-        const int kMisRounds = c->mis_rounds_hint;
+        j.rounds_per_look = c->mis_rounds_hint;
         const int tiles = mis_tiles(nx, ny);
         // two accepted candidates are more than R cells apart in x or in y: at most one per (R+1)x(R+1) block of cells
-        const long long bound = R < 0 ? ncand : (long long)((nx + R) / (R + 1)) * ((ny + R) / (R + 1));
-        const bool by_rank = bound <= 98304;                // rank by counting; beyond that sort the accepted keys
-        long long np2 = 2048;
-        while (np2 < bound) np2 <<= 1;
+        j.bound = R < 0 ? ncand : (long long)((nx + R) / (R + 1)) * ((ny + R) / (R + 1));
+        j.by_rank = j.bound <= 98304;                       // rank by counting; beyond that sort the accepted keys
+        j.np2 = 2048;
+        while (j.np2 < j.bound) j.np2 <<= 1;
         // one allocation of counters: [tiles] list lengths | [kMaxRounds] "undecided left after pass r" | accepted count |
         // workgroup ticket | [tiles] accepted per tile | 8192 histogram bins + 4 words of prefilter info | [bound] ranks
-        const size_t off_rem = (size_t)tiles, off_acc = off_rem + kMaxRounds, off_ticket = off_acc + 1, off_tacc = off_ticket + 1,
+        const size_t off_rem = (size_t)tiles, off_acc = off_rem + SelectJob::kMaxRounds, off_ticket = off_acc + 1, off_tacc = off_ticket + 1,
                      off_hist = off_tacc + tiles, off_rank = off_hist + 8192 + 4;
         const int tile_cap = mis_tile_capacity(R);
-        const size_t n_cnt = off_rank + (by_rank ? (size_t)bound : 0);
-        if (int rc = ensure(c, c->keys2, c->keys2_cap, (size_t)(np2 > npow2 ? np2 : npow2))) return rc;
+        const size_t n_cnt = off_rank + (j.by_rank ? (size_t)j.bound : 0);
+        if (int rc = ensure(c, c->keys2, c->keys2_cap, (size_t)(j.np2 > npow2 ? j.np2 : npow2))) return rc;
         if (int rc = ensure(c, c->mis_st, c->mis_st_cap, (size_t)ncand)) return rc;
         if (int rc = ensure(c, c->mis_list, c->mis_list_cap, (size_t)tiles * 1024)) return rc;
         if (int rc = ensure(c, c->mis_cnt, c->mis_cnt_cap, n_cnt)) return rc;
@@ -1351,96 +1478,25 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
             c->readback = (unsigned *)hp;
             c->pinned.push_back(hp);
         }
-        unsigned *const rem = c->readback, *const info = c->readback + 64;
-        const unsigned *const res = c->readback + 72;
-        unsigned *const info_d = c->mis_cnt + off_hist + 8192, *const rank_d = c->mis_cnt + off_rank;
-        unsigned *const acc_count_d = c->mis_cnt + off_acc;
-        int *const nfill_d = c->placed_d + 2;
-        MisArgs ma;
+        j.fl = b->d; j.n = n; j.ncand = ncand; j.mode = mode; j.prefilter = prefilter; j.target = target; j.pre = pre;
+        j.zero_from = c->mis_cnt + off_rem; j.zero_n = n_cnt - off_rem;
+        j.hist_d = c->mis_cnt + off_hist; j.ticket_d = c->mis_cnt + off_ticket;
+        j.info_d = c->mis_cnt + off_hist + 8192; j.rank_d = c->mis_cnt + off_rank;
+        j.acc_count_d = c->mis_cnt + off_acc;
+        j.nfill_d = c->placed_d + 2;
+        MisArgs &ma = j.ma;
         ma.keys = pre ? pre->keys : c->keys; ma.seed = pre ? seed : nullptr; ma.seed_stamp = c->seed_stamp; ma.ncols = nc; ma.st = c->mis_st; ma.list = c->mis_list; ma.cnt = c->mis_cnt;
         ma.remaining = c->mis_cnt + off_rem; ma.acc_cnt = c->mis_cnt + off_tacc; ma.acc_cap = tile_cap;
-        ma.acc_keys = c->mis_tile_keys; ma.info = info_d;
+        ma.acc_keys = c->mis_tile_keys; ma.info = j.info_d;
         ma.nx = nx; ma.ny = ny; ma.R = R; ma.stage = 1; ma.bx = bx; ma.by = by; ma.step = step;
-        NmsArgs pa = na;                                    // placement: the accepted candidates never exclude each other
-        pa.d = -1; pa.cell = 1; pa.cell_magic = 0u; pa.gw = pa.gh = 1; pa.grid_in_lds = 1; pa.grid_global = nullptr;
-        pa.keys = c->keys2; pa.nkeys = (int)np2;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            const bool filtered = prefilter && attempt == 0;
-            if (attempt == 0) {
-                launch_mis_prepare(c->stream, b->d, n, pa.overwrite_all, pa.slots, nfill_d, c->fl_snapshot, c->mis_cnt + off_rem, n_cnt - off_rem);
-                if (filtered) { sa.hist = c->mis_cnt + off_hist; sa.ticket = c->mis_cnt + off_ticket; sa.info = info_d; sa.hist_target = (unsigned)((target + 3) / 4); }
-                if (filtered && mode == KLT_REPLACING_SOME) {
-                    // only the lost features' slots are filled and the live features' squares are not scored at all: 64 candidates per
-                    // LOST feature (at least 4096) instead of 64 per list entry -- most of a frame's candidates never enter the passes.
-                    // (cfg-5, 50-95 lost of 20000 per frame: a floor of 65536 / 16384 / 4096 / 1024 candidates reads 0.424 / 0.387 /
-                    // 0.365 / 0.364 ms per frame; too tight a cut only costs the repeat below, never the result)
-                    sa.hist_target = 4096 / 4; sa.hist_slots = nfill_d; sa.hist_per_slot = 64 / 4;
-                }
-                if (pre) {
-                    // scored ahead of time without the seed map: histogram of the keys outside it here, the mask itself in mis_init
-                    sa.keys = pre->keys;
-                    TimerScope t(c, F_EIGEN, (double)ncand * 2);
-                    launch_mask_hist(c->stream, sa);
-                } else {
-                    TimerScope t(c, F_EIGEN, (double)ncand * (48 + 4 + 8));
-                    launch_eigen_hist(c->stream, sa);
-                }
-            } else {
-                launch_zero_words(c->stream, c->mis_cnt + off_rem, n_cnt - off_rem);      // threshold bin 0: every candidate
-            }
-            if (!by_rank) HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)np2 * sizeof(unsigned long long), c->stream));
-            int round = 0;
-            {
-                TimerScope t(c, F_NMS, (double)ncand * 12);
-                launch_mis_init(c->stream, ma);
-            }
-            unsigned left = 0;
-            for (;;) {
-                {
-                    TimerScope t(c, F_NMS, (double)n * 16);
-                    for (int r = 0; r < kMisRounds; r++, round++)
-                        if (const int e = launch_mis_round(c->stream, ma, round))
-                            return fail(c, KLT_ERR_DEVICE, std::string("minimum-distance pass: ") + hipGetErrorString((hipError_t)e));
-                }
-                const int look = round < 64 ? round : 64;                        // the last `look` passes
-                const unsigned *rem_d = ma.remaining + round - look;
-                launch_mis_compact(c->stream, ma, c->keys2, acc_count_d);
-                if (by_rank) {
-                    TimerScope t(c, F_NMS, (double)n * 16);
-                    launch_mis_place(c->stream, pa, acc_count_d, rank_d, nfill_d, (int)bound, c->readback, rem_d, look, info_d);
-                } else {
-                    { TimerScope t(c, F_SORT, (double)np2 * 16); launch_sort_desc(c->stream, c->keys2, (int)np2); }
-                    TimerScope t(c, F_NMS, (double)n * 16);
-                    const int e = launch_nms(c->stream, pa);
-                    if (e) return fail(c, KLT_ERR_DEVICE, std::string("nms launch: ") + hipGetErrorString((hipError_t)e));
-                    launch_mis_results(c->stream, c->readback, rem_d, look, info_d, c->placed_d);
-                }
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                left = rem[look - 1];
-                if (left == 0u) {
-                    int needed = look;                                           // learn how many passes were needed
-                    while (needed > 1 && rem[needed - 2] == 0u) needed--;
-                    needed += round - look;
-                    // replacement runs frame after frame: one spare pass, because a frame that needs one pass more than the last
-                    // one costs a host round trip and another batch of passes, an idle pass 2-5 us
-                    if (mode == KLT_REPLACING_SOME) needed += 1;
-                    c->mis_rounds_hint = needed < 2 ? 2 : (needed > 32 ? 32 : needed);
-                    break;
-                }
-                // a dependency chain longer than the passes run so far: put the list back and keep going
-                if (round + kMisRounds > kMaxRounds) return fail(c, KLT_ERR_DEVICE, "minimum-distance passes did not settle");
-                HIPCHK(c, hipMemcpyAsync(b->d, c->fl_snapshot, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
-                if (by_rank) launch_zero_words(c->stream, rank_d, (size_t)bound);
-                else HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)np2 * sizeof(unsigned long long), c->stream));
-            }
-            c->sorted_keys = by_rank ? nullptr : c->keys2; c->sorted_count = by_rank ? 0 : (int)np2;
-            // ran out of accepted candidates although the prefilter dropped some: repeat with every candidate
-            if (filtered && res[1] && info[1] < info[2]) {
-                HIPCHK(c, hipMemcpyAsync(b->d, c->fl_snapshot, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
-                continue;
-            }
-            break;
-        }
+        j.pa = na;                                          // placement: the accepted candidates never exclude each other
+        j.pa.d = -1; j.pa.cell = 1; j.pa.cell_magic = 0u; j.pa.gw = j.pa.gh = 1; j.pa.grid_in_lds = 1; j.pa.grid_global = nullptr;
+        j.pa.keys = c->keys2; j.pa.nkeys = (int)j.np2;
+        j.sa = sa;
+        consume.e = nullptr;                                // the job frees the score set when it is through with it
+        if (int rc = select_job_start(c, j)) return rc;
+        if (int rc = select_job_rounds(c, j)) return rc;
+        c->sel_job = std::move(job);
         HIPCHK(c, hipGetLastError());
         return KLT_OK;
     }
@@ -1480,6 +1536,21 @@ int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, in
     c->sorted_keys = c->keys; c->sorted_count = (int)(ncand < npow2 ? ncand : npow2);
     HIPCHK(c, hipGetLastError());
     return KLT_OK;
+}
+
+int klt_select_finish(klt_ctx *c)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (!c->sel_job) return KLT_OK;                       // nothing pending (or a path that completes in klt_select_begin_async)
+    HIPCHK(c, hipSetDevice(c->device));
+    std::unique_ptr<SelectJob> job = std::move(c->sel_job);
+    return select_job_finish(c, *job);
+}
+
+int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, int n)
+{
+    if (int rc = klt_select_begin_async(c, slot, mode, use_pyramid, fb, n)) return rc;
+    return klt_select_finish(c);
 }
 
 int klt_select(klt_ctx *c, int slot, int mode, int use_pyramid, klt_feat *inout, int n, int *n_placed)

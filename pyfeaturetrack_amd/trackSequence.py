@@ -23,6 +23,52 @@ _OPT_SELECT_AFFINE_STATE = 4
 _OPT_BUILD_STREAM = 15
 
 
+class _FrameStager:
+    """Reads the frames and copies them into pinned staging buffers on a helper thread (numpy's copy and the frame source's decoding
+    release the GIL), so that the host copy of frame k+2 -- 2 MB at 1080p, as long as the tracker of a frame runs -- is made while the
+    calling thread waits for the GPU in frame k's replacement pass.  Only the helper thread advances the iterator; every call
+    into the library stays on the calling thread."""
+
+    def __init__(self, frames, buffers, shape):
+        import queue
+        import threading
+        self._frames, self._shape = frames, shape
+        self._free, self._ready = queue.Queue(), queue.Queue()
+        for b in buffers:
+            self._free.put(b)
+        self._thread = threading.Thread(target=self._run, name="klt-frame-stager", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        try:
+            for img in self._frames:
+                arr = image_to_array(img)
+                if arr.shape != self._shape or arr.dtype != np.uint8:
+                    self._ready.put(("raw", arr))          # the calling thread deals with it (size error, or a synchronous upload)
+                    continue
+                buf = self._free.get()
+                if buf is None:
+                    return
+                buf[...] = arr
+                self._ready.put(("staged", buf))
+            self._ready.put((None, None))
+        except BaseException as e:                          # noqa: BLE001 -- handed to the calling thread
+            self._ready.put(("error", e))
+
+    def next(self):
+        kind, item = self._ready.get()
+        if kind == "error":
+            raise item
+        return kind, item
+
+    def release(self, buf):
+        self._free.put(buf)
+
+    def close(self):
+        self._free.put(None)
+        self._thread.join(timeout=2.0)       # (a frame source that blocks keeps its daemon thread; it touches no buffer any more)
+
+
 def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True, prefetch=True):
     """Track `nFeatures` features through `frames` (an iterable of equally sized 8-bit images) and return the
     KLT_FeatureTable: row 0 = the selected features, row k = the features after tracking frame k-1 -> k (and, with
@@ -57,20 +103,22 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
             tables.append(base)
         return tables[ci] + 1 + off
 
-    stage = ctx.staging((nrows, ncols), count=ring) if async_ingest and first.dtype == np.uint8 else None
+    stage = ctx.staging((nrows, ncols), count=ring + 1) if async_ingest and first.dtype == np.uint8 else None
+    in_flight = []                          # staging buffer whose host-to-device copy may still be running
 
-    def ingest(slot, img, k):
+    def ingest(slot, img, k, staged=False):
         if img.shape != (nrows, ncols):
             from .error import KLTError
             KLTError("(KLTTrackSequence) Size of incoming image ({0} by {1}) is different from size of previous image "
                      "({2} by {3})".format(img.shape[1], img.shape[0], ncols, nrows))
-        if stage is None or img.dtype != np.uint8:
-            ctx.upload(slot, img)
+        if staged:
+            ctx.upload_wait()               # the previous frame's copy has finished (kernels keep running): its buffer goes back
+            while in_flight:
+                stager.release(in_flight.pop())
+            ctx.upload_async(slot, img)
+            in_flight.append(img)
         else:
-            buf = stage[k % len(stage)]
-            ctx.upload_wait()               # the copy that last read this staging buffer has finished (kernels keep running)
-            buf[...] = img
-            ctx.upload_async(slot, buf)
+            ctx.upload(slot, img)
 
     ingest(s[0], first, 0)
     ctx.build_pyramids(s[0], sync=False)
@@ -82,36 +130,49 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
         state = ctx.take_affine_state()
         ctx.affine_alloc(state, nFeatures)
     k = 0
+    stager = _FrameStager(frames, stage, (nrows, ncols)) if stage is not None else None
     try:
         if affine:
             ctx.set_option(_OPT_SELECT_AFFINE_STATE, state)
         if prefetch:
             ctx.set_option(_OPT_BUILD_STREAM, 1)
 
-        def stage_frame(k, img):                     # upload + pyramid build of frame k (enqueued only)
-            ingest(s[k % ring], image_to_array(img), k)
+        def stage_frame(k, item):                    # upload + pyramid build of frame k (enqueued only)
+            ingest(s[k % ring], item[1], k, staged=item[0] == "staged")
             ctx.build_pyramids(s[k % ring], sync=False)
             if replace_lost and prefetch:            # ... and the list-independent half of its replacement pass, on the same stream
                 ctx.select_prepare(s[k % ring])
 
-        nxt = next(frames, None)
+        def next_frame():                            # ("staged", pinned buffer) | ("raw", array) | None at the end
+            if stager is not None:
+                item = stager.next()
+                return item if item[0] is not None else None
+            img = next(frames, None)
+            return None if img is None else ("raw", image_to_array(img))
+
+        nxt = next_frame()
         if nxt is not None:
             stage_frame(1, nxt)
         while nxt is not None:
             k += 1
-            nxt = next(frames, None)
+            nxt = next_frame()
             cur, prev = s[k % ring], s[(k - 1) % ring]
             if affine:
                 ctx.track_affine_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures, state)
             else:
                 ctx.track_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures)
+            if replace_lost:                         # the chain first: tracker, then the replacement pass up to the host's look at it
+                ctx.select_begin(cur, REPLACING_SOME, True, row_fb(k), nFeatures)
             if nxt is not None and prefetch:
-                stage_frame(k + 1, nxt)              # right behind the tracker's launch: the build stream overlaps it and the replacement
+                stage_frame(k + 1, nxt)              # the next frame's upload, build and scores: enqueued while the GPU works on the above
             if replace_lost:
-                ctx.select_async(cur, REPLACING_SOME, True, row_fb(k), nFeatures)
+                ctx.select_finish()
             if nxt is not None and not prefetch:
                 stage_frame(k + 1, nxt)
     finally:
+        ctx.select_finish()                          # (only pending after an exception)
+        if stager is not None:
+            stager.close()
         if prefetch:
             ctx.set_option(_OPT_BUILD_STREAM, 0)
         if affine:

@@ -952,6 +952,51 @@ def test_8k_frame_select_replace_and_track(ko):
         c.close()
 
 
+def test_select_begin_finish(ko):
+    """klt_select_begin_async / klt_select_finish: the selection in two halves with other work (upload, build and score preparation of
+    another slot) enqueued in between; the same list as klt_select_async; a second selection while one is pending is refused."""
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.backend import Context, KltBackendError, REPLACING_SOME, SELECTING_ALL
+    n = 3000
+    base = synth.synth_base(1920, 1080, 13)
+    f0, f1 = synth.synth_frame(1920, 1080, 13, 0, base=base), synth.synth_frame(1920, 1080, 13, 2, base=base)
+    tc = make_tc(levels=3, ss=4)
+    p = params_from_tc(tc)
+    c = Context(0)
+    try:
+        c.configure(tc)
+        c.set_option(15, 1)
+        c.select_finish()                                   # nothing pending: a no-op
+        c.upload(0, f0)
+        c.build_pyramids(0, sync=False)
+        c.featbuf_alloc(0, n)
+        c.select_begin(0, SELECTING_ALL, True, 0, n)
+        with pytest.raises(KltBackendError, match="pending"):
+            c.select_begin(0, SELECTING_ALL, True, 0, n)
+        c.upload(1, f1)                                     # other work between the halves
+        c.build_pyramids(1, sync=False)
+        c.select_prepare(1)
+        c.select_finish()
+        first = c.featbuf_download(0, n)
+        want = ko.select_good_features(p, f0.astype(np.float32), n)
+        assert_feats(first, *oracle_feats(want), what="selection in two halves")
+        fl = first.copy()
+        gone = np.random.default_rng(3).choice(n, 200, replace=False)
+        fl["val"][gone] = -1
+        fl["x"][gone] = -1.0
+        fl["y"][gone] = -1.0
+        c.featbuf_upload(1, fl)
+        c.select_begin(1, REPLACING_SOME, True, 1, n)       # uses the scores prepared above
+        c.build_pyramids(0, sync=False)                     # the other slot is rebuilt and re-scored meanwhile
+        c.select_prepare(0)
+        c.select_finish()
+        got = c.featbuf_download(1, n)
+        want = ko.select_good_features(p, f1.astype(np.float32), n, mode=REPLACING_SOME, fl=fl.copy())
+        assert_feats(got, *oracle_feats(want), what="replacement in two halves")
+    finally:
+        c.close()
+
+
 def test_nms_global_grid_path(ctx, ko):
     """mindist 2 at 1920x1080 -> the cell grid (960x540 u32) exceeds LDS and lives in global memory"""
     from pyfeaturetrack_amd import synth

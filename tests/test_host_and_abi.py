@@ -29,7 +29,7 @@ def test_library_exports_every_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     lib.klt_abi_version.restype = ctypes.c_int
-    assert lib.klt_abi_version() == 5
+    assert lib.klt_abi_version() == 6
 
 
 def test_struct_layouts():
