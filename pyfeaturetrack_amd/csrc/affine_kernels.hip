@@ -47,41 +47,50 @@ __device__ __forceinline__ float wave_sum(float v)
 // p[l] + p[l ^ 32], then ^ 16, ^ 8, ... -- but at every step a lane keeps only the half of the values its bit selects and hands the
 // other half to its partner, so the step costs N/2, N/4, ... shuffles instead of N: 31 + 1 instead of 32 x 6 for N = 32.  On return
 // v[0] of lane l holds the total of value (l >> s) & (N - 1), s = 6 - log2(N) (every total sits on 2^s adjacent lanes).
+// (Every step is a template instantiation with its own constant H and M: written as one loop over run-time copies of them, the
+// compiler indexed v[] dynamically -- 27-way compare / select chains, 860 of the 1620 vector instructions of an iteration.)
+template <int N, int H, int M>
+struct WaveSumScatter {
+    static __device__ __forceinline__ void run(float (&v)[N], int lane)
+    {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        if constexpr (H >= 1) {
+            if constexpr (M == 32) {
+                // gfx950's row swaps: v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second, so
+                // first + second is value i summed over (l, l ^ 32) in the lower half of the wavefront and value i + H in the upper
+                // half -- one swap and one add per pair of values, no selects (v_permlane16_swap below: the same with rows of 16 lanes)
+#pragma unroll
+                for (int i = 0; i < H; i++) {
+                    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + H]), false, false);
+                    v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+                }
+            } else if constexpr (M == 16) {
+#pragma unroll
+                for (int i = 0; i < H; i++) {
+                    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + H]), false, false);
+                    v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+                }
+            } else {
+                const bool up = (lane & M) != 0;
+#pragma unroll
+                for (int i = 0; i < H; i++) {
+                    const float send = up ? v[i] : v[i + H];
+                    const float keep = up ? v[i + H] : v[i];
+                    v[i] = keep + __shfl_xor(send, M);
+                }
+            }
+            WaveSumScatter<N, H / 2, M / 2>::run(v, lane);
+        } else if constexpr (M >= 1) {
+            v[0] = v[0] + __shfl_xor(v[0], M);
+            WaveSumScatter<N, 0, M / 2>::run(v, lane);
+        }
+    }
+};
+
 template <int N>
 __device__ __forceinline__ void wave_sum_scatter(float (&v)[N], int lane)
 {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    int m = 32, h = N / 2;
-    // m = 32 and m = 16 with gfx950's row swaps: v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of
-    // its second, so first + second is value i summed over (l, l ^ 32) in the lower half of the wavefront and value i + h in the
-    // upper half -- one swap and one add per pair of values, no selects (v_permlane16_swap: the same with rows of 16 lanes)
-    if (h >= 1) {
-#pragma unroll
-        for (int i = 0; i < h; i++) {
-            const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + h]), false, false);
-            v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
-        }
-        h >>= 1; m >>= 1;
-    }
-    if (h >= 1) {
-#pragma unroll
-        for (int i = 0; i < h; i++) {
-            const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + h]), false, false);
-            v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
-        }
-        h >>= 1; m >>= 1;
-    }
-#pragma unroll
-    for (; h >= 1; h >>= 1, m >>= 1) {
-        const bool up = (lane & m) != 0;
-#pragma unroll
-        for (int i = 0; i < h; i++) {
-            const float send = up ? v[i] : v[i + h];
-            const float keep = up ? v[i + h] : v[i];
-            v[i] = keep + __shfl_xor(send, m);
-        }
-    }
-    for (; m >= 1; m >>= 1) v[0] = v[0] + __shfl_xor(v[0], m);
+    WaveSumScatter<N, N / 2, 32>::run(v, lane);
 }
 
 // Numerical Recipes' gaussj with full pivoting, as upstream's _am_gauss_jordan_elimination, spread over the wavefront:
@@ -175,19 +184,25 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
     // pixels l, l + 64, ...).  The window loops below are NOT unrolled: four samples at a time with their 48 bilinear reads and 27
     // accumulators in flight needed 250+ VGPRs (one wavefront per SIMD); one sample at a time needs under 100 and five wavefronts
     // per SIMD hide the latency instead.
-    extern __shared__ float tsamp[];                      // [n] image (+ [n] gradx, [n] grady for the translation model)
+    extern __shared__ float tsamp[];                      // [n] image (+ [n] gradx, [n] grady for the translation model), then the offsets
+    // window offsets (i, j) of every sample as floats, once per feature: `k % width` and `k / width` with a run-time width are ~25
+    // integer instructions each, and the sample loops below ran them for every sample of every Newton iteration -- 28 % of this kernel's
+    // 29.9 M wavefront-instructions were integer arithmetic (profiles/r02_g_cfg3_sq_counters.json), and the kernel sits on its issue roof
+    float *const offx = tsamp + (MODE == 0 ? 3 * n : n), *const offy = offx + n;
     for (int k = lane; k < n; k += 64) {
         const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);
+        offx[k] = fi;
+        offy[k] = fj;
         tsamp[k] = bilinear_at(t_img, tw, x1 + fi, y1 + fj);
         if (MODE == 0) {
             tsamp[n + k] = bilinear_at(t_gx, tw, x1 + fi, y1 + fj);
             tsamp[2 * n + k] = bilinear_at(t_gy, tw, x1 + fi, y1 + fj);
         }
     }
-    // body(k, template image, template gradx, template grady) for every window pixel of this lane, in increasing k
+    // body(window offset x, y, template image, template gradx, template grady) for every window pixel of this lane, in increasing k
     auto for_samples = [&](auto body) {
 #pragma unroll 1
-        for (int k = lane; k < n; k += 64) body(k, tsamp[k], MODE == 0 ? tsamp[n + k] : 0.f, MODE == 0 ? tsamp[2 * n + k] : 0.f);
+        for (int k = lane; k < n; k += 64) body(offx[k], offy[k], tsamp[k], MODE == 0 ? tsamp[n + k] : 0.f, MODE == 0 ? tsamp[2 * n + k] : 0.f);
     };
     const float sxs[4] = {-(float)hw, -(float)hw, (float)hw, (float)hw};
     const float sys[4] = {(float)hh, -(float)hh, (float)hh, -(float)hh};
@@ -202,8 +217,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
                 break;
             }
             float gxx = 0.f, gxy = 0.f, gyy = 0.f, ex = 0.f, ey = 0.f;
-            for_samples([&](int k, float ti, float tgx, float tgy) {
-                const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);
+            for_samples([&](float fi, float fj, float ti, float tgx, float tgy) {
                 const float d = ti - bilinear_at(a.i2, nc, x2 + fi, y2 + fj);
                 const float g1 = tgx + bilinear_at(a.gx2, nc, x2 + fi, y2 + fj);
                 const float g2 = tgy + bilinear_at(a.gy2, nc, x2 + fi, y2 + fj);
@@ -230,9 +244,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
             float T[6][6], e[6];
             for (int r = 0; r < 6; r++) { e[r] = 0.f; for (int q = 0; q < 6; q++) T[r][q] = 0.f; }
             const int nn = MODE == 1 ? 4 : 6;
-            for_samples([&](int k, float ti, float, float) {
-                const int i = k % width - hw, j = k / width - hh;
-                const float x = (float)i, y = (float)j;
+            for_samples([&](float x, float y, float ti, float, float) {
                 const float mi = Axx * x + Axy * y, mj = Ayx * x + Ayy * y;
                 const float d = ti - bilinear_at(a.i2, nc, x2 + mi, y2 + mj);
                 const float g1 = bilinear_at(a.gx2, nc, x2 + mi, y2 + mj);
@@ -315,8 +327,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
     if ((x2 - old_x2) > a.max_differ || (y2 - old_y2) > a.max_differ) status = KLT_OOB;
     if (status == KLT_TRACKED) {
         float s = 0.f;
-        for_samples([&](int k, float ti, float, float) {
-            const float x = (float)(k % width - hw), y = (float)(k / width - hh);
+        for_samples([&](float x, float y, float ti, float, float) {
             const float mi = MODE ? Axx * x + Axy * y : x, mj = MODE ? Ayx * x + Ayy * y : y;
             s = s + fabsf(ti - bilinear_at(a.i2, nc, x2 + mi, y2 + mj));
         });
@@ -350,9 +361,10 @@ void launch_affine(hipStream_t s, const AffineArgs &a)
 {
     if (a.n <= 0) return;
     const size_t n = (size_t)a.width * a.height;
-    if (a.mode == 0) hipLaunchKernelGGL(affine_kernel<0>, dim3(a.n), dim3(64), 3 * n * sizeof(float), s, a);
-    else if (a.mode == 1) hipLaunchKernelGGL(affine_kernel<1>, dim3(a.n), dim3(64), n * sizeof(float), s, a);
-    else hipLaunchKernelGGL(affine_kernel<2>, dim3(a.n), dim3(64), n * sizeof(float), s, a);
+    // template samples + the two offset arrays
+    if (a.mode == 0) hipLaunchKernelGGL(affine_kernel<0>, dim3(a.n), dim3(64), 5 * n * sizeof(float), s, a);
+    else if (a.mode == 1) hipLaunchKernelGGL(affine_kernel<1>, dim3(a.n), dim3(64), 3 * n * sizeof(float), s, a);
+    else hipLaunchKernelGGL(affine_kernel<2>, dim3(a.n), dim3(64), 3 * n * sizeof(float), s, a);
 }
 
 void launch_affine_reset(hipStream_t s, klt_affine_rec *rec, int n)
