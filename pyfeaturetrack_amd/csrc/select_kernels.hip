@@ -748,6 +748,9 @@ __global__ __launch_bounds__(MIS_T) void mis_init_kernel(MisArgs a)
 // 1.0, keys 0.3 -- 11 us, and 16.8 us from the first workgroup's start to the last one's end; in the fifth pass (145 tiles, ~3
 // candidates) 0.4 / 2.0 / 0.8 / 0.9 / 0.2 / 0.1 / 0.1 -- 4.4 us in a 7.4 us launch.  Staging is state-map reads that missed the L2
 // (every kernel boundary invalidates it): hence the XCD-contiguous tile order below (-4 % on a 4K frame).
+// RC > 0: the exclusion radius as a compile-time constant (the reference's default mindist 10 -> 9 cells: tile geometry, window
+// loops and the index arithmetic fold); RC = 0: any radius
+template <int RC>
 __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
 {
     // staged tiles: S = states of the tile + halo ((32 + 2R)^2 u32), H = per row of S and interior column the maximum
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     const unsigned have = a.acc_cnt[tile];             // accepted candidates of this tile so far
     const int tiles_x = (a.nx + MIS_TILE - 1) / MIS_TILE;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int R = a.R, W = MIS_TILE + 2 * R, L = 2 * R + 1;
+    const int R = RC > 0 ? RC : a.R, W = MIS_TILE + 2 * R, L = 2 * R + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // (Deciding the last few candidates of a tile without staging it -- a wavefront reading each candidate's window straight from
     // the states -- was measured in round 2: every pass got slower, 11.3 vs 7.4 us for the late ones; the dependent L2 round trips
@@ -1217,15 +1220,21 @@ void launch_mis_init(hipStream_t s, const MisArgs &a)
     hipLaunchKernelGGL(mis_init_kernel, dim3(mis_tiles(a.nx, a.ny)), dim3(MIS_T), 0, s, a);
 }
 
+template <int RC>
+static int launch_mis_round_t(hipStream_t s, const MisArgs &a, int round, size_t lds)
+{
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)mis_round_kernel<RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(mis_round_kernel<RC>, dim3(mis_tiles(a.nx, a.ny)), dim3(MIS_T), lds, s, a, round);
+    return 0;
+}
+
 int launch_mis_round(hipStream_t s, const MisArgs &a, int round)
 {
     const size_t lds = (a.stage ? mis_stage_bytes(a.R) : 0) + (((size_t)a.acc_cap * sizeof(unsigned short) + 15) & ~(size_t)15);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)mis_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(mis_round_kernel, dim3(mis_tiles(a.nx, a.ny)), dim3(MIS_T), lds, s, a, round);
-    return 0;
+    return a.R == 9 ? launch_mis_round_t<9>(s, a, round, lds) : launch_mis_round_t<0>(s, a, round, lds);
 }
 
 void launch_mis_compact(hipStream_t s, const MisArgs &a, unsigned long long *out, unsigned *out_count)
