@@ -160,6 +160,7 @@ __global__ __launch_bounds__(PIPE_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     if (wave == 0) {
         float carry = 0.f;
         for (int s = 0; s < nsteps; s++) {
+            SAT_MARK(0, s, 0);
             if (s >= 1 && s <= ntiles) {
                 float *tile = pipe_lds + ((s - 1) % NSLOT) * CSLOT + lane;
                 float v[CT];
@@ -171,7 +172,9 @@ __global__ __launch_bounds__(PIPE_THREADS) __attribute__((amdgpu_waves_per_eu(1,
                     tile[u * 64] = carry;
                 }
             }
+            SAT_MARK(0, s, 1);
             step_barrier();
+            SAT_MARK(0, s, 2);
         }
     } else if (wave <= NLW) {                                   // ---- loaders: lane = (row of a group of four, quad of the strip)
         const int j = wave - 1;
@@ -179,6 +182,7 @@ __global__ __launch_bounds__(PIPE_THREADS) __attribute__((amdgpu_waves_per_eu(1,
         const int c = min(blockIdx.x * 64 + 4 * q, ncols - 4);
         f32x4 v[CT / 4];
         for (int s = -NLW; s < nsteps; s++) {
+            SAT_MARK(wave, s, 0);
             if (s >= 0 && s % NLW == j && s < ntiles) {
                 float *tile = pipe_lds + (s % NSLOT) * CSLOT;
 #pragma unroll
@@ -190,28 +194,36 @@ __global__ __launch_bounds__(PIPE_THREADS) __attribute__((amdgpu_waves_per_eu(1,
                 for (int g = 0; g < CT / 4; g++)
                     v[g] = *reinterpret_cast<const f32x4 *>(s_ + (size_t)min(t * CT + 4 * g + rsub, nrows - 1) * ncols + c);
             }
+            SAT_MARK(wave, s, 1);
             if (s >= 0) step_barrier();
+            SAT_MARK(wave, s, 2);
         }
     } else {                                                    // ---- storers
+        // every storer takes its share of EVERY tile (a storer that drained whole tiles in turn was busy 0.8-0.96 us of a step the chain
+        // wavefront needs 0.52-0.76 us of, tools/mb/sat_steps: sixteen 1 KB stores in a row; the other storer idled meanwhile)
         const int k = wave - 1 - NLW;
         const int rsub = lane >> 4, q = lane & 15;
         const int c = blockIdx.x * 64 + 4 * q;
+        constexpr int GS = CT / 4 / NSW;                           // groups of four rows per storer and tile
         for (int s = 0; s < nsteps; s++) {
             const int t = s - 2;
-            if (t >= 0 && t % NSW == k) {
+            SAT_MARK(wave, s, 0);
+            if (t >= 0) {
                 const float *tile = pipe_lds + (t % NSLOT) * CSLOT;
-                f32x4 v[CT / 4];
+                f32x4 v[GS];
 #pragma unroll
-                for (int g = 0; g < CT / 4; g++) v[g] = *reinterpret_cast<const f32x4 *>(tile + (4 * g + rsub) * 64 + 4 * q);
+                for (int g = 0; g < GS; g++) v[g] = *reinterpret_cast<const f32x4 *>(tile + (4 * (k * GS + g) + rsub) * 64 + 4 * q);
                 if (c < ncols) {
 #pragma unroll
-                    for (int g = 0; g < CT / 4; g++) {
-                        const int row = t * CT + 4 * g + rsub;
+                    for (int g = 0; g < GS; g++) {
+                        const int row = t * CT + 4 * (k * GS + g) + rsub;
                         if (row < nrows) *reinterpret_cast<f32x4 *>(s_ + (size_t)row * ncols + c) = v[g];
                     }
                 }
             }
+            SAT_MARK(wave, s, 1);
             step_barrier();
+            SAT_MARK(wave, s, 2);
         }
     }
 }

@@ -29,5 +29,22 @@ int main()
         for (int w = 0; w < 6; w++) printf(" %4lld %4lld |", d[(w * 64 + s) * 3 + 1] - d[(w * 64 + s) * 3], d[(w * 64 + s) * 3 + 2] - d[(w * 64 + s) * 3 + 1]);
         printf("\n");
     }
+    // the column pass (in place on the row pass's output): same table for workgroup (0, 0)
+    static long long z[6 * 64 * 3];
+    hipMemcpyToSymbol(HIP_SYMBOL(g_sat_dbg), z, sizeof(z));
+    for (int i = 0; i < 3; i++) launch_sat_cols_pipe(0, sat, nc, nr);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; i++) launch_sat_cols_pipe(0, sat, nc, nr);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("sat_cols_pipe: %.2f us per launch\n", ms * 1000 / 20);
+    hipMemcpyFromSymbol(d, HIP_SYMBOL(g_sat_dbg), sizeof(d));
+    const long long t1 = d[(1 * 64 + 0) * 3];
+    for (int s = 0; s < 19; s++) {
+        printf("%3d  %6lld |", s, d[(0 * 64 + s) * 3] - t1);
+        for (int w = 0; w < 6; w++) printf(" %4lld %4lld |", d[(w * 64 + s) * 3 + 1] - d[(w * 64 + s) * 3], d[(w * 64 + s) * 3 + 2] - d[(w * 64 + s) * 3 + 1]);
+        printf("\n");
+    }
     return 0;
 }
