@@ -1429,6 +1429,45 @@ def test_build_stream_prefetch_keeps_results(ko):
         sgf.KLT_verbose = 1
 
 
+def test_track_sequence_frame_source_errors_surface():
+    """The frames are read and staged on a helper thread: an exception of the frame source, and a frame of another size, surface in the
+    caller as they did when the caller read the frames itself; the next sequence on the same context is unaffected."""
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.trackSequence import KLTTrackSequence
+    w, h, n = 320, 240, 100
+    base = synth.synth_base(w, h, 3)
+    frames = [synth.synth_frame(w, h, 3, k, base=base) for k in range(8)]
+
+    def make():
+        tc = KLT_TrackingContext()
+        tc.sequentialMode = True
+        return tc
+
+    def failing():
+        for k, f in enumerate(frames):
+            if k == 5:
+                raise ValueError("camera unplugged")
+            yield f
+
+    def wrong_size():
+        for k, f in enumerate(frames):
+            yield f[:200, :300].copy() if k == 4 else f
+
+    sgf.KLT_verbose = 0
+    try:
+        with pytest.raises(ValueError, match="camera unplugged"):
+            KLTTrackSequence(make(), failing(), n)
+        with pytest.raises(SystemExit):                     # KLTError prints and exits, as the reference's does
+            KLTTrackSequence(make(), wrong_size(), n)
+        a = KLTTrackSequence(make(), iter(frames), n)
+        b = KLTTrackSequence(make(), iter(frames), n, async_ingest=False, prefetch=False)
+        assert np.array_equal(a.rec, b.rec) and a.rec.shape[0] == len(frames)
+    finally:
+        sgf.KLT_verbose = 1
+
+
 def test_build_stream_waits_for_the_tracker_that_reads_the_slot():
     """A build on the build stream is ordered behind the tracker launches that read the slot it overwrites (per-slot read marks), not
     behind the whole main stream.  A long tracker launch (a million features) on a small frame, the slot refilled (asynchronous ingest +
