@@ -782,7 +782,31 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     uint32_t *list = a.list + (size_t)tile * MIS_CAP;
     unsigned next_p = threadIdx.x < n ? list[threadIdx.x] : 0u;           // first batch, in flight during the staging
     if (threadIdx.x == 0) { s_acc = 0u; s_cursor = 0u; s_top = 0u; s_left = 0u; }
-    if (staged) {
+    // tile + halo inside the frame (all but the tiles along its edges): no test per cell -- column test once per lane, row test on the
+    // wavefront's (scalar) number; the general loop below spends a dozen instructions per load on them
+    const bool interior = staged && ox >= 0 && oy >= 0 && ox + W <= a.nx && oy + W <= a.ny;
+    if (interior) {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        for (int cx0 = 0; cx0 < W; cx0 += 64) {
+            const int cx = cx0 + lane;
+            if (cx < W) {
+                const uint32_t *col = a.st + ((unsigned)oy * (unsigned)a.nx + (unsigned)(ox + cx));
+                for (int r0 = 0; r0 < W; r0 += 64) {
+                    uint32_t v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const int r = min(r0 + wave_u + 4 * u, W - 1);          // (rows past the stage repeat its last one; not written)
+                        v[u] = col[(unsigned)r * (unsigned)a.nx];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const int r = r0 + wave_u + 4 * u;
+                        if (r < W) S[r * W + cx] = v[u];
+                    }
+                }
+            }
+        }
+    } else if (staged) {
         for (int cx0 = 0; cx0 < W; cx0 += 64)
             for (int r0 = 0; r0 < W; r0 += 64) {            // 16 rows per wavefront in flight at once
                 const int cx = cx0 + lane, gx = ox + cx;
@@ -798,6 +822,8 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
                     if (cx < W && r < W) S[r * W + cx] = v[u];
                 }
             }
+    }
+    if (staged) {
         __syncthreads();
         // H[r][c] = max of S[r][c .. c + 2R].  A thread makes 8 adjacent outputs of a row: their windows share the columns
         // c0 + 7 .. c0 + L - 1 (one running maximum), output j adds the last 7 - j columns before and the first j columns after that
