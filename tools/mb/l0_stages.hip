@@ -18,7 +18,7 @@ static void gauss_taps(Taps &g, Taps &d, double sigma, int n)
 int main(int argc, char **argv)
 {
     const bool reduce = argc > 1 && argv[1][0] == 'r';
-    const bool level = argc > 1 && argv[1][0] == 'l';      // pyr_level_kernel on a 480x270 level
+    const bool level = false;
     const int nc = 1920, nr = 1080;
     SmoothGradArgs a = {};
     Taps dummy;
@@ -38,11 +38,10 @@ int main(int argc, char **argv)
     pr.src_nc = nc; pr.src_nr = nr; pr.dst_nc = nc / 4; pr.dst_nr = nr / 4; pr.ss = 4; pr.log2ss = 2;
     for (int b = 0; b < 2; b++) { pr.src[b] = a.img[b]; pr.dst[b] = a.gx[b]; }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    LevelArgs la = {};
-    la.reduce = pr.taps; la.ggauss = a.ggauss; la.gderiv = a.gderiv;
-    la.src_nr = nr; la.nc = nc / 4; la.nr = nr / 4; la.hnext_nc = nc / 16;
-    for (int b = 0; b < 2; b++) { la.hsrc[b] = a.img[b]; la.img[b] = a.gx[b]; la.gx[b] = a.gy[b]; la.gy[b] = a.gy[b] + nc * nr / 2; float *h; hipMalloc(&h, 4 * (size_t)(nr / 4) * (nc / 16)); la.hnext[b] = h; }
-    auto go = [&]() { if (level) launch_pyr_level(0, la, 2, true); else if (reduce) launch_pyr_reduce(0, pr, 2); else launch_smooth_grad(0, a, 2, 0); };
+    const bool plain = argc > 1 && argv[1][0] == 'p';      // the kernel without the fused horizontal reduction
+    a.reduce = pr.taps; a.h1_nc = nc / 4;
+    for (int b = 0; b < 2; b++) { float *h1; hipMalloc(&h1, 4 * (size_t)nr * (nc / 4)); a.h1[b] = h1; }
+    auto go = [&]() { if (reduce) launch_pyr_reduce(0, pr, 2); else launch_smooth_grad(0, a, 2, 0, !plain); };
     for (int rep = 0; rep < 3; rep++) go();
     hipDeviceSynchronize();
     hipEventRecord(e0);
