@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -124,6 +125,7 @@ struct klt_ctx {
     bool track_xcd_order = true;              // KLT_OPT_TRACK_XCD_ORDER
     uint32_t *track_order = nullptr;
     size_t track_order_cap = 0;
+    uint64_t waited_built_serial = ~0ull;     // the build event the main stream waited for last (wait_built)
     int order_n = -1, order_pairs = 0, order_age = 0;   // shape (list length, pairs) the stored order was computed for, and how many launches ago
     // selection scratch
     float *sel_img = nullptr, *sel_gx = nullptr, *sel_gy = nullptr, *sat = nullptr, *valmap = nullptr;
@@ -168,9 +170,19 @@ struct klt_ctx {
     uint64_t bbuild_serial = 0;
     const unsigned long long *sorted_keys = nullptr;   // what the last selection walked (test hook)
     int sorted_count = 0;
-    TrackPairDesc *pair_table = nullptr;
-    size_t pair_table_cap = 0;
-    std::vector<TrackPairDesc> pair_table_host;   // what pair_table holds
+    // batched tracker launches: the descriptor tables (and XCD-aware feature orders) of the last few distinct batches stay on the device --
+    // a shard that goes through in sub-shards, step after step, uploads each table once
+    struct BatchTable {
+        std::vector<TrackPairDesc> host;          // what `dev` holds
+        TrackPairDesc *dev = nullptr;
+        size_t cap = 0;
+        uint32_t *order = nullptr;
+        size_t order_cap = 0;
+        int order_n = -1, order_age = 0;
+        uint64_t used = 0;
+    };
+    std::vector<BatchTable> batch_tables;
+    uint64_t batch_clock = 0;
     klt_affine_params ap{-1, 15, 15, 10, 10.f, 0.02f, 1.5f};      // klt.py:67-73 defaults
     std::vector<AffState> aff;
     int select_aff_state = -1;
@@ -380,8 +392,13 @@ int mark_read(klt_ctx *c, Slot *const *slots, int n)
 int wait_built(klt_ctx *c, Slot *s)
 {
     if (!s->built_pending) return 0;
-    if (event_live(c, s->built_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_built, 0));
-    else HIPCHK(c, hipStreamSynchronize(c->bstream));
+    // the slots of a batched build share its event: the main stream waits for it once (64 slots = 64 barrier packets otherwise, a few
+    // microseconds of queue time each)
+    if (s->built_serial != c->waited_built_serial) {
+        if (event_live(c, s->built_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_built, 0));
+        else HIPCHK(c, hipStreamSynchronize(c->bstream));
+        c->waited_built_serial = s->built_serial;
+    }
     s->built_pending = false;
     return 0;
 }
@@ -599,6 +616,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         else HIPCHK(c, hipStreamSynchronize(c->bstream));
     }
     std::vector<Slot *> sl((size_t)n);
+    std::vector<uint64_t> read_waited;
     for (int i = 0; i < n; i++) {
         if (int rc = get_slot(c, slot_ids[i], &sl[i], false)) return rc;
         if (sl[i]->raw_kind == 0) return fail(c, KLT_ERR_STATE, "slot has no frame");
@@ -610,8 +628,12 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         else if (sl[i]->read_valid) {
             // a tracker on the main stream may still be reading the pyramids this build overwrites: wait for that launch only (a mark on
             // the whole main stream would put the build behind a tracker enqueued just before it -- the overlap the stream is for)
-            if (event_live(c, sl[i]->read_serial)) HIPCHK(c, hipStreamWaitEvent(c->bstream, sl[i]->ev_read, 0));
-            else HIPCHK(c, hipStreamSynchronize(c->stream));
+            // (once per launch: the slots of a batch that one launch read share its event)
+            if (std::find(read_waited.begin(), read_waited.end(), sl[i]->read_serial) == read_waited.end()) {
+                if (event_live(c, sl[i]->read_serial)) HIPCHK(c, hipStreamWaitEvent(c->bstream, sl[i]->ev_read, 0));
+                else HIPCHK(c, hipStreamSynchronize(c->stream));
+                read_waited.push_back(sl[i]->read_serial);
+            }
         }
         sl[i]->read_valid = false;
     }
@@ -795,7 +817,7 @@ void klt_destroy(klt_ctx *c)
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
     for (auto &e : c->pre) hipFree(e.keys);
     hipFree(c->sat_pre);
-    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); hipFree(c->pair_table); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); for (auto &bt : c->batch_tables) { hipFree(bt.dev); hipFree(bt.order); } hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
@@ -1673,21 +1695,41 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
         table[i].in = c->fbs[fb_in[i]].d;
         table[i].out = c->fbs[fb_out[i]].d;
     }
-    if (int rc = ensure(c, c->pair_table, c->pair_table_cap, (size_t)npairs)) return rc;
-    // the descriptor table is uploaded only when it differs from the one already on the device (a shard that is tracked
-    // repeatedly keeps its slots and buffers).  Pageable source: the runtime stages it before returning; stream order protects
-    // the previous launch's table
-    if (c->pair_table_host.size() != table.size() ||
-        std::memcmp(c->pair_table_host.data(), table.data(), table.size() * sizeof(TrackPairDesc)) != 0) {
-        HIPCHK(c, hipMemcpyAsync(c->pair_table, table.data(), (size_t)npairs * sizeof(TrackPairDesc), hipMemcpyHostToDevice, c->stream));
-        c->pair_table_host = table;
+    // the descriptor table is uploaded only when none of the tables kept on the device holds it (at most 16, the least recently used
+    // one is replaced).  Pageable source: the runtime stages it before returning; stream order protects the launch that read the
+    // replaced table
+    klt_ctx::BatchTable *bt = nullptr;
+    for (auto &e : c->batch_tables)
+        if (e.host.size() == table.size() && std::memcmp(e.host.data(), table.data(), table.size() * sizeof(TrackPairDesc)) == 0) { bt = &e; break; }
+    if (!bt) {
+        if (c->batch_tables.size() < 16) {
+            c->batch_tables.emplace_back();
+            bt = &c->batch_tables.back();
+        } else {
+            bt = &c->batch_tables[0];
+            for (auto &e : c->batch_tables)
+                if (e.used < bt->used) bt = &e;
+        }
+        if (int rc = ensure(c, bt->dev, bt->cap, (size_t)npairs)) return rc;
+        HIPCHK(c, hipMemcpyAsync(bt->dev, table.data(), (size_t)npairs * sizeof(TrackPairDesc), hipMemcpyHostToDevice, c->stream));
+        bt->host = table;
+        bt->order_n = -1;
     }
+    bt->used = ++c->batch_clock;
     TrackArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.pairs = c->pair_table;
+    a.pairs = bt->dev;
     a.npairs = npairs;
     fill_track_params(c, first, a, n);
-    if (int rc = set_track_order(c, a, n, npairs)) return rc;
+    if (c->track_xcd_order && n >= 64) {
+        // one permutation per pair, kept with the table (see set_track_order)
+        if (int rc = ensure(c, bt->order, bt->order_cap, (size_t)n * npairs)) return rc;
+        a.order = bt->order;
+        a.order_chunk = (n + 7) / 8;
+        a.order_refresh = (bt->order_n != n || bt->order_age >= 64) ? 1 : 0;
+        if (a.order_refresh) { bt->order_n = n; bt->order_age = 0; }
+        bt->order_age++;
+    }
     {
         const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
         TimerScope t(c, F_TRACK, (double)npairs * n * (foot * 2 * first->nlev + 32), c->stream);

@@ -633,6 +633,40 @@ def test_cfg4_shape_batched_pairs(ctx, ko):
         assert_feats(out, *oracle_feats(ofl), what="cfg-4 pair %d track" % i)
 
 
+def test_batched_pairs_in_alternating_sub_shards(ctx):
+    """A shard tracked in one launch, and the same shard in two sub-shards that alternate step after step with their pyramids rebuilt on the
+    build stream (KLT_OPT_BUILD_STREAM): identical records.  The alternating launches exercise the device-side cache of descriptor tables
+    (one upload per distinct batch), the feature orders kept with them, and the once-per-event waits of the batched calls."""
+    from pyfeaturetrack_amd import synth
+    NP, NF = 6, 1500
+    tc = make_tc(levels=3, ss=4)
+    ctx.configure(tc)
+    frames = [synth.synth_pair(640, 480, 40 + seed) for seed in range(NP)]
+    for i, (a, b) in enumerate(frames):
+        ctx.upload(2 * i, a)
+        ctx.upload(2 * i + 1, b)
+    ctx.build_pyramids_batch(list(range(2 * NP)))
+    IN, OUT, OUT2 = 100, 200, 300
+    for i in range(NP):
+        ctx.select_async(2 * i, 1, True, IN + i, NF)
+    whole = [(2 * i, 2 * i + 1, IN + i, OUT + i) for i in range(NP)]
+    ctx.track_batch_async(whole, NF)
+    ref = [ctx.featbuf_download(OUT + i, NF) for i in range(NP)]
+    assert sum(int((r["val"] == 0).sum()) for r in ref) > 2000
+    ctx.set_option(15, 1)
+    try:
+        halves = [[(2 * i, 2 * i + 1, IN + i, OUT2 + i) for i in range(0, NP // 2)], [(2 * i, 2 * i + 1, IN + i, OUT2 + i) for i in range(NP // 2, NP)]]
+        for step in range(4):
+            for h in halves:
+                ctx.build_pyramids_batch([s for t in h for s in t[:2]])
+                ctx.track_batch_async(h, NF)
+        for i in range(NP):
+            got = ctx.featbuf_download(OUT2 + i, NF)
+            assert got.tobytes() == ref[i].tobytes(), "pair %d differs between the whole shard and its sub-shards" % i
+    finally:
+        ctx.set_option(15, 0)
+
+
 def test_cfg5_shape_4k_sequence_with_replacement(ctx, ko):
     """BASELINE cfg-5 geometry (3840x2160, 20000 features, sequential mode, lost features replaced after every
     frame), three frames.  Pinned at the level the reference implements: tracking + _enforceMinimumDistance in
