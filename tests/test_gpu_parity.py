@@ -667,6 +667,30 @@ def test_batched_pairs_in_alternating_sub_shards(ctx):
         ctx.set_option(15, 0)
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_parameter_draws_vs_oracle(seed):
+    """tools/fuzz_parity.py: frame sizes of any parity, 1-4 levels, subsampling 2 / 4 / 8, windows 3-15, minimum distance 0-24, skipped
+    pixels, borders, residue limits, iteration counts and list lengths drawn at random -- selection, tracking and the replacement of the
+    lost features identical to the oracle's in every record (900 draws were run when the tool was written; 2 x 25 stay in the suite)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from pyfeaturetrack_amd.backend import Context
+    rng = np.random.default_rng(seed)
+    c = Context(0)
+    try:
+        busy = 0
+        for k in range(25):
+            t = fz.draw(rng, 300000)
+            bad = fz.run_trial(c, t)
+            assert bad is None, "draw %d of seed %d: %s differs from the oracle: %r" % (k, seed, bad, t)
+            busy += "tracked 0," not in t["_stat"]
+        assert busy >= 15
+    finally:
+        c.close()
+
+
 def test_cfg5_shape_4k_sequence_with_replacement(ctx, ko):
     """BASELINE cfg-5 geometry (3840x2160, 20000 features, sequential mode, lost features replaced after every
     frame), three frames.  Pinned at the level the reference implements: tracking + _enforceMinimumDistance in

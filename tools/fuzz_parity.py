@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Randomised differential check of the HIP path against the oracle (test infrastructure, like tests/): frame sizes of any parity,
+pyramid depths, subsamplings, window sizes, minimum distances, skipped pixels, borders, residue limits and list lengths drawn at random;
+per trial: pyramids of two frames, selection, tracking, replacement of the lost features on the second frame -- every record compared
+bit for bit.
+
+    python3 tools/fuzz_parity.py [--trials 40] [--seed 1] [--max-pixels 400000]
+Prints one line per trial and exits non-zero at the first difference (with the drawn parameters, so that it can be replayed by seed).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import make_tc, params_from_tc                      # noqa: E402
+from pyfeaturetrack_amd import synth                             # noqa: E402
+from pyfeaturetrack_amd.backend import Context, REPLACING_SOME   # noqa: E402
+from oracle import klt_oracle as ko                              # noqa: E402
+
+
+def same(a, b):
+    return (np.array_equal(a["val"].astype(np.int64), b["val"].astype(np.int64)) and
+            np.array_equal(a["x"].astype(np.float64), b["x"].astype(np.float64)) and
+            np.array_equal(a["y"].astype(np.float64), b["y"].astype(np.float64)))
+
+
+def draw(rng, max_pixels):
+    while True:
+        levels = int(rng.integers(1, 5))
+        ss = int(rng.choice([2, 4, 8]))
+        window = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
+        w = int(rng.integers(48, 900))
+        h = int(rng.integers(48, 700))
+        if w * h > max_pixels:
+            continue
+        # the coarsest level must hold a window and its border (the reference makes the same demand through its border arithmetic)
+        coarse = ss ** (levels - 1)
+        if w // coarse < window + 12 or h // coarse < window + 12:
+            continue
+        return dict(levels=levels, ss=ss, window=window, w=w, h=h,
+                    mindist=int(rng.integers(0, 25)), skip=int(rng.integers(0, 4)),
+                    smooth=bool(rng.integers(0, 2)), mr=(None if rng.random() < 0.3 else float(rng.uniform(2.0, 30.0))),
+                    n=int(rng.integers(1, 700)), seed=int(rng.integers(0, 1 << 30)),
+                    shift=(float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))),
+                    min_eig=int(rng.choice([1, 1, 10, 200])),
+                    border=(None if rng.random() < 0.6 else int(rng.integers(window // 2 + 1, 40))),   # (smaller borders are refused: the reference reads outside the image)
+                    max_iter=int(rng.choice([10, 10, 3, 25])))
+
+
+def run_trial(ctx, t):
+    tc = make_tc(levels=t["levels"], ss=t["ss"], window=t["window"], max_residue=t["mr"], mindist=t["mindist"],
+                 nSkippedPixels=t["skip"], smoothBeforeSelecting=t["smooth"], min_eigenvalue=t["min_eig"],
+                 max_iterations=t["max_iter"])
+    if t["border"] is not None:
+        tc.borderx = tc.bordery = t["border"]
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    base = synth.synth_base(t["w"], t["h"], t["seed"])
+    f0 = synth.shift_frame(base, 0, 0)
+    f1 = synth.shift_frame(base, *t["shift"])
+    ctx.upload(0, f0)
+    ctx.upload(1, f1)
+    ctx.build_pyramids(0)
+    ctx.build_pyramids(1)
+    fl, _ = ctx.select(0, t["n"], use_pyramid=False)
+    ofl = ko.select_good_features(p, f0.astype(np.float32), t["n"])
+    if not same(fl, ofl):
+        return "selection"
+    out, _ = ctx.track(0, 1, fl)
+    ko.track_features(p, ko.Pyramids(p, f0.astype(np.float32)), ko.Pyramids(p, f1.astype(np.float32)), ofl)
+    if not same(out, ofl):
+        return "tracking"
+    rep, _ = ctx.select(1, t["n"], mode=REPLACING_SOME, fl=out, use_pyramid=False)
+    orep = ko.select_good_features(p, f1.astype(np.float32), t["n"], mode=2, fl=ofl)
+    if not same(rep, orep):
+        return "replacement"
+    t["_stat"] = "selected %d, tracked %d, replaced %d" % (int((fl["val"] > 0).sum()), int((out["val"] == 0).sum()), int((rep["val"] > 0).sum()))
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-pixels", type=int, default=400000)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    ctx = Context(0)
+    t0 = time.time()
+    for k in range(a.trials):
+        t = draw(rng, a.max_pixels)
+        try:
+            bad = run_trial(ctx, t)
+        except SystemExit as e:            # KLTError of the host layer
+            bad = "error: %s" % (e,)
+        print("trial %3d %s  %s" % (k, "ok  " if not bad else "FAIL (%s)" % bad, t), flush=True)
+        if bad:
+            sys.exit(1)
+    print("%d trials identical in %.0f s" % (a.trials, time.time() - t0))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
