@@ -65,3 +65,26 @@ def golden_feats_equal(fl, g, tag, what):
 
 
 __all__ += ["baseline_case", "golden_feats_equal"]
+
+
+# ---- random parameter draws pinned by tests/golden/random_draws.npz (the reference itself ran them: gen_random_draws.py) ----
+def random_draws(golden_dir):
+    """[(draw parameters, tracking context, frame 0, frame 1, {stage: (x, y, val)})] of the reference's random-draw goldens."""
+    import json
+    import os
+    g = np.load(os.path.join(golden_dir, "random_draws.npz"))
+    cases = []
+    for k, t in enumerate(json.loads(bytes(g["draws_json"]).decode())):
+        tc = make_tc(levels=t["levels"], ss=t["ss"], window=t["window"], max_residue=t["mr"], mindist=t["mindist"],
+                     nSkippedPixels=t["skip"], smoothBeforeSelecting=t["smooth"], min_eigenvalue=t["min_eig"], max_iterations=t["max_iter"])
+        base = synth.synth_base(t["w"], t["h"], t["seed"])
+        want = {st: (g["d%d_%s_x" % (k, st)], g["d%d_%s_y" % (k, st)], g["d%d_%s_val" % (k, st)]) for st in ("sel", "trk", "rep")}
+        cases.append((t, tc, synth.shift_frame(base, 0, 0), synth.shift_frame(base, *t["shift"]), want))
+    return cases
+
+
+def draw_equal(fl, want):
+    return np.array_equal(fl["val"], want[2]) and np.array_equal(fl["x"], want[0]) and np.array_equal(fl["y"], want[1])
+
+
+__all__ += ["random_draws", "draw_equal"]

@@ -691,6 +691,25 @@ def test_random_parameter_draws_vs_oracle(seed):
         c.close()
 
 
+def test_random_draws_the_reference_ran(ctx, golden_dir):
+    """The HIP path on the 160 random parameter draws the reference itself ran (tests/golden/random_draws.npz): selected, tracked and
+    replaced lists equal the reference's in every record."""
+    from helpers import draw_equal, random_draws
+    from pyfeaturetrack_amd.backend import REPLACING_SOME
+    for t, tc, f0, f1, want in random_draws(golden_dir):
+        ctx.configure(tc)
+        ctx.upload(0, f0)
+        ctx.upload(1, f1)
+        ctx.build_pyramids(0)
+        ctx.build_pyramids(1)
+        fl, _ = ctx.select(0, t["n"])
+        assert draw_equal(fl, want["sel"]), "selection differs from the reference: %r" % (t,)
+        fl, _ = ctx.track(0, 1, fl)
+        assert draw_equal(fl, want["trk"]), "tracking differs from the reference: %r" % (t,)
+        fl, _ = ctx.select(1, t["n"], mode=REPLACING_SOME, fl=fl)
+        assert draw_equal(fl, want["rep"]), "replacement differs from the reference: %r" % (t,)
+
+
 def test_cfg5_shape_4k_sequence_with_replacement(ctx, ko):
     """BASELINE cfg-5 geometry (3840x2160, 20000 features, sequential mode, lost features replaced after every
     frame), three frames.  Pinned at the level the reference implements: tracking + _enforceMinimumDistance in

@@ -243,3 +243,22 @@ def test_write_feature_list_text_and_binary(cfg1, tmp_path):
         assert KLTReadFeatureList(str(ints))[3].val == fl[3].val
     finally:
         sgf.KLT_verbose = 1
+
+
+def test_random_draws_the_reference_ran(golden_dir):
+    """160 random parameter draws (frame sizes of any parity up to 520 x 400, 1-3 levels, subsampling 2 / 4 / 8, windows 3-15, minimum
+    distance 0-19, skipped pixels, pre-smoothing on / off, residue limits, iteration counts, 1-299 features) run through the reference
+    itself (tests/golden/gen_random_draws.py): the oracle's selected list, tracked list and replaced list equal the reference's in every
+    record (/root/reference/selectGoodFeatures.py:45-135,279-294, trackFeatures.py:205-409)."""
+    from helpers import draw_equal, params_from_tc, random_draws
+    from oracle import klt_oracle as ko
+    cases = random_draws(golden_dir)
+    assert len(cases) == 160
+    for t, tc, f0, f1, want in cases:
+        p = params_from_tc(tc)
+        fl = ko.select_good_features(p, f0.astype(np.float32), t["n"])
+        assert draw_equal(fl, want["sel"]), "selection differs from the reference: %r" % (t,)
+        ko.track_features(p, ko.Pyramids(p, f0.astype(np.float32)), ko.Pyramids(p, f1.astype(np.float32)), fl)
+        assert draw_equal(fl, want["trk"]), "tracking differs from the reference: %r" % (t,)
+        fl = ko.select_good_features(p, f1.astype(np.float32), t["n"], mode=2, fl=fl)
+        assert draw_equal(fl, want["rep"]), "replacement differs from the reference: %r" % (t,)
