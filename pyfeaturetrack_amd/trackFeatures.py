@@ -11,6 +11,9 @@ from . import selectGoodFeatures as _sgf
 from .backend import default_context
 from .klt import KLTCountRemainingFeatures, kltState, shared_store  # noqa: F401
 from .selectGoodFeatures import _fix_window, _image_size, _slots_of, features_to_array, image_to_array
+# the reference binds the name at import (trackFeatures.py:7 `from selectGoodFeatures import KLT_verbose`): this module has its own
+# switch, and setting selectGoodFeatures.KLT_verbose later does not reach it
+from .selectGoodFeatures import KLT_verbose  # noqa: E402
 
 
 class _ResidentPyramids:
@@ -81,7 +84,7 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
     reference never defines)."""
     ncols, nrows = _image_size(img1)
     assert _image_size(img2) == (ncols, nrows)
-    if _sgf.KLT_verbose >= 1:
+    if KLT_verbose >= 1:
         print("(KLT) Tracking {0} features in a {1} by {2} image...  ".format(
             KLTCountRemainingFeatures(featurelist), ncols, nrows))
     _fix_window(tc)
@@ -170,5 +173,5 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
         tc.pyramid_last_gradx = _ResidentPyramids(s1, ncols, nrows, "gradx")
         tc.pyramid_last_grady = _ResidentPyramids(s1, ncols, nrows, "grady")
 
-    if _sgf.KLT_verbose >= 1:
+    if KLT_verbose >= 1:
         print("\n\t{0} features successfully tracked.".format(KLTCountRemainingFeatures(featurelist)))

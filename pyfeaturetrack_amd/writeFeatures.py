@@ -3,15 +3,15 @@ from __future__ import print_function
 
 import numpy as np
 
-from . import selectGoodFeatures as _sgf
 from .klt import KLTCountRemainingFeatures
+from .selectGoodFeatures import KLT_verbose       # bound at import, as writeFeatures.py:3 does: this module's own switch
 
 
 def KLTWriteFeatureListToPPM(featurelist, greyimg, filename):
     """Overlay every live feature as a red 3x3 square on an RGB copy and save it
     (writeFeatures.py:10-37; the square is centred on int(x + 0.5), int(y + 0.5))."""
     ncols, nrows = greyimg.size
-    if _sgf.KLT_verbose:
+    if KLT_verbose:
         print("(KLT) Writing {0} features to PPM file: '{1}'".format(KLTCountRemainingFeatures(featurelist), filename))
     rgb = np.array(greyimg.convert("RGB"))
     for feat in featurelist:
@@ -48,7 +48,7 @@ def KLTWriteFeatureList(featurelist, filename, fmt="%5.1f"):
     `KLT Feature List` banner, `nFeatures = n`, one `%7d | (x,y)=val ` row per feature; an integer format prints the
     rounded position.  Binary: b"KLTFL1", int32 nFeatures, then (float32 x, float32 y, int32 val) per feature."""
     fmt_str = "binary" if fmt is None else "text"
-    if _sgf.KLT_verbose >= 1 and filename is not None:
+    if KLT_verbose >= 1 and filename is not None:
         print("(KLT) Writing feature list to {0} file: '{1}'".format(fmt_str, filename))
     n = len(featurelist)
     if fmt is None:

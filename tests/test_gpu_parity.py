@@ -1194,6 +1194,36 @@ def test_python_api_example1_flow(cfg1, golden_dir, tmp_path, capsys):
     assert KLTCountRemainingFeatures(fl) == 50 > before
 
 
+def test_python_api_on_random_draws_the_reference_ran(golden_dir):
+    """Every fourth random draw of tests/golden/random_draws.npz through the reference-shaped Python API (PIL images, a fresh
+    KLT_TrackingContext per draw set up the way the generator set up the reference's): the feature objects hold what the reference's held."""
+    PIL = pytest.importorskip("PIL.Image")
+    from helpers import random_draws
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf, trackFeatures as tf
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    verbose = sgf.KLT_verbose, tf.KLT_verbose
+    sgf.KLT_verbose = tf.KLT_verbose = 0
+    try:
+        for t, _, f0, f1, want in random_draws(golden_dir)[::4]:
+            tc = KLT_TrackingContext()
+            tc.window_width = tc.window_height = t["window"]
+            tc.nPyramidLevels, tc.subsampling = t["levels"], t["ss"]
+            tc.KLTUpdateTCBorder()
+            tc.mindist, tc.nSkippedPixels, tc.smoothBeforeSelecting = t["mindist"], t["skip"], t["smooth"]
+            tc.max_residue, tc.min_eigenvalue, tc.max_iterations = t["mr"], t["min_eig"], t["max_iter"]
+            i0, i1 = PIL.fromarray(f0, "L"), PIL.fromarray(f1, "L")
+            fl = sgf.KLTSelectGoodFeatures(tc, i0, t["n"])
+            for stage in ("sel", "trk"):
+                if stage == "trk":
+                    tf.KLTTrackFeatures(tc, i0, i1, fl)
+                x, y, v = want[stage]
+                assert [int(f.val) for f in fl] == [int(a) for a in v], "%s: val differs: %r" % (stage, t)
+                assert np.array_equal(np.array([f.x for f in fl], np.float32), x) and np.array_equal(np.array([f.y for f in fl], np.float32), y), \
+                    "%s: positions differ: %r" % (stage, t)
+    finally:
+        sgf.KLT_verbose, tf.KLT_verbose = verbose
+
+
 def test_python_api_sequential_mode(cfg1, golden_dir):
     PIL = pytest.importorskip("PIL.Image")
     from pyfeaturetrack_amd.klt import KLT_TrackingContext
