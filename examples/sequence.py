@@ -20,6 +20,7 @@ import numpy as np                                                              
 from pyfeaturetrack_amd import selectGoodFeatures as sgf                              # noqa: E402
 from pyfeaturetrack_amd import synth                                                  # noqa: E402
 from pyfeaturetrack_amd.klt import KLT_TrackingContext, KLTCountRemainingFeatures     # noqa: E402
+from pyfeaturetrack_amd import trackFeatures as tf                                    # noqa: E402
 from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures                         # noqa: E402
 
 
@@ -39,7 +40,7 @@ def main():
     tc.max_residue = 10.0
     if args.affine:
         tc.affineConsistencyCheck = 2
-    sgf.KLT_verbose = 0
+    sgf.KLT_verbose = tf.KLT_verbose = 0            # (each module binds its own switch at import, as the reference's do)
 
     base = synth.synth_base(w, h, seed=3)
     frame = lambda k: synth.synth_frame(w, h, 3, k, base=base)          # noqa: E731  (numpy uint8 frames are accepted)

@@ -11,13 +11,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyfeaturetrack_amd import selectGoodFeatures as sgf          # noqa: E402
 from pyfeaturetrack_amd import synth                               # noqa: E402
 from pyfeaturetrack_amd.klt import KLT_TrackingContext             # noqa: E402
+from pyfeaturetrack_amd import trackFeatures as tf                  # noqa: E402
 from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures      # noqa: E402
 from pyfeaturetrack_amd.trackSequence import KLTTrackSequence      # noqa: E402
 
 
 def main():
     w, h, n = 1920, 1080, 5000
-    sgf.KLT_verbose = 0
+    sgf.KLT_verbose = tf.KLT_verbose = 0       # (each module has its own switch, as in the reference)
     tc = KLT_TrackingContext()
     tc.nPyramidLevels, tc.subsampling = 3, 4
     tc.KLTUpdateTCBorder()
