@@ -4,7 +4,7 @@ pyramid depths, subsamplings, window sizes, minimum distances, skipped pixels, b
 per trial: pyramids of two frames, selection, tracking, replacement of the lost features on the second frame -- every record compared
 bit for bit.
 
-    python3 tools/fuzz_parity.py [--trials 40] [--seed 1] [--max-pixels 400000]
+    python3 tools/fuzz_parity.py [--trials 40] [--seed 1] [--max-pixels 400000] [--max-n 700] [--max-side 900]
 Prints one line per trial and exits non-zero at the first difference (with the drawn parameters, so that it can be replayed by seed).
 """
 import argparse
@@ -29,13 +29,13 @@ def same(a, b):
             np.array_equal(a["y"].astype(np.float64), b["y"].astype(np.float64)))
 
 
-def draw(rng, max_pixels):
+def draw(rng, max_pixels, max_n=700, max_side=900):
     while True:
         levels = int(rng.integers(1, 5))
         ss = int(rng.choice([2, 4, 8]))
         window = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
-        w = int(rng.integers(48, 900))
-        h = int(rng.integers(48, 700))
+        w = int(rng.integers(48, max_side))
+        h = int(rng.integers(48, max(49, max_side * 7 // 9)))
         if w * h > max_pixels:
             continue
         # the coarsest level must hold a window and its border (the reference makes the same demand through its border arithmetic)
@@ -45,7 +45,7 @@ def draw(rng, max_pixels):
         return dict(levels=levels, ss=ss, window=window, w=w, h=h,
                     mindist=int(rng.integers(0, 25)), skip=int(rng.integers(0, 4)),
                     smooth=bool(rng.integers(0, 2)), mr=(None if rng.random() < 0.3 else float(rng.uniform(2.0, 30.0))),
-                    n=int(rng.integers(1, 700)), seed=int(rng.integers(0, 1 << 30)),
+                    n=int(rng.integers(1, max_n)), seed=int(rng.integers(0, 1 << 30)),
                     shift=(float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))),
                     min_eig=int(rng.choice([1, 1, 10, 200])),
                     border=(None if rng.random() < 0.6 else int(rng.integers(window // 2 + 1, 40))),   # (smaller borders are refused: the reference reads outside the image)
@@ -88,12 +88,14 @@ def main():
     ap.add_argument("--trials", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-pixels", type=int, default=400000)
+    ap.add_argument("--max-n", type=int, default=700)
+    ap.add_argument("--max-side", type=int, default=900)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     ctx = Context(0)
     t0 = time.time()
     for k in range(a.trials):
-        t = draw(rng, a.max_pixels)
+        t = draw(rng, a.max_pixels, a.max_n, a.max_side)
         try:
             bad = run_trial(ctx, t)
         except SystemExit as e:            # KLTError of the host layer
