@@ -710,6 +710,28 @@ def test_random_draws_the_reference_ran(ctx, golden_dir):
         assert draw_equal(fl, want["rep"]), "replacement differs from the reference: %r" % (t,)
 
 
+def test_random_sequences_vs_per_frame_api():
+    """tools/fuzz_parity.py --sequence: KLTTrackSequence (device-resident table; build stream, prepared scores and frame stager switched on
+    and off by the draw) against the per-frame host API loop on 20 short random sequences with a wiped region -- identical tables."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf, trackFeatures as tf
+    verbose = sgf.KLT_verbose, tf.KLT_verbose
+    rng = np.random.default_rng(77)
+    try:
+        replaced = 0
+        for k in range(20):
+            t = fz.draw(rng, 250000, 500, 700)
+            bad = fz.run_sequence_trial(t)
+            assert bad is None, "draw %d: %s differs: %r" % (k, bad, t)
+            replaced += " replaced 0" not in t["_stat"]
+        assert replaced >= 5
+    finally:
+        sgf.KLT_verbose, tf.KLT_verbose = verbose
+
+
 def test_cfg5_shape_4k_sequence_with_replacement(ctx, ko):
     """BASELINE cfg-5 geometry (3840x2160, 20000 features, sequential mode, lost features replaced after every
     frame), three frames.  Pinned at the level the reference implements: tracking + _enforceMinimumDistance in

@@ -5,6 +5,8 @@ per trial: pyramids of two frames, selection, tracking, replacement of the lost 
 bit for bit.
 
     python3 tools/fuzz_parity.py [--trials 40] [--seed 1] [--max-pixels 400000] [--max-n 700] [--max-side 900]
+--sequence: KLTTrackSequence against the per-frame host API loop on short random sequences (both are the HIP path; the per-frame
+API is the one pinned to the reference).
 Prints one line per trial and exits non-zero at the first difference (with the drawn parameters, so that it can be replayed by seed).
 """
 import argparse
@@ -83,6 +85,47 @@ def run_trial(ctx, t):
     return None
 
 
+def run_sequence_trial(t):
+    """KLTTrackSequence (device-resident table, build stream, prepared scores, frame stager) against the per-frame host API loop it
+    replaces (track, replace, store) on 5-7 frames; one region of one frame is wiped so that features are lost and replaced."""
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf, storeFeatures as sf, trackFeatures as tf
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.trackSequence import KLTTrackSequence
+    sgf.KLT_verbose = tf.KLT_verbose = 0
+    nf = 5 + t["seed"] % 3
+    base = synth.synth_base(t["w"], t["h"], t["seed"])
+    frames = [synth.synth_frame(t["w"], t["h"], t["seed"], k, shift=t["shift"], base=base) for k in range(nf)]
+    frames[2] = frames[2].copy()
+    frames[2][t["h"] // 4:t["h"] // 2, t["w"] // 4:t["w"] // 2] = 100
+
+    def make():
+        tc = KLT_TrackingContext()
+        tc.window_width = tc.window_height = t["window"]
+        tc.nPyramidLevels, tc.subsampling = t["levels"], t["ss"]
+        tc.KLTUpdateTCBorder()
+        tc.mindist, tc.nSkippedPixels, tc.smoothBeforeSelecting = t["mindist"], t["skip"], t["smooth"]
+        tc.max_residue, tc.min_eigenvalue, tc.max_iterations = t["mr"], t["min_eig"], t["max_iter"]
+        tc.sequentialMode = True
+        return tc
+
+    replace, ingest, prefetch = bool(t["seed"] & 8), bool(t["seed"] & 16), bool(t["seed"] & 32)
+    tc = make()
+    want = sf.KLTCreateFeatureTable(nf, t["n"])
+    fl = sgf.KLTSelectGoodFeatures(tc, frames[0], t["n"])
+    sf.KLTStoreFeatureList(fl, want, 0)
+    for k in range(1, nf):
+        tf.KLTTrackFeatures(tc, frames[k - 1], frames[k], fl)
+        if replace:
+            sgf.KLTReplaceLostFeatures(tc, frames[k], fl)
+        sf.KLTStoreFeatureList(fl, want, k)
+    got = KLTTrackSequence(make(), (f for f in frames), t["n"], replace_lost=replace, async_ingest=ingest, prefetch=prefetch)
+    t["_stat"] = "frames %d, replace %d, ingest %d, prefetch %d, lost entries %d, replaced %d" % (
+        nf, replace, ingest, prefetch, int((want.val[1:] < 0).sum()), int((want.val[1:] > 0).sum()))
+    if not (np.array_equal(got.val, want.val) and np.array_equal(got.x, want.x) and np.array_equal(got.y, want.y)):
+        return "sequence table"
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=40)
@@ -90,21 +133,23 @@ def main():
     ap.add_argument("--max-pixels", type=int, default=400000)
     ap.add_argument("--max-n", type=int, default=700)
     ap.add_argument("--max-side", type=int, default=900)
+    ap.add_argument("--sequence", action="store_true", help="KLTTrackSequence against the per-frame host API instead of HIP against the oracle")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
-    ctx = Context(0)
+    ctx = None if a.sequence else Context(0)
     t0 = time.time()
     for k in range(a.trials):
         t = draw(rng, a.max_pixels, a.max_n, a.max_side)
         try:
-            bad = run_trial(ctx, t)
+            bad = run_sequence_trial(t) if a.sequence else run_trial(ctx, t)
         except SystemExit as e:            # KLTError of the host layer
             bad = "error: %s" % (e,)
         print("trial %3d %s  %s" % (k, "ok  " if not bad else "FAIL (%s)" % bad, t), flush=True)
         if bad:
             sys.exit(1)
     print("%d trials identical in %.0f s" % (a.trials, time.time() - t0))
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":
