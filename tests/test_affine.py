@@ -177,3 +177,28 @@ def test_gpu_affine_python_api_and_replacement(capsys):
         assert all(f.aff_img is None for f in fl if f.val < 0)          # templates of lost features are freed (:292-341, :393-395)
     finally:
         sgf.KLT_verbose = 1
+
+
+@pytest.mark.gpu
+def test_gpu_affine_matches_oracle_on_random_draws():
+    """tools/fuzz_parity.py --affine: frame sizes, pyramid shapes, tracker windows, affine windows 9-21, modes 0 / 1 / 2, residue and
+    displacement limits, iteration counts and a random affine map per frame -- 20 draws (380 were run when the tool was written): every
+    status, position, template offset and matrix entry equals the oracle's after each of three calls."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from pyfeaturetrack_amd.backend import Context
+    rng = np.random.default_rng(31)
+    c = Context(0)
+    try:
+        alive = 0
+        for k in range(20):
+            t = fz.draw(rng, 300000, 400, 800)
+            bad = fz.run_affine_trial(c, t)
+            assert bad is None, "draw %d: %s differs from the oracle: %r" % (k, bad, t)
+            alive += int(t["_stat"].split(", ")[2].split(" of ")[0])
+        assert alive > 500
+    finally:
+        c.close()

@@ -126,6 +126,57 @@ def run_sequence_trial(t):
     return None
 
 
+def run_affine_trial(ctx, t):
+    """The affine consistency check (parity unpinned: the reference does not define it) -- HIP against the oracle on a texture warped
+    by a random affine map per frame: every status, position, template offset and matrix entry after each of three calls."""
+    from pyfeaturetrack_amd.params import affine_params_from_tc
+    rng = np.random.default_rng(t["seed"])
+    tc = make_tc(levels=t["levels"], ss=t["ss"], window=t["window"], max_residue=t["mr"], mindist=t["mindist"],
+                 nSkippedPixels=t["skip"], min_eigenvalue=t["min_eig"], max_iterations=t["max_iter"])
+    tc.affineConsistencyCheck = int(rng.integers(0, 3))
+    tc.affine_window_width = tc.affine_window_height = int(rng.choice([9, 11, 15, 15, 21]))
+    tc.affine_max_residue = float(rng.uniform(4.0, 20.0))
+    tc.affine_max_iterations = int(rng.choice([3, 10, 10, 20]))
+    tc.affine_max_displacement_differ = float(rng.choice([0.3, 1.5, 1.5, 5.0]))
+    p, ap = params_from_tc(tc), affine_params_from_tc(tc)
+    ang, sc = float(rng.uniform(-1.0, 1.0)), float(rng.uniform(0.995, 1.005))
+    c, s_ = np.cos(np.radians(ang)) * sc, np.sin(np.radians(ang)) * sc
+    step = np.array([[c, -s_], [s_, c]]) + rng.uniform(-0.003, 0.003, (2, 2)) * (tc.affineConsistencyCheck == 2)
+    base = synth.synth_base(t["w"], t["h"], t["seed"], sigma=2.5)
+    frames, A = [], np.eye(2)
+    for k in range(4):
+        frames.append(synth.warp_frame(base, A, (k * t["shift"][0] * 0.4, k * t["shift"][1] * 0.4)))
+        A = step @ A
+    ctx.configure(tc)
+    for k, f in enumerate(frames):
+        ctx.upload(k, f)
+    ctx.build_pyramids_batch(list(range(4)), sync=True)
+    n = t["n"]
+    fl, _ = ctx.select(0, n, use_pyramid=True)
+    f32 = [f.astype(np.float32) for f in frames]
+    P = [ko.Pyramids(p, f) for f in f32]
+    # the oracle's list starts from the HIP selection (selection on the smoothed level-0 image is the sequence API's; compared elsewhere)
+    ofl = fl.copy()
+    ctx.affine_alloc(0, n)
+    st = ko.AffineState(ap, n)
+    live = 0
+    try:
+        for k in range(1, 4):
+            fl, _ = ctx.track_affine(k - 1, k, fl, 0)
+            ko.track_features_affine(p, P[k - 1], P[k], ofl, st)
+            rec = ctx.affine_download(0, n)
+            if not same(fl, ofl):
+                return "affine call %d: records" % k
+            for name in ("valid", "aff_x", "aff_y", "Axx", "Ayx", "Axy", "Ayy"):
+                if not np.array_equal(rec[name], st.rec[name]):
+                    return "affine call %d: %s" % (k, name)
+            live = int((fl["val"] == 0).sum())
+    finally:
+        ctx.affine_free(0)              # (the affine window of the next draw differs: no state may exist when it is set)
+    t["_stat"] = "mode %d, window %d, %d of %d alive after three calls" % (tc.affineConsistencyCheck, tc.affine_window_width, live, n)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=40)
@@ -133,6 +184,7 @@ def main():
     ap.add_argument("--max-pixels", type=int, default=400000)
     ap.add_argument("--max-n", type=int, default=700)
     ap.add_argument("--max-side", type=int, default=900)
+    ap.add_argument("--affine", action="store_true", help="the affine consistency check, HIP against the oracle")
     ap.add_argument("--sequence", action="store_true", help="KLTTrackSequence against the per-frame host API instead of HIP against the oracle")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
@@ -141,7 +193,7 @@ def main():
     for k in range(a.trials):
         t = draw(rng, a.max_pixels, a.max_n, a.max_side)
         try:
-            bad = run_sequence_trial(t) if a.sequence else run_trial(ctx, t)
+            bad = run_sequence_trial(t) if a.sequence else run_affine_trial(ctx, t) if a.affine else run_trial(ctx, t)
         except SystemExit as e:            # KLTError of the host layer
             bad = "error: %s" % (e,)
         print("trial %3d %s  %s" % (k, "ok  " if not bad else "FAIL (%s)" % bad, t), flush=True)
