@@ -793,8 +793,25 @@ def main():
             if k["name"] == "track":
                 k["bytes"] = track_bytes * k["launches"]
         dom = max(kernels, key=lambda k: k["total_ms"])
-        per_launch_ms = dom["total_ms"] / dom["launches"]
+        pair_launch_ms = dom["total_ms"] / dom["launches"]        # an event pair AROUND the launch: the kernel + the boundary to the launch before it
+        per_launch_ms = pair_launch_ms
         per_launch_bytes = dom["bytes"] / dom["launches"]
+        # the dominant kernel once more, timed by the start / stop events of its own dispatch (klt_timing_enable(ctx, 2): the runtime fills
+        # them from the dispatch packet's begin / end timestamps) -- the duration rocprofv3 reports for it, which the event pair above
+        # overstates by the ~2.6 us between two dependent launches
+        stamp_launch_ms = None
+        if dom["name"] == "smooth_grad_l0":
+            ctx.timing_enable(2)
+            for i in range(args.steps):
+                a = 0 if i % 2 == 0 else 2
+                ctx.build_pyramids_batch([a, a + 1])
+                ctx.track_async(a, a + 1, FB_SEL, FB_OUT0, NFEAT)
+            for k in ctx.timing_read():
+                if k["name"] == dom["name"] and k["launches"]:
+                    stamp_launch_ms = k["total_ms"] / k["launches"]
+            ctx.timing_enable(False)
+            if stamp_launch_ms:
+                per_launch_ms = stamp_launch_ms
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
         # PMC-derived figures are NOT measured by this run: committed results of the builder's rocprofv3 --pmc passes, with their
         # provenance, dropped when the kernel source changed since (committed_counters)
@@ -814,7 +831,9 @@ def main():
         dev_ms = sum(k["total_ms"] for k in kernels) / args.steps
         roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "issue_bound": issue,
-                    "launch_us": per_launch_ms * 1e3, "launches_per_step": dom["launches"] / args.steps,
+                    "launch_us": per_launch_ms * 1e3, "launch_us_source": "dispatch start/stop events (hipExtLaunchKernelGGL)" if stamp_launch_ms
+                    else "event pair around the launch", "launch_us_event_pair": pair_launch_ms * 1e3,
+                    "launches_per_step": dom["launches"] / args.steps,
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "step_algorithmic_bytes": 2 * pyr_bytes + track_bytes,
                     "step_device_ms": dev_ms,

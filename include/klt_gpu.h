@@ -271,7 +271,10 @@ int klt_gradients_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, cons
 
 /* ---- per-kernel timing (HIP events on the context's stream) -------------------------------- */
 typedef struct { char name[32]; uint32_t launches; float total_ms; double bytes; } klt_kernel_time;
-int klt_timing_enable(klt_ctx *ctx, int on);                /* resets the accumulated figures */
+int klt_timing_enable(klt_ctx *ctx, int on);                /* resets the accumulated figures.  1: an event pair around every launch;
+                                                             * 2: the same, but the level-0 pyramid launch (smooth_grad_l0) is timed by its dispatch's own begin / end
+                                                             * timestamps (hipExtLaunchKernelGGL events) -- the kernel duration a profiler reports, without the
+                                                             * boundary between two dependent launches that an event pair also holds */
 int klt_timing_read(klt_ctx *ctx, klt_kernel_time *out, int max_entries);   /* returns the entry count */
 
 #ifdef __cplusplus

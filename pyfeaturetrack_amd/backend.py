@@ -372,7 +372,8 @@ class Context:
 
     # -------------------------------------------------------------------- timing
     def timing_enable(self, on=True):
-        self._check(self._lib.klt_timing_enable(self._h, int(bool(on))))
+        """1 / True: an event pair around every launch; 2: the level-0 pyramid launch by its dispatch's own timestamps (klt_gpu.h)."""
+        self._check(self._lib.klt_timing_enable(self._h, int(on)))
 
     def timing_read(self):
         buf = (KltKernelTime * 32)()

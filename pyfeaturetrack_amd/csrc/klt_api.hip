@@ -13,6 +13,8 @@
 
 #include "klt_internal.h"
 
+thread_local hipEvent_t g_klt_stamp_start = nullptr, g_klt_stamp_stop = nullptr;      // klt_internal.h: timing by dispatch timestamps
+
 namespace {
 
 enum Family { F_SMOOTH_GRAD, F_PYR_REDUCE, F_GRAD, F_SMOOTH_H, F_SMOOTH_V, F_PYR_H, F_PYR_V, F_GRAD_H, F_GRAD_V, F_TRACK,
@@ -195,6 +197,7 @@ struct klt_ctx {
     bool use_fused = true;            // LDS-tiled fused kernels (pyramid_kernels.hip); off = generic two-pass kernels
     // timing
     bool timing = false;
+    bool timing_stamps = false;               // klt_timing_enable(ctx, 2): the level-0 launch is timed by its dispatch timestamps
     std::vector<Timed> pending;
     std::vector<hipEvent_t> pool;
     double acc_ms[F_COUNT] = {0}, acc_bytes[F_COUNT] = {0};
@@ -221,6 +224,7 @@ struct TimerScope {
     Timed t;
     bool on;
     hipStream_t st;
+    bool stamps = false;
     TimerScope(klt_ctx *c_, int fam, double bytes, hipStream_t st_ = nullptr) : c(c_), on(c_->timing), st(st_ ? st_ : c_->work)
     {
         if (!on) return;
@@ -230,12 +234,22 @@ struct TimerScope {
             if (!c->pool.empty()) { *e = c->pool.back(); c->pool.pop_back(); }
             else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
         }
-        hipEventRecord(t.a, st);
+        stamps = c->timing_stamps && fam == F_SMOOTH_GRAD;
+        if (stamps) { g_klt_stamp_start = t.a; g_klt_stamp_stop = t.b; }      // filled by the launch itself (klt_launch)
+        else hipEventRecord(t.a, st);
     }
     ~TimerScope()
     {
         if (!on) return;
-        hipEventRecord(t.b, st);
+        if (stamps) {
+            if (g_klt_stamp_start) {                 // no launch took them (an error path): nothing was measured
+                g_klt_stamp_start = g_klt_stamp_stop = nullptr;
+                c->pool.push_back(t.a); c->pool.push_back(t.b);
+                return;
+            }
+        } else {
+            hipEventRecord(t.b, st);
+        }
         c->pending.push_back(t);
     }
 };
@@ -2158,6 +2172,7 @@ int klt_timing_enable(klt_ctx *c, int on)
     if (int rc = drain_timers(c)) return rc;
     for (int f = 0; f < F_COUNT; f++) { c->acc_ms[f] = 0; c->acc_bytes[f] = 0; c->acc_n[f] = 0; }
     c->timing = on != 0;
+    c->timing_stamps = on == 2;
     return KLT_OK;
 }
 

@@ -119,6 +119,26 @@ struct MisArgs {
     int ncols;
 };
 
+// ---- timing by the dispatch's own timestamps --------------------------------------------------------------------------------
+// klt_timing_enable(ctx, 2): the level-0 launch is enqueued with hipExtLaunchKernelGGL and a start / stop event pair that the runtime
+// fills from the dispatch packet's begin and end timestamps -- the duration rocprofv3 reports for the kernel.  An event pair recorded
+// around a launch (mode 1) also holds the boundary between two dependent launches (~2.6 us).  The API sets the two events, the next
+// launch that goes through klt_launch takes them.
+extern thread_local hipEvent_t g_klt_stamp_start, g_klt_stamp_stop;
+
+#include <hip/hip_ext.h>
+template <typename... Args, typename F = void (*)(Args...)>
+inline void klt_launch(F kernel, const dim3 &grid, const dim3 &block, unsigned lds, hipStream_t s, Args... args)
+{
+    if (g_klt_stamp_start) {
+        hipEvent_t a = g_klt_stamp_start, b = g_klt_stamp_stop;
+        g_klt_stamp_start = g_klt_stamp_stop = nullptr;
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, s, a, b, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+    }
+}
+
 // ---- launchers (each enqueues on `s`; no synchronisation) ----
 void launch_hconv_u8(hipStream_t s, const uint8_t *in, int ncols, int nrows, float *outA, float *outB,
                      int out_cols, int xstride, int xoff, const Taps &ta, const Taps *tb);

@@ -800,8 +800,8 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
         const dim3 g((a.ncols + TW - 1) / TW, (a.nrows + th - 1) / th, batch);
 #define KLT_RB(T, SM, NSV)                                                                                        \
     do {                                                                                                          \
-        if (tall) hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 32>), g, blk, 0, s, a);                   \
-        else hipLaunchKernelGGL((smooth_grad_rb<T, SM, NSV, 7, 7, 16>), g, blk, 0, s, a);                        \
+        if (tall) klt_launch((smooth_grad_rb<T, SM, NSV, 7, 7, 32>), g, blk, 0, s, a);                   \
+        else klt_launch((smooth_grad_rb<T, SM, NSV, 7, 7, 16>), g, blk, 0, s, a);                        \
         return 0;                                                                                                 \
     } while (0)
         if (hred) {
@@ -809,10 +809,10 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
             // round 2: 29.9 / 29.9 / 30.4 us event-timed against 28.1 for the 32-row tile: the extra halo work outweighs the occupancy)
             // (three / two workgroups per CU instead of four -- dynamic LDS padding, same kernel -- read 0.0379 / 0.0382 ms per pair with
             // three pairs in flight against 0.0365, and 0.0576 against 0.0556 on one stream: round 2)
-            if (kind == 0 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
-            if (kind == 1 && a.smooth.n == 5) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
-            if (kind == 0 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<uint8_t, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
-            if (kind == 1 && a.smooth.n == 9) { hipLaunchKernelGGL((smooth_grad_rb<float, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+            if (kind == 0 && a.smooth.n == 5) { klt_launch((smooth_grad_rb<uint8_t, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+            if (kind == 1 && a.smooth.n == 5) { klt_launch((smooth_grad_rb<float, true, 5, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+            if (kind == 0 && a.smooth.n == 9) { klt_launch((smooth_grad_rb<uint8_t, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
+            if (kind == 1 && a.smooth.n == 9) { klt_launch((smooth_grad_rb<float, true, 9, 7, 7, 32, 256, true>), g, blk, 0, s, a); return 0; }
             return -1;
         }
         if (kind == 0 && a.smooth.n == 5) KLT_RB(uint8_t, true, 5);
@@ -828,13 +828,13 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
     int e = 0;
     switch (kind) {
     case 0: if ((e = set_lds(smooth_grad_kernel<uint8_t, true>, lds))) return e;
-            hipLaunchKernelGGL((smooth_grad_kernel<uint8_t, true>), grid, block, lds, s, a); break;
+            klt_launch((smooth_grad_kernel<uint8_t, true>), grid, block, lds, s, a); break;
     case 1: if ((e = set_lds(smooth_grad_kernel<float, true>, lds))) return e;
-            hipLaunchKernelGGL((smooth_grad_kernel<float, true>), grid, block, lds, s, a); break;
+            klt_launch((smooth_grad_kernel<float, true>), grid, block, lds, s, a); break;
     case 2: if ((e = set_lds(smooth_grad_kernel<float, false>, lds))) return e;
-            hipLaunchKernelGGL((smooth_grad_kernel<float, false>), grid, block, lds, s, a); break;
+            klt_launch((smooth_grad_kernel<float, false>), grid, block, lds, s, a); break;
     default: if ((e = set_lds(smooth_grad_kernel<uint8_t, false>, lds))) return e;
-            hipLaunchKernelGGL((smooth_grad_kernel<uint8_t, false>), grid, block, lds, s, a); break;
+            klt_launch((smooth_grad_kernel<uint8_t, false>), grid, block, lds, s, a); break;
     }
     return 0;
 }

@@ -732,6 +732,28 @@ def test_random_sequences_vs_per_frame_api():
         sgf.KLT_verbose, tf.KLT_verbose = verbose
 
 
+def test_kernel_timing_by_event_pairs_and_by_dispatch_timestamps(ctx):
+    """klt_timing_enable: 1 = an event pair around every launch, 2 = the level-0 pyramid launch by the start / stop events of its own
+    dispatch (what a profiler reports as the kernel's duration).  Both see every launch; the dispatch figure is the smaller one (the pair
+    also holds the boundary between two dependent launches) and not implausibly so; the other families are timed alike in both modes."""
+    from pyfeaturetrack_amd import synth
+    ctx.configure(make_tc(levels=3, ss=4))
+    for k, f in enumerate(synth.synth_pair(1920, 1080, 1)):
+        ctx.upload(k, f)
+    figures = {}
+    for mode in (1, 2):
+        ctx.build_pyramids_batch([0, 1], sync=True)
+        ctx.timing_enable(mode)
+        for _ in range(20):
+            ctx.build_pyramids_batch([0, 1])
+        figures[mode] = {k["name"]: (k["launches"], 1e3 * k["total_ms"] / max(k["launches"], 1)) for k in ctx.timing_read()}
+        ctx.timing_enable(False)
+    pair, stamp = figures[1]["smooth_grad_l0"], figures[2]["smooth_grad_l0"]
+    assert pair[0] == stamp[0] == 20
+    assert 0.6 * pair[1] < stamp[1] < pair[1], (pair, stamp)
+    assert figures[1]["pyramid_reduce"][0] == figures[2]["pyramid_reduce"][0] > 0
+
+
 def test_cfg5_shape_4k_sequence_with_replacement(ctx, ko):
     """BASELINE cfg-5 geometry (3840x2160, 20000 features, sequential mode, lost features replaced after every
     frame), three frames.  Pinned at the level the reference implements: tracking + _enforceMinimumDistance in
