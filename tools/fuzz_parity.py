@@ -177,6 +177,45 @@ def run_affine_trial(ctx, t):
     return None
 
 
+def run_batch_trial(ctx, t):
+    """2-6 pairs of one random size through the batched calls (one pyramid build for all frames, one tracker launch for all pairs, feature
+    lists as views of one table) against the oracle pair by pair."""
+    rng = np.random.default_rng(t["seed"])
+    B, n = int(rng.integers(2, 7)), t["n"]
+    tc = make_tc(levels=t["levels"], ss=t["ss"], window=t["window"], max_residue=t["mr"], mindist=t["mindist"],
+                 nSkippedPixels=t["skip"], min_eigenvalue=t["min_eig"], max_iterations=t["max_iter"])
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    pairs = []
+    for b in range(B):
+        base = synth.synth_base(t["w"], t["h"], t["seed"] + b)
+        sh = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)))
+        pairs.append((synth.shift_frame(base, 0, 0), synth.shift_frame(base, *sh)))
+        ctx.upload(2 * b, pairs[b][0])
+        ctx.upload(2 * b + 1, pairs[b][1])
+    ctx.build_pyramids_batch(list(range(2 * B)))
+    T_IN, T_OUT, V_IN, V_OUT = 400, 401, 410, 420
+    ctx.featbuf_alloc(T_IN, B * n)
+    ctx.featbuf_alloc(T_OUT, B * n)
+    for b in range(B):
+        ctx.featbuf_view(V_IN + b, T_IN, b * n, n)
+        ctx.featbuf_view(V_OUT + b, T_OUT, b * n, n)
+        ctx.select_async(2 * b, 1, True, V_IN + b, n)            # SELECTING_ALL on the smoothed level-0 image
+    ctx.track_batch_async([(2 * b, 2 * b + 1, V_IN + b, V_OUT + b) for b in range(B)], n)
+    sel = ctx.featbuf_download(T_IN, B * n).reshape(B, n)
+    out = ctx.featbuf_download(T_OUT, B * n).reshape(B, n)
+    tracked = 0
+    for b in range(B):
+        P0, P1 = ko.Pyramids(p, pairs[b][0].astype(np.float32)), ko.Pyramids(p, pairs[b][1].astype(np.float32))
+        ofl = sel[b].copy()                                         # (the selection itself is compared by the plain trials)
+        ko.track_features(p, P0, P1, ofl)
+        if not same(out[b], ofl):
+            return "pair %d of %d" % (b, B)
+        tracked += int((ofl["val"] == 0).sum())
+    t["_stat"] = "%d pairs, tracked %d of %d" % (B, tracked, B * n)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=40)
@@ -184,6 +223,7 @@ def main():
     ap.add_argument("--max-pixels", type=int, default=400000)
     ap.add_argument("--max-n", type=int, default=700)
     ap.add_argument("--max-side", type=int, default=900)
+    ap.add_argument("--batch", action="store_true", help="batched build + one tracker launch for several pairs, against the oracle")
     ap.add_argument("--affine", action="store_true", help="the affine consistency check, HIP against the oracle")
     ap.add_argument("--sequence", action="store_true", help="KLTTrackSequence against the per-frame host API instead of HIP against the oracle")
     a = ap.parse_args()
@@ -193,7 +233,7 @@ def main():
     for k in range(a.trials):
         t = draw(rng, a.max_pixels, a.max_n, a.max_side)
         try:
-            bad = run_sequence_trial(t) if a.sequence else run_affine_trial(ctx, t) if a.affine else run_trial(ctx, t)
+            bad = run_sequence_trial(t) if a.sequence else run_affine_trial(ctx, t) if a.affine else run_batch_trial(ctx, t) if a.batch else run_trial(ctx, t)
         except SystemExit as e:            # KLTError of the host layer
             bad = "error: %s" % (e,)
         print("trial %3d %s  %s" % (k, "ok  " if not bad else "FAIL (%s)" % bad, t), flush=True)
