@@ -20,9 +20,11 @@ external launcher (`python -m torch.distributed.run --nproc-per-node N bench.py 
 variables are already set and every process is a rank.  The RCCL unique id travels through the
 rendezvous file (pyfeaturetrack_amd/parallel.py).
 
-Consecutive steps go round-robin to `--inflight` contexts (default 3; one HIP stream each, nothing ordering them): frame pairs
-are independent, so the GPU overlaps the kernels of different pairs.  Every step does the full work of one pair; `--inflight 1`
-and `ms_per_frame_pair` (= `extra.single_stream_ms_per_pair`) give the one-stream figure.  The K-step timed region (barrier +
+Consecutive groups of `--batch` steps (default 2) go round-robin to `--inflight` contexts (default 2; one HIP stream each, nothing
+ordering them): frame pairs are independent, so the steps of a group share every launch of their context (one batched pyramid build,
+one tracker launch -- the reference's workload for a stereo rig or two cameras) and the GPU overlaps the kernels of different groups.
+Every step does the full work of one pair; `ms_per_frame_pair` (= `extra.single_stream_ms_per_pair`) is one pair at a time on one
+stream, `--inflight 3 --batch 1` the round-1 arrangement.  The K-step timed region (barrier +
 synchronise on both sides, MAX over ranks) is repeated `--repeats` times; `ms_per_step` is the median region, the spread is
 in `extra.region_ms_per_step`.
 
@@ -650,9 +652,18 @@ def main():
                     help="cfg2 (default, the headline line); cfg4 = the 256-pair batch sharded over --gpus ranks; the others are "
                          "the remaining BASELINE configs on one GPU, informative")
     ap.add_argument("--pairs", type=int, default=256, help="total pairs per step for --config cfg4 (sharded over the ranks)")
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="independent pairs in flight per GPU: consecutive steps go round-robin to this many contexts (one HIP "
-                         "stream each, no events between them), so kernels of different pairs overlap; 1 = a single stream")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="contexts per GPU (one HIP stream each, no events between them): consecutive groups of --batch steps go "
+                         "round-robin to them, so kernels of different groups overlap; 1 = a single stream")
+    ap.add_argument("--slot-sets", type=int, default=1, choices=[1, 2],
+                    help="1 (default): a context rebuilds the same slots every group, as a caller with a fixed ring of frame slots does -- the "
+                         "pyramids the tracker reads are the ones just written and come out of the 256 MB Infinity Cache; 2: alternate groups "
+                         "use two sets of slots (the working set of 2 contexts x 2 pairs is then 430 MB and every tracker read goes to HBM; "
+                         "the lines up to round-2 set m were measured this way)")
+    ap.add_argument("--batch", type=int, default=2, choices=[1, 2, 4, 8],
+                    help="steps (independent pairs) that share every launch of a context: one batched pyramid build for their frames "
+                         "and one tracker launch for their feature lists (2 contexts x 2 pairs: 0.0333 ms per pair where 3 x 1 reads "
+                         "0.0377, 3 x 2 0.0358, 2 x 4 0.0359: tools/stream_batch_probe.py)")
     args = ap.parse_args()
 
     # N > 1 without a launcher: start the ranks ourselves.  Nothing above or below this point has touched the GPU yet
@@ -681,13 +692,28 @@ def main():
     # and the GPU overlaps the kernels of different pairs -- the drain / ramp between dependent kernels of one pair and the
     # latency-bound tracker are filled with the next pair's convolutions.
     nctx = max(1, args.inflight)
+    B = max(1, args.batch)
+    NSETS = args.slot_sets
+
+    def slots_of(j, nb=None):
+        """frame slots of a context's j-th group: pair b of set t lives in slots 2 (t B + b), + 1"""
+        t = j % NSETS
+        return [2 * (t * B + b) + f for b in range(B if nb is None else nb) for f in (0, 1)]
+
+    def pairs_of(j, outs, nb=None):
+        sl = slots_of(j, nb)
+        return [(sl[2 * b], sl[2 * b + 1], FB_SEL, outs[b]) for b in range(len(sl) // 2)]
+
+    def plain_out(t, b):
+        """output buffer of pair b of set t (one GPU): the two of pair 0 are FB_OUT0 / FB_OUT1"""
+        return (FB_OUT0, FB_OUT1)[t] if b == 0 else 10 + 2 * b + t
+
     ctxs = []
     fl = None
     for c in range(nctx):
         cx = Context(ranks.local_rank)
         cx.set_params(p)
-        # the pair lives in two slot pairs, (0,1) and (2,3), used by alternate steps of a context
-        for s0 in (0, 2):
+        for s0 in range(0, max(4, 2 * NSETS * B), 2):
             cx.upload(s0, f0)
             cx.upload(s0 + 1, f1)
         cx.build_pyramids(0)
@@ -696,8 +722,9 @@ def main():
         assert fl is None or np.array_equal(fl, fl_c), "contexts selected different features"
         fl = fl_c
         cx.featbuf_upload(FB_SEL, fl)
-        cx.featbuf_upload(FB_OUT0, fl)
-        cx.featbuf_upload(FB_OUT1, fl)
+        for t in (0, 1):
+            for b in range(B):
+                cx.featbuf_upload(plain_out(t, b), fl)
         # N > 1: the records of GATHER_EVERY consecutive steps of a context land in one device-side [steps x features] table
         # (two tables, used alternately) and each full table is all-gathered with ONE RCCL collective on the library's side
         # stream -- cfg-4's "gather once per shard", and the host cost of a collective is not paid per step.
@@ -710,64 +737,73 @@ def main():
     ctx = ctxs[0]
     ranks.attach(ctxs)
 
-    def out_buffer(j):
-        """feature buffer that local step j of a context writes"""
+    def out_buffer(lj):
+        """feature buffer that the lj-th pair of a context writes (lj = group * B + pair)"""
         if not distributed:
-            return FB_OUT0 if j % 2 == 0 else FB_OUT1
-        return FB_VIEW0 + ((j // GATHER_EVERY) % 2) * GATHER_EVERY + j % GATHER_EVERY
+            return plain_out((lj // B) % 2, lj % B)
+        return FB_VIEW0 + ((lj // GATHER_EVERY) % 2) * GATHER_EVERY + lj % GATHER_EVERY
 
-    def step(i, last=False):
-        c, j = i % nctx, i // nctx                # context, and the step's index among that context's steps
+    def group(g, nb=B, last=False):
+        """nb consecutive steps (pairs) as one group: every launch of the context is shared by them"""
+        c, j = g % nctx, g // nctx                # context, and the group's index among that context's groups
         cx = ctxs[c]
-        a = 0 if j % 2 == 0 else 2
-        cx.build_pyramids_batch([a, a + 1])       # both frames share every launch
-        if not distributed:
-            cx.track_async(a, a + 1, FB_SEL, out_buffer(j), NFEAT)
-            return
-        t, k = (j // GATHER_EVERY) % 2, j % GATHER_EVERY
-        ring, gath = (FB_RING0, FB_GATH0) if t == 0 else (FB_RING1, FB_GATH1)
-        if k == 0:
-            cx.comm_fence_featbuf(ring)       # the collective that read this table two rounds ago has finished
-        cx.track_async(a, a + 1, FB_SEL, out_buffer(j), NFEAT)
-        if k == GATHER_EVERY - 1 or last:
+        slots = slots_of(j, nb)
+        cx.build_pyramids_batch(slots)            # all frames of the group share every launch
+        lj0 = j * B
+        if distributed and lj0 % GATHER_EVERY == 0:
+            cx.comm_fence_featbuf(FB_RING0 if (lj0 // GATHER_EVERY) % 2 == 0 else FB_RING1)   # the collective that read this table two rounds ago has finished
+        if nb == 1:
+            cx.track_async(slots[0], slots[1], FB_SEL, out_buffer(lj0), NFEAT)
+        else:
+            cx.track_batch_async(pairs_of(j, [out_buffer(lj0 + b) for b in range(nb)], nb), NFEAT)
+        if distributed and ((lj0 + B) % GATHER_EVERY == 0 or last):
+            ring, gath = (FB_RING0, FB_GATH0) if (lj0 // GATHER_EVERY) % 2 == 0 else (FB_RING1, FB_GATH1)
             cx.allgather_featbuf_async(ring, gath, GATHER_EVERY * NFEAT)     # RCCL on the side stream, behind this tracker launch
 
-    # bring the GPU to its steady state first (the same work as a step, into the plain output buffers)
+    def run_steps(n):
+        """n steps = ceil(n / B) groups, the last one partial when B does not divide n"""
+        ngroups = (n + B - 1) // B
+        for g in range(ngroups):
+            group(g, nb=min(B, n - g * B), last=(g >= ngroups - nctx))     # every context closes its open table with a gather
+
+    # bring the GPU to its steady state first (the same work as the steps, into the plain output buffers)
     t_pre = time.perf_counter()
-    i_pre = 0
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for _ in range(32):
-            cx = ctxs[i_pre % nctx]
-            a = 0 if (i_pre // nctx) % 2 == 0 else 2
-            cx.build_pyramids_batch([a, a + 1])
-            cx.track_async(a, a + 1, FB_SEL, FB_OUT0 if (i_pre // nctx) % 2 == 0 else FB_OUT1, NFEAT)
-            i_pre += 1
+        for g in range(32):
+            cx, j = ctxs[g % nctx], g // nctx
+            cx.build_pyramids_batch(slots_of(j))
+            if B == 1:
+                cx.track_async(slots_of(j)[0], slots_of(j)[1], FB_SEL, plain_out(j % 2, 0), NFEAT)
+            else:
+                cx.track_batch_async(pairs_of(j, [plain_out(j % 2, b) for b in range(B)]), NFEAT)
         for cx in ctxs:
             cx.sync()
-    for i in range(args.warmup):
-        step(i, last=(i == args.warmup - 1))
+    if args.warmup:
+        run_steps(args.warmup)
 
     def region():
-        for i in range(args.steps):
-            step(i, last=(i >= args.steps - nctx))       # every context closes its open table with a gather
+        run_steps(args.steps)
 
     elapsed, regions, enqueue_s = timed_regions(ranks, region, args.steps, args.repeats)
 
     # correctness of what was timed: the last step's records (and, N > 1, what the gather delivered of them); every
     # context's last output is the same list (same pair, same features)
-    last_i = args.steps - 1
-    last_c, last_j = last_i % nctx, last_i // nctx
-    out = ctxs[last_c].featbuf_download(out_buffer(last_j), NFEAT)
-    for c in range(nctx):
-        nsteps_c = (args.steps - c + nctx - 1) // nctx
-        if nsteps_c > 0:
-            o = ctxs[c].featbuf_download(out_buffer(nsteps_c - 1), NFEAT)
-            assert np.array_equal(o["x"], out["x"]) and np.array_equal(o["y"], out["y"]) and np.array_equal(o["val"], out["val"]), \
-                "contexts disagree on the tracked records"
+    def where(i):
+        """(context, index among the context's pairs) of step i"""
+        g = i // B
+        return g % nctx, (g // nctx) * B + i % B
+
+    last_c, last_lj = where(args.steps - 1)
+    out = ctxs[last_c].featbuf_download(out_buffer(last_lj), NFEAT)
+    for i in range(max(0, args.steps - 2 * nctx * B), args.steps):          # the last outputs of every context, every pair of a group
+        c_i, lj_i = where(i)
+        o = ctxs[c_i].featbuf_download(out_buffer(lj_i), NFEAT)
+        assert np.array_equal(o["x"], out["x"]) and np.array_equal(o["y"], out["y"]) and np.array_equal(o["val"], out["val"]), \
+            "contexts / pairs of a group disagree on the tracked records"
     if distributed:                 # what this rank received from itself equals what it produced
-        gath = FB_GATH0 if (last_j // GATHER_EVERY) % 2 == 0 else FB_GATH1
+        gath = FB_GATH0 if (last_lj // GATHER_EVERY) % 2 == 0 else FB_GATH1
         got = ctxs[last_c].featbuf_download(gath, world * GATHER_EVERY * NFEAT).reshape(world, GATHER_EVERY, NFEAT)
-        mine = got[rank][last_j % GATHER_EVERY]
+        mine = got[rank][last_lj % GATHER_EVERY]
         assert np.array_equal(mine["x"], out["x"]) and np.array_equal(mine["val"], out["val"]), "gathered records differ"
     tracked = int(np.count_nonzero(out["val"] >= 0))
     live = out["val"] == 0
@@ -778,20 +814,30 @@ def main():
     roofline = None
     kernels = []
     if rank == 0:
+        ngroups_roof = max(1, args.steps // B)
+        npairs_roof = ngroups_roof * B
+
+        def roof_pass(mode):
+            """the groups of the timed region once more, on one context, with every launch timed"""
+            ctx.timing_enable(mode)
+            for g in range(ngroups_roof):
+                ctx.build_pyramids_batch(slots_of(g))
+                if B == 1:
+                    ctx.track_async(slots_of(g)[0], slots_of(g)[1], FB_SEL, plain_out(g % 2, 0), NFEAT)
+                else:
+                    ctx.track_batch_async(pairs_of(g, [plain_out(g % 2, b) for b in range(B)]), NFEAT)
+            res = ctx.timing_read()
+            ctx.timing_enable(False)
+            return res
+
         ctx.track_stats_reset()
-        ctx.timing_enable(True)
-        for i in range(args.steps):
-            a = 0 if i % 2 == 0 else 2
-            ctx.build_pyramids_batch([a, a + 1])
-            ctx.track_async(a, a + 1, FB_SEL, FB_OUT0, NFEAT)
-        kernels = ctx.timing_read()
-        ctx.timing_enable(False)
+        kernels = roof_pass(1)
         st = ctx.track_stats()
-        st = {k: ([x / args.steps for x in v] if isinstance(v, list) else v / args.steps) for k, v in st.items()}
+        st = {k: ([x / npairs_roof for x in v] if isinstance(v, list) else v / npairs_roof) for k, v in st.items()}
         pyr_bytes, track_bytes = algorithmic_bytes(p, WIDTH, HEIGHT, st, NFEAT)
         for k in kernels:
             if k["name"] == "track":
-                k["bytes"] = track_bytes * k["launches"]
+                k["bytes"] = track_bytes * B * k["launches"]
         dom = max(kernels, key=lambda k: k["total_ms"])
         pair_launch_ms = dom["total_ms"] / dom["launches"]        # an event pair AROUND the launch: the kernel + the boundary to the launch before it
         per_launch_ms = pair_launch_ms
@@ -801,15 +847,9 @@ def main():
         # overstates by the ~2.6 us between two dependent launches
         stamp_launch_ms = None
         if dom["name"] == "smooth_grad_l0":
-            ctx.timing_enable(2)
-            for i in range(args.steps):
-                a = 0 if i % 2 == 0 else 2
-                ctx.build_pyramids_batch([a, a + 1])
-                ctx.track_async(a, a + 1, FB_SEL, FB_OUT0, NFEAT)
-            for k in ctx.timing_read():
+            for k in roof_pass(2):
                 if k["name"] == dom["name"] and k["launches"]:
                     stamp_launch_ms = k["total_ms"] / k["launches"]
-            ctx.timing_enable(False)
             if stamp_launch_ms:
                 per_launch_ms = stamp_launch_ms
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
@@ -828,19 +868,19 @@ def main():
                      "clock_mhz": mhz, "ideal_us": ideal_us, "frac": ideal_us / (per_launch_ms * 1e3), "source": sq_source}
         elif sq_source:
             issue = {"source": sq_source}
-        dev_ms = sum(k["total_ms"] for k in kernels) / args.steps
+        dev_ms = sum(k["total_ms"] for k in kernels) / npairs_roof
         roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "issue_bound": issue,
                     "launch_us": per_launch_ms * 1e3, "launch_us_source": "dispatch start/stop events (hipExtLaunchKernelGGL)" if stamp_launch_ms
                     else "event pair around the launch", "launch_us_event_pair": pair_launch_ms * 1e3,
-                    "launches_per_step": dom["launches"] / args.steps,
+                    "launches_per_step": dom["launches"] / npairs_roof, "pairs_per_launch": B,
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "step_algorithmic_bytes": 2 * pyr_bytes + track_bytes,
                     "step_device_ms": dev_ms,
                     "step_frac": (2 * pyr_bytes + track_bytes) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "newton_iterations_per_level": st["iterations"][:p.nPyramidLevels],
                     "kernels": {k["name"]: {"us_per_launch": 1e3 * k["total_ms"] / k["launches"],
-                                            "launches_per_step": k["launches"] / args.steps,
+                                            "launches_per_step": k["launches"] / npairs_roof,
                                             "GBps": k["bytes"] / max(k["total_ms"], 1e-9) / 1e6} for k in kernels}}
 
     # secondary figures (never `value`): selection time, the one-stream figure, and the PCIe-inclusive pair time
@@ -858,7 +898,7 @@ def main():
         for _ in range(5):
             t = time.perf_counter()
             for i in range(args.steps):                        # the same K steps on ONE stream (one pair in flight)
-                a = 0 if i % 2 == 0 else 2
+                a = 0 if i % NSETS == 0 else 2
                 ctx.build_pyramids_batch([a, a + 1])
                 ctx.track_async(a, a + 1, FB_SEL, FB_OUT0 if i % 2 == 0 else FB_OUT1, NFEAT)
             ctx.sync()
@@ -935,10 +975,15 @@ def main():
                          "cfg-2: one 1920x1080 synthetic pair per GPU, 5000 features, 7x7 window, "
                          "3 pyramid levels (subsampling 4), translation only; inputs resident in HBM",
                          extra_cfg={
-                             "pipelining": ("none (one HIP stream)" if nctx == 1 else
-                                            "%d independent pairs in flight: steps go round-robin to %d contexts, one HIP stream each, no "
-                                            "ordering between them (pairs are independent); every step does the full work of one pair" % (nctx, nctx)),
-                             "pairs_in_flight": nctx, "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
+                             "pipelining": (("none (one HIP stream)" if nctx == 1 else
+                                             "groups of steps go round-robin to %d contexts, one HIP stream each, no ordering between them "
+                                             "(pairs are independent)" % nctx) +
+                                            ("; every step does the full work of one pair" if B == 1 else
+                                             "; the %d steps (pairs) of a group share every launch of their context: one batched pyramid "
+                                             "build for their %d frames, one tracker launch for their %d feature lists -- every step still "
+                                             "does the full work of one pair" % (B, 2 * B, B))),
+                             "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "slot_sets": NSETS,
+                             "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
                              "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
                              "rccl_ranks": world if distributed else 0,
                              "parallelism": "1 pair per GPU" + (", RCCL all-gather (libkltgpu side stream) of the [%d steps x 5000] record "

@@ -176,15 +176,24 @@ struct klt_ctx {
     // a shard that goes through in sub-shards, step after step, uploads each table once
     struct BatchTable {
         std::vector<TrackPairDesc> host;          // what `dev` holds
+        uint64_t hash = 0;
         TrackPairDesc *dev = nullptr;
         size_t cap = 0;
-        uint32_t *order = nullptr;
-        size_t order_cap = 0;
-        int order_n = -1, order_age = 0;
         uint64_t used = 0;
     };
-    std::vector<BatchTable> batch_tables;
+    // the XCD-aware feature orders depend on the INPUT lists only: one set of permutations per distinct (inputs, length), whatever
+    // the frames and the output buffers of the launch
+    struct BatchOrder {
+        std::vector<const klt_feat *> in;
+        uint32_t *order = nullptr;
+        size_t cap = 0;
+        int n = -1, age = 0;
+        uint64_t used = 0;
+    };
+    std::vector<BatchTable> batch_tables;         // at most kBatchTables, least recently used one replaced
+    std::vector<BatchOrder> batch_orders;         // at most 16
     uint64_t batch_clock = 0;
+    static constexpr size_t kBatchTables = 256;
     klt_affine_params ap{-1, 15, 15, 10, 10.f, 0.02f, 1.5f};      // klt.py:67-73 defaults
     std::vector<AffState> aff;
     int select_aff_state = -1;
@@ -831,7 +840,7 @@ void klt_destroy(klt_ctx *c)
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
     for (auto &e : c->pre) hipFree(e.keys);
     hipFree(c->sat_pre);
-    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); for (auto &bt : c->batch_tables) { hipFree(bt.dev); hipFree(bt.order); } hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); for (auto &bt : c->batch_tables) hipFree(bt.dev); for (auto &bo : c->batch_orders) hipFree(bo.order); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
@@ -1709,14 +1718,19 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
         table[i].in = c->fbs[fb_in[i]].d;
         table[i].out = c->fbs[fb_out[i]].d;
     }
-    // the descriptor table is uploaded only when none of the tables kept on the device holds it (at most 16, the least recently used
-    // one is replaced).  Pageable source: the runtime stages it before returning; stream order protects the launch that read the
-    // replaced table
+    // the descriptor table is uploaded only when none of the tables kept on the device holds it (found by hash; at most 256 tables,
+    // the least recently used one is replaced).  Pageable source: the runtime stages it before returning; stream order protects the
+    // launch that read the replaced table
+    uint64_t hash = 1469598103934665603ull;
+    {
+        const unsigned char *bytes = reinterpret_cast<const unsigned char *>(table.data());
+        for (size_t i = 0; i < table.size() * sizeof(TrackPairDesc); i++) hash = (hash ^ bytes[i]) * 1099511628211ull;
+    }
     klt_ctx::BatchTable *bt = nullptr;
     for (auto &e : c->batch_tables)
-        if (e.host.size() == table.size() && std::memcmp(e.host.data(), table.data(), table.size() * sizeof(TrackPairDesc)) == 0) { bt = &e; break; }
+        if (e.hash == hash && e.host.size() == table.size() && std::memcmp(e.host.data(), table.data(), table.size() * sizeof(TrackPairDesc)) == 0) { bt = &e; break; }
     if (!bt) {
-        if (c->batch_tables.size() < 16) {
+        if (c->batch_tables.size() < klt_ctx::kBatchTables) {
             c->batch_tables.emplace_back();
             bt = &c->batch_tables.back();
         } else {
@@ -1727,7 +1741,7 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
         if (int rc = ensure(c, bt->dev, bt->cap, (size_t)npairs)) return rc;
         HIPCHK(c, hipMemcpyAsync(bt->dev, table.data(), (size_t)npairs * sizeof(TrackPairDesc), hipMemcpyHostToDevice, c->stream));
         bt->host = table;
-        bt->order_n = -1;
+        bt->hash = hash;
     }
     bt->used = ++c->batch_clock;
     TrackArgs a;
@@ -1736,13 +1750,33 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
     a.npairs = npairs;
     fill_track_params(c, first, a, n);
     if (c->track_xcd_order && n >= 64) {
-        // one permutation per pair, kept with the table (see set_track_order)
-        if (int rc = ensure(c, bt->order, bt->order_cap, (size_t)n * npairs)) return rc;
-        a.order = bt->order;
+        // one permutation per pair, kept with the set of input lists (see set_track_order)
+        std::vector<const klt_feat *> ins((size_t)npairs);
+        for (int i = 0; i < npairs; i++) ins[i] = table[i].in;
+        klt_ctx::BatchOrder *bo = nullptr;
+        for (auto &e : c->batch_orders)
+            if (e.in == ins) { bo = &e; break; }
+        if (!bo) {
+            if (c->batch_orders.size() < 16) {
+                c->batch_orders.emplace_back();
+                bo = &c->batch_orders.back();
+            } else {
+                bo = &c->batch_orders[0];
+                for (auto &e : c->batch_orders)
+                    if (e.used < bo->used) bo = &e;
+            }
+            bo->in = ins;
+            bo->n = -1;
+        }
+        bo->used = c->batch_clock;
+        const size_t cap_before = bo->cap;
+        if (int rc = ensure(c, bo->order, bo->cap, (size_t)n * npairs)) return rc;
+        if (bo->cap != cap_before) bo->n = -1;               // a new buffer holds no order yet
+        a.order = bo->order;
         a.order_chunk = (n + 7) / 8;
-        a.order_refresh = (bt->order_n != n || bt->order_age >= 64) ? 1 : 0;
-        if (a.order_refresh) { bt->order_n = n; bt->order_age = 0; }
-        bt->order_age++;
+        a.order_refresh = (bo->n != n || bo->age >= 64) ? 1 : 0;
+        if (a.order_refresh) { bo->n = n; bo->age = 0; }
+        bo->age++;
     }
     {
         const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
