@@ -173,7 +173,7 @@ def file_sha16(rel):
         return None
 
 
-def committed_counters(name, kernel_family):
+def committed_counters(name, kernel_family, pairs_per_launch=None):
     """Per-launch PMC figures of `kernel_family` from profiles/<name> -- NOT measurements of this run: they come from the
     builder's rocprofv3 --pmc passes (tools/pmc_traffic.py, tools/pmc_sq.py) and carry their provenance; they are dropped when
     the kernel source they were collected for is no longer the one in the tree."""
@@ -187,6 +187,8 @@ def committed_counters(name, kernel_family):
             return None, "profiles/%s is stale: %s changed since it was collected" % (name, rel)
     if not meta:
         return None, "profiles/%s carries no provenance record" % name
+    if pairs_per_launch is not None and meta.get("cfg2_pairs_per_launch", 1) != pairs_per_launch:
+        return None, "profiles/%s was collected for launches of %d pair(s), this run's hold %d" % (name, meta.get("cfg2_pairs_per_launch", 1), pairs_per_launch)
     return data.get(kernel_family), "profiles/%s, %s" % (name, meta.get("source", "builder gpurun"))
 
 
@@ -855,12 +857,12 @@ def main():
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
         # PMC-derived figures are NOT measured by this run: committed results of the builder's rocprofv3 --pmc passes, with their
         # provenance, dropped when the kernel source changed since (committed_counters)
-        traffic, traffic_source = committed_counters("traffic.json", dom["name"])
+        traffic, traffic_source = committed_counters("traffic.json", dom["name"], B)
         # the same kernel against the roof that actually bounds it: VALU issue.  Wavefront-instructions per launch come from a
         # rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/sq_counters.json, tools/pmc_sq.py); 4.5 clocks per instruction and SIMD
         # is what the FP64-rate instruction mix of the convolutions sustains on gfx950 (tools/mb/valu_rate.hip, fp64_mix.hip).
         issue = None
-        sq, sq_source = committed_counters("sq_counters.json", dom["name"])
+        sq, sq_source = committed_counters("sq_counters.json", dom["name"], B)
         if sq and sq.get("SQ_INSTS_VALU"):
             simds, cpi, mhz = 256 * 4, 4.5, 2400.0
             ideal_us = sq["SQ_INSTS_VALU"] / simds * cpi / mhz

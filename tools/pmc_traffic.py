@@ -65,7 +65,9 @@ def provenance(what):
             pass
     return {"source": "%s, builder gpurun (rocprofv3 --pmc, kernel-trace only), tag %s, %s" %
                       (what, os.environ.get("KLT_PROFILE_TAG", "?"), time.strftime("%Y-%m-%d")),
-            "kernel_source_sha16": shas}
+            "kernel_source_sha16": shas,
+            # frame pairs that share a launch of the cfg-2 passes (bench.py --batch): per-launch counters only describe launches of that size
+            "cfg2_pairs_per_launch": int(os.environ.get("KLT_PROFILE_BATCH", "2"))}
 
 
 def main():

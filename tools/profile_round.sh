@@ -10,7 +10,8 @@ export KLT_PROFILE_TAG=r02_$TAG
 O=gpurun_out
 mkdir -p $O
 python3 bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
-python3 bench.py --inflight 1 --no-cpu-baseline > $O/bench_${TAG}_single_stream.json 2>> $O/bench_$TAG.err
+python3 bench.py --inflight 1 --batch 1 --no-cpu-baseline > $O/bench_${TAG}_single_stream.json 2>> $O/bench_$TAG.err
+python3 bench.py --inflight 3 --batch 1 --slot-sets 2 --no-cpu-baseline > $O/bench_${TAG}_3x1_two_slot_sets.json 2>> $O/bench_$TAG.err
 KLT_FORCE_DIST=1 python3 bench.py --gpus 1 --no-cpu-baseline > $O/bench_${TAG}_rccl_1rank.json 2>> $O/bench_$TAG.err
 for c in cfg1 cfg3 cfg5; do python3 bench.py --config $c > $O/bench_${TAG}_$c.json 2>> $O/bench_$TAG.err; done
 python3 bench.py --config cfg4 --pairs 32 --steps 50 --warmup 5 > $O/bench_${TAG}_cfg4_shard32.json 2>> $O/bench_$TAG.err
