@@ -650,6 +650,9 @@ def main():
                     help="untimed hot-path work before the W warm-up steps: the GPU needs ~10 ms of load to reach its steady clocks / "
                          "cache state (a 200-step run right after start-up measures 50 us per pair, the same loop after 50 ms 43 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary figures (selection, one pair at a time, PCIe-inclusive): a profiler then sees only the launches "
+                         "of the timed regions and of the roofline pass, all of the headline's size")
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 (default, the headline line); cfg4 = the 256-pair batch sharded over --gpus ranks; the others are "
                          "the remaining BASELINE configs on one GPU, informative")
@@ -888,7 +891,11 @@ def main():
     # secondary figures (never `value`): selection time, the one-stream figure, and the PCIe-inclusive pair time
     extra = None
     ms_single = None
-    if rank == 0:
+    if rank == 0 and args.no_extras:
+        extra = {"region_ms_per_step": {"median": elapsed / args.steps * 1e3, "min": min(regions) / args.steps * 1e3,
+                                        "max": max(regions) / args.steps * 1e3, "regions": len(regions)},
+                 "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "note": "--no-extras: secondary figures skipped"}
+    elif rank == 0:
         reps = max(5, min(20, args.steps))
         ctx.sync()
         t = time.perf_counter()
