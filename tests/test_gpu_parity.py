@@ -754,6 +754,28 @@ def test_kernel_timing_by_event_pairs_and_by_dispatch_timestamps(ctx):
     assert figures[1]["pyramid_reduce"][0] == figures[2]["pyramid_reduce"][0] > 0
 
 
+def test_more_distinct_batches_than_the_table_cache_holds(ctx, img0, img1):
+    """klt_track_batch_async keeps the descriptor tables of the last 256 distinct batches on the device: 300 batches that differ in their
+    output buffers (then the first ones again, whose tables have been replaced meanwhile) all give the records of the first."""
+    ctx.configure(make_tc(max_residue=10.0))
+    for k, im in enumerate((img0, img1, img0, img1)):
+        ctx.upload(k, im)
+    ctx.build_pyramids_batch([0, 1, 2, 3], sync=True)
+    N, NB = 100, 300
+    fl, _ = ctx.select(0, N, use_pyramid=True)
+    ctx.featbuf_upload(700, fl)
+    ctx.featbuf_alloc(701, 2 * NB * N)
+    for k in range(2 * NB):
+        ctx.featbuf_view(1000 + k, 701, k * N, N)
+    order = list(range(NB)) + [0, 1, 2]
+    for k in order:
+        ctx.track_batch_async([(0, 1, 700, 1000 + 2 * k), (2, 3, 700, 1000 + 2 * k + 1)], N)
+    out = ctx.featbuf_download(701, 2 * NB * N).reshape(2 * NB, N)
+    assert (out[0]["val"] == 0).sum() > N // 2
+    for k in range(1, 2 * NB):
+        assert out[k].tobytes() == out[0].tobytes(), "batch %d differs" % (k // 2)
+
+
 def test_cfg5_shape_4k_sequence_with_replacement(ctx, ko):
     """BASELINE cfg-5 geometry (3840x2160, 20000 features, sequential mode, lost features replaced after every
     frame), three frames.  Pinned at the level the reference implements: tracking + _enforceMinimumDistance in
