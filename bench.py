@@ -990,7 +990,9 @@ def main():
                                             ("; every step does the full work of one pair" if B == 1 else
                                              "; the %d steps (pairs) of a group share every launch of their context: one batched pyramid "
                                              "build for their %d frames, one tracker launch for their %d feature lists -- every step still "
-                                             "does the full work of one pair" % (B, 2 * B, B))),
+                                             "does the full work of one pair" % (B, 2 * B, B)) +
+                                            ("; a context rebuilds the same frame slots every group (the pyramid planes the tracker reads "
+                                             "are still in the Infinity Cache)" if NSETS == 1 else "; alternate groups of a context use two sets of frame slots")),
                              "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "slot_sets": NSETS,
                              "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
                              "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
