@@ -8,6 +8,7 @@ implements replacement: SURVEY a-23).  Inputs are regenerated from the seeds by 
 parameters and the three feature lists per draw.
 
     python tests/golden/gen_random_draws.py [--draws 160] [--seed 2026]      ->  tests/golden/random_draws.npz
+    python tests/golden/gen_random_draws.py --draws 60 --seed 2027 --max-w 1400 --max-h 1000 --max-n 2000 --out random_draws_large.npz
 """
 import argparse
 import json
@@ -23,19 +24,19 @@ from gen_golden import build_reference, feats_to_arrays  # noqa: E402
 from pyfeaturetrack_amd import synth  # noqa: E402
 
 
-def draw(rng):
+def draw(rng, max_w=520, max_h=400, max_n=300):
     while True:
         levels = int(rng.integers(1, 4))
         ss = int(rng.choice([2, 4, 8]))
         window = int(rng.choice([3, 5, 7, 9, 11, 15]))
-        w = int(rng.integers(60, 520))
-        h = int(rng.integers(60, 400))
+        w = int(rng.integers(60, max_w))
+        h = int(rng.integers(60, max_h))
         coarse = ss ** (levels - 1)
         if w // coarse < window + 12 or h // coarse < window + 12:
             continue
         return dict(levels=levels, ss=ss, window=window, w=w, h=h, mindist=int(rng.integers(0, 20)), skip=int(rng.integers(0, 3)),
                     smooth=bool(rng.integers(0, 2)), mr=(None if rng.random() < 0.3 else round(float(rng.uniform(2.0, 30.0)), 3)),
-                    n=int(rng.integers(1, 300)), seed=int(rng.integers(0, 1 << 30)),
+                    n=int(rng.integers(1, max_n)), seed=int(rng.integers(0, 1 << 30)),
                     shift=(round(float(rng.uniform(-2.5, 2.5)), 3), round(float(rng.uniform(-2.5, 2.5)), 3)),
                     min_eig=int(rng.choice([1, 1, 10, 200])), max_iter=int(rng.choice([10, 10, 3, 25])))
 
@@ -44,6 +45,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--draws", type=int, default=160)
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--max-w", type=int, default=520)
+    ap.add_argument("--max-h", type=int, default=400)
+    ap.add_argument("--max-n", type=int, default=300)
+    ap.add_argument("--out", default="random_draws.npz")
     a = ap.parse_args()
     refdir = build_reference()
     sys.path.insert(0, refdir)
@@ -77,7 +82,7 @@ def main():
     out, draws = {}, []
     k = skipped = 0
     while k < a.draws:
-        t = draw(rng)
+        t = draw(rng, a.max_w, a.max_h, a.max_n)
         tc = klt.KLT_TrackingContext()
         tc.window_width = tc.window_height = t["window"]
         tc.nPyramidLevels, tc.subsampling = t["levels"], t["ss"]
@@ -111,8 +116,8 @@ def main():
             out[key] = out[key].astype(np.float32)
         elif key.endswith("_val"):
             out[key] = out[key].astype(np.int32)
-    np.savez_compressed(os.path.join(HERE, "random_draws.npz"), **out)
-    print("wrote", os.path.join(HERE, "random_draws.npz"))
+    np.savez_compressed(os.path.join(HERE, a.out), **out)
+    print("wrote", os.path.join(HERE, a.out))
 
 
 if __name__ == "__main__":

@@ -68,11 +68,11 @@ __all__ += ["baseline_case", "golden_feats_equal"]
 
 
 # ---- random parameter draws pinned by tests/golden/random_draws.npz (the reference itself ran them: gen_random_draws.py) ----
-def random_draws(golden_dir):
+def random_draws(golden_dir, name="random_draws.npz"):
     """[(draw parameters, tracking context, frame 0, frame 1, {stage: (x, y, val)})] of the reference's random-draw goldens."""
     import json
     import os
-    g = np.load(os.path.join(golden_dir, "random_draws.npz"))
+    g = np.load(os.path.join(golden_dir, name))
     cases = []
     for k, t in enumerate(json.loads(bytes(g["draws_json"]).decode())):
         tc = make_tc(levels=t["levels"], ss=t["ss"], window=t["window"], max_residue=t["mr"], mindist=t["mindist"],

@@ -692,11 +692,11 @@ def test_random_parameter_draws_vs_oracle(seed):
 
 
 def test_random_draws_the_reference_ran(ctx, golden_dir):
-    """The HIP path on the 160 random parameter draws the reference itself ran (tests/golden/random_draws.npz): selected, tracked and
-    replaced lists equal the reference's in every record."""
+    """The HIP path on the 160 + 60 random parameter draws the reference itself ran (tests/golden/random_draws.npz, random_draws_large.npz:
+    frames up to 1400 x 1000, lists up to 2000 features): selected, tracked and replaced lists equal the reference's in every record."""
     from helpers import draw_equal, random_draws
     from pyfeaturetrack_amd.backend import REPLACING_SOME
-    for t, tc, f0, f1, want in random_draws(golden_dir):
+    for t, tc, f0, f1, want in random_draws(golden_dir) + random_draws(golden_dir, "random_draws_large.npz"):
         ctx.configure(tc)
         ctx.upload(0, f0)
         ctx.upload(1, f1)

@@ -254,7 +254,9 @@ def test_random_draws_the_reference_ran(golden_dir):
     from oracle import klt_oracle as ko
     cases = random_draws(golden_dir)
     assert len(cases) == 160
-    for t, tc, f0, f1, want in cases:
+    large = random_draws(golden_dir, "random_draws_large.npz")     # 60 more: frames up to 1400 x 1000, lists up to 2000 features
+    assert len(large) == 60
+    for t, tc, f0, f1, want in cases + large:
         p = params_from_tc(tc)
         fl = ko.select_good_features(p, f0.astype(np.float32), t["n"])
         assert draw_equal(fl, want["sel"]), "selection differs from the reference: %r" % (t,)
