@@ -69,7 +69,8 @@ __all__ += ["baseline_case", "golden_feats_equal"]
 
 # ---- random parameter draws pinned by tests/golden/random_draws.npz (the reference itself ran them: gen_random_draws.py) ----
 def random_draws(golden_dir, name="random_draws.npz"):
-    """[(draw parameters, tracking context, frame 0, frame 1, {stage: (x, y, val)})] of the reference's random-draw goldens."""
+    """[(draw parameters (+ "frame2", "sequential"), tracking context, frame 0, frame 1, {stage: (x, y, val)})] of the reference's
+    random-draw goldens; stages: sel(ected on frame 0), tr(ac)k(ed into frame 1), rep(laced on frame 1), trk2 (tracked into frame 2)."""
     import json
     import os
     g = np.load(os.path.join(golden_dir, name))
@@ -78,7 +79,9 @@ def random_draws(golden_dir, name="random_draws.npz"):
         tc = make_tc(levels=t["levels"], ss=t["ss"], window=t["window"], max_residue=t["mr"], mindist=t["mindist"],
                      nSkippedPixels=t["skip"], smoothBeforeSelecting=t["smooth"], min_eigenvalue=t["min_eig"], max_iterations=t["max_iter"])
         base = synth.synth_base(t["w"], t["h"], t["seed"])
-        want = {st: (g["d%d_%s_x" % (k, st)], g["d%d_%s_y" % (k, st)], g["d%d_%s_val" % (k, st)]) for st in ("sel", "trk", "rep")}
+        want = {st: (g["d%d_%s_x" % (k, st)], g["d%d_%s_y" % (k, st)], g["d%d_%s_val" % (k, st)]) for st in ("sel", "trk", "rep", "trk2")}
+        t["frame2"] = synth.shift_frame(base, 2 * t["shift"][0], 2 * t["shift"][1])       # the frame of the second tracking call
+        t["sequential"] = bool(t["seed"] & 1)                                             # (the reference ran it in sequential mode)
         cases.append((t, tc, synth.shift_frame(base, 0, 0), synth.shift_frame(base, *t["shift"]), want))
     return cases
 

@@ -703,11 +703,15 @@ def test_random_draws_the_reference_ran(ctx, golden_dir):
         ctx.build_pyramids(0)
         ctx.build_pyramids(1)
         fl, _ = ctx.select(0, t["n"])
-        assert draw_equal(fl, want["sel"]), "selection differs from the reference: %r" % (t,)
+        assert draw_equal(fl, want["sel"]), "selection differs from the reference: %r" % (t["seed"],)
         fl, _ = ctx.track(0, 1, fl)
-        assert draw_equal(fl, want["trk"]), "tracking differs from the reference: %r" % (t,)
+        assert draw_equal(fl, want["trk"]), "tracking differs from the reference: %r" % (t["seed"],)
         fl, _ = ctx.select(1, t["n"], mode=REPLACING_SOME, fl=fl)
-        assert draw_equal(fl, want["rep"]), "replacement differs from the reference: %r" % (t,)
+        assert draw_equal(fl, want["rep"]), "replacement differs from the reference: %r" % (t["seed"],)
+        ctx.upload(2, t["frame2"])
+        ctx.build_pyramids(2)
+        fl, _ = ctx.track(1, 2, fl)                    # frame 1's pyramids stay in their slot, as the reference's sequential mode keeps them
+        assert draw_equal(fl, want["trk2"]), "second tracking call differs from the reference: %r" % (t["seed"],)
 
 
 def test_random_sequences_vs_per_frame_api():
@@ -1278,14 +1282,23 @@ def test_python_api_on_random_draws_the_reference_ran(golden_dir):
             tc.mindist, tc.nSkippedPixels, tc.smoothBeforeSelecting = t["mindist"], t["skip"], t["smooth"]
             tc.max_residue, tc.min_eigenvalue, tc.max_iterations = t["mr"], t["min_eig"], t["max_iter"]
             i0, i1 = PIL.fromarray(f0, "L"), PIL.fromarray(f1, "L")
+            tc.sequentialMode = t["sequential"]
+            i2 = PIL.fromarray(t["frame2"], "L")
             fl = sgf.KLTSelectGoodFeatures(tc, i0, t["n"])
-            for stage in ("sel", "trk"):
+            for stage in ("sel", "trk", "trk2"):
                 if stage == "trk":
                     tf.KLTTrackFeatures(tc, i0, i1, fl)
+                if stage == "trk2":
+                    # the reference's list went through _enforceMinimumDistance in between: take its state, then make the second call
+                    # (sequential draws: the first image argument is ignored, the resident pyramids of frame 1 are used)
+                    rx, ry, rv = want["rep"]
+                    for f, a, b, c in zip(fl, rx, ry, rv):
+                        f.x, f.y, f.val = float(a), float(b), int(c)
+                    tf.KLTTrackFeatures(tc, i1, i2, fl)
                 x, y, v = want[stage]
-                assert [int(f.val) for f in fl] == [int(a) for a in v], "%s: val differs: %r" % (stage, t)
+                assert [int(f.val) for f in fl] == [int(a) for a in v], "%s: val differs: seed %r" % (stage, t["seed"])
                 assert np.array_equal(np.array([f.x for f in fl], np.float32), x) and np.array_equal(np.array([f.y for f in fl], np.float32), y), \
-                    "%s: positions differ: %r" % (stage, t)
+                    "%s: positions differ: seed %r" % (stage, t["seed"])
     finally:
         sgf.KLT_verbose, tf.KLT_verbose = verbose
 

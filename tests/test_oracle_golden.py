@@ -264,3 +264,6 @@ def test_random_draws_the_reference_ran(golden_dir):
         assert draw_equal(fl, want["trk"]), "tracking differs from the reference: %r" % (t,)
         fl = ko.select_good_features(p, f1.astype(np.float32), t["n"], mode=2, fl=fl)
         assert draw_equal(fl, want["rep"]), "replacement differs from the reference: %r" % (t,)
+        # the second call (tracked, replaced and lost features in one list; in sequential mode the reference reused frame 1's pyramids)
+        ko.track_features(p, ko.Pyramids(p, f1.astype(np.float32)), ko.Pyramids(p, t["frame2"].astype(np.float32)), fl)
+        assert draw_equal(fl, want["trk2"]), "second tracking call differs from the reference: %r" % ({k: v for k, v in t.items() if k != "frame2"},)
