@@ -748,12 +748,16 @@ def main():
             return plain_out((lj // B) % 2, lj % B)
         return FB_VIEW0 + ((lj // GATHER_EVERY) % 2) * GATHER_EVERY + lj % GATHER_EVERY
 
-    def group(g, nb=B, last=False):
-        """nb consecutive steps (pairs) as one group: every launch of the context is shared by them"""
+    def group_build(g, nb=B):
+        """nb consecutive steps (pairs) as one group: every launch of the context is shared by them.  First half: the pyramids"""
         c, j = g % nctx, g // nctx                # context, and the group's index among that context's groups
+        ctxs[c].build_pyramids_batch(slots_of(j, nb))            # all frames of the group share every launch
+
+    def group_track(g, nb=B, last=False):
+        """second half: the tracker launch (and, N > 1, the collective behind it)"""
+        c, j = g % nctx, g // nctx
         cx = ctxs[c]
         slots = slots_of(j, nb)
-        cx.build_pyramids_batch(slots)            # all frames of the group share every launch
         lj0 = j * B
         if distributed and lj0 % GATHER_EVERY == 0:
             cx.comm_fence_featbuf(FB_RING0 if (lj0 // GATHER_EVERY) % 2 == 0 else FB_RING1)   # the collective that read this table two rounds ago has finished
@@ -766,10 +770,16 @@ def main():
             cx.allgather_featbuf_async(ring, gath, GATHER_EVERY * NFEAT)     # RCCL on the side stream, behind this tracker launch
 
     def run_steps(n):
-        """n steps = ceil(n / B) groups, the last one partial when B does not divide n"""
+        """n steps = ceil(n / B) groups, the last one partial when B does not divide n.  The groups go out in rounds of one group per
+        context, the builds of a round before its tracker launches: every stream has work a few microseconds after the region starts
+        (enqueueing a whole group takes the host ~25 us); the order inside each stream, and the work, are the same either way"""
         ngroups = (n + B - 1) // B
-        for g in range(ngroups):
-            group(g, nb=min(B, n - g * B), last=(g >= ngroups - nctx))     # every context closes its open table with a gather
+        for g0 in range(0, ngroups, nctx):
+            wave = range(g0, min(g0 + nctx, ngroups))
+            for g in wave:
+                group_build(g, nb=min(B, n - g * B))
+            for g in wave:
+                group_track(g, nb=min(B, n - g * B), last=(g >= ngroups - nctx))     # every context closes its open table with a gather
 
     # bring the GPU to its steady state first (the same work as the steps, into the plain output buffers)
     t_pre = time.perf_counter()
