@@ -3,42 +3,47 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one KLTTrackFeatures-equivalent on one frame pair per rank: build the image / gradx /
-grady pyramids of both frames from the u8 frames already resident in HBM, then track every live
-feature coarse-to-fine (device-resident feature records in, device-resident records out).
-Workload at every N = BASELINE cfg-2 (1920x1080 synthetic pair, 5000 features, 7x7 window,
-3 pyramid levels / subsampling 4, translation only); with N > 1 every rank runs its own pair
-(seed = rank + 1: weak scaling, the path shards by frame pair with no data-path exchange) and the
-16-byte feature records of 128 consecutive steps are collected in a device-side table and gathered to
-every rank with one RCCL all-gather issued by libkltgpu.so on its side stream (event-ordered behind the
-tracker launch, overlapped with the next steps' kernels).  No torch anywhere.
+Workload at every N = BASELINE cfg-2 (1920x1080 synthetic pairs, 5000 features each, 7x7 window, 3 pyramid levels / subsampling 4,
+translation only).  `--resident-pairs` (default 64) DISTINCT pairs per GPU (seeds rank * 64 + 1 ...) are resident in HBM with their
+own frame slots, pyramids (3.7 GB per GPU) and feature lists; a *step* is one pass of the hot path over that batch: for every pair,
+build the image / gradx / grady pyramids of both frames from the u8 frames in HBM, then track every live feature coarse-to-fine
+(device-resident feature records in, device-resident records out) -- 64 KLTTrackFeatures-equivalents per step.  The timed region
+therefore streams 3.7 GB of distinct frames and pyramids per step: nothing it reads was left in the 256 MB Infinity Cache by the
+step before (round 2 rebuilt the same four slots from the same two frames, `extra.cache_resident_ms_per_pair` keeps that figure).
+With N > 1 every rank runs its own 64 pairs (weak scaling: the path shards by frame pair with no data-path exchange) and the
+16-byte records of a step are collected in one device-side [pairs x features] table per context and gathered to every rank with
+one RCCL all-gather per table, issued by libkltgpu.so on its side stream (event-ordered behind the last tracker launch of the step,
+overlapped with the next step's kernels).  No torch anywhere.
 
-Launching.  `--gpus N` with N > 1 and no RANK in the environment: this process -- before it touches
-the GPU in any way -- starts N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE and a rendezvous
-file in their environment), forwards rank 0's JSON line and exits non-zero if any rank failed.  Under an
-external launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) the same
-variables are already set and every process is a rank.  The RCCL unique id travels through the
-rendezvous file (pyfeaturetrack_amd/parallel.py).
+Launching.  `--gpus N` with N > 1 and no RANK in the environment: this process -- before it touches the GPU in any way -- starts N
+fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE and a rendezvous file in their environment), forwards rank 0's JSON line and
+exits non-zero if any rank failed.  Under an external launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus
+N ...`) the same variables are already set and every process is a rank.  The RCCL unique id travels through the rendezvous file
+(pyfeaturetrack_amd/parallel.py).
 
-Consecutive groups of `--batch` steps (default 2) go round-robin to `--inflight` contexts (default 2; one HIP stream each, nothing
-ordering them): frame pairs are independent, so the steps of a group share every launch of their context (one batched pyramid build,
+Consecutive groups of `--batch` pairs (default 2) go round-robin to `--inflight` contexts (default 2; one HIP stream each, nothing
+ordering them): frame pairs are independent, so the pairs of a group share every launch of their context (one batched pyramid build,
 one tracker launch -- the reference's workload for a stereo rig or two cameras) and the GPU overlaps the kernels of different groups.
-Every step does the full work of one pair; `ms_per_frame_pair` (= `extra.single_stream_ms_per_pair`) is one pair at a time on one
-stream, `--inflight 3 --batch 1` the round-1 arrangement.  The K-step timed region (barrier +
-synchronise on both sides, MAX over ranks) is repeated `--repeats` times; `ms_per_step` is the median region, the spread is
-in `extra.region_ms_per_step`.
+Every pair gets the full work of one KLTTrackFeatures call.  `ms_per_frame_pair` (= `extra.single_stream_ms_per_pair`) is one pair
+at a time on one stream, rotating through the resident pairs.  The K-step timed region (barrier + synchronise on both sides, MAX
+over ranks) is repeated until at least `--repeats` regions AND 2 s of timed work are in (never fewer than 5 regions); `ms_per_step`
+is the median region, the spread is in `extra.region_ms_per_step`.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  parity_checked -- the records of the timed steps equal the CPU oracle's on the same pair (the run fails otherwise);
-  roofline     -- the dominant kernel of the step (largest share of device time), timed with HIP
-                  events on the context's stream in a second pass over the same K steps (events
-                  around every launch would distort the un-instrumented `value`);
-  cpu_baseline -- the CPU oracle (oracle/klt_oracle.c, a bit-exact port of the reference's
-                  Python/Cython/SciPy path) on the same workload, 1 thread, rank 0, N = 1 only.
+  parity_checked -- the records of the last timed step of EVERY resident pair equal the CPU oracle's (the run fails otherwise);
+  roofline     -- the dominant kernel of the step (largest share of device time), timed by its dispatches' own start / stop
+                  timestamps in a second pass over the same pairs (events on every launch would distort the un-instrumented
+                  `value`), next to the whole step (`step_frac`) and the per-kernel table; bench.py refuses to print a line in
+                  which any fraction of peak exceeds 1;
+  cpu_baseline -- the CPU oracle (oracle/klt_oracle.c, a bit-exact port of the reference's Python/Cython/SciPy path) on the same
+                  workload, 1 thread, rank 0, N = 1 only.
+`--config cfg1|cfg3|cfg4|cfg5` run the other BASELINE configs the same way: timed regions, records checked against the oracle,
+`roofline` with the per-kernel table, `cpu_baseline`.
 """
 import argparse
 import hashlib
 import json
+import math
 import os
 import statistics
 import sys
@@ -54,15 +59,14 @@ if ROOT not in sys.path:
 from pyfeaturetrack_amd import parallel, synth                          # noqa: E402
 from pyfeaturetrack_amd.backend import Context                          # noqa: E402
 from pyfeaturetrack_amd.klt import KLT_TrackingContext                  # noqa: E402
-from pyfeaturetrack_amd.params import params_from_tc                    # noqa: E402
+from pyfeaturetrack_amd.params import affine_params_from_tc, params_from_tc   # noqa: E402
 
 WIDTH, HEIGHT, NFEAT = 1920, 1080, 5000
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TOL_PX = 1e-3             # north_star: sub-pixel x/y within 1e-3 (observed: 0)
-FB_SEL, FB_OUT0, FB_OUT1 = 0, 1, 2
-FB_RING0, FB_RING1, FB_GATH0, FB_GATH1, FB_VIEW0 = 3, 4, 5, 6, 100
-GATHER_EVERY = 128
 DTYPE = "f32 (convolutions accumulate in f64)"
+MIN_TIMED_S = 2.0         # the timed regions of a run add up to at least this much GPU work
+ORACLE_NOTE = "oracle/klt_oracle.c (pinned to reference-generated goldens)"
 
 
 def cfg2_context():
@@ -73,17 +77,31 @@ def cfg2_context():
     return tc
 
 
-def algorithmic_bytes(p, ncols, nrows, stats, nfeat):
-    """minimum traffic per pair = 2 * bytes_pyramid + sum over features of bytes_track."""
-    ss, L = p.subsampling, p.nPyramidLevels
+def level_pixels(p, ncols, nrows):
     n, dims = [], (ncols, nrows)
-    for _ in range(L):
+    for _ in range(p.nPyramidLevels):
         n.append(dims[0] * dims[1])
-        dims = (dims[0] // ss, dims[1] // ss)
-    pyr = n[0] * (1 + 4) + sum(4 * (n[l - 1] + n[l]) for l in range(1, L)) + sum(12 * v for v in n)
+        dims = (dims[0] // p.subsampling, dims[1] // p.subsampling)
+    return n
+
+
+def pyramid_bytes(p, ncols, nrows, b_in=1):
+    """N0 (b_in + 4) + sum 4 (N_{l-1} + N_l) + sum 12 N_l -- one frame"""
+    n = level_pixels(p, ncols, nrows)
+    return n[0] * (b_in + 4) + sum(4 * (n[l - 1] + n[l]) for l in range(1, len(n))) + sum(12 * v for v in n)
+
+
+def track_bytes(p, stats, nfeat):
+    """sum over features and levels of 12 (w+1)(h+1) (1 + iterations) + 24 per record; `stats` = totals of the
+    device counters (klt_track_stats) over the launches they cover, nfeat = records those launches read and wrote"""
+    L = p.nPyramidLevels
     foot = 12.0 * (p.window_width + 1) * (p.window_height + 1)
-    track = foot * (sum(stats["level_visits"][:L]) + sum(stats["iterations"][:L])) + 24.0 * nfeat
-    return pyr, track
+    return foot * (sum(stats["level_visits"][:L]) + sum(stats["iterations"][:L])) + 24.0 * nfeat
+
+
+def algorithmic_bytes(p, ncols, nrows, stats, nfeat):
+    """per pair (pyramid bytes of one frame, tracker bytes); `stats` = per-pair averages"""
+    return pyramid_bytes(p, ncols, nrows), track_bytes(p, stats, nfeat)
 
 
 def usable_cores(cap=32):
@@ -107,63 +125,89 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def oracle_track(p, f0, f1, fl):
-    """The CPU oracle's records for one pair (the checker; never the thing measured).  None if the oracle is not built."""
+# ============================================================================= the checker (oracle) and the CPU baseline
+def load_oracle():
+    """oracle/klt_oracle.py -- the checker and the cpu_baseline leg only; never the thing measured.  None if it is not built."""
     try:
         from oracle import klt_oracle as ko
+        ko.lib()
+        return ko
     except (ImportError, OSError) as e:
         print("oracle unavailable: %s" % e, file=sys.stderr)
         return None
+
+
+def oracle_track(ko, p, f0, f1, fl, threads=1):
+    """The CPU oracle's records for one pair."""
     a0, a1 = f0.astype(np.float32), f1.astype(np.float32)
     ofl = fl.copy()
-    ko.set_threads(1)
+    ko.set_threads(threads)
     ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), ofl)
+    ko.set_threads(1)
     return ofl
 
 
-def parity_against(out, ofl):
-    """{parity_checked, max_abs_dx, ...} of timed records `out` against the oracle's `ofl` (None: unchecked)."""
-    if ofl is None:
-        return {"parity_checked": False, "parity_note": "oracle library not built on this box"}
+def records_equal(out, ofl):
+    """(status codes equal, max |dx, dy|) of records `out` against the oracle's `ofl`"""
     same_val = bool(np.array_equal(out["val"], ofl["val"]))
-    dx = float(max(np.abs(out["x"].astype(np.float64) - ofl["x"]).max(), np.abs(out["y"].astype(np.float64) - ofl["y"]).max()))
-    return {"parity_checked": bool(same_val and dx <= TOL_PX), "max_abs_dx": dx, "status_codes_equal": same_val,
-            "parity_tolerance_px": TOL_PX, "parity_against": "oracle/klt_oracle.c (pinned to reference-generated goldens)"}
+    dx = float(max(np.abs(out["x"].astype(np.float64) - ofl["x"]).max(), np.abs(out["y"].astype(np.float64) - ofl["y"]).max())) if len(out) else 0.0
+    return same_val, dx
 
 
-def cpu_baseline(p, f0, f1, fl, nfeat, label):
-    """Oracle timed on the host: bounded sample of the same workload (about 10-20 s of CPU work)."""
-    from oracle import klt_oracle as ko
-    a0, a1 = f0.astype(np.float32), f1.astype(np.float32)
+def parity_summary(checks, what):
+    """{parity_checked, ...} from [(label, status codes equal, max |dx|)]; an empty list = unchecked"""
+    if not checks:
+        return {"parity_checked": False, "parity_note": "oracle library not built on this box"}
+    worst = max(c[2] for c in checks)
+    same = all(c[1] for c in checks)
+    bad = [c[0] for c in checks if not c[1] or c[2] > TOL_PX]
+    out = {"parity_checked": bool(same and worst <= TOL_PX), "max_abs_dx": worst, "status_codes_equal": same,
+           "parity_tolerance_px": TOL_PX, "parity_against": ORACLE_NOTE, "parity_cases": len(checks), "parity_what": what}
+    if bad:
+        out["parity_failed_cases"] = bad[:8]
+    return out
 
-    def one_pair():
-        P0, P1 = ko.Pyramids(p, a0), ko.Pyramids(p, a1)
-        return ko.track_features(p, P0, P1, fl.copy())
 
-    ko.set_threads(1)
+def fail_on_parity(par):
+    if par and not par.get("parity_checked") and "max_abs_dx" in par:
+        raise SystemExit("timed records differ from the oracle: %r" % par)
+
+
+def cpu_time(fn, budget_s=10.0, max_reps=200):
+    """(seconds per call, calls): one call to size the sample, then about `budget_s` of them"""
     t = time.perf_counter()
-    one_pair()
+    fn()
     t1 = time.perf_counter() - t
-    reps = int(max(2, min(200, 10.0 / max(t1, 1e-3))))      # about 10 s of single-thread work
+    reps = int(max(2, min(max_reps, budget_s / max(t1, 1e-4))))
     t = time.perf_counter()
     for _ in range(reps):
-        one_pair()
-    dt = (time.perf_counter() - t) / reps
-    # the same port on the host cores this process may actually use (OpenMP over image lines / features;
-    # bit-identical results).  Time-bounded: a container with a CPU quota can make many threads slower than one.
-    ncores = ko.set_threads(usable_cores())
-    t = time.perf_counter()
-    reps_all = 0
-    while reps_all < 40 and (reps_all < 2 or time.perf_counter() - t < 4.0) and time.perf_counter() - t < 12.0:
-        one_pair()
-        reps_all += 1
-    dt_all = (time.perf_counter() - t) / reps_all
+        fn()
+    return (time.perf_counter() - t) / reps, reps
+
+
+def cpu_baseline_of(ko, one_step, nfeat, what, all_cores=True, budget_s=10.0):
+    """Oracle timed on the host: a bounded sample of the same workload (about 10-20 s of CPU work).  `one_step()` = one step of the
+    config on the CPU; value = nfeat / seconds."""
+    if ko is None:
+        return None
     ko.set_threads(1)
-    return {"value": nfeat / dt, "unit": "features/s", "cores": 1, "kind": "port",
-            "ms_per_pair": dt * 1e3,
-            "sample": "%d x (pyramids of both frames + track %d features) of %s, oracle/klt_oracle.c, 1 thread" % (reps, nfeat, label),
-            "all_cores": {"value": nfeat / dt_all, "cores": ncores, "ms_per_pair": dt_all * 1e3,
-                          "sample": "%d x the same pair, OpenMP over image lines and features" % reps_all}}
+    dt, reps = cpu_time(one_step, budget_s)
+    out = {"value": nfeat / dt, "unit": "features/s", "cores": 1, "kind": "port", "ms_per_step": dt * 1e3,
+           "sample": "%d x (%s), oracle/klt_oracle.c, 1 thread" % (reps, what)}
+    if all_cores:
+        # the same port on the host cores this process may actually use (OpenMP over image lines / features; bit-identical
+        # results).  Time-bounded: a container with a CPU quota can make many threads slower than one.
+        ncores = ko.set_threads(usable_cores())
+        t = time.perf_counter()
+        reps_all = 0
+        while reps_all < 40 and (reps_all < 2 or time.perf_counter() - t < 4.0) and time.perf_counter() - t < 12.0:
+            one_step()
+            reps_all += 1
+        dt_all = (time.perf_counter() - t) / reps_all
+        ko.set_threads(1)
+        out["all_cores"] = {"value": nfeat / dt_all, "cores": ncores, "ms_per_step": dt_all * 1e3,
+                            "sample": "%d x the same step, OpenMP over image lines and features" % reps_all}
+    return out
 
 
 def file_sha16(rel):
@@ -238,13 +282,36 @@ class Ranks:
         return self.max_over_ranks(el), enq
 
 
-def timed_regions(ranks, run_region, steps, repeats, budget_s=25.0):
-    """`repeats` K-step regions (each bracketed as the contract says).  Returns (median seconds per region, all regions, host
-    enqueue seconds of the median region).  The repeat count shrinks (never below 5) if the regions are long."""
+class OneGpu:
+    """The same bracket for the single-GPU configs (no communicator)."""
+    distributed = False
+    rank, world = 0, 1
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+
+    def max_over_ranks(self, v):
+        return v
+
+    def timed(self, fn):
+        for cx in self.ctxs:
+            cx.sync()
+        t0 = time.perf_counter()
+        fn()
+        enq = time.perf_counter() - t0
+        for cx in self.ctxs:
+            cx.sync()
+        return time.perf_counter() - t0, enq
+
+
+def timed_regions(ranks, run_region, repeats, min_total_s=MIN_TIMED_S, budget_s=30.0):
+    """K-step regions, each bracketed as the contract says, until `repeats` regions AND `min_total_s` of timed work are in (so that
+    a sampler outside this process sees a busy GPU even when one region lasts a millisecond); fewer -- never below 5 -- when the
+    regions are long.  Returns (median seconds per region, all regions, host enqueue seconds of the median region)."""
     el, enq = ranks.timed(run_region)
     regions = [(el, enq)]
-    n = repeats
-    if el * repeats > budget_s:
+    n = max(repeats, int(math.ceil(min_total_s / max(el, 1e-9))))
+    if el * n > budget_s:
         n = max(5, int(budget_s / max(el, 1e-9)))
     n = int(ranks.max_over_ranks(n)) if ranks.distributed else n      # every rank runs the same number of regions
     while len(regions) < n:
@@ -254,7 +321,90 @@ def timed_regions(ranks, run_region, steps, repeats, budget_s=25.0):
     return med[0], [r[0] for r in regions], med[1]
 
 
+def region_stats(regions, units, elapsed):
+    """spread of the timed regions in ms per unit (`units` per region)"""
+    return {"median": elapsed / units * 1e3, "min": min(regions) / units * 1e3, "max": max(regions) / units * 1e3,
+            "regions": len(regions), "timed_s_total": sum(regions)}
+
+
+# ------------------------------------------------------------------------------------------------- roofline bookkeeping
+def timed_pass(ctx, run, mode):
+    """`run()` with every launch timed: mode 1 = an event pair around each launch (it also holds the boundary to the launch before,
+    ~2.6 us); mode 2 = the kernels that are one launch per call by their dispatch's own start / stop timestamps -- what rocprofv3
+    reports as the kernel's duration.  {family: {launches, total_ms, bytes}}"""
+    ctx.sync()
+    ctx.timing_enable(mode)
+    run()
+    res = ctx.timing_read()
+    ctx.timing_enable(False)
+    return {k["name"]: k for k in res}
+
+
+def kernel_table(stamped, paired, nsteps, bytes_override=None, peak=HBM_PEAK_GBS):
+    """per-kernel figures of a config's step: duration per launch (dispatch timestamps where the family has them, else the event
+    pair), launches per step, algorithmic bytes per launch (the library books SURVEY 8(d)'s figure per launch; the tracker's and the
+    affine check's come from the device counters: `bytes_override` = {family: total bytes over the pass}), GB/s and fraction of peak"""
+    out = {}
+    for name, k in sorted(paired.items(), key=lambda kv: -kv[1]["total_ms"]):
+        s = stamped.get(name) if stamped else None
+        src = s if s and s["launches"] == k["launches"] else k
+        total_bytes = (bytes_override or {}).get(name, k["bytes"])
+        us = 1e3 * src["total_ms"] / src["launches"]
+        gbps = total_bytes / max(src["total_ms"], 1e-9) / 1e6
+        out[name] = {"us_per_launch": us, "launches_per_step": k["launches"] / nsteps,
+                     "timed_by": "dispatch timestamps" if src is s else "event pair",
+                     "us_per_launch_event_pair": 1e3 * k["total_ms"] / k["launches"],
+                     "algorithmic_bytes_per_launch": total_bytes / k["launches"], "GBps": gbps, "frac": gbps / peak}
+    return out
+
+
+def roofline_of(table, nsteps, ms_per_step, peak=HBM_PEAK_GBS, dominant=None, extra=None):
+    """the `roofline` object: the dominant kernel (largest share of device time) against the HBM roof, the whole step next to it"""
+    dom = dominant or max(table, key=lambda n: table[n]["us_per_launch"] * table[n]["launches_per_step"])
+    d = table[dom]
+    step_bytes = sum(k["algorithmic_bytes_per_launch"] * k["launches_per_step"] for k in table.values())
+    dev_ms = sum(k["us_per_launch"] * k["launches_per_step"] for k in table.values()) * 1e-3
+    r = {"bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": peak, "unit": "GB/s", "frac": d["frac"], "traffic": None,
+         "launch_us": d["us_per_launch"], "launch_us_source": d["timed_by"], "launch_us_event_pair": d["us_per_launch_event_pair"],
+         "launches_per_step": d["launches_per_step"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+         "step_algorithmic_bytes": step_bytes, "step_kernel_ms": dev_ms,
+         "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / peak,
+         "step_frac_note": "step_algorithmic_bytes / ms_per_step / peak (the un-instrumented timed regions); step_kernel_ms = sum of the kernels' own durations",
+         "kernels": table}
+    r.update(extra or {})
+    return r
+
+
+def check_fractions(obj, path="line"):
+    """Every fraction of peak in the line must be <= 1 (and every GB/s <= the peak next to it): a figure above the roof is a
+    bookkeeping error (round 2 shipped step_frac 2.6 from counters that included warm-up launches), never a result."""
+    bad = []
+
+    def walk(o, p, peak):
+        if isinstance(o, dict):
+            peak = o.get("peak", peak) if isinstance(o.get("peak"), (int, float)) else peak
+            for k, v in o.items():
+                if isinstance(v, bool) or v is None:
+                    continue
+                if isinstance(v, (int, float)):
+                    if (k == "frac" or k.endswith("_frac") or k.startswith("frac_")) and not (0.0 <= v <= 1.0):
+                        bad.append("%s.%s = %r" % (p, k, v))
+                    if k == "GBps" and peak and v > peak:
+                        bad.append("%s.%s = %r > peak %r" % (p, k, v, peak))
+                else:
+                    walk(v, p + "." + k, peak)
+        elif isinstance(o, list):
+            for i, v in enumerate(o):
+                walk(v, "%s[%d]" % (p, i), peak)
+
+    walk(obj, path, HBM_PEAK_GBS)
+    return bad
+
+
 def emit(json_fd, line):
+    bad = check_fractions(line)
+    if bad:
+        raise SystemExit("refusing to print a line with figures above the roof: " + "; ".join(bad))
     os.write(json_fd, (json.dumps(line) + "\n").encode())      # the ONE JSON line on the real stdout
 
 
@@ -267,18 +417,27 @@ def base_line(value, n_gpus, steps, warmup, ms_step, ms_pair, workload, scaling=
             "config": cfg, "roofline": None, "cpu_baseline": None}
 
 
+def sane_iterations(stats, nfeat_total, levels, what):
+    """The Newton-iteration counters must describe exactly the launches they are divided by: per feature and level between 1 and
+    max_iterations (10) on average.  (Round 2 reset them before a warm-up loop.)"""
+    for l in range(levels):
+        per = stats["iterations"][l] / max(1, nfeat_total)
+        if not (0.5 <= per <= 10.0):
+            raise SystemExit("%s: %.2f Newton iterations per feature at level %d -- the counters cover other launches than the ones "
+                             "they are booked on" % (what, per, l))
+
+
 # ========================================================================================== cfg-4
 def run_cfg4(args, json_fd):
     """BASELINE cfg-4: 256 independent 1280x720 pairs (seeds 0..255), 2000 features each, 7x7, 3 levels / ss 4, sharded
-    contiguously over the ranks (32 per GPU at N = 8), frames resident in HBM.  Per step every rank builds the pyramids
-    of its whole shard (frames share launches through blockIdx.z), tracks it with ONE launch into a device-side
-    [pairs x features] table and the table is gathered to rank 0 with one RCCL gather.  Total work is fixed: strong scaling."""
+    contiguously over the ranks (32 per GPU at N = 8; shards may differ by one pair), frames resident in HBM.  Per step every rank
+    builds the pyramids of its whole shard (frames share launches through blockIdx.z), tracks it with ONE launch into a device-side
+    [pairs x features] table and the table is gathered to rank 0 with one RCCL gather (a count per rank).  Total work is fixed:
+    strong scaling."""
     ranks = Ranks(args)
     total, w, h, nf = args.pairs, 1280, 720, 2000
     mine = parallel.shard_range(total, ranks.world, ranks.rank)
     pairs = len(mine)
-    if ranks.distributed and total % ranks.world:
-        raise SystemExit("--pairs must be a multiple of the number of ranks")
     tc = cfg2_context()
     p = params_from_tc(tc)
     ctx = Context(ranks.local_rank)
@@ -290,10 +449,11 @@ def run_cfg4(args, json_fd):
         ctx.upload(2 * k, f0)
         ctx.upload(2 * k + 1, f1)
     slots = list(range(2 * pairs))
-    ctx.build_pyramids_batch(slots, sync=True)
-    T_IN, T_OUT, T_ALL, V_IN, V_OUT = 0, 1, 2, 1000, 1000 + pairs
-    ctx.featbuf_alloc(T_IN, pairs * nf)
-    ctx.featbuf_alloc(T_OUT, pairs * nf)
+    T_IN, T_OUT, T_ALL, V_IN, V_OUT = 0, 1, 2, 1000, 1000 + max(pairs, 1)
+    if pairs:
+        ctx.build_pyramids_batch(slots, sync=True)
+        ctx.featbuf_alloc(T_IN, pairs * nf)
+        ctx.featbuf_alloc(T_OUT, pairs * nf)
     for k in range(pairs):
         ctx.featbuf_view(V_IN + k, T_IN, k * nf, nf)
         ctx.featbuf_view(V_OUT + k, T_OUT, k * nf, nf)
@@ -301,13 +461,15 @@ def run_cfg4(args, json_fd):
     ctx.sync()
     table = [(2 * k, 2 * k + 1, V_IN + k, V_OUT + k) for k in range(pairs)]
     ranks.attach([ctx])
-    gather = parallel.ShardGather(ctx, T_OUT, T_ALL, pairs, nf, root=0) if ranks.distributed else None
+    gather = parallel.ShardGather(ctx, T_OUT, T_ALL, total, nf, root=0) if ranks.distributed else None
 
     def step():
-        ctx.build_pyramids_batch(slots)
-        if gather:
+        if pairs:
+            ctx.build_pyramids_batch(slots)
+        if gather and pairs:
             ctx.comm_fence_featbuf(T_OUT)          # the gather of the previous step has read the table
-        ctx.track_batch_async(table, nf)
+        if pairs:
+            ctx.track_batch_async(table, nf)
         if gather:
             gather.gather_async()
 
@@ -317,54 +479,75 @@ def run_cfg4(args, json_fd):
 
     for _ in range(max(1, args.warmup)):
         step()
-    el, regions, enq = timed_regions(ranks, region, args.steps, args.repeats)
-    # what was timed, against the oracle: the first pair of rank 0's shard
-    out = ctx.featbuf_download(T_OUT, pairs * nf).reshape(pairs, nf)
-    fl0 = ctx.featbuf_download(V_IN, nf)
-    par = parity_against(out[0], oracle_track(p, frames[0][0], frames[0][1], fl0)) if ranks.rank == 0 else {}
+    el, regions, enq = timed_regions(ranks, region, args.repeats)
+    # what was timed, against the oracle: the first and the last pair of rank 0's shard
+    out = ctx.featbuf_download(T_OUT, pairs * nf).reshape(pairs, nf) if pairs else np.zeros((0, nf), parallel.FEAT_DTYPE)
+    ko = load_oracle() if ranks.rank == 0 else None
+    par = {}
+    fl_in = ctx.featbuf_download(T_IN, pairs * nf).reshape(pairs, nf) if pairs else None
+    if ranks.rank == 0 and pairs:
+        checks = []
+        for k in sorted({0, pairs - 1}) if ko else []:
+            same, dx = records_equal(out[k], oracle_track(ko, p, frames[k][0], frames[k][1], fl_in[k], threads=usable_cores()))
+            checks.append(("pair %d" % mine[k], same, dx))
+        par = parity_summary(checks, "tracked records of the first and the last pair of rank 0's shard, last timed step")
     gathered_ok = None
     if gather:
         full = gather.result()
         if ranks.rank == 0:
             gathered_ok = bool(full.shape == (total, nf) and np.array_equal(full[:pairs], out))
-    roof = None
-    if ranks.rank == 0:
+    roof = cpu = None
+    if ranks.rank == 0 and pairs:
+        nst = min(args.steps, 10)
+
+        def plain_steps():
+            for _ in range(nst):
+                ctx.build_pyramids_batch(slots)
+                ctx.track_batch_async(table, nf)
+
+        plain_steps()                                   # (the parity check left the GPU idle)
+        ctx.sync()
         ctx.track_stats_reset()
-        ctx.timing_enable(True)
-        for _ in range(min(args.steps, 20)):
-            ctx.build_pyramids_batch(slots)
-            ctx.track_batch_async(table, nf)
-        kernels = ctx.timing_read()
-        ctx.timing_enable(False)
-        nst = min(args.steps, 20)
+        paired = timed_pass(ctx, plain_steps, 1)
         st = ctx.track_stats()
-        st = {k: ([x / (nst * pairs) for x in v] if isinstance(v, list) else v / (nst * pairs)) for k, v in st.items()}
-        pyr_bytes, track_bytes = algorithmic_bytes(p, w, h, st, nf)
-        step_bytes = total * (2 * pyr_bytes + track_bytes)
-        roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS * ranks.world, "step_algorithmic_bytes": step_bytes,
-                "achieved": step_bytes / el * args.steps / 1e9, "frac": step_bytes / el * args.steps / 1e9 / (HBM_PEAK_GBS * ranks.world),
-                "traffic": None,
-                "kernels_rank0": {k["name"]: {"us_per_launch": 1e3 * k["total_ms"] / k["launches"],
-                                              "launches_per_step": k["launches"] / nst} for k in kernels}}
+        sane_iterations(st, nst * pairs * nf, p.nPyramidLevels, "cfg-4")
+        stamped = timed_pass(ctx, plain_steps, 2)
+        kt = kernel_table(stamped, paired, nst, {"track": track_bytes(p, st, nst * pairs * nf)})
+        # the line's step is the whole batch on all ranks: rank 0's kernels describe its own shard
+        ms_step = el / args.steps * 1e3
+        roof = roofline_of(kt, nst, ms_step)
+        rank0_bytes = roof["step_algorithmic_bytes"]
+        step_bytes = rank0_bytes * total / pairs
+        roof.update({"peak": HBM_PEAK_GBS * ranks.world, "step_algorithmic_bytes": step_bytes, "rank0_shard_algorithmic_bytes": rank0_bytes,
+                     "step_frac": step_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * ranks.world),
+                     "kernels_note": "rank 0's shard (%d of %d pairs), per-GPU peak %g GB/s" % (pairs, total, HBM_PEAK_GBS)})
+        for k in roof["kernels"].values():
+            k["frac"] = k["GBps"] / HBM_PEAK_GBS
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["kernel_peak"] = HBM_PEAK_GBS
+        if ko and not ranks.distributed and not args.no_cpu_baseline:
+            a0, a1 = frames[0][0].astype(np.float32), frames[0][1].astype(np.float32)
+            cpu = cpu_baseline_of(ko, lambda: ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), fl_in[0].copy()), nf,
+                                  "pyramids of both frames + track 2000 features of ONE 1280x720 pair of cfg-4 (seed %d)" % mine[0])
     ctx.close()
     if ranks.rank == 0:
         ms_step = el / args.steps * 1e3
         tracked = int(np.count_nonzero(out["val"] >= 0))
         line = base_line(total * nf * args.steps / el, ranks.world, args.steps, args.warmup, ms_step, ms_step / total,
-                         "cfg-4: %d independent 1280x720 pairs per step (%d per GPU), 2000 features each, 7x7, 3 levels "
+                         "cfg-4: %d independent 1280x720 pairs per step (%d on rank 0), 2000 features each, 7x7, 3 levels "
                          "(subsampling 4); per rank: batched pyramid build + one tracker launch + one RCCL gather of the "
                          "[pairs x 2000] record table to rank 0" % (total, pairs), scaling="strong",
-                         extra_cfg={"pairs_per_step": total, "pairs_per_rank": pairs, "tracked_rank0": tracked,
+                         extra_cfg={"pairs_per_step": total, "pairs_per_rank": [len(parallel.shard_range(total, ranks.world, r)) for r in range(ranks.world)],
+                                    "tracked_rank0": tracked,
                                     "rccl_ranks": ranks.world if ranks.distributed else 0, "gathered_table_ok": gathered_ok,
-                                    "parallelism": "pairs sharded contiguously, %d per GPU; no data-path collective, one gather" % pairs})
+                                    "parallelism": "pairs sharded contiguously (shards differ by at most one pair); no data-path collective, one gather with a count per rank"})
         line.update(par)
-        line["roofline"] = roof
-        line["extra"] = {"region_ms_per_step": {"median": ms_step, "min": min(regions) / args.steps * 1e3,
-                                                "max": max(regions) / args.steps * 1e3, "regions": len(regions)},
-                         "host_enqueue_ms_per_step": enq / args.steps * 1e3}
+        line["roofline"], line["cpu_baseline"] = roof, cpu
+        line["extra"] = {"region_ms_per_step": region_stats(regions, args.steps, el), "host_enqueue_ms_per_step": enq / args.steps * 1e3}
         emit(json_fd, line)
-        if par and not par.get("parity_checked") and "max_abs_dx" in par:
-            raise SystemExit("timed records differ from the oracle: %r" % par)
+        if gathered_ok is False:
+            raise SystemExit("the gathered table differs from the shards")
+        fail_on_parity(par)
 
 
 # ==================================================================================== cfg-1 / 3 / 5
@@ -373,91 +556,219 @@ def run_cfg1(args, json_fd):
     from tests.conftest import read_pgm
     g = os.path.join(ROOT, "tests", "golden")
     i0, i1 = read_pgm(os.path.join(g, "img0.pgm")), read_pgm(os.path.join(g, "img1.pgm"))
+    n = 100
     tc = KLT_TrackingContext()
     tc.max_residue = 10.0
+    p = params_from_tc(tc)
     ctx = Context(0)
     ctx.configure(tc)
     ctx.upload(0, i0)
     ctx.upload(1, i1)
     ctx.build_pyramids_batch([0, 1], sync=True)
-    ctx.select(0, 100, use_pyramid=True)                 # first call allocates the selection scratch
+    ctx.select(0, n, use_pyramid=True)                 # first call allocates the selection scratch
     t = time.perf_counter()
-    fl, _ = ctx.select(0, 100, use_pyramid=True)
+    fl, _ = ctx.select(0, n, use_pyramid=True)
     ms_select = (time.perf_counter() - t) * 1e3
     ctx.featbuf_upload(0, fl)
 
     def step():
         ctx.build_pyramids_batch([0, 1])
-        ctx.track_async(0, 1, 0, 1, 100)
+        ctx.track_async(0, 1, 0, 1, n)
 
-    for _ in range(args.warmup):
+    def region():
+        for _ in range(args.steps):
+            step()
+
+    for _ in range(max(1, args.warmup)):
         step()
+    el, regions, enq = timed_regions(OneGpu([ctx]), region, args.repeats)
+    out = ctx.featbuf_download(1, n)
+    ko = load_oracle()
+    checks = []
+    if ko:
+        ofl = ko.select_good_features(p, i0.astype(np.float32), n)
+        same_sel = bool(np.array_equal(fl["x"], ofl["x"]) and np.array_equal(fl["y"], ofl["y"]) and np.array_equal(fl["val"], ofl["val"]))
+        checks.append(("selection of 100 on img0", same_sel, 0.0))
+        same, dx = records_equal(out, oracle_track(ko, p, i0, i1, fl))
+        checks.append(("100 features tracked img0 -> img1", same, dx))
+    par = parity_summary(checks, "selected list and the tracked records of the last timed step")
+    nst = min(args.steps, 50)
+
+    def plain():
+        for _ in range(nst):
+            step()
+
+    plain()
     ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync()
-    el = time.perf_counter() - t0
-    out = ctx.featbuf_download(1, 100)
+    ctx.track_stats_reset()
+    paired = timed_pass(ctx, plain, 1)
+    st = ctx.track_stats()
+    sane_iterations(st, nst * int((fl["val"] >= 0).sum()), p.nPyramidLevels, "cfg-1")
+    stamped = timed_pass(ctx, plain, 2)
+    ms_step = el / args.steps * 1e3
+    roof = roofline_of(kernel_table(stamped, paired, nst, {"track": track_bytes(p, st, nst * n)}), nst, ms_step)
+    cpu = None
+    if ko and not args.no_cpu_baseline:
+        a0, a1 = i0.astype(np.float32), i1.astype(np.float32)
+        cpu = cpu_baseline_of(ko, lambda: ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), fl.copy()), n,
+                              "pyramids of img0 and img1 + track 100 features (cfg-1)", budget_s=5.0)
     ctx.close()
-    line = base_line(100 * args.steps / el, 1, args.steps, args.warmup, el / args.steps * 1e3, el / args.steps * 1e3,
-                     "cfg-1: img0.pgm -> img1.pgm (320x240), 100 features, 7x7, 2 levels (ss 4), max_residue 10",
+    line = base_line(n * args.steps / el, 1, args.steps, args.warmup, ms_step, ms_step,
+                     "cfg-1: img0.pgm -> img1.pgm (320x240), 100 features, 7x7, 2 levels (ss 4), max_residue 10; per step: pyramids of "
+                     "both frames + track",
                      extra_cfg={"tracked": int((out["val"] >= 0).sum()), "ms_select_100": ms_select})
-    line.update(parity_against(out, oracle_track(params_from_tc(tc), i0, i1, fl)))
+    line.update(par)
+    line["roofline"], line["cpu_baseline"] = roof, cpu
+    line["extra"] = {"region_ms_per_step": region_stats(regions, args.steps, el), "host_enqueue_ms_per_step": enq / args.steps * 1e3}
     emit(json_fd, line)
+    fail_on_parity(par)
 
 
-def run_cfg3(args, json_fd):
-    """BASELINE cfg-3: 1920x1080, 15x15 window, 4 levels / ss 2 (border 108), 5000 features, affine consistency check
-    (mode 2, 15x15 affine window) -- 3-frame sequence; the first call only stores templates, steps time later calls."""
+def cfg3_context():
     tc = KLT_TrackingContext()
     tc.window_width = tc.window_height = 15
     tc.nPyramidLevels, tc.subsampling = 4, 2
     tc.KLTUpdateTCBorder()
     tc.affineConsistencyCheck = 2
-    n = 5000
+    return tc
+
+
+def cfg3_frames(count=4):
+    base = synth.synth_base(WIDTH, HEIGHT, 1)
+    return [synth.synth_frame(WIDTH, HEIGHT, 1, k, shift=(1.1, -0.7), base=base) for k in range(count)]
+
+
+def affine_bytes(ap, recs, live_in):
+    """algorithmic bytes of one affine-check launch: per checked feature the three (w+2)(h+2) templates once, the frame-2 footprint
+    of image / gradx / grady per Newton iteration (klt_affine_rec.pad holds the count), the image footprint of the residue pass, and
+    the records (16 B in, 16 out, 32 state in / out)"""
+    w, h = ap.window_width, ap.window_height
+    it = recs["pad"][live_in].astype(np.int64)
+    checked = int((it > 0).sum())
+    return checked * (12.0 * (w + 2) * (h + 2) + 4.0 * (w + 1) * (h + 1) + 96.0) + 12.0 * (w + 1) * (h + 1) * float(it.sum()), checked, int(it.sum())
+
+
+def run_cfg3(args, json_fd):
+    """BASELINE cfg-3: 1920x1080, 15x15 window, 4 levels / ss 2 (border 108), 5000 features, affine consistency check (mode 2,
+    15x15 affine window) -- a four-frame sequence = three KLTTrackFeatures calls; the first only stores the templates, the steps
+    time the second and the third (state restored to what the first call left before every repetition)."""
+    tc = cfg3_context()
+    p, ap = params_from_tc(tc), affine_params_from_tc(tc)
+    n = NFEAT
     ctx = Context(0)
     ctx.configure(tc)
-    base = synth.synth_base(WIDTH, HEIGHT, 1)
-    frames = [synth.synth_frame(WIDTH, HEIGHT, 1, k, shift=(1.1, -0.7), base=base) for k in range(3)]
+    frames = cfg3_frames(4)
     for k, f in enumerate(frames):
         ctx.upload(k, f)
-    ctx.build_pyramids_batch([0, 1, 2], sync=True)
+    ctx.build_pyramids_batch([0, 1, 2, 3], sync=True)
     fl, placed = ctx.select(0, n, use_pyramid=True)
-    ctx.affine_alloc(0, n)
+    ST, SNAP = 0, 1
+    ctx.affine_alloc(ST, n)
     ctx.featbuf_upload(0, fl)
-    ctx.track_affine_async(0, 1, 0, 1, n, 0)            # stores the templates
+    ctx.track_affine_async(0, 1, 0, 1, n, ST)            # call 1: stores the templates
+    ctx.affine_copy(SNAP, ST, n)                          # the state every repetition starts from (records; templates never change while valid)
     ctx.sync()
-    live1 = int((ctx.featbuf_download(1, n)["val"] >= 0).sum())
+    list1 = ctx.featbuf_download(1, n)
+    live1 = int((list1["val"] >= 0).sum())
 
-    def step():                                          # frame 1 -> frame 2 with the affine check active
-        ctx.build_pyramids_batch([1, 2])
-        ctx.track_affine_async(1, 2, 1, 2, n, 0)
+    def step(k):                                          # call k + 2: frame k+1 -> k+2 with the affine check active
+        ctx.build_pyramids_batch([k + 1, k + 2])
+        ctx.track_affine_async(k + 1, k + 2, k + 1, k + 2, n, ST)
 
-    for _ in range(args.warmup):
-        step()
+    def rep():
+        ctx.affine_copy(ST, SNAP, n)
+        step(0)
+        step(1)
+
+    def region():
+        for _ in range(max(1, args.steps // 2)):
+            rep()
+
+    nsteps = 2 * max(1, args.steps // 2)
+    for _ in range(max(1, args.warmup // 2)):
+        rep()
+    el, regions, enq = timed_regions(OneGpu([ctx]), region, args.repeats)
+    lists = [ctx.featbuf_download(k, n) for k in (2, 3)]
+    recs_end = ctx.affine_download(ST, n)
+    ko = load_oracle()
+    checks = []
+    if ko:
+        ko.set_threads(usable_cores())
+        pyr = [ko.Pyramids(p, f.astype(np.float32)) for f in frames]
+        ofl = ko.select_good_features(p, frames[0].astype(np.float32), n)
+        checks.append(("selection of 5000", bool(np.array_equal(ofl["x"], fl["x"]) and np.array_equal(ofl["y"], fl["y"]) and np.array_equal(ofl["val"], fl["val"])), 0.0))
+        ost = ko.AffineState(ap, n)
+        for call in range(3):
+            ko.track_features_affine(p, pyr[call], pyr[call + 1], ofl, ost)
+            got = list1 if call == 0 else lists[call - 1]
+            same, dx = records_equal(got, ofl)
+            checks.append(("records after call %d" % (call + 1), same, dx))
+        ko.set_threads(1)
+        same_state = all(np.array_equal(recs_end[f], ost.rec[f]) for f in ("valid", "aff_x", "aff_y", "Axx", "Ayx", "Axy", "Ayy"))
+        checks.append(("affine state (valid, aff_x, aff_y, A) after call 3", bool(same_state), 0.0))
+    par = parity_summary(checks, "selection, the records after each of the three calls and the per-feature affine state at the end (parity "
+                         "of the affine check is UNPINNED: the reference does not define it; the oracle restates upstream KLT 1.3.4)")
+    # roofline pass: the two timed calls once more, each launch timed; tracker / affine bytes from the device counters
+    ctx.affine_copy(ST, SNAP, n)
+    rep()
     ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync()
-    el = time.perf_counter() - t0
-    out = ctx.featbuf_download(2, n)
-    ctx.timing_enable(True)
-    for _ in range(min(args.steps, 20)):
-        step()
-    kern = {k["name"]: round(1e3 * k["total_ms"] / k["launches"], 1) for k in ctx.timing_read()}
+
+    def counted(mode):
+        res = {}
+        abytes = checked = its = 0
+        for k in (0, 1):
+            if k == 0:
+                ctx.affine_copy(ST, SNAP, n)
+            ctx.sync()
+            before = ctx.featbuf_download(k + 1, n)
+            r = timed_pass(ctx, lambda: step(k), mode)
+            b, c, i = affine_bytes(ap, ctx.affine_download(ST, n), before["val"] >= 0)
+            abytes, checked, its = abytes + b, checked + c, its + i
+            for name, v in r.items():
+                e = res.setdefault(name, {"name": name, "launches": 0, "total_ms": 0.0, "bytes": 0.0})
+                for f in ("launches", "total_ms", "bytes"):
+                    e[f] += v[f]
+        return res, abytes, checked, its
+
+    ctx.track_stats_reset()
+    paired, abytes, checked, its = counted(1)
+    st = ctx.track_stats()
+    sane_iterations(st, st["features"], p.nPyramidLevels, "cfg-3")
+    stamped, _, _, _ = counted(2)
+    ms_step = el / nsteps * 1e3
+    kt = kernel_table(stamped, paired, 2, {"track": track_bytes(p, st, 2 * n), "affine_check": abytes})
+    roof = roofline_of(kt, 2, ms_step, extra={"affine_checked_features_per_step": checked / 2.0, "affine_iterations_per_checked_feature": its / max(1, checked),
+                                              "newton_iterations_per_level": [v / 2.0 for v in st["iterations"][:p.nPyramidLevels]]})
+    cpu = None
+    if ko and not args.no_cpu_baseline:
+        snap_rec, snap_fl = None, None
+        ost = ko.AffineState(ap, n)
+        ofl = fl.copy()
+        ko.track_features_affine(p, pyr[0], pyr[1], ofl, ost)
+        snap_rec, snap_fl = ost.rec.copy(), ofl.copy()
+        a1, a2 = frames[1].astype(np.float32), frames[2].astype(np.float32)
+
+        def one_step():
+            ost.rec[:] = snap_rec
+            ko.track_features_affine(p, ko.Pyramids(p, a1), ko.Pyramids(p, a2), snap_fl.copy(), ost)
+
+        cpu = cpu_baseline_of(ko, one_step, live1, "pyramids of both frames + track + affine check of the second call of cfg-3 (%d live features)" % live1)
     ctx.close()
-    emit(json_fd, base_line(live1 * args.steps / el, 1, args.steps, args.warmup, el / args.steps * 1e3, el / args.steps * 1e3,
-                            "cfg-3: 1920x1080, %d features placed (%d live), 15x15 window, 4 levels (ss 2), affine consistency "
-                            "check mode 2 (parity unpinned); per step: pyramids of both frames + translation tracker + affine check"
-                            % (placed, live1),
-                            extra_cfg={"tracked_after_affine": int((out["val"] >= 0).sum()), "kernel_us": kern}))
+    line = base_line(live1 * nsteps / el, 1, nsteps, args.warmup, ms_step, ms_step,
+                     "cfg-3: 1920x1080 four-frame sequence, %d features placed (%d live after call 1), 15x15 window, 4 levels (ss 2), affine "
+                     "consistency check mode 2; a step = one KLTTrackFeatures call with the check active (calls 2 and 3 alternate): "
+                     "pyramids of both frames + translation tracker + affine check" % (placed, live1),
+                     extra_cfg={"tracked_after_call_2": int((lists[0]["val"] >= 0).sum()), "tracked_after_call_3": int((lists[1]["val"] >= 0).sum())})
+    line.update(par)
+    line["roofline"], line["cpu_baseline"] = roof, cpu
+    line["extra"] = {"region_ms_per_step": region_stats(regions, nsteps, el), "host_enqueue_ms_per_step": enq / nsteps * 1e3}
+    emit(json_fd, line)
+    fail_on_parity(par)
 
 
 def run_cfg5(args, json_fd):
     """BASELINE cfg-5 (single GPU): 3840x2160 sequence, 20000 features, sequential mode, lost features replaced after every
-    frame.  Per step: upload is excluded (frames resident), pyramid of the new frame, track, REPLACING_SOME selection."""
+    frame.  Per step (= frame): upload is excluded (frames resident), pyramid of the new frame, track, REPLACING_SOME selection."""
     ranks = Ranks(args)
     if ranks.distributed:
         return run_cfg5_blocks(args, json_fd, ranks)
@@ -465,11 +776,13 @@ def run_cfg5(args, json_fd):
     nframes = 8
     tc = cfg2_context()
     tc.max_residue = 10.0
+    p = params_from_tc(tc)
     ctx = Context(0)
     ctx.configure(tc)
     base = synth.synth_base(w, h, 4)
+    frames = [synth.synth_frame(w, h, 4, k, base=base) for k in range(nframes)]
     for k in range(nframes):
-        ctx.upload(10 + k, synth.synth_frame(w, h, 4, k, base=base))
+        ctx.upload(10 + k, frames[k])
     ctx.build_pyramids(10)
     fl, placed = ctx.select(10, n, use_pyramid=True)
     ctx.featbuf_upload(0, fl)
@@ -482,10 +795,8 @@ def run_cfg5(args, json_fd):
     if prefetch:
         ctx.set_option(15, 1)
 
-    lost = []
-
-    def run_sequence(timed):
-        t_sel = 0.0
+    def run_sequence(look=None):
+        """one pass over the sequence; `look(k)` (instrumented passes) is called after frame k's replacement, synchronised"""
         if prefetch:
             ctx.build_pyramids(10 + 1, sync=False)
             if prepare:
@@ -494,45 +805,100 @@ def run_cfg5(args, json_fd):
             if not prefetch:
                 ctx.build_pyramids(10 + k, sync=False)
             ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)      # the chain first: the build stream waits for nothing on this one
-            if prefetch and not timed:
-                ctx.select_begin(10 + k, 2, True, k % 2, n)   # ... KLTReplaceLostFeatures on the resident level-0 images, up to the host's look
+            ctx.select_begin(10 + k, 2, True, k % 2, n)      # ... KLTReplaceLostFeatures on the resident level-0 images, up to the host's look
             if prefetch and k + 1 < nframes:
                 ctx.build_pyramids(10 + k + 1, sync=False)
                 if prepare:
                     ctx.select_prepare(10 + k + 1)        # SAT + eigenvalues of the next frame, behind its build on the build stream
-            if prefetch and not timed:
-                ctx.select_finish()
-                continue
-            if timed:
-                lost.append(int((ctx.featbuf_download(k % 2, n)["val"] < 0).sum()))      # (synchronises)
-                t = time.perf_counter()
-            ctx.select_async(10 + k, 2, True, k % 2, n)       # KLTReplaceLostFeatures on the resident level-0 images
-            if timed:
+            ctx.select_finish()
+            if look:
                 ctx.sync()
-                t_sel += time.perf_counter() - t
+                look(k)
         ctx.sync()
-        return t_sel
 
+    def region():
+        for _ in range(max(1, args.steps // (nframes - 1))):
+            ctx.featbuf_upload(0, fl)
+            run_sequence()
+
+    frames_per_region = max(1, args.steps // (nframes - 1)) * (nframes - 1)
     ctx.featbuf_upload(0, fl)
-    run_sequence(False)
-    reps = max(1, args.steps // (nframes - 1))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ctx.featbuf_upload(0, fl)
-        run_sequence(False)
-    el = time.perf_counter() - t0
-    ctx.featbuf_upload(0, fl)
-    t_sel = run_sequence(True)
+    run_sequence()
+    el, regions, enq = timed_regions(OneGpu([ctx]), region, max(5, min(args.repeats, 10)))
     out = ctx.featbuf_download((nframes - 1) % 2, n)
-    frames_done = reps * (nframes - 1)
+
+    # instrumented pass 1: the list after every frame (parity) and how long the replacement alone takes
+    lists = {}
+    ctx.featbuf_upload(0, fl)
+    run_sequence(look=lambda k: lists.__setitem__(k, ctx.featbuf_download(k % 2, n)))
+    same_end = bool(np.array_equal(lists[nframes - 1], out))
+    t_sel, lost = 0.0, []
+    ctx.featbuf_upload(0, fl)
+    for k in range(1, nframes):                              # (plain loop: tracker, look at the losses, replacement timed on its own)
+        ctx.build_pyramids(10 + k, sync=False)
+        ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)
+        lost.append(int((ctx.featbuf_download(k % 2, n)["val"] < 0).sum()))
+        t = time.perf_counter()
+        ctx.select_async(10 + k, 2, True, k % 2, n)
+        ctx.sync()
+        t_sel += time.perf_counter() - t
+    ko = load_oracle()
+    checks = [("the timed passes end with the list of the instrumented pass", same_end, 0.0)]
+    PAR_FRAMES = 3
+    if ko:
+        ko.set_threads(usable_cores())
+        ofl = ko.select_good_features(p, frames[0].astype(np.float32), n)
+        checks.append(("selection of 20000 on frame 0", bool(np.array_equal(ofl["x"], fl["x"]) and np.array_equal(ofl["y"], fl["y"]) and np.array_equal(ofl["val"], fl["val"])), 0.0))
+        P_prev = ko.Pyramids(p, frames[0].astype(np.float32))
+        for k in range(1, PAR_FRAMES + 1):
+            P_cur = ko.Pyramids(p, frames[k].astype(np.float32))
+            ko.track_features(p, P_prev, P_cur, ofl)
+            ofl = ko.select_good_features(p, frames[k].astype(np.float32), n, mode=2, fl=ofl)
+            same, dx = records_equal(lists[k], ofl)
+            checks.append(("list after tracking into frame %d and replacing the lost features" % k, same, dx))
+            P_prev = P_cur
+        ko.set_threads(1)
+    par = parity_summary(checks, "initial selection and the whole feature list (tracked and replaced records) after each of the first %d frames; "
+                         "the wrapper KLTReplaceLostFeatures is absent from the reference (pinned at the level of _enforceMinimumDistance)" % PAR_FRAMES)
+
+    # instrumented pass 2: every launch timed (one stream order per stream; the build stream's launches carry their own timestamps)
+    def seq():
+        ctx.featbuf_upload(0, fl)
+        run_sequence()
+
+    seq()
+    ctx.track_stats_reset()
+    paired = timed_pass(ctx, seq, 1)
+    st = ctx.track_stats()
+    sane_iterations(st, st["features"], p.nPyramidLevels, "cfg-5")
+    stamped = timed_pass(ctx, seq, 2)
+    ms_step = el / frames_per_region * 1e3
+    kt = kernel_table(stamped, paired, nframes - 1, {"track": track_bytes(p, st, (nframes - 1) * n)})
+    roof = roofline_of(kt, nframes - 1, ms_step, extra={"newton_iterations_per_level": [v / (nframes - 1.0) for v in st["iterations"][:p.nPyramidLevels]]})
+    cpu = None
+    if ko and not args.no_cpu_baseline:
+        a0, a1 = frames[0].astype(np.float32), frames[1].astype(np.float32)
+        P0 = ko.Pyramids(p, a0)
+
+        def one_frame():
+            o = fl.copy()
+            ko.track_features(p, P0, ko.Pyramids(p, a1), o)
+            ko.select_good_features(p, a1, n, mode=2, fl=o)
+
+        cpu = cpu_baseline_of(ko, one_frame, n, "pyramid of the new 3840x2160 frame + track 20000 features + replacement selection (one frame of cfg-5)", budget_s=8.0)
     ctx.close()
-    emit(json_fd, base_line(n * frames_done / el, 1, frames_done, 0, el / frames_done * 1e3, el / frames_done * 1e3,
-                            "cfg-5 (one GPU): 3840x2160 sequence, 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost "
-                            "features replaced after every frame; per frame: pyramid of the new frame + track + replacement"
-                            + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else "")
-                            + (", and so are its summed-area tables and eigenvalues (klt_select_prepare_async)" if prepare else ""),
-                            extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
-                                       "lost_per_frame": lost, "build_stream": bool(prefetch), "scores_prepared": bool(prepare)}))
+    line = base_line(n * frames_per_region / el, 1, frames_per_region, 0, ms_step, ms_step,
+                     "cfg-5 (one GPU): 3840x2160 sequence, 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost "
+                     "features replaced after every frame; per step (frame): pyramid of the new frame + track + replacement"
+                     + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else "")
+                     + (", and so are its summed-area tables and eigenvalues (klt_select_prepare_async)" if prepare else ""),
+                     extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
+                                "lost_per_frame": lost, "build_stream": bool(prefetch), "scores_prepared": bool(prepare)})
+    line.update(par)
+    line["roofline"], line["cpu_baseline"] = roof, cpu
+    line["extra"] = {"region_ms_per_step": region_stats(regions, frames_per_region, el), "host_enqueue_ms_per_step": enq / frames_per_region * 1e3}
+    emit(json_fd, line)
+    fail_on_parity(par)
 
 
 def run_cfg5_blocks(args, json_fd, ranks):
@@ -586,7 +952,7 @@ def run_cfg5_blocks(args, json_fd, ranks):
     # a timed region is ONE pass of the sequence over the ranks (a second pass inside the region would let rank 0 start it while the
     # others still work on the first: N pipelined replicas, not one sequence)
     reps = 1
-    el, regions, enq = timed_regions(ranks, block, B * world, max(5, min(args.repeats, 15)))
+    el, regions, enq = timed_regions(ranks, block, max(5, min(args.repeats, 15)))
     # the list after the last frame of every block, gathered on rank 0 (rank order = frame order)
     ctx.gather_featbuf_async(last, FB_ALL, n, 0)
     ctx.comm_wait()
@@ -635,40 +1001,406 @@ def dry_run(args, json_fd):
                 time.sleep(0.01)
     emit(json_fd, {"dryrun": True, "n_gpus": world, "ids_agree": all(s["digest"] == digest for s in seen),
                    "pairs_covered": sorted(i for s in seen for i in s["pairs"]) == list(range(args.pairs)),
+                   "gatherv_counts": [len(s["pairs"]) for s in seen],
                    "local_ranks": [s["local_rank"] for s in seen], "spawned": os.environ.get("KLT_SPAWNED") == "1"})
+
+
+# ================================================================================= cfg-2 (headline)
+T_OUT0, T_OUT1, T_GATH0, T_GATH1, FB_IN0, V_OUT0, FB_MISC = 10, 11, 20, 21, 1000, 3000, 90
+
+
+def run_cfg2(args, json_fd):
+    ranks = Ranks(args)
+    rank, world, distributed = ranks.rank, ranks.world, ranks.distributed
+    tc = cfg2_context()
+    p = params_from_tc(tc)
+    nctx, B, NP = max(1, args.inflight), max(1, args.batch), args.resident_pairs
+    if NP < nctx * B or NP % (nctx * B):
+        raise SystemExit("--resident-pairs must be a positive multiple of --inflight x --batch")
+    PL = NP // nctx                              # pairs per context
+    NG = PL // B                                 # groups (launch sets) per context and step
+    seeds = [rank * NP + i + 1 for i in range(NP)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, usable_cores(16) // max(1, min(world, 8)))) as ex:
+        frames = list(ex.map(lambda s: synth.synth_pair(WIDTH, HEIGHT, seed=s), seeds))
+
+    # pair i: group i // B of the step; groups go round-robin to the contexts.  Context c, its j-th group, pair b of the group:
+    # local pair index lp = j B + b, frame slots 2 lp and 2 lp + 1, input list FB_IN0 + lp, output row lp of the step's table
+    def pair_index(c, lp):
+        j, b = divmod(lp, B)
+        return (j * nctx + c) * B + b
+
+    ctxs, lists = [], {}
+    for c in range(nctx):
+        cx = Context(ranks.local_rank)
+        cx.set_params(p)
+        for lp in range(PL):
+            f0, f1 = frames[pair_index(c, lp)]
+            cx.upload(2 * lp, f0)
+            cx.upload(2 * lp + 1, f1)
+        for t in (T_OUT0, T_OUT1):
+            cx.featbuf_alloc(t, PL * NFEAT)
+        for t in (0, 1):
+            for lp in range(PL):
+                cx.featbuf_view(V_OUT0 + t * PL + lp, (T_OUT0, T_OUT1)[t], lp * NFEAT, NFEAT)
+        for lp in range(PL):
+            cx.build_pyramids(2 * lp, sync=False)
+            fl_c, placed = cx.select(2 * lp, NFEAT, use_pyramid=True)
+            assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)
+            lists[pair_index(c, lp)] = fl_c
+            cx.featbuf_upload(FB_IN0 + lp, fl_c)
+        ctxs.append(cx)
+    ctx = ctxs[0]
+    ranks.attach(ctxs)
+
+    def group_slots(j, nb=B):
+        return [2 * (j * B + b) + f for b in range(nb) for f in (0, 1)]
+
+    def group_build(cx, j):
+        cx.build_pyramids_batch(group_slots(j))                  # all frames of the group share every launch
+
+    def group_track(cx, j, t):
+        if B == 1:
+            cx.track_async(2 * j, 2 * j + 1, FB_IN0 + j, V_OUT0 + t * PL + j, NFEAT)
+        else:
+            cx.track_batch_async([(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + t * PL + lp) for lp in range(j * B, j * B + B)], NFEAT)
+
+    step_no = [0]
+
+    def one_step():
+        """one pass over the resident pairs.  The groups go out in rounds of one group per context, the builds of a round before its
+        tracker launches: every stream has work a few microseconds after the step starts (enqueueing a group takes the host ~25 us);
+        the order inside each stream, and the work, are the same either way.  N > 1: the step's record table of every context is
+        all-gathered with ONE collective behind its last tracker launch; two tables alternate, a table is reused once its collective
+        of two steps ago has read it."""
+        t = step_no[0] % 2
+        step_no[0] += 1
+        if distributed:
+            for cx in ctxs:
+                cx.comm_fence_featbuf((T_OUT0, T_OUT1)[t])
+        for j in range(NG):
+            for cx in ctxs:
+                group_build(cx, j)
+            for cx in ctxs:
+                group_track(cx, j, t)
+        if distributed:
+            for cx in ctxs:
+                cx.allgather_featbuf_async((T_OUT0, T_OUT1)[t], (T_GATH0, T_GATH1)[t], PL * NFEAT)
+        return t
+
+    # bring the GPU to its steady state first (the same work as the steps)
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        one_step()
+        for cx in ctxs:
+            cx.sync()
+    for _ in range(args.warmup):
+        one_step()
+
+    def region():
+        for _ in range(args.steps):
+            one_step()
+
+    elapsed, regions, enqueue_s = timed_regions(ranks, region, args.repeats)
+    t_last = (step_no[0] - 1) % 2
+
+    # correctness of what was timed: the last step's records of EVERY resident pair (and, N > 1, what the gather delivered of them)
+    outs = {}
+    for c, cx in enumerate(ctxs):
+        tab = cx.featbuf_download((T_OUT0, T_OUT1)[t_last], PL * NFEAT).reshape(PL, NFEAT)
+        for lp in range(PL):
+            outs[pair_index(c, lp)] = tab[lp]
+        if distributed:                 # what this rank received from itself equals what it produced
+            got = cx.featbuf_download((T_GATH0, T_GATH1)[t_last], world * PL * NFEAT).reshape(world, PL, NFEAT)
+            assert np.array_equal(got[rank], tab), "gathered records differ"
+    out, fl = outs[0], lists[0]
+    tracked = int(np.count_nonzero(out["val"] >= 0))
+    live = out["val"] == 0
+    shift = (float(np.median(out["x"][live] - fl["x"][live])), float(np.median(out["y"][live] - fl["y"][live])))
+    ko = load_oracle() if rank == 0 else None
+    parity = {}
+    if rank == 0:
+        checks = []
+        if ko:
+            nthreads = usable_cores()
+            for i in range(NP):
+                same, dx = records_equal(outs[i], oracle_track(ko, p, frames[i][0], frames[i][1], lists[i], threads=nthreads))
+                checks.append(("pair %d (seed %d)" % (i, seeds[i]), same, dx))
+        parity = parity_summary(checks, "tracked records of all %d resident pairs, last timed step" % NP)
+
+    # second pass: per-kernel timing + iteration counters for the roofline, on context 0 over its own pairs
+    roofline = None
+    ms_per_pair = elapsed / (args.steps * NP) * 1e3
+    if rank == 0:
+        passes = max(1, min(args.steps, 4))
+
+        def ctx0_passes(n=passes):
+            for _ in range(n):
+                for j in range(NG):
+                    group_build(ctx, j)
+                    group_track(ctx, j, 0)
+
+        def warm():
+            """at the clocks the timed regions ran at: the parity check and the downloads above left the GPU idle"""
+            t_warm = time.perf_counter()
+            while (time.perf_counter() - t_warm) * 1e3 < min(args.prewarm_ms, 30.0):
+                ctx0_passes(1)
+                ctx.sync()
+
+        warm()
+        ctx.track_stats_reset()                        # AFTER the warm-up: the counters cover exactly the launches they are divided by
+        paired = timed_pass(ctx, ctx0_passes, 1)
+        st = ctx.track_stats()
+        npairs_roof = passes * PL
+        sane_iterations(st, npairs_roof * NFEAT, p.nPyramidLevels, "cfg-2")
+        warm()
+        stamped = timed_pass(ctx, ctx0_passes, 2)
+        kt = kernel_table(stamped, paired, npairs_roof, {"track": track_bytes(p, st, npairs_roof * NFEAT)})
+        st_pair = {k: ([x / npairs_roof for x in v] if isinstance(v, list) else v / npairs_roof) for k, v in st.items()}
+        pyr_b, trk_b = algorithmic_bytes(p, WIDTH, HEIGHT, st_pair, NFEAT)
+        dom = "smooth_grad_l0"
+        # PMC-derived figures are NOT measured by this run: committed results of the builder's rocprofv3 --pmc passes, with their
+        # provenance, dropped when the kernel source changed since (committed_counters)
+        traffic, traffic_source = committed_counters("traffic.json", dom, B)
+        # the same kernel against the roof that actually bounds it: VALU issue.  Wavefront-instructions per launch come from a
+        # rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/sq_counters.json, tools/pmc_sq.py); 4.5 clocks per instruction and SIMD
+        # is what the FP64-rate instruction mix of the convolutions sustains on gfx950 (tools/mb/valu_rate.hip, fp64_mix.hip).
+        issue = None
+        sq, sq_source = committed_counters("sq_counters.json", dom, B)
+        if sq and sq.get("SQ_INSTS_VALU"):
+            simds, cpi, mhz = 256 * 4, 4.5, 2400.0
+            ideal_us = sq["SQ_INSTS_VALU"] / simds * cpi / mhz
+            issue = {"valu_wavefront_instructions_per_launch": sq["SQ_INSTS_VALU"], "simds": simds, "clocks_per_instruction": cpi,
+                     "clock_mhz": mhz, "ideal_us": ideal_us, "frac": ideal_us / kt[dom]["us_per_launch"], "source": sq_source}
+        elif sq_source:
+            issue = {"source": sq_source}
+        npx = WIDTH * HEIGHT * 2 * B
+        moved = npx * (1 + 4 + 12) + npx // p.subsampling * 4      # what crosses L2: u8 in, image + two gradients + the H1 plane out
+        roofline = roofline_of(kt, npairs_roof, ms_per_pair, dominant=dom, extra={
+            "traffic": traffic, "traffic_source": traffic_source, "issue_bound": issue, "pairs_per_launch": B,
+            "frac_note": "frac books SURVEY 8(d)'s 21 B per pixel (17 for smoothing + gradients, 4 for the first reduction's input, which this "
+                         "kernel consumes from LDS); frac_moved books the 18 B per pixel that actually cross the L2 (4 of the 21 never leave LDS, "
+                         "the H1 plane adds 1)",
+            "moved_bytes_per_launch": moved, "achieved_moved": moved / (kt[dom]["us_per_launch"] * 1e-6) / 1e9,
+            "frac_moved": moved / (kt[dom]["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "step_unit": "one frame pair", "step_algorithmic_bytes_formula": 2 * pyr_b + trk_b,
+            "newton_iterations_per_level": st_pair["iterations"][:p.nPyramidLevels]})
+
+    # secondary figures (never `value`): selection time, the one-stream figure, the cache-resident figure and the PCIe-inclusive pair time
+    extra = None
+    ms_single = None
+    reg = region_stats(regions, args.steps, elapsed)
+    if rank == 0 and args.no_extras:
+        extra = {"region_ms_per_step": reg, "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "note": "--no-extras: secondary figures skipped"}
+    elif rank == 0:
+        reps = 10
+        ctx.sync()
+        t = time.perf_counter()
+        for k in range(reps):
+            ctx.select_async(2 * (k % PL), 1, True, FB_MISC, NFEAT)      # SELECTING_ALL on a resident level-0 pyramid
+        ctx.sync()
+        ms_select = (time.perf_counter() - t) / reps * 1e3
+        singles = []
+        for _ in range(5):
+            t = time.perf_counter()
+            for i in range(4 * PL):                              # ONE stream, one pair in flight, rotating through the context's pairs
+                lp = i % PL
+                ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
+                ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp, NFEAT)
+            ctx.sync()
+            singles.append((time.perf_counter() - t) / (4 * PL) * 1e3)
+        ms_single = statistics.median(singles)
+        # round 2's headline arrangement: every context rebuilds the SAME two pairs (four slots) over and over, so the pyramid planes
+        # the tracker reads are still in the Infinity Cache
+        nrep = 8 * NG
+        hots = []
+        for _ in range(5):
+            for cx in ctxs:
+                cx.sync()
+            t = time.perf_counter()
+            for _ in range(nrep):
+                for cx in ctxs:
+                    group_build(cx, 0)
+                for cx in ctxs:
+                    group_track(cx, 0, 0)
+            for cx in ctxs:
+                cx.sync()
+            hots.append((time.perf_counter() - t) / (nrep * nctx * B) * 1e3)
+        ms_hot = statistics.median(hots)
+        t = time.perf_counter()
+        for k in range(reps):                                  # un-pipelined latency of one pair
+            lp = k % PL
+            ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
+            ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp, NFEAT)
+            ctx.sync()
+        ms_latency = (time.perf_counter() - t) / reps * 1e3
+        t = time.perf_counter()
+        for k in range(reps):
+            lp = k % PL
+            f0, f1 = frames[pair_index(0, lp)]
+            ctx.upload(2 * lp, f0)
+            ctx.upload(2 * lp + 1, f1)
+            ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
+            ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp, NFEAT)
+            ctx.featbuf_download(V_OUT0 + lp, NFEAT)
+        ms_pcie = (time.perf_counter() - t) / reps * 1e3
+        # pipelined ingest: frames already sit in pinned host memory (as a decoder would leave them), uploads run on the
+        # copy stream and overlap the previous pair's kernels; records go to a device table read back every 16 pairs
+        NPIN = min(PL, 4)
+        pins = []
+        for lp in range(NPIN):
+            a, b = ctx.pinned_array((HEIGHT, WIDTH)), ctx.pinned_array((HEIGHT, WIDTH))
+            a[:], b[:] = frames[pair_index(0, lp)]
+            pins.append((a, b))
+        TAB, NT = FB_MISC + 1, 16
+        ctx.featbuf_alloc(TAB, NT * NFEAT)
+        for k in range(NT):
+            ctx.featbuf_view(TAB + 1 + k, TAB, k * NFEAT, NFEAT)
+        npipe = 8 * NT
+
+        def pipelined_step(i):
+            lp = i % NPIN
+            ctx.upload_async(2 * lp, pins[lp][0])
+            ctx.upload_async(2 * lp + 1, pins[lp][1])
+            ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
+            ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, TAB + 1 + i % NT, NFEAT)
+            return ctx.featbuf_download(TAB, NT * NFEAT) if i % NT == NT - 1 else None
+
+        for i in range(NT):                 # warm-up: the alternate raw buffers are allocated on first use
+            table = pipelined_step(i)
+        ctx.sync()
+        t = time.perf_counter()
+        for i in range(npipe):
+            got = pipelined_step(i)
+            table = got if got is not None else table
+        ctx.sync()
+        ms_pipe = (time.perf_counter() - t) / npipe * 1e3
+        last_lp = (npipe - 1) % NPIN
+        assert np.array_equal(table[-NFEAT:]["x"], outs[pair_index(0, last_lp)]["x"]), "pipelined ingest changed the result"
+        extra = {"region_ms_per_step": reg,
+                 "overlapped_ms_per_pair": ms_per_pair,
+                 "cache_resident_ms_per_pair": ms_hot, "cache_resident_features_per_s": NFEAT / (ms_hot * 1e-3),
+                 "pcie_pipelined_ms_per_pair": ms_pipe, "pcie_pipelined_features_per_s": NFEAT / (ms_pipe * 1e-3),
+                 "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "latency_ms_per_pair_synchronised": ms_latency,
+                 "single_stream_ms_per_pair": ms_single, "single_stream_features_per_s": NFEAT / (ms_single * 1e-3),
+                 "single_stream_runs_ms": singles,
+                 "ms_per_select_5000": ms_select,
+                 "pcie_inclusive_ms_per_pair": ms_pcie, "pcie_inclusive_features_per_s": NFEAT / (ms_pcie * 1e-3),
+                 "note": "ms_per_frame_pair = single_stream_ms_per_pair: one pair at a time on ONE stream, rotating through the resident "
+                         "pairs, no overlap with other pairs (ms_per_step / pairs_per_step = overlapped_ms_per_pair is the inverse "
+                         "throughput with pairs_in_flight pairs overlapping).  cache_resident = round 2's headline arrangement: every "
+                         "context rebuilds the same four frame slots, which then never leave the 256 MB Infinity Cache.  pcie_inclusive "
+                         "= H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the records, synchronised per "
+                         "pair; pcie_pipelined = the same bytes with klt_upload_u8_async from pinned memory on a copy stream and the "
+                         "records read back every 16 pairs"}
+        if not args.no_api:
+            extra.update(api_figures(frames[0], tc))
+
+    cpu = None
+    if rank == 0 and not distributed and not args.no_cpu_baseline and ko:
+        a0, a1 = frames[0][0].astype(np.float32), frames[0][1].astype(np.float32)
+        cpu = cpu_baseline_of(ko, lambda: ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), lists[0].copy()), NFEAT,
+                              "pyramids of both frames + track 5000 features of ONE pair of cfg-2 (1920x1080, seed %d)" % seeds[0])
+        if cpu:
+            cpu["ms_per_pair"] = cpu["ms_per_step"]
+
+    line = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        line = base_line(world * NP * NFEAT * args.steps / elapsed, world, args.steps, args.warmup, ms_per_step,
+                         ms_single if ms_single is not None else ms_per_pair,
+                         "cfg-2: %d DISTINCT 1920x1080 synthetic pairs resident per GPU (seeds %d..%d; own frame slots, pyramids and "
+                         "feature lists: %.1f GB), 5000 features each, 7x7 window, 3 pyramid levels (subsampling 4), translation only; "
+                         "a step = one pass of pyramid build + tracking over all of them (%d KLTTrackFeatures-equivalents); inputs "
+                         "resident in HBM, no frame or pyramid is touched twice within a step"
+                         % (NP, seeds[0], seeds[-1], NP * 2 * (WIDTH * HEIGHT + 4 * 3 * sum(level_pixels(p, WIDTH, HEIGHT))) / 1e9, NP),
+                         extra_cfg={
+                             "pipelining": (("none (one HIP stream)" if nctx == 1 else
+                                             "groups of pairs go round-robin to %d contexts, one HIP stream each, no ordering between them "
+                                             "(pairs are independent)" % nctx) +
+                                            ("; every pair has its own launches" if B == 1 else
+                                             "; the %d pairs of a group share every launch of their context: one batched pyramid "
+                                             "build for their %d frames, one tracker launch for their %d feature lists -- every pair still "
+                                             "gets the full work of one KLTTrackFeatures call" % (B, 2 * B, B))),
+                             "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "resident_pairs": NP,
+                             "features_per_pair": NFEAT, "pairs_per_step": NP * world, "ms_per_pair": ms_per_pair, "tracked": tracked,
+                             "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
+                             "rccl_ranks": world if distributed else 0,
+                             "parallelism": "%d pairs per GPU" % NP + (", one RCCL all-gather (libkltgpu side stream) of each context's [%d pairs x "
+                                                                      "5000] record table per step" % PL if distributed else "")})
+        line.update(parity)
+        line["roofline"], line["cpu_baseline"], line["extra"] = roofline, cpu, extra
+    for cx in ctxs:
+        cx.close()
+    if line is not None:
+        emit(json_fd, line)
+        fail_on_parity(parity)
+
+
+def api_figures(pair, tc):
+    """What a caller of the reference-shaped Python API sees (KLTSelectGoodFeatures / KLTTrackFeatures on PIL-like arrays, uploads
+    and the download of the list included): ms per call at cfg-2's size, on the package's default context."""
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import trackFeatures as trk
+    v0 = sgf.KLT_verbose
+    sgf.KLT_verbose = trk.KLT_verbose = 0
+    try:
+        f0, f1 = pair
+        t_sel, t_trk, t_pp = [], [], []
+        fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
+        trk.KLTTrackFeatures(tc, f0, f1, fl)
+        for _ in range(10):
+            t = time.perf_counter()
+            fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
+            t_sel.append(time.perf_counter() - t)
+            t = time.perf_counter()
+            trk.KLTTrackFeatures(tc, f0, f1, fl)
+            t_trk.append(time.perf_counter() - t)
+        # example1's ping-pong (example1.py:53-56): the same two images, back and forth
+        fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
+        for k in range(20):
+            a, b = (f0, f1) if k % 2 == 0 else (f1, f0)
+            t = time.perf_counter()
+            trk.KLTTrackFeatures(tc, a, b, fl)
+            t_pp.append(time.perf_counter() - t)
+        return {"api_ms_per_KLTSelectGoodFeatures": statistics.median(t_sel) * 1e3, "api_ms_per_KLTTrackFeatures": statistics.median(t_trk) * 1e3,
+                "api_ms_per_KLTTrackFeatures_pingpong": statistics.median(t_pp) * 1e3,
+                "api_note": "reference-shaped Python API on numpy u8 frames of cfg-2's size, 5000 features; host-to-device copies and the "
+                            "download of the list are inside the figures"}
+    finally:
+        sgf.KLT_verbose = trk.KLT_verbose = v0
 
 
 # ============================================================================================ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=25,
-                    help="how many times the K-step timed region is run (median reported; fewer, never below 5, when a region is long)")
+                    help="the K-step timed region is run at least this often AND until 2 s of timed work are in (median reported; "
+                         "fewer, never below 5, when a region is long)")
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed hot-path work before the W warm-up steps: the GPU needs ~10 ms of load to reach its steady clocks / "
-                         "cache state (a 200-step run right after start-up measures 50 us per pair, the same loop after 50 ms 43 us)")
+                         "cache state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the secondary figures (selection, one pair at a time, PCIe-inclusive): a profiler then sees only the launches "
-                         "of the timed regions and of the roofline pass, all of the headline's size")
+                    help="skip the secondary figures (selection, one pair at a time, PCIe-inclusive, Python API): a profiler then sees only "
+                         "the launches of the timed regions and of the roofline pass, all of the headline's size")
+    ap.add_argument("--no-api", action="store_true", help="skip the reference-shaped Python API figures in `extra`")
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 (default, the headline line); cfg4 = the 256-pair batch sharded over --gpus ranks; the others are "
-                         "the remaining BASELINE configs on one GPU, informative")
+                         "the remaining BASELINE configs on one GPU")
     ap.add_argument("--pairs", type=int, default=256, help="total pairs per step for --config cfg4 (sharded over the ranks)")
+    ap.add_argument("--resident-pairs", type=int, default=64,
+                    help="cfg2: distinct synthetic pairs resident per GPU, all of them processed by every step (64 pairs = 3.7 GB of frames "
+                         "and pyramids: a step's working set is 14x the 256 MB Infinity Cache)")
     ap.add_argument("--inflight", type=int, default=2,
-                    help="contexts per GPU (one HIP stream each, no events between them): consecutive groups of --batch steps go "
+                    help="contexts per GPU (one HIP stream each, no events between them): consecutive groups of --batch pairs go "
                          "round-robin to them, so kernels of different groups overlap; 1 = a single stream")
-    ap.add_argument("--slot-sets", type=int, default=1, choices=[1, 2],
-                    help="1 (default): a context rebuilds the same slots every group, as a caller with a fixed ring of frame slots does -- the "
-                         "pyramids the tracker reads are the ones just written and come out of the 256 MB Infinity Cache; 2: alternate groups "
-                         "use two sets of slots (the working set of 2 contexts x 2 pairs is then 430 MB and every tracker read goes to HBM; "
-                         "the lines up to round-2 set m were measured this way)")
     ap.add_argument("--batch", type=int, default=2, choices=[1, 2, 4, 8],
-                    help="steps (independent pairs) that share every launch of a context: one batched pyramid build for their frames "
-                         "and one tracker launch for their feature lists (2 contexts x 2 pairs: 0.0333 ms per pair where 3 x 1 reads "
-                         "0.0377, 3 x 2 0.0358, 2 x 4 0.0359: tools/stream_batch_probe.py)")
+                    help="pairs that share every launch of a context: one batched pyramid build for their frames and one tracker launch "
+                         "for their feature lists")
     args = ap.parse_args()
 
     # N > 1 without a launcher: start the ranks ourselves.  Nothing above or below this point has touched the GPU yet
@@ -684,352 +1416,7 @@ def main():
 
     if os.environ.get("KLT_BENCH_DRYRUN") == "1":
         return dry_run(args, json_fd)
-    if args.config != "cfg2":
-        return {"cfg1": run_cfg1, "cfg3": run_cfg3, "cfg4": run_cfg4, "cfg5": run_cfg5}[args.config](args, json_fd)
-
-    ranks = Ranks(args)
-    rank, world, distributed = ranks.rank, ranks.world, ranks.distributed
-    tc = cfg2_context()
-    p = params_from_tc(tc)
-    f0, f1 = synth.synth_pair(WIDTH, HEIGHT, seed=rank + 1)
-    # `--inflight` contexts per GPU, each with its own HIP stream, slots and feature buffers.  Step i runs on context
-    # i % inflight: pairs are independent (the path shards by frame pair), so nothing orders the streams against each other
-    # and the GPU overlaps the kernels of different pairs -- the drain / ramp between dependent kernels of one pair and the
-    # latency-bound tracker are filled with the next pair's convolutions.
-    nctx = max(1, args.inflight)
-    B = max(1, args.batch)
-    NSETS = args.slot_sets
-
-    def slots_of(j, nb=None):
-        """frame slots of a context's j-th group: pair b of set t lives in slots 2 (t B + b), + 1"""
-        t = j % NSETS
-        return [2 * (t * B + b) + f for b in range(B if nb is None else nb) for f in (0, 1)]
-
-    def pairs_of(j, outs, nb=None):
-        sl = slots_of(j, nb)
-        return [(sl[2 * b], sl[2 * b + 1], FB_SEL, outs[b]) for b in range(len(sl) // 2)]
-
-    def plain_out(t, b):
-        """output buffer of pair b of set t (one GPU): the two of pair 0 are FB_OUT0 / FB_OUT1"""
-        return (FB_OUT0, FB_OUT1)[t] if b == 0 else 10 + 2 * b + t
-
-    ctxs = []
-    fl = None
-    for c in range(nctx):
-        cx = Context(ranks.local_rank)
-        cx.set_params(p)
-        for s0 in range(0, max(4, 2 * NSETS * B), 2):
-            cx.upload(s0, f0)
-            cx.upload(s0 + 1, f1)
-        cx.build_pyramids(0)
-        fl_c, placed = cx.select(0, NFEAT, use_pyramid=True)
-        assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)
-        assert fl is None or np.array_equal(fl, fl_c), "contexts selected different features"
-        fl = fl_c
-        cx.featbuf_upload(FB_SEL, fl)
-        for t in (0, 1):
-            for b in range(B):
-                cx.featbuf_upload(plain_out(t, b), fl)
-        # N > 1: the records of GATHER_EVERY consecutive steps of a context land in one device-side [steps x features] table
-        # (two tables, used alternately) and each full table is all-gathered with ONE RCCL collective on the library's side
-        # stream -- cfg-4's "gather once per shard", and the host cost of a collective is not paid per step.
-        if distributed:
-            for t, ring in enumerate((FB_RING0, FB_RING1)):
-                cx.featbuf_alloc(ring, GATHER_EVERY * NFEAT)
-                for k in range(GATHER_EVERY):
-                    cx.featbuf_view(FB_VIEW0 + t * GATHER_EVERY + k, ring, k * NFEAT, NFEAT)
-        ctxs.append(cx)
-    ctx = ctxs[0]
-    ranks.attach(ctxs)
-
-    def out_buffer(lj):
-        """feature buffer that the lj-th pair of a context writes (lj = group * B + pair)"""
-        if not distributed:
-            return plain_out((lj // B) % 2, lj % B)
-        return FB_VIEW0 + ((lj // GATHER_EVERY) % 2) * GATHER_EVERY + lj % GATHER_EVERY
-
-    def group_build(g, nb=B):
-        """nb consecutive steps (pairs) as one group: every launch of the context is shared by them.  First half: the pyramids"""
-        c, j = g % nctx, g // nctx                # context, and the group's index among that context's groups
-        ctxs[c].build_pyramids_batch(slots_of(j, nb))            # all frames of the group share every launch
-
-    def group_track(g, nb=B, last=False):
-        """second half: the tracker launch (and, N > 1, the collective behind it)"""
-        c, j = g % nctx, g // nctx
-        cx = ctxs[c]
-        slots = slots_of(j, nb)
-        lj0 = j * B
-        if distributed and lj0 % GATHER_EVERY == 0:
-            cx.comm_fence_featbuf(FB_RING0 if (lj0 // GATHER_EVERY) % 2 == 0 else FB_RING1)   # the collective that read this table two rounds ago has finished
-        if nb == 1:
-            cx.track_async(slots[0], slots[1], FB_SEL, out_buffer(lj0), NFEAT)
-        else:
-            cx.track_batch_async(pairs_of(j, [out_buffer(lj0 + b) for b in range(nb)], nb), NFEAT)
-        if distributed and ((lj0 + B) % GATHER_EVERY == 0 or last):
-            ring, gath = (FB_RING0, FB_GATH0) if (lj0 // GATHER_EVERY) % 2 == 0 else (FB_RING1, FB_GATH1)
-            cx.allgather_featbuf_async(ring, gath, GATHER_EVERY * NFEAT)     # RCCL on the side stream, behind this tracker launch
-
-    def run_steps(n):
-        """n steps = ceil(n / B) groups, the last one partial when B does not divide n.  The groups go out in rounds of one group per
-        context, the builds of a round before its tracker launches: every stream has work a few microseconds after the region starts
-        (enqueueing a whole group takes the host ~25 us); the order inside each stream, and the work, are the same either way"""
-        ngroups = (n + B - 1) // B
-        for g0 in range(0, ngroups, nctx):
-            wave = range(g0, min(g0 + nctx, ngroups))
-            for g in wave:
-                group_build(g, nb=min(B, n - g * B))
-            for g in wave:
-                group_track(g, nb=min(B, n - g * B), last=(g >= ngroups - nctx))     # every context closes its open table with a gather
-
-    # bring the GPU to its steady state first (the same work as the steps, into the plain output buffers)
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for g in range(32):
-            cx, j = ctxs[g % nctx], g // nctx
-            cx.build_pyramids_batch(slots_of(j))
-            if B == 1:
-                cx.track_async(slots_of(j)[0], slots_of(j)[1], FB_SEL, plain_out(j % 2, 0), NFEAT)
-            else:
-                cx.track_batch_async(pairs_of(j, [plain_out(j % 2, b) for b in range(B)]), NFEAT)
-        for cx in ctxs:
-            cx.sync()
-    if args.warmup:
-        run_steps(args.warmup)
-
-    def region():
-        run_steps(args.steps)
-
-    elapsed, regions, enqueue_s = timed_regions(ranks, region, args.steps, args.repeats)
-
-    # correctness of what was timed: the last step's records (and, N > 1, what the gather delivered of them); every
-    # context's last output is the same list (same pair, same features)
-    def where(i):
-        """(context, index among the context's pairs) of step i"""
-        g = i // B
-        return g % nctx, (g // nctx) * B + i % B
-
-    last_c, last_lj = where(args.steps - 1)
-    out = ctxs[last_c].featbuf_download(out_buffer(last_lj), NFEAT)
-    for i in range(max(0, args.steps - 2 * nctx * B), args.steps):          # the last outputs of every context, every pair of a group
-        c_i, lj_i = where(i)
-        o = ctxs[c_i].featbuf_download(out_buffer(lj_i), NFEAT)
-        assert np.array_equal(o["x"], out["x"]) and np.array_equal(o["y"], out["y"]) and np.array_equal(o["val"], out["val"]), \
-            "contexts / pairs of a group disagree on the tracked records"
-    if distributed:                 # what this rank received from itself equals what it produced
-        gath = FB_GATH0 if (last_lj // GATHER_EVERY) % 2 == 0 else FB_GATH1
-        got = ctxs[last_c].featbuf_download(gath, world * GATHER_EVERY * NFEAT).reshape(world, GATHER_EVERY, NFEAT)
-        mine = got[rank][last_lj % GATHER_EVERY]
-        assert np.array_equal(mine["x"], out["x"]) and np.array_equal(mine["val"], out["val"]), "gathered records differ"
-    tracked = int(np.count_nonzero(out["val"] >= 0))
-    live = out["val"] == 0
-    shift = (float(np.median(out["x"][live] - fl["x"][live])), float(np.median(out["y"][live] - fl["y"][live])))
-    parity = parity_against(out, oracle_track(p, f0, f1, fl)) if rank == 0 else {}
-
-    # second pass: per-kernel HIP-event timing + iteration counters for the roofline
-    roofline = None
-    kernels = []
-    if rank == 0:
-        ngroups_roof = max(1, args.steps // B)
-        npairs_roof = ngroups_roof * B
-
-        def roof_groups(n):
-            for g in range(n):
-                ctx.build_pyramids_batch(slots_of(g))
-                if B == 1:
-                    ctx.track_async(slots_of(g)[0], slots_of(g)[1], FB_SEL, plain_out(g % 2, 0), NFEAT)
-                else:
-                    ctx.track_batch_async(pairs_of(g, [plain_out(g % 2, b) for b in range(B)]), NFEAT)
-
-        def roof_pass(mode):
-            """the groups of the timed region once more, on one context, with every launch timed -- at the clocks the timed regions ran
-            at: the parity check and the downloads above left the GPU idle, so the same untimed groups run first, as before the regions"""
-            t_warm = time.perf_counter()
-            while (time.perf_counter() - t_warm) * 1e3 < min(args.prewarm_ms, 30.0):
-                roof_groups(16)
-                ctx.sync()
-            ctx.timing_enable(mode)
-            for g in range(ngroups_roof):
-                ctx.build_pyramids_batch(slots_of(g))
-                if B == 1:
-                    ctx.track_async(slots_of(g)[0], slots_of(g)[1], FB_SEL, plain_out(g % 2, 0), NFEAT)
-                else:
-                    ctx.track_batch_async(pairs_of(g, [plain_out(g % 2, b) for b in range(B)]), NFEAT)
-            res = ctx.timing_read()
-            ctx.timing_enable(False)
-            return res
-
-        ctx.track_stats_reset()
-        kernels = roof_pass(1)
-        st = ctx.track_stats()
-        st = {k: ([x / npairs_roof for x in v] if isinstance(v, list) else v / npairs_roof) for k, v in st.items()}
-        pyr_bytes, track_bytes = algorithmic_bytes(p, WIDTH, HEIGHT, st, NFEAT)
-        for k in kernels:
-            if k["name"] == "track":
-                k["bytes"] = track_bytes * B * k["launches"]
-        dom = max(kernels, key=lambda k: k["total_ms"])
-        pair_launch_ms = dom["total_ms"] / dom["launches"]        # an event pair AROUND the launch: the kernel + the boundary to the launch before it
-        per_launch_ms = pair_launch_ms
-        per_launch_bytes = dom["bytes"] / dom["launches"]
-        # the dominant kernel once more, timed by the start / stop events of its own dispatch (klt_timing_enable(ctx, 2): the runtime fills
-        # them from the dispatch packet's begin / end timestamps) -- the duration rocprofv3 reports for it, which the event pair above
-        # overstates by the ~2.6 us between two dependent launches
-        stamp_launch_ms = None
-        if dom["name"] == "smooth_grad_l0":
-            for k in roof_pass(2):
-                if k["name"] == dom["name"] and k["launches"]:
-                    stamp_launch_ms = k["total_ms"] / k["launches"]
-            if stamp_launch_ms:
-                per_launch_ms = stamp_launch_ms
-        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-        # PMC-derived figures are NOT measured by this run: committed results of the builder's rocprofv3 --pmc passes, with their
-        # provenance, dropped when the kernel source changed since (committed_counters)
-        traffic, traffic_source = committed_counters("traffic.json", dom["name"], B)
-        # the same kernel against the roof that actually bounds it: VALU issue.  Wavefront-instructions per launch come from a
-        # rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/sq_counters.json, tools/pmc_sq.py); 4.5 clocks per instruction and SIMD
-        # is what the FP64-rate instruction mix of the convolutions sustains on gfx950 (tools/mb/valu_rate.hip, fp64_mix.hip).
-        issue = None
-        sq, sq_source = committed_counters("sq_counters.json", dom["name"], B)
-        if sq and sq.get("SQ_INSTS_VALU"):
-            simds, cpi, mhz = 256 * 4, 4.5, 2400.0
-            ideal_us = sq["SQ_INSTS_VALU"] / simds * cpi / mhz
-            issue = {"valu_wavefront_instructions_per_launch": sq["SQ_INSTS_VALU"], "simds": simds, "clocks_per_instruction": cpi,
-                     "clock_mhz": mhz, "ideal_us": ideal_us, "frac": ideal_us / (per_launch_ms * 1e3), "source": sq_source}
-        elif sq_source:
-            issue = {"source": sq_source}
-        dev_ms = sum(k["total_ms"] for k in kernels) / npairs_roof
-        roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "issue_bound": issue,
-                    "launch_us": per_launch_ms * 1e3, "launch_us_source": "dispatch start/stop events (hipExtLaunchKernelGGL)" if stamp_launch_ms
-                    else "event pair around the launch", "launch_us_event_pair": pair_launch_ms * 1e3,
-                    "launches_per_step": dom["launches"] / npairs_roof, "pairs_per_launch": B,
-                    "algorithmic_bytes_per_launch": per_launch_bytes,
-                    "step_algorithmic_bytes": 2 * pyr_bytes + track_bytes,
-                    "step_device_ms": dev_ms,
-                    "step_frac": (2 * pyr_bytes + track_bytes) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "newton_iterations_per_level": st["iterations"][:p.nPyramidLevels],
-                    "kernels": {k["name"]: {"us_per_launch": 1e3 * k["total_ms"] / k["launches"],
-                                            "launches_per_step": k["launches"] / npairs_roof,
-                                            "GBps": k["bytes"] / max(k["total_ms"], 1e-9) / 1e6} for k in kernels}}
-
-    # secondary figures (never `value`): selection time, the one-stream figure, and the PCIe-inclusive pair time
-    extra = None
-    ms_single = None
-    if rank == 0 and args.no_extras:
-        extra = {"region_ms_per_step": {"median": elapsed / args.steps * 1e3, "min": min(regions) / args.steps * 1e3,
-                                        "max": max(regions) / args.steps * 1e3, "regions": len(regions)},
-                 "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "note": "--no-extras: secondary figures skipped"}
-    elif rank == 0:
-        reps = max(5, min(20, args.steps))
-        ctx.sync()
-        t = time.perf_counter()
-        for _ in range(reps):
-            ctx.select_async(0, 1, True, FB_OUT1, NFEAT)      # SELECTING_ALL on the resident level-0 pyramid
-        ctx.sync()
-        ms_select = (time.perf_counter() - t) / reps * 1e3
-        singles = []
-        for _ in range(5):
-            t = time.perf_counter()
-            for i in range(args.steps):                        # the same K steps on ONE stream (one pair in flight)
-                a = 0 if i % NSETS == 0 else 2
-                ctx.build_pyramids_batch([a, a + 1])
-                ctx.track_async(a, a + 1, FB_SEL, FB_OUT0 if i % 2 == 0 else FB_OUT1, NFEAT)
-            ctx.sync()
-            singles.append((time.perf_counter() - t) / args.steps * 1e3)
-        ms_single = statistics.median(singles)
-        t = time.perf_counter()
-        for _ in range(reps):                                  # un-pipelined latency of one pair
-            ctx.build_pyramids_batch([0, 1])
-            ctx.track_async(0, 1, FB_SEL, FB_OUT0, NFEAT)
-            ctx.sync()
-        ms_latency = (time.perf_counter() - t) / reps * 1e3
-        t = time.perf_counter()
-        for _ in range(reps):
-            ctx.upload(0, f0)
-            ctx.upload(1, f1)
-            ctx.build_pyramids_batch([0, 1])
-            ctx.track_async(0, 1, FB_SEL, FB_OUT0, NFEAT)
-            ctx.featbuf_download(FB_OUT0, NFEAT)
-        ms_pcie = (time.perf_counter() - t) / reps * 1e3
-        # pipelined ingest: frames already sit in pinned host memory (as a decoder would leave them), uploads run on the
-        # copy stream and overlap the previous pair's kernels; records go to a device table read back every 16 pairs
-        pins = {s0: ctx.pinned_array((HEIGHT, WIDTH)) for s0 in (0, 1, 2, 3)}
-        for s0 in (0, 2):
-            pins[s0][:] = f0
-            pins[s0 + 1][:] = f1
-        TAB, NT = 90, 16
-        ctx.featbuf_alloc(TAB, NT * NFEAT)
-        for k in range(NT):
-            ctx.featbuf_view(TAB + 1 + k, TAB, k * NFEAT, NFEAT)
-        npipe = 8 * NT
-
-        def pipelined_step(i):
-            a = 0 if i % 2 == 0 else 2
-            ctx.upload_async(a, pins[a])
-            ctx.upload_async(a + 1, pins[a + 1])
-            ctx.build_pyramids_batch([a, a + 1])
-            ctx.track_async(a, a + 1, FB_SEL, TAB + 1 + i % NT, NFEAT)
-            return ctx.featbuf_download(TAB, NT * NFEAT) if i % NT == NT - 1 else None
-
-        for i in range(NT):                 # warm-up: the alternate raw buffers are allocated on first use
-            table = pipelined_step(i)
-        ctx.sync()
-        t = time.perf_counter()
-        for i in range(npipe):
-            got = pipelined_step(i)
-            table = got if got is not None else table
-        ctx.sync()
-        ms_pipe = (time.perf_counter() - t) / npipe * 1e3
-        assert np.array_equal(table[-NFEAT:]["x"], out["x"]), "pipelined ingest changed the result"
-        extra = {"region_ms_per_step": {"median": elapsed / args.steps * 1e3, "min": min(regions) / args.steps * 1e3,
-                                        "max": max(regions) / args.steps * 1e3, "regions": len(regions)},
-                 "overlapped_ms_per_pair": elapsed / args.steps * 1e3,
-                 "pcie_pipelined_ms_per_pair": ms_pipe, "pcie_pipelined_features_per_s": NFEAT / (ms_pipe * 1e-3),
-                 "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "latency_ms_per_pair_synchronised": ms_latency,
-                 "single_stream_ms_per_pair": ms_single, "single_stream_features_per_s": NFEAT / (ms_single * 1e-3),
-                 "single_stream_runs_ms": singles,
-                 "ms_per_select_5000": ms_select,
-                 "pcie_inclusive_ms_per_pair": ms_pcie, "pcie_inclusive_features_per_s": NFEAT / (ms_pcie * 1e-3),
-                 "note": "ms_per_frame_pair = single_stream_ms_per_pair: one pair at a time on ONE stream, no overlap with other "
-                         "pairs (ms_per_step is the inverse throughput with pairs_in_flight pairs overlapping).  "
-                         "pcie_inclusive = H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the "
-                         "records, synchronised per pair; pcie_pipelined = the same bytes with klt_upload_u8_async from "
-                         "pinned memory on a copy stream and the records read back every 16 pairs"}
-
-    cpu = None
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
-        cpu = cpu_baseline(p, f0, f1, fl, NFEAT, "cfg-2 (1920x1080, 5000 features)")
-
-    line = None
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        line = base_line(world * NFEAT * args.steps / elapsed, world, args.steps, args.warmup, ms_per_step,
-                         ms_single if ms_single is not None else ms_per_step,
-                         "cfg-2: one 1920x1080 synthetic pair per GPU, 5000 features, 7x7 window, "
-                         "3 pyramid levels (subsampling 4), translation only; inputs resident in HBM",
-                         extra_cfg={
-                             "pipelining": (("none (one HIP stream)" if nctx == 1 else
-                                             "groups of steps go round-robin to %d contexts, one HIP stream each, no ordering between them "
-                                             "(pairs are independent)" % nctx) +
-                                            ("; every step does the full work of one pair" if B == 1 else
-                                             "; the %d steps (pairs) of a group share every launch of their context: one batched pyramid "
-                                             "build for their %d frames, one tracker launch for their %d feature lists -- every step still "
-                                             "does the full work of one pair" % (B, 2 * B, B)) +
-                                            ("; a context rebuilds the same frame slots every group (the pyramid planes the tracker reads "
-                                             "are still in the Infinity Cache)" if NSETS == 1 else "; alternate groups of a context use two sets of frame slots")),
-                             "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "slot_sets": NSETS,
-                             "features_per_pair": NFEAT, "pairs_per_step": world, "tracked": tracked,
-                             "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
-                             "rccl_ranks": world if distributed else 0,
-                             "parallelism": "1 pair per GPU" + (", RCCL all-gather (libkltgpu side stream) of the [%d steps x 5000] record "
-                                                                "table every %d steps" % (GATHER_EVERY, GATHER_EVERY) if distributed else "")})
-        line.update(parity)
-        line["roofline"], line["cpu_baseline"], line["extra"] = roofline, cpu, extra
-    for cx in ctxs:
-        cx.close()
-    if line is not None:
-        emit(json_fd, line)
-        if parity and not parity.get("parity_checked") and "max_abs_dx" in parity:
-            raise SystemExit("timed records differ from the oracle: %r" % parity)
+    return {"cfg1": run_cfg1, "cfg2": run_cfg2, "cfg3": run_cfg3, "cfg4": run_cfg4, "cfg5": run_cfg5}[args.config](args, json_fd)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 6
+#define KLT_ABI_VERSION 7
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -39,7 +39,8 @@ typedef enum {
     KLT_ERR_ARG = -1,        /* bad argument / unsupported parameter combination */
     KLT_ERR_DEVICE = -2,     /* HIP runtime error */
     KLT_ERR_STATE = -3,      /* call order (e.g. tracking a slot whose pyramids were never built) */
-    KLT_ERR_NOMEM = -4
+    KLT_ERR_NOMEM = -4,
+    KLT_ERR_TIMEOUT = -5     /* a host-side wait for a collective gave up (klt_comm_set_timeout): a peer is gone or stuck */
 } klt_status;
 
 /* feature status codes, klt.py:23-29 (kltState) */
@@ -190,10 +191,13 @@ typedef struct {
 } klt_affine_params;
 /* per-feature state the reference keeps in KLT_Feature (klt.py:255-263); the three (window+2)^2 templates live in a
  * device array next to these records */
-typedef struct { float aff_x, aff_y, Axx, Ayx, Axy, Ayy; int32_t valid, pad; } klt_affine_rec;
+typedef struct { float aff_x, aff_y, Axx, Ayx, Axy, Ayy; int32_t valid, pad /* Newton iterations of the feature's last check */; } klt_affine_rec;
 int klt_set_affine_params(klt_ctx *ctx, const klt_affine_params *p);
 int klt_affine_alloc(klt_ctx *ctx, int state, int n);          /* n feature slots, no templates yet */
 int klt_affine_download(klt_ctx *ctx, int state, klt_affine_rec *dst, int n);
+/* device-side snapshot: the records (and, with_templates != 0, the templates) of the first n features of state `src` into `dst`
+ * (allocated if needed), on the context's stream.  The templates of a feature never change while its record is valid. */
+int klt_affine_copy_async(klt_ctx *ctx, int dst, int src, int n, int with_templates);
 int klt_affine_free(klt_ctx *ctx, int state);                  /* releases records + templates; the id can be allocated again */
 /* klt_track_async followed by the consistency check of the features it tracked; fb_in != fb_out.  `state` travels
  * with the feature list (same index = same feature). */
@@ -230,6 +234,10 @@ int klt_comm_info(klt_ctx *ctx, int *nranks, int *rank);       /* 1 / 0 when the
  * whole device-side [pairs x features] table (klt_featbuf_view). */
 int klt_allgather_featbuf_async(klt_ctx *ctx, int fb_src, int fb_dst, int n);
 int klt_gather_featbuf_async(klt_ctx *ctx, int fb_src, int fb_dst, int n, int root);
+/* gather with a count per rank (shards of unequal size: 7 or 257 pairs over 8 GPUs): rank r contributes the first counts[r]
+ * records of its fb_src, the root's fb_dst receives sum(counts) records back to back in rank order.  Every rank passes the same
+ * table of nranks counts; a rank with count 0 takes no part in the transfer (its fb_src may be -1). */
+int klt_gatherv_featbuf_async(klt_ctx *ctx, int fb_src, int fb_dst, const int *counts, int root);
 /* The feature list as the baton of ONE temporal sequence cut into blocks of frames, one block per GPU (the tracker and the
  * replacement pass are a serial chain, trackFeatures.py:250-346 / selectGoodFeatures.py:45-135; everything that depends on the pixels
  * only is prepared by the block's owner meanwhile): n records of fb_send go to rank `to` and / or n records from rank `from` arrive in
@@ -240,7 +248,12 @@ int klt_comm_fence_async(klt_ctx *ctx);    /* the context's stream waits (on the
 /* ... only for the last collective that read or wrote feature buffer fb (call it before overwriting a table whose
  * gather may still be in flight; collectives on other tables keep overlapping) */
 int klt_comm_fence_featbuf_async(klt_ctx *ctx, int fb);
-int klt_comm_wait(klt_ctx *ctx);           /* the host waits for them */
+int klt_comm_wait(klt_ctx *ctx);           /* the host waits for them -- at most the communicator's timeout, then KLT_ERR_TIMEOUT */
+/* Host-side waits on the communicator (klt_comm_wait, klt_sync, klt_comm_allreduce_max, and the waits before device memory that a
+ * collective may touch is freed) give up after `ms` milliseconds with KLT_ERR_TIMEOUT instead of hanging when a peer has died;
+ * default 120 000, or KLT_COMM_TIMEOUT_MS in the environment; <= 0 waits for ever.  After a timeout the communicator is unusable:
+ * the rank should report and exit non-zero (never restart in place a process that has touched the GPU). */
+int klt_comm_set_timeout(klt_ctx *ctx, double ms);
 /* element-wise maximum over all ranks of n <= 16 doubles (host in, host out; synchronous -- also the barrier the
  * benchmark brackets its timed region with) */
 int klt_comm_allreduce_max(klt_ctx *ctx, double *inout, int n);
@@ -272,9 +285,10 @@ int klt_gradients_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, cons
 /* ---- per-kernel timing (HIP events on the context's stream) -------------------------------- */
 typedef struct { char name[32]; uint32_t launches; float total_ms; double bytes; } klt_kernel_time;
 int klt_timing_enable(klt_ctx *ctx, int on);                /* resets the accumulated figures.  1: an event pair around every launch;
-                                                             * 2: the same, but the level-0 pyramid launch (smooth_grad_l0) is timed by its dispatch's own begin / end
-                                                             * timestamps (hipExtLaunchKernelGGL events) -- the kernel duration a profiler reports, without the
-                                                             * boundary between two dependent launches that an event pair also holds */
+                                                             * 2: the same, but the kernels that are one launch per call (smooth_grad_l0, pyramid_reduce, gradients, track,
+                                                             * affine_check, sat_rows, sat_cols, eigen_keys) are timed by their dispatch's own begin / end timestamps
+                                                             * (hipExtLaunchKernelGGL events) -- the kernel duration a profiler reports, without the boundary between
+                                                             * two dependent launches that an event pair also holds */
 int klt_timing_read(klt_ctx *ctx, klt_kernel_time *out, int max_entries);   /* returns the entry count */
 
 #ifdef __cplusplus

@@ -93,6 +93,7 @@ SYMBOLS = {
     "klt_affine_alloc": (_I, [_P, _I, _I]),
     "klt_affine_download": (_I, [_P, _I, _P, _I]),
     "klt_affine_free": (_I, [_P, _I]),
+    "klt_affine_copy_async": (_I, [_P, _I, _I, _I, _I]),
     "klt_track_affine_async": (_I, [_P, _I, _I, _I, _I, _I, _I]),
     "klt_track_affine": (_I, [_P, _I, _I, _P, _I, _I, _PI]),
     "klt_track_stats_reset": (_I, [_P]),
@@ -111,6 +112,8 @@ SYMBOLS = {
     "klt_comm_info": (_I, [_P, _PI, _PI]),
     "klt_allgather_featbuf_async": (_I, [_P, _I, _I, _I]),
     "klt_gather_featbuf_async": (_I, [_P, _I, _I, _I, _I]),
+    "klt_gatherv_featbuf_async": (_I, [_P, _I, _I, _PI, _I]),
+    "klt_comm_set_timeout": (_I, [_P, C.c_double]),
     "klt_sendrecv_featbuf_async": (_I, [_P, _I, _I, _I, _I, _I]),
     "klt_comm_fence_async": (_I, [_P]),
     "klt_comm_fence_featbuf_async": (_I, [_P, _I]),

@@ -93,6 +93,10 @@ class Context:
     def affine_alloc(self, state, n):
         self._check(self._lib.klt_affine_alloc(self._h, state, n))
 
+    def affine_copy(self, dst, src, n, with_templates=False):
+        """Device-side snapshot of the per-feature affine state (klt_affine_copy_async); asynchronous."""
+        self._check(self._lib.klt_affine_copy_async(self._h, dst, src, n, int(bool(with_templates))))
+
     def affine_free(self, state):
         if getattr(self, "_h", None):
             self._check(self._lib.klt_affine_free(self._h, state))
@@ -187,6 +191,10 @@ class Context:
         if key not in cache:
             cache[key] = [self.pinned_array(shape) for _ in range(count)]
         return cache[key]
+
+    def staging_forget(self, shape, count=2):
+        """Drops a cached staging set without freeing it (somebody may still write to it); the next staging() allocates anew."""
+        self.__dict__.setdefault("_staging", {}).pop((tuple(shape), count), None)
 
     def build_pyramids(self, slot, sync=True):
         fn = self._lib.klt_build_pyramids if sync else self._lib.klt_build_pyramids_async
@@ -331,6 +339,15 @@ class Context:
 
     def gather_featbuf_async(self, fb_src, fb_dst, n, root=0):
         self._check(self._lib.klt_gather_featbuf_async(self._h, fb_src, fb_dst, n, root))
+
+    def gatherv_featbuf_async(self, fb_src, fb_dst, counts, root=0):
+        """Gather with a count per rank (shards of unequal size): rank r contributes counts[r] records (klt_gatherv_featbuf_async)."""
+        arr = (C.c_int * len(counts))(*[int(v) for v in counts])
+        self._check(self._lib.klt_gatherv_featbuf_async(self._h, fb_src, fb_dst, arr, root))
+
+    def comm_set_timeout(self, ms):
+        """Host-side waits on the communicator give up after `ms` milliseconds (KLT_ERR_TIMEOUT) instead of hanging."""
+        self._check(self._lib.klt_comm_set_timeout(self._h, float(ms)))
 
     def sendrecv_featbuf(self, fb_send, to, fb_recv, frm, n):
         """The feature list as a baton (klt_sendrecv_featbuf_async): n records of fb_send to rank `to` and / or from rank `frm` into

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
     klt_feat after = a.out[f];
     klt_affine_rec st = a.rec[f];
     if (after.val != KLT_TRACKED) {                       // lost by the translation tracker: template freed
-        if (lane == 0 && st.valid) { st.valid = 0; a.rec[f] = st; }
+        if (lane == 0 && (st.valid || st.pad)) { st.valid = 0; st.pad = 0; a.rec[f] = st; }
         return;
     }
     const int width = a.width, height = a.height, hw = width / 2, hh = height / 2, n = width * height;
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
             st.aff_y = before.y - (float)y0 + (float)thh;
             st.Axx = 1.f; st.Ayx = 0.f; st.Axy = 0.f; st.Ayy = 1.f;
             st.valid = 1;
+            st.pad = 0;
             a.rec[f] = st;
         }
         return;
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
     }
     if (lane == 0) {
         st.Axx = Axx; st.Ayx = Ayx; st.Axy = Axy; st.Ayy = Ayy;
+        st.pad = iteration;                                  // iterations of this check (bench.py's algorithmic bytes)
         if (status != KLT_TRACKED) {
             after.x = -1.f; after.y = -1.f;
             st.aff_x = -1.f; st.aff_y = -1.f; st.valid = 0;
@@ -362,9 +364,9 @@ void launch_affine(hipStream_t s, const AffineArgs &a)
     if (a.n <= 0) return;
     const size_t n = (size_t)a.width * a.height;
     // template samples + the two offset arrays
-    if (a.mode == 0) hipLaunchKernelGGL(affine_kernel<0>, dim3(a.n), dim3(64), 5 * n * sizeof(float), s, a);
-    else if (a.mode == 1) hipLaunchKernelGGL(affine_kernel<1>, dim3(a.n), dim3(64), 3 * n * sizeof(float), s, a);
-    else hipLaunchKernelGGL(affine_kernel<2>, dim3(a.n), dim3(64), 3 * n * sizeof(float), s, a);
+    if (a.mode == 0) klt_launch(affine_kernel<0>, dim3(a.n), dim3(64), (unsigned)(5 * n * sizeof(float)), s, a);
+    else if (a.mode == 1) klt_launch(affine_kernel<1>, dim3(a.n), dim3(64), (unsigned)(3 * n * sizeof(float)), s, a);
+    else klt_launch(affine_kernel<2>, dim3(a.n), dim3(64), (unsigned)(3 * n * sizeof(float)), s, a);
 }
 
 void launch_affine_reset(hipStream_t s, klt_affine_rec *rec, int n)

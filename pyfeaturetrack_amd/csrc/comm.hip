@@ -12,6 +12,11 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,14 +54,21 @@ bool load_rccl(std::string &err)
 {
     if (g_rccl.handle && g_rccl.error.empty()) return true;
     if (!g_rccl.handle) {
-        const char *names[] = {getenv("KLT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // KLT_RCCL_LIB names THE library to use (no fallback to the system's: a wrong path must not go unnoticed)
+        const char *forced = getenv("KLT_RCCL_LIB");
+        const char *defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::vector<const char *> names;
+        if (forced && *forced) names.push_back(forced);
+        else names.assign(defaults, defaults + 3);
+        std::string tried;
         for (const char *n : names) {
-            if (!n || !*n) continue;
             g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (g_rccl.handle) break;
+            const char *m = dlerror();                    // (dlerror() clears its state: read it once per failure)
+            tried += std::string(tried.empty() ? "" : "; ") + n + ": " + (m ? m : "not found");
         }
         if (!g_rccl.handle) {
-            err = std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "not found");
+            err = "cannot open librccl (" + tried + ")";
             return false;
         }
         g_rccl.error.clear();
@@ -80,6 +92,7 @@ struct KltComm {
     size_t ring_next = 0;
     hipEvent_t last_done = nullptr;        // end of the most recent collective
     double *scratch = nullptr;             // device scratch for the small reductions (16 doubles)
+    double timeout_ms = 120000.0;          // host-side waits give up after this long (KLT_COMM_TIMEOUT_MS / comm_set_timeout; <= 0: never)
 };
 
 #define COMM_HIP(call)                                                                  \
@@ -126,6 +139,7 @@ int comm_create(int device, int nranks, int rank, const void *unique_id, KltComm
     COMM_HIP(hipSetDevice(device));
     KltComm *k = new KltComm();
     k->device = device; k->nranks = nranks; k->rank = rank;
+    if (const char *t = getenv("KLT_COMM_TIMEOUT_MS")) k->timeout_ms = atof(t);
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof(id));
     ncclResult_t r = g_rccl.CommInitRank(&k->comm, nranks, id, rank);
@@ -199,12 +213,43 @@ int comm_gather(KltComm *k, hipStream_t producer, const void *src, void *dst, si
         COMM_HIP(hipMemcpyAsync((char *)dst + (size_t)root * bytes, src, bytes, hipMemcpyDeviceToDevice, k->side));
         if (k->nranks > 1) {
             COMM_NCCL(g_rccl.GroupStart());
-            for (int r = 0; r < k->nranks; r++)
-                if (r != root) COMM_NCCL(g_rccl.Recv((char *)dst + (size_t)r * bytes, bytes, ncclUint8, r, k->comm, k->side));
-            COMM_NCCL(g_rccl.GroupEnd());
+            ncclResult_t first = ncclSuccess;             // an open group is always closed, whatever failed inside it
+            for (int r = 0; r < k->nranks && first == ncclSuccess; r++)
+                if (r != root) first = g_rccl.Recv((char *)dst + (size_t)r * bytes, bytes, ncclUint8, r, k->comm, k->side);
+            const ncclResult_t end = g_rccl.GroupEnd();
+            COMM_NCCL(first);
+            COMM_NCCL(end);
         }
     } else {
         COMM_NCCL(g_rccl.Send(src, bytes, ncclUint8, root, k->comm, k->side));
+    }
+    return comm_mark_done(k, err);
+}
+
+// the same with a count per rank (shards of unequal size, SURVEY 8(e): any contiguous / round-robin partition): rank r contributes
+// counts[r] bytes, the root receives them back to back in rank order.  Every rank passes the same table.
+int comm_gatherv(KltComm *k, hipStream_t producer, const void *src, void *dst, const size_t *counts, int root, std::string &err)
+{
+    if (root < 0 || root >= k->nranks || !counts) { err = "gatherv: bad root / counts"; return KLT_ERR_ARG; }
+    COMM_HIP(hipSetDevice(k->device));
+    if (int rc = comm_order_behind(k, producer, err)) return rc;
+    const size_t mine = counts[k->rank];
+    if (k->rank == root) {
+        if (!dst) { err = "the gather root needs a destination buffer"; return KLT_ERR_ARG; }
+        std::vector<size_t> off((size_t)k->nranks + 1, 0);
+        for (int r = 0; r < k->nranks; r++) off[r + 1] = off[r] + counts[r];
+        if (mine) COMM_HIP(hipMemcpyAsync((char *)dst + off[root], src, mine, hipMemcpyDeviceToDevice, k->side));
+        if (k->nranks > 1) {
+            COMM_NCCL(g_rccl.GroupStart());
+            ncclResult_t first = ncclSuccess;
+            for (int r = 0; r < k->nranks && first == ncclSuccess; r++)
+                if (r != root && counts[r]) first = g_rccl.Recv((char *)dst + off[r], counts[r], ncclUint8, r, k->comm, k->side);
+            const ncclResult_t end = g_rccl.GroupEnd();
+            COMM_NCCL(first);
+            COMM_NCCL(end);
+        }
+    } else if (mine) {
+        COMM_NCCL(g_rccl.Send(src, mine, ncclUint8, root, k->comm, k->side));
     }
     return comm_mark_done(k, err);
 }
@@ -222,9 +267,12 @@ int comm_sendrecv(KltComm *k, hipStream_t producer, const void *src, int to, voi
         COMM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, k->side));
     } else {
         COMM_NCCL(g_rccl.GroupStart());
-        if (to >= 0) COMM_NCCL(g_rccl.Send(src, bytes, ncclUint8, to, k->comm, k->side));
-        if (from >= 0) COMM_NCCL(g_rccl.Recv(dst, bytes, ncclUint8, from, k->comm, k->side));
-        COMM_NCCL(g_rccl.GroupEnd());
+        ncclResult_t first = ncclSuccess;
+        if (to >= 0) first = g_rccl.Send(src, bytes, ncclUint8, to, k->comm, k->side);
+        if (from >= 0 && first == ncclSuccess) first = g_rccl.Recv(dst, bytes, ncclUint8, from, k->comm, k->side);
+        const ncclResult_t end = g_rccl.GroupEnd();
+        COMM_NCCL(first);
+        COMM_NCCL(end);
     }
     return comm_mark_done(k, err);
 }
@@ -236,11 +284,30 @@ int comm_fence(KltComm *k, hipStream_t consumer, std::string &err)
     return 0;
 }
 
+void comm_set_timeout(KltComm *k, double ms) { if (k) k->timeout_ms = ms; }
+
+// The host waits for the side stream -- but never for ever: a peer that died leaves a collective that cannot complete, and a rank
+// stuck in hipStreamSynchronize cannot even report it.  Polls (spinning for the first 200 us: the timing barrier of bench.py sits
+// here) and gives up with KLT_ERR_TIMEOUT after timeout_ms; the caller is expected to exit non-zero (a process that has touched
+// the GPU is never restarted in place).
 int comm_wait(KltComm *k, std::string &err)
 {
     COMM_HIP(hipSetDevice(k->device));
-    COMM_HIP(hipStreamSynchronize(k->side));
-    return 0;
+    if (k->timeout_ms <= 0) { COMM_HIP(hipStreamSynchronize(k->side)); return 0; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(k->side);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { err = std::string("hipStreamQuery(side stream): ") + hipGetErrorString(q); return KLT_ERR_DEVICE; }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > k->timeout_ms) {
+            char buf[160];
+            std::snprintf(buf, sizeof(buf), "collective still pending after %.0f ms (rank %d of %d): a peer is gone or stuck", ms, k->rank, k->nranks);
+            err = buf;
+            return KLT_ERR_TIMEOUT;
+        }
+        if (ms > 0.2) usleep(50);
+    }
 }
 
 // max over ranks of up to 16 doubles, host in / host out, synchronous (bench timing: MAX over ranks); doubles as the barrier
@@ -251,6 +318,5 @@ int comm_allreduce_max(KltComm *k, double *inout, int n, std::string &err)
     COMM_HIP(hipMemcpyAsync(k->scratch, inout, n * sizeof(double), hipMemcpyHostToDevice, k->side));
     COMM_NCCL(g_rccl.AllReduce(k->scratch, k->scratch, (size_t)n, ncclDouble, ncclMax, k->comm, k->side));
     COMM_HIP(hipMemcpyAsync(inout, k->scratch, n * sizeof(double), hipMemcpyDeviceToHost, k->side));
-    COMM_HIP(hipStreamSynchronize(k->side));
-    return 0;
+    return comm_wait(k, err);
 }

@@ -125,10 +125,7 @@ struct klt_ctx {
     size_t h1_cap = 0;
     bool fuse_hreduce = true;                 // KLT_OPT_FUSED_HREDUCE
     bool track_xcd_order = true;              // KLT_OPT_TRACK_XCD_ORDER
-    uint32_t *track_order = nullptr;
-    size_t track_order_cap = 0;
     uint64_t waited_built_serial = ~0ull;     // the build event the main stream waited for last (wait_built)
-    int order_n = -1, order_pairs = 0, order_age = 0;   // shape (list length, pairs) the stored order was computed for, and how many launches ago
     // selection scratch
     float *sel_img = nullptr, *sel_gx = nullptr, *sel_gy = nullptr, *sat = nullptr, *valmap = nullptr;
     size_t sel_cap = 0;               // pixels
@@ -191,9 +188,11 @@ struct klt_ctx {
         uint64_t used = 0;
     };
     std::vector<BatchTable> batch_tables;         // at most kBatchTables, least recently used one replaced
-    std::vector<BatchOrder> batch_orders;         // at most 16
+    std::vector<BatchOrder> batch_orders;         // at most kBatchOrders
+    BatchOrder shared_order;                      // single-pair launches on lists seen for the first time
+    std::vector<const klt_feat *> seen_once;      // input lists of single-pair launches seen once so far (set_track_order)
     uint64_t batch_clock = 0;
-    static constexpr size_t kBatchTables = 256;
+    static constexpr size_t kBatchTables = 256, kBatchOrders = 128;
     klt_affine_params ap{-1, 15, 15, 10, 10.f, 0.02f, 1.5f};      // klt.py:67-73 defaults
     std::vector<AffState> aff;
     int select_aff_state = -1;
@@ -206,7 +205,7 @@ struct klt_ctx {
     bool use_fused = true;            // LDS-tiled fused kernels (pyramid_kernels.hip); off = generic two-pass kernels
     // timing
     bool timing = false;
-    bool timing_stamps = false;               // klt_timing_enable(ctx, 2): the level-0 launch is timed by its dispatch timestamps
+    bool timing_stamps = false;               // klt_timing_enable(ctx, 2): single-launch kernel families are timed by their dispatch timestamps
     std::vector<Timed> pending;
     std::vector<hipEvent_t> pool;
     double acc_ms[F_COUNT] = {0}, acc_bytes[F_COUNT] = {0};
@@ -243,7 +242,10 @@ struct TimerScope {
             if (!c->pool.empty()) { *e = c->pool.back(); c->pool.pop_back(); }
             else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
         }
-        stamps = c->timing_stamps && fam == F_SMOOTH_GRAD;
+        // families whose scope holds ONE launch that goes through klt_launch (the order kernel in front of a tracker and the threshold
+        // kernel behind the eigenvalue pass do not): timed by that dispatch's own timestamps.  Scopes with several launches keep the pair
+        stamps = c->timing_stamps && (fam == F_SMOOTH_GRAD || fam == F_PYR_REDUCE || fam == F_GRAD || fam == F_TRACK || fam == F_AFFINE ||
+                                      fam == F_SAT_ROWS || fam == F_SAT_COLS || fam == F_EIGEN);
         if (stamps) { g_klt_stamp_start = t.a; g_klt_stamp_stop = t.b; }      // filled by the launch itself (klt_launch)
         else hipEventRecord(t.a, st);
     }
@@ -281,12 +283,14 @@ int drain_timers(klt_ctx *c)
     return 0;
 }
 
-// every stream idle: required before freeing anything a queued kernel may still use
+// every stream idle -- the communicator's side stream included: a gather still in flight reads / writes feature tables -- : required
+// before freeing anything a queued kernel or collective may still use
 int sync_all(klt_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
     if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
+    if (c->comm) { std::string err; if (int rc = comm_wait(c->comm, err)) return fail(c, rc, err); }
     return 0;
 }
 
@@ -836,11 +840,11 @@ void klt_destroy(klt_ctx *c)
     for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes); }
     for (FeatBuf &b : c->fbs)
         if (!b.view) hipFree(b.d);
-    hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1); hipFree(c->track_order);
+    hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
     for (auto &e : c->pre) hipFree(e.keys);
     hipFree(c->sat_pre);
-    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); for (auto &bt : c->batch_tables) hipFree(bt.dev); for (auto &bo : c->batch_orders) hipFree(bo.order); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
+    hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); for (auto &bt : c->batch_tables) hipFree(bt.dev); for (auto &bo : c->batch_orders) hipFree(bo.order); hipFree(c->shared_order.order); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
     for (AffState &a : c->aff) { hipFree(a.rec); hipFree(a.tpl); } hipFree(c->placed_d); hipFree(c->stats_d);
     for (Timed &t : c->pending) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
@@ -958,7 +962,9 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
     if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc;
     if (s->consumed_valid) {
         if (!event_live(c, s->consumed_serial)) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));       // the event has been re-used since: wait for the reading stream itself
+            // the event has been re-used since: wait for the reading streams themselves (a build on the build stream reads raw frames too)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
         } else {
             const hipError_t q = hipEventQuery(s->ev_consumed);
             if (q == hipErrorNotReady) HIPCHK(c, hipEventSynchronize(s->ev_consumed));
@@ -1006,6 +1012,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
     }
     if (option == KLT_OPT_SCORE_SETS) {
         if (value < 2 || value > 256) return fail(c, KLT_ERR_ARG, "KLT_OPT_SCORE_SETS takes 2..256");
+        if (c->sel_job) return fail(c, KLT_ERR_STATE, "a selection is pending (it may hold one of the score sets): klt_select_finish first");
         if (int rc = sync_all(c)) return rc;
         for (size_t i = (size_t)value; i < c->pre.size(); i++) hipFree(c->pre[i].keys);
         c->pre.resize((size_t)value);
@@ -1627,15 +1634,48 @@ static void fill_track_params(const klt_ctx *c, const Slot *s1, TrackArgs &a, in
 // XCD-aware feature order (KLT_OPT_TRACK_XCD_ORDER): one permutation of 0..n-1 per pair of the launch.  It is only a locality
 // hint (any permutation tracks every feature exactly once), so it is recomputed when the shape of the launch changes and every
 // 64th launch (a sequence's features drift, and its lists alternate between two buffers); in between the stored one is reused.
-static int set_track_order(klt_ctx *c, TrackArgs &a, int n, int npairs)
+// The orders are kept per set of INPUT lists (at most kBatchOrders sets, least recently used one replaced): a caller that rotates
+// through many resident pairs -- each with its own list -- finds every list's own order again instead of tracking pair B in the
+// order of pair A's rows.  A single-pair launch on a list seen for the FIRST time takes the context's shared order instead (refreshed every
+// 64 launches): the rows of a sequence's feature table are all new buffers holding nearly the same
+// positions, and an order kernel per frame would buy nothing; the second launch on the same buffer gives it its own entry.
+static int set_track_order(klt_ctx *c, TrackArgs &a, int n, const std::vector<const klt_feat *> &ins)
 {
     if (!c->track_xcd_order || n < 64) return 0;
-    if (int rc = ensure(c, c->track_order, c->track_order_cap, (size_t)n * npairs)) return rc;
-    a.order = c->track_order;
+    const int npairs = (int)ins.size();
+    klt_ctx::BatchOrder *bo = nullptr;
+    for (auto &e : c->batch_orders)
+        if (e.in == ins) { bo = &e; break; }
+    if (npairs == 1) {
+        bool seen = false;
+        for (const klt_feat *p : c->seen_once) seen = seen || p == ins[0];
+        if (!bo && !seen) {
+            if (c->seen_once.size() >= 256) c->seen_once.erase(c->seen_once.begin());
+            c->seen_once.push_back(ins[0]);
+            bo = &c->shared_order;
+        }
+    }
+    if (!bo) {
+        if (c->batch_orders.size() < klt_ctx::kBatchOrders) {
+            c->batch_orders.emplace_back();
+            bo = &c->batch_orders.back();
+        } else {
+            bo = &c->batch_orders[0];
+            for (auto &e : c->batch_orders)
+                if (e.used < bo->used) bo = &e;
+        }
+        bo->in = ins;
+        bo->n = -1;
+    }
+    bo->used = ++c->batch_clock;
+    const size_t cap_before = bo->cap;
+    if (int rc = ensure(c, bo->order, bo->cap, (size_t)n * npairs)) return rc;
+    if (bo->cap != cap_before) bo->n = -1;               // a new buffer holds no order yet
+    a.order = bo->order;
     a.order_chunk = (n + 7) / 8;
-    a.order_refresh = (c->order_n != n || c->order_pairs != npairs || c->order_age >= 64) ? 1 : 0;
-    if (a.order_refresh) { c->order_n = n; c->order_pairs = npairs; c->order_age = 0; }
-    c->order_age++;
+    a.order_refresh = (bo->n != n || bo->age >= 64) ? 1 : 0;
+    if (a.order_refresh) { bo->n = n; bo->age = 0; }
+    bo->age++;
     return 0;
 }
 
@@ -1676,7 +1716,7 @@ int klt_track_async(klt_ctx *c, int slot1, int slot2, int fb_in, int fb_out, int
     fill_levels(s1, s2, a.lv);
     a.in = c->fbs[fb_in].d; a.out = bo->d;
     fill_track_params(c, s1, a, n);
-    if (int rc = set_track_order(c, a, n, 1)) return rc;
+    if (int rc = set_track_order(c, a, n, std::vector<const klt_feat *>{a.in})) return rc;
     {
         const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
         TimerScope t(c, F_TRACK, (double)n * (foot * 2 * s1->nlev + 32), c->stream);   // refined by the caller from klt_track_stats
@@ -1749,34 +1789,11 @@ int klt_track_batch_async(klt_ctx *c, const int *slot1, const int *slot2, const 
     a.pairs = bt->dev;
     a.npairs = npairs;
     fill_track_params(c, first, a, n);
-    if (c->track_xcd_order && n >= 64) {
+    {
         // one permutation per pair, kept with the set of input lists (see set_track_order)
         std::vector<const klt_feat *> ins((size_t)npairs);
         for (int i = 0; i < npairs; i++) ins[i] = table[i].in;
-        klt_ctx::BatchOrder *bo = nullptr;
-        for (auto &e : c->batch_orders)
-            if (e.in == ins) { bo = &e; break; }
-        if (!bo) {
-            if (c->batch_orders.size() < 16) {
-                c->batch_orders.emplace_back();
-                bo = &c->batch_orders.back();
-            } else {
-                bo = &c->batch_orders[0];
-                for (auto &e : c->batch_orders)
-                    if (e.used < bo->used) bo = &e;
-            }
-            bo->in = ins;
-            bo->n = -1;
-        }
-        bo->used = c->batch_clock;
-        const size_t cap_before = bo->cap;
-        if (int rc = ensure(c, bo->order, bo->cap, (size_t)n * npairs)) return rc;
-        if (bo->cap != cap_before) bo->n = -1;               // a new buffer holds no order yet
-        a.order = bo->order;
-        a.order_chunk = (n + 7) / 8;
-        a.order_refresh = (bo->n != n || bo->age >= 64) ? 1 : 0;
-        if (a.order_refresh) { bo->n = n; bo->age = 0; }
-        bo->age++;
+        if (int rc = set_track_order(c, a, n, ins)) return rc;
     }
     {
         const double foot = 12.0 * (c->p.window_width + 1) * (c->p.window_width + 1);
@@ -1849,6 +1866,26 @@ int klt_affine_free(klt_ctx *c, int state)
     hipFree(a.rec); hipFree(a.tpl);
     a = AffState();
     if (c->select_aff_state == state) c->select_aff_state = -1;
+    return KLT_OK;
+}
+
+// records (and, if asked, templates) of the first n features of `src` into `dst` (allocated here if needed), on the context's stream:
+// a snapshot of the per-feature state, e.g. to replay a step of a sequence from the same state
+int klt_affine_copy_async(klt_ctx *c, int dst, int src, int n, int with_templates)
+{
+    if (!c || dst == src || n <= 0) return fail(c, KLT_ERR_ARG, "bad argument");
+    if (src < 0 || (size_t)src >= c->aff.size() || !c->aff[src].rec || c->aff[src].n < n)
+        return fail(c, KLT_ERR_STATE, "source affine state not allocated (or smaller than requested)");
+    if (dst < 0 || (size_t)dst >= c->aff.size() || !c->aff[dst].rec || c->aff[dst].n < n) {
+        if (int rc = klt_affine_alloc(c, dst, c->aff[src].n)) return rc;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const AffState &s = c->aff[src];
+    AffState &d = c->aff[dst];
+    if (d.tn != s.tn) return fail(c, KLT_ERR_STATE, "affine states of different window sizes");
+    HIPCHK(c, hipMemcpyAsync(d.rec, s.rec, (size_t)n * sizeof(klt_affine_rec), hipMemcpyDeviceToDevice, c->stream));
+    if (with_templates)
+        HIPCHK(c, hipMemcpyAsync(d.tpl, s.tpl, (size_t)n * 3 * s.tn * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return KLT_OK;
 }
 
@@ -1950,7 +1987,11 @@ int klt_comm_init_rank(klt_ctx *c, int nranks, int rank, const void *unique_id)
 int klt_comm_destroy(klt_ctx *c)
 {
     if (!c) return KLT_ERR_ARG;
-    if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
+    if (c->comm) {
+        comm_destroy(c->comm);                    // (waits for the side stream, then destroys the communicator's events)
+        c->comm = nullptr;
+        for (FeatBuf &b : c->fbs) b.comm_done = nullptr;      // ... which the feature buffers must not keep
+    }
     return KLT_OK;
 }
 
@@ -1986,6 +2027,47 @@ static int gather_common(klt_ctx *c, int fb_src, int fb_dst, int n, int root /* 
     if (rc) return fail(c, rc, err);
     c->fbs[fb_src].comm_done = comm_last_done(c->comm);
     if (need_dst) c->fbs[fb_dst].comm_done = c->fbs[fb_src].comm_done;
+    return KLT_OK;
+}
+
+// gather with a count per rank: rank r contributes the first counts[r] records of its fb_src, the root's fb_dst receives them back to
+// back in rank order.  Every rank passes the same table of nranks counts (the caller's shard arithmetic).
+int klt_gatherv_featbuf_async(klt_ctx *c, int fb_src, int fb_dst, const int *counts, int root)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (!c->comm) return fail(c, KLT_ERR_STATE, "klt_comm_init_rank has not been called");
+    const int nranks = comm_nranks(c->comm), rank = comm_rank(c->comm);
+    if (!counts || root < 0 || root >= nranks || fb_src == fb_dst) return fail(c, KLT_ERR_ARG, "bad gatherv arguments");
+    long long total = 0;
+    std::vector<size_t> bytes((size_t)nranks);
+    for (int r = 0; r < nranks; r++) {
+        if (counts[r] < 0) return fail(c, KLT_ERR_ARG, "negative count");
+        total += counts[r];
+        bytes[r] = (size_t)counts[r] * sizeof(klt_feat);
+    }
+    if (total <= 0 || total > 0x7fffffffLL) return fail(c, KLT_ERR_ARG, "gathered table empty or too large");
+    const int n = counts[rank];
+    if (n > 0 && (fb_src < 0 || (size_t)fb_src >= c->fbs.size() || c->fbs[fb_src].cap < n)) return fail(c, KLT_ERR_STATE, "source feature buffer not that large");
+    HIPCHK(c, hipSetDevice(c->device));
+    klt_feat *dst = nullptr;
+    if (rank == root) {
+        FeatBuf *bd;
+        if (int rc = get_fb(c, fb_dst, (int)total, &bd)) return rc;      // may grow c->fbs: take the source pointer afterwards
+        dst = bd->d;
+    }
+    const klt_feat *src = n > 0 ? c->fbs[fb_src].d : nullptr;
+    std::string err;
+    if (const int rc = comm_gatherv(c->comm, c->stream, src, dst, bytes.data(), root, err)) return fail(c, rc, err);
+    if (n > 0) c->fbs[fb_src].comm_done = comm_last_done(c->comm);
+    if (rank == root) c->fbs[fb_dst].comm_done = comm_last_done(c->comm);
+    return KLT_OK;
+}
+
+int klt_comm_set_timeout(klt_ctx *c, double ms)
+{
+    if (!c) return KLT_ERR_ARG;
+    if (!c->comm) return fail(c, KLT_ERR_STATE, "klt_comm_init_rank has not been called");
+    comm_set_timeout(c->comm, ms);
     return KLT_OK;
 }
 

@@ -200,6 +200,8 @@ hipEvent_t comm_last_done(const KltComm *k);   // end of the most recent collect
 int  comm_rank(const KltComm *k);
 int  comm_allgather(KltComm *k, hipStream_t producer, const void *src, void *dst, size_t bytes, std::string &err);
 int  comm_gather(KltComm *k, hipStream_t producer, const void *src, void *dst, size_t bytes, int root, std::string &err);
+int  comm_gatherv(KltComm *k, hipStream_t producer, const void *src, void *dst, const size_t *counts, int root, std::string &err);
+void comm_set_timeout(KltComm *k, double ms);
 int  comm_sendrecv(KltComm *k, hipStream_t producer, const void *src, int to, void *dst, int from, size_t bytes, std::string &err);
 int  comm_fence(KltComm *k, hipStream_t consumer, std::string &err);
 int  comm_wait(KltComm *k, std::string &err);

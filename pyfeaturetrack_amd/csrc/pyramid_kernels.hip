@@ -677,7 +677,7 @@ static int launch_pyr_reduce_fast(hipStream_t s, const PyrReduceArgs &a, int bat
     constexpr size_t l = pyr_reduce_fast_lds<SS, NT, TS, OW, OH>();
     if (int e = set_lds(pyr_reduce_fast<SS, NT, NTHR, TS, OW, OH>, l)) return e;
     const dim3 grid((a.dst_nc + OW - 1) / OW, (a.dst_nr + OH - 1) / OH, batch);
-    hipLaunchKernelGGL((pyr_reduce_fast<SS, NT, NTHR, TS, OW, OH>), grid, dim3(NTHR), l, s, a);
+    klt_launch((pyr_reduce_fast<SS, NT, NTHR, TS, OW, OH>), grid, dim3(NTHR), (unsigned)l, s, a);
     return 0;
 }
 
@@ -783,7 +783,7 @@ bool smooth_grad_hred_ok(const SmoothGradArgs &a, int batch, int kind, const Tap
 int launch_pyr_vreduce(hipStream_t s, const PyrReduceArgs &a, int batch)
 {
     const dim3 grid((a.dst_nc + 63) / 64, (a.dst_nr + 15) / 16, batch);
-    hipLaunchKernelGGL((pyr_vreduce_kernel<4, 21>), grid, dim3(256), 0, s, a);
+    klt_launch((pyr_vreduce_kernel<4, 21>), grid, dim3(256), 0, s, a);
     return 0;
 }
 

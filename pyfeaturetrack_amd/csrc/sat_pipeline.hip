@@ -247,7 +247,7 @@ int launch_sat_rows_pipe(hipStream_t s, const float *gx, const float *gy, float 
         if (e != hipSuccess) return (int)e;
         set = true;
     }
-    hipLaunchKernelGGL(sat_rows_pipe, dim3((nrows + RB - 1) / RB), dim3(PIPE_THREADS), lds, s, gx, gy, sat, ncols, nrows);
+    klt_launch(sat_rows_pipe, dim3((nrows + RB - 1) / RB), dim3(PIPE_THREADS), (unsigned)lds, s, gx, gy, sat, ncols, nrows);
     return 0;
 }
 
@@ -261,6 +261,6 @@ int launch_sat_cols_pipe(hipStream_t s, float *sat, int ncols, int nrows)
         if (e != hipSuccess) return (int)e;
         set = true;
     }
-    hipLaunchKernelGGL(sat_cols_pipe, dim3((ncols + 63) / 64, 3), dim3(PIPE_THREADS), lds, s, sat, ncols, nrows);
+    klt_launch(sat_cols_pipe, dim3((ncols + 63) / 64, 3), dim3(PIPE_THREADS), (unsigned)lds, s, sat, ncols, nrows);
     return 0;
 }

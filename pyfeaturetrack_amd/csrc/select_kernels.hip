@@ -1288,7 +1288,7 @@ void launch_mis_prepare(hipStream_t s, const klt_feat *fl, int nfeat, int overwr
 void launch_eigen_hist(hipStream_t s, const SelectArgs &a)
 {
     const int blocks = (a.nx * a.ny + 255) / 256;
-    hipLaunchKernelGGL(eigen_hist_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, a);
+    klt_launch(eigen_hist_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, a);
     if (a.hist) hipLaunchKernelGGL(key_threshold_kernel, dim3(1), dim3(1024), 0, s, a.hist, a.hist_target, a.info, a.hist_slots, a.hist_per_slot);
 }
 

@@ -680,7 +680,7 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     // features in lock step lengthen)
     if (g_track_variant != 0 && a.window == 7 && (long long)a.n * ny >= 2048) {
         const dim3 gq(a.order ? 8 * ((a.order_chunk + 3) / 4) : (a.n + 3) / 4, ny);
-        hipLaunchKernelGGL((track_kernel_quad<BATCH, 7>), gq, block, 4 * lds, s, a);
+        klt_launch((track_kernel_quad<BATCH, 7>), gq, block, (unsigned)(4 * lds), s, a);
         return 0;
     }
     if (g_track_variant != 0 && a.window == 15) {
@@ -688,17 +688,17 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
         // occupancy target 5 (96 VGPRs, 40 bytes of scratch per lane instead of 107 VGPRs): the 5000 wavefronts of cfg-3 are then
         // resident at once instead of in two rounds -- 57.9 -> 49.3 us.  (The 7x7 kernel loses from the same cap: its spills land
         // in the Newton loop -- 143 -> 211 us at cfg-4.)
-        hipLaunchKernelGGL((track_kernel_quad<BATCH, 15, 5>), gq, block, lds, s, a);
+        klt_launch((track_kernel_quad<BATCH, 15, 5>), gq, block, (unsigned)lds, s, a);
         return 0;
     }
     const dim3 grid(a.order ? 8 * a.order_chunk : a.n, ny);
-    if (a.window == 7) hipLaunchKernelGGL((track_kernel<1, 7, BATCH>), grid, block, lds, s, a);
-    else if (a.window == 15) hipLaunchKernelGGL((track_kernel<4, 15, BATCH>), grid, block, lds, s, a);
-    else if (n <= 64) hipLaunchKernelGGL((track_kernel<1, 0, BATCH>), grid, block, lds, s, a);
-    else if (n <= 128) hipLaunchKernelGGL((track_kernel<2, 0, BATCH>), grid, block, lds, s, a);
-    else if (n <= 256) hipLaunchKernelGGL((track_kernel<4, 0, BATCH>), grid, block, lds, s, a);
-    else if (n <= 512) hipLaunchKernelGGL((track_kernel<8, 0, BATCH>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((track_kernel<16, 0, BATCH>), grid, block, lds, s, a);
+    if (a.window == 7) klt_launch((track_kernel<1, 7, BATCH>), grid, block, (unsigned)lds, s, a);
+    else if (a.window == 15) klt_launch((track_kernel<4, 15, BATCH>), grid, block, (unsigned)lds, s, a);
+    else if (n <= 64) klt_launch((track_kernel<1, 0, BATCH>), grid, block, (unsigned)lds, s, a);
+    else if (n <= 128) klt_launch((track_kernel<2, 0, BATCH>), grid, block, (unsigned)lds, s, a);
+    else if (n <= 256) klt_launch((track_kernel<4, 0, BATCH>), grid, block, (unsigned)lds, s, a);
+    else if (n <= 512) klt_launch((track_kernel<8, 0, BATCH>), grid, block, (unsigned)lds, s, a);
+    else klt_launch((track_kernel<16, 0, BATCH>), grid, block, (unsigned)lds, s, a);
     return 0;
 }
 

@@ -171,24 +171,26 @@ class ShardGather:
     """Device-side gather of a rank's [pairs_local x n_feat] record table to `root` (RCCL, libkltgpu's side stream).
 
     The table is one feature buffer (`fb_table`) whose rows are `klt_featbuf_view`s the tracker writes into, so a
-    shard is gathered with ONE collective.  Ranks own equal numbers of pairs (`n_pairs % world == 0`)."""
+    shard is gathered with ONE collective.  Shards may differ in size (`shard_range`: 7 or 257 pairs over 8 GPUs):
+    the gather carries a count per rank (`klt_gatherv_featbuf_async`); a rank whose shard is empty takes no part."""
 
-    def __init__(self, ctx, fb_table, fb_gathered, pairs_local, n_feat, root=0):
+    def __init__(self, ctx, fb_table, fb_gathered, n_pairs, n_feat, root=0):
         self.ctx, self.fb_table, self.fb_gathered = ctx, fb_table, fb_gathered
-        self.pairs_local, self.n_feat, self.root = pairs_local, n_feat, root
+        self.n_pairs, self.n_feat, self.root = n_pairs, n_feat, root
         self.world, self.rank = ctx.comm_info()
+        self.counts = [len(shard_range(n_pairs, self.world, r)) * n_feat for r in range(self.world)]
+        self.pairs_local = len(shard_range(n_pairs, self.world, self.rank))
 
     def gather_async(self):
-        self.ctx.gather_featbuf_async(self.fb_table, self.fb_gathered if self.rank == self.root else -1,
-                                      self.pairs_local * self.n_feat, self.root)
+        self.ctx.gatherv_featbuf_async(self.fb_table if self.pairs_local else -1,
+                                       self.fb_gathered if self.rank == self.root else -1, self.counts, self.root)
 
     def result(self):
-        """[world * pairs_local, n_feat] records on the root (synchronises), None elsewhere."""
+        """[n_pairs, n_feat] records in pair order on the root (synchronises), None elsewhere."""
         self.ctx.comm_wait()
         if self.rank != self.root:
             return None
-        n = self.world * self.pairs_local * self.n_feat
-        return self.ctx.featbuf_download(self.fb_gathered, n).reshape(self.world * self.pairs_local, self.n_feat)
+        return self.ctx.featbuf_download(self.fb_gathered, self.n_pairs * self.n_feat).reshape(self.n_pairs, self.n_feat)
 
 
 __all__ = ["shard_range", "world_from_env", "rendezvous_file", "exchange_ids", "init_communicators", "cleanup_rendezvous",

@@ -34,6 +34,7 @@ class _FrameStager:
         import threading
         self._frames, self._shape = frames, shape
         self._free, self._ready = queue.Queue(), queue.Queue()
+        self._stop = threading.Event()
         for b in buffers:
             self._free.put(b)
         self._thread = threading.Thread(target=self._run, name="klt-frame-stager", daemon=True)
@@ -42,12 +43,14 @@ class _FrameStager:
     def _run(self):
         try:
             for img in self._frames:
+                if self._stop.is_set():                     # closed: no further frame is pulled, no buffer written
+                    return
                 arr = image_to_array(img)
                 if arr.shape != self._shape or arr.dtype != np.uint8:
                     self._ready.put(("raw", arr))          # the calling thread deals with it (size error, or a synchronous upload)
                     continue
                 buf = self._free.get()
-                if buf is None:
+                if buf is None or self._stop.is_set():
                     return
                 buf[...] = arr
                 self._ready.put(("staged", buf))
@@ -65,8 +68,19 @@ class _FrameStager:
         self._free.put(buf)
 
     def close(self):
+        """Stops the helper thread: the stop flag is looked at before every frame and before every copy, the free queue is drained
+        (so that the thread cannot pick up a buffer any more) and the sentinel wakes a thread waiting for one.  Returns True when
+        the thread has ended -- only then may the staging buffers be handed to somebody else."""
+        import queue
+        self._stop.set()
+        try:
+            while True:
+                self._free.get_nowait()
+        except queue.Empty:
+            pass
         self._free.put(None)
         self._thread.join(timeout=2.0)       # (a frame source that blocks keeps its daemon thread; it touches no buffer any more)
+        return not self._thread.is_alive()
 
 
 def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True, prefetch=True):
@@ -103,7 +117,8 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
             tables.append(base)
         return tables[ci] + 1 + off
 
-    stage = ctx.staging((nrows, ncols), count=ring + 1) if async_ingest and first.dtype == np.uint8 else None
+    stage_key = ((nrows, ncols), ring + 1)
+    stage = ctx.staging(*stage_key) if async_ingest and first.dtype == np.uint8 else None
     in_flight = []                          # staging buffer whose host-to-device copy may still be running
 
     def ingest(slot, img, k, staged=False):
@@ -170,14 +185,25 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
             if nxt is not None and not prefetch:
                 stage_frame(k + 1, nxt)
     finally:
-        ctx.select_finish()                          # (only pending after an exception)
-        if stager is not None:
-            stager.close()
-        if prefetch:
-            ctx.set_option(_OPT_BUILD_STREAM, 0)
-        if affine:
-            ctx.set_option(_OPT_SELECT_AFFINE_STATE, -1)
-            ctx.release_affine_state(state)
+        # every step on its own: a failing one must not skip the rest (the options live on the shared default context)
+        try:
+            ctx.select_finish()                      # (only pending after an exception)
+        finally:
+            try:
+                if stager is not None and not stager.close():
+                    # the helper thread is still inside the caller's frame source: it may yet write one buffer of this set, so the
+                    # next call must not get the same pinned memory (a fresh set is allocated instead)
+                    ctx.staging_forget(*stage_key)
+            finally:
+                try:
+                    if prefetch:
+                        ctx.set_option(_OPT_BUILD_STREAM, 0)
+                finally:
+                    if affine:
+                        try:
+                            ctx.set_option(_OPT_SELECT_AFFINE_STATE, -1)
+                        finally:
+                            ctx.release_affine_state(state)
     nframes = k + 1
     ft = KLT_FeatureTable(nframes, nFeatures)
     for ci, base in enumerate(tables):

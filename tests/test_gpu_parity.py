@@ -833,10 +833,11 @@ def _run_bench(extra_args, **env_kw):
 def test_rccl_path_on_one_gpu(tmp_path):
     """bench.py's N > 1 code path -- rendezvous file, klt_comm_init_rank, the all-gather of the device-side record table on
     libkltgpu's side stream, barrier / max over ranks through klt_comm_allreduce_max -- with a single rank (no torch)."""
-    line = _run_bench(["--gpus", "1", "--steps", "6", "--warmup", "2", "--repeats", "5", "--no-cpu-baseline"],
+    line = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--repeats", "5", "--resident-pairs", "8", "--no-cpu-baseline", "--no-extras"],
                       KLT_FORCE_DIST="1", KLT_RDZV_FILE=str(tmp_path / "ids"))
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["tracked"] > 4500
     assert line["config"]["rccl_ranks"] == 1 and line["parity_checked"] is True and line["max_abs_dx"] <= 1e-3
+    assert line["parity_cases"] == 8 and line["config"]["resident_pairs"] == 8
 
 
 def test_cfg4_sharded_bench_with_native_gather(tmp_path):
@@ -845,6 +846,7 @@ def test_cfg4_sharded_bench_with_native_gather(tmp_path):
                       KLT_FORCE_DIST="1", KLT_RDZV_FILE=str(tmp_path / "ids"))
     assert line["config"]["pairs_per_step"] == 4 and line["config"]["rccl_ranks"] == 1 and line["config"]["gathered_table_ok"] is True
     assert line["parity_checked"] is True and line["scaling"] == "strong" and line["value"] > 0
+    assert 0 < line["roofline"]["step_frac"] < 1 and line["roofline"]["kernels"]["track"]["timed_by"] == "dispatch timestamps"
 
 
 def test_cfg5_blocks_with_the_baton_on_one_rank(tmp_path):
@@ -857,8 +859,9 @@ def test_cfg5_blocks_with_the_baton_on_one_rank(tmp_path):
     cfg = line["config"]
     assert line["n_gpus"] == 1 and cfg["rccl_ranks"] == 1 and line["value"] > 0
     assert cfg["baton_copy_ok"] is True and cfg["live_after_each_block"] == [20000]
-    plain = _run_bench(["--config", "cfg5", "--steps", "7"])
+    plain = _run_bench(["--config", "cfg5", "--steps", "7", "--repeats", "5"])
     assert plain["config"]["live_at_end"] == 20000 and plain["config"]["scores_prepared"] is True
+    assert plain["parity_checked"] is True and plain["roofline"]["step_frac"] < 1 and plain["cpu_baseline"]["value"] > 0
 
 
 def test_sendrecv_featbuf_to_oneself():
@@ -1720,8 +1723,8 @@ def test_two_rank_launch_reaches_rccl_on_one_gpu():
     from conftest import REPO
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KLT_RDZV_FILE")}
     env["KLT_RANKS_SHARE_DEVICE"] = "0"
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "5",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "5",
+                        "--resident-pairs", "4", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
     if r.returncode == 0:
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["parity_checked"] is True

@@ -1,0 +1,232 @@
+"""Round-3 GPU checks: cfg-3 at its own size with the affine consistency check on, the driver's bench command line, and a
+star-import driver (the reference's example1.py call sequence) through pyfeaturetrack_amd/compat in a fresh process."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from helpers import params_from_tc
+from pyfeaturetrack_amd import synth
+from pyfeaturetrack_amd.params import affine_params_from_tc
+
+pytestmark = pytest.mark.gpu
+
+W, H, NF = 1920, 1080, 5000
+STATE_FIELDS = ("valid", "aff_x", "aff_y", "Axx", "Ayx", "Axy", "Ayy", "pad")
+
+
+def cfg3_tc(mode):
+    import bench
+    tc = bench.cfg3_context()                      # 15x15, 4 levels / ss 2 (border 108), affine window 15x15
+    tc.affineConsistencyCheck = mode
+    return tc
+
+
+def shifted_frames():
+    import bench
+    return bench.cfg3_frames(4)                    # what `bench.py --config cfg3` times: pure translation by (1.1, -0.7) per frame
+
+
+def warped_frames():
+    """a small similarity + shear per frame on top of the translation: the affine matrices have something to converge to"""
+    base = synth.synth_base(W, H, 1)
+    A_step = np.array([[1.0015, 0.0012], [-0.0009, 0.9988]])
+    frames, A = [], np.eye(2)
+    for k in range(4):
+        frames.append(synth.warp_frame(base, A, (1.1 * k, -0.7 * k)))
+        A = A_step @ A
+    return frames
+
+
+def three_calls_gpu(frames, tc):
+    from pyfeaturetrack_amd.backend import Context
+    c = Context(0)
+    try:
+        c.configure(tc)
+        for k, f in enumerate(frames):
+            c.upload(k, f)
+        c.build_pyramids_batch(list(range(len(frames))), sync=True)
+        fl, placed = c.select(0, NF, use_pyramid=True)
+        assert placed == NF
+        c.affine_alloc(0, NF)
+        c.featbuf_upload(0, fl)
+        hist = [(fl.copy(), None)]
+        for k in range(1, len(frames)):
+            c.track_affine_async(k - 1, k, k - 1, k, NF, 0)          # through the asynchronous ABI entry point bench.py times
+            hist.append((c.featbuf_download(k, NF), c.affine_download(0, NF)))
+        return hist
+    finally:
+        c.close()
+
+
+def three_calls_oracle(frames, tc):
+    from oracle import klt_oracle as ko
+    p, ap = params_from_tc(tc), affine_params_from_tc(tc)
+    ko.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        f32 = [f.astype(np.float32) for f in frames]
+        fl = ko.select_good_features(p, f32[0], NF)
+        st = ko.AffineState(ap, NF)
+        P = [ko.Pyramids(p, f) for f in f32]
+        hist = [(fl.copy(), None)]
+        for k in range(1, len(frames)):
+            ko.track_features_affine(p, P[k - 1], P[k], fl, st)
+            hist.append((fl.copy(), st.rec.copy()))
+        return hist
+    finally:
+        ko.set_threads(1)
+
+
+def assert_same_history(g, o, what):
+    for k, ((gfl, grec), (ofl, orec)) in enumerate(zip(g, o)):
+        assert np.array_equal(gfl["val"], ofl["val"]), "%s, call %d: %d status codes differ" % (what, k, int((gfl["val"] != ofl["val"]).sum()))
+        assert np.array_equal(gfl["x"], ofl["x"]) and np.array_equal(gfl["y"], ofl["y"]), "%s, call %d: positions" % (what, k)
+        if grec is not None:
+            for name in STATE_FIELDS:
+                assert np.array_equal(grec[name], orec[name]), "%s, call %d: affine state field %s" % (what, k, name)
+
+
+@pytest.mark.parametrize("mode,frames_of", [(2, "shifted"), (2, "warped"), (1, "warped"), (0, "warped")])
+def test_cfg3_full_size_with_the_affine_check_on(mode, frames_of):
+    """BASELINE cfg-3 at its real geometry -- 1920x1080, 15x15 window, 4 levels / ss 2, 5000 features, four frames = three
+    KLTTrackFeatures calls (the first stores the templates, the second and third run the check; interface:
+    /root/reference trackFeatures.py:347-399) -- HIP == oracle on val, x, y and on valid, aff_x / aff_y, the four entries of A and
+    the iteration count of every feature, after every call.  Parity of the check itself is UNPINNED (the reference does not define
+    the functions it calls there); this is the implementation against the stated specification."""
+    frames = shifted_frames() if frames_of == "shifted" else warped_frames()
+    tc = cfg3_tc(mode)
+    g, o = three_calls_gpu(frames, tc), three_calls_oracle(frames, tc)
+    assert_same_history(g, o, "mode %d, %s frames" % (mode, frames_of))
+    last_fl, last_rec = g[-1]
+    assert (last_fl["val"] == 0).sum() > 0.9 * NF
+    live = last_fl["val"] == 0
+    assert last_rec["pad"][live].min() >= 1, "the check ran on every surviving feature"
+    if frames_of == "warped" and mode == 2:
+        want = np.linalg.matrix_power(np.array([[1.0015, 0.0012], [-0.0009, 0.9988]]), 3)
+        got = np.array([[np.median(last_rec["Axx"][live]), np.median(last_rec["Axy"][live])],
+                        [np.median(last_rec["Ayx"][live]), np.median(last_rec["Ayy"][live])]])
+        assert np.abs(got - want).max() < 4e-3, (got, want)
+
+
+def run_bench(extra_args, timeout=1200, **env_kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KLT_RDZV_FILE")}
+    env.update(env_kw)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + extra_args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_the_drivers_command_line_prints_a_clean_record():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` -- exactly what the driver runs at round end: no figure above its roof,
+    iteration counters that describe the launches they are divided by, 64 distinct pairs all checked against the oracle, a timed
+    phase long enough to be seen from outside the process, and a value that does not depend on K."""
+    line = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    roof = line["roofline"]
+    assert line["parity_checked"] is True and line["parity_cases"] == 64 and line["max_abs_dx"] <= 1e-3
+    assert line["config"]["resident_pairs"] == 64 and line["config"]["pairs_per_step"] == 64
+    assert 0 < roof["frac"] < 1 and 0 < roof["frac_moved"] < roof["frac"] and 0 < roof["step_frac"] < 1
+    assert roof["kernel"] == "smooth_grad_l0" and roof["launch_us_source"] == "dispatch timestamps"
+    for name, k in roof["kernels"].items():
+        assert 0 <= k["frac"] < 1 and k["GBps"] < roof["peak"], name
+    for l, it in enumerate(roof["newton_iterations_per_level"]):
+        assert 5000 <= it <= 25000, "level %d: %.0f Newton iterations per pair" % (l, it)
+    assert abs(roof["step_algorithmic_bytes"] / roof["step_algorithmic_bytes_formula"] - 1) < 1e-6
+    assert line["extra"]["region_ms_per_step"]["timed_s_total"] >= 2.0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1
+    # the same figures from a run with five times the steps per region
+    long = run_bench(["--gpus", "1", "--steps", "100", "--warmup", "5", "--repeats", "8", "--no-cpu-baseline", "--no-extras"])
+    assert abs(long["roofline"]["step_algorithmic_bytes"] / roof["step_algorithmic_bytes"] - 1) < 0.05
+    assert abs(long["value"] / line["value"] - 1) < 0.05, (long["value"], line["value"])
+
+
+def test_bench_refuses_figures_above_the_roof():
+    import bench
+    ok = {"roofline": {"peak": 8000.0, "frac": 0.4, "step_frac": 0.2, "kernels": {"track": {"GBps": 900.0, "frac": 0.11}}}}
+    assert bench.check_fractions(ok) == []
+    for path, bad in (("step_frac", {"roofline": {"peak": 8000.0, "frac": 0.4, "step_frac": 2.6}}),
+                      ("GBps", {"roofline": {"peak": 8000.0, "kernels": {"track": {"GBps": 72833.0, "frac": 0.5}}}}),
+                      ("frac_moved", {"roofline": {"frac_moved": 1.01}})):
+        assert any(path in m for m in bench.check_fractions(bad)), path
+    fd = os.open(os.devnull, os.O_WRONLY)
+    try:
+        with pytest.raises(SystemExit):
+            bench.emit(fd, {"roofline": {"peak": 8000.0, "frac": 0.4, "step_frac": 2.6}})
+    finally:
+        os.close(fd)
+
+
+@pytest.mark.parametrize("cfg,extra", [("cfg1", []), ("cfg3", ["--steps", "10", "--repeats", "5"])])
+def test_every_config_line_carries_checker_roofline_and_baseline(cfg, extra):
+    line = run_bench(["--config", cfg] + extra)
+    assert line["parity_checked"] is True, line
+    assert 0 < line["roofline"]["frac"] < 1 and 0 < line["roofline"]["step_frac"] < 1
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    if cfg == "cfg3":
+        k = line["roofline"]["kernels"]
+        assert k["affine_check"]["timed_by"] == "dispatch timestamps" and k["track"]["timed_by"] == "dispatch timestamps"
+        assert line["roofline"]["affine_iterations_per_checked_feature"] >= 1
+
+
+# a driver written the way scripts written against the reference are: star imports of the reference's module names, time.clock()
+STAR_IMPORT_DRIVER = '''
+from __future__ import print_function
+from klt import *
+from PIL import Image
+from selectGoodFeatures import *
+from writeFeatures import *
+from trackFeatures import *
+import time
+
+tc = KLT_TrackingContext()
+tc.nSkippedPixels = 0
+tc.max_residue = 10.0
+KLTPrintTrackingContext(tc)
+first, second = Image.open("img0.pgm"), Image.open("img1.pgm")
+features = KLTSelectGoodFeatures(tc, first, 50)
+for k, f in enumerate(features):
+    print("Feature #{0}:  ({1},{2}) with value of {3}".format(k, f.x, f.y, f.val))
+KLTWriteFeatureListToPPM(features, first, "feat1.ppm")
+calls, started = 0, time.clock()
+for _ in range(100):
+    KLTTrackFeatures(tc, first, second, features)
+    KLTTrackFeatures(tc, second, first, features)
+    calls += 2
+print("seconds per call", (time.clock() - started) / calls)
+print("remaining", KLTCountRemainingFeatures(features))
+for k, f in enumerate(features):
+    print("Feature #{0}:  ({1},{2}) with value of {3}".format(k, f.x, f.y, f.val))
+KLTWriteFeatureListToPPM(features, second, "feat2.ppm")
+'''
+
+
+def test_star_import_driver_through_compat(tmp_path, golden_dir):
+    """north_star: "example1.py runs unchanged".  A script that imports the reference's top-level module names with `import *` and
+    times itself with time.clock() (/root/reference example1.py:10-14, :17-65 -- the call sequence, not the file) runs in a fresh
+    process with only PYTHONPATH pointing at this repository and its compat directory; the two PPM files and the list after the
+    200-call ping-pong are the reference's own (tests/golden/example1.npz)."""
+    pytest.importorskip("PIL.Image")
+    import shutil
+    for name in ("img0.pgm", "img1.pgm"):
+        shutil.copy(os.path.join(golden_dir, name), tmp_path / name)
+    script = tmp_path / "driver.py"
+    script.write_text(STAR_IMPORT_DRIVER)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([REPO, os.path.join(REPO, "pyfeaturetrack_amd", "compat")]))
+    r = subprocess.run([sys.executable, str(script)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ex = np.load(os.path.join(golden_dir, "example1.npz"))
+    for name in ("feat1", "feat2"):
+        data = (tmp_path / (name + ".ppm")).read_bytes()
+        assert np.array_equal(np.frombuffer(hashlib.sha256(data).digest(), np.uint8), ex[name + "_ppm_sha"]), name
+    feats = [l for l in r.stdout.splitlines() if l.startswith("Feature #")]
+    assert len(feats) == 100
+    for k in range(50):
+        x, y, v = ex["pp_after_200_x"][k], ex["pp_after_200_y"][k], int(ex["pp_after_200_val"][k])
+        assert feats[50 + k] == "Feature #{0}:  ({1},{2}) with value of {3}".format(k, float(x), float(y), v), k
+    assert "remaining %d" % int((ex["pp_after_200_val"] >= 0).sum()) in r.stdout

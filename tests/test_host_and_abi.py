@@ -29,7 +29,7 @@ def test_library_exports_every_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     lib.klt_abi_version.restype = ctypes.c_int
-    assert lib.klt_abi_version() == 6
+    assert lib.klt_abi_version() == 7
 
 
 def test_struct_layouts():
@@ -240,3 +240,75 @@ def test_no_fma_contraction_in_the_device_code(tmp_path):
     assert not stray, "fused multiply-adds outside division / sqrt expansions: %r" % stray[:5]
     # the kernels that carry the reference's FP64 convolution arithmetic are FMA-free
     assert not [k for k in per_kernel if re.search(r"smooth_grad|pyr_|hconv|vconv|sat_", k)]
+
+
+def test_unloadable_rccl_is_an_error_not_a_crash(tmp_path):
+    """KLT_RCCL_LIB names a file that cannot be opened: klt_comm_unique_id returns KLT_ERR_DEVICE with a message that names the
+    path (round 2 built the message from two dlerror() calls -- the second returns NULL -- and crashed in strlen).  No GPU needed:
+    the library is opened before any HIP call.  Fresh process: the loaded RCCL is process-wide state."""
+    import subprocess
+    import sys
+    bogus = str(tmp_path / "not_rccl.so")
+    open(bogus, "wb").write(b"this is not a shared object")
+    code = (
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from pyfeaturetrack_amd import _abi\n"
+        "lib = _abi.load_library()\n"
+        "buf = (ctypes.c_uint8 * 128)()\n"
+        "rc = lib.klt_comm_unique_id(buf)\n"
+        "msg = (lib.klt_last_error(None) or b'').decode()\n"
+        "print('RC', rc)\n"
+        "print('MSG', msg)\n"
+        "rc2 = lib.klt_comm_unique_id(buf)\n"          # a second attempt fails the same way
+        "print('RC2', rc2)\n" % REPO)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KLT_RCCL_LIB=bogus), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RC -2" in r.stdout and "RC2 -2" in r.stdout, r.stdout
+    assert "cannot open librccl" in r.stdout and "not_rccl.so" in r.stdout, r.stdout
+
+
+def test_frame_stager_stops_when_closed():
+    """close() on the exception path: the helper thread pulls no further frame from the caller's iterator and writes no
+    staging buffer afterwards (it used to drain up to ring + 1 more frames into cached pinned buffers)."""
+    import threading
+    import time
+    from pyfeaturetrack_amd.trackSequence import _FrameStager
+    shape = (8, 8)
+    pulled = []
+    gate = threading.Event()
+
+    def frames():
+        for k in range(100):
+            if k == 2:
+                gate.wait(5.0)              # the consumer closes the stager while the source is producing frame 2
+            pulled.append(k)
+            yield np.full(shape, k, np.uint8)
+
+    bufs = [np.zeros(shape, np.uint8) for _ in range(4)]
+    st = _FrameStager(frames(), bufs, shape)
+    kind, b0 = st.next()
+    assert kind == "staged" and int(b0[0, 0]) == 0
+    kind, b1 = st.next()
+    assert int(b1[0, 0]) == 1
+    snapshot = [b.copy() for b in bufs]
+    closer = threading.Thread(target=lambda: (time.sleep(0.1), gate.set()))
+    closer.start()
+    ended = st.close()
+    closer.join()
+    time.sleep(0.2)
+    assert ended, "the helper thread is still alive"
+    assert max(pulled) <= 2, "frames pulled after close: %r" % pulled
+    assert all(np.array_equal(a, b) for a, b in zip(snapshot, bufs)), "a staging buffer was written after close()"
+
+
+def test_shard_gather_counts():
+    """ShardGather's per-rank counts (klt_gatherv_featbuf_async) for shards of unequal size: 7 and 257 pairs over 2 / 8 ranks."""
+    from pyfeaturetrack_amd.parallel import shard_range
+    for n_pairs, world in ((7, 2), (7, 8), (257, 8), (256, 8), (3, 8)):
+        counts = [len(shard_range(n_pairs, world, r)) * 2000 for r in range(world)]
+        assert sum(counts) == n_pairs * 2000
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        for r in range(world):
+            sr = shard_range(n_pairs, world, r)
+            assert offs[r] == (sr.start if len(sr) else offs[r]) * 2000 or not len(sr)

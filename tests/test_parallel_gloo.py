@@ -106,7 +106,25 @@ def test_bench_launcher_spawns_its_own_ranks():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
-    assert line == {"dryrun": True, "n_gpus": 2, "ids_agree": True, "pairs_covered": True, "local_ranks": [0, 1], "spawned": True}
+    assert line == {"dryrun": True, "n_gpus": 2, "ids_agree": True, "pairs_covered": True, "gatherv_counts": [4, 3], "local_ranks": [0, 1],
+                    "spawned": True}
+
+
+def test_bench_launcher_with_shards_of_unequal_size():
+    """7 and 257 pairs over 2 ranks (and 3 pairs over 4: one rank owns nothing): every pair is covered exactly once."""
+    for gpus, pairs in ((2, 7), (2, 257), (4, 3)):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--config", "cfg4", "--pairs", str(pairs)],
+                           env=_clean_env(), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+        assert line["pairs_covered"] and line["ids_agree"] and line["n_gpus"] == gpus, line
+        assert line["gatherv_counts"] == [len(range(*divmod_range(pairs, gpus, k))) for k in range(gpus)], line
+
+
+def divmod_range(n, world, rank):
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
 
 
 def test_bench_launcher_reports_a_failed_rank():
