@@ -1034,6 +1034,8 @@ def run_cfg2(args, json_fd):
     for c in range(nctx):
         cx = Context(ranks.local_rank)
         cx.set_params(p)
+        if args.l0_stream:
+            cx.set_option(17, 1)                 # KLT_OPT_L0_STREAM
         for lp in range(PL):
             f0, f1 = frames[pair_index(c, lp)]
             cx.upload(2 * lp, f0)
@@ -1200,16 +1202,27 @@ def run_cfg2(args, json_fd):
             ctx.select_async(2 * (k % PL), 1, True, FB_MISC, NFEAT)      # SELECTING_ALL on a resident level-0 pyramid
         ctx.sync()
         ms_select = (time.perf_counter() - t) / reps * 1e3
-        singles = []
-        for _ in range(5):
-            t = time.perf_counter()
-            for i in range(4 * PL):                              # ONE stream, one pair in flight, rotating through the context's pairs
-                lp = i % PL
-                ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
-                ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp, NFEAT)
-            ctx.sync()
-            singles.append((time.perf_counter() - t) / (4 * PL) * 1e3)
+        def one_pair_at_a_time():
+            runs = []
+            for _ in range(5):
+                t = time.perf_counter()
+                for i in range(4 * PL):                          # one pair per build / tracker call, rotating through the context's pairs
+                    lp = i % PL
+                    ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
+                    ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp, NFEAT)
+                ctx.sync()
+                runs.append((time.perf_counter() - t) / (4 * PL) * 1e3)
+            return runs
+
+        # ONE context, the calls of one pair after the other.  With KLT_OPT_L0_STREAM the level-0 kernel of pair k + 1 runs on the
+        # context's second stream next to levels >= 1 and the tracker of pair k; without it everything is one in-order stream
+        ctx.set_option(17, 1)
+        ctx_runs = one_pair_at_a_time()
+        ctx.set_option(17, 0)
+        singles = one_pair_at_a_time()
+        ctx.set_option(17, 1 if args.l0_stream else 0)
         ms_single = statistics.median(singles)
+        ms_one_ctx = statistics.median(ctx_runs)
         # round 2's headline arrangement: every context rebuilds the SAME two pairs (four slots) over and over, so the pyramid planes
         # the tracker reads are still in the Infinity Cache
         nrep = 8 * NG
@@ -1283,12 +1296,15 @@ def run_cfg2(args, json_fd):
                  "pcie_pipelined_ms_per_pair": ms_pipe, "pcie_pipelined_features_per_s": NFEAT / (ms_pipe * 1e-3),
                  "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "latency_ms_per_pair_synchronised": ms_latency,
                  "single_stream_ms_per_pair": ms_single, "single_stream_features_per_s": NFEAT / (ms_single * 1e-3),
+                 "one_context_ms_per_pair": ms_one_ctx, "one_context_features_per_s": NFEAT / (ms_one_ctx * 1e-3),
                  "single_stream_runs_ms": singles,
                  "ms_per_select_5000": ms_select,
                  "pcie_inclusive_ms_per_pair": ms_pcie, "pcie_inclusive_features_per_s": NFEAT / (ms_pcie * 1e-3),
-                 "note": "ms_per_frame_pair = single_stream_ms_per_pair: one pair at a time on ONE stream, rotating through the resident "
-                         "pairs, no overlap with other pairs (ms_per_step / pairs_per_step = overlapped_ms_per_pair is the inverse "
-                         "throughput with pairs_in_flight pairs overlapping).  cache_resident = round 2's headline arrangement: every "
+                 "note": "ms_per_frame_pair = one_context_ms_per_pair: ONE context, one pair per call, rotating through the resident pairs -- "
+                         "a caller's plain loop of klt_build_pyramids_batch_async + klt_track_async; KLT_OPT_L0_STREAM lets the level-0 kernel of "
+                         "the next pair run on the context's second stream next to levels >= 1 and the tracker of this one "
+                         "(single_stream_ms_per_pair: the same loop with the option off, everything on one in-order stream; ms_per_step / "
+                         "pairs_per_step = overlapped_ms_per_pair is the inverse throughput with pairs_in_flight pairs overlapping).  cache_resident = round 2's headline arrangement: every "
                          "context rebuilds the same four frame slots, which then never leave the 256 MB Infinity Cache.  pcie_inclusive "
                          "= H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the records, synchronised per "
                          "pair; pcie_pipelined = the same bytes with klt_upload_u8_async from pinned memory on a copy stream and the "
@@ -1308,7 +1324,7 @@ def run_cfg2(args, json_fd):
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         line = base_line(world * NP * NFEAT * args.steps / elapsed, world, args.steps, args.warmup, ms_per_step,
-                         ms_single if ms_single is not None else ms_per_pair,
+                         ms_one_ctx if ms_single is not None else ms_per_pair,
                          "cfg-2: %d DISTINCT 1920x1080 synthetic pairs resident per GPU (seeds %d..%d; own frame slots, pyramids and "
                          "feature lists: %.1f GB), 5000 features each, 7x7 window, 3 pyramid levels (subsampling 4), translation only; "
                          "a step = one pass of pyramid build + tracking over all of them (%d KLTTrackFeatures-equivalents); inputs "
@@ -1322,7 +1338,7 @@ def run_cfg2(args, json_fd):
                                              "; the %d pairs of a group share every launch of their context: one batched pyramid "
                                              "build for their %d frames, one tracker launch for their %d feature lists -- every pair still "
                                              "gets the full work of one KLTTrackFeatures call" % (B, 2 * B, B))),
-                             "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "resident_pairs": NP,
+                             "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "resident_pairs": NP, "l0_stream": bool(args.l0_stream),
                              "features_per_pair": NFEAT, "pairs_per_step": NP * world, "ms_per_pair": ms_per_pair, "tracked": tracked,
                              "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
                              "rccl_ranks": world if distributed else 0,
@@ -1398,6 +1414,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="contexts per GPU (one HIP stream each, no events between them): consecutive groups of --batch pairs go "
                          "round-robin to them, so kernels of different groups overlap; 1 = a single stream")
+    ap.add_argument("--l0-stream", type=int, default=1, choices=[0, 1],
+                    help="KLT_OPT_L0_STREAM of every context: 1 (default) = the level-0 kernel of a build on the context's second HIP stream, "
+                         "levels >= 1 and the tracker on its main stream")
     ap.add_argument("--batch", type=int, default=2, choices=[1, 2, 4, 8],
                     help="pairs that share every launch of a context: one batched pyramid build for their frames and one tracker launch "
                          "for their feature lists")

@@ -77,6 +77,7 @@ SYMBOLS = {
     "klt_slot_free": (_I, [_P, _I]),
     "klt_swap_slots": (_I, [_P, _I, _I]),
     "klt_featbuf_upload": (_I, [_P, _I, _P, _I]),
+    "klt_featbuf_upload_async": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_download": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_alloc": (_I, [_P, _I, _I]),
     "klt_featbuf_view": (_I, [_P, _I, _I, _I, _I]),

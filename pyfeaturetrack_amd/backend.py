@@ -213,6 +213,10 @@ class Context:
         """True while the slot's pyramids are built and match the current parameters."""
         return bool(self._check(self._lib.klt_slot_state(self._h, slot)) & 2)
 
+    def frame_resident(self, slot):
+        """True while the slot holds a frame (raw pixels on the device)."""
+        return bool(self._check(self._lib.klt_slot_state(self._h, slot)) & 1)
+
     def swap_slots(self, a, b):
         self._check(self._lib.klt_swap_slots(self._h, a, b))
 
@@ -258,6 +262,38 @@ class Context:
         placed = C.c_int()
         self._check(self._lib.klt_select(self._h, slot, mode, int(bool(use_pyramid)), fl.ctypes.data, len(fl), C.byref(placed)))
         return fl, placed.value
+
+    def host_records(self, n):
+        """(in, out): two pinned arrays of n klt_feat records, cached per length -- the host side of the reference-shaped API's
+        lists (no staging copy inside the runtime, and the copies can be asynchronous).  Valid until the next call that uses them."""
+        cache = self.__dict__.setdefault("_host_records", {})
+        pair = cache.get(n)
+        if pair is None:
+            pair = cache[n] = (self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n], self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n])
+        return pair
+
+    def select_records(self, slot, n, mode=SELECTING_ALL, use_pyramid=False, fb=65533):
+        """klt_select for the host API without its spare round trips: SELECTING_ALL needs no list on the way in (every slot is
+        written), REPLACING_SOME sends host_records(n)[0] (filled by the caller) without waiting for the copy; one download brings
+        the records back into host_records(n)[1], which is returned."""
+        rin, rout = self.host_records(n)
+        if mode == REPLACING_SOME:
+            self._check(self._lib.klt_featbuf_upload_async(self._h, fb, rin.ctypes.data, n))
+        self._check(self._lib.klt_select_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))
+        self._check(self._lib.klt_featbuf_download(self._h, fb, rout.ctypes.data, n))
+        return rout
+
+    def track_records(self, slot1, slot2, n, state=None, fb_in=65534, fb_out=65535):
+        """klt_track / klt_track_affine on host_records(n): [0] (filled by the caller) goes up without waiting for the copy, the
+        tracked records come back in [1], which is returned."""
+        rin, rout = self.host_records(n)
+        self._check(self._lib.klt_featbuf_upload_async(self._h, fb_in, rin.ctypes.data, n))
+        if state is None:
+            self._check(self._lib.klt_track_async(self._h, slot1, slot2, fb_in, fb_out, n))
+        else:
+            self._check(self._lib.klt_track_affine_async(self._h, slot1, slot2, fb_in, fb_out, n, state))
+        self._check(self._lib.klt_featbuf_download(self._h, fb_out, rout.ctypes.data, n))
+        return rout
 
     def select_async(self, slot, mode, use_pyramid, fb, n):
         self._check(self._lib.klt_select_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))

@@ -274,8 +274,10 @@ __device__ __forceinline__ void widen12(const float *row, double *d)
 // reduction kernel -- with its halo re-reads of the level-0 image, its 1.6x redundant horizontal pass and its latency-bound
 // tile loads -- disappears for level 1.  Same values: the tile is addressed in virtual coordinates whose smoothed values equal
 // the reflected ones (header of this file), which is what the reference's reduction reads beyond the frame edge.
-template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_, int NTHR = 256, bool HRED = false>
-__global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradArgs a)
+// EDGE = false: the instantiation for tiles whose outputs all land inside the frame (every tile but the last row / column of tiles of
+// a frame whose size is not a multiple of the tile): the per-row and per-column store predicates fold away.
+template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_, int NTHR, bool HRED, bool EDGE>
+__device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, float *const lds, const int nc, const int nr)
 {
     static_assert(!HRED || SMOOTH, "the fused horizontal reduction needs the smoothing stages");
     constexpr int HB = HRED ? 12 : 4;                           // halo columns of the image tile (B, C) on each side
@@ -291,13 +293,12 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
     // 2040 tiles of a 1080p pair are two full rounds of the 1024 slots (44 KB / three per CU before: 2.66 rounds).
     // Without smoothing (gradients of levels >= 1): C, then D E.
     constexpr int AC = SMOOTH ? (RH * AW > IH * BW ? RH * AW : IH * BW) : IH * BW;
-    constexpr int BDE = SMOOTH ? (RH * BW > 2 * IH * DW ? RH * BW : 2 * IH * DW) : 2 * IH * DW;
-    __shared__ __attribute__((aligned(16))) float lds[AC + BDE];
     float *const A = lds, *const C = lds, *const B = lds + AC, *const D = lds + AC, *const E = lds + AC + IH * DW;
     const int tid = threadIdx.x, b = blockIdx.z;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
-    const int nc = a.dim_c[b] ? a.dim_c[b] : a.ncols, nr = a.dim_r[b] ? a.dim_r[b] : a.nrows;
-    if (tx0 >= nc || ty0 >= nr) return;              // entries smaller than the grid extent (mixed pyramid levels)
+    // two adjacent outputs go out as one 8-byte store where every row of the planes keeps them aligned (block-uniform)
+    const bool vec2_ok = (nc & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.img[b]) | reinterpret_cast<uintptr_t>(a.gx[b]) |
+                                            reinterpret_cast<uintptr_t>(a.gy[b])) & 7) == 0;
     const TIn *__restrict__ raw = (const TIn *)a.raw[b];
     TapRegs<NG> kg;
     TapRegs<ND> kd;
@@ -428,10 +429,14 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
                 o.x = corr_regs<NS, 1>(v[0] + rs + dr, ks); o.y = corr_regs<NS, 1>(v[1] + rs + dr, ks);
                 *reinterpret_cast<float2 *>(C + rr * BW + 2 * h) = o;
                 const int y = ty0 - R + rr, x = tx0 - HB + 2 * h;
-                if (rr >= R && rr < R + TH_ && h >= HB / 2 && h < HB / 2 + DW / 2 && y < nr) {
+                if (rr >= R && rr < R + TH_ && h >= HB / 2 && h < HB / 2 + DW / 2 && (!EDGE || y < nr)) {
                     float *dstp = img + (size_t)y * nc + x;
-                    if (x < nc) dstp[0] = o.x;
-                    if (x + 1 < nc) dstp[1] = o.y;
+                    if (!EDGE && vec2_ok) *reinterpret_cast<float2 *>(dstp) = o;      // x is even
+                    else if (!EDGE) { dstp[0] = o.x; dstp[1] = o.y; }
+                    else {
+                        if (x < nc) dstp[0] = o.x;
+                        if (x + 1 < nc) dstp[1] = o.y;
+                    }
                 }
             }
         }
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
 #pragma unroll
                 for (int jj = -HR; jj < 0; jj++) acc = acc + (c[jj] + c[-jj]) * kr.k[HR + jj];
                 const int xg = tx0 / 4 + xs + o;
-                if (y < nr && xg < h1_nc) h1[(size_t)y * h1_nc + xg] = (float)acc;
+                if (!EDGE || (y < nr && xg < h1_nc)) h1[(size_t)y * h1_nc + xg] = (float)acc;
             }
         }
     }
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
     for (int i = tid; i < (TH_ / 4) * DH; i += NTHR) {
         const int r = 4 * (i / DH), h = i % DH;
         const int x = tx0 + 2 * h;
-        if (ty0 + r >= nr || x >= nc) continue;
+        if (EDGE && (ty0 + r >= nr || x >= nc)) continue;
         float2 ox[4], oy[4];
         {
             double v[2][NG + 3];
@@ -530,13 +535,35 @@ __global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradA
 #pragma unroll
         for (int dr = 0; dr < 4; dr++) {
             const int y = ty0 + r + dr;
-            if (y >= nr) break;
+            if (EDGE && y >= nr) break;
             float *px = gxo + (size_t)y * nc + x, *py = gyo + (size_t)y * nc + x;
-            px[0] = ox[dr].x; py[0] = oy[dr].x;
-            if (x + 1 < nc) { px[1] = ox[dr].y; py[1] = oy[dr].y; }
+            if (!EDGE && vec2_ok) {
+                *reinterpret_cast<float2 *>(px) = ox[dr]; *reinterpret_cast<float2 *>(py) = oy[dr];
+            } else {
+                px[0] = ox[dr].x; py[0] = oy[dr].x;
+                if (!EDGE || x + 1 < nc) { px[1] = ox[dr].y; py[1] = oy[dr].y; }
+            }
         }
     }
     STAGE_MARK(5);
+}
+
+template <typename TIn, bool SMOOTH, int NS, int NG, int ND, int TH_, int NTHR = 256, bool HRED = false>
+__global__ __launch_bounds__(NTHR, KLT_L0_WAVES) void smooth_grad_rb(SmoothGradArgs a)
+{
+    constexpr int HB = HRED ? 12 : 4, rs = SMOOTH ? NS / 2 : 0, R = (NG > ND ? NG : ND) / 2;
+    constexpr int AW = TW + 2 * HB + 8, BW = TW + 2 * HB, DW = TW, IH = TH_ + 2 * R, RH = IH + 2 * rs;
+    constexpr int AC = SMOOTH ? (RH * AW > IH * BW ? RH * AW : IH * BW) : IH * BW;
+    constexpr int BDE = SMOOTH ? (RH * BW > 2 * IH * DW ? RH * BW : 2 * IH * DW) : 2 * IH * DW;
+    __shared__ __attribute__((aligned(16))) float lds[AC + BDE];
+    const int b = blockIdx.z;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
+    const int nc = a.dim_c[b] ? a.dim_c[b] : a.ncols, nr = a.dim_r[b] ? a.dim_r[b] : a.nrows;
+    if (tx0 >= nc || ty0 >= nr) return;              // entries smaller than the grid extent (mixed pyramid levels)
+    // every output of the tile inside the frame (and, with the fused reduction, inside the H1 plane): block-uniform
+    const bool inside = tx0 + TW <= nc && ty0 + TH_ <= nr && (!HRED || tx0 / 4 + TW / 4 <= a.h1_nc);
+    if (inside) smooth_grad_rb_tile<TIn, SMOOTH, NS, NG, ND, TH_, NTHR, HRED, false>(a, lds, nc, nr);
+    else smooth_grad_rb_tile<TIn, SMOOTH, NS, NG, ND, TH_, NTHR, HRED, true>(a, lds, nc, nr);
 }
 
 // The f32-rounded horizontal result is kept in LDS as the double it widens to (one widening per sample instead of one

@@ -234,18 +234,66 @@ class KLT_Feature:
         self._s.reset_affine(self._i)
 
 
+class KLT_FeatureList(list):
+    """The list KLTSelectGoodFeatures / KLTCreateFeatureList hand out (the reference builds `[KLT_Feature() for i in
+    range(nFeatures)]`, selectGoodFeatures.py:143; its own KLT_FeatureList is commented out, klt.py:266-270).  It IS a list of
+    KLT_Feature objects -- but the 5000 Python objects of a cfg-2 list cost 1.1 ms to create, four times what the device needs to
+    select the features, and a tracking loop that only hands the list from one KLT* call to the next never looks at one of them.
+    The objects are therefore made when somebody first touches an element (indexing, iteration, any list method); `len()`,
+    truth value and the KLT* calls themselves work on the column store and do not."""
+
+    __slots__ = ("_store", "_pending")
+
+    def __init__(self, store):
+        list.__init__(self)
+        self._store = store
+        self._pending = len(store)
+
+    def _fill(self):
+        n = self._pending
+        if n:
+            self._pending = 0
+            store = self._store
+            list.extend(self, [KLT_Feature(store, i) for i in range(n)])
+            store.features = list(self)         # a private copy: the caller's list may be edited
+
+    def __len__(self):
+        return self._pending or list.__len__(self)
+
+    def __reduce_ex__(self, protocol):
+        self._fill()
+        return (list, (list(self),))            # pickles (and copies) as the plain list of features it stands for
+
+
+def _filled_first(name):
+    inherited = getattr(list, name)
+
+    def method(self, *args, **kw):
+        self._fill()
+        return inherited(self, *args, **kw)
+    method.__name__ = name
+    method.__doc__ = inherited.__doc__
+    return method
+
+
+for _name in ("__getitem__", "__setitem__", "__delitem__", "__iter__", "__reversed__", "__contains__", "__add__", "__iadd__", "__mul__",
+              "__imul__", "__rmul__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__repr__", "append", "extend", "insert", "pop",
+              "remove", "clear", "index", "count", "sort", "reverse", "copy"):
+    setattr(KLT_FeatureList, _name, _filled_first(_name))
+KLT_FeatureList.__hash__ = None
+
+
 def new_feature_list(n):
     """n lost features sharing one column store (what KLTSelectGoodFeatures / KLTCreateFeatureList hand out)."""
-    store = _FeatureStore(n)
-    fl = [KLT_Feature(store, i) for i in range(n)]
-    store.features = list(fl)         # a private copy: the caller's list may be edited
-    return fl
+    return KLT_FeatureList(_FeatureStore(n))
 
 
 def shared_store(featurelist):
     """The _FeatureStore whose rows 0 .. n-1 are exactly this list's features, in order -- or None (a list assembled by hand,
     re-ordered, or mixing features of several lists), in which case callers fall back to per-feature access.  The test is one
     C-level list comparison (identity of every element)."""
+    if type(featurelist) is KLT_FeatureList and featurelist._pending:
+        return featurelist._store           # nobody has looked at an element yet: the list is the store's rows by construction
     try:
         s = featurelist[0]._s
     except (IndexError, AttributeError):

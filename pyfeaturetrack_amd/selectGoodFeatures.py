@@ -37,10 +37,12 @@ def _image_size(img):
     return img.size
 
 
-def features_to_array(featurelist):
-    """KLT_Feature list -> record array.  A list whose features share one column store (every list this package hands out)
-    is converted column by column; anything else feature by feature."""
-    fl = np.zeros(len(featurelist), FEAT_DTYPE)
+def features_to_array(featurelist, out=None):
+    """KLT_Feature list -> record array (`out`, or a new one).  A list whose features share one column store (every list this
+    package hands out) is converted column by column; anything else feature by feature."""
+    fl = np.zeros(len(featurelist), FEAT_DTYPE) if out is None else out
+    if out is not None:
+        fl["aux"] = 0
     store = shared_store(featurelist)
     if store is not None:
         fl["x"], fl["y"], fl["val"] = store.x, store.y, store.val
@@ -89,23 +91,41 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
     slots = _slots_of(tc)
     if featurelist is None:
         featurelist = new_feature_list(nFeatures)
+    from ._frames import FrameKey, cache_of, send_frame, settle_frames
     reuse = (mode == selectionMode.REPLACING_SOME and tc.sequentialMode and tc.pyramid_last is not None
              and ctx.pyramids_valid(slots[0]))
     if reuse:
         slot = slots[0]            # selectGoodFeatures.py:176-181: level 0 of the pyramids kept from the last track
+    elif tc.smoothBeforeSelecting:
+        # The smoothed image and its gradients ARE level 0 of the image's pyramids (same taps: selectGoodFeatures.py:183-197 and
+        # trackFeatures.py:165-172).  An image one of the two frame slots already holds (_frames.py) is neither uploaded nor
+        # smoothed again; a new one goes to the slot the next KLTTrackFeatures call will look for it in (frame 1 -- or frame 2 while
+        # sequential mode keeps the last frame in slot 1) and gets its whole pyramid, which that call then does not build.
+        frames = cache_of(tc)
+        key = FrameKey(img)
+        slot = frames.find(img, key, slots[:2], ctx)
+        if slot is None:
+            slot = slots[1] if (tc.sequentialMode and tc.pyramid_last is not None) else slots[0]
+            send_frame(ctx, slot, image_to_array(img))
+            frames.note(slot, key)
+            ctx.build_pyramids(slot, sync=False)
+        elif not ctx.pyramids_valid(slot):
+            ctx.build_pyramids(slot, sync=False)
+        reuse = True
     else:
-        slot = slots[2]
+        slot = slots[2]            # gradients of the raw frame: nothing a pyramid holds
         ctx.upload(slot, image_to_array(img))
-    fl_in = features_to_array(featurelist) if mode == selectionMode.REPLACING_SOME else None
+    fl_in = features_to_array(featurelist, ctx.host_records(len(featurelist))[0]) if mode == selectionMode.REPLACING_SOME else None
     from .trackFeatures import affine_state_lookup
     aff = affine_state_lookup(ctx, featurelist)
     if aff is not None and aff[1] == len(featurelist):
         ctx.set_option(4, aff[0])       # newly placed features lose their affine templates (:120-128)
     try:
-        fl, _ = ctx.select(slot, len(featurelist), mode=mode, fl=fl_in, use_pyramid=reuse)
+        fl = ctx.select_records(slot, len(featurelist), mode=mode, use_pyramid=reuse)
     finally:
         if aff is not None:
             ctx.set_option(4, -1)
+    settle_frames(ctx, _image_size(img)[::-1])
     affine_used = aff is not None or tc.affineConsistencyCheck >= 0     # otherwise the affine fields were never assigned
     vals = fl["val"]
     olds = fl_in["val"] if mode == selectionMode.REPLACING_SOME else None

@@ -10,6 +10,7 @@ from __future__ import print_function
 from . import selectGoodFeatures as _sgf
 from .backend import default_context
 from .klt import KLTCountRemainingFeatures, kltState, shared_store  # noqa: F401
+from ._frames import FrameKey, KLTForgetFrames, cache_of, send_frame, settle_frames  # noqa: F401
 from .selectGoodFeatures import _fix_window, _image_size, _slots_of, features_to_array, image_to_array
 # the reference binds the name at import (trackFeatures.py:7 `from selectGoodFeatures import KLT_verbose`): this module has its own
 # switch, and setting selectGoodFeatures.KLT_verbose later does not reach it
@@ -101,24 +102,48 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
             from .error import KLTError
             KLTError("(KLTTrackFeatures) Size of incoming image ({0} by {1}) is different from size of previous image "
                      "({2} by {3})".format(ncols, nrows, tc.pyramid_last.ncols[0], tc.pyramid_last.nrows[0]))
-        ctx.upload(s2, image_to_array(img2))
-        ctx.build_pyramids(s2, sync=False)
+        frames = cache_of(tc)
+        k2 = FrameKey(img2)
+        if frames.find(img2, k2, (s2,), ctx) is None:
+            send_frame(ctx, s2, image_to_array(img2))
+            frames.note(s2, k2)
+            ctx.build_pyramids(s2, sync=False)
+        elif not ctx.pyramids_valid(s2):
+            ctx.build_pyramids(s2, sync=False)
     else:
-        ctx.upload(s1, image_to_array(img1))
-        ctx.upload(s2, image_to_array(img2))
-        ctx.build_pyramids_batch([s1, s2])            # both frames share every kernel launch
+        # A slot that already holds one of the two images (same object, size and sampled content -- _frames.py) keeps it: the
+        # reference converts and rebuilds both on every call, example1's ping-pong (example1.py:53-56) the same two 200 times.
+        frames = cache_of(tc)
+        k1, k2 = FrameKey(img1), FrameKey(img2)
+        at1, at2 = frames.find(img1, k1, (s1, s2), ctx), frames.find(img2, k2, (s1, s2), ctx)
+        if at1 == s2 or at2 == s1:                    # the pair arrives the other way round (or shifted by one frame)
+            ctx.swap_slots(s1, s2)
+            frames.swap(s1, s2)
+            at1 = {s1: s2, s2: s1}.get(at1)
+            at2 = {s1: s2, s2: s1}.get(at2)
+        build = []
+        for slot, img, key, at in ((s1, img1, k1, at1), (s2, img2, k2, at2)):
+            if at != slot:
+                send_frame(ctx, slot, image_to_array(img))
+                frames.note(slot, key)
+                build.append(slot)
+            elif not ctx.pyramids_valid(slot):        # the frame is there, the pyramid geometry / taps changed since
+                build.append(slot)
+        if build:
+            ctx.build_pyramids_batch(build)           # frames share every kernel launch
 
-    fl_in = features_to_array(featurelist)
+    nfeat = len(featurelist)
+    fl_in = features_to_array(featurelist, ctx.host_records(nfeat)[0])      # pinned: goes up without a staging copy
     affine = tc.affineConsistencyCheck >= 0
     if affine:
         # The reference calls _am_trackFeatureAffine here but never defines it (trackFeatures.py:347-399); behaviour
         # follows upstream KLT 1.3.4.  The per-feature templates / A matrices live on the device, keyed
         # by the feature list object.
         state = _affine_state_of(tc, ctx, featurelist)
-        fl_out, _ = ctx.track_affine(s1, s2, fl_in, state)
-        rec = ctx.affine_download(state, len(featurelist))
+        fl_out = ctx.track_records(s1, s2, nfeat, state)
+        rec = ctx.affine_download(state, nfeat)
     else:
-        fl_out, _ = ctx.track(s1, s2, fl_in)
+        fl_out = ctx.track_records(s1, s2, nfeat)
     store = shared_store(featurelist)
     if store is not None:
         # whole columns at once (the reference walks the list: trackFeatures.py:288-399)
@@ -167,8 +192,10 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
                 feat.val = vals[i]
                 feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = None
 
+    settle_frames(ctx, (nrows, ncols))                # (the results are back: the staged frames left their buffers long ago)
     if tc.sequentialMode:
         ctx.swap_slots(s1, s2)                        # frame-2 pyramids become frame 1 (:401-404)
+        cache_of(tc).swap(s1, s2)
         tc.pyramid_last = _ResidentPyramids(s1, ncols, nrows, "img")
         tc.pyramid_last_gradx = _ResidentPyramids(s1, ncols, nrows, "gradx")
         tc.pyramid_last_grady = _ResidentPyramids(s1, ncols, nrows, "grady")

@@ -95,6 +95,8 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
     ctx = default_context()
     ctx.configure(tc)
     s = list(_slots_of(tc))              # ring of three frame slots (the third is otherwise the per-frame API's selection slot)
+    from ._frames import cache_of
+    cache_of(tc).forget()               # this call fills the slots itself: what the per-frame API remembers of them is void
     ring = 3 if prefetch else 2
     first = image_to_array(next(frames))
     rows = [first]

@@ -16,7 +16,32 @@ from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures      # noqa: E402
 from pyfeaturetrack_amd.trackSequence import KLTTrackSequence      # noqa: E402
 
 
+def profile():
+    """cProfile of 200 KLTTrackFeatures / KLTSelectGoodFeatures calls (the same two frames): where the host time of a call goes"""
+    import cProfile
+    import pstats
+    w, h, n = 1920, 1080, 5000
+    sgf.KLT_verbose = tf.KLT_verbose = 0
+    tc = KLT_TrackingContext()
+    tc.nPyramidLevels, tc.subsampling = 3, 4
+    tc.KLTUpdateTCBorder()
+    base = synth.synth_base(w, h, 1)
+    f0, f1 = synth.shift_frame(base, 0, 0), synth.shift_frame(base, 3.3, -2.1)
+    fl = sgf.KLTSelectGoodFeatures(tc, f0, n)
+    KLTTrackFeatures(tc, f0, f1, fl)
+    for name, fn in (("track", lambda: KLTTrackFeatures(tc, f0, f1, sgf.KLTSelectGoodFeatures(tc, f0, n))),):
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(200):
+            fn()
+        pr.disable()
+        st = pstats.Stats(pr, stream=sys.stderr)
+        st.sort_stats("tottime").print_stats(22)
+
+
 def main():
+    if "--profile" in sys.argv:
+        return profile()
     w, h, n = 1920, 1080, 5000
     sgf.KLT_verbose = tf.KLT_verbose = 0       # (each module has its own switch, as in the reference)
     tc = KLT_TrackingContext()
@@ -25,16 +50,30 @@ def main():
     base = synth.synth_base(w, h, 1)
     f0, f1 = synth.shift_frame(base, 0, 0), synth.shift_frame(base, 3.3, -2.1)
     out = {}
-    for rep in range(3):
+    sel, trk = [], []
+    for rep in range(12):
         t = time.perf_counter()
         fl = sgf.KLTSelectGoodFeatures(tc, f0, n)
-        out["ms_KLTSelectGoodFeatures"] = (time.perf_counter() - t) * 1e3
-        keep = [(f.x, f.y, f.val) for f in fl]
+        sel.append((time.perf_counter() - t) * 1e3)
         t = time.perf_counter()
         KLTTrackFeatures(tc, f0, f1, fl)
-        out["ms_KLTTrackFeatures"] = (time.perf_counter() - t) * 1e3
+        trk.append((time.perf_counter() - t) * 1e3)
         out["tracked"] = sum(1 for f in fl if f.val == 0)
-        del keep
+    out["ms_KLTSelectGoodFeatures_first_call"], out["ms_KLTTrackFeatures_first_call"] = sel[0], trk[0]
+    out["ms_KLTSelectGoodFeatures"] = sorted(sel[2:])[len(sel[2:]) // 2]           # the frames are resident after the first calls
+    out["ms_KLTTrackFeatures"] = sorted(trk[2:])[len(trk[2:]) // 2]
+    # frames the device has not seen (a fresh array object per call): upload through the pinned ring + pyramids inside the call
+    sel, trk = [], []
+    for rep in range(8):
+        g0, g1 = f0.copy(), f1.copy()
+        t = time.perf_counter()
+        fl = sgf.KLTSelectGoodFeatures(tc, g0, n)
+        sel.append((time.perf_counter() - t) * 1e3)
+        t = time.perf_counter()
+        KLTTrackFeatures(tc, g0, g1, fl)
+        trk.append((time.perf_counter() - t) * 1e3)
+    out["ms_KLTSelectGoodFeatures_new_frame"] = sorted(sel[1:])[len(sel[1:]) // 2]
+    out["ms_KLTTrackFeatures_one_new_frame"] = sorted(trk[1:])[len(trk[1:]) // 2]
     frames = [synth.synth_frame(w, h, 1, k, base=base) for k in range(16)]
     tc2 = KLT_TrackingContext()
     tc2.nPyramidLevels, tc2.subsampling = 3, 4
