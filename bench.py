@@ -304,10 +304,11 @@ class OneGpu:
         return time.perf_counter() - t0, enq
 
 
-def timed_regions(ranks, run_region, repeats, min_total_s=MIN_TIMED_S, budget_s=30.0):
+def timed_regions(ranks, run_region, repeats, min_total_s=None, budget_s=30.0):
     """K-step regions, each bracketed as the contract says, until `repeats` regions AND `min_total_s` of timed work are in (so that
     a sampler outside this process sees a busy GPU even when one region lasts a millisecond); fewer -- never below 5 -- when the
     regions are long.  Returns (median seconds per region, all regions, host enqueue seconds of the median region)."""
+    min_total_s = MIN_TIMED_S if min_total_s is None else min_total_s
     el, enq = ranks.timed(run_region)
     regions = [(el, enq)]
     n = max(repeats, int(math.ceil(min_total_s / max(el, 1e-9))))
@@ -1034,8 +1035,6 @@ def run_cfg2(args, json_fd):
     for c in range(nctx):
         cx = Context(ranks.local_rank)
         cx.set_params(p)
-        if args.l0_stream:
-            cx.set_option(17, 1)                 # KLT_OPT_L0_STREAM
         for lp in range(PL):
             f0, f1 = frames[pair_index(c, lp)]
             cx.upload(2 * lp, f0)
@@ -1045,8 +1044,9 @@ def run_cfg2(args, json_fd):
         for t in (0, 1):
             for lp in range(PL):
                 cx.featbuf_view(V_OUT0 + t * PL + lp, (T_OUT0, T_OUT1)[t], lp * NFEAT, NFEAT)
+        for j in range(PL // B):                 # (launches of the same shape as the timed ones: a profiler's per-kernel averages stay clean)
+            cx.build_pyramids_batch([2 * (j * B + b) + f for b in range(B) for f in (0, 1)])
         for lp in range(PL):
-            cx.build_pyramids(2 * lp, sync=False)
             fl_c, placed = cx.select(2 * lp, NFEAT, use_pyramid=True)
             assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)
             lists[pair_index(c, lp)] = fl_c
@@ -1214,15 +1214,8 @@ def run_cfg2(args, json_fd):
                 runs.append((time.perf_counter() - t) / (4 * PL) * 1e3)
             return runs
 
-        # ONE context, the calls of one pair after the other.  With KLT_OPT_L0_STREAM the level-0 kernel of pair k + 1 runs on the
-        # context's second stream next to levels >= 1 and the tracker of pair k; without it everything is one in-order stream
-        ctx.set_option(17, 1)
-        ctx_runs = one_pair_at_a_time()
-        ctx.set_option(17, 0)
         singles = one_pair_at_a_time()
-        ctx.set_option(17, 1 if args.l0_stream else 0)
         ms_single = statistics.median(singles)
-        ms_one_ctx = statistics.median(ctx_runs)
         # round 2's headline arrangement: every context rebuilds the SAME two pairs (four slots) over and over, so the pyramid planes
         # the tracker reads are still in the Infinity Cache
         nrep = 8 * NG
@@ -1296,15 +1289,12 @@ def run_cfg2(args, json_fd):
                  "pcie_pipelined_ms_per_pair": ms_pipe, "pcie_pipelined_features_per_s": NFEAT / (ms_pipe * 1e-3),
                  "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "latency_ms_per_pair_synchronised": ms_latency,
                  "single_stream_ms_per_pair": ms_single, "single_stream_features_per_s": NFEAT / (ms_single * 1e-3),
-                 "one_context_ms_per_pair": ms_one_ctx, "one_context_features_per_s": NFEAT / (ms_one_ctx * 1e-3),
                  "single_stream_runs_ms": singles,
                  "ms_per_select_5000": ms_select,
                  "pcie_inclusive_ms_per_pair": ms_pcie, "pcie_inclusive_features_per_s": NFEAT / (ms_pcie * 1e-3),
-                 "note": "ms_per_frame_pair = one_context_ms_per_pair: ONE context, one pair per call, rotating through the resident pairs -- "
-                         "a caller's plain loop of klt_build_pyramids_batch_async + klt_track_async; KLT_OPT_L0_STREAM lets the level-0 kernel of "
-                         "the next pair run on the context's second stream next to levels >= 1 and the tracker of this one "
-                         "(single_stream_ms_per_pair: the same loop with the option off, everything on one in-order stream; ms_per_step / "
-                         "pairs_per_step = overlapped_ms_per_pair is the inverse throughput with pairs_in_flight pairs overlapping).  cache_resident = round 2's headline arrangement: every "
+                 "note": "ms_per_frame_pair = single_stream_ms_per_pair: one pair at a time on ONE stream, rotating through the resident "
+                         "pairs, no overlap with other pairs (ms_per_step / pairs_per_step = overlapped_ms_per_pair is the inverse "
+                         "throughput with pairs_in_flight pairs overlapping).  cache_resident = round 2's headline arrangement: every "
                          "context rebuilds the same four frame slots, which then never leave the 256 MB Infinity Cache.  pcie_inclusive "
                          "= H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the records, synchronised per "
                          "pair; pcie_pipelined = the same bytes with klt_upload_u8_async from pinned memory on a copy stream and the "
@@ -1324,7 +1314,7 @@ def run_cfg2(args, json_fd):
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         line = base_line(world * NP * NFEAT * args.steps / elapsed, world, args.steps, args.warmup, ms_per_step,
-                         ms_one_ctx if ms_single is not None else ms_per_pair,
+                         ms_single if ms_single is not None else ms_per_pair,
                          "cfg-2: %d DISTINCT 1920x1080 synthetic pairs resident per GPU (seeds %d..%d; own frame slots, pyramids and "
                          "feature lists: %.1f GB), 5000 features each, 7x7 window, 3 pyramid levels (subsampling 4), translation only; "
                          "a step = one pass of pyramid build + tracking over all of them (%d KLTTrackFeatures-equivalents); inputs "
@@ -1338,7 +1328,7 @@ def run_cfg2(args, json_fd):
                                              "; the %d pairs of a group share every launch of their context: one batched pyramid "
                                              "build for their %d frames, one tracker launch for their %d feature lists -- every pair still "
                                              "gets the full work of one KLTTrackFeatures call" % (B, 2 * B, B))),
-                             "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "resident_pairs": NP, "l0_stream": bool(args.l0_stream),
+                             "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "resident_pairs": NP,
                              "features_per_pair": NFEAT, "pairs_per_step": NP * world, "ms_per_pair": ms_per_pair, "tracked": tracked,
                              "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
                              "rccl_ranks": world if distributed else 0,
@@ -1414,13 +1404,13 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="contexts per GPU (one HIP stream each, no events between them): consecutive groups of --batch pairs go "
                          "round-robin to them, so kernels of different groups overlap; 1 = a single stream")
-    ap.add_argument("--l0-stream", type=int, default=1, choices=[0, 1],
-                    help="KLT_OPT_L0_STREAM of every context: 1 (default) = the level-0 kernel of a build on the context's second HIP stream, "
-                         "levels >= 1 and the tracker on its main stream")
     ap.add_argument("--batch", type=int, default=2, choices=[1, 2, 4, 8],
                     help="pairs that share every launch of a context: one batched pyramid build for their frames and one tracker launch "
                          "for their feature lists")
+    ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S,
+                    help="the timed regions of a run add up to at least this many seconds (0 for profiler passes, which replay every kernel)")
     args = ap.parse_args()
+    globals()["MIN_TIMED_S"] = args.min_timed_s
 
     # N > 1 without a launcher: start the ranks ourselves.  Nothing above or below this point has touched the GPU yet
     # (no HIP call, no library load): the children are fresh processes, this one only waits for them.

@@ -100,13 +100,6 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
  * them (one event each way per frame).  0 (default): one stream.  The caller must give frame t+1 a slot that no call still to be
  * enqueued reads (a ring of three slots for a sequence). */
 #define KLT_OPT_BUILD_STREAM 15
-/* 1: only the level-0 kernel of a pyramid build (smoothing + gradients + the horizontal pass of the first reduction -- the one kernel
- * of a KLTTrackFeatures-equivalent that fills the chip with arithmetic) is enqueued on the context's second HIP stream; levels >= 1
- * and whatever the caller enqueues next (the tracker) follow it on the main stream, ordered by one event.  The level-0 kernel of the
- * NEXT build then runs next to the latency-bound kernels of this one without any help from the caller (no second context, no
- * reordered calls).  Slots may be reused freely: the level-0 kernel waits for the tracker launches and for the main-stream part of the
- * build that last touched the slots it overwrites.  Excludes KLT_OPT_BUILD_STREAM.  0 (default): one stream. */
-#define KLT_OPT_L0_STREAM 17
 #define KLT_OPT_SCORE_SETS 16            /* how many sets of prepared selection scores (klt_select_prepare_async) the context keeps: 2 (default) .. 256; a selection frees the set it uses */
 int klt_set_option(klt_ctx *ctx, int option, int value);
 

@@ -47,9 +47,6 @@ struct Slot {
     hipEvent_t ev_read = nullptr;     // last tracker launch on the main stream that reads this slot's pyramids (a build on the build
     uint64_t read_serial = 0;         // stream waits for it; selections synchronise before they return and need no mark)
     bool read_valid = false;
-    hipEvent_t ev_tail = nullptr;     // KLT_OPT_L0_STREAM: end of the main-stream part (levels >= 1) of the slot's last split build
-    uint64_t tail_serial = 0;
-    bool tail_valid = false;
     bool upload_pending = false, consumed_valid = false;
     // asynchronous ingest alternates between two raw buffers so that a copy never has to wait (on the device) for
     // kernels still reading the previous frame: making the copy stream wait on a compute-stream event blocks the
@@ -107,15 +104,6 @@ struct klt_ctx {
     hipStream_t bstream = nullptr;    // KLT_OPT_BUILD_STREAM: pyramid builds run here, overlapping the tracker / selection of earlier frames
     hipStream_t work = nullptr;       // stream the pyramid-build helpers enqueue on: `stream`, or `bstream` inside a build
     bool build_stream_on = false;
-    // KLT_OPT_L0_STREAM: only the level-0 kernel of a build (smoothing + gradients + first horizontal reduction: the one kernel of the
-    // step that fills the chip with arithmetic) runs on the build stream; levels >= 1 and the tracker follow on the main stream.  The
-    // level-0 kernel of the next build then runs next to the latency-bound kernels of this one, whatever the caller enqueues next.
-    bool l0_stream_on = false;
-    float *h1s[2] = {nullptr, nullptr};      // H1 planes of split builds alternate between two buffers (the level-0 kernel of build
-    size_t h1s_cap[2] = {0, 0};              // g + 1 writes one while the vertical reduction of build g still reads the other)
-    hipEvent_t ev_h1[2] = {nullptr, nullptr};   // main stream: the vertical reduction that read h1s[t] has finished
-    uint64_t h1_serial[2] = {0, 0};
-    int h1_turn = 0;
     KltComm *comm = nullptr;          // RCCL communicator + side stream (klt_comm_init_rank), comm.hip
     std::vector<void *> pinned;       // klt_host_alloc allocations
     // Ordering events come from one ring and are never re-recorded while a waiter may still be queued on them
@@ -417,7 +405,7 @@ int mark_consumed(klt_ctx *c, Slot *const *slots, int n, hipStream_t reader)
 // stream waits for it (and for nothing else on the main stream)
 int mark_read(klt_ctx *c, Slot *const *slots, int n)
 {
-    if (!c->build_stream_on && !c->l0_stream_on) { for (int i = 0; i < n; i++) slots[i]->read_valid = false; return 0; }    // main-stream builds are in order
+    if (!c->build_stream_on) { for (int i = 0; i < n; i++) slots[i]->read_valid = false; return 0; }    // main-stream builds are in order
     hipEvent_t e;
     uint64_t serial;
     if (int rc = fresh_event(c, &e, &serial)) return rc;
@@ -585,7 +573,7 @@ bool fused_reduce_ok(const klt_ctx *c) { return c->use_fused && pyr_reduce_lds_b
 // *fused_h1 (optional, in/out): in = the caller wants the horizontal pass of the first reduction fused into this launch; out =
 // whether it was (then c->h1 holds one H1 plane of nr x (nc / ss) floats per frame)
 int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int raw_kind, float *const *img,
-                              float *const *gx, float *const *gy, int nc, int nr, bool *fused_h1 = nullptr, int h1_slot = -1)
+                              float *const *gx, float *const *gy, int nc, int nr, bool *fused_h1 = nullptr)
 {
     SmoothGradArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -596,12 +584,10 @@ int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int
     bool hred = fused_h1 && *fused_h1 && c->fuse_hreduce && smooth_grad_hred_ok(a, batch, kind, c->gauss[1], c->p.subsampling);
     if (hred) {
         const size_t plane = (size_t)nr * (nc / c->p.subsampling);
-        float *h1 = nullptr;
-        if (h1_slot >= 0) { if (int rc = ensure(c, c->h1s[h1_slot], c->h1s_cap[h1_slot], plane * batch)) return rc; h1 = c->h1s[h1_slot]; }
-        else { if (int rc = ensure_h1(c, plane * batch)) return rc; h1 = c->h1; }
+        if (int rc = ensure_h1(c, plane * batch)) return rc;
         a.reduce = c->gauss[1];
         a.h1_nc = nc / c->p.subsampling;
-        for (int b = 0; b < batch; b++) a.h1[b] = h1 + plane * b;
+        for (int b = 0; b < batch; b++) a.h1[b] = c->h1 + plane * b;
     }
     if (fused_h1) *fused_h1 = hred;
     const double N = (double)nc * nr * batch;
@@ -641,19 +627,12 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         klt_ctx *c;
         ~WorkScope() { c->work = c->stream; }
     } work_scope{c};
-    const bool fused_all = c->use_fused && fused_smooth_ok(c) && fused_grad_ok(c) && fused_reduce_ok(c);
-    const bool on_bstream = c->build_stream_on && fused_all;
-    const bool split = !on_bstream && c->l0_stream_on && fused_all;      // level-0 kernel on the build stream, the rest on the main stream
-    if (split) {
-        if (!c->bstream) HIPCHK(c, hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking));
-        if (c->last_build_on_bstream != 2) {
-            // the first split build: its level-0 kernel goes behind everything on the main stream (uploads, other kinds of builds)
-            hipEvent_t mark;
-            if (int rc = fresh_event(c, &mark)) return rc;
-            HIPCHK(c, hipEventRecord(mark, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->bstream, mark, 0));
-        }
-    } else if (on_bstream) {
+    // (Round 3 measured the level-0 kernel alone on the build stream, levels >= 1 and the tracker on the main stream -- "KLT_OPT_L0_STREAM",
+    // commit 72f1f4e: bit-identical, and no faster: one context 0.0452 ms per pair against 0.0462 on one stream with two pairs per launch.
+    // The level-0 kernel and the tracker are both bound by VALU issue: running side by side they take 70 us where they take 48 + 26 one
+    // after the other, profiles/README.md.)
+    const bool on_bstream = c->build_stream_on && c->use_fused && fused_smooth_ok(c) && fused_grad_ok(c) && fused_reduce_ok(c);
+    if (on_bstream) {
         if (!c->bstream) HIPCHK(c, hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking));
         if (c->last_build_on_bstream != 1) {
             // the first build over here: behind everything on the main stream (earlier builds there share the H1 scratch)
@@ -675,20 +654,9 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         for (int j = 0; j < i; j++)
             if (sl[j] == sl[i]) return fail(c, KLT_ERR_ARG, "slot listed twice");
         if (int rc = layout_pyramid(c, sl[i])) return rc;
-        if (int rc = wait_upload(c, sl[i], split ? c->bstream : c->work)) return rc;      // asynchronous ingest: the frame must have landed
+        if (int rc = wait_upload(c, sl[i], c->work)) return rc;      // asynchronous ingest: the frame must have landed
         if (!on_bstream) { if (int rc = wait_built(c, sl[i])) return rc; }
-        static const bool dbg_nomarks = getenv("KLT_DBG_NOMARKS") != nullptr;
-        if (dbg_nomarks) { sl[i]->tail_valid = false; sl[i]->read_valid = false; }
-        if (split && sl[i]->tail_valid) {
-            // the level-0 kernel overwrites planes that the main-stream part of the slot's previous split build may still read
-            if (std::find(read_waited.begin(), read_waited.end(), ~sl[i]->tail_serial) == read_waited.end()) {
-                if (event_live(c, sl[i]->tail_serial)) HIPCHK(c, hipStreamWaitEvent(c->bstream, sl[i]->ev_tail, 0));
-                else HIPCHK(c, hipStreamSynchronize(c->stream));
-                read_waited.push_back(~sl[i]->tail_serial);
-            }
-            sl[i]->tail_valid = false;
-        }
-        if ((on_bstream || split) && sl[i]->read_valid) {
+        else if (sl[i]->read_valid) {
             // a tracker on the main stream may still be reading the pyramids this build overwrites: wait for that launch only (a mark on
             // the whole main stream would put the build behind a tracker enqueued just before it -- the overlap the stream is for)
             // (once per launch: the slots of a batch that one launch read share its event)
@@ -700,7 +668,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         }
         sl[i]->read_valid = false;
     }
-    c->last_build_on_bstream = on_bstream ? 1 : split ? 2 : 0;
+    c->last_build_on_bstream = on_bstream ? 1 : 0;
     const int ss = c->p.subsampling;
     // groups of frames with the same geometry and input type share launches
     std::vector<bool> done((size_t)n, false);
@@ -721,39 +689,13 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
 
         // level 0: smoothed frame (trackFeatures.py:165-166) and its gradients (:171-172)
         bool h1_fused = false;              // level 1 comes from the H1 planes written by the level-0 kernel
-        const float *h1_cur = nullptr;      // (split builds: which of the two H1 buffers)
-        int h1_cur_slot = -1;
         if (fused_smooth_ok(c)) {
             for (int b = 0; b < B; b++) {
                 raw[b] = g[b]->raw_kind == 1 ? (const void *)g[b]->u8 : (const void *)g[b]->f32;
                 img[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy;
             }
             h1_fused = s0->nlev > 1 && fused_reduce_ok(c);
-            int h1_slot = -1;
-            if (split) {
-                // this launch on the build stream, behind the vertical reduction (main stream) that last read the H1 buffer it writes
-                h1_slot = c->h1_turn;
-                c->h1_turn ^= 1;
-                static const bool dbg_noh1 = getenv("KLT_DBG_NOH1") != nullptr;
-                if (c->ev_h1[h1_slot] && !dbg_noh1) {
-                    if (event_live(c, c->h1_serial[h1_slot])) HIPCHK(c, hipStreamWaitEvent(c->bstream, c->ev_h1[h1_slot], 0));
-                    else HIPCHK(c, hipStreamSynchronize(c->stream));
-                    c->ev_h1[h1_slot] = nullptr;
-                }
-                c->work = c->bstream;
-            }
-            if (int rc = enqueue_fused_smooth_grad(c, B, raw, s0->raw_kind, img, gx, gy, s0->nc, s0->nr, &h1_fused, h1_slot)) return rc;
-            if (split) {
-                // the kernel has read the raw frames; everything else of the build follows it on the main stream
-                if (int rc = mark_consumed(c, g.data(), B, c->bstream)) return rc;
-                hipEvent_t l0_done;
-                if (int rc = fresh_event(c, &l0_done)) return rc;
-                HIPCHK(c, hipEventRecord(l0_done, c->bstream));
-                HIPCHK(c, hipStreamWaitEvent(c->stream, l0_done, 0));
-                c->work = c->stream;
-                h1_cur = h1_fused ? c->h1s[h1_slot] : nullptr;
-                h1_cur_slot = h1_slot;
-            }
+            if (int rc = enqueue_fused_smooth_grad(c, B, raw, s0->raw_kind, img, gx, gy, s0->nc, s0->nr, &h1_fused)) return rc;
         } else {
             for (int b = 0; b < B; b++) {
                 enqueue_smooth_raw(c, g[b], g[b]->lv[0].img);
@@ -776,16 +718,10 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                 if (l == 1 && h1_fused) {
                     // vertical pass only: H1 (level-0 rows x level-1 columns) -> level 1
                     const size_t plane = (size_t)ls.nr * ld.nc;
-                    for (int b = 0; b < B; b++) a.src[b] = (h1_cur ? h1_cur : c->h1) + plane * b;
-                    {
-                        TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ld.nc * ld.nr));
-                        if (int e = launch_pyr_vreduce(c->work, a, B))
-                            return fail(c, KLT_ERR_DEVICE, std::string("pyr_vreduce launch: ") + hipGetErrorString((hipError_t)e));
-                    }
-                    if (h1_cur) {            // the H1 buffer may be written again once this launch is through
-                        if (int rc = fresh_event(c, &c->ev_h1[h1_cur_slot], &c->h1_serial[h1_cur_slot])) return rc;
-                        HIPCHK(c, hipEventRecord(c->ev_h1[h1_cur_slot], c->stream));
-                    }
+                    for (int b = 0; b < B; b++) a.src[b] = c->h1 + plane * b;
+                    TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ld.nc * ld.nr));
+                    if (int e = launch_pyr_vreduce(c->work, a, B))
+                        return fail(c, KLT_ERR_DEVICE, std::string("pyr_vreduce launch: ") + hipGetErrorString((hipError_t)e));
                 } else {
                     TimerScope t(c, F_PYR_REDUCE, 4.0 * B * ((double)ls.nc * ls.nr + (double)ld.nc * ld.nr));
                     if (int e = launch_pyr_reduce(c->work, a, B))
@@ -833,14 +769,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         for (Slot *s : g) { s->pyr_valid = true; s->gen = ++c->gen_counter; }
     }
     // the next asynchronous copy into these slots waits for this build
-    if (!split) { if (int rc = mark_consumed(c, sl.data(), n, c->work)) return rc; }
-    if (split) {
-        hipEvent_t e;
-        uint64_t serial;
-        if (int rc = fresh_event(c, &e, &serial)) return rc;
-        HIPCHK(c, hipEventRecord(e, c->stream));
-        for (Slot *s : sl) { s->ev_tail = e; s->tail_serial = serial; s->tail_valid = true; }
-    }
+    if (int rc = mark_consumed(c, sl.data(), n, c->work)) return rc;
     if (on_bstream) {
         hipEvent_t e;
         uint64_t serial;
@@ -915,7 +844,7 @@ void klt_destroy(klt_ctx *c)
     for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes); }
     for (FeatBuf &b : c->fbs)
         if (!b.view) hipFree(b.d);
-    hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1); hipFree(c->h1s[0]); hipFree(c->h1s[1]);
+    hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1);
     hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
     for (auto &e : c->pre) hipFree(e.keys);
     hipFree(c->sat_pre);
@@ -1080,17 +1009,9 @@ int klt_set_option(klt_ctx *c, int option, int value)
     if (option == KLT_OPT_FUSED_HREDUCE) { c->fuse_hreduce = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TRACK_XCD_ORDER) { c->track_xcd_order = value != 0; return KLT_OK; }
     if (option == KLT_OPT_BUILD_STREAM) {
-        if (value && c->l0_stream_on) return fail(c, KLT_ERR_STATE, "KLT_OPT_L0_STREAM and KLT_OPT_BUILD_STREAM exclude each other");
         if (!value && c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));      // pending builds finish; their events stay valid
         if (c->build_stream_on != (value != 0)) c->last_build_on_bstream = -1;   // trackers launched meanwhile carry no read marks: the next
         c->build_stream_on = value != 0;                                          // build over there waits for the whole main stream
-        return KLT_OK;
-    }
-    if (option == KLT_OPT_L0_STREAM) {
-        if (value && c->build_stream_on) return fail(c, KLT_ERR_STATE, "KLT_OPT_L0_STREAM and KLT_OPT_BUILD_STREAM exclude each other");
-        if (!value && c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
-        if (c->l0_stream_on != (value != 0)) c->last_build_on_bstream = -1;
-        c->l0_stream_on = value != 0;
         return KLT_OK;
     }
     if (option == KLT_OPT_SCORE_SETS) {

@@ -230,78 +230,3 @@ def test_star_import_driver_through_compat(tmp_path, golden_dir):
         x, y, v = ex["pp_after_200_x"][k], ex["pp_after_200_y"][k], int(ex["pp_after_200_val"][k])
         assert feats[50 + k] == "Feature #{0}:  ({1},{2}) with value of {3}".format(k, float(x), float(y), v), k
     assert "remaining %d" % int((ex["pp_after_200_val"] >= 0).sum()) in r.stdout
-
-
-# ------------------------------------------------------------------------------------------------ KLT_OPT_L0_STREAM
-OPT_L0_STREAM = 17
-
-
-def _pair_results(c, frames_by_step, fl, n, slots=(0, 1)):
-    """upload + build + track for every (frame a, frame b) of `frames_by_step` into the SAME two slots, back to back without a
-    host synchronisation in between (asynchronous uploads from pinned memory); returns the tracked records of every step"""
-    h, w = frames_by_step[0][0].shape
-    pins = [[c.pinned_array((h, w)), c.pinned_array((h, w))] for _ in frames_by_step]
-    for (a, b), (pa, pb) in zip(frames_by_step, pins):
-        pa[:], pb[:] = a, b
-    c.featbuf_upload(0, fl)
-    for k, (pa, pb) in enumerate(pins):
-        c.upload_async(slots[0], pa)
-        c.upload_async(slots[1], pb)
-        c.build_pyramids_batch(list(slots))
-        c.track_async(slots[0], slots[1], 0, 10 + k, n)
-    c.sync()
-    return [c.featbuf_download(10 + k, n) for k in range(len(pins))]
-
-
-def test_l0_stream_gives_the_same_pyramids_and_records():
-    """KLT_OPT_L0_STREAM (level-0 kernel of a build on the context's second stream, the rest on the main stream): every pyramid plane
-    and every tracked record equal those of the one-stream build -- also when the same two slots are refilled and rebuilt step after
-    step with nothing but stream order and the library's events between the level-0 kernel of step k + 1 and the tracker of step k."""
-    from helpers import make_tc
-    from pyfeaturetrack_amd.backend import Context
-    n = 1000
-    base = synth.synth_base(960, 540, 5)
-    frames = [synth.synth_frame(960, 540, 5, k, shift=(2.2, -1.4), base=base) for k in range(7)]
-    steps = [(frames[k], frames[k + 1]) for k in range(6)]
-    tc = make_tc(levels=3, ss=4)
-    c = Context(0)
-    try:
-        c.configure(tc)
-        c.upload(0, frames[0])
-        c.build_pyramids(0)
-        fl, placed = c.select(0, n, use_pyramid=True)
-        assert placed == n
-        want = _pair_results(c, steps, fl, n)
-        planes_want = [c.download_level(1, pyr, l) for pyr in range(3) for l in range(3)]
-        c.set_option(OPT_L0_STREAM, 1)
-        for rep in range(3):
-            got = _pair_results(c, steps, fl, n)
-            for k, (g, w) in enumerate(zip(got, want)):
-                assert np.array_equal(g, w), "rep %d, step %d: records differ with the level-0 kernel on its own stream" % (rep, k)
-        planes_got = [c.download_level(1, pyr, l) for pyr in range(3) for l in range(3)]
-        for a, b in zip(planes_got, planes_want):
-            assert np.array_equal(a, b)
-        # batched builds / trackers through the same option, slots reused by every group
-        c.featbuf_upload(1, fl)
-        for k in range(4):
-            c.upload(2 * (k % 2), frames[k])
-            c.upload(2 * (k % 2) + 1, frames[k + 1])
-        outs = []
-        for rep in range(4):
-            c.build_pyramids_batch([0, 1, 2, 3])
-            c.track_batch_async([(0, 1, 0, 30 + 2 * rep), (2, 3, 1, 31 + 2 * rep)], n)
-        c.sync()
-        c.set_option(OPT_L0_STREAM, 0)
-        c.build_pyramids_batch([0, 1, 2, 3])
-        c.track_batch_async([(0, 1, 0, 50), (2, 3, 1, 51)], n)
-        ref = [c.featbuf_download(50, n), c.featbuf_download(51, n)]
-        for rep in range(4):
-            assert np.array_equal(c.featbuf_download(30 + 2 * rep, n), ref[0]) and np.array_equal(c.featbuf_download(31 + 2 * rep, n), ref[1])
-        # the two stream options exclude each other
-        from pyfeaturetrack_amd.backend import KltBackendError
-        c.set_option(15, 1)
-        with pytest.raises(KltBackendError, match="exclude"):
-            c.set_option(OPT_L0_STREAM, 1)
-        c.set_option(15, 0)
-    finally:
-        c.close()
