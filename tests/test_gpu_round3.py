@@ -230,3 +230,97 @@ def test_star_import_driver_through_compat(tmp_path, golden_dir):
         x, y, v = ex["pp_after_200_x"][k], ex["pp_after_200_y"][k], int(ex["pp_after_200_val"][k])
         assert feats[50 + k] == "Feature #{0}:  ({1},{2}) with value of {3}".format(k, float(x), float(y), v), k
     assert "remaining %d" % int((ex["pp_after_200_val"] >= 0).sum()) in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------ Python API: resident frames
+def _api_modules():
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import trackFeatures as trk
+    sgf.KLT_verbose = trk.KLT_verbose = 0
+    return sgf, trk
+
+
+def _records(fl):
+    return [(f.x, f.y, f.val) for f in fl]
+
+
+def test_python_api_keeps_frames_resident_and_notices_changes():
+    """The reference-shaped API with the frame cache (_frames.py): the ping-pong of example1 uploads and builds nothing after its
+    first round trip, results are those of a cache-less run, an image edited in place is seen as new, KLTForgetFrames voids the
+    cache, and KLT_NO_FRAME_CACHE=1 (a fresh process) gives the same lists."""
+    from helpers import make_tc
+    from pyfeaturetrack_amd.backend import default_context
+    from pyfeaturetrack_amd._frames import cache_of
+    sgf, trk = _api_modules()
+    try:
+        base = synth.synth_base(640, 480, 21)
+        f = [synth.synth_frame(640, 480, 21, k, shift=(1.7, -1.1), base=base) for k in range(3)]
+        n = 400
+
+        def run(tc, forget):
+            out = []
+            fl = sgf.KLTSelectGoodFeatures(tc, f[0], n)
+            out.append(_records(fl))
+            for k in range(6):                                   # ping-pong between two frames, then a third one
+                a, b = (f[0], f[1]) if k % 2 == 0 else (f[1], f[0])
+                if forget:
+                    trk.KLTForgetFrames(tc)
+                trk.KLTTrackFeatures(tc, a, b, fl)
+                out.append(_records(fl))
+            trk.KLTTrackFeatures(tc, f[0], f[2], fl)
+            out.append(_records(fl))
+            sgf.KLTReplaceLostFeatures(tc, f[2], fl)             # the image frame 2's slot holds: selected on level 0 of its pyramid
+            out.append(_records(fl))
+            return out
+
+        tc1, tc2 = make_tc(levels=2, ss=4, max_residue=10.0), make_tc(levels=2, ss=4, max_residue=10.0)
+        want = run(tc1, forget=True)
+        ctx = default_context()
+        ctx.timing_enable(1)
+        got = run(tc2, forget=False)
+        launches = {k["name"]: k["launches"] for k in ctx.timing_read()}
+        ctx.timing_enable(0)
+        assert got == want
+        # select(f0) builds f0's pyramid, track #1 builds f1's, track #7 builds f2's: three level-0 launches in all
+        assert launches.get("smooth_grad_l0") == 3, launches
+        assert launches.get("track") == 7
+        # an in-place edit of the frame is a new frame
+        tc3 = make_tc(levels=2, ss=4, max_residue=10.0)
+        g0, g1 = f[0].copy(), f[1].copy()
+        fl = sgf.KLTSelectGoodFeatures(tc3, g0, n)
+        trk.KLTTrackFeatures(tc3, g0, g1, fl)
+        first = _records(fl)
+        g1[:] = f[2]                                             # same object, other pixels
+        fl2 = sgf.KLTSelectGoodFeatures(tc3, g0, n)
+        trk.KLTTrackFeatures(tc3, g0, g1, fl2)
+        tc4 = make_tc(levels=2, ss=4, max_residue=10.0)
+        fl3 = sgf.KLTSelectGoodFeatures(tc4, f[0], n)
+        trk.KLTTrackFeatures(tc4, f[0], f[2], fl3)
+        assert _records(fl2) == _records(fl3) and _records(fl2) != first
+        assert len(cache_of(tc3).held) == 2
+        # sequential mode keeps working through the cache (frame 2 becomes frame 1)
+        tc5, tc6 = make_tc(levels=2, ss=4), make_tc(levels=2, ss=4)
+        tc5.sequentialMode = True
+        a = sgf.KLTSelectGoodFeatures(tc5, f[0], n)
+        b = sgf.KLTSelectGoodFeatures(tc6, f[0], n)
+        for k in (1, 2):
+            trk.KLTTrackFeatures(tc5, f[k - 1], f[k], a)
+            trk.KLTTrackFeatures(tc6, f[k - 1], f[k], b)
+            assert _records(a) == _records(b), k
+    finally:
+        sgf.KLT_verbose = trk.KLT_verbose = 1
+
+
+def test_python_api_without_the_frame_cache_gives_the_same_example1(tmp_path, golden_dir):
+    """KLT_NO_FRAME_CACHE=1: every call uploads and rebuilds what it is given, as the reference does; example1's files and lists
+    are the same."""
+    env = dict(os.environ, KLT_NO_FRAME_CACHE="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "examples", "example1.py"), "--out", str(tmp_path), "--iterations", "10"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ex = np.load(os.path.join(golden_dir, "example1.npz"))
+    data = (tmp_path / "feat1.ppm").read_bytes()
+    assert np.array_equal(np.frombuffer(hashlib.sha256(data).digest(), np.uint8), ex["feat1_ppm_sha"])
+    last = [l for l in r.stdout.splitlines() if l.startswith("Feature #49:")][-1]
+    x, y, v = ex["pp_after_20_x"][49], ex["pp_after_20_y"][49], int(ex["pp_after_20_val"][49])
+    assert last == "Feature #49:  ({0},{1}) with value of {2}".format(float(x), float(y), v)

@@ -312,3 +312,78 @@ def test_shard_gather_counts():
         for r in range(world):
             sr = shard_range(n_pairs, world, r)
             assert offs[r] == (sr.start if len(sr) else offs[r]) * 2000 or not len(sr)
+
+
+def test_feature_list_is_a_list_that_makes_its_features_on_first_access():
+    """klt.KLT_FeatureList: what KLTSelectGoodFeatures / KLTCreateFeatureList return.  A list subclass (the reference returns a plain
+    list of KLT_Feature objects, selectGoodFeatures.py:143) whose 5000 objects are created when an element is first touched."""
+    import copy
+    import pickle
+    from pyfeaturetrack_amd.klt import KLT_Feature, KLT_FeatureList, KLTCountRemainingFeatures, new_feature_list, shared_store
+    fl = new_feature_list(50)
+    assert isinstance(fl, list) and type(fl) is KLT_FeatureList and len(fl) == 50 and bool(fl)
+    assert fl._pending == 50 and list.__len__(fl) == 0                      # nothing made yet
+    assert shared_store(fl) is fl._store and KLTCountRemainingFeatures(fl) == 0
+    fl._store.val[:10] = 7                                                   # (what a KLT* call does: whole columns)
+    assert KLTCountRemainingFeatures(fl) == 10 and fl._pending == 50
+    f3 = fl[3]                                                               # first touch
+    assert isinstance(f3, KLT_Feature) and fl._pending == 0 and list.__len__(fl) == 50
+    assert fl[3] is f3 and f3.val == 7 and fl[20].val == -1 and shared_store(fl) is fl._store
+    assert [f.val for f in fl][:11] == [7] * 10 + [-1] and sum(1 for _ in fl) == 50
+    for i, f in enumerate(new_feature_list(3)):
+        assert (f.x, f.y, f.val) == (-1, -1, -1)
+    assert len(new_feature_list(4)[1:3]) == 2 and len(sorted(new_feature_list(4), key=lambda f: f.val)) == 4
+    g = new_feature_list(3)
+    g.append(KLT_Feature())
+    assert len(g) == 4 and shared_store(g) is None                           # an edited list falls back to per-feature access
+    h = new_feature_list(3)
+    assert h == list(h) and (h + [1])[-1] == 1 and h.index(h[2]) == 2 and h[1] in h
+    assert type(pickle.loads(pickle.dumps(new_feature_list(3)))) is list and len(copy.copy(new_feature_list(3))) == 3
+    e = new_feature_list(0)
+    assert len(e) == 0 and not e and list(e) == []
+
+
+def test_frame_cache_recognises_images_it_has_seen():
+    """_frames.FrameCache: object identity + size + a signature of sampled pixels; an in-place edit of a sampled pixel, another object
+    with the same content, a dead object or a slot that lost its frame are all 'not resident'."""
+    from pyfeaturetrack_amd._frames import FrameCache, FrameKey
+
+    class FakeCtx:
+        def __init__(self):
+            self.has = {0: True, 1: True}
+
+        def frame_resident(self, slot):
+            return self.has.get(slot, False)
+
+    ctx, cache = FakeCtx(), FrameCache()
+    a = (np.arange(64 * 96) % 251).astype(np.uint8).reshape(64, 96)
+    b = a.copy()
+    ka = FrameKey(a)
+    cache.note(0, ka)
+    assert cache.find(a, FrameKey(a), (0, 1), ctx) == 0
+    assert cache.find(b, FrameKey(b), (0, 1), ctx) is None                   # same content, another object: the reference would convert it again too
+    a[0, 0] ^= 0xff                                                          # a sampled pixel changes (row 0, column 0 is on the lattice)
+    assert cache.find(a, FrameKey(a), (0, 1), ctx) is None
+    a[0, 0] ^= 0xff
+    assert cache.find(a, FrameKey(a), (0, 1), ctx) == 0
+    cache.swap(0, 1)
+    assert cache.find(a, FrameKey(a), (0, 1), ctx) == 1 and cache.find(a, FrameKey(a), (0,), ctx) is None
+    ctx.has[1] = False                                                       # the slot was freed / never uploaded
+    assert cache.find(a, FrameKey(a), (0, 1), ctx) is None
+    ctx.has[1] = True
+    cache.forget()
+    assert cache.find(a, FrameKey(a), (0, 1), ctx) is None
+    f32 = a.astype(np.float32)
+    cache.note(0, FrameKey(f32))
+    assert cache.find(f32, FrameKey(f32), (0,), ctx) == 0
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    img = Image.fromarray(a)
+    cache.note(1, FrameKey(img))
+    assert cache.find(img, FrameKey(img), (0, 1), ctx) == 1
+    for x in range(3):                                                       # (a 3 x 3 block holds a sample of Pillow's lattice)
+        for y in range(3):
+            img.putpixel((x, y), 255 - img.getpixel((x, y)))
+    assert cache.find(img, FrameKey(img), (0, 1), ctx) is None
