@@ -21,7 +21,7 @@ exits non-zero if any rank failed.  Under an external launcher (`python -m torch
 N ...`) the same variables are already set and every process is a rank.  The RCCL unique id travels through the rendezvous file
 (pyfeaturetrack_amd/parallel.py).
 
-Consecutive groups of `--batch` pairs (default 2) go round-robin to `--inflight` contexts (default 2; one HIP stream each, nothing
+Consecutive groups of `--batch` pairs (default 8) go round-robin to `--inflight` contexts (default 2; one HIP stream each, nothing
 ordering them): frame pairs are independent, so the pairs of a group share every launch of their context (one batched pyramid build,
 one tracker launch -- the reference's workload for a stereo rig or two cameras) and the GPU overlaps the kernels of different groups.
 Every pair gets the full work of one KLTTrackFeatures call.  `ms_per_frame_pair` (= `extra.single_stream_ms_per_pair`) is one pair
@@ -796,22 +796,33 @@ def run_cfg5(args, json_fd):
     if prefetch:
         ctx.set_option(15, 1)
 
+    redone = [0]
+
     def run_sequence(look=None):
         """one pass over the sequence; `look(k)` (instrumented passes) is called after frame k's replacement, synchronised"""
+        def track(k):                                     # frame k - 1 -> k; the lists alternate between two buffers
+            ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)
+
         if prefetch:
             ctx.build_pyramids(10 + 1, sync=False)
             if prepare:
                 ctx.select_prepare(10 + 1)
+            track(1)
         for k in range(1, nframes):
             if not prefetch:
                 ctx.build_pyramids(10 + k, sync=False)
-            ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)      # the chain first: the build stream waits for nothing on this one
-            ctx.select_begin(10 + k, 2, True, k % 2, n)      # ... KLTReplaceLostFeatures on the resident level-0 images, up to the host's look
+                track(k)
+            ctx.select_begin(10 + k, 2, True, k % 2, n)      # KLTReplaceLostFeatures on the resident level-0 images, up to the host's look
             if prefetch and k + 1 < nframes:
                 ctx.build_pyramids(10 + k + 1, sync=False)
                 if prepare:
                     ctx.select_prepare(10 + k + 1)        # SAT + eigenvalues of the next frame, behind its build on the build stream
-            ctx.select_finish()
+                # the NEXT frame's tracker goes out before the host looks at this frame's selection: it only reads the list, and the GPU
+                # has it queued while the host turns around (44 us of an idle main stream per frame in the round-3 kernel trace)
+                track(k + 1)
+            if ctx.select_finish() and prefetch and k + 1 < nframes:
+                redone[0] += 1
+                track(k + 1)                              # (rare) the selection rewrote the list after the tracker had read it
             if look:
                 ctx.sync()
                 look(k)
@@ -894,7 +905,8 @@ def run_cfg5(args, json_fd):
                      + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else "")
                      + (", and so are its summed-area tables and eigenvalues (klt_select_prepare_async)" if prepare else ""),
                      extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
-                                "lost_per_frame": lost, "build_stream": bool(prefetch), "scores_prepared": bool(prepare)})
+                                "lost_per_frame": lost, "build_stream": bool(prefetch), "scores_prepared": bool(prepare),
+                                "tracker_enqueued_ahead": bool(prefetch), "trackers_repeated": redone[0]})
     line.update(par)
     line["roofline"], line["cpu_baseline"] = roof, cpu
     line["extra"] = {"region_ms_per_step": region_stats(regions, frames_per_region, el), "host_enqueue_ms_per_step": enq / frames_per_region * 1e3}
@@ -1218,7 +1230,8 @@ def run_cfg2(args, json_fd):
         ms_single = statistics.median(singles)
         # round 2's headline arrangement: every context rebuilds the SAME two pairs (four slots) over and over, so the pyramid planes
         # the tracker reads are still in the Infinity Cache
-        nrep = 8 * NG
+        nrep, HB = 64, min(2, PL)                  # (two pairs per launch: 4 x 27 MB of planes per context stay below the cache's 256 MB)
+        hot_pairs = [(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp) for lp in range(HB)]
         hots = []
         for _ in range(5):
             for cx in ctxs:
@@ -1226,12 +1239,12 @@ def run_cfg2(args, json_fd):
             t = time.perf_counter()
             for _ in range(nrep):
                 for cx in ctxs:
-                    group_build(cx, 0)
+                    cx.build_pyramids_batch(list(range(2 * HB)))
                 for cx in ctxs:
-                    group_track(cx, 0, 0)
+                    cx.track_batch_async(hot_pairs, NFEAT) if HB > 1 else cx.track_async(0, 1, FB_IN0, V_OUT0, NFEAT)
             for cx in ctxs:
                 cx.sync()
-            hots.append((time.perf_counter() - t) / (nrep * nctx * B) * 1e3)
+            hots.append((time.perf_counter() - t) / (nrep * nctx * HB) * 1e3)
         ms_hot = statistics.median(hots)
         t = time.perf_counter()
         for k in range(reps):                                  # un-pipelined latency of one pair
@@ -1404,9 +1417,11 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="contexts per GPU (one HIP stream each, no events between them): consecutive groups of --batch pairs go "
                          "round-robin to them, so kernels of different groups overlap; 1 = a single stream")
-    ap.add_argument("--batch", type=int, default=2, choices=[1, 2, 4, 8],
+    ap.add_argument("--batch", type=int, default=8, choices=[1, 2, 4, 8, 16],
                     help="pairs that share every launch of a context: one batched pyramid build for their frames and one tracker launch "
-                         "for their feature lists")
+                         "for their feature lists.  On distinct resident pairs (nothing to keep in a cache) longer launches win: 2 contexts x "
+                         "1 / 2 / 4 / 8 / 16 pairs per launch read 0.0414 / 0.0358 / 0.0345 / 0.0332 / 0.0333 ms per pair (the level-0 kernel pays "
+                         "its ramp and tail once per launch: 11.7 us per frame in a 4-frame launch, 9.8 in a 16-frame launch)")
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S,
                     help="the timed regions of a run add up to at least this many seconds (0 for profiler passes, which replay every kernel)")
     args = ap.parse_args()

@@ -160,8 +160,12 @@ int klt_select_async(klt_ctx *ctx, int slot, int mode, int use_pyramid, int fb, 
 /* klt_select_async in two halves.  klt_select_begin_async enqueues everything up to the point where the host has to look at the
  * outcome (how many passes the minimum-distance stage needed, whether the candidate cut held); klt_select_finish waits, looks and --
  * rarely -- enqueues more passes or the repeat with every candidate.  Between the two the caller may enqueue other work that does not
- * touch the list or select again: the next frame's upload, build and klt_select_prepare_async (a sequence overlaps the host side of
- * frame t+1 with the GPU side of frame t's replacement this way).  klt_select_finish without a pending selection returns KLT_OK. */
+ * WRITE the list or select again: the next frame's upload, build and klt_select_prepare_async (a sequence overlaps the host side of
+ * frame t+1 with the GPU side of frame t's replacement this way) -- and work that only READS the list, such as the tracker launch of the
+ * next frame into another buffer (klt_track_async: the GPU then has the tracker queued while the host looks at the outcome and enqueues
+ * the next selection, instead of idling through that turn-around).  klt_select_finish returns KLT_OK, or 1 (not an error) when it had to
+ * rewrite the list after the launches of klt_select_begin_async had run (more passes, or the repeat with every candidate): whatever
+ * read the list in between must then be enqueued again.  klt_select_finish without a pending selection returns KLT_OK. */
 int klt_select_begin_async(klt_ctx *ctx, int slot, int mode, int use_pyramid, int fb, int n);
 int klt_select_finish(klt_ctx *ctx);
 /* The list-independent half of a later klt_select_async(slot, KLT_REPLACING_SOME, use_pyramid = 1, ...): the summed-area tables and

@@ -267,9 +267,14 @@ class Context:
         """(in, out): two pinned arrays of n klt_feat records, cached per length -- the host side of the reference-shaped API's
         lists (no staging copy inside the runtime, and the copies can be asynchronous).  Valid until the next call that uses them."""
         cache = self.__dict__.setdefault("_host_records", {})
-        pair = cache.get(n)
+        pair = cache.pop(n, None)
         if pair is None:
-            pair = cache[n] = (self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n], self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n])
+            if len(cache) >= 8:                                   # a script with lists of many lengths: the least recently used pair goes
+                old = cache.pop(next(iter(cache)))
+                for a in old:
+                    self._check(self._lib.klt_host_free(self._h, C.c_void_p(a.ctypes.data)))
+            pair = (self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n], self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n])
+        cache[n] = pair                                            # (re-inserted last: dicts keep insertion order)
         return pair
 
     def select_records(self, slot, n, mode=SELECTING_ALL, use_pyramid=False, fb=65533):
@@ -303,8 +308,9 @@ class Context:
         self._check(self._lib.klt_select_begin_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))
 
     def select_finish(self):
-        """Second half: waits, and completes the selection (klt_select_finish)."""
-        self._check(self._lib.klt_select_finish(self._h))
+        """Second half: waits, and completes the selection (klt_select_finish).  True when the list was rewritten after the first half's
+        launches had run: work enqueued in between that read the list (a tracker launch of the next frame) must be enqueued again."""
+        return self._check(self._lib.klt_select_finish(self._h)) > 0
 
     def select_prepare(self, slot):
         """Scores of the slot's level-0 images ahead of a REPLACING_SOME selection on it (klt_select_prepare_async); asynchronous."""

@@ -161,6 +161,7 @@ struct klt_ctx {
     // a rank that prepares a whole block of frames while it waits for the feature list of the previous block keeps one per frame.
     std::vector<ScoreCache> pre = std::vector<ScoreCache>(2);      // KLT_OPT_SCORE_SETS
     std::unique_ptr<SelectJob> sel_job;       // a selection between klt_select_begin_async and klt_select_finish
+    hipEvent_t ev_sel = nullptr;              // behind the last launch of the pending selection's latest batch: what klt_select_finish waits for
     float *sat_pre = nullptr;
     size_t sat_pre_cap = 0;
     uint64_t gen_counter = 0, pre_stamp = 0;
@@ -841,6 +842,7 @@ void klt_destroy(klt_ctx *c)
     if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
     for (void *p : c->pinned) hipHostFree(p);
     for (hipEvent_t e : c->ring) hipEventDestroy(e);
+    if (c->ev_sel) hipEventDestroy(c->ev_sel);
     for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes); }
     for (FeatBuf &b : c->fbs)
         if (!b.view) hipFree(b.d);
@@ -1192,6 +1194,10 @@ int select_job_rounds(klt_ctx *c, SelectJob &j)
         if (e) return fail(c, KLT_ERR_DEVICE, std::string("nms launch: ") + hipGetErrorString((hipError_t)e));
         launch_mis_results(c->stream, c->readback, rem_d, j.look, j.info_d, c->placed_d);
     }
+    // the host's look waits for THIS point of the stream, not for the stream: a caller may enqueue work that only reads the list (the next
+    // frame's tracker) between the two halves, and the GPU keeps it queued while the host looks and enqueues the next selection
+    if (!c->ev_sel) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
     return 0;
 }
 
@@ -1199,8 +1205,10 @@ int select_job_rounds(klt_ctx *c, SelectJob &j)
 int select_job_finish(klt_ctx *c, SelectJob &j)
 {
     const unsigned *const rem = c->readback, *const info = c->readback + 64, *const res = c->readback + 72;
+    int looks = 0;                       // > 1: the list was rewritten after the launches of klt_select_begin_async had run
     for (;;) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev_sel));
+        looks++;
         if (rem[j.look - 1] != 0u) {
             // a dependency chain longer than the passes run so far: put the list back and keep going
             if (j.round + j.rounds_per_look > SelectJob::kMaxRounds) return fail(c, KLT_ERR_DEVICE, "minimum-distance passes did not settle");
@@ -1230,7 +1238,7 @@ int select_job_finish(klt_ctx *c, SelectJob &j)
     }
     if (j.pre) j.pre->gen = 0;                                       // a score set is used once
     HIPCHK(c, hipGetLastError());
-    return KLT_OK;
+    return looks > 1 ? 1 : KLT_OK;
 }
 }  // namespace
 
@@ -1617,7 +1625,8 @@ int klt_select_finish(klt_ctx *c)
 int klt_select_async(klt_ctx *c, int slot, int mode, int use_pyramid, int fb, int n)
 {
     if (int rc = klt_select_begin_async(c, slot, mode, use_pyramid, fb, n)) return rc;
-    return klt_select_finish(c);
+    const int rc = klt_select_finish(c);
+    return rc > 0 ? KLT_OK : rc;
 }
 
 int klt_select(klt_ctx *c, int slot, int mode, int use_pyramid, klt_feat *inout, int n, int *n_placed)

@@ -1036,7 +1036,23 @@ __global__ __launch_bounds__(256) void mis_compact_kernel(const unsigned long lo
     __shared__ unsigned red[4];
     const int tid = threadIdx.x, t0 = blockIdx.x * 256, t = t0 + tid;
     unsigned before = 0;
-    for (int i = tid; i < t0; i += 256) before += acc_cnt[i];
+    {
+        // sixteen loads in flight: the last workgroup of a 4K frame walks 22 strides of 256 counts, and a loop that waits for every
+        // load in turn made this kernel 22 us long (round-3 kernel trace) for 5 us of work
+        int i = tid;
+        for (; i + 15 * 256 < t0; i += 16 * 256) {
+            unsigned v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = acc_cnt[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 16; u++) before += v[u];
+        }
+        unsigned v[16];                                         // the tail: clamped, unconditional loads (a guard is a branch)
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = acc_cnt[min(i + u * 256, max(t0 - 1, 0))];
+#pragma unroll
+        for (int u = 0; u < 16; u++) before += i + u * 256 < t0 ? v[u] : 0u;
+    }
     const unsigned base = block_sum_256(before, red);
     const unsigned c = t < tiles ? acc_cnt[t] : 0u;
     const unsigned incl = block_scan_256(c, red);
@@ -1080,14 +1096,20 @@ __global__ __launch_bounds__(256) void mis_prepare_kernel(const klt_feat *__rest
     {
         // (eight loads in flight: the last workgroup of a 20 000-feature list walks 78 strides of 256 records)
         int i = tid;
-        for (; i + 7 * 256 < f0; i += 8 * 256) {
-            int v[8];
+        for (; i + 15 * 256 < f0; i += 16 * 256) {
+            int v[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = fl[i + u * 256].val;
+            for (int u = 0; u < 16; u++) v[u] = fl[i + u * 256].val;
 #pragma unroll
-            for (int u = 0; u < 8; u++) before += v[u] < 0 ? 1u : 0u;
+            for (int u = 0; u < 16; u++) before += v[u] < 0 ? 1u : 0u;
         }
-        for (; i < f0; i += 256) before += fl[i].val < 0 ? 1u : 0u;
+        {                                                       // the tail as one more batch: clamped, unconditional loads
+            int v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = fl[min(i + u * 256, max(f0 - 1, 0))].val;
+#pragma unroll
+            for (int u = 0; u < 16; u++) before += (i + u * 256 < f0 && v[u] < 0) ? 1u : 0u;
+        }
     }
     const unsigned base = block_sum_256(before, red);
     const unsigned lost = (f < nfeat && ft.val < 0) ? 1u : 0u;

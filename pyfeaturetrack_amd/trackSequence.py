@@ -167,23 +167,38 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
             img = next(frames, None)
             return None if img is None else ("raw", image_to_array(img))
 
+        def track(j):                                # frame j - 1 -> j: row j - 1 of the table in, row j out
+                cur, prev = s[j % ring], s[(j - 1) % ring]
+                if affine:
+                    ctx.track_affine_async(prev, cur, row_fb(j - 1), row_fb(j), nFeatures, state)
+                else:
+                    ctx.track_async(prev, cur, row_fb(j - 1), row_fb(j), nFeatures)
+
+        # The tracker of frame k + 1 only READS the list that frame k's replacement completes, so it is enqueued before the host looks at
+        # that replacement's outcome (klt_select_finish): the GPU has it queued while the host turns around.  In the rare case that the
+        # look makes the selection rewrite the list, the tracker is enqueued once more.  Not with the affine check: it updates the
+        # per-feature state in place, so its launch cannot simply be repeated.
+        ahead = prefetch and replace_lost and not affine
         nxt = next_frame()
         if nxt is not None:
             stage_frame(1, nxt)
+            if ahead:
+                track(1)
         while nxt is not None:
             k += 1
             nxt = next_frame()
-            cur, prev = s[k % ring], s[(k - 1) % ring]
-            if affine:
-                ctx.track_affine_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures, state)
-            else:
-                ctx.track_async(prev, cur, row_fb(k - 1), row_fb(k), nFeatures)
+            if not ahead:
+                track(k)
             if replace_lost:                         # the chain first: tracker, then the replacement pass up to the host's look at it
-                ctx.select_begin(cur, REPLACING_SOME, True, row_fb(k), nFeatures)
+                ctx.select_begin(s[k % ring], REPLACING_SOME, True, row_fb(k), nFeatures)
             if nxt is not None and prefetch:
                 stage_frame(k + 1, nxt)              # the next frame's upload, build and scores: enqueued while the GPU works on the above
+                if ahead:
+                    track(k + 1)
             if replace_lost:
-                ctx.select_finish()
+                redo = ctx.select_finish()
+                if redo and ahead and nxt is not None:
+                    track(k + 1)
             if nxt is not None and not prefetch:
                 stage_frame(k + 1, nxt)
     finally:

@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `-m gpu`)")
 
 
+def pytest_sessionstart(session):
+    """The tests exercise the libraries in the tree: make sure they were built from the sources in the tree (a no-op when they are
+    up to date; hipcc cross-compiles without a GPU).  A stale libkltgpu.so once cost an afternoon."""
+    import shutil
+    import subprocess
+    if shutil.which("make") is None:
+        return
+    for sub, target in (("pyfeaturetrack_amd/csrc", "libkltgpu.so"), ("oracle", "libkltoracle.so")):
+        d = os.path.join(REPO, sub)
+        if subprocess.run(["make", "-q", "-C", d, target], capture_output=True).returncode != 0:
+            subprocess.run(["make", "-C", d, "-j4", target], check=False, capture_output=True)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

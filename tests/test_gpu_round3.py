@@ -388,3 +388,55 @@ def test_gatherv_timeout_and_the_fixed_teardown_paths():
             c.affine_copy(2, 7, 64)
     finally:
         c.close()
+
+
+def test_tracker_enqueued_before_the_selections_look_is_repeated_when_the_list_changes():
+    """klt_select_finish returns 1 when the host's look made the selection rewrite the list after the first half's launches had run
+    (here: a score ramp -- one dependency chain across the frame -- needs far more minimum-distance passes than a fresh context
+    enqueues before it looks); a tracker launched in between has then read an unfinished list and must be launched again, which is
+    what KLTTrackSequence and bench.py --config cfg5 do.  The repeated launch gives the records of the plain order (select, then
+    track), whether or not the look asked for more (real scores: either way)."""
+    from helpers import make_tc
+    from pyfeaturetrack_amd.backend import Context, SELECTING_ALL
+    n, w, h = 400, 500, 300
+    base = synth.synth_base(w, h, 13)
+    f0, f1 = synth.synth_frame(w, h, 13, 0, shift=(1.5, -1.0), base=base), synth.synth_frame(w, h, 13, 1, shift=(1.5, -1.0), base=base)
+    tc = make_tc(levels=2, ss=2, mindist=10)
+    p = params_from_tc(tc)
+    bx, by = int(max(p.borderx, p.window_width / 2.0)), int(max(p.bordery, p.window_height / 2.0))
+    ys, xs = np.mgrid[0:h - 2 * by, 0:w - 2 * bx]
+    ramp = (10.0 + xs + 0.001 * ys).astype(np.float32)
+    for scores in (ramp, None):
+        c = Context(0)                                         # fresh: it enqueues its default number of passes before the first look
+        try:
+            c.configure(tc)
+            c.upload(0, f0)
+            c.upload(1, f1)
+            c.build_pyramids_batch([0, 1], sync=True)
+            # plain order
+            if scores is not None:
+                c.set_score_override(scores)
+            c.select_async(0, SELECTING_ALL, True, 0, n)
+            c.track_async(0, 1, 0, 1, n)
+            want_list, want_trk = c.featbuf_download(0, n), c.featbuf_download(1, n)
+            assert (want_list["val"] > 0).sum() > n // 2
+        finally:
+            c.close()
+        c = Context(0)
+        try:
+            c.configure(tc)
+            c.upload(0, f0)
+            c.upload(1, f1)
+            c.build_pyramids_batch([0, 1], sync=True)
+            if scores is not None:
+                c.set_score_override(scores)
+            c.select_begin(0, SELECTING_ALL, True, 0, n)
+            c.track_async(0, 1, 0, 2, n)                       # reads the list the selection may still be working on
+            rewritten = c.select_finish()
+            assert rewritten or scores is None, "the ramp needs more passes than a fresh context enqueues before it looks"
+            if rewritten:
+                c.track_async(0, 1, 0, 2, n)
+            assert np.array_equal(c.featbuf_download(0, n), want_list)
+            assert np.array_equal(c.featbuf_download(2, n), want_trk)
+        finally:
+            c.close()
