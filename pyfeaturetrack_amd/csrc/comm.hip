@@ -298,6 +298,7 @@ int comm_wait(KltComm *k, std::string &err)
     for (;;) {
         const hipError_t q = hipStreamQuery(k->side);
         if (q == hipSuccess) return 0;
+        (void)hipGetLastError();                 // "not ready" is an answer, not an error: it must not surface in a later hipGetLastError check
         if (q != hipErrorNotReady) { err = std::string("hipStreamQuery(side stream): ") + hipGetErrorString(q); return KLT_ERR_DEVICE; }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (ms > k->timeout_ms) {

@@ -973,6 +973,7 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
             if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
         } else {
             const hipError_t q = hipEventQuery(s->ev_consumed);
+            if (q != hipSuccess) (void)hipGetLastError();         // ("not ready" must not surface in a later hipGetLastError check)
             if (q == hipErrorNotReady) HIPCHK(c, hipEventSynchronize(s->ev_consumed));
             else if (q != hipSuccess) return fail(c, KLT_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
         }
