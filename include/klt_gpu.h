@@ -258,7 +258,7 @@ int klt_comm_fence_featbuf_async(klt_ctx *ctx, int fb);
 int klt_comm_wait(klt_ctx *ctx);           /* the host waits for them -- at most the communicator's timeout, then KLT_ERR_TIMEOUT */
 /* Host-side waits on the communicator (klt_comm_wait, klt_sync, klt_comm_allreduce_max, and the waits before device memory that a
  * collective may touch is freed) give up after `ms` milliseconds with KLT_ERR_TIMEOUT instead of hanging when a peer has died;
- * default 120 000, or KLT_COMM_TIMEOUT_MS in the environment; <= 0 waits for ever.  After a timeout the communicator is unusable:
+ * default 300 000, or KLT_COMM_TIMEOUT_MS in the environment; <= 0 waits for ever.  After a timeout the communicator is unusable:
  * the rank should report and exit non-zero (never restart in place a process that has touched the GPU). */
 int klt_comm_set_timeout(klt_ctx *ctx, double ms);
 /* element-wise maximum over all ranks of n <= 16 doubles (host in, host out; synchronous -- also the barrier the

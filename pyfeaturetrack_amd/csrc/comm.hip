@@ -92,7 +92,7 @@ struct KltComm {
     size_t ring_next = 0;
     hipEvent_t last_done = nullptr;        // end of the most recent collective
     double *scratch = nullptr;             // device scratch for the small reductions (16 doubles)
-    double timeout_ms = 120000.0;          // host-side waits give up after this long (KLT_COMM_TIMEOUT_MS / comm_set_timeout; <= 0: never)
+    double timeout_ms = 300000.0;          // host-side waits give up after this long (KLT_COMM_TIMEOUT_MS / comm_set_timeout; <= 0: never)
 };
 
 #define COMM_HIP(call)                                                                  \
