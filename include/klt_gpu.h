@@ -10,7 +10,8 @@
  *
  * Conventions
  *   - plain C types only; no torch / HIP types cross the boundary;
- *   - every function returns 0 on success or a negative klt_status; the message is available
+ *   - every function returns 0 on success or a negative klt_status (klt_timing_read: the entry count; klt_slot_state: the
+ *     state bits; klt_select_finish: also 1, "done, and the list was rewritten on the way" -- see there); the message is available
  *     from klt_last_error(); nothing exits the process or throws across the ABI
  *     (the reference's KLTError prints and calls exit(1), error.py:12-14);
  *   - per-feature failures are data (klt_feat.val < 0, klt.py:23-29), not errors;
