@@ -440,3 +440,56 @@ def test_tracker_enqueued_before_the_selections_look_is_repeated_when_the_list_c
             assert np.array_equal(c.featbuf_download(2, n), want_trk)
         finally:
             c.close()
+
+
+def test_frame_cache_on_random_call_sequences():
+    """Random sequences of KLTSelectGoodFeatures / KLTTrackFeatures / KLTReplaceLostFeatures over a pool of five frames (some of them
+    edited in place between calls), with and without sequential mode: a tracking context that remembers what its slots hold gives
+    the same lists, call by call, as one that forgets before every call (= the reference's behaviour of converting and rebuilding
+    everything every time)."""
+    from helpers import make_tc
+    sgf, trk = _api_modules()
+    rng = np.random.default_rng(5)
+    try:
+        base = synth.synth_base(400, 300, 8)
+        pool = [synth.synth_frame(400, 300, 8, k, shift=(1.3, 0.9), base=base) for k in range(5)]
+        for trial in range(40):
+            seq_mode = bool(trial & 1)
+            frames_a = [f.copy() for f in pool]
+            frames_b = [f.copy() for f in pool]
+            tcs = []
+            for _ in range(2):
+                tc = make_tc(levels=2, ss=2, max_residue=12.0)
+                tc.sequentialMode = seq_mode
+                tcs.append(tc)
+            n = int(rng.integers(40, 200))
+            i0 = int(rng.integers(0, 5))
+            fls = [sgf.KLTSelectGoodFeatures(tcs[0], frames_a[i0], n)]
+            trk.KLTForgetFrames(tcs[1])
+            fls.append(sgf.KLTSelectGoodFeatures(tcs[1], frames_b[i0], n))
+            assert _records(fls[0]) == _records(fls[1])
+            cur = i0
+            for step in range(10):
+                op = rng.choice(["track", "track", "track", "replace", "select", "edit"])
+                if op == "edit":                               # same object, new pixels (a block large enough to hold lattice samples)
+                    k = int(rng.integers(0, 5))
+                    y, x = int(rng.integers(0, 200)), int(rng.integers(0, 300))
+                    val = int(rng.integers(0, 255))
+                    for fr in (frames_a, frames_b):
+                        fr[k][y:y + 60, x:x + 60] = val
+                    continue
+                nxt = int(rng.integers(0, 5))
+                for which, (tc, fr) in enumerate(zip(tcs, (frames_a, frames_b))):
+                    if which == 1:
+                        trk.KLTForgetFrames(tc)
+                    if op == "track":
+                        trk.KLTTrackFeatures(tc, fr[cur], fr[nxt], fls[which])
+                    elif op == "replace":
+                        sgf.KLTReplaceLostFeatures(tc, fr[cur], fls[which])
+                    else:
+                        fls[which] = sgf.KLTSelectGoodFeatures(tc, fr[nxt], n)
+                if op != "replace":
+                    cur = nxt
+                assert _records(fls[0]) == _records(fls[1]), "trial %d step %d (%s, sequential %s)" % (trial, step, op, seq_mode)
+    finally:
+        sgf.KLT_verbose = trk.KLT_verbose = 1
