@@ -290,6 +290,12 @@ int klt_smooth_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, const d
 int klt_gradients_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, const double *gauss, int ng,
                       const double *deriv, int nd, float *gradx, float *grady);
 
+/* KLTPyramid.Compute, pyramid.py:37-77: level 0 = src unchanged; level i = level i-1 smoothed with `gauss` (the taps of sigma =
+ * subsampling * sigma_fact, convolve.py:27-93) and sampled at (ss y + ss/2, ss x + ss/2), dimensions int(n / ss).  dst receives
+ * levels 1 .. nlevels-1 back to back (nothing for nlevels = 1); all levels stay on the device until the one download. */
+int klt_pyramid_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, int nlevels, int subsampling, const double *gauss, int ng,
+                    float *dst);
+
 /* ---- per-kernel timing (HIP events on the context's stream) -------------------------------- */
 typedef struct { char name[32]; uint32_t launches; float total_ms; double bytes; } klt_kernel_time;
 int klt_timing_enable(klt_ctx *ctx, int on);                /* resets the accumulated figures.  1: an event pair around every launch;

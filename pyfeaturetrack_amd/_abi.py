@@ -106,6 +106,7 @@ SYMBOLS = {
     "klt_set_score_override": (_I, [_P, _P, _I]),
     "klt_download_sorted_candidates": (_I, [_P, _P, _P, _P, _I, _PI]),
     "klt_smooth_f32": (_I, [_P, _P, _I, _I, C.POINTER(C.c_double), _I, _P]),
+    "klt_pyramid_f32": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_double), _I, _P]),
     "klt_gradients_f32": (_I, [_P, _P, _I, _I, C.POINTER(C.c_double), _I, C.POINTER(C.c_double), _I, _P, _P]),
     "klt_comm_unique_id": (_I, [_P]),
     "klt_comm_init_rank": (_I, [_P, _I, _I, _P]),

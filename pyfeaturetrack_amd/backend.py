@@ -421,6 +421,22 @@ class Context:
                                              out.ctypes.data))
         return out
 
+    def pyramid(self, img, subsampling, nlevels, gauss):
+        """[level 1, ..., level nlevels-1] of KLTPyramid.Compute (klt_pyramid_f32): every level smoothed and subsampled on the device."""
+        img = np.ascontiguousarray(img, np.float32)
+        dims, (nr, nc) = [], img.shape
+        for _ in range(1, nlevels):
+            nc, nr = nc // subsampling, nr // subsampling
+            dims.append((nr, nc))
+        out = np.empty(sum(r * c for r, c in dims), np.float32)
+        self._check(self._lib.klt_pyramid_f32(self._h, img.ctypes.data, img.shape[1], img.shape[0], nlevels, subsampling, _dp(gauss), len(gauss),
+                                              out.ctypes.data))
+        levels, off = [], 0
+        for r, c in dims:
+            levels.append(out[off:off + r * c].reshape(r, c))
+            off += r * c
+        return levels
+
     def gradients(self, img, gauss, deriv):
         img = np.ascontiguousarray(img, np.float32)
         gx = np.empty_like(img)

@@ -2306,6 +2306,55 @@ int klt_gradients_f32(klt_ctx *c, const float *src, int ncols, int nrows, const 
     return KLT_OK;
 }
 
+// KLTPyramid.Compute, pyramid.py:37-77: level 0 = src as it is; level i = level i-1 smoothed with `gauss` (sigma = subsampling *
+// sigma_fact, computed by the caller) and sampled at (ss y + ss/2, ss x + ss/2), dims int(n / ss).  Levels 1 .. nlevels-1 come back
+// concatenated in dst.  Only the surviving columns / rows are evaluated; every level stays on the device until the one download.
+int klt_pyramid_f32(klt_ctx *c, const float *src, int ncols, int nrows, int nlevels, int subsampling, const double *gauss, int ng, float *dst)
+{
+    if (!c || !src || !gauss || (nlevels > 1 && !dst)) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ng < 1 || ng > KLT_MAX_KERNEL_WIDTH || !(ng & 1)) return fail(c, KLT_ERR_ARG, "tap count must be odd and at most 71");
+    if (ncols <= 0 || nrows <= 0 || nlevels < 1 || nlevels > KLT_MAX_LEVELS) return fail(c, KLT_ERR_ARG, "bad pyramid geometry");
+    const int ss = subsampling;
+    if (nlevels > 1 && ss != 2 && ss != 4 && ss != 8 && ss != 16 && ss != 32) return fail(c, KLT_ERR_ARG, "subsampling must be 2, 4, 8, 16 or 32");
+    if (nlevels == 1) return KLT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)ncols * nrows;
+    size_t total = 0;
+    {
+        int nc = ncols, nr = nrows;
+        for (int l = 1; l < nlevels; l++) {
+            nc /= ss; nr /= ss;
+            if (nc <= 0 || nr <= 0) return fail(c, KLT_ERR_ARG, "image too small for the requested pyramid");
+            total += (size_t)nc * nr;
+        }
+    }
+    if (int rc = ensure_tmp(c, N)) return rc;
+    float *d_in = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_in, (N + total) * sizeof(float)));
+    float *d_lv = d_in + N;
+    Taps g;
+    make_taps(gauss, ng, g);
+    hipError_t e = hipMemcpyAsync(d_in, src, N * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const float *cur = d_in;
+        float *out = d_lv;
+        int nc = ncols, nr = nrows;
+        for (int l = 1; l < nlevels; l++) {
+            const int dc = nc / ss, dr = nr / ss;
+            launch_hconv_f32(c->stream, cur, nc, nr, c->tmpA, nullptr, dc, ss, ss / 2, g, nullptr);
+            launch_vconv(c->stream, c->tmpA, nullptr, dc, nr, out, nullptr, dr, ss, ss / 2, g, nullptr);
+            cur = out;
+            out += (size_t)dc * dr;
+            nc = dc; nr = dr;
+        }
+        e = hipMemcpyAsync(dst, d_lv, total * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_in);
+    if (e != hipSuccess) return fail(c, KLT_ERR_DEVICE, hipGetErrorString(e));
+    return KLT_OK;
+}
+
 // ------------------------------------------------------------------------------------------ timing
 int klt_timing_enable(klt_ctx *c, int on)
 {

@@ -2,12 +2,13 @@
 
 The tracker does not use this class -- it builds all three pyramids of a frame on the device in
 one enqueue (klt_build_pyramids).  The class is kept for API compatibility: level 0 is the input,
-level i is level i-1 smoothed with sigma = subsampling * sigma_fact (on the GPU) and sampled at
-(ss*y + ss/2, ss*x + ss/2), dimensions int(n / ss) per level.
+level i is level i-1 smoothed with sigma = subsampling * sigma_fact and sampled at
+(ss*y + ss/2, ss*x + ss/2), dimensions int(n / ss) per level -- all levels in one call on the GPU
+(klt_pyramid_f32: only the surviving columns / rows are evaluated, one download at the end).
 """
 import numpy as np
 
-from .convolve import KLTComputeSmoothedImage
+from .convolve import _computeKernels
 from .error import KLTError
 
 _ALLOWED = (2, 4, 8, 16, 32)
@@ -29,16 +30,10 @@ class KLTPyramid:
             nrows /= subsampling
 
     def Compute(self, img, sigma_fact):
+        from .backend import default_context
         img = np.ascontiguousarray(img, np.float32)
-        ss = self.subsampling
         assert self.ncols[0] == img.shape[1] and self.nrows[0] == img.shape[0]
-        sigma = ss * sigma_fact
         self.img[0] = img
-        cur = img
-        nrows, ncols = img.shape
-        for i in range(1, self.nLevels):
-            smooth = KLTComputeSmoothedImage(cur, sigma)
-            ncols = int(ncols / ss)
-            nrows = int(nrows / ss)
-            cur = np.ascontiguousarray(smooth[ss // 2::ss, ss // 2::ss][:nrows, :ncols])
-            self.img[i] = cur
+        if self.nLevels > 1:
+            gauss, _ = _computeKernels(self.subsampling * sigma_fact)
+            self.img[1:] = default_context().pyramid(img, self.subsampling, self.nLevels, gauss)

@@ -493,3 +493,34 @@ def test_frame_cache_on_random_call_sequences():
                 assert _records(fls[0]) == _records(fls[1]), "trial %d step %d (%s, sequential %s)" % (trial, step, op, seq_mode)
     finally:
         sgf.KLT_verbose = trk.KLT_verbose = 1
+
+
+def test_klt_pyramid_class_on_the_device(cfg1, synth251):
+    """KLTPyramid.Compute (pyramid.py:37-77; an API-compatibility class, the tracker builds its pyramids with klt_build_pyramids):
+    all levels in one call on the device, equal to the reference's pyramid planes -- level 1 of img0's and img1's image pyramids from
+    their level 0 (goldens of the reference itself), and to the levels of the tracker's own build at an odd size with three levels."""
+    from helpers import make_tc, synth251_frames
+    from pyfeaturetrack_amd.backend import Context
+    from pyfeaturetrack_amd.pyramid import KLTPyramid
+    for name in ("p0", "p1"):
+        lvl0 = cfg1[name + "_img_0"]
+        pyr = KLTPyramid(lvl0.shape[1], lvl0.shape[0], 4, 2)
+        pyr.Compute(lvl0, 0.9)
+        assert np.array_equal(pyr.img[0], lvl0) and np.array_equal(pyr.img[1], cfg1[name + "_img_1"])
+        assert pyr.ncols == [320, 80.0] and pyr.nrows == [240, 60.0]
+    tc = make_tc(levels=3, ss=2)
+    c = Context(0)
+    try:
+        c.configure(tc)
+        c.upload(0, synth251_frames()[0])
+        c.build_pyramids(0)
+        want = [c.download_level(0, 0, l) for l in range(3)]
+    finally:
+        c.close()
+    pyr = KLTPyramid(251, 187, 2, 3)
+    pyr.Compute(want[0], tc.pyramid_sigma_fact)
+    for l in range(3):
+        assert np.array_equal(pyr.img[l], want[l]), l
+    one = KLTPyramid(64, 48, 4, 1)
+    one.Compute(np.ones((48, 64), np.float32), 0.9)
+    assert len(one.img) == 1
