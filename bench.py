@@ -210,6 +210,12 @@ def cpu_baseline_of(ko, one_step, nfeat, what, all_cores=True, budget_s=10.0):
     return out
 
 
+def list_digest(fl):
+    """sha256 (16 hex digits) of the (x, y, val) columns of a feature list"""
+    cols = np.stack([fl["x"].view(np.int32), fl["y"].view(np.int32), fl["val"].astype(np.int32)], axis=1)
+    return hashlib.sha256(np.ascontiguousarray(cols).tobytes()).hexdigest()[:16]
+
+
 def file_sha16(rel):
     try:
         return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
@@ -497,6 +503,16 @@ def run_cfg4(args, json_fd):
         full = gather.result()
         if ranks.rank == 0:
             gathered_ok = bool(full.shape == (total, nf) and np.array_equal(full[:pairs], out))
+            if ko and ranks.world > 1 and par.get("parity_checked") is not None:
+                # what another rank contributed, against the oracle: the last pair of the batch (the last rank's shard), selected and
+                # tracked on the CPU from its seed
+                g0, g1 = synth.synth_pair(w, h, seed=total - 1)
+                ko.set_threads(usable_cores())
+                osel = ko.select_good_features(p, g0.astype(np.float32), nf)
+                ko.set_threads(1)
+                same, dx = records_equal(full[total - 1], oracle_track(ko, p, g0, g1, osel, threads=usable_cores()))
+                checks.append(("pair %d as gathered from rank %d" % (total - 1, ranks.world - 1), same, dx))
+                par = parity_summary(checks, "tracked records of the first and the last pair of rank 0's shard and of the batch's last pair as gathered")
     roof = cpu = None
     if ranks.rank == 0 and pairs:
         nst = min(args.steps, 10)
@@ -981,6 +997,7 @@ def run_cfg5_blocks(args, json_fd, ranks):
                                 "mode, lost features replaced after every frame; the feature list is the baton between the blocks (RCCL "
                                 "send / receive), the blocks' pyramids and selection scores are prepared on the owners' build streams" % (world, B),
                                 extra_cfg={"rccl_ranks": world, "live_after_each_block": [int((t["val"] >= 0).sum()) for t in table],
+                                           "list_sha16_after_each_block": [list_digest(t) for t in table],
                                            "ms_per_frame_of_the_chain": el / (reps * B * world) * 1e3, "baton_copy_ok": baton_ok,
                                            "region_ms": {"median": el * 1e3, "min": min(regions) * 1e3, "max": max(regions) * 1e3}}))
     ctx.close()
@@ -1081,14 +1098,16 @@ def run_cfg2(args, json_fd):
 
     step_no = [0]
 
-    def one_step():
-        """one pass over the resident pairs.  The groups go out in rounds of one group per context, the builds of a round before its
+    def one_step(collect=True):
+        """one pass over the resident pairs (collect = False: without the collectives -- the untimed prewarm runs for a TIME, i.e. a
+        different number of steps on every rank, and a collective must be issued by all ranks or by none).  The groups go out in rounds of one group per context, the builds of a round before its
         tracker launches: every stream has work a few microseconds after the step starts (enqueueing a group takes the host ~25 us);
         the order inside each stream, and the work, are the same either way.  N > 1: the step's record table of every context is
         all-gathered with ONE collective behind its last tracker launch; two tables alternate, a table is reused once its collective
         of two steps ago has read it."""
         t = step_no[0] % 2
         step_no[0] += 1
+        gather = distributed and collect
         if distributed:
             for cx in ctxs:
                 cx.comm_fence_featbuf((T_OUT0, T_OUT1)[t])
@@ -1097,7 +1116,7 @@ def run_cfg2(args, json_fd):
                 group_build(cx, j)
             for cx in ctxs:
                 group_track(cx, j, t)
-        if distributed:
+        if gather:
             for cx in ctxs:
                 cx.allgather_featbuf_async((T_OUT0, T_OUT1)[t], (T_GATH0, T_GATH1)[t], PL * NFEAT)
         return t
@@ -1105,7 +1124,7 @@ def run_cfg2(args, json_fd):
     # bring the GPU to its steady state first (the same work as the steps)
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        one_step()
+        one_step(collect=False)
         for cx in ctxs:
             cx.sync()
     for _ in range(args.warmup):
@@ -1140,7 +1159,19 @@ def run_cfg2(args, json_fd):
             for i in range(NP):
                 same, dx = records_equal(outs[i], oracle_track(ko, p, frames[i][0], frames[i][1], lists[i], threads=nthreads))
                 checks.append(("pair %d (seed %d)" % (i, seeds[i]), same, dx))
-        parity = parity_summary(checks, "tracked records of all %d resident pairs, last timed step" % NP)
+        what = "tracked records of all %d resident pairs, last timed step" % NP
+        if ko and world > 1:
+            # ... and what another rank contributed: pair 0 of the last rank (context 0, row 0 of its table) as this rank received it,
+            # against the oracle's selection + tracking of that pair from its seed
+            g0, g1 = synth.synth_pair(WIDTH, HEIGHT, seed=(world - 1) * NP + 1)
+            ko.set_threads(usable_cores())
+            osel = ko.select_good_features(p, g0.astype(np.float32), NFEAT)
+            ko.set_threads(1)
+            got0 = ctxs[0].featbuf_download((T_GATH0, T_GATH1)[t_last], world * PL * NFEAT).reshape(world, PL, NFEAT)
+            same, dx = records_equal(got0[world - 1][0], oracle_track(ko, p, g0, g1, osel, threads=usable_cores()))
+            checks.append(("pair 0 of rank %d as gathered" % (world - 1), same, dx))
+            what += " + pair 0 of the last rank as received through the all-gather"
+        parity = parity_summary(checks, what)
 
     # second pass: per-kernel timing + iteration counters for the roofline, on context 0 over its own pairs
     roofline = None

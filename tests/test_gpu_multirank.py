@@ -1,0 +1,99 @@
+"""Several ranks of the multi-GPU path on ONE GPU: the ranks share device 0 (KLT_RANKS_SHARE_DEVICE) and librccl is replaced by
+tests/stub_rccl (KLT_RCCL_LIB), a file-based stand-in with RCCL's entry points -- RCCL itself refuses two ranks of a communicator on
+one device.  Everything else is the real thing: bench.py's launcher and rendezvous, one process per rank, libkltgpu.so's comm.hip
+(gather with per-rank counts, all-gather of the record tables, send / receive of the feature list, barrier and max over ranks), the
+per-rank seeds and shard arithmetic, the cross-rank checks against the oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+STUB_DIR = os.path.join(REPO, "tests", "stub_rccl")
+STUB = os.path.join(STUB_DIR, "libstubrccl.so")
+
+
+@pytest.fixture(scope="module")
+def stub_rccl():
+    src = os.path.join(STUB_DIR, "stub_rccl.cpp")
+    if not os.path.exists(STUB) or os.path.getmtime(STUB) < os.path.getmtime(src):
+        subprocess.run(["g++", "-shared", "-fPIC", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", STUB,
+                        "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return STUB
+
+
+def run_ranks(args, tmp_path, stub, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KLT_RDZV_FILE", "MASTER_PORT")}
+    env.update(KLT_RANKS_SHARE_DEVICE="0", KLT_RCCL_LIB=stub, KLT_STUB_RCCL_DIR=str(tmp_path / "mail"), KLT_COMM_TIMEOUT_MS="240000")
+    os.makedirs(env["KLT_STUB_RCCL_DIR"], exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cfg2_ranks_with_their_own_pairs_and_the_all_gather(world, tmp_path, stub_rccl):
+    """`bench.py --gpus N`: every rank runs its own distinct pairs (seeds rank * NP + 1 ...), each context's record table is all-gathered
+    every step; rank 0 checks all of its own pairs against the oracle AND pair 0 of the last rank as it arrived through the gather."""
+    line = run_ranks(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--repeats", "5", "--resident-pairs", "4", "--batch", "2",
+                      "--no-cpu-baseline", "--no-extras", "--min-timed-s", "0"], tmp_path, stub_rccl)
+    assert line["n_gpus"] == world and line["config"]["rccl_ranks"] == world and line["config"]["pairs_per_step"] == 4 * world
+    assert line["parity_checked"] is True and line["parity_cases"] == 5 and line["max_abs_dx"] <= 1e-3
+    assert "as received through the all-gather" in line["parity_what"]
+    assert line["value"] > 0 and line["scaling"] == "weak"
+
+
+def test_cfg4_shards_of_unequal_size_through_the_gather_with_counts(tmp_path, stub_rccl):
+    """7 pairs over 2 ranks (4 + 3) and over 3 ranks (3 + 2 + 2): klt_gatherv_featbuf_async with a count per rank; rank 0 holds the whole
+    [7 x 2000] table, its own shard equals what it produced and the batch's last pair -- tracked by another rank -- equals the
+    oracle's."""
+    for world, shards in ((2, [4, 3]), (3, [3, 2, 2])):
+        line = run_ranks(["--config", "cfg4", "--gpus", str(world), "--pairs", "7", "--steps", "2", "--warmup", "1", "--repeats", "5",
+                          "--no-cpu-baseline", "--min-timed-s", "0"], tmp_path / str(world), stub_rccl)
+        cfg = line["config"]
+        assert cfg["pairs_per_rank"] == shards and cfg["rccl_ranks"] == world and cfg["gathered_table_ok"] is True
+        assert line["parity_checked"] is True and line["parity_cases"] == 3, line
+        assert "as gathered" in line["parity_what"]
+
+
+def test_cfg5_blocks_hand_the_feature_list_from_rank_to_rank(tmp_path, stub_rccl):
+    """`bench.py --config cfg5 --gpus 2`: ONE 4K sequence, frames 0..7 on rank 0 and 7..14 on rank 1, the feature list travelling from
+    rank 0 to rank 1 as a baton (klt_sendrecv_featbuf_async) and both blocks' final lists gathered on rank 0.  The same 14 steps on a
+    single context in this process give the same two lists (sha256 of x, y, val)."""
+    sys.path.insert(0, REPO)
+    import bench
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.backend import Context
+    line = run_ranks(["--config", "cfg5", "--gpus", "2", "--steps", "7", "--repeats", "5", "--min-timed-s", "0"], tmp_path, stub_rccl)
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["rccl_ranks"] == 2 and len(cfg["live_after_each_block"]) == 2
+    w, h, n, B = 3840, 2160, 20000, 7
+    tc = bench.cfg2_context()
+    tc.max_residue = 10.0
+    c = Context(0)
+    try:
+        c.configure(tc)
+        base = synth.synth_base(w, h, 4)
+        c.upload(0, synth.synth_frame(w, h, 4, 0, base=base))
+        c.build_pyramids(0)
+        fl, placed = c.select(0, n, use_pyramid=True)
+        c.featbuf_upload(0, fl)
+        want = []
+        for k in range(1, 2 * B + 1):
+            c.upload(k % 2, synth.synth_frame(w, h, 4, k, base=base))
+            c.build_pyramids(k % 2, sync=False)
+            c.track_async((k - 1) % 2, k % 2, (k - 1) % 2, k % 2, n)
+            c.select_async(k % 2, 2, True, k % 2, n)
+            if k % B == 0:
+                want.append(bench.list_digest(c.featbuf_download(k % 2, n)))
+    finally:
+        c.close()
+    assert cfg["list_sha16_after_each_block"] == want
