@@ -1129,6 +1129,8 @@ def run_cfg2(args, json_fd):
             cx.sync()
     for _ in range(args.warmup):
         one_step()
+    if os.environ.get("KLT_BENCH_DIE_RANK") == str(rank):      # test hook: a rank that vanishes with collectives in flight
+        os._exit(7)
 
     def region():
         for _ in range(args.steps):

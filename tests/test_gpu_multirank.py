@@ -97,3 +97,19 @@ def test_cfg5_blocks_hand_the_feature_list_from_rank_to_rank(tmp_path, stub_rccl
     finally:
         c.close()
     assert cfg["list_sha16_after_each_block"] == want
+
+
+def test_a_rank_that_dies_takes_the_run_down(tmp_path, stub_rccl):
+    """A rank that vanishes after the warm-up, with its peers in (or about to enter) a collective: the launcher sees its exit code, stops
+    the others at once -- none of them is left waiting -- and bench.py exits non-zero without a JSON line."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KLT_RDZV_FILE", "MASTER_PORT")}
+    env.update(KLT_RANKS_SHARE_DEVICE="0", KLT_RCCL_LIB=stub_rccl, KLT_STUB_RCCL_DIR=str(tmp_path / "mail"), KLT_BENCH_DIE_RANK="1")
+    os.makedirs(env["KLT_STUB_RCCL_DIR"], exist_ok=True)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "5",
+                        "--resident-pairs", "4", "--batch", "2", "--no-cpu-baseline", "--no-extras", "--min-timed-s", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert time.monotonic() - t0 < 60, "the surviving rank was left waiting"
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
