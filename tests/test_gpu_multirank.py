@@ -113,3 +113,27 @@ def test_a_rank_that_dies_takes_the_run_down(tmp_path, stub_rccl):
     assert r.returncode != 0
     assert time.monotonic() - t0 < 60, "the surviving rank was left waiting"
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_the_drivers_multi_gpu_launch_line(tmp_path, stub_rccl):
+    """The driver's own launch form for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks on this box's one GPU: RANK / LOCAL_RANK / WORLD_SIZE come
+    from the launcher, the rendezvous file is named after its process and port, rank 0 alone prints the JSON line."""
+    pytest.importorskip("torch")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KLT_RDZV_FILE", "MASTER_PORT")}
+    env.update(KLT_RANKS_SHARE_DEVICE="0", KLT_RCCL_LIB=stub_rccl, KLT_STUB_RCCL_DIR=str(tmp_path / "mail"), TMPDIR=str(tmp_path))
+    os.makedirs(env["KLT_STUB_RCCL_DIR"], exist_ok=True)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--repeats", "5", "--resident-pairs", "4", "--batch", "2", "--no-cpu-baseline", "--no-extras", "--min-timed-s", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["parity_checked"] is True and line["parity_cases"] == 5
