@@ -56,7 +56,12 @@ bool load_rccl(std::string &err)
     if (!g_rccl.handle) {
         // KLT_RCCL_LIB names THE library to use (no fallback to the system's: a wrong path must not go unnoticed)
         const char *forced = getenv("KLT_RCCL_LIB");
-        const char *defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // the ROCm installation's own library first, by path: a bare soname would resolve to whatever copy the process has already
+        // loaded -- e.g. the librccl a PyTorch wheel bundles next to its own HIP runtime, which is not the runtime this library talks to
+        // ("ncclCommInitRank: unhandled cuda error" in a process that had imported torch)
+        std::string rocm = getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm";
+        rocm += "/lib/librccl.so.1";
+        const char *defaults[] = {rocm.c_str(), "librccl.so.1", "librccl.so"};
         std::vector<const char *> names;
         if (forced && *forced) names.push_back(forced);
         else names.assign(defaults, defaults + 3);
@@ -94,6 +99,15 @@ struct KltComm {
     double *scratch = nullptr;             // device scratch for the small reductions (16 doubles)
     double timeout_ms = 300000.0;          // host-side waits give up after this long (KLT_COMM_TIMEOUT_MS / comm_set_timeout; <= 0: never)
 };
+
+// Collectives of DIFFERENT communicators of one process (bench.py gives every context its own) must not run side by side: two RCCL
+// kernels on one GPU that each wait for their peers on the other GPUs can starve each other when the GPUs start them in different order.
+// Every collective therefore waits (on the device) for the previous collective of this process, whatever communicator issued it: one at
+// a time, in issue order -- which is the same on every rank.  The records are small (megabytes per step); the chain costs nothing.
+namespace {
+hipEvent_t g_chain_done = nullptr;       // end of the most recent collective of this process
+const KltComm *g_chain_owner = nullptr;  // whose ring the event lives in
+}
 
 #define COMM_HIP(call)                                                                  \
     do {                                                                                \
@@ -164,6 +178,7 @@ void comm_destroy(KltComm *k)
     if (!k) return;
     hipSetDevice(k->device);
     if (k->side) hipStreamSynchronize(k->side);
+    if (g_chain_owner == k) { g_chain_done = nullptr; g_chain_owner = nullptr; }      // (its events are about to go; the stream above is idle)
     if (k->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(k->comm);
     for (hipEvent_t e : k->ring) hipEventDestroy(e);
     if (k->scratch) hipFree(k->scratch);
@@ -182,6 +197,7 @@ static int comm_order_behind(KltComm *k, hipStream_t producer, std::string &err)
     if (int rc = comm_event(k, &ready, err)) return rc;
     COMM_HIP(hipEventRecord(ready, producer));
     COMM_HIP(hipStreamWaitEvent(k->side, ready, 0));
+    if (g_chain_done && g_chain_owner != k) COMM_HIP(hipStreamWaitEvent(k->side, g_chain_done, 0));     // (the own side stream is in order anyway)
     return 0;
 }
 
@@ -191,6 +207,8 @@ static int comm_mark_done(KltComm *k, std::string &err)
     if (int rc = comm_event(k, &done, err)) return rc;
     COMM_HIP(hipEventRecord(done, k->side));
     k->last_done = done;
+    g_chain_done = done;
+    g_chain_owner = k;
     return 0;
 }
 
@@ -316,6 +334,7 @@ int comm_allreduce_max(KltComm *k, double *inout, int n, std::string &err)
 {
     if (!inout || n < 1 || n > 16) { err = "allreduce takes 1..16 doubles"; return KLT_ERR_ARG; }
     COMM_HIP(hipSetDevice(k->device));
+    if (g_chain_done && g_chain_owner != k) COMM_HIP(hipStreamWaitEvent(k->side, g_chain_done, 0));     // one collective of the process at a time
     COMM_HIP(hipMemcpyAsync(k->scratch, inout, n * sizeof(double), hipMemcpyHostToDevice, k->side));
     COMM_NCCL(g_rccl.AllReduce(k->scratch, k->scratch, (size_t)n, ncclDouble, ncclMax, k->comm, k->side));
     COMM_HIP(hipMemcpyAsync(inout, k->scratch, n * sizeof(double), hipMemcpyDeviceToHost, k->side));

@@ -119,7 +119,9 @@ def test_the_drivers_multi_gpu_launch_line(tmp_path, stub_rccl):
     """The driver's own launch form for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks on this box's one GPU: RANK / LOCAL_RANK / WORLD_SIZE come
     from the launcher, the rendezvous file is named after its process and port, rank 0 alone prints the JSON line."""
-    pytest.importorskip("torch")
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:          # (not imported here: torch brings its own HIP / RCCL libraries into the process)
+        pytest.skip("torch.distributed.run is not installed")
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
