@@ -61,8 +61,10 @@ __device__ __forceinline__ Bilinear make_bilinear(float x, float y)
     return b;
 }
 
-__device__ __forceinline__ float sample(const float *__restrict__ q, int nc, const Bilinear &b)
+__device__ __forceinline__ float sample(const float *__restrict__ qg, int nc, const Bilinear &b)
 {
+    // the planes live in device memory: global loads (a flat load also counts as an LDS operation)
+    const __attribute__((address_space(1))) float *q = (const __attribute__((address_space(1))) float *)qg;
     const float t4 = b.w11 * q[nc + 1];
     double v = b.w00 * (double)q[0];
     v = v + b.w01 * (double)q[1];
@@ -108,6 +110,21 @@ template <>
 __device__ float pairwise_sum<0>(const float *a, int n, int lane)
 {
     return pairwise_block_wave(a, n < 128 ? n : 128, lane);
+}
+
+// A level of a pair's descriptor table.  The table is written by the host before the launch and never by a kernel, so it is read
+// through the constant address space: scalar loads, the six plane pointers stay in SGPRs (as they do for a single-pair launch, whose
+// levels travel in the kernarg segment).  Read as generic memory the pointers arrive in VGPRs (the compiler cannot rule out that the
+// feature stores alias the table): 12 more vector registers, and flat loads through them.
+__device__ __forceinline__ TrackLevel load_level(const TrackLevel *p)
+{
+    typedef const __attribute__((address_space(4))) TrackLevel *cptr;
+    const cptr c = (cptr)p;
+    TrackLevel lv;
+    lv.i1 = c->i1; lv.gx1 = c->gx1; lv.gy1 = c->gy1;
+    lv.i2 = c->i2; lv.gx2 = c->gx2; lv.gy2 = c->gy2;
+    lv.nc = c->nc; lv.nr = c->nr;
+    return lv;
 }
 
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -278,7 +295,8 @@ __global__ __launch_bounds__(64) void track_kernel(TrackArgs a)
     for (int r = L - 1; r >= 0; r--) {
         xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss;
         int it = 0;
-        val = track_level<MAXK, WCT>(a, levels[r], xloc, yloc, xout, yout, lds, lane, it, 1 + 9 * (L - 1 - r));
+        const TrackLevel lv = BATCH ? load_level(levels + r) : levels[r];
+        val = track_level<MAXK, WCT>(a, lv, xloc, yloc, xout, yout, lds, lane, it, 1 + 9 * (L - 1 - r));
         aux |= (uint32_t)(it < 14 ? it + 1 : 15) << (4 * r);      // visited level r with `it` Newton iterations
         if (val == KLT_SMALL_DET || val == KLT_OOB) break;             // :284-285
     }
@@ -350,10 +368,14 @@ __device__ __forceinline__ float pairwise_group<0>(const float *a, int n, int s)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x4 load_quad(const float *p)      // 4-byte aligned 16-byte load
+// 4-byte aligned 16-byte load of elements q .. q + 3 of a plane, as a raw buffer load: the plane pointer is wavefront-uniform, so the
+// descriptor sits in four SGPRs and the lane's 32-bit byte offset is the whole vector address (a plane is far below 2 GB).  A global
+// load of plane + q costs a 64-bit vector add per load and a register pair for the address; a flat load (what a pointer read from
+// generic memory gives) also counts as an LDS operation.  Word 3 of the descriptor: data format 32 bits, nothing else (raw dwords).
+__device__ __forceinline__ f32x4 load_quad(const float *plane, unsigned q)
 {
-    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-    return *reinterpret_cast<const f32x4_u *>(p);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)plane, 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, q << 2, 0, 0));
 }
 
 // the four window samples of a lane from its quad `a`: pairs (a.x,a.y), (a.y,a.z), (a.z,a.w), (a.w, right neighbour) and the same
@@ -421,7 +443,7 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
 
     for (int r = L - 1; r >= 0; r--) {
         if (!__any(alive)) break;
-        const TrackLevel &lv = levels[r];
+        const TrackLevel lv = BATCH ? load_level(levels + r) : levels[r];
         const int nc = lv.nc, nr = lv.nr;
         if (alive) { xloc = xloc * a.ss; yloc = yloc * a.ss; xout = xout * a.ss; yout = yout * a.ss; }
 
@@ -430,7 +452,7 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
         const bool t_ok = b1.ix - hw >= 0 && b1.iy - hw >= 0 && b1.ix + hw + 2 <= nc && b1.iy + hw + 2 <= nr;
         const bool run = alive && t_ok;
         const unsigned q1 = run ? (unsigned)(b1.iy - hw + qr) * (unsigned)nc + (unsigned)(b1.ix - hw + 4 * qh) : 0u;   // 32-bit element offsets: scalar base + vector offset loads
-        const f32x4 t_qi = load_quad(lv.i1 + q1), t_qgx = load_quad(lv.gx1 + q1), t_qgy = load_quad(lv.gy1 + q1);
+        const f32x4 t_qi = load_quad(lv.i1, q1), t_qgx = load_quad(lv.gx1, q1), t_qgy = load_quad(lv.gy1, q1);
 
         // the first Newton iteration starts from a position that is already known: its bounds test (trackFeaturesUtils.pyx:428-431)
         // and its footprint loads go out now, behind the template's
@@ -445,7 +467,7 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
             if (iterating && oob) { status = KLT_OOB; iterating = false; }
             b2 = make_bilinear(x2, y2);
             const unsigned q = iterating ? (unsigned)(b2.iy - hw + qr) * (unsigned)nc + (unsigned)(b2.ix - hw + 4 * qh) : 0u;
-            s_qi = load_quad(lv.i2 + q); s_qgx = load_quad(lv.gx2 + q); s_qgy = load_quad(lv.gy2 + q);
+            s_qi = load_quad(lv.i2, q); s_qgx = load_quad(lv.gx2, q); s_qgy = load_quad(lv.gy2, q);
         };
         request_footprint();
 
@@ -539,7 +561,7 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
             const Bilinear br = make_bilinear(x2, y2);
             const unsigned q = need_res ? (unsigned)(br.iy - hw + qr) * (unsigned)nc + (unsigned)(br.ix - hw + 4 * qh) : 0u;
             float s_i[4];
-            sample_quad<QPR>(load_quad(lv.i2 + q), br, s_i);
+            sample_quad<QPR>(load_quad(lv.i2, q), br, s_i);
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 if (qr < w && 4 * qh + m < w) gl[k0 + m] = fabsf(t_i[m] - s_i[m]);
@@ -680,14 +702,18 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     // features in lock step lengthen)
     if (g_track_variant != 0 && a.window == 7 && (long long)a.n * ny >= 2048) {
         const dim3 gq(a.order ? 8 * ((a.order_chunk + 3) / 4) : (a.n + 3) / 4, ny);
+        // (occupancy targets 5 / 6 for this kernel -- 96 / 80 VGPRs with 84 / 172 bytes of scratch per lane instead of 122 VGPRs -- were
+        // measured again in round 3 on eight-pair launches, 10 000 wavefronts, where a fifth resident wavefront per SIMD could hide
+        // latency: 112 / 199 us per launch against 87.5, cfg-4's 32-pair shard 0.535 / 0.687 ms against 0.495.  A scratch reload is a
+        // vector memory operation and those return in order: it waits behind the footprint loads in flight, i.e. for the round trip
+        // the extra wavefront was meant to hide.)
         klt_launch((track_kernel_quad<BATCH, 7>), gq, block, (unsigned)(4 * lds), s, a);
         return 0;
     }
     if (g_track_variant != 0 && a.window == 15) {
         const dim3 gq(a.order ? 8 * a.order_chunk : a.n, ny);
         // occupancy target 5 (96 VGPRs, 40 bytes of scratch per lane instead of 107 VGPRs): the 5000 wavefronts of cfg-3 are then
-        // resident at once instead of in two rounds -- 57.9 -> 49.3 us.  (The 7x7 kernel loses from the same cap: its spills land
-        // in the Newton loop -- 143 -> 211 us at cfg-4.)
+        // resident at once instead of in two rounds -- 57.9 -> 49.3 us.  (The 7x7 kernel loses from the same cap, see above.)
         klt_launch((track_kernel_quad<BATCH, 15, 5>), gq, block, (unsigned)lds, s, a);
         return 0;
     }
