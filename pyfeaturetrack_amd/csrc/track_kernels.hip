@@ -407,6 +407,7 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
     constexpr int LPF = 64 / FPW;                            // lanes per feature = quads of its footprint
     constexpr int QPR = (W + 1) / 4;                         // quads per footprint row
     constexpr int w = W, n = W * W, hw = W / 2, npad = (n + 3) & ~3;
+    constexpr bool REUSE = W == 7;                           // keep a footprint whose integer corner has not moved (see request_footprint)
     static_assert((W + 1) * QPR == LPF, "one quad per lane");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x, g = lane / LPF, s = lane % LPF, glead = lane - s;
@@ -460,14 +461,29 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
         float x2 = xout, y2 = yout;
         bool iterating = run;
         Bilinear b2;
-        f32x4 s_qi, s_qgx, s_qgy;
+        f32x4 s_qi = {0.f, 0.f, 0.f, 0.f}, s_qgx = s_qi, s_qgy = s_qi;
+        unsigned q_held = ~0u;                               // element offset of the footprint quads in s_q*: none of this level yet
+        // A Newton step usually moves the window by less than a pixel: when its integer corner stays where it was, the footprint is
+        // the one already in registers (only the bilinear weights change) and nothing is requested; neither is anything for a
+        // feature that has stopped.  The launch is bound by the L1's requests to the L2 in flight (tools/pmc_mem.sh: ~78 per CU
+        // all the time at ~750 clocks each), so a request not made is time saved: 89.2 -> 86.6 us per eight-pair launch of cfg-2,
+        // 131.6 -> 125.7 us at cfg-4.  7x7 only: the 15x15 kernel, at its occupancy target of five, pays for the held offset and the
+        // conditional loads with 16 more bytes of scratch and goes from 38.9 to 42.4 us at cfg-3.
         auto request_footprint = [&]() {
             const bool oob = (double)(x2 - (float)hw) < 0. || (float)nc - (x2 + (float)hw) < one_plus_eps ||
                              (double)(y2 - (float)hw) < 0. || (float)nr - (y2 + (float)hw) < one_plus_eps;
             if (iterating && oob) { status = KLT_OOB; iterating = false; }
             b2 = make_bilinear(x2, y2);
-            const unsigned q = iterating ? (unsigned)(b2.iy - hw + qr) * (unsigned)nc + (unsigned)(b2.ix - hw + 4 * qh) : 0u;
-            s_qi = load_quad(lv.i2, q); s_qgx = load_quad(lv.gx2, q); s_qgy = load_quad(lv.gy2, q);
+            if (REUSE) {
+                const unsigned q = (unsigned)(b2.iy - hw + qr) * (unsigned)nc + (unsigned)(b2.ix - hw + 4 * qh);
+                if (iterating && q != q_held) {
+                    s_qi = load_quad(lv.i2, q); s_qgx = load_quad(lv.gx2, q); s_qgy = load_quad(lv.gy2, q);
+                    q_held = q;
+                }
+            } else {
+                const unsigned q = iterating ? (unsigned)(b2.iy - hw + qr) * (unsigned)nc + (unsigned)(b2.ix - hw + 4 * qh) : 0u;
+                s_qi = load_quad(lv.i2, q); s_qgx = load_quad(lv.gx2, q); s_qgy = load_quad(lv.gy2, q);
+            }
         };
         request_footprint();
 
@@ -559,9 +575,17 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
         const bool need_res = run && status == KLT_TRACKED && a.use_max_residue;
         if (__any(need_res)) {
             const Bilinear br = make_bilinear(x2, y2);
-            const unsigned q = need_res ? (unsigned)(br.iy - hw + qr) * (unsigned)nc + (unsigned)(br.ix - hw + 4 * qh) : 0u;
+            f32x4 r_qi;
+            if (REUSE) {
+                const unsigned q = (unsigned)(br.iy - hw + qr) * (unsigned)nc + (unsigned)(br.ix - hw + 4 * qh);
+                r_qi = s_qi;                                 // the last footprint, if the final position has the same integer corner
+                if (need_res && q != q_held) r_qi = load_quad(lv.i2, q);
+            } else {
+                const unsigned q = need_res ? (unsigned)(br.iy - hw + qr) * (unsigned)nc + (unsigned)(br.ix - hw + 4 * qh) : 0u;
+                r_qi = load_quad(lv.i2, q);
+            }
             float s_i[4];
-            sample_quad<QPR>(load_quad(lv.i2, q), br, s_i);
+            sample_quad<QPR>(r_qi, br, s_i);
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 if (qr < w && 4 * qh + m < w) gl[k0 + m] = fabsf(t_i[m] - s_i[m]);
