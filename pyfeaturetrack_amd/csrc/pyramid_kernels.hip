@@ -265,6 +265,27 @@ __device__ __forceinline__ void widen12(const float *row, double *d)
     d[8] = (double)c.x; d[9] = (double)c.y; d[10] = (double)c.z; d[11] = (double)c.w;
 }
 
+// Plane accesses of the register-blocked kernel as raw buffer operations: the plane pointer is workgroup-uniform (a descriptor in four
+// SGPRs), the lane's 32-bit BYTE offset is the whole vector address.  With `plane + (size_t)y * nc + x` every row of every thread cost a
+// 64-bit multiply-add (a quarter-rate instruction) and a 64-bit add; the offsets below are one 24-bit multiply per thread and one
+// 32-bit add per row.  (A plane is far below 2 GB; word 3 of the descriptor: data format 32 bits, raw dwords.)
+typedef __amdgpu_buffer_rsrc_t plane_rsrc;
+__device__ __forceinline__ plane_rsrc plane_of(const void *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void plane_store(plane_rsrc r, unsigned byte_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void plane_store2(plane_rsrc r, unsigned byte_off, float2 v)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 w;
+    w.x = __builtin_bit_cast(unsigned, v.x); w.y = __builtin_bit_cast(unsigned, v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, byte_off, 0, 0);
+}
+
 #ifndef KLT_L0_WAVES
 #define KLT_L0_WAVES 4
 #endif
@@ -300,6 +321,8 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
     const bool vec2_ok = (nc & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.img[b]) | reinterpret_cast<uintptr_t>(a.gx[b]) |
                                             reinterpret_cast<uintptr_t>(a.gy[b])) & 7) == 0;
     const TIn *__restrict__ raw = (const TIn *)a.raw[b];
+    const unsigned row_bytes = 4u * (unsigned)nc;                // of the f32 planes
+    const unsigned tile_b0 = (unsigned)ty0 * row_bytes + 4u * (unsigned)tx0;   // byte offset of the tile's first output in them
     TapRegs<NG> kg;
     TapRegs<ND> kd;
     load_taps(kg, a.ggauss);
@@ -315,13 +338,14 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
         // is used.  The general loop below waits for each of its 3-4 loads in turn -- 2.2 of the 9 us a workgroup lives.
         const bool interior = (nc & 3) == 0 && tx0 + X0 >= 0 && tx0 + X0 + 4 * W0 <= nc && ty0 + Y0 >= 0 && ty0 + Y0 + H0 <= nr;
         if (interior) {
-            const TIn *const base = raw + (size_t)(ty0 + Y0) * nc + (tx0 + X0);
+            const plane_rsrc rawp = plane_of(raw);
+            const unsigned raw_b0 = ((unsigned)(ty0 + Y0) * (unsigned)nc + (unsigned)(tx0 + X0)) * (unsigned)sizeof(TIn);
             if (sizeof(TIn) == 1) {
                 uint32_t w[U0];
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
                     const int i = min(tid + u * NTHR, N0 - 1);          // clamped, unconditional (the last threads repeat a quad)
-                    w[u] = *reinterpret_cast<const uint32_t *>(base + (unsigned)((i / W0) * nc + 4 * (i % W0)));
+                    w[u] = __builtin_amdgcn_raw_buffer_load_b32(rawp, raw_b0 + __umul24((unsigned)(i / W0), (unsigned)nc) + 4u * (unsigned)(i % W0), 0, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
@@ -336,7 +360,9 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
                     const int i = min(tid + u * NTHR, N0 - 1);
-                    w[u] = *reinterpret_cast<const float4 *>(base + (size_t)(i / W0) * nc + 4 * (i % W0));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rawp, raw_b0 + __umul24((unsigned)(i / W0), row_bytes) + 16u * (unsigned)(i % W0), 0, 0);
+                    w[u] = __builtin_bit_cast(float4, q);
                 }
 #pragma unroll
                 for (int u = 0; u < U0; u++) {
@@ -410,10 +436,12 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
         // ---- stage 2: vertical smoothing, B -> C (+ store the tile interior of the smoothed image).
         // A thread produces two adjacent columns on FOUR consecutive rows: NS + 3 rows of two samples are read (ds_read_b64) and
         // widened for 8 outputs -- 2 widenings per output (a quad on two rows: 3).
-        float *__restrict__ img = a.img[b];
+        const plane_rsrc img = plane_of(a.img[b]);
         constexpr int BH = BW / 2, G2 = (IH + 3) / 4;           // half-quads per row, groups of four rows (the last one may be partial)
         for (int i = tid; i < G2 * BH; i += NTHR) {
             const int r = 4 * (i / BH), h = i % BH;
+            // byte offset of (ty0 - R + r, tx0 - HB + 2 h) modulo 2^32 (rows above the frame are never stored)
+            const unsigned img_b0 = tile_b0 + __umul24((unsigned)r, row_bytes) - (unsigned)R * row_bytes + (unsigned)(8 * h) - (unsigned)(4 * HB);
             double v[2][NS + 3];
 #pragma unroll
             for (int j = 0; j < NS + 3; j++) {
@@ -430,12 +458,12 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
                 *reinterpret_cast<float2 *>(C + rr * BW + 2 * h) = o;
                 const int y = ty0 - R + rr, x = tx0 - HB + 2 * h;
                 if (rr >= R && rr < R + TH_ && h >= HB / 2 && h < HB / 2 + DW / 2 && (!EDGE || y < nr)) {
-                    float *dstp = img + (size_t)y * nc + x;
-                    if (!EDGE && vec2_ok) *reinterpret_cast<float2 *>(dstp) = o;      // x is even
-                    else if (!EDGE) { dstp[0] = o.x; dstp[1] = o.y; }
+                    const unsigned ob = img_b0 + (unsigned)dr * row_bytes;          // byte offset of (y, x)
+                    if (!EDGE && vec2_ok) plane_store2(img, ob, o);                  // x is even
+                    else if (!EDGE) { plane_store(img, ob, o.x); plane_store(img, ob + 4, o.y); }
                     else {
-                        if (x < nc) dstp[0] = o.x;
-                        if (x + 1 < nc) dstp[1] = o.y;
+                        if (x < nc) plane_store(img, ob, o.x);
+                        if (x + 1 < nc) plane_store(img, ob + 4, o.y);
                     }
                 }
             }
@@ -465,8 +493,9 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
         TapRegs<HR + 1> kr;                                     // k[0..HR]: the taps left of and at the centre (symmetric)
 #pragma unroll
         for (int t = 0; t <= HR; t++) kr.k[t] = a.reduce.k[t];
-        float *__restrict__ h1 = a.h1[b];
+        const plane_rsrc h1 = plane_of(a.h1[b]);
         const int h1_nc = a.h1_nc;
+        const unsigned h1_row_bytes = 4u * (unsigned)h1_nc, h1_b0 = (unsigned)ty0 * h1_row_bytes + (unsigned)tx0;   // (ty0, tx0 / 4); tx0 % 4 == 0
         // a thread makes TWO adjacent outputs (columns 4 xs + 2 and 4 xs + 6 of the tile): their 21-sample windows share 17
         // samples, so 28 samples are read and widened for two outputs instead of 24 for each
         static_assert(DQ % 2 == 0, "tile width must be a multiple of eight");
@@ -489,7 +518,8 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
 #pragma unroll
                 for (int jj = -HR; jj < 0; jj++) acc = acc + (c[jj] + c[-jj]) * kr.k[HR + jj];
                 const int xg = tx0 / 4 + xs + o;
-                if (!EDGE || (y < nr && xg < h1_nc)) h1[(size_t)y * h1_nc + xg] = (float)acc;
+                if (!EDGE || (y < nr && xg < h1_nc))
+                    plane_store(h1, h1_b0 + __umul24((unsigned)r, h1_row_bytes) + 4u * (unsigned)(xs + o), (float)acc);
             }
         }
     }
@@ -498,8 +528,7 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
     // ---- stage 4: vertical pass, D -> gradx (Gaussian taps), E -> grady (derivative taps).  A thread makes two adjacent columns on
     // FOUR consecutive rows: NG + 3 rows of two samples are read (ds_read_b64) and widened once for 8 outputs per plane -- 2.5
     // widenings per output where a quad on two rows needs 4 (the widening is an FP64-rate instruction like the adds and multiplies).
-    float *__restrict__ gxo = a.gx[b];
-    float *__restrict__ gyo = a.gy[b];
+    const plane_rsrc gxo = plane_of(a.gx[b]), gyo = plane_of(a.gy[b]);
     static_assert(TH_ % 4 == 0, "tile height must be a multiple of four");
     static_assert(NG == ND, "the vertical pass shares its row window between the two planes");
     constexpr int DH = DW / 2;                                   // half-quads per row
@@ -532,16 +561,17 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
                 oy[dr].x = corr_regs<ND, -1>(v[0] + ND / 2 + dr, kd); oy[dr].y = corr_regs<ND, -1>(v[1] + ND / 2 + dr, kd);
             }
         }
+        const unsigned g_b0 = tile_b0 + __umul24((unsigned)r, row_bytes) + (unsigned)(8 * h);   // byte offset of (ty0 + r, x) in both planes
 #pragma unroll
         for (int dr = 0; dr < 4; dr++) {
             const int y = ty0 + r + dr;
             if (EDGE && y >= nr) break;
-            float *px = gxo + (size_t)y * nc + x, *py = gyo + (size_t)y * nc + x;
+            const unsigned ob = g_b0 + (unsigned)dr * row_bytes;
             if (!EDGE && vec2_ok) {
-                *reinterpret_cast<float2 *>(px) = ox[dr]; *reinterpret_cast<float2 *>(py) = oy[dr];
+                plane_store2(gxo, ob, ox[dr]); plane_store2(gyo, ob, oy[dr]);
             } else {
-                px[0] = ox[dr].x; py[0] = oy[dr].x;
-                if (!EDGE || x + 1 < nc) { px[1] = ox[dr].y; py[1] = oy[dr].y; }
+                plane_store(gxo, ob, ox[dr].x); plane_store(gyo, ob, oy[dr].x);
+                if (!EDGE || x + 1 < nc) { plane_store(gxo, ob + 4, ox[dr].y); plane_store(gyo, ob + 4, oy[dr].y); }
             }
         }
     }
