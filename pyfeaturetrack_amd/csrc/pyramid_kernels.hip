@@ -635,12 +635,16 @@ __global__ __launch_bounds__(NTHR) void pyr_reduce_fast(PyrReduceArgs a)
     constexpr int NQ = SH * SQ, QPT = (NQ + NTHR - 1) / NTHR;
     const bool interior = quads && (gx0 & 3) == 0 && gx0 >= 0 && gy0 >= 0 && gx0 + 4 * SQ <= nc && gy0 + SH <= nr;
     if (interior) {
+        const plane_rsrc srcp = plane_of(src);                           // raw buffer loads: 32-bit byte offsets
+        const unsigned src_b0 = 4u * ((unsigned)gy0 * (unsigned)nc + (unsigned)gx0);
         float4 v[QPT];
 #pragma unroll
         for (int u = 0; u < QPT; u++) {
             const int i = min(tid + u * NTHR, NQ - 1);                    // clamped: the last threads repeat the last quad
             const int rr = i / SQ, q = i - rr * SQ;
-            v[u] = *reinterpret_cast<const float4 *>(src + (size_t)(gy0 + rr) * nc + gx0 + 4 * q);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(srcp, src_b0 + 4u * (__umul24((unsigned)rr, (unsigned)nc) + 4u * (unsigned)q), 0, 0);
+            v[u] = __builtin_bit_cast(float4, w);
         }
 #pragma unroll
         for (int u = 0; u < QPT; u++) {
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(256) void pyr_vreduce_kernel(PyrReduceArgs a)
     const int tid = threadIdx.x, b = blockIdx.z;
     const int xs0 = blockIdx.x * VW, ys0 = blockIdx.y * VH;
     const int nc = a.dst_nc, nr = a.src_nr;                     // H1 is src_nr rows x dst_nc columns
-    const float *__restrict__ src = a.src[b];
+    const plane_rsrc src = plane_of(a.src[b]);                  // raw buffer loads: 32-bit byte offsets, no 64-bit multiply-add per row
     TapRegs<r + 1> k;
 #pragma unroll
     for (int t = 0; t <= r; t++) k.k[t] = a.taps.k[t];
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(256) void pyr_vreduce_kernel(PyrReduceArgs a)
             int y = gy0 + rr;
             y = y < 0 ? -1 - y : y >= nr ? 2 * nr - 1 - y : y;
             y = min(max(y, 0), nr - 1);                          // (frames shorter than the halo never take this kernel)
-            v[u] = src[(size_t)y * nc + col];
+            v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, 4u * (__umul24((unsigned)y, (unsigned)nc) + (unsigned)col), 0, 0));
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -775,6 +779,7 @@ __global__ __launch_bounds__(256) void pyr_vreduce_kernel(PyrReduceArgs a)
     }
     __syncthreads();
     const int xs = tid & 63, yq = tid >> 6;                      // output rows ys0 + 4 yq .. + 3
+    const plane_rsrc dst = plane_of(a.dst[b]);
     double v[3 * SS + 2 * r + 1];                                // 33 rows
 #pragma unroll
     for (int j = 0; j < 3 * SS + 2 * r + 1; j++) v[j] = (double)T[(4 * yq * SS + j) * VW + xs];
@@ -785,7 +790,7 @@ __global__ __launch_bounds__(256) void pyr_vreduce_kernel(PyrReduceArgs a)
 #pragma unroll
         for (int jj = -r; jj < 0; jj++) acc = acc + (c[jj] + c[-jj]) * k.k[r + jj];
         const int oy = ys0 + 4 * yq + o, ox = xs0 + xs;
-        if (oy < a.dst_nr && ox < a.dst_nc) a.dst[b][(size_t)oy * a.dst_nc + ox] = (float)acc;
+        if (oy < a.dst_nr && ox < a.dst_nc) plane_store(dst, 4u * (__umul24((unsigned)oy, (unsigned)a.dst_nc) + (unsigned)ox), (float)acc);
     }
 }
 

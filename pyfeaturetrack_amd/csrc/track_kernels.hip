@@ -452,7 +452,8 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
         const Bilinear b1 = make_bilinear(xloc, yloc);
         const bool t_ok = b1.ix - hw >= 0 && b1.iy - hw >= 0 && b1.ix + hw + 2 <= nc && b1.iy + hw + 2 <= nr;
         const bool run = alive && t_ok;
-        const unsigned q1 = run ? (unsigned)(b1.iy - hw + qr) * (unsigned)nc + (unsigned)(b1.ix - hw + 4 * qh) : 0u;   // 32-bit element offsets: scalar base + vector offset loads
+        // (row * nc as a 24-bit multiply: both are far below 2^24, and the 32-bit integer multiply is a quarter-rate instruction)
+        const unsigned q1 = run ? __umul24((unsigned)(b1.iy - hw + qr), (unsigned)nc) + (unsigned)(b1.ix - hw + 4 * qh) : 0u;   // 32-bit element offsets: scalar base + vector offset loads
         const f32x4 t_qi = load_quad(lv.i1, q1), t_qgx = load_quad(lv.gx1, q1), t_qgy = load_quad(lv.gy1, q1);
 
         // the first Newton iteration starts from a position that is already known: its bounds test (trackFeaturesUtils.pyx:428-431)
@@ -475,13 +476,13 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
             if (iterating && oob) { status = KLT_OOB; iterating = false; }
             b2 = make_bilinear(x2, y2);
             if (REUSE) {
-                const unsigned q = (unsigned)(b2.iy - hw + qr) * (unsigned)nc + (unsigned)(b2.ix - hw + 4 * qh);
+                const unsigned q = __umul24((unsigned)(b2.iy - hw + qr), (unsigned)nc) + (unsigned)(b2.ix - hw + 4 * qh);
                 if (iterating && q != q_held) {
                     s_qi = load_quad(lv.i2, q); s_qgx = load_quad(lv.gx2, q); s_qgy = load_quad(lv.gy2, q);
                     q_held = q;
                 }
             } else {
-                const unsigned q = iterating ? (unsigned)(b2.iy - hw + qr) * (unsigned)nc + (unsigned)(b2.ix - hw + 4 * qh) : 0u;
+                const unsigned q = iterating ? __umul24((unsigned)(b2.iy - hw + qr), (unsigned)nc) + (unsigned)(b2.ix - hw + 4 * qh) : 0u;
                 s_qi = load_quad(lv.i2, q); s_qgx = load_quad(lv.gx2, q); s_qgy = load_quad(lv.gy2, q);
             }
         };
@@ -577,11 +578,11 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
             const Bilinear br = make_bilinear(x2, y2);
             f32x4 r_qi;
             if (REUSE) {
-                const unsigned q = (unsigned)(br.iy - hw + qr) * (unsigned)nc + (unsigned)(br.ix - hw + 4 * qh);
+                const unsigned q = __umul24((unsigned)(br.iy - hw + qr), (unsigned)nc) + (unsigned)(br.ix - hw + 4 * qh);
                 r_qi = s_qi;                                 // the last footprint, if the final position has the same integer corner
                 if (need_res && q != q_held) r_qi = load_quad(lv.i2, q);
             } else {
-                const unsigned q = need_res ? (unsigned)(br.iy - hw + qr) * (unsigned)nc + (unsigned)(br.ix - hw + 4 * qh) : 0u;
+                const unsigned q = need_res ? __umul24((unsigned)(br.iy - hw + qr), (unsigned)nc) + (unsigned)(br.ix - hw + 4 * qh) : 0u;
                 r_qi = load_quad(lv.i2, q);
             }
             float s_i[4];
