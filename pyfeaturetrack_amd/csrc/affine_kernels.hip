@@ -25,13 +25,15 @@ __device__ __forceinline__ float bilinear_at(const float *__restrict__ img, int 
     const float ax = (float)((double)x - (double)ix), ay = (float)((double)y - (double)iy);
     const double w00 = (1. - (double)ax) * (1. - (double)ay), w01 = (double)ax * (1. - (double)ay), w10 = (1. - (double)ax) * (double)ay;
     const float w11 = ax * ay;
-    // 32-bit element offsets from the (wave-uniform) plane pointer: the loads take the scalar-base + vector-offset form, one VGPR
-    // per address instead of a 64-bit pointer pair (the model-2 kernel has 48 of them in flight and was at 200+ VGPRs)
-    const unsigned o = (unsigned)iy * (unsigned)nc + (unsigned)ix;
-    const float t4 = w11 * img[o + (unsigned)nc + 1u];
-    double v = w00 * (double)img[o];
-    v = v + w01 * (double)img[o + 1u];
-    v = v + w10 * (double)img[o + (unsigned)nc];
+    // raw buffer loads from the (wave-uniform) plane pointer: the descriptor in SGPRs, one VGPR with a 32-bit byte offset per
+    // address instead of a 64-bit pointer pair (the model-2 kernel has 48 of them in flight and was at 200+ VGPRs), the row offset a
+    // 24-bit multiply (rows and row lengths are far below 2^24; the 32-bit and 64-bit integer multiplies are quarter-rate)
+    const plane_rsrc r = plane_of(img);
+    const unsigned o = 4u * (__umul24((unsigned)iy, (unsigned)nc) + (unsigned)ix), down = 4u * (unsigned)nc;
+    const float t4 = w11 * plane_load(r, o + down + 4u);
+    double v = w00 * (double)plane_load(r, o);
+    v = v + w01 * (double)plane_load(r, o + 4u);
+    v = v + w10 * (double)plane_load(r, o + down);
     v = v + (double)t4;
     return (float)v;
 }

@@ -147,6 +147,31 @@ void launch_hconv_f32(hipStream_t s, const float *in, int ncols, int nrows, floa
 void launch_vconv(hipStream_t s, const float *inA, const float *inB, int ncols, int nrows, float *outA, float *outB,
                   int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb);
 
+// Plane accesses as raw buffer operations (device code): the plane pointer is workgroup-uniform (a descriptor in four
+// SGPRs), the lane's 32-bit BYTE offset is the whole vector address.  With `plane + (size_t)y * nc + x` every access costs a
+// 64-bit multiply-add (a quarter-rate instruction) and a 64-bit add; 32-bit offsets are a 24-bit multiply (full rate) and 32-bit adds.  (A plane is far below 2 GB; word 3 of the descriptor: data format 32 bits, raw dwords.)
+typedef __amdgpu_buffer_rsrc_t plane_rsrc;
+__device__ __forceinline__ plane_rsrc plane_of(const void *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void plane_store(plane_rsrc r, unsigned byte_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void plane_store2(plane_rsrc r, unsigned byte_off, float2 v)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 w;
+    w.x = __builtin_bit_cast(unsigned, v.x); w.y = __builtin_bit_cast(unsigned, v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, byte_off, 0, 0);
+}
+
+__device__ __forceinline__ float plane_load(plane_rsrc r, unsigned byte_off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
 extern int g_track_variant;         // tracker kernels: 4 (default) quad-load kernels where they apply, 0 always track_kernel
 size_t smooth_grad_lds_bytes(int smooth_radius /* -1: no smoothing stage */, int R);
 size_t pyr_reduce_lds_bytes(int ss, int ntaps);

@@ -265,27 +265,6 @@ __device__ __forceinline__ void widen12(const float *row, double *d)
     d[8] = (double)c.x; d[9] = (double)c.y; d[10] = (double)c.z; d[11] = (double)c.w;
 }
 
-// Plane accesses of the register-blocked kernel as raw buffer operations: the plane pointer is workgroup-uniform (a descriptor in four
-// SGPRs), the lane's 32-bit BYTE offset is the whole vector address.  With `plane + (size_t)y * nc + x` every row of every thread cost a
-// 64-bit multiply-add (a quarter-rate instruction) and a 64-bit add; the offsets below are one 24-bit multiply per thread and one
-// 32-bit add per row.  (A plane is far below 2 GB; word 3 of the descriptor: data format 32 bits, raw dwords.)
-typedef __amdgpu_buffer_rsrc_t plane_rsrc;
-__device__ __forceinline__ plane_rsrc plane_of(const void *p)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ void plane_store(plane_rsrc r, unsigned byte_off, float v)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
-}
-__device__ __forceinline__ void plane_store2(plane_rsrc r, unsigned byte_off, float2 v)
-{
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 w;
-    w.x = __builtin_bit_cast(unsigned, v.x); w.y = __builtin_bit_cast(unsigned, v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(w, r, byte_off, 0, 0);
-}
-
 #ifndef KLT_L0_WAVES
 #define KLT_L0_WAVES 4
 #endif
