@@ -451,11 +451,16 @@ void make_taps(const double *k, int n, Taps &t)
     }
 }
 
+// The kernels address a plane with 32-bit BYTE offsets (raw buffer operations, klt_internal.h): an f32 plane must stay below 2 GB.
+// 2^29 - 1 pixels is a 23 170 x 23 170 frame; the largest frame of the test suite is 7680 x 4320.
+constexpr long long kMaxFramePixels = (1LL << 29) - 1;
+
 int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int pitch, int kind)
 {
     if (!c || !px) return fail(c, KLT_ERR_ARG, "null argument");
     if (ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535 || pitch < ncols)
         return fail(c, KLT_ERR_ARG, "bad image geometry");
+    if ((long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "frame too large (an f32 plane must stay below 2 GB)");
     HIPCHK(c, hipSetDevice(c->device));
     Slot *s;
     if (int rc = get_slot(c, slot, &s, true)) return rc;
@@ -949,6 +954,7 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
 {
     if (!c || !px) return fail(c, KLT_ERR_ARG, "null argument");
     if (ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535 || pitch < ncols) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    if ((long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "frame too large (an f32 plane must stay below 2 GB)");
     HIPCHK(c, hipSetDevice(c->device));
     hipPointerAttribute_t attr;                           // the source must be pinned: a pageable copy would be staged synchronously
     if (hipPointerGetAttributes(&attr, px) != hipSuccess || attr.type != hipMemoryTypeHost) {
@@ -2256,7 +2262,7 @@ int klt_smooth_f32(klt_ctx *c, const float *src, int ncols, int nrows, const dou
 {
     if (!c || !src || !dst || !gauss) return fail(c, KLT_ERR_ARG, "null argument");
     if (ng < 1 || ng > KLT_MAX_KERNEL_WIDTH || !(ng & 1)) return fail(c, KLT_ERR_ARG, "tap count must be odd and at most 71");
-    if (ncols <= 0 || nrows <= 0) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    if (ncols <= 0 || nrows <= 0 || (long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "bad image geometry");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t N = (size_t)ncols * nrows;
     if (int rc = ensure_tmp(c, N)) return rc;
@@ -2283,7 +2289,7 @@ int klt_gradients_f32(klt_ctx *c, const float *src, int ncols, int nrows, const 
     if (!c || !src || !gx || !gy || !gauss || !deriv) return fail(c, KLT_ERR_ARG, "null argument");
     if (ng < 1 || nd < 1 || ng > KLT_MAX_KERNEL_WIDTH || nd > KLT_MAX_KERNEL_WIDTH || !(ng & 1) || !(nd & 1))
         return fail(c, KLT_ERR_ARG, "tap counts must be odd and at most 71");
-    if (ncols <= 0 || nrows <= 0) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    if (ncols <= 0 || nrows <= 0 || (long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "bad image geometry");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t N = (size_t)ncols * nrows;
     if (int rc = ensure_tmp(c, N)) return rc;
@@ -2313,7 +2319,7 @@ int klt_pyramid_f32(klt_ctx *c, const float *src, int ncols, int nrows, int nlev
 {
     if (!c || !src || !gauss || (nlevels > 1 && !dst)) return fail(c, KLT_ERR_ARG, "null argument");
     if (ng < 1 || ng > KLT_MAX_KERNEL_WIDTH || !(ng & 1)) return fail(c, KLT_ERR_ARG, "tap count must be odd and at most 71");
-    if (ncols <= 0 || nrows <= 0 || nlevels < 1 || nlevels > KLT_MAX_LEVELS) return fail(c, KLT_ERR_ARG, "bad pyramid geometry");
+    if (ncols <= 0 || nrows <= 0 || (long long)ncols * nrows > kMaxFramePixels || nlevels < 1 || nlevels > KLT_MAX_LEVELS) return fail(c, KLT_ERR_ARG, "bad pyramid geometry");
     const int ss = subsampling;
     if (nlevels > 1 && ss != 2 && ss != 4 && ss != 8 && ss != 16 && ss != 32) return fail(c, KLT_ERR_ARG, "subsampling must be 2, 4, 8, 16 or 32");
     if (nlevels == 1) return KLT_OK;

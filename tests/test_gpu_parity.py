@@ -738,8 +738,8 @@ def test_random_sequences_vs_per_frame_api():
 
 def test_kernel_timing_by_event_pairs_and_by_dispatch_timestamps(ctx):
     """klt_timing_enable: 1 = an event pair around every launch, 2 = the level-0 pyramid launch by the start / stop events of its own
-    dispatch (what a profiler reports as the kernel's duration).  Both see every launch; the dispatch figure is the smaller one (the pair
-    also holds the boundary between two dependent launches) and not implausibly so; the other families are timed alike in both modes."""
+    dispatch (what a profiler reports as the kernel's duration).  Both see every launch; the dispatch figure is usually the smaller one (the pair
+    also holds the boundary between two dependent launches) and never implausibly far from it; the other families are timed alike in both modes."""
     from pyfeaturetrack_amd import synth
     ctx.configure(make_tc(levels=3, ss=4))
     for k, f in enumerate(synth.synth_pair(1920, 1080, 1)):
@@ -754,7 +754,7 @@ def test_kernel_timing_by_event_pairs_and_by_dispatch_timestamps(ctx):
         ctx.timing_enable(False)
     pair, stamp = figures[1]["smooth_grad_l0"], figures[2]["smooth_grad_l0"]
     assert pair[0] == stamp[0] == 20
-    assert 0.6 * pair[1] < stamp[1] < pair[1], (pair, stamp)
+    assert 0.6 * pair[1] < stamp[1] < 1.1 * pair[1], (pair, stamp)     # (the two have been seen within 1 % of each other: no strict order)
     assert figures[1]["pyramid_reduce"][0] == figures[2]["pyramid_reduce"][0] > 0
 
 

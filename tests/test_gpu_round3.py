@@ -143,7 +143,7 @@ def test_the_drivers_command_line_prints_a_clean_record():
     # the same figures from a run with five times the steps per region
     long = run_bench(["--gpus", "1", "--steps", "100", "--warmup", "5", "--repeats", "8", "--no-cpu-baseline", "--no-extras"])
     assert abs(long["roofline"]["step_algorithmic_bytes"] / roof["step_algorithmic_bytes"] - 1) < 0.05
-    assert abs(long["value"] / line["value"] - 1) < 0.05, (long["value"], line["value"])
+    assert abs(long["value"] / line["value"] - 1) < 0.08, (long["value"], line["value"])     # (seen: 0.3-1.7 %)
 
 
 def test_bench_refuses_figures_above_the_roof():
@@ -524,3 +524,24 @@ def test_klt_pyramid_class_on_the_device(cfg1, synth251):
     one = KLTPyramid(64, 48, 4, 1)
     one.Compute(np.ones((48, 64), np.float32), 0.9)
     assert len(one.img) == 1
+
+
+@pytest.mark.gpu
+def test_frames_whose_planes_would_pass_2_gb_are_refused():
+    """The kernels address a plane with 32-bit byte offsets (raw buffer operations): a frame of 2^29 pixels or more is an
+    argument error at the boundary, before anything is read or allocated; the next size down the ABI's own limits allow is not."""
+    import ctypes
+    from pyfeaturetrack_amd.backend import Context, KltBackendError
+    ctx = Context()
+    small = np.zeros((8, 8), np.uint8)                          # never read: the geometry is checked first
+    for ncols, nrows in ((32768, 16384), (65535, 65535), (23171, 23171)):
+        with pytest.raises(KltBackendError, match="frame too large"):
+            ctx._check(ctx._lib.klt_upload_u8(ctx._h, 0, small.ctypes.data, ncols, nrows, ncols))
+    taps = np.array([0.1, 0.2, 0.4, 0.2, 0.1])
+    dst = np.zeros(64, np.float32)
+    with pytest.raises(KltBackendError, match="bad image geometry"):
+        ctx._check(ctx._lib.klt_smooth_f32(ctx._h, dst.ctypes.data, 32768, 16384, taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 5, dst.ctypes.data))
+    img = (np.arange(64 * 48, dtype=np.uint32) % 251).astype(np.uint8).reshape(48, 64)
+    ctx.upload(0, img)                                          # the context is still usable
+    ctx.sync()
+    ctx.close()
