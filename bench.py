@@ -4,13 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
 
 Workload at every N = BASELINE cfg-2 (1920x1080 synthetic pairs, 5000 features each, 7x7 window, 3 pyramid levels / subsampling 4,
-translation only).  `--resident-pairs` (default 64) DISTINCT pairs per GPU (seeds rank * 64 + 1 ...) are resident in HBM with their
-own frame slots, pyramids (3.7 GB per GPU) and feature lists; a *step* is one pass of the hot path over that batch: for every pair,
+translation only).  `--resident-pairs` (default 72) DISTINCT pairs per GPU (seeds rank * 72 + 1 ...) are resident in HBM with their
+own frame slots, pyramids (4.2 GB per GPU) and feature lists; a *step* is one pass of the hot path over that batch: for every pair,
 build the image / gradx / grady pyramids of both frames from the u8 frames in HBM, then track every live feature coarse-to-fine
-(device-resident feature records in, device-resident records out) -- 64 KLTTrackFeatures-equivalents per step.  The timed region
-therefore streams 3.7 GB of distinct frames and pyramids per step: nothing it reads was left in the 256 MB Infinity Cache by the
+(device-resident feature records in, device-resident records out) -- 72 KLTTrackFeatures-equivalents per step.  The timed region
+therefore streams 4.2 GB of distinct frames and pyramids per step: nothing it reads was left in the 256 MB Infinity Cache by the
 step before (round 2 rebuilt the same four slots from the same two frames, `extra.cache_resident_ms_per_pair` keeps that figure).
-With N > 1 every rank runs its own 64 pairs (weak scaling: the path shards by frame pair with no data-path exchange) and the
+With N > 1 every rank runs its own 72 pairs (weak scaling: the path shards by frame pair with no data-path exchange) and the
 16-byte records of a step are collected in one device-side [pairs x features] table per context and gathered to every rank with
 one RCCL all-gather per table, issued by libkltgpu.so on its side stream (event-ordered behind the last tracker launch of the step,
 overlapped with the next step's kernels).  No torch anywhere.
@@ -21,7 +21,7 @@ exits non-zero if any rank failed.  Under an external launcher (`python -m torch
 N ...`) the same variables are already set and every process is a rank.  The RCCL unique id travels through the rendezvous file
 (pyfeaturetrack_amd/parallel.py).
 
-Consecutive groups of `--batch` pairs (default 8) go round-robin to `--inflight` contexts (default 2; one HIP stream each, nothing
+Consecutive groups of `--batch` pairs (default 8) go round-robin to `--inflight` contexts (default 3; one HIP stream each, nothing
 ordering them): frame pairs are independent, so the pairs of a group share every launch of their context (one batched pyramid build,
 one tracker launch -- the reference's workload for a stereo rig or two cameras) and the GPU overlaps the kernels of different groups.
 Every pair gets the full work of one KLTTrackFeatures call.  `ms_per_frame_pair` (= `extra.single_stream_ms_per_pair`) is one pair
@@ -1448,12 +1448,14 @@ def main():
                     help="cfg2 (default, the headline line); cfg4 = the 256-pair batch sharded over --gpus ranks; the others are "
                          "the remaining BASELINE configs on one GPU")
     ap.add_argument("--pairs", type=int, default=256, help="total pairs per step for --config cfg4 (sharded over the ranks)")
-    ap.add_argument("--resident-pairs", type=int, default=64,
-                    help="cfg2: distinct synthetic pairs resident per GPU, all of them processed by every step (64 pairs = 3.7 GB of frames "
-                         "and pyramids: a step's working set is 14x the 256 MB Infinity Cache)")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--resident-pairs", type=int, default=72,
+                    help="cfg2: distinct synthetic pairs resident per GPU, all of them processed by every step (72 pairs = 4.2 GB of frames "
+                         "and pyramids: a step's working set is 16x the 256 MB Infinity Cache); a multiple of --inflight x --batch")
+    ap.add_argument("--inflight", type=int, default=3,
                     help="contexts per GPU (one HIP stream each, no events between them): consecutive groups of --batch pairs go "
-                         "round-robin to them, so kernels of different groups overlap; 1 = a single stream")
+                         "round-robin to them, so kernels of different groups overlap; 1 = a single stream.  With eight pairs per launch "
+                         "3 contexts read 0.6-2.5 %% above 2 in every session (163.3 / 159.3, 158-160 / 154-155, 153.0 / 152.1 M features/s); "
+                         "4 x 4 pairs 7 %% below")
     ap.add_argument("--batch", type=int, default=8, choices=[1, 2, 4, 8, 16],
                     help="pairs that share every launch of a context: one batched pyramid build for their frames and one tracker launch "
                          "for their feature lists.  On distinct resident pairs (nothing to keep in a cache) longer launches win: 2 contexts x "

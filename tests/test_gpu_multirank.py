@@ -43,7 +43,7 @@ def run_ranks(args, tmp_path, stub, timeout=900):
 def test_cfg2_ranks_with_their_own_pairs_and_the_all_gather(world, tmp_path, stub_rccl):
     """`bench.py --gpus N`: every rank runs its own distinct pairs (seeds rank * NP + 1 ...), each context's record table is all-gathered
     every step; rank 0 checks all of its own pairs against the oracle AND pair 0 of the last rank as it arrived through the gather."""
-    line = run_ranks(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--repeats", "5", "--resident-pairs", "4", "--batch", "2",
+    line = run_ranks(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--repeats", "5", "--resident-pairs", "4", "--inflight", "2", "--batch", "2",
                       "--no-cpu-baseline", "--no-extras", "--min-timed-s", "0"], tmp_path, stub_rccl)
     assert line["n_gpus"] == world and line["config"]["rccl_ranks"] == world and line["config"]["pairs_per_step"] == 4 * world
     assert line["parity_checked"] is True and line["parity_cases"] == 5 and line["max_abs_dx"] <= 1e-3
@@ -108,7 +108,7 @@ def test_a_rank_that_dies_takes_the_run_down(tmp_path, stub_rccl):
     os.makedirs(env["KLT_STUB_RCCL_DIR"], exist_ok=True)
     t0 = time.monotonic()
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "5",
-                        "--resident-pairs", "4", "--batch", "2", "--no-cpu-baseline", "--no-extras", "--min-timed-s", "0"],
+                        "--resident-pairs", "4", "--inflight", "2", "--batch", "2", "--no-cpu-baseline", "--no-extras", "--min-timed-s", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert time.monotonic() - t0 < 60, "the surviving rank was left waiting"
@@ -132,7 +132,7 @@ def test_the_drivers_multi_gpu_launch_line(tmp_path, stub_rccl):
     os.makedirs(env["KLT_STUB_RCCL_DIR"], exist_ok=True)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--repeats", "5", "--resident-pairs", "4", "--batch", "2", "--no-cpu-baseline", "--no-extras", "--min-timed-s", "0"],
+                        "--repeats", "5", "--resident-pairs", "4", "--inflight", "2", "--batch", "2", "--no-cpu-baseline", "--no-extras", "--min-timed-s", "0"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -833,7 +833,7 @@ def _run_bench(extra_args, **env_kw):
 def test_rccl_path_on_one_gpu(tmp_path):
     """bench.py's N > 1 code path -- rendezvous file, klt_comm_init_rank, the all-gather of the device-side record table on
     libkltgpu's side stream, barrier / max over ranks through klt_comm_allreduce_max -- with a single rank (no torch)."""
-    line = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--repeats", "5", "--resident-pairs", "8", "--batch", "2", "--no-cpu-baseline", "--no-extras"],
+    line = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--repeats", "5", "--resident-pairs", "8", "--inflight", "2", "--batch", "2", "--no-cpu-baseline", "--no-extras"],
                       KLT_FORCE_DIST="1", KLT_RDZV_FILE=str(tmp_path / "ids"))
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["tracked"] > 4500
     assert line["config"]["rccl_ranks"] == 1 and line["parity_checked"] is True and line["max_abs_dx"] <= 1e-3
@@ -1724,7 +1724,7 @@ def test_two_rank_launch_reaches_rccl_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KLT_RDZV_FILE")}
     env["KLT_RANKS_SHARE_DEVICE"] = "0"
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "5",
-                        "--resident-pairs", "4", "--batch", "2", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+                        "--resident-pairs", "4", "--inflight", "2", "--batch", "2", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
     if r.returncode == 0:
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["parity_checked"] is True

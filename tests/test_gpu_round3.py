@@ -125,12 +125,12 @@ def run_bench(extra_args, timeout=1200, **env_kw):
 
 def test_the_drivers_command_line_prints_a_clean_record():
     """`python bench.py --gpus 1 --steps 20 --warmup 5` -- exactly what the driver runs at round end: no figure above its roof,
-    iteration counters that describe the launches they are divided by, 64 distinct pairs all checked against the oracle, a timed
+    iteration counters that describe the launches they are divided by, 72 distinct pairs all checked against the oracle, a timed
     phase long enough to be seen from outside the process, and a value that does not depend on K."""
     line = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
     roof = line["roofline"]
-    assert line["parity_checked"] is True and line["parity_cases"] == 64 and line["max_abs_dx"] <= 1e-3
-    assert line["config"]["resident_pairs"] == 64 and line["config"]["pairs_per_step"] == 64
+    assert line["parity_checked"] is True and line["parity_cases"] == 72 and line["max_abs_dx"] <= 1e-3
+    assert line["config"]["resident_pairs"] == 72 and line["config"]["pairs_per_step"] == 72 and line["config"]["contexts"] == 3
     assert 0 < roof["frac"] < 1 and 0 < roof["frac_moved"] < roof["frac"] and 0 < roof["step_frac"] < 1
     assert roof["kernel"] == "smooth_grad_l0" and roof["launch_us_source"] == "dispatch timestamps"
     for name, k in roof["kernels"].items():

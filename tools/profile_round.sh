@@ -34,6 +34,7 @@ python3 bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_steps20.json 2>> $O/ben
 python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_${TAG}_steps200.json 2>> $O/bench_$TAG.err
 python3 bench.py --inflight 1 --batch 1 --no-cpu-baseline --no-api > $O/bench_${TAG}_single_stream.json 2>> $O/bench_$TAG.err
 python3 bench.py --inflight 2 --batch 2 --no-cpu-baseline --no-api > $O/bench_${TAG}_2x2.json 2>> $O/bench_$TAG.err
+python3 bench.py --inflight 2 --batch 8 --resident-pairs 64 --no-cpu-baseline --no-api > $O/bench_${TAG}_2x8.json 2>> $O/bench_$TAG.err
 python3 bench.py --inflight 3 --batch 1 --resident-pairs 66 --no-cpu-baseline --no-api > $O/bench_${TAG}_3x1.json 2>> $O/bench_$TAG.err
 KLT_FORCE_DIST=1 python3 bench.py --gpus 1 --no-cpu-baseline --no-api > $O/bench_${TAG}_rccl_1rank.json 2>> $O/bench_$TAG.err
 for c in cfg1 cfg3 cfg5; do python3 bench.py --config $c > $O/bench_${TAG}_$c.json 2>> $O/bench_$TAG.err; done
