@@ -51,6 +51,15 @@ def test_cfg2_ranks_with_their_own_pairs_and_the_all_gather(world, tmp_path, stu
     assert line["value"] > 0 and line["scaling"] == "weak"
 
 
+def test_cfg2_three_contexts_per_rank_as_in_the_default_arrangement(tmp_path, stub_rccl):
+    """The default line runs three contexts per rank (three record tables, three all-gathers per step through one communicator each,
+    chained in issue order): the same at a small size, two ranks."""
+    line = run_ranks(["--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "5", "--resident-pairs", "6", "--inflight", "3", "--batch", "2",
+                      "--no-cpu-baseline", "--no-extras", "--min-timed-s", "0"], tmp_path, stub_rccl)
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["contexts"] == 3 and line["config"]["pairs_per_step"] == 12
+    assert line["parity_checked"] is True and line["parity_cases"] == 7 and line["max_abs_dx"] <= 1e-3
+
+
 def test_cfg4_shards_of_unequal_size_through_the_gather_with_counts(tmp_path, stub_rccl):
     """7 pairs over 2 ranks (4 + 3) and over 3 ranks (3 + 2 + 2): klt_gatherv_featbuf_async with a count per rank; rank 0 holds the whole
     [7 x 2000] table, its own shard equals what it produced and the batch's last pair -- tracked by another rank -- equals the
