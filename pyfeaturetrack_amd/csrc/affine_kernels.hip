@@ -19,6 +19,9 @@
 
 namespace {
 
+// ST = element stride of the plane: 1 (image planes, the kernel's own template copies) or KLT_GRAD_STRIDE (one of the two interleaved
+// gradient planes of a frame; `img` is then the plane's own first element)
+template <int ST = 1>
 __device__ __forceinline__ float bilinear_at(const float *__restrict__ img, int nc, float x, float y)
 {
     const int ix = (int)x, iy = (int)y;
@@ -29,10 +32,10 @@ __device__ __forceinline__ float bilinear_at(const float *__restrict__ img, int 
     // address instead of a 64-bit pointer pair (the model-2 kernel has 48 of them in flight and was at 200+ VGPRs), the row offset a
     // 24-bit multiply (rows and row lengths are far below 2^24; the 32-bit and 64-bit integer multiplies are quarter-rate)
     const plane_rsrc r = plane_of(img);
-    const unsigned o = 4u * (__umul24((unsigned)iy, (unsigned)nc) + (unsigned)ix), down = 4u * (unsigned)nc;
-    const float t4 = w11 * plane_load(r, o + down + 4u);
+    const unsigned o = 4u * ST * (__umul24((unsigned)iy, (unsigned)nc) + (unsigned)ix), down = 4u * ST * (unsigned)nc;
+    const float t4 = w11 * plane_load(r, o + down + 4u * ST);
     double v = w00 * (double)plane_load(r, o);
-    v = v + w01 * (double)plane_load(r, o + 4u);
+    v = v + w01 * (double)plane_load(r, o + 4u * ST);
     v = v + w10 * (double)plane_load(r, o + down);
     v = v + (double)t4;
     return (float)v;
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
         for (int k = lane; k < tn; k += 64) {
             const size_t o = (size_t)(y0 - thh + k / tw) * nc + (x0 - thw + k % tw);
             tpl[k] = a.i1[o];
-            tpl[tn + k] = a.gx1[o];
-            tpl[2 * tn + k] = a.gy1[o];
+            tpl[tn + k] = a.gx1[KLT_GRAD_STRIDE * o];                 // interleaved gradient planes (klt_internal.h)
+            tpl[2 * tn + k] = a.gy1[KLT_GRAD_STRIDE * o];
         }
         if (lane == 0) {
             st.aff_x = before.x - (float)x0 + (float)thw;
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
             float gxx = 0.f, gxy = 0.f, gyy = 0.f, ex = 0.f, ey = 0.f;
             for_samples([&](float fi, float fj, float ti, float tgx, float tgy) {
                 const float d = ti - bilinear_at(a.i2, nc, x2 + fi, y2 + fj);
-                const float g1 = tgx + bilinear_at(a.gx2, nc, x2 + fi, y2 + fj);
-                const float g2 = tgy + bilinear_at(a.gy2, nc, x2 + fi, y2 + fj);
+                const float g1 = tgx + bilinear_at<KLT_GRAD_STRIDE>(a.gx2, nc, x2 + fi, y2 + fj);
+                const float g2 = tgy + bilinear_at<KLT_GRAD_STRIDE>(a.gy2, nc, x2 + fi, y2 + fj);
                 gxx = gxx + g1 * g1; gxy = gxy + g1 * g2; gyy = gyy + g2 * g2;
                 ex = ex + d * g1; ey = ey + d * g2;
             });
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
             for_samples([&](float x, float y, float ti, float, float) {
                 const float mi = Axx * x + Axy * y, mj = Ayx * x + Ayy * y;
                 const float d = ti - bilinear_at(a.i2, nc, x2 + mi, y2 + mj);
-                const float g1 = bilinear_at(a.gx2, nc, x2 + mi, y2 + mj);
-                const float g2 = bilinear_at(a.gy2, nc, x2 + mi, y2 + mj);
+                const float g1 = bilinear_at<KLT_GRAD_STRIDE>(a.gx2, nc, x2 + mi, y2 + mj);
+                const float g2 = bilinear_at<KLT_GRAD_STRIDE>(a.gy2, nc, x2 + mi, y2 + mj);
                 if (MODE == 1) {
                     const float u = x * g1 + y * g2, v = x * g2 - y * g1;
                     e[0] = e[0] + (d * g1 * x + d * g2 * y); e[1] = e[1] + (d * g2 * x - d * g1 * y);

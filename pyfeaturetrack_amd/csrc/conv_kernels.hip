@@ -98,14 +98,15 @@ template <int NOUT>
 __global__ __launch_bounds__(256) void vconv_kernel(const float *__restrict__ inA, const float *__restrict__ inB,
                                                      int ncols, int nrows, float *__restrict__ outA,
                                                      float *__restrict__ outB, int out_rows, int ystride, int yoff,
-                                                     Taps ta, Taps tb)
+                                                     Taps ta, Taps tb, int ostride)
 {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int ys = blockIdx.y * 4 + threadIdx.y;
     if (x >= ncols || ys >= out_rows) return;
     const int y = ys * ystride + yoff;
-    outA[(size_t)ys * ncols + x] = correlate_at(inA + x, (size_t)ncols, y, nrows, ta);
-    if (NOUT == 2) outB[(size_t)ys * ncols + x] = correlate_at(inB + x, (size_t)ncols, y, nrows, tb);
+    const size_t o = ((size_t)ys * ncols + x) * ostride;          // ostride 2: outB == outA + 1, interleaved gradient planes
+    outA[o] = correlate_at(inA + x, (size_t)ncols, y, nrows, ta);
+    if (NOUT == 2) outB[o] = correlate_at(inB + x, (size_t)ncols, y, nrows, tb);
 }
 
 }  // namespace
@@ -133,12 +134,25 @@ void launch_hconv_f32(hipStream_t s, const float *in, int ncols, int nrows, floa
     launch_hconv_t<float>(s, in, ncols, nrows, outA, outB, out_cols, xstride, xoff, ta, tb);
 }
 
+// dst[i] = src[i * stride]: one of the two interleaved gradient planes as a plane of its own (the ABI's plane downloads)
+__global__ __launch_bounds__(256) void take_strided_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n, int stride)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i * stride];
+}
+
+void launch_take_strided(hipStream_t s, const float *src, float *dst, size_t n, int stride)
+{
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(take_strided_kernel, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, s, src, dst, n, stride);
+}
+
 void launch_vconv(hipStream_t s, const float *inA, const float *inB, int ncols, int nrows, float *outA, float *outB,
                   int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb)
 {
     dim3 block(64, 4), grid((ncols + 63) / 64, (out_rows + 3) / 4);
+    const int ostride = (tb && outB == outA + 1) ? 2 : 1;          // two outputs one element apart: the interleaved gradient planes
     if (tb)
-        hipLaunchKernelGGL((vconv_kernel<2>), grid, block, 0, s, inA, inB, ncols, nrows, outA, outB, out_rows, ystride, yoff, ta, *tb);
+        hipLaunchKernelGGL((vconv_kernel<2>), grid, block, 0, s, inA, inB, ncols, nrows, outA, outB, out_rows, ystride, yoff, ta, *tb, ostride);
     else
-        hipLaunchKernelGGL((vconv_kernel<1>), grid, block, 0, s, inA, inB, ncols, nrows, outA, outB, out_rows, ystride, yoff, ta, ta);
+        hipLaunchKernelGGL((vconv_kernel<1>), grid, block, 0, s, inA, inB, ncols, nrows, outA, outB, out_rows, ystride, yoff, ta, ta, ostride);
 }

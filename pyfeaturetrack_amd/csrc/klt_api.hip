@@ -486,11 +486,13 @@ int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int p
 int layout_pyramid(klt_ctx *c, Slot *s)
 {
     const int L = c->p.nPyramidLevels, ss = c->p.subsampling;
+    // [image planes of all levels][interleaved gradient planes of all levels]; every level starts on a 16-byte boundary
+    auto padded = [](int nc_, int nr_) { return ((size_t)nc_ * nr_ + 3) & ~(size_t)3; };
     size_t total = 0;
     int nc = s->nc, nr = s->nr;
     for (int l = 0; l < L; l++) {
         if (nc <= 0 || nr <= 0) return fail(c, KLT_ERR_ARG, "image too small for the requested pyramid");
-        total += (size_t)nc * nr;
+        total += padded(nc, nr);
         nc /= ss;
         nr /= ss;
     }
@@ -506,9 +508,9 @@ int layout_pyramid(klt_ctx *c, Slot *s)
         s->lv[l].nc = nc;
         s->lv[l].nr = nr;
         s->lv[l].img = s->planes + off;
-        s->lv[l].gx = s->planes + total + off;
-        s->lv[l].gy = s->planes + 2 * total + off;
-        off += (size_t)nc * nr;
+        s->lv[l].gx = s->planes + total + KLT_GRAD_STRIDE * off;      // gradx and grady of a pixel side by side (klt_internal.h)
+        s->lv[l].gy = s->lv[l].gx + 1;
+        off += padded(nc, nr);
         nc /= ss;
         nr /= ss;
     }
@@ -575,6 +577,14 @@ bool merged_grad_ok(const klt_ctx *c)
 bool fused_grad_ok(const klt_ctx *c) { return c->use_fused && smooth_grad_lds_bytes(-1, grad_radius(c)) <= kMaxLds; }
 bool fused_reduce_ok(const klt_ctx *c) { return c->use_fused && pyr_reduce_lds_bytes(c->p.subsampling, c->gauss[1].n) <= kMaxLds; }
 
+// 2 when every entry's grady plane starts one element behind its gradx plane (the interleaved planes of slots and of the selection), else 1
+static int grad_stride_of(float *const *gx, float *const *gy, int batch)
+{
+    for (int b = 0; b < batch; b++)
+        if (gy[b] != gx[b] + 1) return 1;
+    return KLT_GRAD_STRIDE;
+}
+
 // smooth(raw frame) + gradients for up to KLT_MAX_BATCH same-sized frames in one launch
 // *fused_h1 (optional, in/out): in = the caller wants the horizontal pass of the first reduction fused into this launch; out =
 // whether it was (then c->h1 holds one H1 plane of nr x (nc / ss) floats per frame)
@@ -584,6 +594,7 @@ int enqueue_fused_smooth_grad(klt_ctx *c, int batch, const void *const *raw, int
     SmoothGradArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int b = 0; b < batch; b++) { a.raw[b] = raw[b]; a.img[b] = img[b]; a.gx[b] = gx[b]; a.gy[b] = gy[b]; }
+    a.gstride = grad_stride_of(gx, gy, batch);
     a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
     a.ncols = nc; a.nrows = nr; a.R = grad_radius(c);
     const int kind = raw_kind == 1 ? 0 : 1;
@@ -613,6 +624,7 @@ int enqueue_fused_grad(klt_ctx *c, int batch, const float *const *img, float *co
     SmoothGradArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int b = 0; b < batch; b++) { a.raw[b] = img[b]; a.gx[b] = gx[b]; a.gy[b] = gy[b]; }
+    a.gstride = grad_stride_of(gx, gy, batch);
     a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
     a.ncols = nc; a.nrows = nr; a.R = grad_radius(c);
     TimerScope t(c, F_GRAD, (double)nc * nr * batch * 12);
@@ -766,6 +778,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
                     a.dim_c[e] = (short)g[b]->lv[l].nc; a.dim_r[e] = (short)g[b]->lv[l].nr;
                     bytes += 12.0 * g[b]->lv[l].nc * g[b]->lv[l].nr;
                 }
+            a.gstride = KLT_GRAD_STRIDE;                              // slot planes: gradx / grady interleaved
             a.smooth = c->gauss[0]; a.ggauss = c->gauss[2]; a.gderiv = c->deriv[2];
             a.ncols = s0->lv[1].nc; a.nrows = s0->lv[1].nr; a.R = grad_radius(c);
             TimerScope t(c, F_GRAD, bytes);
@@ -852,7 +865,7 @@ void klt_destroy(klt_ctx *c)
     for (FeatBuf &b : c->fbs)
         if (!b.view) hipFree(b.d);
     hipFree(c->tmpA); hipFree(c->tmpB); hipFree(c->h1);
-    hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap);
+    hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sat); hipFree(c->valmap);      // (sel_gy points into sel_gx's allocation)
     for (auto &e : c->pre) hipFree(e.keys);
     hipFree(c->sat_pre);
     hipFree(c->keys); hipFree(c->seedmap); hipFree(c->grid); hipFree(c->nms_slots); for (auto &bt : c->batch_tables) hipFree(bt.dev); for (auto &bo : c->batch_orders) hipFree(bo.order); hipFree(c->shared_order.order); hipFree(c->keys2); hipFree(c->topk_hist); hipFree(c->fl_snapshot); hipFree(c->mis_st); hipFree(c->mis_list); hipFree(c->mis_cnt); hipFree(c->score_override); hipFree(c->mis_tile_keys);
@@ -1384,11 +1397,11 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
 
     // scratch
     if (N > c->sel_cap) {
-        if (c->sel_img) { if (int rc = sync_all(c)) return rc; hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sel_gy); hipFree(c->sat); hipFree(c->valmap); }
+        if (c->sel_img) { if (int rc = sync_all(c)) return rc; hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sat); hipFree(c->valmap); }
         c->sel_img = c->sel_gx = c->sel_gy = c->sat = c->valmap = nullptr;
         HIPCHK(c, hipMalloc((void **)&c->sel_img, N * sizeof(float)));
-        HIPCHK(c, hipMalloc((void **)&c->sel_gx, N * sizeof(float)));
-        HIPCHK(c, hipMalloc((void **)&c->sel_gy, N * sizeof(float)));
+        HIPCHK(c, hipMalloc((void **)&c->sel_gx, KLT_GRAD_STRIDE * N * sizeof(float)));      // gradx / grady interleaved, like a slot's planes
+        c->sel_gy = c->sel_gx + 1;
         HIPCHK(c, hipMalloc((void **)&c->sat, 3 * N * sizeof(float)));
         HIPCHK(c, hipMalloc((void **)&c->valmap, N * sizeof(float)));
         c->sel_cap = N;
@@ -2188,6 +2201,22 @@ int klt_level_dims(klt_ctx *c, int slot, int level, int *ncols, int *nrows)
     return KLT_OK;
 }
 
+// a plane to the host; the gradient planes are stored interleaved (klt_internal.h) and leave through a plane of their own
+static int download_plane(klt_ctx *c, const float *src, int stride, size_t cnt, float *dst)
+{
+    float *tmp = nullptr;
+    if (stride != 1) {
+        HIPCHK(c, hipMalloc((void **)&tmp, cnt * sizeof(float)));
+        launch_take_strided(c->stream, src, tmp, cnt, stride);
+        src = tmp;
+    }
+    hipError_t e = hipMemcpyAsync(dst, src, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (tmp) hipFree(tmp);
+    HIPCHK(c, e);
+    return KLT_OK;
+}
+
 int klt_download_f32(klt_ctx *c, int slot, int pyramid, int level, float *dst)
 {
     if (!c || !dst) return fail(c, KLT_ERR_ARG, "null argument");
@@ -2198,9 +2227,7 @@ int klt_download_f32(klt_ctx *c, int slot, int pyramid, int level, float *dst)
     const float *src = pyramid == 0 ? l.img : (pyramid == 1 ? l.gx : l.gy);
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = wait_built(c, s)) return rc;
-    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)l.nc * l.nr * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return KLT_OK;
+    return download_plane(c, src, pyramid == 0 ? 1 : KLT_GRAD_STRIDE, (size_t)l.nc * l.nr, dst);
 }
 
 int klt_select_dims(klt_ctx *c, int what, int *ncols, int *nrows)
@@ -2220,9 +2247,7 @@ int klt_download_select_f32(klt_ctx *c, int what, float *dst)
     const float *src = what == 3 ? c->valmap : c->last_sel[what];
     const size_t cnt = what == 3 ? (size_t)c->sel_nx * c->sel_ny : (size_t)c->sel_nc * c->sel_nr;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(dst, src, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return KLT_OK;
+    return download_plane(c, src, (what == 1 || what == 2) ? KLT_GRAD_STRIDE : 1, cnt, dst);
 }
 
 int klt_set_score_override(klt_ctx *c, const float *val, int count)

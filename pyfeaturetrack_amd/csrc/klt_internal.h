@@ -20,7 +20,8 @@ constexpr int KLT_MAX_BATCH = 32;   // frames per fused pyramid launch (pointer 
 struct SmoothGradArgs {
     const void *raw[KLT_MAX_BATCH];   // u8 or f32 frame (or, for gradients only, the level image)
     float *img[KLT_MAX_BATCH];        // smoothed image out (unused for gradients only)
-    float *gx[KLT_MAX_BATCH], *gy[KLT_MAX_BATCH];
+    float *gx[KLT_MAX_BATCH], *gy[KLT_MAX_BATCH];   // gradient planes; gstride == 2: ONE interleaved plane per entry, gy[b] == gx[b] + 1
+    int gstride;                      // element stride of a gradient plane: 2 for the planes of slots / the selection (KLT_GRAD_STRIDE), 1 for separate planes
     Taps smooth, ggauss, gderiv;
     int ncols, nrows, R;              // R = max gradient tap radius; ncols/nrows = largest entry (grid extent)
     short dim_c[KLT_MAX_BATCH], dim_r[KLT_MAX_BATCH];   // per-entry geometry when entries differ (0 = use ncols/nrows)
@@ -37,8 +38,15 @@ struct PyrReduceArgs {
     int src_nc, src_nr, dst_nc, dst_nr, ss, log2ss;
 };
 
+// The two gradient planes of a pyramid level are stored INTERLEAVED: pixel (y, x) holds gradx at element 2 (y nc + x) and grady right
+// behind it, so gy == gx + 1 and a row of a tracking window's footprint is one contiguous piece (64 bytes for an 8-pixel row) instead of
+// two 32-byte pieces in two planes -- the tracker is bound by the cache lines its footprints touch.  Producers
+// (level-0 kernel, gradient kernels) write both values of a pixel together, consumers (tracker, affine check, summed-area row pass)
+// read them together; only the plane download of the ABI separates them again.
+constexpr int KLT_GRAD_STRIDE = 2;
+
 struct TrackLevel {
-    const float *i1, *gx1, *gy1, *i2, *gx2, *gy2;
+    const float *i1, *gx1, *gy1, *i2, *gx2, *gy2;   // gy == gx + 1 (interleaved gradient planes)
     int nc, nr;
 };
 
@@ -144,6 +152,7 @@ void launch_hconv_u8(hipStream_t s, const uint8_t *in, int ncols, int nrows, flo
                      int out_cols, int xstride, int xoff, const Taps &ta, const Taps *tb);
 void launch_hconv_f32(hipStream_t s, const float *in, int ncols, int nrows, float *outA, float *outB,
                       int out_cols, int xstride, int xoff, const Taps &ta, const Taps *tb);
+void launch_take_strided(hipStream_t s, const float *src, float *dst, size_t n, int stride);
 void launch_vconv(hipStream_t s, const float *inA, const float *inB, int ncols, int nrows, float *outA, float *outB,
                   int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb);
 
@@ -167,6 +176,14 @@ __device__ __forceinline__ void plane_store2(plane_rsrc r, unsigned byte_off, fl
     __builtin_amdgcn_raw_buffer_store_b64(w, r, byte_off, 0, 0);
 }
 
+__device__ __forceinline__ void plane_store4(plane_rsrc r, unsigned byte_off, float2 a, float2 b)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w;
+    w.x = __builtin_bit_cast(unsigned, a.x); w.y = __builtin_bit_cast(unsigned, a.y);
+    w.z = __builtin_bit_cast(unsigned, b.x); w.w = __builtin_bit_cast(unsigned, b.y);
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, byte_off, 0, 0);
+}
 __device__ __forceinline__ float plane_load(plane_rsrc r, unsigned byte_off)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));

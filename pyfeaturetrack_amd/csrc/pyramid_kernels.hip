@@ -144,8 +144,9 @@ __global__ __launch_bounds__(256) void smooth_grad_kernel(SmoothGradArgs a)
         const int r = i / TW, x = i - r * TW;
         const int y = ty0 + r, xx = tx0 + x;
         if (y < nr && xx < nc) {
-            gxo[(size_t)y * nc + xx] = correlate_lds(D + (r + R) * TW + x, TW, a.ggauss);
-            gyo[(size_t)y * nc + xx] = correlate_lds(E + (r + R) * TW + x, TW, a.gderiv);
+            const size_t o = ((size_t)y * nc + xx) * a.gstride;      // gstride 2: gyo == gxo + 1 (interleaved planes)
+            gxo[o] = correlate_lds(D + (r + R) * TW + x, TW, a.ggauss);
+            gyo[o] = correlate_lds(E + (r + R) * TW + x, TW, a.gderiv);
         }
     }
 }
@@ -297,8 +298,7 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
     const int tid = threadIdx.x, b = blockIdx.z;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH_;
     // two adjacent outputs go out as one 8-byte store where every row of the planes keeps them aligned (block-uniform)
-    const bool vec2_ok = (nc & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.img[b]) | reinterpret_cast<uintptr_t>(a.gx[b]) |
-                                            reinterpret_cast<uintptr_t>(a.gy[b])) & 7) == 0;
+    const bool vec2_ok = (nc & 1) == 0 && (reinterpret_cast<uintptr_t>(a.img[b]) & 7) == 0;
     const TIn *__restrict__ raw = (const TIn *)a.raw[b];
     const unsigned row_bytes = 4u * (unsigned)nc;                // of the f32 planes
     const unsigned tile_b0 = (unsigned)ty0 * row_bytes + 4u * (unsigned)tx0;   // byte offset of the tile's first output in them
@@ -507,7 +507,8 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
     // ---- stage 4: vertical pass, D -> gradx (Gaussian taps), E -> grady (derivative taps).  A thread makes two adjacent columns on
     // FOUR consecutive rows: NG + 3 rows of two samples are read (ds_read_b64) and widened once for 8 outputs per plane -- 2.5
     // widenings per output where a quad on two rows needs 4 (the widening is an FP64-rate instruction like the adds and multiplies).
-    const plane_rsrc gxo = plane_of(a.gx[b]), gyo = plane_of(a.gy[b]);
+    const plane_rsrc gxy = plane_of(a.gx[b]);                    // the interleaved gradient plane: gradx, grady of a pixel side by side
+    const bool vec4_ok = (nc & 1) == 0 && (reinterpret_cast<uintptr_t>(a.gx[b]) & 15) == 0;    // both pixels of a pair as one 16-byte store
     static_assert(TH_ % 4 == 0, "tile height must be a multiple of four");
     static_assert(NG == ND, "the vertical pass shares its row window between the two planes");
     constexpr int DH = DW / 2;                                   // half-quads per row
@@ -540,17 +541,18 @@ __device__ __forceinline__ void smooth_grad_rb_tile(const SmoothGradArgs &a, flo
                 oy[dr].x = corr_regs<ND, -1>(v[0] + ND / 2 + dr, kd); oy[dr].y = corr_regs<ND, -1>(v[1] + ND / 2 + dr, kd);
             }
         }
-        const unsigned g_b0 = tile_b0 + __umul24((unsigned)r, row_bytes) + (unsigned)(8 * h);   // byte offset of (ty0 + r, x) in both planes
+        const unsigned g_b0 = 2u * (tile_b0 + __umul24((unsigned)r, row_bytes) + (unsigned)(8 * h));   // byte offset of (ty0 + r, x) in the interleaved plane
 #pragma unroll
         for (int dr = 0; dr < 4; dr++) {
             const int y = ty0 + r + dr;
             if (EDGE && y >= nr) break;
-            const unsigned ob = g_b0 + (unsigned)dr * row_bytes;
-            if (!EDGE && vec2_ok) {
-                plane_store2(gxo, ob, ox[dr]); plane_store2(gyo, ob, oy[dr]);
-            } else {
-                plane_store(gxo, ob, ox[dr].x); plane_store(gyo, ob, oy[dr].x);
-                if (!EDGE || x + 1 < nc) { plane_store(gxo, ob + 4, ox[dr].y); plane_store(gyo, ob + 4, oy[dr].y); }
+            const unsigned ob = g_b0 + (unsigned)dr * 2u * row_bytes;
+            float2 p0, p1;
+            p0.x = ox[dr].x; p0.y = oy[dr].x; p1.x = ox[dr].y; p1.y = oy[dr].y;
+            if (!EDGE && vec4_ok) plane_store4(gxy, ob, p0, p1);
+            else {
+                plane_store2(gxy, ob, p0);
+                if (!EDGE || x + 1 < nc) plane_store2(gxy, ob + 8, p1);
             }
         }
     }
@@ -816,7 +818,7 @@ bool smooth_grad_hred_ok(const SmoothGradArgs &a, int batch, int kind, const Tap
 {
     static const int force_th = getenv("KLT_RB_TH") ? atoi(getenv("KLT_RB_TH")) : 0;
     const bool tall = force_th ? force_th == 32 : (long long)a.ncols * a.nrows * batch >= 1000000;
-    return tall && kind < 2 && a.smooth.sym == 1 && (a.smooth.n == 5 || a.smooth.n == 9) &&
+    return tall && kind < 2 && a.gstride == 2 && a.smooth.sym == 1 && (a.smooth.n == 5 || a.smooth.n == 9) &&
            a.ggauss.sym == 1 && a.gderiv.sym == -1 && a.ggauss.n == 7 && a.gderiv.n == 7 && ss == 4 && reduce.sym == 1 && reduce.n == 21 &&
            a.nrows >= 64 && a.ncols >= 64;
 }
@@ -832,7 +834,7 @@ int launch_smooth_grad(hipStream_t s, const SmoothGradArgs &a, int batch, int ki
 {
     const bool smooth = kind < 2;
     // compile-time specialisations: Gaussian smoothing (symmetric), Gaussian / derivative gradient taps
-    if (a.ggauss.sym == 1 && a.gderiv.sym == -1 && a.ggauss.n == 7 && a.gderiv.n == 7 && (!smooth || a.smooth.sym == 1)) {
+    if (a.gstride == 2 && a.ggauss.sym == 1 && a.gderiv.sym == -1 && a.ggauss.n == 7 && a.gderiv.n == 7 && (!smooth || a.smooth.sym == 1)) {
         const dim3 blk(256);
         // register-blocked kernels; small frames take the shorter tile so that the grid still covers the chip
         static const int force_th = getenv("KLT_RB_TH") ? atoi(getenv("KLT_RB_TH")) : 0;   // experiment hook

@@ -76,17 +76,20 @@ __global__ __launch_bounds__(PIPE_THREADS) __attribute__((amdgpu_waves_per_eu(1,
             step_barrier();
             SAT_MARK(0, s, 2);
         }
-    } else if (wave <= NLW) {                                   // ---- loaders: lane = (row parity, quad of the tile row)
+    } else if (wave <= NLW) {                                   // ---- loaders: lane = (row parity, pixel pair of each half of the tile row)
+        // The gradient planes are interleaved (klt_internal.h): a tile row is RT x 8 = 1024 contiguous bytes behind gx.  Lane q takes
+        // the 16 bytes at 16 q of each 512-byte half -- pixels 2 q, 2 q + 1 and RT / 2 + 2 q, RT / 2 + 2 q + 1 with gradx and grady side
+        // by side -- so every load instruction of a row reads one contiguous 512-byte piece.
         const int j = wave - 1;
         const int half = lane >> 5, q = lane & 31;
-        float4 vx[RB / 2], vy[RB / 2];
+        float4 va[RB / 2], vb[RB / 2];                          // {gx, gy, gx, gy} of the lane's pixel pair in the first / second half
         auto request = [&](int t) {
-            const int c = min(t * RT + 4 * q, ncols - 4);       // clamped, unconditional (ncols % 4 == 0)
+            const int c0 = min(t * RT + 2 * q, ncols - 2), c1 = min(t * RT + RT / 2 + 2 * q, ncols - 2);    // clamped, unconditional (ncols % 4 == 0)
 #pragma unroll
             for (int rp = 0; rp < RB / 2; rp++) {
-                const size_t o = (size_t)min(row0 + 2 * rp + half, nrows - 1) * ncols + c;
-                vx[rp] = *reinterpret_cast<const float4 *>(gx + o);
-                vy[rp] = *reinterpret_cast<const float4 *>(gy + o);
+                const size_t o = (size_t)min(row0 + 2 * rp + half, nrows - 1) * ncols;
+                va[rp] = *reinterpret_cast<const float4 *>(gx + KLT_GRAD_STRIDE * (o + c0));
+                vb[rp] = *reinterpret_cast<const float4 *>(gx + KLT_GRAD_STRIDE * (o + c1));
             }
         };
         for (int s = -NLW; s < nsteps; s++) {                   // (steps -NLW .. -1: the first requests only; one request site)
@@ -95,15 +98,19 @@ __global__ __launch_bounds__(PIPE_THREADS) __attribute__((amdgpu_waves_per_eu(1,
                 float *slot = pipe_lds + (s % NSLOT) * RSLOT;
 #pragma unroll
                 for (int rp = 0; rp < RB / 2; rp++) {
-                    const float4 a = vx[rp], b = vy[rp];
                     const int r = 2 * rp + half;
-                    float4 xx, xy, yy;
-                    xx.x = a.x * a.x; xx.y = a.y * a.y; xx.z = a.z * a.z; xx.w = a.w * a.w;       // goodFeaturesUtils.pyx:49
-                    xy.x = a.x * b.x; xy.y = a.y * b.y; xy.z = a.z * b.z; xy.w = a.w * b.w;       // :50
-                    yy.x = b.x * b.x; yy.y = b.y * b.y; yy.z = b.z * b.z; yy.w = b.w * b.w;       // :51
-                    *reinterpret_cast<float4 *>(slot + (0 * RB + r) * RLD + 4 * q) = xx;
-                    *reinterpret_cast<float4 *>(slot + (1 * RB + r) * RLD + 4 * q) = xy;
-                    *reinterpret_cast<float4 *>(slot + (2 * RB + r) * RLD + 4 * q) = yy;
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        const float4 p = hh ? vb[rp] : va[rp];                  // x0 y0 x1 y1
+                        float2 xx, xy, yy;
+                        xx.x = p.x * p.x; xx.y = p.z * p.z;                     // goodFeaturesUtils.pyx:49
+                        xy.x = p.x * p.y; xy.y = p.z * p.w;                     // :50
+                        yy.x = p.y * p.y; yy.y = p.w * p.w;                     // :51
+                        const int col = hh * (RT / 2) + 2 * q;
+                        *reinterpret_cast<float2 *>(slot + (0 * RB + r) * RLD + col) = xx;
+                        *reinterpret_cast<float2 *>(slot + (1 * RB + r) * RLD + col) = xy;
+                        *reinterpret_cast<float2 *>(slot + (2 * RB + r) * RLD + col) = yy;
+                    }
                 }
             }
             if ((s + NLW) % NLW == j && s + NLW < ntiles) request(s + NLW);
@@ -239,7 +246,7 @@ static bool quads_ok(const void *a, const void *b, const void *c, int ncols, int
 
 int launch_sat_rows_pipe(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows)
 {
-    if (!quads_ok(gx, gy, sat, ncols, nrows)) return -1;
+    if (gy != gx + 1 || !quads_ok(gx, gx, sat, ncols, nrows)) return -1;      // the interleaved gradient planes (klt_internal.h)
     constexpr size_t lds = sizeof(float) * NSLOT * RSLOT;
     static bool set = false;
     if (!set) {

@@ -46,8 +46,8 @@ __global__ __launch_bounds__(SR_T) void sat_rows_kernel(const float *__restrict_
         for (int k = 0; k < 4; k++) {
             const int row = row0 + lr + 4 * k, col = t * 64 + lc;
             const bool ok = t < ntiles && row < nrows && col < ncols;
-            rgx[slot][k] = ok ? gx[(size_t)row * ncols + col] : 0.f;
-            rgy[slot][k] = ok ? gy[(size_t)row * ncols + col] : 0.f;
+            rgx[slot][k] = ok ? gx[KLT_GRAD_STRIDE * ((size_t)row * ncols + col)] : 0.f;      // interleaved gradient planes (klt_internal.h)
+            rgy[slot][k] = ok ? gy[KLT_GRAD_STRIDE * ((size_t)row * ncols + col)] : 0.f;
         }
     };
     auto put = [&](int slot, int buf) {

@@ -61,14 +61,17 @@ __device__ __forceinline__ Bilinear make_bilinear(float x, float y)
     return b;
 }
 
+// ST = element stride of the plane: 1 for an image plane, KLT_GRAD_STRIDE for one of the two interleaved gradient planes (qg then
+// points at the plane's own first element: gradx at +0, grady at +1)
+template <int ST = 1>
 __device__ __forceinline__ float sample(const float *__restrict__ qg, int nc, const Bilinear &b)
 {
     // the planes live in device memory: global loads (a flat load also counts as an LDS operation)
     const __attribute__((address_space(1))) float *q = (const __attribute__((address_space(1))) float *)qg;
-    const float t4 = b.w11 * q[nc + 1];
+    const float t4 = b.w11 * q[ST * (nc + 1)];
     double v = b.w00 * (double)q[0];
-    v = v + b.w01 * (double)q[1];
-    v = v + b.w10 * (double)q[nc];
+    v = v + b.w01 * (double)q[ST];
+    v = v + b.w10 * (double)q[ST * nc];
     v = v + (double)t4;
     return (float)v;
 }
@@ -157,8 +160,8 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
             off[kk] = (k / w) * nc + (k % w);
             const size_t q = (size_t)(b1.iy - hw) * nc + (b1.ix - hw) + off[kk];
             t_i[kk] = sample(lv.i1 + q, nc, b1);
-            t_gx[kk] = sample(lv.gx1 + q, nc, b1);
-            t_gy[kk] = sample(lv.gy1 + q, nc, b1);
+            t_gx[kk] = sample<KLT_GRAD_STRIDE>(lv.gx1 + KLT_GRAD_STRIDE * q, nc, b1);
+            t_gy[kk] = sample<KLT_GRAD_STRIDE>(lv.gy1 + KLT_GRAD_STRIDE * q, nc, b1);
         }
     }
 
@@ -183,8 +186,8 @@ __device__ int track_level(const TrackArgs &a, const TrackLevel &lv, float x1, f
             if (k < n) {
                 const size_t q = base + off[kk];
                 const float diff = t_i[kk] - sample(lv.i2 + q, nc, b2);          // :82-85
-                const float sx = t_gx[kk] + sample(lv.gx2 + q, nc, b2);          // -( -g1 - g2 ), :128 and :297
-                const float sy = t_gy[kk] + sample(lv.gy2 + q, nc, b2);
+                const float sx = t_gx[kk] + sample<KLT_GRAD_STRIDE>(lv.gx2 + KLT_GRAD_STRIDE * q, nc, b2);          // -( -g1 - g2 ), :128 and :297
+                const float sy = t_gy[kk] + sample<KLT_GRAD_STRIDE>(lv.gy2 + KLT_GRAD_STRIDE * q, nc, b2);
                 lds[k] = sx * sx;                  // gxx terms, :299
                 lds[npad + k] = sx * sy;           // gxy terms, :300
                 lds[2 * npad + k] = sy * sy;       // gyy terms, :301
@@ -378,6 +381,17 @@ __device__ __forceinline__ f32x4 load_quad(const float *plane, unsigned q)
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, q << 2, 0, 0));
 }
 
+// the gradient quads of pixels q .. q + 3: the two planes are interleaved (gxy = the gradx plane's pointer, grady one element behind),
+// so the eight values are 32 contiguous bytes -- two 16-byte loads, as for two separate planes, but ONE piece of memory per footprint row
+__device__ __forceinline__ void load_grad_quads(const float *gxy, unsigned q, f32x4 &gx, f32x4 &gy)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gxy, 0, 0x7fffffff, 0x00020000);
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, q << 3, 0, 0));
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (q << 3) + 16u, 0, 0));
+    gx.x = a.x; gx.y = a.z; gx.z = b.x; gx.w = b.z;
+    gy.x = a.y; gy.y = a.w; gy.z = b.y; gy.w = b.w;
+}
+
 // the four window samples of a lane from its quad `a`: pairs (a.x,a.y), (a.y,a.z), (a.z,a.w), (a.w, right neighbour) and the same
 // pairs of the row below (QPR = quads per footprint row: the lane holding the quad below is QPR lanes up)
 template <int QPR>
@@ -454,7 +468,9 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
         const bool run = alive && t_ok;
         // (row * nc as a 24-bit multiply: both are far below 2^24, and the 32-bit integer multiply is a quarter-rate instruction)
         const unsigned q1 = run ? __umul24((unsigned)(b1.iy - hw + qr), (unsigned)nc) + (unsigned)(b1.ix - hw + 4 * qh) : 0u;   // 32-bit element offsets: scalar base + vector offset loads
-        const f32x4 t_qi = load_quad(lv.i1, q1), t_qgx = load_quad(lv.gx1, q1), t_qgy = load_quad(lv.gy1, q1);
+        const f32x4 t_qi = load_quad(lv.i1, q1);
+        f32x4 t_qgx, t_qgy;
+        load_grad_quads(lv.gx1, q1, t_qgx, t_qgy);
 
         // the first Newton iteration starts from a position that is already known: its bounds test (trackFeaturesUtils.pyx:428-431)
         // and its footprint loads go out now, behind the template's
@@ -478,12 +494,12 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
             if (REUSE) {
                 const unsigned q = __umul24((unsigned)(b2.iy - hw + qr), (unsigned)nc) + (unsigned)(b2.ix - hw + 4 * qh);
                 if (iterating && q != q_held) {
-                    s_qi = load_quad(lv.i2, q); s_qgx = load_quad(lv.gx2, q); s_qgy = load_quad(lv.gy2, q);
+                    s_qi = load_quad(lv.i2, q); load_grad_quads(lv.gx2, q, s_qgx, s_qgy);
                     q_held = q;
                 }
             } else {
                 const unsigned q = iterating ? __umul24((unsigned)(b2.iy - hw + qr), (unsigned)nc) + (unsigned)(b2.ix - hw + 4 * qh) : 0u;
-                s_qi = load_quad(lv.i2, q); s_qgx = load_quad(lv.gx2, q); s_qgy = load_quad(lv.gy2, q);
+                s_qi = load_quad(lv.i2, q); load_grad_quads(lv.gx2, q, s_qgx, s_qgy);
             }
         };
         request_footprint();
