@@ -269,7 +269,8 @@ int klt_comm_set_timeout(klt_ctx *ctx, double ms);
 int klt_comm_allreduce_max(klt_ctx *ctx, double *inout, int n);
 
 /* ---- test / inspection hooks --------------------------------------------------------------- */
-/* pyramid: 0 = image, 1 = gradx, 2 = grady; dst holds level_ncols*level_nrows floats */
+/* pyramid: 0 = image, 1 = gradx, 2 = grady; dst holds level_ncols*level_nrows floats.  (On the device the two gradient planes of a level are
+ * stored interleaved -- gradx, grady of a pixel side by side, DESIGN.md section 4 --; this call and klt_download_select_f32 hand out separate planes.) */
 int klt_level_dims(klt_ctx *ctx, int slot, int level, int *ncols, int *nrows);
 int klt_download_f32(klt_ctx *ctx, int slot, int pyramid, int level, float *dst);
 /* selection intermediates of the last klt_select*: 0 = smoothed image, 1 = gradx, 2 = grady (full frame),
