@@ -113,7 +113,8 @@ int klt_set_kernels(klt_ctx *ctx, int which, const double *gauss, int ng, const 
 /* ---- frames (slots) ------------------------------------------------------------------------ */
 /* replaces `np.array(img.convert("F"))`, trackFeatures.py:165,176 / selectGoodFeatures.py:190.
  * pitch is in elements.  The upload is enqueued; the host buffer may be reused on return.
- * Limits: 1 <= ncols, nrows <= 65535 and ncols * nrows < 2^29 (the kernels address an f32 plane with 32-bit byte offsets); a frame
+ * Limits: 1 <= ncols, nrows <= 65535 and ncols * nrows < 2^28 (the kernels address a plane with 32-bit byte offsets below 2 GB, and
+ * the interleaved gradient plane of level 0 has 8 bytes per pixel); a frame
  * beyond them is KLT_ERR_ARG here, at klt_upload_u8_async and at the stand-alone convolution / pyramid calls. */
 int klt_upload_u8(klt_ctx *ctx, int slot, const uint8_t *px, int ncols, int nrows, int pitch);
 int klt_upload_f32(klt_ctx *ctx, int slot, const float *px, int ncols, int nrows, int pitch);

@@ -451,16 +451,17 @@ void make_taps(const double *k, int n, Taps &t)
     }
 }
 
-// The kernels address a plane with 32-bit BYTE offsets (raw buffer operations, klt_internal.h): an f32 plane must stay below 2 GB.
-// 2^29 - 1 pixels is a 23 170 x 23 170 frame; the largest frame of the test suite is 7680 x 4320.
-constexpr long long kMaxFramePixels = (1LL << 29) - 1;
+// The kernels address a plane with 32-bit BYTE offsets into a buffer descriptor of 2 GB (raw buffer operations, klt_internal.h), and the
+// largest plane is the interleaved gradient plane of level 0 with 8 bytes per pixel: a frame must stay below 2^28 pixels.
+// 2^28 - 1 pixels is a 16 384 x 16 383 frame; the largest frame of the test suite is 7680 x 4320.
+constexpr long long kMaxFramePixels = (1LL << 28) - 1;
 
 int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int pitch, int kind)
 {
     if (!c || !px) return fail(c, KLT_ERR_ARG, "null argument");
     if (ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535 || pitch < ncols)
         return fail(c, KLT_ERR_ARG, "bad image geometry");
-    if ((long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "frame too large (an f32 plane must stay below 2 GB)");
+    if ((long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "frame too large (2^28 pixels or more: a plane must stay below 2 GB)");
     HIPCHK(c, hipSetDevice(c->device));
     Slot *s;
     if (int rc = get_slot(c, slot, &s, true)) return rc;
@@ -967,7 +968,7 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
 {
     if (!c || !px) return fail(c, KLT_ERR_ARG, "null argument");
     if (ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535 || pitch < ncols) return fail(c, KLT_ERR_ARG, "bad image geometry");
-    if ((long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "frame too large (an f32 plane must stay below 2 GB)");
+    if ((long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "frame too large (2^28 pixels or more: a plane must stay below 2 GB)");
     HIPCHK(c, hipSetDevice(c->device));
     hipPointerAttribute_t attr;                           // the source must be pinned: a pageable copy would be staged synchronously
     if (hipPointerGetAttributes(&attr, px) != hipSuccess || attr.type != hipMemoryTypeHost) {

@@ -528,13 +528,13 @@ def test_klt_pyramid_class_on_the_device(cfg1, synth251):
 
 @pytest.mark.gpu
 def test_frames_whose_planes_would_pass_2_gb_are_refused():
-    """The kernels address a plane with 32-bit byte offsets (raw buffer operations): a frame of 2^29 pixels or more is an
+    """The kernels address a plane with 32-bit byte offsets below 2 GB (raw buffer operations): a frame of 2^28 pixels or more is an
     argument error at the boundary, before anything is read or allocated; the next size down the ABI's own limits allow is not."""
     import ctypes
     from pyfeaturetrack_amd.backend import Context, KltBackendError
     ctx = Context()
     small = np.zeros((8, 8), np.uint8)                          # never read: the geometry is checked first
-    for ncols, nrows in ((32768, 16384), (65535, 65535), (23171, 23171)):
+    for ncols, nrows in ((16384, 16384), (32768, 16384), (65535, 65535), (23171, 23171)):
         with pytest.raises(KltBackendError, match="frame too large"):
             ctx._check(ctx._lib.klt_upload_u8(ctx._h, 0, small.ctypes.data, ncols, nrows, ncols))
     taps = np.array([0.1, 0.2, 0.4, 0.2, 0.1])
