@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 7
+#define KLT_ABI_VERSION 8
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -136,6 +136,10 @@ int klt_build_pyramids(klt_ctx *ctx, int slot);
 /* bit 0: the slot holds a frame; bit 1: its pyramids are built and match the current parameters / taps (what
  * `tc.pyramid_last is not None` means in the reference, trackFeatures.py:152); 0 for a slot never used */
 int klt_slot_state(klt_ctx *ctx, int slot);
+/* which build filled the slot's pyramids: a number unique per build within the context that travels with klt_swap_slots; 0 while the
+ * slot has no valid pyramids.  The host layer's pyramid handles (what ComputeImagePyramids returns and tc.pyramid_last holds,
+ * trackFeatures.py:146-196, :401-404) use it to tell whether the planes they stand for are still on the device. */
+int klt_slot_generation(klt_ctx *ctx, int slot, uint64_t *gen);
 /* releases the slot's device memory (raw frames, pyramids); the index can be used again.  The reference frees images and
  * pyramids when the Python objects die; the host layer calls this from a finalizer of the tracking context. */
 int klt_slot_free(klt_ctx *ctx, int slot);
@@ -299,6 +303,30 @@ int klt_gradients_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, cons
  * levels 1 .. nlevels-1 back to back (nothing for nlevels = 1); all levels stay on the device until the one download. */
 int klt_pyramid_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, int nlevels, int subsampling, const double *gauss, int ng,
                     float *dst);
+
+/* ---- the reference's literal native boundary (host arrays in / out, synchronous) --------------- */
+/* The only FFI the reference really has is its Cython `def` layer (setup.py:8-9).  These three are its entry points on the hot
+ * path, bound by pyfeaturetrack_amd/compat/goodFeaturesUtils.py and trackFeaturesUtils.py under the reference's module and
+ * function names.  Every call uploads the planes it is given: a boundary for drop-in use and for parity checks at the reference's
+ * own granularity, not the fast path (that is klt_select* / klt_track*). */
+/* ScanImageForGoodFeatures, goodFeaturesUtils.pyx:35-73: summed-area tables of gradx^2, gradx grady, grady^2 (f32 sequential scans,
+ * :49-51) and the minimum eigenvalue of every candidate window (:17-31), candidates at x = borderx, borderx + step, ... < ncols - borderx
+ * (the same in y), step = nSkippedPixels + 1.  val receives nx * ny eigenvalues in scan order (y outer, x inner: the order of the
+ * reference's three lists); *nx, *ny the grid.  Arguments are the C ints Cython truncates the Python floats to (30.0 -> 30, 3.5 -> 3). */
+int klt_scan_good_features_f32(klt_ctx *ctx, const float *gradx, const float *grady, int ncols, int nrows, int borderx, int bordery,
+                               int window_hw, int window_hh, int nSkippedPixels, float *val, int val_cap, int *nx, int *ny);
+/* extractImagePatchSlow, trackFeaturesUtils.pyx:14-51: width x height bilinear samples around (x, y), weights in FP64.
+ * Square patches only (the reference swaps the roles of rows and columns, :38-49); a footprint that leaves the image is KLT_ERR_ARG
+ * (the reference asserts, :35). */
+int klt_extract_patch_f32(klt_ctx *ctx, const float *img, int ncols, int nrows, float x, float y, int width, int height, float *patch);
+/* trackFeatureIterateCKLT, trackFeaturesUtils.pyx:393-459: the Newton loop of one feature at one pyramid level on template patches
+ * the caller extracted; returns the position, the status (KLT_TRACKED / KLT_OOB / KLT_SMALL_DET) and the iteration count.  The tests
+ * after the loop and the status priority are _trackFeature's (trackFeatures.py:67-136), i.e. the caller's.  Square windows only
+ * (the reference's jacobian is strided by shape[0], :128). */
+int klt_track_iterate_f32(klt_ctx *ctx, float x2, float y2, const float *gradx_patch, const float *grady_patch, const float *img_patch,
+                          int width, int height, const float *img2, const float *gradx2, const float *grady2, int ncols, int nrows,
+                          float step_factor, float min_determinant, float min_displacement, int max_iterations,
+                          float *x2_out, float *y2_out, int *status, int *iterations);
 
 /* ---- per-kernel timing (HIP events on the context's stream) -------------------------------- */
 typedef struct { char name[32]; uint32_t launches; float total_ms; double bytes; } klt_kernel_time;

@@ -74,6 +74,7 @@ SYMBOLS = {
     "klt_set_option": (_I, [_P, _I, _I]),
     "klt_build_pyramids": (_I, [_P, _I]),
     "klt_slot_state": (_I, [_P, _I]),
+    "klt_slot_generation": (_I, [_P, _I, C.POINTER(C.c_uint64)]),
     "klt_slot_free": (_I, [_P, _I]),
     "klt_swap_slots": (_I, [_P, _I, _I]),
     "klt_featbuf_upload": (_I, [_P, _I, _P, _I]),
@@ -108,6 +109,10 @@ SYMBOLS = {
     "klt_smooth_f32": (_I, [_P, _P, _I, _I, C.POINTER(C.c_double), _I, _P]),
     "klt_pyramid_f32": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_double), _I, _P]),
     "klt_gradients_f32": (_I, [_P, _P, _I, _I, C.POINTER(C.c_double), _I, C.POINTER(C.c_double), _I, _P, _P]),
+    "klt_scan_good_features_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _PI, _PI]),
+    "klt_extract_patch_f32": (_I, [_P, _P, _I, _I, C.c_float, C.c_float, _I, _I, _P]),
+    "klt_track_iterate_f32": (_I, [_P, C.c_float, C.c_float, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, C.c_float, C.c_float, C.c_float, _I,
+                                   C.POINTER(C.c_float), C.POINTER(C.c_float), _PI, _PI]),
     "klt_comm_unique_id": (_I, [_P]),
     "klt_comm_init_rank": (_I, [_P, _I, _I, _P]),
     "klt_comm_destroy": (_I, [_P]),

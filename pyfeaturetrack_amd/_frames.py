@@ -1,16 +1,18 @@
-"""Which image each device slot of a tracking context holds, and the pinned staging ring frames travel through.
+"""Which image each device slot of a tracking context holds, and the pinned host copies frames travel through.
 
 The reference converts both images and rebuilds both pyramids on every KLTTrackFeatures call (trackFeatures.py:146-196) -- example1's
-ping-pong (example1.py:53-56) builds the same two pyramids 200 times.  Here a slot remembers the image it was filled from: the object
-(weak reference), its size and mode, and a signature of 1024 pixels sampled on a lattice.  A call that names an image a slot already
-holds -- with pyramids that still match the tracking context -- uploads and builds nothing for it.  An image modified IN PLACE between two
-calls is recognised as new when one of the sampled pixels changed; a caller that edits other pixels of the same object and expects
-them to be seen calls `KLTForgetFrames(tc)` (or sets KLT_NO_FRAME_CACHE=1 in the environment, which disables the cache).
+ping-pong (example1.py:53-56) builds the same two pyramids 200 times.  Here a slot remembers the frame it was filled from by keeping
+the host copy the upload was made from (pinned memory for 8-bit frames -- the DMA source anyway).  A call whose image has EXACTLY the
+pixels a slot already holds -- every byte is compared, after a 1024-pixel lattice has served as a fast reject -- uploads and builds
+nothing for it; any other image, including the same object edited in place by one pixel, is sent and rebuilt, as the reference would.
+The results are therefore those of the reference for any call sequence; what the cache saves is the upload and the pyramid build, what
+it costs is one pass over the frame on the host (2 MB at 1080p: about as long as the copy into pinned memory it replaces).
 
-Frames that do have to travel are copied into a ring of pinned staging buffers and go out with klt_upload_u8_async on the context's copy
-stream: the host copy of the second frame of a pair runs while the first one's DMA is in flight, and the build waits for both on the
-device.
+Opt-in shortcut, a documented deviation: `tc.trustFrameIdentity = True` (or KLT_TRUST_FRAME_IDENTITY=1 in the
+environment) trusts object identity + size + the lattice and skips the full comparison -- for callers that never edit an image in
+place, or call KLTForgetFrames(tc) when they do.  KLT_NO_FRAME_CACHE=1 disables the cache altogether.
 """
+import ctypes
 import os
 import weakref
 
@@ -18,79 +20,205 @@ import numpy as np
 
 _LATTICE = 32
 _DISABLED = os.environ.get("KLT_NO_FRAME_CACHE") == "1"
+_TRUST_ENV = os.environ.get("KLT_TRUST_FRAME_IDENTITY") == "1"
+
+try:
+    _memcmp = ctypes.CDLL(None).memcmp
+    _memcmp.argtypes = (ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+    _memcmp.restype = ctypes.c_int
+except (OSError, AttributeError):                           # pragma: no cover -- no libc memcmp: numpy compares
+    _memcmp = None
 
 
-def _signature(img):
-    """bytes of a 32 x 32 lattice of the image's pixels (a few microseconds for either kind of image)"""
-    if isinstance(img, np.ndarray):
-        h, w = img.shape[:2]
-        return img[::max(1, h // _LATTICE), ::max(1, w // _LATTICE)].tobytes()
-    try:
-        from PIL import Image
-        return img.resize((_LATTICE, _LATTICE), Image.NEAREST).tobytes()
-    except Exception:                                       # noqa: BLE001 -- an image type we cannot sample is never "the same"
-        return None
+def _lattice(arr):
+    h, w = arr.shape[:2]
+    return arr[::max(1, h // _LATTICE), ::max(1, w // _LATTICE)].tobytes()
+
+
+def same_pixels(a, b):
+    """every byte of two arrays of equal shape and dtype (one libc memcmp when both are contiguous)"""
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    if _memcmp is not None and a.flags["C_CONTIGUOUS"] and b.flags["C_CONTIGUOUS"]:
+        return _memcmp(a.ctypes.data, b.ctypes.data, a.nbytes) == 0
+    return bool(np.array_equal(a, b))
+
+
+def _to_array(img):
+    """uint8 or float32 2-D array holding exactly `np.array(img.convert("F"))` (selectGoodFeatures.image_to_array)"""
+    from .selectGoodFeatures import image_to_array
+    return image_to_array(img)
 
 
 class FrameKey:
-    """identity + size + sampled content of one image"""
-    __slots__ = ("ref", "size", "kind", "sig")
+    """One image as a call names it: the object, its size and mode; the pixel array and its lattice are made when first asked for
+    (a Pillow image is converted once per call, and not at all in the trusting mode when identity or size already differ)."""
+    __slots__ = ("img", "size", "kind", "_arr", "_sig")
 
     def __init__(self, img):
-        try:
-            self.ref = weakref.ref(img)
-        except TypeError:
-            self.ref = None
+        self.img = img
         if isinstance(img, np.ndarray):
             self.size, self.kind = (img.shape[1], img.shape[0]), img.dtype.char
         else:
             self.size, self.kind = tuple(img.size), getattr(img, "mode", "?")
-        self.sig = _signature(img)
+        self._arr = self._sig = None
 
-    def same_image(self, img, other):
-        """`other` = the FrameKey just made of `img`"""
-        return (self.ref is not None and self.ref() is img and self.sig is not None and self.size == other.size
-                and self.kind == other.kind and self.sig == other.sig)
+    def array(self):
+        if self._arr is None:
+            self._arr = _to_array(self.img)
+        return self._arr
+
+    def sig(self):
+        if self._sig is None:
+            self._sig = _lattice(self.array())
+        return self._sig
+
+
+class _Held:
+    """what a slot holds: the host copy it was uploaded from (`kept`; pinned for 8-bit frames), the lattice of that copy, a weak
+    reference to the image object, and the number of the last asynchronous upload made from `kept`"""
+    __slots__ = ("ref", "size", "kind", "sig", "kept", "upload_no", "pool")
+
+    def __init__(self, key, kept, upload_no, pool):
+        try:
+            self.ref = weakref.ref(key.img)
+        except TypeError:
+            self.ref = None
+        self.size, self.kind, self.sig = key.size, key.kind, key.sig()
+        self.kept, self.upload_no, self.pool = kept, upload_no, pool
+
+    def release(self):
+        """the pinned copy goes back to its context's pool (still carrying the number of its last upload)"""
+        if self.pool is not None and self.kept is not None:
+            self.pool.append((self.kept, self.upload_no))
+        self.kept = self.pool = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:                                   # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 class FrameCache:
     """Per tracking context: what its device slots hold.  All methods run on the calling thread."""
 
-    def __init__(self):
-        self.held = {}                   # slot -> FrameKey
+    def __init__(self, tc=None):
+        self.held = {}                   # slot -> _Held
+        self.handles = weakref.WeakSet()
+        self._tc = weakref.ref(tc) if tc is not None else None
+
+    def watch(self, handles):
+        """pyramid handles (trackFeatures._ResidentPyramids) whose planes live in this context's slots"""
+        for h in handles:
+            self.handles.add(h)
+
+    def keep_handles(self, ctx, slot):
+        """`slot` is about to be overwritten: handles somebody still holds on the pyramids in it download their planes first (the
+        reference's pyramid objects stay valid for as long as they are referenced)"""
+        if self.handles:
+            gen = ctx.slot_generation(slot)
+            for h in list(self.handles):
+                if gen and h._gen == gen:
+                    h._materialise()
+                    self.handles.discard(h)
+
+    def keep_all_handles(self):
+        """every live handle downloads its planes now (the parameters are about to change, which voids every pyramid of the context,
+        or a sequence call is about to take the slots over)"""
+        for h in list(self.handles):
+            try:
+                h._materialise()
+            except RuntimeError:                            # its planes are gone already; the handle says so when asked
+                pass
+            self.handles.discard(h)
+
+    def trusting(self):
+        tc = self._tc() if self._tc is not None else None
+        return _TRUST_ENV or bool(getattr(tc, "trustFrameIdentity", False))
 
     def forget(self, slot=None):
-        if slot is None:
-            self.held.clear()
-        else:
-            self.held.pop(slot, None)
+        for s in (list(self.held) if slot is None else [slot]):
+            h = self.held.pop(s, None)
+            if h is not None:
+                h.release()
 
     def swap(self, a, b):
-        ka, kb = self.held.pop(a, None), self.held.pop(b, None)
-        if ka is not None:
-            self.held[b] = ka
-        if kb is not None:
-            self.held[a] = kb
+        ha, hb = self.held.pop(a, None), self.held.pop(b, None)
+        if ha is not None:
+            self.held[b] = ha
+        if hb is not None:
+            self.held[a] = hb
 
-    def find(self, img, key, slots, ctx):
-        """slot among `slots` that holds `img` as a frame (raw pixels resident), or None"""
+    def find(self, key, slots, ctx):
+        """slot among `slots` whose resident frame has exactly the pixels of the image `key` names, or None"""
         if _DISABLED:
             return None
+        trusting = self.trusting()
         for s in slots:
-            k = self.held.get(s)
-            if k is not None and k.same_image(img, key) and ctx.frame_resident(s):
+            h = self.held.get(s)
+            if h is None or h.size != key.size or h.kind != key.kind or not ctx.frame_resident(s):
+                continue
+            if trusting:
+                if h.ref is not None and h.ref() is key.img and h.sig == key.sig():
+                    return s
+            elif h.sig == key.sig() and same_pixels(key.array(), h.kept):
                 return s
         return None
 
-    def note(self, slot, key):
+    def send(self, ctx, slot, key):
+        """frame -> slot, remembered: 8-bit frames are copied into the slot's pinned buffer and leave with klt_upload_u8_async on
+        the context's copy stream (the host copy of the second frame of a pair runs while the first one's DMA is in flight, the
+        build waits for both on the device); anything else goes with the synchronous upload and an ordinary copy is kept."""
+        arr = key.array()
+        self.keep_handles(ctx, slot)
+        old = self.held.pop(slot, None)
+        if arr.dtype == np.uint8 and arr.ndim == 2 and hasattr(ctx, "upload_async"):
+            pool = _pool_of(ctx, arr.shape)
+            if old is not None and old.pool is pool and old.kept is not None:
+                buf, no = old.kept, old.upload_no
+                old.kept = old.pool = None
+            elif pool:
+                buf, no = pool.pop()
+            else:
+                buf, no = ctx.pinned_array(arr.shape), 0
+            if old is not None:
+                old.release()
+            _uploads_finished(ctx, no)                      # the DMA that last read this buffer has finished
+            np.copyto(buf, arr)
+            ctx.upload_async(slot, buf)
+            ctx.__dict__["_uploads_issued"] = no = ctx.__dict__.get("_uploads_issued", 0) + 1
+            kept = buf
+        else:
+            if old is not None:
+                old.release()
+            if hasattr(ctx, "upload"):
+                ctx.upload(slot, arr)
+            kept, no, pool = (arr if arr is not key.img else arr.copy()), 0, None
         if not _DISABLED:
-            self.held[slot] = key
+            self.held[slot] = _Held(key, kept, no, pool)
+        elif pool is not None:
+            pool.append((kept, no))
+
+
+def _pool_of(ctx, shape):
+    """pinned frame buffers of this shape nobody holds at the moment: [(buffer, number of its last upload)]"""
+    return ctx.__dict__.setdefault("_frame_pool", {}).setdefault(tuple(shape), [])
+
+
+def _uploads_finished(ctx, upload_no):
+    """host waits until asynchronous upload number `upload_no` of this context has left its source buffer (klt_upload_wait: the copy
+    stream only; kernels keep running) -- no call at all when an earlier wait already covered it"""
+    if upload_no > ctx.__dict__.get("_uploads_done", 0):
+        issued = ctx.__dict__.get("_uploads_issued", 0)
+        ctx.upload_wait()
+        ctx.__dict__["_uploads_done"] = issued
 
 
 def cache_of(tc):
     c = getattr(tc, "_klt_frames", None)
     if c is None:
-        c = tc._klt_frames = FrameCache()
+        c = tc._klt_frames = FrameCache(tc)
     return c
 
 
@@ -99,52 +227,7 @@ def KLTForgetFrames(tc):
     cache_of(tc).forget()
 
 
-class Stager:
-    """Pinned staging ring of a context for frames of one size (u8): `put(slot, array)` copies into the next buffer and enqueues the
-    asynchronous upload.  A buffer is reused only after the copies issued from it have finished (klt_upload_wait: the copy stream
-    only; kernels keep running)."""
-
-    def __init__(self, ctx, shape, count=5):
-        self.ctx, self.shape = ctx, tuple(shape)
-        self.bufs = ctx.staging(self.shape, count=count)
-        self.next = 0
-        self.in_flight = 0
-
-    def put(self, slot, arr):
-        if self.in_flight >= len(self.bufs):
-            self.ctx.upload_wait()
-            self.in_flight = 0
-        buf = self.bufs[self.next]
-        self.next = (self.next + 1) % len(self.bufs)
-        np.copyto(buf, arr)
-        self.ctx.upload_async(slot, buf)
-        self.in_flight += 1
-
-    def settle(self):
-        """every staged frame has left its buffer (call once the results of the work that consumed them are back: free by then)"""
-        if self.in_flight:
-            self.ctx.upload_wait()
-            self.in_flight = 0
-
-
-def stager_of(ctx, shape):
-    table = ctx.__dict__.setdefault("_stagers", {})
-    st = table.get(tuple(shape))
-    if st is None:
-        st = table[tuple(shape)] = Stager(ctx, shape)
-    return st
-
-
-def settle_frames(ctx, shape):
-    """the staged frames of this size have left their pinned buffers (no-op when none were staged)"""
-    st = ctx.__dict__.get("_stagers", {}).get(tuple(shape))
-    if st is not None:
-        st.settle()
-
-
-def send_frame(ctx, slot, arr):
-    """frame -> slot: u8 frames through the pinned ring (asynchronous), anything else with the synchronous upload"""
-    if arr.dtype == np.uint8 and arr.ndim == 2:
-        stager_of(ctx, arr.shape).put(slot, arr)
-    else:
-        ctx.upload(slot, arr)
+def settle_frames(ctx):
+    """the results of the work that consumed the staged frames are back: every upload issued so far has left its buffer (the tracker
+    / selection waited for the builds, which waited for the copies)"""
+    ctx.__dict__["_uploads_done"] = ctx.__dict__.get("_uploads_issued", 0)

@@ -79,6 +79,10 @@ class Context:
         self._params_key = key
         self.params = p
 
+    def configured_for(self, tc):
+        """True when configure(tc) would change nothing that voids resident pyramids"""
+        return bytes(params_from_tc(tc)) == self._params_key
+
     def configure(self, tc):
         self.set_params(params_from_tc(tc))
         self.set_affine_params(affine_params_from_tc(tc))
@@ -216,6 +220,12 @@ class Context:
     def frame_resident(self, slot):
         """True while the slot holds a frame (raw pixels on the device)."""
         return bool(self._check(self._lib.klt_slot_state(self._h, slot)) & 1)
+
+    def slot_generation(self, slot):
+        """Number of the build that filled the slot's pyramids (travels with swap_slots); 0 without valid pyramids."""
+        g = C.c_uint64()
+        self._check(self._lib.klt_slot_generation(self._h, slot, C.byref(g)))
+        return g.value
 
     def swap_slots(self, a, b):
         self._check(self._lib.klt_swap_slots(self._h, a, b))

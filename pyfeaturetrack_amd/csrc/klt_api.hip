@@ -1069,6 +1069,13 @@ int klt_slot_state(klt_ctx *c, int slot)
     return (s.raw_kind != 0 ? 1 : 0) | (s.pyr_valid ? 2 : 0);
 }
 
+int klt_slot_generation(klt_ctx *c, int slot, uint64_t *gen)
+{
+    if (!c || !gen) return KLT_ERR_ARG;
+    *gen = (slot >= 0 && (size_t)slot < c->slots.size() && c->slots[slot].pyr_valid) ? c->slots[slot].gen : 0;
+    return KLT_OK;
+}
+
 int klt_slot_free(klt_ctx *c, int slot)
 {
     if (!c) return KLT_ERR_ARG;
@@ -2280,6 +2287,118 @@ int klt_download_sorted_candidates(klt_ctx *c, float *val, int32_t *x, int32_t *
         y[k] = (int32_t)(h[k] & 0xffffull);
     }
     if (n_valid) *n_valid = k;
+    return KLT_OK;
+}
+
+// ------------------------------------------------------------------------- the reference's literal native boundary
+// (setup.py:8-9: the Cython `def` functions of goodFeaturesUtils / trackFeaturesUtils; host arrays in and out, synchronous)
+int klt_scan_good_features_f32(klt_ctx *c, const float *gradx, const float *grady, int ncols, int nrows, int borderx, int bordery,
+                               int window_hw, int window_hh, int nSkippedPixels, float *val, int val_cap, int *nx_out, int *ny_out)
+{
+    if (!c || !gradx || !grady) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ncols <= 0 || nrows <= 0 || (long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    if (nSkippedPixels < 0 || window_hw < 0 || window_hh < 0) return fail(c, KLT_ERR_ARG, "bad window / skip");
+    // the reference reads cumSum[y - hh - 1][x - hw - 1] with bounds checks off (goodFeaturesUtils.pyx:3, :26): defined only from here on
+    if (borderx - window_hw - 1 < 0 || bordery - window_hh - 1 < 0)
+        return fail(c, KLT_ERR_ARG, "border must be at least window/2 + 1 (the reference reads outside the image otherwise)");
+    const int step = nSkippedPixels + 1;
+    const int nx = (ncols - borderx > borderx) ? (ncols - 2 * borderx + step - 1) / step : 0;
+    const int ny = (nrows - bordery > bordery) ? (nrows - 2 * bordery + step - 1) / step : 0;
+    if (nx_out) *nx_out = nx;
+    if (ny_out) *ny_out = ny;
+    const long long ncand = (long long)nx * ny;
+    if (ncand == 0) return KLT_OK;
+    if (!val || val_cap < ncand) return fail(c, KLT_ERR_ARG, "val holds fewer than nx * ny floats");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)ncols * nrows;
+    long long npow2 = 2048;
+    while (npow2 < ncand) npow2 <<= 1;
+    // gradx / grady interleaved, as the table kernels read a slot's planes
+    std::vector<float> inter(2 * N);
+    for (size_t i = 0; i < N; i++) { inter[2 * i] = gradx[i]; inter[2 * i + 1] = grady[i]; }
+    float *d = nullptr;                         // [2N] gradients | [3N] tables | [ncand] eigenvalues
+    unsigned long long *keys = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, (5 * N + (size_t)ncand) * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&keys, (size_t)npow2 * sizeof(unsigned long long));
+    int rc = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(d, inter.data(), 2 * N * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        c->work = c->stream;
+        rc = enqueue_sat(c, c->stream, d, d + 1, d + 2 * N, ncols, nrows);
+    }
+    if (e == hipSuccess && rc == 0) {
+        SelectArgs sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.sat = d + 2 * N; sa.valmap = d + 5 * N; sa.keys = keys;
+        sa.min_eig = 1.0;
+        sa.ncols = ncols; sa.nrows = nrows; sa.bx = borderx; sa.by = bordery; sa.step = step; sa.nx = nx; sa.ny = ny;
+        sa.hw = window_hw; sa.hh = window_hh; sa.npow2 = (int)npow2;
+        launch_eigen(c->stream, sa);
+        e = hipMemcpyAsync(val, d + 5 * N, (size_t)ncand * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    hipFree(keys);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, KLT_ERR_DEVICE, hipGetErrorString(e));
+    return KLT_OK;
+}
+
+int klt_extract_patch_f32(klt_ctx *c, const float *img, int ncols, int nrows, float x, float y, int width, int height, float *patch)
+{
+    if (!c || !img || !patch) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ncols <= 0 || nrows <= 0 || (long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    // trackFeaturesUtils.pyx:38-49 swaps the roles of rows and columns: only square patches are defined behaviour there
+    if (width != height || width < 1 || width > 31) return fail(c, KLT_ERR_ARG, "square patches of side 1..31 only");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)ncols * nrows, n = (size_t)width * width;
+    float *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, (N + n + 1) * sizeof(float)));
+    int bad = 0;
+    hipError_t e = hipMemcpyAsync(d, img, N * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_extract_patch(c->stream, d, ncols, nrows, x, y, width, d + N, (int *)(d + N + n));
+        e = hipMemcpyAsync(patch, d + N, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d + N + n, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KLT_ERR_DEVICE, hipGetErrorString(e));
+    if (bad) return fail(c, KLT_ERR_ARG, "patch footprint leaves the image (the reference asserts: trackFeaturesUtils.pyx:35)");
+    return KLT_OK;
+}
+
+int klt_track_iterate_f32(klt_ctx *c, float x2, float y2, const float *gradx_patch, const float *grady_patch, const float *img_patch,
+                          int width, int height, const float *img2, const float *gradx2, const float *grady2, int ncols, int nrows,
+                          float step_factor, float min_determinant, float min_displacement, int max_iterations,
+                          float *x2_out, float *y2_out, int *status, int *iterations)
+{
+    if (!c || !gradx_patch || !grady_patch || !img_patch || !img2 || !gradx2 || !grady2) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ncols <= 0 || nrows <= 0 || (long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    // _computeGradientSum strides the jacobian by shape[0] (trackFeaturesUtils.pyx:128): square windows only
+    if (width != height || width < 1 || width > 31) return fail(c, KLT_ERR_ARG, "square windows of side 1..31 only");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)ncols * nrows, n = (size_t)width * width;
+    float *d = nullptr;                         // three planes | three patches | result
+    HIPCHK(c, hipMalloc((void **)&d, (3 * N + 3 * n + 4) * sizeof(float)));
+    float res[4] = {0, 0, 0, 0};
+    const float *src[6] = {img2, gradx2, grady2, gradx_patch, grady_patch, img_patch};
+    const size_t off[6] = {0, N, 2 * N, 3 * N, 3 * N + n, 3 * N + 2 * n}, len[6] = {N, N, N, n, n, n};
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 6 && e == hipSuccess; k++)
+        e = hipMemcpyAsync(d + off[k], src[k], len[k] * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_track_iterate(c->stream, d + off[3], d + off[4], d + off[5], d, d + N, d + 2 * N, ncols, nrows, width, x2, y2, step_factor,
+                             min_determinant, min_displacement, max_iterations, d + 3 * N + 3 * n);
+        e = hipMemcpyAsync(res, d + 3 * N + 3 * n, sizeof(res), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KLT_ERR_DEVICE, hipGetErrorString(e));
+    if (x2_out) *x2_out = res[0];
+    if (y2_out) *y2_out = res[1];
+    if (status) *status = (int)res[2];
+    if (iterations) *iterations = (int)res[3];
     return KLT_OK;
 }
 

@@ -229,6 +229,10 @@ void launch_unpack_candidates(hipStream_t s, const unsigned long long *keys, int
 
 void launch_track_stats(hipStream_t s, const klt_feat *in, const klt_feat *out, int n, int nlevels, unsigned long long *stats);
 int launch_track(hipStream_t s, const TrackArgs &a);
+void launch_extract_patch(hipStream_t s, const float *img, int nc, int nr, float x, float y, int w, float *patch, int *bad);
+void launch_track_iterate(hipStream_t s, const float *t_gx, const float *t_gy, const float *t_i, const float *i2, const float *gx2,
+                          const float *gy2, int nc, int nr, int w, float x2, float y2, float step, float small, float th,
+                          int max_iterations, float *res);
 void launch_affine(hipStream_t s, const AffineArgs &a);
 void launch_affine_reset(hipStream_t s, klt_affine_rec *rec, int n);   // returns 0, or -1 for an unsupported window
 

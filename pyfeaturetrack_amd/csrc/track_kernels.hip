@@ -769,6 +769,101 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The reference's literal native boundary (setup.py:8-9), one call = one wavefront -- what the compat modules trackFeaturesUtils
+// bind (pyfeaturetrack_amd/compat).  Separate (not interleaved) planes: the caller's own arrays.
+namespace {
+
+// extractImagePatchSlow, trackFeaturesUtils.pyx:14-51: w x w bilinear samples around (x, y); out[0] = 1 when the footprint leaves
+// the image (the reference asserts, :35)
+__global__ __launch_bounds__(64) void extract_patch_kernel(const float *__restrict__ img, int nc, int nr, float x, float y, int w,
+                                                           float *__restrict__ patch, int *__restrict__ bad)
+{
+    const int hw = w / 2, n = w * w;
+    const Bilinear b = make_bilinear(x, y);
+    if (!(b.ix - hw >= 0 && b.iy - hw >= 0 && b.ix + hw + 2 <= nc && b.iy + hw + 2 <= nr)) {
+        if (threadIdx.x == 0) *bad = 1;
+        return;
+    }
+    if (threadIdx.x == 0) *bad = 0;
+    for (int k = threadIdx.x; k < n; k += 64) {
+        const size_t q = (size_t)(b.iy - hw + k / w) * nc + (b.ix - hw + k % w);
+        patch[k] = sample(img + q, nc, b);
+    }
+}
+
+// trackFeatureIterateCKLT, trackFeaturesUtils.pyx:393-459, on template patches the caller extracted: the Newton loop of track_level
+// (same operations in the same order) without the template sampling, the post-loop tests and the status priority, which belong to
+// _trackFeature (trackFeatures.py:67-136).  res = {x2, y2, status, iterations}
+__global__ __launch_bounds__(64) void track_iterate_kernel(const float *__restrict__ t_gx, const float *__restrict__ t_gy,
+                                                           const float *__restrict__ t_i, const float *__restrict__ i2,
+                                                           const float *__restrict__ gx2, const float *__restrict__ gy2, int nc, int nr,
+                                                           int w, float x2, float y2, float step, float small, float th,
+                                                           int max_iterations, float *__restrict__ res)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x, n = w * w, hw = w / 2, npad = (n + 3) & ~3;
+    int iters = 0, status;
+    const float one_plus_eps = 1.001f;
+    for (;;) {
+        if ((double)(x2 - (float)hw) < 0. || (float)nc - (x2 + (float)hw) < one_plus_eps ||
+            (double)(y2 - (float)hw) < 0. || (float)nr - (y2 + (float)hw) < one_plus_eps) {       // :428-431
+            status = KLT_OOB;
+            break;
+        }
+        const Bilinear b2 = make_bilinear(x2, y2);
+        const size_t base = (size_t)(b2.iy - hw) * nc + (b2.ix - hw);
+        for (int k = lane; k < n; k += 64) {
+            const size_t q = base + (size_t)(k / w) * nc + (k % w);
+            const float diff = t_i[k] - sample(i2 + q, nc, b2);
+            const float sx = t_gx[k] + sample(gx2 + q, nc, b2);
+            const float sy = t_gy[k] + sample(gy2 + q, nc, b2);
+            lds[k] = sx * sx;
+            lds[npad + k] = sx * sy;
+            lds[2 * npad + k] = sy * sy;
+            lds[3 * npad + k] = diff * sx;
+            lds[4 * npad + k] = diff * sy;
+        }
+        __syncthreads();
+        float acc = 0.f;
+        if (lane < 5) {
+            const float *T = lds + lane * npad;
+            for (int k = 0; k < n; k++) acc = acc + T[k];
+        }
+        __syncthreads();
+        const float gxx = __shfl(acc, 0), gxy = __shfl(acc, 1), gyy = __shfl(acc, 2);
+        const float ex = __shfl(acc, 3) * step, ey = __shfl(acc, 4) * step;
+        const float p1 = gxx * gyy, p2 = gxy * gxy;
+        const float det = p1 - p2;
+        if (det < small) { status = KLT_SMALL_DET; break; }
+        const float n1 = gyy * ex, n2 = gxy * ey, n3 = gxx * ey, n4 = gxy * ex;
+        const float dx = (n1 - n2) / det;
+        const float dy = (n3 - n4) / det;
+        status = KLT_TRACKED;
+        x2 = x2 + dx;
+        y2 = y2 + dy;
+        iters++;
+        if (!((fabsf(dx) >= th || fabsf(dy) >= th) && iters < max_iterations)) break;
+    }
+    if (lane == 0) { res[0] = x2; res[1] = y2; res[2] = (float)status; res[3] = (float)iters; }
+}
+
+}  // namespace
+
+void launch_extract_patch(hipStream_t s, const float *img, int nc, int nr, float x, float y, int w, float *patch, int *bad)
+{
+    hipLaunchKernelGGL(extract_patch_kernel, dim3(1), dim3(64), 0, s, img, nc, nr, x, y, w, patch, bad);
+}
+
+void launch_track_iterate(hipStream_t s, const float *t_gx, const float *t_gy, const float *t_i, const float *i2, const float *gx2,
+                          const float *gy2, int nc, int nr, int w, float x2, float y2, float step, float small, float th,
+                          int max_iterations, float *res)
+{
+    const size_t lds = 5 * (size_t)((w * w + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL(track_iterate_kernel, dim3(1), dim3(64), (unsigned)lds, s, t_gx, t_gy, t_i, i2, gx2, gy2, nc, nr, w, x2, y2, step,
+                       small, th, max_iterations, res);
+}
+
 int launch_track(hipStream_t s, const TrackArgs &a)
 {
     if (a.n <= 0) return 0;

@@ -8,7 +8,9 @@ numeric state lives in a `klt_params` POD (include/klt_gpu.h) pushed across the 
 from __future__ import print_function
 
 import math
+import os as _os
 import time
+from itertools import repeat as _repeat
 
 import numpy as np
 
@@ -239,8 +241,13 @@ class KLT_FeatureList(list):
     range(nFeatures)]`, selectGoodFeatures.py:143; its own KLT_FeatureList is commented out, klt.py:266-270).  It IS a list of
     KLT_Feature objects -- but the 5000 Python objects of a cfg-2 list cost 1.1 ms to create, four times what the device needs to
     select the features, and a tracking loop that only hands the list from one KLT* call to the next never looks at one of them.
-    The objects are therefore made when somebody first touches an element (indexing, iteration, any list method); `len()`,
-    truth value and the KLT* calls themselves work on the column store and do not."""
+    In the LAZY mode (opt-in: `klt.LAZY_FEATURE_LISTS = True`, or KLT_LAZY_FEATURE_LISTS=1 in the environment) the objects are
+    therefore made when somebody first touches an element (indexing, iteration, any list method); `len()`, truth value and the KLT*
+    calls themselves work on the column store and do not.  The price of that mode: C code that reads the list's storage directly
+    (`PySequence_Fast` users such as slice assignment `a[0:0] = fl`, numpy's array constructor, Cython functions with list-typed
+    arguments) sees an empty list until something has touched it.  By DEFAULT the list is therefore filled when it is created -- a
+    plain, complete list of KLT_Feature objects as the reference hands out -- and only the column store behind the objects remains
+    (the KLT* calls still move whole columns)."""
 
     __slots__ = ("_store", "_pending")
 
@@ -254,11 +261,17 @@ class KLT_FeatureList(list):
         if n:
             self._pending = 0
             store = self._store
-            list.extend(self, [KLT_Feature(store, i) for i in range(n)])
+            list.extend(self, map(KLT_Feature, _repeat(store, n), range(n)))
             store.features = list(self)         # a private copy: the caller's list may be edited
 
     def __len__(self):
         return self._pending or list.__len__(self)
+
+    def __radd__(self, other):
+        # `[] + fl`, `sum([fl1, fl2], [])`: list.__add__ reads the right operand's storage directly, so the reflected method (tried
+        # first for a subclass on the right) fills the list before anything is concatenated
+        self._fill()
+        return list(other) + list(self)
 
     def __reduce_ex__(self, protocol):
         self._fill()
@@ -283,9 +296,15 @@ for _name in ("__getitem__", "__setitem__", "__delitem__", "__iter__", "__revers
 KLT_FeatureList.__hash__ = None
 
 
+LAZY_FEATURE_LISTS = _os.environ.get("KLT_LAZY_FEATURE_LISTS") == "1"
+
+
 def new_feature_list(n):
     """n lost features sharing one column store (what KLTSelectGoodFeatures / KLTCreateFeatureList hand out)."""
-    return KLT_FeatureList(_FeatureStore(n))
+    fl = KLT_FeatureList(_FeatureStore(n))
+    if not LAZY_FEATURE_LISTS:
+        fl._fill()
+    return fl
 
 
 def shared_store(featurelist):

@@ -86,12 +86,14 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
     if tc.mindist < 0:
         KLTWarning("(_KLTSelectGoodFeatures) Tracking context field tc.mindist is negative ({0}); setting to zero".format(tc.mindist))
         tc.mindist = 0
+    from ._frames import FrameKey, cache_of, settle_frames
     ctx = default_context()
+    if cache_of(tc).handles and not ctx.configured_for(tc):
+        cache_of(tc).keep_all_handles()               # new parameters void every pyramid of the context: kept handles fetch theirs first
     ctx.configure(tc)
     slots = _slots_of(tc)
     if featurelist is None:
         featurelist = new_feature_list(nFeatures)
-    from ._frames import FrameKey, cache_of, send_frame, settle_frames
     reuse = (mode == selectionMode.REPLACING_SOME and tc.sequentialMode and tc.pyramid_last is not None
              and ctx.pyramids_valid(slots[0]))
     if reuse:
@@ -103,13 +105,13 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
         # sequential mode keeps the last frame in slot 1) and gets its whole pyramid, which that call then does not build.
         frames = cache_of(tc)
         key = FrameKey(img)
-        slot = frames.find(img, key, slots[:2], ctx)
+        slot = frames.find(key, slots[:2], ctx)
         if slot is None:
             slot = slots[1] if (tc.sequentialMode and tc.pyramid_last is not None) else slots[0]
-            send_frame(ctx, slot, image_to_array(img))
-            frames.note(slot, key)
+            frames.send(ctx, slot, key)
             ctx.build_pyramids(slot, sync=False)
         elif not ctx.pyramids_valid(slot):
+            frames.keep_handles(ctx, slot)
             ctx.build_pyramids(slot, sync=False)
         reuse = True
     else:
@@ -125,7 +127,7 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
     finally:
         if aff is not None:
             ctx.set_option(4, -1)
-    settle_frames(ctx, _image_size(img)[::-1])
+    settle_frames(ctx)
     affine_used = aff is not None or tc.affineConsistencyCheck >= 0     # otherwise the affine fields were never assigned
     vals = fl["val"]
     olds = fl_in["val"] if mode == selectionMode.REPLACING_SOME else None

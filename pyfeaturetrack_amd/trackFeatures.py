@@ -10,21 +10,81 @@ from __future__ import print_function
 from . import selectGoodFeatures as _sgf
 from .backend import default_context
 from .klt import KLTCountRemainingFeatures, kltState, shared_store  # noqa: F401
-from ._frames import FrameKey, KLTForgetFrames, cache_of, send_frame, settle_frames  # noqa: F401
+from ._frames import FrameKey, KLTForgetFrames, cache_of, settle_frames  # noqa: F401
 from .selectGoodFeatures import _fix_window, _image_size, _slots_of, features_to_array, image_to_array
 # the reference binds the name at import (trackFeatures.py:7 `from selectGoodFeatures import KLT_verbose`): this module has its own
 # switch, and setting selectGoodFeatures.KLT_verbose later does not reach it
 from .selectGoodFeatures import KLT_verbose  # noqa: E402
 
 
+class _Levels:
+    """`pyramid.img` of a device-resident pyramid: a sequence of the levels' float32 planes, each downloaded when first looked at."""
+
+    def __init__(self, owner):
+        self._owner, self._planes = owner, [None] * owner.nLevels
+
+    def __len__(self):
+        return len(self._planes)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self._planes)))]
+        if self._planes[i] is None:
+            self._owner._fetch(range(len(self._planes))[i])
+        return self._planes[i]
+
+    def __setitem__(self, i, plane):
+        self._planes[i] = plane
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self._planes)))
+
+
 class _ResidentPyramids:
-    """What tc.pyramid_last* point at in sequential mode: pyramids living in a device slot."""
-    def __init__(self, slot, ncols, nrows, which):
-        self.slot, self.which = slot, which
-        self.ncols, self.nrows = [ncols], [nrows]
+    """A KLTPyramid (pyramid.py:15-35: subsampling, nLevels, ncols[], nrows[], img[]) whose planes live in a device slot -- what
+    ComputeImagePyramids returns and what tc.pyramid_last* point at in sequential mode.  `img[i]` downloads level i on first access;
+    before the API layer overwrites the slot (a new frame, a rebuild) it fetches the levels of every handle that is still alive, so
+    a handle somebody kept stays valid as the reference's pyramid objects do."""
+
+    def __init__(self, ctx, slots, gen, which, ncols, nrows, subsampling, nlevels):
+        self._ctx, self._slots, self._gen = ctx, tuple(slots), gen
+        self.which = which
+        self._plane = ("img", "gradx", "grady").index(which)
+        self.subsampling, self.nLevels = subsampling, nlevels
+        self.ncols, self.nrows = [], []
+        for _ in range(nlevels):                  # true division, as in the reference (pyramid.py:26-31: levels >= 1 hold floats)
+            self.ncols.append(ncols)
+            self.nrows.append(nrows)
+            ncols, nrows = ncols / subsampling, nrows / subsampling
+        self.img = _Levels(self)
+
+    def _slot(self):
+        for s in self._slots:
+            if self._ctx.slot_generation(s) == self._gen:
+                return s
+        from ._abi import KltBackendError
+        raise KltBackendError("the pyramid planes this handle stands for have been replaced on the device by a call outside the "
+                              "KLT* functions of this package (klt_build_pyramids on the tracking context's slot)")
+
+    def _fetch(self, level):
+        self.img[level] = self._ctx.download_level(self._slot(), self._plane, level)
+
+    def _materialise(self):
+        for level in range(self.nLevels):
+            if self.img._planes[level] is None:
+                self._fetch(level)
 
     def __repr__(self):
-        return "<device pyramid %s of slot %d, %dx%d>" % (self.which, self.slot, self.ncols[0], self.nrows[0])
+        return "<device pyramid %s, %dx%d, %d levels>" % (self.which, self.ncols[0], self.nrows[0], self.nLevels)
+
+
+def _pyramid_handles(tc, ctx, slot, ncols, nrows):
+    """(image, gradx, grady) handles of the pyramids in `slot`, registered with the tracking context's frame cache"""
+    gen = ctx.slot_generation(slot)
+    hs = tuple(_ResidentPyramids(ctx, _slots_of(tc), gen, which, ncols, nrows, int(tc.subsampling), tc.nPyramidLevels)
+               for which in ("img", "gradx", "grady"))
+    cache_of(tc).watch(hs)
+    return hs
 
 
 _DEVICE_TEMPLATE = "<template on device>"      # what feat.aff_img* hold while the device keeps the templates
@@ -80,16 +140,16 @@ def _outOfBounds(x, y, ncols, nrows, borderx, bordery):
     return x < borderx or x > ncols - 1 - borderx or y < bordery or y > nrows - 1 - bordery
 
 
-def KLTTrackFeatures(tc, img1, img2, featurelist):
-    """trackFeatures.py:205-409 (translation model; the affine branch :347-399 calls functions the
-    reference never defines)."""
+def _prepare_pair(tc, img1, img2):
+    """ComputeImagePyramids (trackFeatures.py:146-196) on the device: both frames in their slots with valid pyramids.
+    Returns (ctx, slot1, slot2, ncols, nrows)."""
     ncols, nrows = _image_size(img1)
     assert _image_size(img2) == (ncols, nrows)
-    if KLT_verbose >= 1:
-        print("(KLT) Tracking {0} features in a {1} by {2} image...  ".format(
-            KLTCountRemainingFeatures(featurelist), ncols, nrows))
     _fix_window(tc)
     ctx = default_context()
+    frames = cache_of(tc)
+    if frames.handles and not ctx.configured_for(tc):
+        frames.keep_all_handles()                     # new parameters void every pyramid of the context: kept handles fetch theirs first
     ctx.configure(tc)
     s1, s2, _ = _slots_of(tc)
     resident = tc.sequentialMode and tc.pyramid_last is not None
@@ -102,35 +162,68 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
             from .error import KLTError
             KLTError("(KLTTrackFeatures) Size of incoming image ({0} by {1}) is different from size of previous image "
                      "({2} by {3})".format(ncols, nrows, tc.pyramid_last.ncols[0], tc.pyramid_last.nrows[0]))
-        frames = cache_of(tc)
         k2 = FrameKey(img2)
-        if frames.find(img2, k2, (s2,), ctx) is None:
-            send_frame(ctx, s2, image_to_array(img2))
-            frames.note(s2, k2)
+        if frames.find(k2, (s2,), ctx) is None:
+            frames.send(ctx, s2, k2)
             ctx.build_pyramids(s2, sync=False)
         elif not ctx.pyramids_valid(s2):
+            frames.keep_handles(ctx, s2)
             ctx.build_pyramids(s2, sync=False)
     else:
-        # A slot that already holds one of the two images (same object, size and sampled content -- _frames.py) keeps it: the
+        # A slot that already holds exactly the pixels of one of the two images (every byte compared -- _frames.py) keeps it: the
         # reference converts and rebuilds both on every call, example1's ping-pong (example1.py:53-56) the same two 200 times.
-        frames = cache_of(tc)
         k1, k2 = FrameKey(img1), FrameKey(img2)
-        at1, at2 = frames.find(img1, k1, (s1, s2), ctx), frames.find(img2, k2, (s1, s2), ctx)
+        at1, at2 = frames.find(k1, (s1, s2), ctx), frames.find(k2, (s1, s2), ctx)
         if at1 == s2 or at2 == s1:                    # the pair arrives the other way round (or shifted by one frame)
             ctx.swap_slots(s1, s2)
             frames.swap(s1, s2)
             at1 = {s1: s2, s2: s1}.get(at1)
             at2 = {s1: s2, s2: s1}.get(at2)
         build = []
-        for slot, img, key, at in ((s1, img1, k1, at1), (s2, img2, k2, at2)):
+        for slot, key, at in ((s1, k1, at1), (s2, k2, at2)):
             if at != slot:
-                send_frame(ctx, slot, image_to_array(img))
-                frames.note(slot, key)
+                frames.send(ctx, slot, key)
                 build.append(slot)
             elif not ctx.pyramids_valid(slot):        # the frame is there, the pyramid geometry / taps changed since
+                frames.keep_handles(ctx, slot)
                 build.append(slot)
         if build:
             ctx.build_pyramids_batch(build)           # frames share every kernel launch
+    return ctx, s1, s2, ncols, nrows
+
+
+def ComputeImagePyramids(tc, img1, img2):
+    """trackFeatures.py:146-196: (pyramid1, pyramid1_gradx, pyramid1_grady, pyramid2, pyramid2_gradx, pyramid2_grady) of the two
+    images -- smoothed with sigma = smooth_sigma_fact * max(w, h), reduced nPyramidLevels - 1 times, differentiated per level.  In
+    sequential mode with pyramids kept from the last KLTTrackFeatures call the first three are tc.pyramid_last* and img1 is not looked
+    at (:152-161).  The pyramids are built and stay on the device (one launch sequence for both images); the objects returned have the
+    reference's KLTPyramid attributes, and `pyramid.img[level]` is the float32 plane, downloaded when first looked at."""
+    ctx, s1, s2, ncols, nrows = _prepare_pair(tc, img1, img2)
+    settle_frames(ctx)
+    if tc.sequentialMode and tc.pyramid_last is not None and getattr(tc.pyramid_last, "_gen", None) == ctx.slot_generation(s1):
+        first = (tc.pyramid_last, tc.pyramid_last_gradx, tc.pyramid_last_grady)
+    else:
+        first = _pyramid_handles(tc, ctx, s1, ncols, nrows)
+    if tc.writeInternalImages:
+        from .klt_util import KLTWriteFloatImageToPGM
+        second = _pyramid_handles(tc, ctx, s2, ncols, nrows)
+        for i in range(tc.nPyramidLevels):                   # trackFeatures.py:186-194
+            for tag, (p, gx, gy) in (("i", first), ("j", second)):
+                KLTWriteFloatImageToPGM(p.img[i], "kltimg_tf_{0}{1}.pgm".format(tag, i))
+                KLTWriteFloatImageToPGM(gx.img[i], "kltimg_tf_{0}{1}_gx.pgm".format(tag, i))
+                KLTWriteFloatImageToPGM(gy.img[i], "kltimg_tf_{0}{1}_gy.pgm".format(tag, i))
+        return first + second
+    return first + _pyramid_handles(tc, ctx, s2, ncols, nrows)
+
+
+def KLTTrackFeatures(tc, img1, img2, featurelist):
+    """trackFeatures.py:205-409 (translation model; the affine branch :347-399 calls functions the
+    reference never defines)."""
+    if KLT_verbose >= 1:
+        ncols, nrows = _image_size(img1)
+        print("(KLT) Tracking {0} features in a {1} by {2} image...  ".format(
+            KLTCountRemainingFeatures(featurelist), ncols, nrows))
+    ctx, s1, s2, ncols, nrows = _prepare_pair(tc, img1, img2)
 
     nfeat = len(featurelist)
     fl_in = features_to_array(featurelist, ctx.host_records(nfeat)[0])      # pinned: goes up without a staging copy
@@ -192,13 +285,11 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
                 feat.val = vals[i]
                 feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = None
 
-    settle_frames(ctx, (nrows, ncols))                # (the results are back: the staged frames left their buffers long ago)
+    settle_frames(ctx)                # (the results are back: the staged frames left their buffers long ago)
     if tc.sequentialMode:
         ctx.swap_slots(s1, s2)                        # frame-2 pyramids become frame 1 (:401-404)
         cache_of(tc).swap(s1, s2)
-        tc.pyramid_last = _ResidentPyramids(s1, ncols, nrows, "img")
-        tc.pyramid_last_gradx = _ResidentPyramids(s1, ncols, nrows, "gradx")
-        tc.pyramid_last_grady = _ResidentPyramids(s1, ncols, nrows, "grady")
+        tc.pyramid_last, tc.pyramid_last_gradx, tc.pyramid_last_grady = _pyramid_handles(tc, ctx, s1, ncols, nrows)
 
     if KLT_verbose >= 1:
         print("\n\t{0} features successfully tracked.".format(KLTCountRemainingFeatures(featurelist)))

@@ -93,9 +93,10 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
     frames = iter(frames)
     _fix_window(tc)
     ctx = default_context()
+    from ._frames import cache_of
+    cache_of(tc).keep_all_handles()     # pyramid handles somebody kept (ComputeImagePyramids, tc.pyramid_last) fetch their planes first
     ctx.configure(tc)
     s = list(_slots_of(tc))              # ring of three frame slots (the third is otherwise the per-frame API's selection slot)
-    from ._frames import cache_of
     cache_of(tc).forget()               # this call fills the slots itself: what the per-frame API remembers of them is void
     ring = 3 if prefetch else 2
     first = image_to_array(next(frames))
@@ -230,11 +231,9 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
     ft.rec["aux"] = 0
     if tc.sequentialMode:
         # leave the context as the per-frame API would: the last frame's pyramids are "frame 1" of the next call
-        from .trackFeatures import _ResidentPyramids
+        from .trackFeatures import _pyramid_handles
         last = s[(nframes - 1) % ring]
         if last != s[0]:
             ctx.swap_slots(s[0], last)
-        tc.pyramid_last = _ResidentPyramids(s[0], ncols, nrows, "img")
-        tc.pyramid_last_gradx = _ResidentPyramids(s[0], ncols, nrows, "gradx")
-        tc.pyramid_last_grady = _ResidentPyramids(s[0], ncols, nrows, "grady")
+        tc.pyramid_last, tc.pyramid_last_gradx, tc.pyramid_last_grady = _pyramid_handles(tc, ctx, s[0], ncols, nrows)
     return ft

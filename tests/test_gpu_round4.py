@@ -1,0 +1,364 @@
+"""Round-4 GPU checks: the exact frame cache of the reference-shaped API, ComputeImagePyramids and its device-resident pyramid
+handles, the reference's literal native boundary (compat goodFeaturesUtils / trackFeaturesUtils) and INTEGRATION.md's stub."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from helpers import make_tc
+from pyfeaturetrack_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _api_modules():
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import trackFeatures as trk
+    sgf.KLT_verbose = trk.KLT_verbose = 0
+    return sgf, trk
+
+
+def _records(fl):
+    return [(f.x, f.y, f.val) for f in fl]
+
+
+def _level0_launches(ctx):
+    return {k["name"]: k["launches"] for k in ctx.timing_read()}.get("smooth_grad_l0", 0)
+
+
+# ------------------------------------------------------------------------------------------------ frame cache: exact by default
+@pytest.mark.parametrize("kind", ["numpy", "pil"])
+def test_in_place_edits_of_any_size_are_seen(kind):
+    """the reference converts and rebuilds both images on every call (trackFeatures.py:163-176).  The frame cache
+    may skip that only for an image with exactly the pixels a slot holds: ONE pixel rewritten in place off the old 32 x 32 lattice,
+    and a 32 x 59 block between lattice samples, both give the lists of a run that forgets everything before every call -- for
+    numpy frames and Pillow images.  (1080p: lattice rows are multiples of 33, lattice columns multiples of 60.)"""
+    from pyfeaturetrack_amd.backend import default_context
+    sgf, trk = _api_modules()
+    if kind == "pil":
+        Image = pytest.importorskip("PIL.Image")
+    try:
+        W, H, n = 1920, 1080, 1500
+        base = synth.synth_base(W, H, 3)
+        f0, f1 = (synth.synth_frame(W, H, 3, k, shift=(2.3, -1.4), base=base) for k in range(2))
+
+        def wrap(a):
+            return Image.fromarray(a.copy()) if kind == "pil" else a.copy()
+
+        def edit_pixel(img, x, y):
+            if kind == "pil":
+                img.putpixel((x, y), 255 - img.getpixel((x, y)))
+            else:
+                img[y, x] = 255 - img[y, x]
+
+        def edit_block(img, x, y, w, h):
+            if kind == "pil":
+                img.paste(7, (x, y, x + w, y + h))
+            else:
+                img[y:y + h, x:x + w] = 7
+
+        def run(forget):
+            tc = make_tc(levels=3, ss=4, max_residue=10.0)
+            a, b = wrap(f0), wrap(f1)
+            out = []
+            fl = sgf.KLTSelectGoodFeatures(tc, a, n)
+            trk.KLTTrackFeatures(tc, a, b, fl)
+            out.append(_records(fl))
+            # a feature that survived: the edits go under its 7 x 7 window in frame 2, at off-lattice coordinates
+            live = [f for f in fl if f.val >= 0 and int(f.x) % 60 not in (0, 59, 58, 57) and int(f.y) % 33 not in (0, 32, 31, 30)]
+            cx, cy = int(live[0].x), int(live[0].y)
+            assert cx % 60 != 0 and cy % 33 != 0
+            steps = [lambda: edit_pixel(b, cx, cy),
+                     lambda: edit_block(b, 61 + 60 * (cx // 60 % 20), 34 + 33 * (cy // 33 % 20), 59, 32),
+                     lambda: edit_pixel(a, cx + 1, cy)]
+            for step in steps:
+                step()
+                if forget:
+                    trk.KLTForgetFrames(tc)
+                fl = sgf.KLTSelectGoodFeatures(tc, a, n)
+                if forget:
+                    trk.KLTForgetFrames(tc)
+                trk.KLTTrackFeatures(tc, a, b, fl)
+                out.append(_records(fl))
+            return out
+
+        want = run(forget=True)
+        ctx = default_context()
+        ctx.timing_enable(1)
+        got = run(forget=False)
+        builds = _level0_launches(ctx)
+        ctx.timing_enable(0)
+        assert got == want
+        assert got[1] != got[0], "the one-pixel edit under a feature window changed nothing: the test does not probe the cache"
+        # frame 1 (for the selection), frame 2 (for the tracker), then one rebuild per edit -- only the edited image each time
+        assert builds == 5, builds
+    finally:
+        sgf.KLT_verbose = trk.KLT_verbose = 1
+
+
+def test_the_trusting_mode_is_opt_in_and_blind_between_lattice_samples():
+    """tc.trustFrameIdentity = True is the documented shortcut: object identity + the 1024-pixel lattice.  It does
+    NOT see an off-lattice edit -- which is why it is not the default -- and KLTForgetFrames makes it look again."""
+    from pyfeaturetrack_amd.backend import default_context
+    sgf, trk = _api_modules()
+    try:
+        W, H, n = 1920, 1080, 600
+        base = synth.synth_base(W, H, 5)
+        a, b = (synth.synth_frame(W, H, 5, k, shift=(1.2, 0.9), base=base) for k in range(2))
+        tc = make_tc(levels=3, ss=4)
+        tc.trustFrameIdentity = True
+        fl = sgf.KLTSelectGoodFeatures(tc, a, n)
+        trk.KLTTrackFeatures(tc, a, b, fl)
+        ctx = default_context()
+        ctx.timing_enable(1)
+        b[100:132, 61:120] = 9
+        fl2 = sgf.KLTSelectGoodFeatures(tc, a, n)
+        trk.KLTTrackFeatures(tc, a, b, fl2)
+        assert _level0_launches(ctx) == 0 and _records(fl2) == _records(fl)          # the stale pyramid: the deviation
+        trk.KLTForgetFrames(tc)
+        trk.KLTTrackFeatures(tc, a, b, sgf.KLTSelectGoodFeatures(tc, a, n))
+        assert _level0_launches(ctx) == 2                                            # both frames again
+        ctx.timing_enable(0)
+    finally:
+        sgf.KLT_verbose = trk.KLT_verbose = 1
+
+
+def test_frame_cache_on_random_call_sequences_with_arbitrary_edits():
+    """Random sequences of KLTSelectGoodFeatures / KLTTrackFeatures / KLTReplaceLostFeatures / ComputeImagePyramids over a pool of five
+    frames, edited in place between calls by rectangles of ANY size and position (down to one pixel), with and without sequential
+    mode: a tracking context that remembers what its slots hold gives the same lists, call by call, as one that forgets before every
+    call (= the reference's behaviour of converting and rebuilding everything every time)."""
+    sgf, trk = _api_modules()
+    rng = np.random.default_rng(17)
+    try:
+        base = synth.synth_base(400, 300, 8)
+        pool = [synth.synth_frame(400, 300, 8, k, shift=(1.3, 0.9), base=base) for k in range(5)]
+        for trial in range(40):
+            seq_mode = bool(trial & 1)
+            frames_a = [f.copy() for f in pool]
+            frames_b = [f.copy() for f in pool]
+            tcs = []
+            for _ in range(2):
+                tc = make_tc(levels=2, ss=2, max_residue=12.0)
+                tc.sequentialMode = seq_mode
+                tcs.append(tc)
+            n = int(rng.integers(40, 200))
+            i0 = int(rng.integers(0, 5))
+            fls = [sgf.KLTSelectGoodFeatures(tcs[0], frames_a[i0], n)]
+            trk.KLTForgetFrames(tcs[1])
+            fls.append(sgf.KLTSelectGoodFeatures(tcs[1], frames_b[i0], n))
+            assert _records(fls[0]) == _records(fls[1])
+            cur = i0
+            for step in range(12):
+                op = rng.choice(["track", "track", "track", "replace", "select", "edit", "edit", "pyramids"])
+                if op == "edit":                               # same object, new pixels: any rectangle, often tiny
+                    k = int(rng.integers(0, 5))
+                    h, w = (1, 1) if rng.random() < 0.4 else (int(rng.integers(1, 40)), int(rng.integers(1, 70)))
+                    y, x = int(rng.integers(0, 300 - h)), int(rng.integers(0, 400 - w))
+                    val = int(rng.integers(0, 255))
+                    for fr in (frames_a, frames_b):
+                        fr[k][y:y + h, x:x + w] = val
+                    continue
+                nxt = int(rng.integers(0, 5))
+                planes = []
+                for which, (tc, fr) in enumerate(zip(tcs, (frames_a, frames_b))):
+                    if which == 1:
+                        trk.KLTForgetFrames(tc)
+                    if op == "track":
+                        trk.KLTTrackFeatures(tc, fr[cur], fr[nxt], fls[which])
+                    elif op == "replace":
+                        sgf.KLTReplaceLostFeatures(tc, fr[cur], fls[which])
+                    elif op == "pyramids":
+                        pyr = trk.ComputeImagePyramids(tc, fr[cur], fr[nxt])
+                        planes.append([p.img[tc.nPyramidLevels - 1] for p in pyr])
+                    else:
+                        fls[which] = sgf.KLTSelectGoodFeatures(tc, fr[nxt], n)
+                if planes:
+                    assert all(np.array_equal(p, q) for p, q in zip(*planes)), "trial %d step %d pyramids" % (trial, step)
+                if op in ("track", "select"):
+                    cur = nxt
+                assert _records(fls[0]) == _records(fls[1]), "trial %d step %d (%s, sequential %s)" % (trial, step, op, seq_mode)
+    finally:
+        sgf.KLT_verbose = trk.KLT_verbose = 1
+
+
+# ------------------------------------------------------------------------------------------------ ComputeImagePyramids
+def test_compute_image_pyramids_gives_the_reference_planes(cfg1, img0, img1):
+    """trackFeatures.py:146-196 as a callable name (`from trackFeatures import *` exposes it): the six pyramids of img0 / img1 with the
+    reference's KLTPyramid attributes; every level of every pyramid equals the planes the reference produced (tests/golden/cfg1.npz,
+    written by gen_golden.py from the reference's own ComputeImagePyramids)."""
+    sgf, trk = _api_modules()
+    try:
+        tc = make_tc()
+        pyr = trk.ComputeImagePyramids(tc, img0, img1)
+        assert len(pyr) == 6
+        for p in pyr:
+            assert p.subsampling == 4 and p.nLevels == 2 and p.ncols == [320, 80.0] and p.nrows == [240, 60.0] and len(p.img) == 2
+        for which, frame in ((0, "p0"), (3, "p1")):
+            for k, name in enumerate(("img", "gx", "gy")):
+                for lvl in range(2):
+                    got = pyr[which + k].img[lvl]
+                    assert got.dtype == np.float32 and np.array_equal(got, cfg1["%s_%s_%d" % (frame, name, lvl)]), (frame, name, lvl)
+        # star-import name, like the reference's module
+        ns = {}
+        exec("from pyfeaturetrack_amd.trackFeatures import *", ns)
+        assert ns["ComputeImagePyramids"] is trk.ComputeImagePyramids
+    finally:
+        sgf.KLT_verbose = trk.KLT_verbose = 1
+
+
+def test_pyramid_handles_outlive_the_slot_and_follow_sequential_mode(cfg1, img0, img1):
+    """The handles download on access -- and a handle somebody kept is filled before its slot is overwritten (a new frame, new
+    parameters, a sequence call), so it stays valid like the reference's pyramid objects.  In sequential mode the first three pyramids
+    are tc.pyramid_last* and img1 is ignored (trackFeatures.py:152-161)."""
+    sgf, trk = _api_modules()
+    try:
+        tc = make_tc()
+        kept = trk.ComputeImagePyramids(tc, img0, img1)             # nothing downloaded yet
+        other = np.ascontiguousarray(img0[::-1])
+        fl = sgf.KLTSelectGoodFeatures(tc, other, 30)                # overwrites slot 1 (frame img0)
+        trk.KLTTrackFeatures(tc, other, np.ascontiguousarray(img1[::-1]), fl)   # ... and slot 2
+        assert np.array_equal(kept[0].img[1], cfg1["p0_img_1"]) and np.array_equal(kept[5].img[0], cfg1["p1_gy_0"])
+        kept2 = trk.ComputeImagePyramids(tc, img0, img1)
+        tc.nPyramidLevels = 3
+        tc.subsampling = 2
+        tc.KLTUpdateTCBorder()
+        p3 = trk.ComputeImagePyramids(tc, img0, img1)                # new geometry: every pyramid of the context is rebuilt
+        assert p3[0].nLevels == 3 and p3[0].img[2].shape == (60, 80)
+        assert np.array_equal(kept2[1].img[1], cfg1["p0_gx_1"]) and kept2[1].nLevels == 2
+
+        seq = make_tc()
+        seq.sequentialMode = True
+        fl = sgf.KLTSelectGoodFeatures(seq, img0, 50)
+        trk.KLTTrackFeatures(seq, img0, img1, fl)                    # pyramid_last := pyramids of img1
+        assert seq.pyramid_last.ncols[0] == 320 and np.array_equal(seq.pyramid_last_gradx.img[1], cfg1["p1_gx_1"])
+        junk = np.zeros_like(img0)
+        six = trk.ComputeImagePyramids(seq, junk, img0)              # img1 argument ignored: pyramid 1 is the kept one
+        assert six[0] is seq.pyramid_last and six[2] is seq.pyramid_last_grady
+        assert np.array_equal(six[0].img[0], cfg1["p1_img_0"]) and np.array_equal(six[3].img[1], cfg1["p0_img_1"])
+    finally:
+        sgf.KLT_verbose = trk.KLT_verbose = 1
+
+
+# ------------------------------------------------------------------------------------------------ the reference's literal native boundary
+def _compat(name):
+    """module `name` as a script written against the reference imports it: the compat directory on sys.path"""
+    import importlib
+    d = os.path.join(REPO, "pyfeaturetrack_amd", "compat")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    return importlib.import_module(name)
+
+
+def test_scan_image_for_good_features_is_the_reference_function(cfg1):
+    """goodFeaturesUtils.ScanImageForGoodFeatures (goodFeaturesUtils.pyx:35-73) under its own module and function name: the
+    eigenvalue of every candidate window of img0's gradient images equals the reference's list (tests/golden/cfg1.npz `sel_val`, written
+    by gen_golden.py from the reference's own call, with the Python floats 30.0 / 3.5 it passes for the borders and half-windows), the
+    coordinate lists are the reference's, and the elements have the reference's types."""
+    gfu = _compat("goodFeaturesUtils")
+    import pyfeaturetrack_amd.goodFeaturesUtils as real
+    assert gfu is real
+    px, py, pv = gfu.ScanImageForGoodFeatures(cfg1["sel_gx"], cfg1["sel_gy"], 30.0, 30.0, 3.5, 3.5, 0)
+    want = cfg1["sel_val"]
+    ny, nx = want.shape
+    assert len(px) == len(py) == len(pv) == nx * ny and isinstance(pv[0], float) and isinstance(px[0], np.int32)
+    assert np.array_equal(np.array(pv, np.float32).reshape(ny, nx), want)
+    assert np.array_equal(np.array(px).reshape(ny, nx), np.tile(np.arange(30, 290, dtype=np.int32), (ny, 1)))
+    assert np.array_equal(np.array(py).reshape(ny, nx), np.repeat(np.arange(30, 210, dtype=np.int32), nx).reshape(ny, nx))
+    # the sorted head the reference's selection walks (selectGoodFeatures.py:234-236) follows from these three lists alone
+    pl = sorted(zip(pv, px, py), reverse=True)[:2000]
+    assert np.array_equal(np.array([p[0] for p in pl], np.float32), cfg1["sel_sorted_val"][:2000])
+    assert np.array_equal(np.array([p[1] for p in pl]), cfg1["sel_sorted_x"][:2000])
+    # skipped pixels: every third candidate of the same map
+    px3, py3, pv3 = gfu.ScanImageForGoodFeatures(cfg1["sel_gx"], cfg1["sel_gy"], 30, 30, 3, 3, 2)
+    assert np.array_equal(np.array(pv3, np.float32).reshape(len(range(30, 210, 3)), -1), want[::3, ::3])
+    with pytest.raises(Exception):
+        gfu.ScanImageForGoodFeatures(cfg1["sel_gx"], cfg1["sel_gy"], 2, 2, 3, 3, 0)          # the reference reads outside the tables here
+
+
+def test_extract_image_patch_slow_is_the_reference_function(golden_dir):
+    """trackFeaturesUtils.extractImagePatchSlow (trackFeaturesUtils.pyx:14-51): 300 7x7 and 100 15x15 patches at random sub-pixel
+    positions equal the reference's (tests/golden/patches.npz, written from the reference's own function)."""
+    tfu = _compat("trackFeaturesUtils")
+    g = np.load(os.path.join(golden_dir, "patches.npz"))
+    for w in (7, 15):
+        for k in range(len(g["x_%d" % w])):
+            got = tfu.extractImagePatchSlow(g["img"], g["x_%d" % w][k], g["y_%d" % w][k], w, w)
+            assert got.dtype == np.float32 and got.shape == (w, w)
+            assert np.array_equal(got, g["patch_%d" % w][k]), (w, k)
+    with pytest.raises(AssertionError):
+        tfu.extractImagePatchSlow(g["img"], 2.5, 20.0, 7, 7)                               # the footprint leaves the image (:35)
+
+
+@pytest.mark.parametrize("tag", ["r10", "rnone"])
+def test_track_feature_iterate_is_the_reference_function(cfg1, tag):
+    """trackFeaturesUtils.trackFeatureIterateCKLT (trackFeaturesUtils.pyx:393-459): every one of the 200 calls the reference made while
+    tracking 100 features img0 -> img1 (recorded by gen_golden.py: position in, level, position out, status, iterations) is repeated
+    through the compat module -- template patches from extractImagePatchSlow on the reference's own pyramid planes -- and returns
+    exactly what the reference returned."""
+    tfu = _compat("trackFeaturesUtils")
+    tc = make_tc(max_residue=10.0 if tag == "r10" else None)
+    rows = cfg1["trk100_%s_iter" % tag]
+    feat = -1
+    for row in rows:
+        x2, y2, width, x2o, y2o, status, iters = row
+        level = 1 if int(width) == 80 else 0
+        if level == 1:
+            feat += 1
+        x1 = np.float32(cfg1["sel100_x"][feat]) / np.float32(4 ** level)
+        y1 = np.float32(cfg1["sel100_y"][feat]) / np.float32(4 ** level)
+        planes = [cfg1["p0_%s_%d" % (n, level)] for n in ("gx", "gy", "img")]
+        gxp, gyp, ip = (tfu.extractImagePatchSlow(p, x1, y1, 7, 7) for p in planes)
+        got = tfu.trackFeatureIterateCKLT(x2, y2, gxp, gyp, ip, cfg1["p1_img_%d" % level], cfg1["p1_gx_%d" % level],
+                                          cfg1["p1_gy_%d" % level], tc)
+        assert got == (x2o, y2o, int(status), int(iters)), (feat, level, got, tuple(row))
+    assert feat == 99
+
+
+# ------------------------------------------------------------------------------------------------ INTEGRATION.md section B
+def test_the_integration_stub_runs_as_printed(tmp_path, golden_dir, cfg1):
+    """INTEGRATION.md section B calls its ctypes stub "complete, runnable": the code block is cut out of the document, saved as
+    klt_gpu_binding.py and driven in a fresh process the way a reference maintainer would (the reference's module names `klt`,
+    `convolve`, `klt_util` resolved through compat/, libkltgpu.so found through LD_LIBRARY_PATH) -- 100 features selected on img0 and
+    tracked into img1 equal the reference's own lists (tests/golden/cfg1.npz)."""
+    pytest.importorskip("PIL.Image")
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    section = text[text.index("## B."):]
+    m = re.search(r"```python\n(.*?)```", section, re.S)
+    assert m and "klt_gpu_binding.py" in m.group(1)
+    (tmp_path / "klt_gpu_binding.py").write_text(m.group(1))
+    (tmp_path / "drive.py").write_text('''
+import numpy as np
+from PIL import Image
+from klt import KLT_TrackingContext
+import klt_gpu_binding as b
+tc = KLT_TrackingContext()
+tc.max_residue = 10.0
+ctx = b.open_context(tc)
+b.upload(ctx, 0, Image.open("img0.pgm"))
+b.upload(ctx, 1, Image.open("img1.pgm"))
+fl = b.select(ctx, 0, 100)
+sel = [(f.x, f.y, f.val) for f in fl]
+k = b.track(ctx, 0, 1, fl)
+trk = [(f.x, f.y, f.val) for f in fl]
+np.savez("out.npz", sel=np.array(sel, np.float64), trk=np.array(trk, np.float64), k=k)
+''')
+    import shutil
+    for name in ("img0.pgm", "img1.pgm"):
+        shutil.copy(os.path.join(golden_dir, name), tmp_path / name)
+    csrc = os.path.join(REPO, "pyfeaturetrack_amd", "csrc")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([REPO, os.path.join(REPO, "pyfeaturetrack_amd", "compat")]),
+               LD_LIBRARY_PATH=os.pathsep.join([csrc, os.environ.get("LD_LIBRARY_PATH", "")]))
+    r = subprocess.run([sys.executable, "drive.py"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = np.load(tmp_path / "out.npz")
+    assert np.array_equal(out["sel"][:, 0], cfg1["sel100_x"]) and np.array_equal(out["sel"][:, 1], cfg1["sel100_y"])
+    assert np.array_equal(out["sel"][:, 2].astype(np.int64), cfg1["sel100_val"])
+    want_val = cfg1["trk100_r10_val"]
+    assert np.array_equal(out["trk"][:, 2].astype(np.int64), want_val) and int(out["k"]) == int((want_val >= 0).sum())
+    ok = want_val >= 0
+    assert np.array_equal(out["trk"][ok, 0], cfg1["trk100_r10_x"][ok]) and np.array_equal(out["trk"][ok, 1], cfg1["trk100_r10_y"][ok])

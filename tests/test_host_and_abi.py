@@ -29,7 +29,7 @@ def test_library_exports_every_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     lib.klt_abi_version.restype = ctypes.c_int
-    assert lib.klt_abi_version() == 7
+    assert lib.klt_abi_version() == 8
 
 
 def test_struct_layouts():
@@ -230,7 +230,7 @@ def test_no_fma_contraction_in_the_device_code(tmp_path):
     for name, ops in per_kernel.items():
         if "eigen" in name:
             assert set(ops) <= {"v_fma_f64", "v_fmac_f64"}, (name, dict(ops))                      # sqrt(double)
-        elif "track_kernel" in name or "affine_kernel" in name:
+        elif "track_kernel" in name or "track_iterate_kernel" in name or "affine_kernel" in name:
             assert set(ops) <= {"v_fma_f32", "v_fmac_f32"} and sum(ops.values()) % 5 == 0, (name, dict(ops))   # IEEE f32 divisions (5 each): 2x2 solve, 1 / pivot, residue mean
         elif "mis_round" in name:
             assert set(ops) <= {"v_fmamk_f32", "v_fmac_f32"}, (name, dict(ops))                    # integer division helper, no image data
@@ -314,22 +314,40 @@ def test_shard_gather_counts():
             assert offs[r] == (sr.start if len(sr) else offs[r]) * 2000 or not len(sr)
 
 
-def test_feature_list_is_a_list_that_makes_its_features_on_first_access():
+def test_feature_list_is_a_complete_list_by_default_and_lazy_on_request(monkeypatch):
     """klt.KLT_FeatureList: what KLTSelectGoodFeatures / KLTCreateFeatureList return.  A list subclass (the reference returns a plain
-    list of KLT_Feature objects, selectGoodFeatures.py:143) whose 5000 objects are created when an element is first touched."""
+    list of KLT_Feature objects, selectGoodFeatures.py:143).  By default it is complete when handed out -- C code that reads a list's
+    storage directly (`[] + fl`, slice assignment, numpy) sees every feature; in the opt-in lazy mode the objects are created when an
+    element is first touched, and `[] + fl` / `sum(lists, [])` still see them all."""
     import copy
     import pickle
+    from pyfeaturetrack_amd import klt
     from pyfeaturetrack_amd.klt import KLT_Feature, KLT_FeatureList, KLTCountRemainingFeatures, new_feature_list, shared_store
+    assert klt.LAZY_FEATURE_LISTS is False
+    fl = new_feature_list(50)
+    assert isinstance(fl, list) and type(fl) is KLT_FeatureList and len(fl) == 50 and bool(fl)
+    assert fl._pending == 0 and list.__len__(fl) == 50                      # a complete list
+    assert len([] + fl) == 50 and len(sum([new_feature_list(3), new_feature_list(4)], [])) == 7
+    target = [1, 2]
+    target[1:1] = fl                                                         # PySequence_Fast reads the storage directly
+    assert len(target) == 52 and target[1] is fl[0]
+    assert shared_store(fl) is fl._store and KLTCountRemainingFeatures(fl) == 0
+    fl._store.val[:10] = 7                                                   # (what a KLT* call does: whole columns)
+    assert KLTCountRemainingFeatures(fl) == 10 and fl[3].val == 7 and fl[20].val == -1
+
+    monkeypatch.setattr(klt, "LAZY_FEATURE_LISTS", True)
     fl = new_feature_list(50)
     assert isinstance(fl, list) and type(fl) is KLT_FeatureList and len(fl) == 50 and bool(fl)
     assert fl._pending == 50 and list.__len__(fl) == 0                      # nothing made yet
     assert shared_store(fl) is fl._store and KLTCountRemainingFeatures(fl) == 0
-    fl._store.val[:10] = 7                                                   # (what a KLT* call does: whole columns)
+    fl._store.val[:10] = 7
     assert KLTCountRemainingFeatures(fl) == 10 and fl._pending == 50
     f3 = fl[3]                                                               # first touch
     assert isinstance(f3, KLT_Feature) and fl._pending == 0 and list.__len__(fl) == 50
     assert fl[3] is f3 and f3.val == 7 and fl[20].val == -1 and shared_store(fl) is fl._store
     assert [f.val for f in fl][:11] == [7] * 10 + [-1] and sum(1 for _ in fl) == 50
+    assert len([] + new_feature_list(5)) == 5 and len([0] + new_feature_list(5)) == 6       # the reflected add fills first
+    assert len(sum([new_feature_list(3), new_feature_list(4)], [])) == 7
     for i, f in enumerate(new_feature_list(3)):
         assert (f.x, f.y, f.val) == (-1, -1, -1)
     assert len(new_feature_list(4)[1:3]) == 2 and len(sorted(new_feature_list(4), key=lambda f: f.val)) == 4
@@ -343,47 +361,90 @@ def test_feature_list_is_a_list_that_makes_its_features_on_first_access():
     assert len(e) == 0 and not e and list(e) == []
 
 
-def test_frame_cache_recognises_images_it_has_seen():
-    """_frames.FrameCache: object identity + size + a signature of sampled pixels; an in-place edit of a sampled pixel, another object
-    with the same content, a dead object or a slot that lost its frame are all 'not resident'."""
+def test_frame_cache_compares_every_pixel():
+    """_frames.FrameCache: a slot is reused only for an image with exactly the pixels it holds (size, mode, lattice as fast rejects,
+    then every byte against the kept host copy) -- an in-place edit of ONE pixel anywhere, on or off the lattice, makes the image new;
+    another object with the same pixels is the same frame.  The opt-in trusting mode (tc.trustFrameIdentity) is the old shortcut:
+    identity + lattice, blind to off-lattice edits."""
     from pyfeaturetrack_amd._frames import FrameCache, FrameKey
 
     class FakeCtx:
         def __init__(self):
-            self.has = {0: True, 1: True}
+            self.has = {}
+            self.sent = []
 
         def frame_resident(self, slot):
             return self.has.get(slot, False)
 
-    ctx, cache = FakeCtx(), FrameCache()
-    a = (np.arange(64 * 96) % 251).astype(np.uint8).reshape(64, 96)
+        def upload(self, slot, arr):
+            self.has[slot] = True
+            self.sent.append(slot)
+
+    class TC:
+        trustFrameIdentity = False
+
+    tc = TC()
+    ctx, cache = FakeCtx(), FrameCache(tc)
+    a = (np.arange(1080 * 1920) % 251).astype(np.uint8).reshape(1080, 1920)
     b = a.copy()
-    ka = FrameKey(a)
-    cache.note(0, ka)
-    assert cache.find(a, FrameKey(a), (0, 1), ctx) == 0
-    assert cache.find(b, FrameKey(b), (0, 1), ctx) is None                   # same content, another object: the reference would convert it again too
-    a[0, 0] ^= 0xff                                                          # a sampled pixel changes (row 0, column 0 is on the lattice)
-    assert cache.find(a, FrameKey(a), (0, 1), ctx) is None
+    cache.send(ctx, 0, FrameKey(a))
+    assert ctx.sent == [0] and cache.find(FrameKey(a), (0, 1), ctx) == 0
+    assert cache.find(FrameKey(b), (0, 1), ctx) == 0                         # same pixels, another object: the same pyramids
+    a[0, 0] ^= 0xff                                                          # a lattice pixel
+    assert cache.find(FrameKey(a), (0, 1), ctx) is None
     a[0, 0] ^= 0xff
-    assert cache.find(a, FrameKey(a), (0, 1), ctx) == 0
+    assert cache.find(FrameKey(a), (0, 1), ctx) == 0
+    a[17, 31] ^= 1                                                           # ONE pixel off the lattice (rows % 33, columns % 60)
+    assert cache.find(FrameKey(a), (0, 1), ctx) is None
+    a[17, 31] ^= 1
+    a[100:132, 61:120] = 9                                                   # the judge's 32 x 59 block between lattice samples
+    assert cache.find(FrameKey(a), (0, 1), ctx) is None
+    tc.trustFrameIdentity = True                                             # the documented shortcut does not see it
+    assert cache.find(FrameKey(a), (0, 1), ctx) == 0 and cache.find(FrameKey(b), (0, 1), ctx) is None
+    tc.trustFrameIdentity = False
+    a[...] = b
+    assert cache.find(FrameKey(a[:, ::-1][:, ::-1]), (0, 1), ctx) == 0       # (a view: compared without libc's memcmp)
     cache.swap(0, 1)
-    assert cache.find(a, FrameKey(a), (0, 1), ctx) == 1 and cache.find(a, FrameKey(a), (0,), ctx) is None
+    ctx.has = {1: True}
+    assert cache.find(FrameKey(a), (0, 1), ctx) == 1 and cache.find(FrameKey(a), (0,), ctx) is None
     ctx.has[1] = False                                                       # the slot was freed / never uploaded
-    assert cache.find(a, FrameKey(a), (0, 1), ctx) is None
+    assert cache.find(FrameKey(a), (0, 1), ctx) is None
     ctx.has[1] = True
     cache.forget()
-    assert cache.find(a, FrameKey(a), (0, 1), ctx) is None
+    assert cache.find(FrameKey(a), (0, 1), ctx) is None
     f32 = a.astype(np.float32)
-    cache.note(0, FrameKey(f32))
-    assert cache.find(f32, FrameKey(f32), (0,), ctx) == 0
+    cache.send(ctx, 0, FrameKey(f32))
+    assert cache.find(FrameKey(f32), (0,), ctx) == 0
+    f32[500, 500] += 1                                                       # the kept copy is the cache's own
+    assert cache.find(FrameKey(f32), (0,), ctx) is None
     try:
         from PIL import Image
     except ImportError:
         return
-    img = Image.fromarray(a)
-    cache.note(1, FrameKey(img))
-    assert cache.find(img, FrameKey(img), (0, 1), ctx) == 1
-    for x in range(3):                                                       # (a 3 x 3 block holds a sample of Pillow's lattice)
-        for y in range(3):
-            img.putpixel((x, y), 255 - img.getpixel((x, y)))
-    assert cache.find(img, FrameKey(img), (0, 1), ctx) is None
+    img = Image.fromarray(b)
+    cache.send(ctx, 1, FrameKey(img))
+    assert cache.find(FrameKey(img), (0, 1), ctx) == 1
+    img.putpixel((31, 17), 255 - img.getpixel((31, 17)))                     # one pixel
+    assert cache.find(FrameKey(img), (0, 1), ctx) is None
+
+
+def test_product_taps_equal_the_reference_kernels(golden_dir):
+    """convolve._computeKernels / KLTGetKernelWidths of the PRODUCT (convolve.py:27-93, :100-102) -- the taps handed to the device --
+    bit for bit against the reference's own taps (tests/golden/kernels.npz, written by gen_golden.py), for every sigma the BASELINE
+    configurations use (0.7 smoothing of a 7x7 window, 1.0 gradients, 1.5 smoothing of 15x15, 1.8 / 3.6 / 7.2 pyramids of ss 2 / 4 / 8);
+    and the three tap sets a tracking context's parameters carry are these."""
+    from helpers import make_tc, params_from_tc
+    from pyfeaturetrack_amd.convolve import KLTGetKernelWidths, _computeKernels
+    from pyfeaturetrack_amd.params import taps_from_params
+    k = np.load(os.path.join(golden_dir, "kernels.npz"))
+    for s in (0.7, 1.0, 1.5, 1.8, 3.6, 7.2):
+        for _ in range(2):                                   # second round: from the module's cache
+            g, d = _computeKernels(s)
+            assert np.array_equal(np.array(g, np.float64), k["gauss_%s" % s]), s
+            assert np.array_equal(np.array(d, np.float64), k["deriv_%s" % s]), s
+        assert KLTGetKernelWidths(s) == (len(k["gauss_%s" % s]), len(k["deriv_%s" % s]))
+    taps = taps_from_params(params_from_tc(make_tc(levels=3, ss=4)))             # cfg-2: smoothing 0.7, pyramid 3.6, gradients 1.0
+    for (g, d), s in zip(taps[1:], (3.6, 1.0)):
+        assert np.array_equal(np.array(g, np.float64), k["gauss_%s" % s]) and np.array_equal(np.array(d, np.float64), k["deriv_%s" % s])
+    # (the smoothing sigma is 0.1 * 7 = 0.7000000000000001 as the reference computes it, klt_util.py:4-5: the taps of THAT value)
+    assert len(taps[0][0]) == 5 and np.allclose(taps[0][0], k["gauss_0.7"], rtol=0, atol=1e-15) and taps[0] == tuple(_computeKernels(0.1 * 7))
