@@ -335,7 +335,9 @@ int klt_timing_enable(klt_ctx *ctx, int on);                /* resets the accumu
                                                              * affine_check, sat_rows, sat_cols, eigen_keys) are timed by their dispatch's own begin / end timestamps
                                                              * (hipExtLaunchKernelGGL events) -- the kernel duration a profiler reports, without the boundary between
                                                              * two dependent launches that an event pair also holds */
-int klt_timing_read(klt_ctx *ctx, klt_kernel_time *out, int max_entries);   /* returns the entry count */
+int klt_timing_read(klt_ctx *ctx, klt_kernel_time *out, int max_entries);   /* returns the entry count.  Mode 2: a launch of a stamped family that took
+                                                                              * a path without dispatch timestamps (a fallback kernel) is not measured; such
+                                                                              * launches are counted in an extra entry "<family>!unstamped" (no time) */
 
 #ifdef __cplusplus
 }

@@ -137,6 +137,20 @@ class KltBackendError(RuntimeError):
     pass
 
 
+class KltCommTimeout(KltBackendError):
+    """KLT_ERR_TIMEOUT: a host-side wait for a collective gave up (a peer is gone or stuck).  The communicator is unusable from then
+    on; the rank is expected to report and exit non-zero -- `exit_on_comm_timeout` does -- and is never restarted in place."""
+
+
+def exit_on_comm_timeout(exc, code=3):
+    """Print the timeout and leave the process at once (os._exit: no finalizer gets the chance to wait for a stream that is fenced
+    behind the dead collective)."""
+    import sys
+    sys.stderr.write("pyfeaturetrack_amd: %s -- exiting with code %d\n" % (exc, code))
+    sys.stderr.flush()
+    os._exit(code)
+
+
 def load_library(path=None):
     """Load libkltgpu.so and type every entry point.  Raises if it is missing."""
     global _lib

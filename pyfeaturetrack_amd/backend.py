@@ -8,8 +8,8 @@ import ctypes as C
 
 import numpy as np
 
-from ._abi import (KLT_MAX_LEVELS, KltAffineRec, KltBackendError, KltFeat, KltKernelTime, KltParams, KltTrackStats,
-                   load_library)
+from ._abi import (KLT_MAX_LEVELS, KltAffineRec, KltBackendError, KltCommTimeout, KltFeat, KltKernelTime, KltParams,
+                   KltTrackStats, load_library)
 from .params import affine_params_from_tc, params_from_tc, taps_from_params
 
 FEAT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("val", np.int32), ("aux", np.int32)])
@@ -53,7 +53,8 @@ class Context:
     def _check(self, rc):
         if rc < 0:
             msg = self._lib.klt_last_error(self._h)
-            raise KltBackendError("libkltgpu error %d: %s" % (rc, (msg or b"").decode()))
+            kind = KltCommTimeout if rc == -5 else KltBackendError          # KLT_ERR_TIMEOUT
+            raise kind("libkltgpu error %d: %s" % (rc, (msg or b"").decode()))
         return rc
 
     def sync(self):
@@ -484,5 +485,5 @@ def default_context(device=None):
     return ctx
 
 
-__all__ = ["Context", "default_context", "FEAT_DTYPE", "SELECTING_ALL", "REPLACING_SOME", "KltBackendError",
+__all__ = ["Context", "default_context", "FEAT_DTYPE", "SELECTING_ALL", "REPLACING_SOME", "KltBackendError", "KltCommTimeout",
            "KLT_MAX_LEVELS", "KltParams"]

@@ -30,6 +30,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;          // optional: used to tear down a communicator whose collective can never complete
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -82,6 +83,7 @@ bool load_rccl(std::string &err)
             sym(g_rccl.AllReduce, "ncclAllReduce") && sym(g_rccl.Send, "ncclSend") && sym(g_rccl.Recv, "ncclRecv") &&
             sym(g_rccl.GroupStart, "ncclGroupStart") && sym(g_rccl.GroupEnd, "ncclGroupEnd") &&
             sym(g_rccl.GetErrorString, "ncclGetErrorString");
+        g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(g_rccl.handle, "ncclCommAbort"));
     }
     if (!g_rccl.error.empty()) { err = g_rccl.error; return false; }
     return true;
@@ -98,6 +100,8 @@ struct KltComm {
     hipEvent_t last_done = nullptr;        // end of the most recent collective
     double *scratch = nullptr;             // device scratch for the small reductions (16 doubles)
     double timeout_ms = 300000.0;          // host-side waits give up after this long (KLT_COMM_TIMEOUT_MS / comm_set_timeout; <= 0: never)
+    bool poisoned = false;                 // a host-side wait timed out: a collective on the side stream can never complete.  Nothing waits
+                                           // for that stream again -- not even the teardown -- and every further call fails at once
 };
 
 // Collectives of DIFFERENT communicators of one process (bench.py gives every context its own) must not run side by side: two RCCL
@@ -173,10 +177,21 @@ int comm_create(int device, int nranks, int rank, const void *unique_id, KltComm
     return 0;
 }
 
+bool comm_poisoned(const KltComm *k) { return k && k->poisoned; }
+
 void comm_destroy(KltComm *k)
 {
     if (!k) return;
     hipSetDevice(k->device);
+    if (k->poisoned) {
+        // The side stream holds a collective whose peer is gone: synchronising it, or ncclCommDestroy (which does), would hang the
+        // rank that is trying to report and exit.  Abort the communicator where the library can, and leak the stream, its events and
+        // the scratch -- the process is on its way out (comm_wait's caller exits non-zero; nothing is restarted in place).
+        if (g_chain_owner == k) { g_chain_done = nullptr; g_chain_owner = nullptr; }
+        if (k->comm && g_rccl.CommAbort) g_rccl.CommAbort(k->comm);
+        delete k;
+        return;
+    }
     if (k->side) hipStreamSynchronize(k->side);
     if (g_chain_owner == k) { g_chain_done = nullptr; g_chain_owner = nullptr; }      // (its events are about to go; the stream above is idle)
     if (k->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(k->comm);
@@ -193,6 +208,7 @@ int comm_rank(const KltComm *k) { return k ? k->rank : 0; }
 // side stream waits for everything enqueued on `producer` so far
 static int comm_order_behind(KltComm *k, hipStream_t producer, std::string &err)
 {
+    if (k->poisoned) { err = "the communicator is unusable: an earlier wait for a collective timed out (a peer is gone or stuck)"; return KLT_ERR_TIMEOUT; }
     hipEvent_t ready;
     if (int rc = comm_event(k, &ready, err)) return rc;
     COMM_HIP(hipEventRecord(ready, producer));
@@ -310,6 +326,7 @@ void comm_set_timeout(KltComm *k, double ms) { if (k) k->timeout_ms = ms; }
 // the GPU is never restarted in place).
 int comm_wait(KltComm *k, std::string &err)
 {
+    if (k->poisoned) { err = "the communicator is unusable: an earlier wait for a collective timed out (a peer is gone or stuck)"; return KLT_ERR_TIMEOUT; }
     COMM_HIP(hipSetDevice(k->device));
     if (k->timeout_ms <= 0) { COMM_HIP(hipStreamSynchronize(k->side)); return 0; }
     const auto t0 = std::chrono::steady_clock::now();
@@ -323,6 +340,7 @@ int comm_wait(KltComm *k, std::string &err)
             char buf[160];
             std::snprintf(buf, sizeof(buf), "collective still pending after %.0f ms (rank %d of %d): a peer is gone or stuck", ms, k->rank, k->nranks);
             err = buf;
+            k->poisoned = true;
             return KLT_ERR_TIMEOUT;
         }
         if (ms > 0.2) usleep(50);
@@ -333,6 +351,7 @@ int comm_wait(KltComm *k, std::string &err)
 int comm_allreduce_max(KltComm *k, double *inout, int n, std::string &err)
 {
     if (!inout || n < 1 || n > 16) { err = "allreduce takes 1..16 doubles"; return KLT_ERR_ARG; }
+    if (k->poisoned) { err = "the communicator is unusable: an earlier wait for a collective timed out (a peer is gone or stuck)"; return KLT_ERR_TIMEOUT; }
     COMM_HIP(hipSetDevice(k->device));
     if (g_chain_done && g_chain_owner != k) COMM_HIP(hipStreamWaitEvent(k->side, g_chain_done, 0));     // one collective of the process at a time
     COMM_HIP(hipMemcpyAsync(k->scratch, inout, n * sizeof(double), hipMemcpyHostToDevice, k->side));

@@ -147,10 +147,9 @@ void launch_take_strided(hipStream_t s, const float *src, float *dst, size_t n, 
 }
 
 void launch_vconv(hipStream_t s, const float *inA, const float *inB, int ncols, int nrows, float *outA, float *outB,
-                  int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb)
+                  int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb, int ostride)
 {
     dim3 block(64, 4), grid((ncols + 63) / 64, (out_rows + 3) / 4);
-    const int ostride = (tb && outB == outA + 1) ? 2 : 1;          // two outputs one element apart: the interleaved gradient planes
     if (tb)
         hipLaunchKernelGGL((vconv_kernel<2>), grid, block, 0, s, inA, inB, ncols, nrows, outA, outB, out_rows, ystride, yoff, ta, *tb, ostride);
     else

@@ -211,6 +211,7 @@ struct klt_ctx {
     std::vector<hipEvent_t> pool;
     double acc_ms[F_COUNT] = {0}, acc_bytes[F_COUNT] = {0};
     unsigned acc_n[F_COUNT] = {0};
+    unsigned acc_unstamped[F_COUNT] = {0};    // timing mode 2: scopes of a family whose launch did not go through klt_launch (nothing measured)
 };
 
 namespace {
@@ -254,7 +255,8 @@ struct TimerScope {
     {
         if (!on) return;
         if (stamps) {
-            if (g_klt_stamp_start) {                 // no launch took them (an error path): nothing was measured
+            if (g_klt_stamp_start) {                 // no launch took them (an error path, or a launcher that does not go through
+                c->acc_unstamped[t.fam]++;           // klt_launch): nothing was measured -- counted, klt_timing_read says so
                 g_klt_stamp_start = g_klt_stamp_stop = nullptr;
                 c->pool.push_back(t.a); c->pool.push_back(t.b);
                 return;
@@ -291,7 +293,9 @@ int sync_all(klt_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
     if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
-    if (c->comm) { std::string err; if (int rc = comm_wait(c->comm, err)) return fail(c, rc, err); }
+    // (a communicator whose collective timed out is left alone: the wait that found out has reported it, and calls that only free
+    // host memory or lay out a pyramid must not fail because of it -- the main stream is idle at this point, which is what they need)
+    if (c->comm && !comm_poisoned(c->comm)) { std::string err; if (int rc = comm_wait(c->comm, err)) return fail(c, rc, err); }
     return 0;
 }
 
@@ -557,7 +561,7 @@ int enqueue_gradients(klt_ctx *c, const float *img, int nc, int nr, float *gx, f
     }
     {
         TimerScope t(c, F_GRAD_V, N * 16);
-        launch_vconv(c->work, c->tmpA, c->tmpB, nc, nr, gx, gy, nr, 1, 0, c->gauss[2], &c->deriv[2]);
+        launch_vconv(c->work, c->tmpA, c->tmpB, nc, nr, gx, gy, nr, 1, 0, c->gauss[2], &c->deriv[2], KLT_GRAD_STRIDE);   // a level's interleaved planes
     }
     return 0;
 }
@@ -855,6 +859,15 @@ void klt_destroy(klt_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->comm && comm_poisoned(c->comm)) {
+        // A collective of this context can never complete (klt_comm_wait timed out: a peer is gone).  The main stream may be fenced
+        // behind it, and hipStreamSynchronize / hipFree (which synchronises the device) would hang the rank that is trying to report and
+        // exit non-zero.  Abort the communicator and leave the device memory to the process's end.
+        comm_destroy(c->comm);
+        c->comm = nullptr;
+        delete c;
+        return;
+    }
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
     if (c->bstream) { hipStreamSynchronize(c->bstream); hipStreamDestroy(c->bstream); }
@@ -2511,7 +2524,7 @@ int klt_timing_enable(klt_ctx *c, int on)
 {
     if (!c) return KLT_ERR_ARG;
     if (int rc = drain_timers(c)) return rc;
-    for (int f = 0; f < F_COUNT; f++) { c->acc_ms[f] = 0; c->acc_bytes[f] = 0; c->acc_n[f] = 0; }
+    for (int f = 0; f < F_COUNT; f++) { c->acc_ms[f] = 0; c->acc_bytes[f] = 0; c->acc_n[f] = 0; c->acc_unstamped[f] = 0; }
     c->timing = on != 0;
     c->timing_stamps = on == 2;
     return KLT_OK;
@@ -2529,6 +2542,15 @@ int klt_timing_read(klt_ctx *c, klt_kernel_time *out, int max_entries)
         out[k].launches = c->acc_n[f];
         out[k].total_ms = (float)c->acc_ms[f];
         out[k].bytes = c->acc_bytes[f];
+        k++;
+    }
+    // mode 2: launches of a stamped family that took a path without dispatch timestamps are reported, not dropped: "<family>!unstamped"
+    // carries their number (no time, no bytes) -- a reader must not quote the family's figures as covering every launch
+    for (int f = 0; f < F_COUNT && k < max_entries; f++) {
+        if (!c->acc_unstamped[f]) continue;
+        std::memset(&out[k], 0, sizeof(out[k]));
+        std::snprintf(out[k].name, sizeof(out[k].name), "%s!unstamped", kFamilyName[f]);
+        out[k].launches = c->acc_unstamped[f];
         k++;
     }
     return k;

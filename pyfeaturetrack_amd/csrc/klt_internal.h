@@ -153,8 +153,10 @@ void launch_hconv_u8(hipStream_t s, const uint8_t *in, int ncols, int nrows, flo
 void launch_hconv_f32(hipStream_t s, const float *in, int ncols, int nrows, float *outA, float *outB,
                       int out_cols, int xstride, int xoff, const Taps &ta, const Taps *tb);
 void launch_take_strided(hipStream_t s, const float *src, float *dst, size_t n, int stride);
+// ostride: element stride of the output plane(s) -- KLT_GRAD_STRIDE when outA / outB are the two interleaved gradient planes of a
+// level (outB == outA + 1), 1 for separate planes (stated by the caller, never inferred from the pointers)
 void launch_vconv(hipStream_t s, const float *inA, const float *inB, int ncols, int nrows, float *outA, float *outB,
-                  int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb);
+                  int out_rows, int ystride, int yoff, const Taps &ta, const Taps *tb, int ostride = 1);
 
 // Plane accesses as raw buffer operations (device code): the plane pointer is workgroup-uniform (a descriptor in four
 // SGPRs), the lane's 32-bit BYTE offset is the whole vector address.  With `plane + (size_t)y * nc + x` every access costs a
@@ -241,6 +243,7 @@ struct KltComm;
 int  comm_unique_id(void *out128, std::string &err);
 int  comm_create(int device, int nranks, int rank, const void *unique_id, KltComm **out, std::string &err);
 void comm_destroy(KltComm *k);
+bool comm_poisoned(const KltComm *k);         // a host-side wait timed out: nothing may wait for this communicator's stream again
 int  comm_nranks(const KltComm *k);
 hipEvent_t comm_last_done(const KltComm *k);   // end of the most recent collective (an event of the communicator's ring)
 int  comm_rank(const KltComm *k);

@@ -65,6 +65,13 @@ def _slots_of(tc):
     return s
 
 
+def _pyramid_fits(tc, ncols, nrows):
+    """every level of the tracking context's pyramid has at least one pixel (pyramid.py:26-31: int(n / ss) per level)"""
+    for _ in range(int(tc.nPyramidLevels) - 1):
+        ncols, nrows = ncols // int(tc.subsampling), nrows // int(tc.subsampling)
+    return ncols >= 1 and nrows >= 1
+
+
 def _fix_window(tc):
     if tc.window_width % 2 != 1:
         tc.window_width += 1
@@ -98,7 +105,7 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
              and ctx.pyramids_valid(slots[0]))
     if reuse:
         slot = slots[0]            # selectGoodFeatures.py:176-181: level 0 of the pyramids kept from the last track
-    elif tc.smoothBeforeSelecting:
+    elif tc.smoothBeforeSelecting and _pyramid_fits(tc, *_image_size(img)):
         # The smoothed image and its gradients ARE level 0 of the image's pyramids (same taps: selectGoodFeatures.py:183-197 and
         # trackFeatures.py:165-172).  An image one of the two frame slots already holds (_frames.py) is neither uploaded nor
         # smoothed again; a new one goes to the slot the next KLTTrackFeatures call will look for it in (frame 1 -- or frame 2 while
@@ -115,7 +122,10 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
             ctx.build_pyramids(slot, sync=False)
         reuse = True
     else:
-        slot = slots[2]            # gradients of the raw frame: nothing a pyramid holds
+        # gradients of the raw frame (nothing a pyramid holds) -- or a frame too small for the tracking context's pyramid, e.g. after
+        # KLTChangeTCPyramid with a large search range: the reference's selection never builds a pyramid (selectGoodFeatures.py:183-197)
+        # and succeeds on such a frame, so the selection smooths and differentiates in its own slot
+        slot = slots[2]
         ctx.upload(slot, image_to_array(img))
     fl_in = features_to_array(featurelist, ctx.host_records(len(featurelist))[0]) if mode == selectionMode.REPLACING_SOME else None
     from .trackFeatures import affine_state_lookup

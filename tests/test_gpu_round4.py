@@ -362,3 +362,46 @@ np.savez("out.npz", sel=np.array(sel, np.float64), trk=np.array(trk, np.float64)
     assert np.array_equal(out["trk"][:, 2].astype(np.int64), want_val) and int(out["k"]) == int((want_val >= 0).sum())
     ok = want_val >= 0
     assert np.array_equal(out["trk"][ok, 0], cfg1["trk100_r10_x"][ok]) and np.array_equal(out["trk"][ok, 1], cfg1["trk100_r10_y"][ok])
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r3 (low)
+def test_selection_on_a_frame_too_small_for_the_pyramid(img0):
+    """KLTSelectGoodFeatures never builds a pyramid in the reference (selectGoodFeatures.py:183-197), so it succeeds on a
+    frame the tracking context's pyramid does not fit -- here 8 levels of subsampling 4 on 320x240 (level 4 would be 1x0 pixels).  The
+    level-0 shortcut must not turn that into an error; the list is the one a fitting pyramid geometry gives with the same border."""
+    sgf, trk = _api_modules()
+    try:
+        small = make_tc()
+        small.nPyramidLevels, small.subsampling = 8, 4
+        small.borderx = small.bordery = 30.0
+        fits = make_tc()                                       # 2 levels of 4: border 30.0 as well
+        assert (fits.borderx, fits.bordery) == (30.0, 30.0)
+        a = sgf.KLTSelectGoodFeatures(small, img0, 80)
+        b = sgf.KLTSelectGoodFeatures(fits, img0, 80)
+        assert _records(a) == _records(b) and sum(f.val >= 0 for f in a) == 80
+    finally:
+        sgf.KLT_verbose = trk.KLT_verbose = 1
+
+
+def test_dispatch_timestamps_never_drop_a_launch_silently():
+    """klt_timing_enable(ctx, 2) times single-launch families by their dispatch's own timestamps, which only launches that
+    go through klt_launch carry.  On a frame whose width is not a multiple of 4 the summed-area passes take the barrier-coupled
+    fallback kernels: every scope is either measured or counted in "<family>!unstamped" -- never lost."""
+    from helpers import synth251_frames
+    from pyfeaturetrack_amd.backend import Context
+    c = Context(0)
+    try:
+        for frame, tc in ((synth251_frames()[0], make_tc(levels=2, ss=2)), (synth.synth_pair(640, 480, 2)[0], make_tc(levels=2, ss=4))):
+            c.configure(tc)
+            c.upload(0, frame)
+            c.build_pyramids(0)
+            for mode in (1, 2):
+                c.timing_enable(mode)
+                c.select(0, 40, use_pyramid=True)
+                t = {k["name"]: k["launches"] for k in c.timing_read()}
+                c.timing_enable(0)
+                for fam in ("sat_rows", "sat_cols"):
+                    assert t.get(fam, 0) + t.get(fam + "!unstamped", 0) == 1, (frame.shape, mode, t)
+                assert mode == 2 or not any(k.endswith("!unstamped") for k in t)
+    finally:
+        c.close()

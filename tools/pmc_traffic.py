@@ -47,8 +47,11 @@ def read(dirname, counter):
     return acc
 
 
+# everything a per-launch counter depends on: the kernels, the shared load / store helpers (klt_internal.h) and the launch geometry
+# (klt_api.hip)
 KERNEL_SOURCES = ["pyfeaturetrack_amd/csrc/pyramid_kernels.hip", "pyfeaturetrack_amd/csrc/track_kernels.hip",
-                  "pyfeaturetrack_amd/csrc/select_kernels.hip", "pyfeaturetrack_amd/csrc/sat_pipeline.hip"]
+                  "pyfeaturetrack_amd/csrc/select_kernels.hip", "pyfeaturetrack_amd/csrc/sat_pipeline.hip",
+                  "pyfeaturetrack_amd/csrc/klt_internal.h", "pyfeaturetrack_amd/csrc/klt_api.hip"]
 
 
 def provenance(what):
