@@ -499,10 +499,10 @@ def run_cfg4(args, json_fd):
     fl_in = ctx.featbuf_download(T_IN, pairs * nf).reshape(pairs, nf) if pairs else None
     if ranks.rank == 0 and pairs:
         checks = []
-        for k in sorted({0, pairs - 1}) if ko else []:
+        for k in range(pairs) if ko else []:
             same, dx = records_equal(out[k], oracle_track(ko, p, frames[k][0], frames[k][1], fl_in[k], threads=usable_cores()))
             checks.append(("pair %d" % mine[k], same, dx))
-        par = parity_summary(checks, "tracked records of the first and the last pair of rank 0's shard, last timed step")
+        par = parity_summary(checks, "tracked records of ALL %d pairs of rank 0's shard, last timed step" % pairs)
     gathered_ok = None
     if gather:
         full = gather.result()
@@ -517,7 +517,7 @@ def run_cfg4(args, json_fd):
                 ko.set_threads(1)
                 same, dx = records_equal(full[total - 1], oracle_track(ko, p, g0, g1, osel, threads=usable_cores()))
                 checks.append(("pair %d as gathered from rank %d" % (total - 1, ranks.world - 1), same, dx))
-                par = parity_summary(checks, "tracked records of the first and the last pair of rank 0's shard and of the batch's last pair as gathered")
+                par = parity_summary(checks, "tracked records of all %d pairs of rank 0's shard and of the batch's last pair as gathered" % pairs)
     roof = cpu = None
     if ranks.rank == 0 and pairs:
         nst = min(args.steps, 10)
@@ -795,16 +795,18 @@ def run_cfg5(args, json_fd):
     if ranks.distributed:
         return run_cfg5_blocks(args, json_fd, ranks)
     w, h, n = 3840, 2160, 20000
-    nframes = 8
-    tc = cfg2_context()
+    nframes = max(2, args.frames)                # BASELINE cfg-5: a 512-frame sequence; every frame resident in its own slot (115 MB of
+    tc = cfg2_context()                          # raw frame + pyramid planes each: 59 GB of the 288 GB for 512 frames)
     tc.max_residue = 10.0
     p = params_from_tc(tc)
     ctx = Context(0)
     ctx.configure(tc)
-    base = synth.synth_base(w, h, 4)
-    frames = [synth.synth_frame(w, h, 4, k, base=base) for k in range(nframes)]
-    for k in range(nframes):
-        ctx.upload(10 + k, frames[k])
+    phases = synth.sequence_phases(w, h, 4, workers=usable_cores(10))
+    frames = []                                  # only the first frames stay on the host (parity check, CPU baseline)
+    for k, f in enumerate(synth.periodic_sequence(w, h, 4, nframes, phases=phases)):
+        ctx.upload(10 + k, f)
+        if k < 8:
+            frames.append(f)
     ctx.build_pyramids(10)
     fl, placed = ctx.select(10, n, use_pyramid=True)
     ctx.featbuf_upload(0, fl)
@@ -921,12 +923,13 @@ def run_cfg5(args, json_fd):
         cpu = cpu_baseline_of(ko, one_frame, n, "pyramid of the new 3840x2160 frame + track 20000 features + replacement selection (one frame of cfg-5)", budget_s=8.0)
     ctx.close()
     line = base_line(n * frames_per_region / el, 1, frames_per_region, 0, ms_step, ms_step,
-                     "cfg-5 (one GPU): 3840x2160 sequence, 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost "
+                     "cfg-5 (one GPU): ONE 3840x2160 sequence of %d frames (resident in HBM as u8, one slot each), 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost " % nframes +
                      "features replaced after every frame; per step (frame): pyramid of the new frame + track + replacement"
                      + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else "")
                      + (", and so are its summed-area tables and eigenvalues (klt_select_prepare_async)" if prepare else ""),
-                     extra_cfg={"live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
-                                "lost_per_frame": lost, "build_stream": bool(prefetch), "scores_prepared": bool(prepare),
+                     extra_cfg={"frames": nframes, "live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
+                                "lost_per_frame": {"first": lost[:8], "min": min(lost), "median": float(statistics.median(lost)), "max": max(lost)},
+                                "build_stream": bool(prefetch), "scores_prepared": bool(prepare),
                                 "tracker_enqueued_ahead": bool(prefetch), "trackers_repeated": redone[0]})
     line.update(par)
     line["roofline"], line["cpu_baseline"] = roof, cpu
@@ -1480,6 +1483,7 @@ def main():
                     help="cfg2 (default, the headline line); cfg4 = the 256-pair batch sharded over --gpus ranks; the others are "
                          "the remaining BASELINE configs on one GPU")
     ap.add_argument("--pairs", type=int, default=256, help="total pairs per step for --config cfg4 (sharded over the ranks)")
+    ap.add_argument("--frames", type=int, default=512, help="length of the sequence of --config cfg5 on one GPU (BASELINE: 512 frames); a timed region is whole passes over it")
     ap.add_argument("--resident-pairs", type=int, default=72,
                     help="cfg2: distinct synthetic pairs resident per GPU, all of them processed by every step (72 pairs = 4.2 GB of frames "
                          "and pyramids: a step's working set is 16x the 256 MB Infinity Cache); a multiple of --inflight x --batch")

@@ -136,6 +136,9 @@ int klt_build_pyramids(klt_ctx *ctx, int slot);
 /* bit 0: the slot holds a frame; bit 1: its pyramids are built and match the current parameters / taps (what
  * `tc.pyramid_last is not None` means in the reference, trackFeatures.py:152); 0 for a slot never used */
 int klt_slot_state(klt_ctx *ctx, int slot);
+/* free / total memory of the context's device (hipMemGetInfo): what a long-running sequence watches to see that slots, score sets and
+ * descriptor tables are recycled, not accumulated */
+int klt_device_memory(klt_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 /* which build filled the slot's pyramids: a number unique per build within the context that travels with klt_swap_slots; 0 while the
  * slot has no valid pyramids.  The host layer's pyramid handles (what ComputeImagePyramids returns and tc.pyramid_last holds,
  * trackFeatures.py:146-196, :401-404) use it to tell whether the planes they stand for are still on the device. */

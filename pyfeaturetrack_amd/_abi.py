@@ -74,6 +74,7 @@ SYMBOLS = {
     "klt_set_option": (_I, [_P, _I, _I]),
     "klt_build_pyramids": (_I, [_P, _I]),
     "klt_slot_state": (_I, [_P, _I]),
+    "klt_device_memory": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "klt_slot_generation": (_I, [_P, _I, C.POINTER(C.c_uint64)]),
     "klt_slot_free": (_I, [_P, _I]),
     "klt_swap_slots": (_I, [_P, _I, _I]),

@@ -222,6 +222,12 @@ class Context:
         """True while the slot holds a frame (raw pixels on the device)."""
         return bool(self._check(self._lib.klt_slot_state(self._h, slot)) & 1)
 
+    def device_memory(self):
+        """(free, total) bytes of the context's device"""
+        f, t = C.c_size_t(), C.c_size_t()
+        self._check(self._lib.klt_device_memory(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def slot_generation(self, slot):
         """Number of the build that filled the slot's pyramids (travels with swap_slots); 0 without valid pyramids."""
         g = C.c_uint64()

@@ -1082,6 +1082,17 @@ int klt_slot_state(klt_ctx *c, int slot)
     return (s.raw_kind != 0 ? 1 : 0) | (s.pyr_valid ? 2 : 0);
 }
 
+int klt_device_memory(klt_ctx *c, size_t *free_bytes, size_t *total_bytes)
+{
+    if (!c) return KLT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(c, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return KLT_OK;
+}
+
 int klt_slot_generation(klt_ctx *c, int slot, uint64_t *gen)
 {
     if (!c || !gen) return KLT_ERR_ARG;

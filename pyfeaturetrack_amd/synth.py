@@ -68,6 +68,36 @@ def synth_frame(width, height, seed, k, shift=DEFAULT_SHIFT, base=None):
     return shift_frame(base, k * shift[0], k * shift[1])
 
 
+def sequence_phases(width, height, seed, shift=DEFAULT_SHIFT, base=None, workers=1):
+    """frames 0..9 of the sequence: the ten sub-pixel phases periodic_sequence rolls (computed side by side with `workers` threads)"""
+    if base is None:
+        base = synth_base(width, height, seed)
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(workers, 10)) as ex:
+            return list(ex.map(lambda k: synth_frame(width, height, seed, k, shift=shift, base=base), range(10)))
+    return [synth_frame(width, height, seed, k, shift=shift, base=base) for k in range(10)]
+
+
+def periodic_sequence(width, height, seed, count, shift=DEFAULT_SHIFT, base=None, phases=None, start=0):
+    """Generator of `count` frames of a LONG sequence (BASELINE cfg-5: 512 frames of 3840x2160) at a few milliseconds per frame.
+    With a shift whose tenfold is a whole number of pixels (the default 3.3, -2.1) the sub-pixel phase of frame k depends on k % 10
+    only: frames 0..9 are synth_frame's, frame k >= 10 is frame k % 10 rolled by (k // 10) * (10 sx, 10 sy) whole pixels -- the same
+    periodic texture moved by exactly k * (sx, sy).  (synth_frame(k) itself evaluates k * sx in floating point, whose fractional part can
+    differ from that of (k % 10) * sx in the last bit: a frame of this generator is defined by the generator, not by synth_frame.)
+    `phases` = sequence_phases(...) computed once for several passes over the sequence; `start` = first frame to yield."""
+    sx10, sy10 = round(10 * shift[0]), round(10 * shift[1])
+    if abs(10 * shift[0] - sx10) > 1e-9 or abs(10 * shift[1] - sy10) > 1e-9:
+        raise ValueError("periodic_sequence needs a shift whose tenfold is a whole number of pixels")
+    if phases is None and base is None:
+        base = synth_base(width, height, seed)
+    made = list(phases) if phases is not None else []
+    for k in range(start, count):
+        while len(made) <= k % 10:                          # `phases` (sequence_phases) given: nothing to compute
+            made.append(synth_frame(width, height, seed, len(made), shift=shift, base=base))
+        yield made[k] if k < 10 else np.roll(made[k % 10], ((k // 10) * sy10, (k // 10) * sx10), axis=(0, 1))
+
+
 def synth_pair(width, height, seed, shift=DEFAULT_SHIFT):
     base = synth_base(width, height, seed)
     return shift_frame(base, 0.0, 0.0), shift_frame(base, shift[0], shift[1])

@@ -859,7 +859,7 @@ def test_cfg5_blocks_with_the_baton_on_one_rank(tmp_path):
     cfg = line["config"]
     assert line["n_gpus"] == 1 and cfg["rccl_ranks"] == 1 and line["value"] > 0
     assert cfg["baton_copy_ok"] is True and cfg["live_after_each_block"] == [20000]
-    plain = _run_bench(["--config", "cfg5", "--steps", "7", "--repeats", "5"])
+    plain = _run_bench(["--config", "cfg5", "--frames", "8", "--steps", "7", "--repeats", "5", "--min-timed-s", "1"])
     assert plain["config"]["live_at_end"] == 20000 and plain["config"]["scores_prepared"] is True
     assert plain["parity_checked"] is True and plain["roofline"]["step_frac"] < 1 and plain["cpu_baseline"]["value"] > 0
 

@@ -3,7 +3,7 @@
 # -> gpurun_out/sq_counters_<tag>_<cfg>.json (tools/pmc_sq.py: counters per launch of every kernel family, largest launch)
 TAG=${1:-vX}; CFG=${2:-cfg3}
 O=gpurun_out
-ST=20; [ $CFG = cfg5 ] && ST=14
+ST=20; [ $CFG = cfg5 ] && ST="14 --frames 8"
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32" \

@@ -45,7 +45,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_select -o run -- python3 tools/profile_select.py 50 > $O/prof_${TAG}_select.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_cfg3 -o run -- python3 bench.py --config cfg3 --steps 100 --warmup 10 --min-timed-s 0 --repeats 5 --no-cpu-baseline > $O/prof_${TAG}_cfg3.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_cfg4 -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 30 --warmup 3 --min-timed-s 0 --repeats 5 --no-cpu-baseline > $O/prof_${TAG}_cfg4.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_cfg5 -o run -- python3 bench.py --config cfg5 --steps 28 --min-timed-s 0 --repeats 5 --no-cpu-baseline > $O/prof_${TAG}_cfg5.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_cfg5 -o run -- python3 bench.py --config cfg5 --frames 32 --steps 31 --min-timed-s 0 --repeats 5 --no-cpu-baseline > $O/prof_${TAG}_cfg5.log 2>&1
 python3 tools/api_probe.py > $O/api_probe_$TAG.json 2>> $O/bench_$TAG.err
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${TAG}_cfg4_fetch -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 10 --warmup 2 --min-timed-s 0 --repeats 3 --no-cpu-baseline > $O/pmc_${TAG}_cfg4_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${TAG}_cfg4_write -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 10 --warmup 2 --min-timed-s 0 --repeats 3 --no-cpu-baseline > $O/pmc_${TAG}_cfg4_write.log 2>&1
