@@ -212,6 +212,9 @@ struct klt_ctx {
     double acc_ms[F_COUNT] = {0}, acc_bytes[F_COUNT] = {0};
     unsigned acc_n[F_COUNT] = {0};
     unsigned acc_unstamped[F_COUNT] = {0};    // timing mode 2: scopes of a family whose launch did not go through klt_launch (nothing measured)
+    // experiment (tools/graph_frame_probe.py, profiles/README.md "HIP graphs"): one frame's launch set captured into a HIP graph and replayed
+    bool capturing = false;                   // the streams are being captured: nothing may synchronise or allocate
+    hipGraphExec_t probe_graph = nullptr;
 };
 
 namespace {
@@ -303,6 +306,7 @@ template <typename T>
 int ensure(klt_ctx *c, T *&ptr, size_t &cap, size_t want)
 {
     if (want <= cap && ptr) return 0;
+    if (c->capturing) return fail(c, KLT_ERR_STATE, "a buffer would have to grow during a stream capture");
     if (ptr) { if (int rc = sync_all(c)) return rc; HIPCHK(c, hipFree(ptr)); ptr = nullptr; cap = 0; }
     HIPCHK(c, hipMalloc((void **)&ptr, want * sizeof(T)));
     cap = want;
@@ -388,7 +392,8 @@ bool event_live(const klt_ctx *c, uint64_t serial) { return c->ring_serial - ser
 int wait_upload(klt_ctx *c, Slot *s, hipStream_t consumer)
 {
     if (!s->upload_pending) return 0;
-    if (event_live(c, s->upload_serial)) HIPCHK(c, hipStreamWaitEvent(consumer, s->ev_upload, 0));
+    if (c->capturing) { }                                   // (the capturing caller has waited for the copy on the host)
+    else if (event_live(c, s->upload_serial)) HIPCHK(c, hipStreamWaitEvent(consumer, s->ev_upload, 0));
     else HIPCHK(c, hipStreamSynchronize(c->cstream));
     s->upload_pending = false;
     return 0;
@@ -428,7 +433,7 @@ int wait_built(klt_ctx *c, Slot *s)
     // microseconds of queue time each)
     if (s->built_serial != c->waited_built_serial) {
         if (event_live(c, s->built_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, s->ev_built, 0));
-        else HIPCHK(c, hipStreamSynchronize(c->bstream));
+        else if (!c->capturing) HIPCHK(c, hipStreamSynchronize(c->bstream));
         c->waited_built_serial = s->built_serial;
     }
     s->built_pending = false;
@@ -1502,7 +1507,7 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
     } consume{pre};
     if (pre) {
         if (event_live(c, pre->ev_serial)) HIPCHK(c, hipStreamWaitEvent(c->stream, pre->ev, 0));
-        else if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
+        else if (c->bstream && !c->capturing) HIPCHK(c, hipStreamSynchronize(c->bstream));
     } else {
         // summed-area tables (goodFeaturesUtils.pyx:49-51)
         if (int rc = enqueue_sat(c, c->stream, gx, gy, c->sat, nc, nr)) return rc;
@@ -2528,6 +2533,66 @@ int klt_pyramid_f32(klt_ctx *c, const float *src, int ncols, int nrows, int nlev
     hipFree(d_in);
     if (e != hipSuccess) return fail(c, KLT_ERR_DEVICE, hipGetErrorString(e));
     return KLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ experiment: a frame as a HIP graph
+// Not part of include/klt_gpu.h.  op 0: every stream idle, the cross-stream bookkeeping forgotten (no event recorded before the capture
+// is waited for inside it), capture begins on the main stream; the caller then enqueues ONE frame's work through the ordinary *_async
+// entry points -- the build first, so that the build stream forks off the main stream at the graph's root.  op 1: the build stream joins,
+// the capture ends, the graph is instantiated; the selection the capture left pending is dropped (its launches are in the graph).
+// op 2: hipGraphLaunch on the main stream.  op 3: destroy.  Returns the node count from op 1.
+int klt_debug_graph(klt_ctx *c, int op)
+{
+    if (!c) return KLT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    auto forget = [&]() {
+        for (Slot &s : c->slots) { s.upload_pending = s.built_pending = s.read_valid = s.consumed_valid = s.consumed_alt_valid = false; }
+        c->ring_serial += kEventRing;                 // every event handed out so far counts as re-used: nobody waits for it any more
+        c->last_build_on_bstream = -1;                // the next build on the build stream orders itself behind the main stream
+        c->waited_built_serial = ~0ull;
+    };
+    if (op == 0) {
+        if (c->capturing) return fail(c, KLT_ERR_STATE, "already capturing");
+        if (int rc = sync_all(c)) return rc;
+        forget();
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        c->capturing = true;
+        return KLT_OK;
+    }
+    if (op == 1) {
+        if (!c->capturing) return fail(c, KLT_ERR_STATE, "not capturing");
+        c->capturing = false;
+        hipError_t e = hipSuccess;
+        if (c->bstream && c->last_build_on_bstream == 1) {         // the build stream took part: its tail joins the main stream
+            hipEvent_t j;
+            if (int rc = fresh_event(c, &j)) return rc;
+            e = hipEventRecord(j, c->bstream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, j, 0);
+        }
+        hipGraph_t g = nullptr;
+        const hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+        c->sel_job.reset();
+        forget();
+        if (e != hipSuccess) return fail(c, KLT_ERR_DEVICE, std::string("join: ") + hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(c, KLT_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e2));
+        size_t nodes = 0;
+        hipGraphGetNodes(g, nullptr, &nodes);
+        if (c->probe_graph) { hipGraphExecDestroy(c->probe_graph); c->probe_graph = nullptr; }
+        const hipError_t e3 = hipGraphInstantiate(&c->probe_graph, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e3 != hipSuccess) return fail(c, KLT_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e3));
+        return (int)nodes;
+    }
+    if (op == 2) {
+        if (!c->probe_graph) return fail(c, KLT_ERR_STATE, "no graph");
+        HIPCHK(c, hipGraphLaunch(c->probe_graph, c->stream));
+        return KLT_OK;
+    }
+    if (op == 3) {
+        if (c->probe_graph) { hipGraphExecDestroy(c->probe_graph); c->probe_graph = nullptr; }
+        return KLT_OK;
+    }
+    return fail(c, KLT_ERR_ARG, "unknown op");
 }
 
 // ------------------------------------------------------------------------------------------ timing

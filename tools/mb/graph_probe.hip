@@ -4,13 +4,16 @@
 //       hipMemcpyAsync as captured nodes;
 //   (3) a kernel in the middle of a graph publishing a word to pinned host memory (system-scope store) that the host polls while the rest
 //       of the graph is still running -- the host's "look" at a selection's outcome without an event;
-//   (4) kernels that index through a device-side counter they advance themselves, so that one graph serves every frame.
+//   (4) kernels that index through a device-side counter they advance themselves, so that one graph serves every frame;
+//   (5) the same eager frame with the side stream's launches issued by a second host thread (two enqueue threads, one per stream).
 // Build: hipcc -O3 --offload-arch=gfx950 tools/mb/graph_probe.hip -o tools/mb/graph_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <atomic>
+#include <thread>
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -50,7 +53,7 @@ int main()
     CHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
     unsigned *acc, *counter, *row, *src, *table, *scratch;
     CHK(hipMalloc(&acc, 4)); CHK(hipMalloc(&counter, 4)); CHK(hipMalloc(&row, 4));
-    const int N = 4096, ROWS = 600;
+    const int N = 4096, ROWS = 1200;
     CHK(hipMalloc(&src, N * 4)); CHK(hipMalloc(&table, (size_t)N * ROWS * 4)); CHK(hipMalloc(&scratch, 1 << 20));
     CHK(hipMemset(acc, 0, 4)); CHK(hipMemset(counter, 0, 4)); CHK(hipMemset(row, 0, 4)); CHK(hipMemset(src, 0, N * 4));
     unsigned *host_word;
@@ -140,5 +143,52 @@ int main()
     for (int f = 0; f < F; f++) if (enqueue_frame(false)) return 1;
     CHK(hipStreamSynchronize(s0)); CHK(hipStreamSynchronize(s1));
     printf("eager : %.1f us per frame when enqueued back to back (no look)\n", (now_us() - t0) / F);
+
+    // ---- eager with two enqueue threads: the helper issues the side stream's work of frame f as soon as the main thread has recorded
+    // the frame's fork event; the main thread waits for the helper's join event to be recorded before it makes its stream wait for it
+    {
+        std::vector<hipEvent_t> forks(F + 8), joins(F + 8);
+        for (auto &e : forks) CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : joins) CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        std::atomic<int> forked{0}, joined{0};
+        std::atomic<bool> stop{false};
+        double helper_busy = 0;
+        std::thread helper([&] {
+            hipSetDevice(0);
+            for (int f = 0; f < F; f++) {
+                while (forked.load(std::memory_order_acquire) <= f) { if (stop.load()) return; }
+                const double a = now_us();
+                hipStreamWaitEvent(s1, forks[f], 0);
+                hipMemsetAsync(scratch, 0, 1 << 20, s1);
+                for (int i = 0; i < 8; i++) hipLaunchKernelGGL(spin, dim3(64), dim3(256), 0, s1, 2 * T3, acc);
+                hipMemcpyAsync(scratch + 1024, scratch, 4096, hipMemcpyDeviceToDevice, s1);
+                hipEventRecord(joins[f], s1);
+                helper_busy += now_us() - a;
+                joined.store(f + 1, std::memory_order_release);
+            }
+        });
+        unsigned base = 0;
+        CHK(hipMemcpy(&base, counter, 4, hipMemcpyDeviceToHost));
+        double main_busy = 0;
+        t0 = now_us();
+        for (int f = 0; f < F; f++) {
+            const double a = now_us();
+            CHK(hipEventRecord(forks[f], s0));
+            forked.store(f + 1, std::memory_order_release);
+            for (int i = 0; i < 12; i++) hipLaunchKernelGGL(spin, dim3(64), dim3(256), 0, s0, T3, acc);
+            hipLaunchKernelGGL(publish, dim3(1), dim3(64), 0, s0, counter, host_word, acc);
+            while (joined.load(std::memory_order_acquire) <= f) { }
+            CHK(hipStreamWaitEvent(s0, joins[f], 0));
+            for (int i = 0; i < 2; i++) hipLaunchKernelGGL(spin, dim3(64), dim3(256), 0, s0, 5 * T3, acc);
+            hipLaunchKernelGGL(append_row, dim3(1), dim3(256), 0, s0, src, table, row, N);
+            main_busy += now_us() - a;
+            while (*(volatile unsigned *)host_word < base + f + 1) { }
+        }
+        CHK(hipStreamSynchronize(s0)); CHK(hipStreamSynchronize(s1));
+        const double two = (now_us() - t0) / F;
+        stop.store(true);
+        helper.join();
+        printf("eager, two enqueue threads: %.1f us per frame wall; main thread %.1f us, helper %.1f us of enqueue per frame\n", two, main_busy / F, helper_busy / F);
+    }
     return 0;
 }
