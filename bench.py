@@ -1322,24 +1322,31 @@ def run_cfg2(args, json_fd):
             ctx.featbuf_view(TAB + 1 + k, TAB, k * NFEAT, NFEAT)
         npipe = 8 * NT
 
-        def pipelined_step(i):
+        def send(i):                         # the two frames of pair i leave on the two copy streams
             lp = i % NPIN
             ctx.upload_async(2 * lp, pins[lp][0])
             ctx.upload_async(2 * lp + 1, pins[lp][1])
+
+        def pipelined_step(i):
+            # the NEXT pair's frames are sent before this pair's kernels are enqueued: the link works on pair i + 1 while the GPU works on
+            # pair i (four pairs of slots in rotation; a slot's raw buffers alternate, so the copy never waits for the build before last)
+            lp = i % NPIN
+            send(i + 1)
             ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
             ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, TAB + 1 + i % NT, NFEAT)
             return ctx.featbuf_download(TAB, NT * NFEAT) if i % NT == NT - 1 else None
 
+        send(0)
         for i in range(NT):                 # warm-up: the alternate raw buffers are allocated on first use
             table = pipelined_step(i)
         ctx.sync()
         t = time.perf_counter()
-        for i in range(npipe):
+        for i in range(NT, NT + npipe):
             got = pipelined_step(i)
             table = got if got is not None else table
         ctx.sync()
         ms_pipe = (time.perf_counter() - t) / npipe * 1e3
-        last_lp = (npipe - 1) % NPIN
+        last_lp = (NT + npipe - 1) % NPIN
         assert np.array_equal(table[-NFEAT:]["x"], outs[pair_index(0, last_lp)]["x"]), "pipelined ingest changed the result"
         extra = {"region_ms_per_step": reg,
                  "overlapped_ms_per_pair": ms_per_pair,
@@ -1357,8 +1364,17 @@ def run_cfg2(args, json_fd):
                          "= H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the records, synchronised per "
                          "pair; pcie_pipelined = the same bytes with klt_upload_u8_async from pinned memory on a copy stream and the "
                          "records read back every 16 pairs"}
+        link = link_rates()
+        extra["pcie_pipelined_GBps"] = 2 * WIDTH * HEIGHT / (ms_pipe * 1e-3) / 1e9
+        if link:
+            extra["pcie_link"] = link
+            extra["pcie_pipelined_frac_of_link"] = extra["pcie_pipelined_GBps"] / link["1080p"]
         if not args.no_api:
             extra.update(api_figures(frames[0], tc))
+        if not args.no_sequences:
+            extra["sequence_from_host"] = {"1080p": sequence_from_host(ranks.local_rank, 1920, 1080, 5000, 256, link.get("1080p")),
+                                           "4k": sequence_from_host(ranks.local_rank, 3840, 2160, 20000, 128, link.get("4k")),
+                                           "note": sequence_from_host.__doc__.split("  Secondary")[0].replace("\n    ", " ")}
 
     cpu = None
     if rank == 0 and not distributed and not args.no_cpu_baseline and ko:
@@ -1409,6 +1425,99 @@ def run_cfg2(args, json_fd):
     if line is not None:
         emit(json_fd, line)
         fail_on_parity(parity)
+
+
+def sequence_from_host(device, w, h, n, nframes=256, link_gbps=None):
+    """What a video pipeline pays per frame when the frames come from the host: sequential mode, ONE new u8 frame per
+    step from pinned host memory (klt_upload_u8_async on the copy streams, overlapping the previous frame's kernels), pyramid of the new
+    frame + score preparation on the build stream, track + replacement of the lost features on the main stream, the next tracker enqueued
+    ahead of the host's look -- the loop of `--config cfg5` with an upload per frame -- and the records written into a device table of 16
+    rows that is downloaded every 16 frames.  16 distinct frames of the periodic texture sit in pinned memory and are visited up and down
+    (0, 1, ... 15, 14, ... 0, ...), so consecutive frames always differ by one step of (3.3, -2.1) pixels.  Secondary figure, never `value`."""
+    tc = cfg2_context()
+    tc.max_residue = 10.0
+    ctx = Context(device)
+    ctx.configure(tc)
+    try:
+        NPIN, NT = 16, 16
+        phases = synth.sequence_phases(w, h, 4, workers=usable_cores(10))
+        pins = []
+        for f in synth.periodic_sequence(w, h, 4, NPIN, phases=phases):
+            a = ctx.pinned_array((h, w))
+            a[:] = f
+            pins.append(a)
+        order = list(range(NPIN)) + list(range(NPIN - 2, 0, -1))              # 0..15..1: period 30
+        S = [0, 1, 2]
+        TAB, HALF = 100, (200, 201)                                           # 2 x 16 rows: one half fills while the other is read back
+        ctx.featbuf_alloc(TAB, 2 * NT * n)
+        for k in range(2 * NT):
+            ctx.featbuf_view(TAB + 1 + k, TAB, k * n, n)
+        for i in range(2):
+            ctx.featbuf_view(HALF[i], TAB, i * NT * n, NT * n)
+        row = lambda k: TAB + 1 + k % (2 * NT)                                # noqa: E731
+        ctx.set_option(15, 1)                                                 # KLT_OPT_BUILD_STREAM
+
+        def send(k):                         # frame k leaves for its slot (the copy overlaps whatever the GPU is doing)
+            ctx.upload_async(S[k % 3], pins[order[k % len(order)]])
+
+        def stage(k):
+            ctx.build_pyramids(S[k % 3], sync=False)
+            ctx.select_prepare(S[k % 3])
+
+        def track(k):
+            ctx.track_async(S[(k - 1) % 3], S[k % 3], row(k - 1), row(k), n)
+
+        def run(count):
+            live = None
+            send(0)
+            ctx.build_pyramids(S[0], sync=False)
+            ctx.select_async(S[0], 1, True, row(0), n)
+            send(1)
+            send(2)
+            stage(1)
+            track(1)
+            send(3)
+            for k in range(1, count):
+                ctx.select_begin(S[k % 3], 2, True, row(k), n)
+                stage(k + 1)
+                track(k + 1)
+                if ctx.select_finish():
+                    track(k + 1)
+                # frame k + 3 goes into the slot of frame k, whose pyramids only the tracker just enqueued (k -> k + 1) still reads: the copy fills
+                # the slot's other raw buffer, two frame times before its build needs it (a frame sent one step ahead is not there
+                # in time: 155 us of copy + the build = the whole frame time at 4K).  After the look: a repeated tracker needs slot k valid.
+                send(k + 3)
+                if k % NT == NT - 1:
+                    # the half holding rows k-15 .. k is complete once frame k's selection is; the tracker of k+1 already writes into the
+                    # other half.  (The download waits for the main stream.)
+                    live = ctx.featbuf_download(HALF[(k // NT) % 2], NT * n)
+            ctx.sync()
+            return live
+
+        run(2 * NT)                                                           # sizes every buffer
+        t = time.perf_counter()
+        table = run(nframes)
+        ms = (time.perf_counter() - t) / (nframes - 1) * 1e3
+        alive = int((table.reshape(NT, n)[NT - 2]["val"] >= 0).sum())
+        gbps = w * h / (ms * 1e-3) / 1e9
+        out = {"ms_per_frame": ms, "features_per_s": n / (ms * 1e-3), "frames": nframes, "ingest_GBps": gbps,
+               "alive_after_replacement": alive, "frame": "%dx%d" % (w, h), "features": n}
+        if link_gbps:
+            out["link_GBps"] = link_gbps
+            out["ingest_frac_of_link"] = gbps / link_gbps
+        return out
+    finally:
+        ctx.close()
+
+
+def link_rates():
+    """profiles/r04_h2d_probe.json (tools/h2d_probe.cpp on the builder's GPU box): what pinned host-to-device copies of one frame sustain"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_h2d_probe.json")))
+        return {"1080p": d["h2d_1080p_2.07MB"]["two_streams_GBps"], "4k": d["h2d_4k_8.29MB"]["two_streams_GBps"],
+                "source": "profiles/r04_h2d_probe.json (tools/h2d_probe.cpp, builder gpurun): pinned H2D on two copy streams"}
+    except (OSError, KeyError, ValueError):
+        return {}
 
 
 def api_figures(pair, tc):
@@ -1479,6 +1588,7 @@ def main():
                     help="skip the secondary figures (selection, one pair at a time, PCIe-inclusive, Python API): a profiler then sees only "
                          "the launches of the timed regions and of the roofline pass, all of the headline's size")
     ap.add_argument("--no-api", action="store_true", help="skip the reference-shaped Python API figures in `extra`")
+    ap.add_argument("--no-sequences", action="store_true", help="skip extra.sequence_from_host (a 1080p and a 4K sequence fed from pinned host memory)")
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 (default, the headline line); cfg4 = the 256-pair batch sharded over --gpus ranks; the others are "
                          "the remaining BASELINE configs on one GPU")

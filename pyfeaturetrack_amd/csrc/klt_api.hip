@@ -101,6 +101,12 @@ struct klt_ctx {
     int device = -1;
     hipStream_t stream = nullptr;     // uploads, pyramid build, selection, tracker
     hipStream_t cstream = nullptr;    // asynchronous frame ingest from pinned host memory (created on first use)
+    // ... and more copy streams: consecutive uploads go round-robin over all of them, i.e. over several DMA engines (2 MB frames: 44 GB/s
+    // on one stream, 55 GB/s on two -- profiles/r04_h2d_probe.json), and a stream's next copy is not queued right behind the event of its last one
+    static constexpr int kMaxCopyStreams = 8;
+    hipStream_t cextra[kMaxCopyStreams - 1] = {nullptr};
+    int ncopy = 2;                    // copy streams in use (KLT_COPY_STREAMS)
+    unsigned upload_count = 0;
     hipStream_t bstream = nullptr;    // KLT_OPT_BUILD_STREAM: pyramid builds run here, overlapping the tracker / selection of earlier frames
     hipStream_t work = nullptr;       // stream the pyramid-build helpers enqueue on: `stream`, or `bstream` inside a build
     bool build_stream_on = false;
@@ -295,6 +301,7 @@ int sync_all(klt_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
+    for (hipStream_t x : c->cextra) if (x) HIPCHK(c, hipStreamSynchronize(x));
     if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
     // (a communicator whose collective timed out is left alone: the wait that found out has reported it, and calls that only free
     // host memory or lay out a pyramid must not fail because of it -- the main stream is idle at this point, which is what they need)
@@ -394,7 +401,7 @@ int wait_upload(klt_ctx *c, Slot *s, hipStream_t consumer)
     if (!s->upload_pending) return 0;
     if (c->capturing) { }                                   // (the capturing caller has waited for the copy on the host)
     else if (event_live(c, s->upload_serial)) HIPCHK(c, hipStreamWaitEvent(consumer, s->ev_upload, 0));
-    else HIPCHK(c, hipStreamSynchronize(c->cstream));
+    else { HIPCHK(c, hipStreamSynchronize(c->cstream)); for (hipStream_t x : c->cextra) if (x) HIPCHK(c, hipStreamSynchronize(x)); }
     s->upload_pending = false;
     return 0;
 }
@@ -474,7 +481,11 @@ int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int p
     HIPCHK(c, hipSetDevice(c->device));
     Slot *s;
     if (int rc = get_slot(c, slot, &s, true)) return rc;
-    if (s->upload_pending) { HIPCHK(c, hipStreamSynchronize(c->cstream)); s->upload_pending = false; }
+    if (s->upload_pending) {
+        HIPCHK(c, hipStreamSynchronize(c->cstream));
+        for (hipStream_t x : c->cextra) if (x) HIPCHK(c, hipStreamSynchronize(x));
+        s->upload_pending = false;
+    }
     if (int rc = wait_built(c, s)) return rc;                 // a build on the build stream may still read the old frame
     const size_t px_count = (size_t)ncols * nrows;
     if (kind == 1) { if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc; }
@@ -856,6 +867,7 @@ int klt_create(int device, klt_ctx **out)
     c->work = c->stream;
     if (const char *v = getenv("KLT_FUSED_HREDUCE")) c->fuse_hreduce = atoi(v) != 0;      // experiment hook (initial value of the option)
     if (const char *v = getenv("KLT_TRACK_XCD_ORDER")) c->track_xcd_order = atoi(v) != 0;
+    if (const char *v = getenv("KLT_COPY_STREAMS")) { const int k = atoi(v); c->ncopy = k < 1 ? 1 : (k > klt_ctx::kMaxCopyStreams ? klt_ctx::kMaxCopyStreams : k); }
     *out = c;
     return KLT_OK;
 }
@@ -875,6 +887,7 @@ void klt_destroy(klt_ctx *c)
     }
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
+    for (hipStream_t x : c->cextra) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
     if (c->bstream) { hipStreamSynchronize(c->bstream); hipStreamDestroy(c->bstream); }
     if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
     for (void *p : c->pinned) hipHostFree(p);
@@ -901,6 +914,7 @@ int klt_sync(klt_ctx *c)
 {
     if (!c) return KLT_ERR_ARG;
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
+    for (hipStream_t x : c->cextra) if (x) HIPCHK(c, hipStreamSynchronize(x));
     if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->comm) { std::string err; if (int rc = comm_wait(c->comm, err)) return fail(c, rc, err); }
@@ -994,6 +1008,9 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
         return fail(c, KLT_ERR_ARG, "klt_upload_u8_async needs pinned host memory (klt_host_alloc)");
     }
     if (!c->cstream) HIPCHK(c, hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    const int lane = (int)(c->upload_count++ % (unsigned)c->ncopy);                 // the two frames of a pair travel side by side
+    if (lane > 0 && !c->cextra[lane - 1]) HIPCHK(c, hipStreamCreateWithFlags(&c->cextra[lane - 1], hipStreamNonBlocking));
+    const hipStream_t cs = lane == 0 ? c->cstream : c->cextra[lane - 1];
     Slot *s;
     if (int rc = get_slot(c, slot, &s, true)) return rc;
     const size_t px_count = (size_t)ncols * nrows;
@@ -1010,17 +1027,22 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
         } else {
-            const hipError_t q = hipEventQuery(s->ev_consumed);
-            if (q != hipSuccess) (void)hipGetLastError();         // ("not ready" must not surface in a later hipGetLastError check)
-            if (q == hipErrorNotReady) HIPCHK(c, hipEventSynchronize(s->ev_consumed));
-            else if (q != hipSuccess) return fail(c, KLT_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+            // poll: the build in question is at most a few launches from done, and hipEventSynchronize wakes the host 50-100 us late --
+            // long enough for the queues to run dry behind it (tools/ingest_probe.py: 246 us per pair with the blocking wait)
+            hipError_t q = hipEventQuery(s->ev_consumed);
+            for (long spins = 0; q == hipErrorNotReady; spins++) {
+                (void)hipGetLastError();                          // ("not ready" must not surface in a later hipGetLastError check)
+                if (spins > 2000000) { HIPCHK(c, hipEventSynchronize(s->ev_consumed)); q = hipSuccess; break; }   // (seconds: something else is wrong)
+                q = hipEventQuery(s->ev_consumed);
+            }
+            if (q != hipSuccess) return fail(c, KLT_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
         }
         s->consumed_valid = false;
     }
-    if (pitch == ncols) HIPCHK(c, hipMemcpyAsync(s->u8, px, px_count, hipMemcpyHostToDevice, c->cstream));
-    else HIPCHK(c, hipMemcpy2DAsync(s->u8, (size_t)ncols, px, (size_t)pitch, (size_t)ncols, nrows, hipMemcpyHostToDevice, c->cstream));
+    if (pitch == ncols) HIPCHK(c, hipMemcpyAsync(s->u8, px, px_count, hipMemcpyHostToDevice, cs));
+    else HIPCHK(c, hipMemcpy2DAsync(s->u8, (size_t)ncols, px, (size_t)pitch, (size_t)ncols, nrows, hipMemcpyHostToDevice, cs));
     if (int rc = fresh_event(c, &s->ev_upload, &s->upload_serial)) return rc;
-    HIPCHK(c, hipEventRecord(s->ev_upload, c->cstream));
+    HIPCHK(c, hipEventRecord(s->ev_upload, cs));
     s->upload_pending = true;
     s->nc = ncols;
     s->nr = nrows;
@@ -1034,6 +1056,7 @@ int klt_upload_wait(klt_ctx *c)
     if (!c) return KLT_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
+    for (hipStream_t x : c->cextra) if (x) HIPCHK(c, hipStreamSynchronize(x));
     return KLT_OK;
 }
 

@@ -120,23 +120,30 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
             tables.append(base)
         return tables[ci] + 1 + off
 
-    stage_key = ((nrows, ncols), ring + 1)
+    stage_key = ((nrows, ncols), ring + 3)      # frames k+1 .. k+3 on their way, one being filled by the helper thread, one spare
     stage = ctx.staging(*stage_key) if async_ingest and first.dtype == np.uint8 else None
     in_flight = []                          # staging buffer whose host-to-device copy may still be running
 
-    def ingest(slot, img, k, staged=False):
+    def ingest(slot, img, k, staged=False, wait=True):
         if img.shape != (nrows, ncols):
             from .error import KLTError
             KLTError("(KLTTrackSequence) Size of incoming image ({0} by {1}) is different from size of previous image "
                      "({2} by {3})".format(img.shape[1], img.shape[0], ncols, nrows))
         if staged:
-            ctx.upload_wait()               # the previous frame's copy has finished (kernels keep running): its buffer goes back
-            while in_flight:
-                stager.release(in_flight.pop())
+            if wait:
+                ctx.upload_wait()           # the previous frame's copy has finished (kernels keep running): its buffer goes back
+                while in_flight:
+                    stager.release(in_flight.pop()[1])
             ctx.upload_async(slot, img)
-            in_flight.append(img)
+            in_flight.append((k, img))
         else:
             ctx.upload(slot, img)
+
+    def landed(k):
+        """frame k's selection has completed, so its pyramid was built, so its copy has left the staging buffer: the buffer goes back
+        (no host wait for the copy streams -- klt_upload_wait costs the host the rest of the copy)"""
+        while in_flight and in_flight[0][0] <= k:
+            stager.release(in_flight.pop(0)[1])
 
     ingest(s[0], first, 0)
     ctx.build_pyramids(s[0], sync=False)
@@ -180,11 +187,46 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
         # look makes the selection rewrite the list, the tracker is enqueued once more.  Not with the affine check: it updates the
         # per-feature state in place, so its launch cannot simply be repeated.
         ahead = prefetch and replace_lost and not affine
-        nxt = next_frame()
-        if nxt is not None:
-            stage_frame(1, nxt)
-            if ahead:
+        if ahead:
+            # Frames are SENT two steps before their pyramid is built: frame k + 3 leaves for the slot of frame k (its other raw buffer) at the
+            # end of step k, while the tracker k -> k + 1 still reads that slot's pyramids.  Sent one step ahead, a 4K frame's 155 us copy and
+            # its build sit behind each other in front of the tracker that needs them (0.329 instead of 0.277 ms per frame, profiles/README.md).
+            def send(j):
+                item = next_frame()
+                if item is not None:
+                    ingest(s[j % ring], item[1], j, staged=item[0] == "staged", wait=False)
+                return item is not None
+
+            def build(j):
+                ctx.build_pyramids(s[j % ring], sync=False)
+                ctx.select_prepare(s[j % ring])
+
+            have = 0                                 # frames sent so far beyond frame 0: 1 .. have
+            for j in (1, 2):
+                if send(j):
+                    have = j
+            if have >= 1:
+                build(1)
                 track(1)
+            if have == 2 and send(3):                # into frame 0's slot, which only the tracker just enqueued still reads
+                have = 3
+            while k + 1 <= have:
+                k += 1
+                ctx.select_begin(s[k % ring], REPLACING_SOME, True, row_fb(k), nFeatures)
+                if k + 1 <= have:
+                    build(k + 1)
+                    track(k + 1)
+                if ctx.select_finish() and k + 1 <= have:
+                    track(k + 1)
+                if stager is not None:
+                    landed(k)
+                if have == k + 2 and send(k + 3):    # (after the look: a repeated tracker needs slot k's pyramids valid)
+                    have = k + 3
+            nxt = None
+        else:
+            nxt = next_frame()
+            if nxt is not None:
+                stage_frame(1, nxt)
         while nxt is not None:
             k += 1
             nxt = next_frame()
