@@ -4,12 +4,21 @@
 // so the N > 1 code of csrc/comm.hip, klt_api.hip and bench.py (per-rank counts of the gather, the feature list as a baton between
 // ranks, all-gather of the record tables, barrier / max over ranks) would only ever meet a single rank.  This library exports the ten
 // RCCL entry points comm.hip binds, with the same signatures (rccl.h), and moves the bytes through files in a directory all ranks
-// share (KLT_STUB_RCCL_DIR): every operation first waits for the stream it was given (so the producer's work is complete), copies device
-// -> host -> file, and the receiving side polls for the file and copies host -> device, synchronously.  Point KLT_RCCL_LIB at the built
-// library and give every rank the same device (KLT_RANKS_SHARE_DEVICE=0): tests/test_gpu_multirank.py.
+// share (KLT_STUB_RCCL_DIR).  Point KLT_RCCL_LIB at the built library and give every rank the same device (KLT_RANKS_SHARE_DEVICE=0):
+// tests/test_gpu_multirank.py.
 //
-// It is NOT a communication library: no overlap, no performance, one node, trusted peers.  It exists so that rank arithmetic, buffer
-// offsets, ordering and teardown of the real code are exercised by more than one process.
+// ASYNCHRONOUS, like the library it stands in for (round 4; the first version waited for the stream and copied synchronously inside every
+// call, which serialised everything and could hide ordering mistakes of the caller):
+//   * an entry point only ENQUEUES: device -> pinned copies of what is sent, ONE host function on the caller's stream (hipLaunchHostFunc)
+//     that exchanges the files, pinned -> device copies of what is received.  The call returns at once; the stream -- and nothing else --
+//     is held until the exchange is through, so work the caller enqueues behind the collective waits for it and work on other streams
+//     does not;
+//   * operations between ncclGroupStart and ncclGroupEnd form one batch per (communicator, stream): inside the host function they are
+//     carried out in RANDOM order with RANDOM delays (0 .. KLT_STUB_RCCL_MAX_DELAY_US, default 1500 us; every send before any receive, so
+//     that no order of a group's operations can deadlock -- a group's operations progress together in the real library too);
+//   * a receive may be posted long before its send exists: it polls; a send never waits for its receiver;
+//   * communicators share nothing: progress on one says nothing about another.
+// What it is NOT: a communication library -- no performance, one node, trusted peers.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -17,10 +26,14 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -30,6 +43,7 @@ struct ncclComm {
     int nranks = 1, rank = 0;
     std::vector<unsigned long long> send_seq, recv_seq;
     unsigned long long coll_seq = 0;
+    std::atomic<bool> failed{false};
 };
 
 namespace {
@@ -81,11 +95,155 @@ size_t type_size(ncclDataType_t t)
     }
 }
 
-ncclResult_t to_host(const void *dev, size_t bytes, hipStream_t s, std::vector<char> &h)
+// ---- one exchange = the operations of a group (or a single call) on one communicator and stream
+enum Kind { SEND, RECV, PUBLISH /* own part of a collective */, COLLECT /* a peer's part of a collective */, REDUCE /* after the COLLECTs: combine */ };
+
+struct Op {
+    Kind kind;
+    std::string path, unlink_first;
+    const void *dev_src = nullptr;
+    void *dev_dst = nullptr;
+    size_t bytes = 0;
+    char *host = nullptr;          // pinned staging
+    bool remove_after = false;
+    int red_op = 0, red_count = 0;
+};
+
+struct Batch {
+    ncclComm *comm = nullptr;
+    std::vector<Op> ops;
+    unsigned long long seed = 0;
+};
+
+std::mutex g_pool_mutex;
+std::vector<std::pair<char *, size_t>> g_pool;      // pinned staging buffers not in use
+
+char *staging(size_t bytes)
 {
-    h.resize(bytes ? bytes : 1);
-    if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;          // the producer's work is complete
-    if (bytes && hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    bytes = bytes ? bytes : 1;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i].second >= bytes && g_pool[i].second <= 4 * bytes + 4096) {
+                char *p = g_pool[i].first;
+                g_pool.erase(g_pool.begin() + (long)i);
+                return p;
+            }
+    }
+    // the size travels in front of the buffer (returned to the pool by give_back)
+    char *p = nullptr;
+    if (hipHostMalloc((void **)&p, bytes + 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+    *reinterpret_cast<size_t *>(p) = bytes;
+    return p + 64;
+}
+
+void give_back(char *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool.emplace_back(p, *reinterpret_cast<size_t *>(p - 64));
+}
+
+unsigned max_delay_us()
+{
+    static const unsigned v = [] { const char *e = getenv("KLT_STUB_RCCL_MAX_DELAY_US"); return e ? (unsigned)atoi(e) : 1500u; }();
+    return v;
+}
+
+std::atomic<unsigned long long> g_batches{0};
+
+// runs on a thread of the HIP runtime, in stream order: no HIP call in here
+void exchange(void *arg)
+{
+    Batch *b = static_cast<Batch *>(arg);
+    std::mt19937_64 rng(b->seed);
+    auto nap = [&] {
+        const unsigned m = max_delay_us();
+        if (m) std::this_thread::sleep_for(std::chrono::microseconds(rng() % (m + 1)));
+    };
+    std::vector<size_t> first, second;
+    for (size_t i = 0; i < b->ops.size(); i++) {
+        const Kind k = b->ops[i].kind;
+        if (k == SEND || k == PUBLISH) first.push_back(i);
+        else if (k == RECV || k == COLLECT) second.push_back(i);
+    }
+    std::shuffle(first.begin(), first.end(), rng);
+    std::shuffle(second.begin(), second.end(), rng);
+    bool ok = !b->comm->failed.load();
+    for (size_t i : first) {
+        Op &o = b->ops[i];
+        nap();
+        if (!o.unlink_first.empty()) unlink(o.unlink_first.c_str());
+        ok = ok && write_file(o.path, o.host, o.bytes);
+    }
+    for (size_t i : second) {
+        Op &o = b->ops[i];
+        nap();
+        ok = ok && read_file_when_there(o.path, o.host, o.bytes);
+        if (ok && o.remove_after) unlink(o.path.c_str());
+    }
+    for (Op &o : b->ops) {
+        if (o.kind != REDUCE || !ok) continue;
+        // o.host: the result; the parts are the COLLECT staging buffers of this batch, in rank order
+        double *res = reinterpret_cast<double *>(o.host);
+        bool have = false;
+        for (const Op &p : b->ops) {
+            if (p.kind != COLLECT) continue;
+            const double *v = reinterpret_cast<const double *>(p.host);
+            for (int i = 0; i < o.red_count; i++)
+                res[i] = !have ? v[i] : (o.red_op == (int)ncclMax ? (v[i] > res[i] ? v[i] : res[i]) : res[i] + v[i]);
+            have = true;
+        }
+    }
+    if (!ok) b->comm->failed.store(true);
+}
+
+void retire(void *arg)
+{
+    Batch *b = static_cast<Batch *>(arg);
+    for (Op &o : b->ops) give_back(o.host);
+    delete b;
+}
+
+// enqueue one batch on `s`: copies out, the exchange, copies in, clean-up
+ncclResult_t submit(Batch *b, hipStream_t s)
+{
+    b->seed = 0x9e3779b97f4a7c15ull * (g_batches.fetch_add(1) + 1) + (unsigned long long)getpid();
+    if (const char *e = getenv("KLT_STUB_RCCL_SEED")) b->seed ^= strtoull(e, nullptr, 10) * 0xbf58476d1ce4e5b9ull;
+    for (Op &o : b->ops) {
+        o.host = staging(o.bytes);
+        if (!o.host) return ncclSystemError;
+        if ((o.kind == SEND || o.kind == PUBLISH) && o.bytes &&
+            hipMemcpyAsync(o.host, o.dev_src, o.bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ncclUnhandledCudaError;
+    }
+    if (hipLaunchHostFunc(s, exchange, b) != hipSuccess) return ncclUnhandledCudaError;
+    for (Op &o : b->ops)
+        if (o.dev_dst && o.bytes && (o.kind == RECV || o.kind == COLLECT || o.kind == REDUCE) &&
+            hipMemcpyAsync(o.dev_dst, o.host, o.bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipLaunchHostFunc(s, retire, b) != hipSuccess) return ncclUnhandledCudaError;
+    return ncclSuccess;
+}
+
+// ---- groups: per calling thread
+thread_local int t_group_depth = 0;
+struct Pending { ncclComm *comm; hipStream_t stream; Batch *batch; };
+thread_local std::vector<Pending> t_pending;
+
+ncclResult_t add_op(ncclComm *c, hipStream_t s, Op &&op)
+{
+    if (c->failed.load()) return ncclSystemError;
+    if (t_group_depth == 0) {
+        Batch *b = new Batch();
+        b->comm = c;
+        b->ops.push_back(std::move(op));
+        return submit(b, s);
+    }
+    for (Pending &p : t_pending)
+        if (p.comm == c && p.stream == s) { p.batch->ops.push_back(std::move(op)); return ncclSuccess; }
+    Batch *b = new Batch();
+    b->comm = c;
+    b->ops.push_back(std::move(op));
+    t_pending.push_back({c, s, b});
     return ncclSuccess;
 }
 
@@ -122,9 +280,17 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     return ncclSuccess;
 }
 
+// (the caller has synchronised the stream its collectives ran on -- comm.hip does -- so no host function still holds the communicator)
 ncclResult_t ncclCommDestroy(ncclComm_t c)
 {
     delete c;
+    return ncclSuccess;
+}
+
+// a communicator whose exchange can never complete: its host functions may still be polling -- leaked, as the caller is about to exit
+ncclResult_t ncclCommAbort(ncclComm_t c)
+{
+    if (c) c->failed.store(true);
     return ncclSuccess;
 }
 
@@ -139,76 +305,95 @@ const char *ncclGetErrorString(ncclResult_t r)
     }
 }
 
-ncclResult_t ncclGroupStart() { return ncclSuccess; }     // every operation completes before it returns: a group is its operations in order
-ncclResult_t ncclGroupEnd() { return ncclSuccess; }
+ncclResult_t ncclGroupStart()
+{
+    t_group_depth++;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupEnd()
+{
+    if (t_group_depth <= 0) return ncclInvalidUsage;
+    if (--t_group_depth > 0) return ncclSuccess;
+    ncclResult_t res = ncclSuccess;
+    for (Pending &p : t_pending) {
+        const ncclResult_t r = submit(p.batch, p.stream);
+        if (r != ncclSuccess && res == ncclSuccess) res = r;
+    }
+    t_pending.clear();
+    return res;
+}
 
 ncclResult_t ncclSend(const void *buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t s)
 {
     if (!c || peer < 0 || peer >= c->nranks || !type_size(t)) return ncclInvalidArgument;
-    std::vector<char> h;
-    if (ncclResult_t r = to_host(buf, count * type_size(t), s, h)) return r;
-    const std::string path = c->dir + "/msg_" + std::to_string(c->rank) + "_" + std::to_string(peer) + "_" + std::to_string(c->send_seq[peer]++);
-    return write_file(path, h.data(), count * type_size(t)) ? ncclSuccess : ncclSystemError;      // never blocks: no send / receive order can deadlock
+    Op o;
+    o.kind = SEND;
+    o.dev_src = buf;
+    o.bytes = count * type_size(t);
+    o.path = c->dir + "/msg_" + std::to_string(c->rank) + "_" + std::to_string(peer) + "_" + std::to_string(c->send_seq[peer]++);
+    return add_op(c, s, std::move(o));
 }
 
 ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t s)
 {
     if (!c || peer < 0 || peer >= c->nranks || !type_size(t)) return ncclInvalidArgument;
-    const size_t bytes = count * type_size(t);
-    std::vector<char> h(bytes ? bytes : 1);
-    const std::string path = c->dir + "/msg_" + std::to_string(peer) + "_" + std::to_string(c->rank) + "_" + std::to_string(c->recv_seq[peer]++);
-    if (!read_file_when_there(path, h.data(), bytes)) return ncclSystemError;
-    unlink(path.c_str());
-    if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
-    if (bytes && hipMemcpy(buf, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-    return ncclSuccess;
+    Op o;
+    o.kind = RECV;
+    o.dev_dst = buf;
+    o.bytes = count * type_size(t);
+    o.remove_after = true;
+    o.path = c->dir + "/msg_" + std::to_string(peer) + "_" + std::to_string(c->rank) + "_" + std::to_string(c->recv_seq[peer]++);
+    return add_op(c, s, std::move(o));
 }
 
-// every rank publishes its part as coll_<seq>_<rank>; a rank removes its own file of operation seq - 2 when it starts operation seq
+// every rank publishes its part as coll_<seq>_<rank>; a rank removes its own file of operation seq - 2 when it carries out operation seq
 // (everybody has read it by then: to publish seq - 1 a rank must have finished seq - 2)
-static ncclResult_t publish_and_collect(ncclComm_t c, const std::vector<char> &mine, size_t bytes, std::vector<std::vector<char>> &all)
+static void add_collective_ops(ncclComm_t c, Batch *b, const void *send, size_t bytes, char *recv_base /* null: staging only */)
 {
     const unsigned long long seq = c->coll_seq++;
-    if (seq >= 2) unlink((c->dir + "/coll_" + std::to_string(seq - 2) + "_" + std::to_string(c->rank)).c_str());
-    if (!write_file(c->dir + "/coll_" + std::to_string(seq) + "_" + std::to_string(c->rank), mine.data(), bytes)) return ncclSystemError;
-    all.assign((size_t)c->nranks, std::vector<char>(bytes ? bytes : 1));
-    for (int r = 0; r < c->nranks; r++)
-        if (!read_file_when_there(c->dir + "/coll_" + std::to_string(seq) + "_" + std::to_string(r), all[r].data(), bytes)) return ncclSystemError;
-    return ncclSuccess;
+    Op pub;
+    pub.kind = PUBLISH;
+    pub.dev_src = send;
+    pub.bytes = bytes;
+    pub.path = c->dir + "/coll_" + std::to_string(seq) + "_" + std::to_string(c->rank);
+    if (seq >= 2) pub.unlink_first = c->dir + "/coll_" + std::to_string(seq - 2) + "_" + std::to_string(c->rank);
+    b->ops.push_back(std::move(pub));
+    for (int r = 0; r < c->nranks; r++) {
+        Op col;
+        col.kind = COLLECT;
+        col.bytes = bytes;
+        col.dev_dst = recv_base ? recv_base + (size_t)r * bytes : nullptr;
+        col.path = c->dir + "/coll_" + std::to_string(seq) + "_" + std::to_string(r);
+        b->ops.push_back(std::move(col));
+    }
 }
 
 ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t s)
 {
     if (!c || !type_size(t)) return ncclInvalidArgument;
-    const size_t bytes = count * type_size(t);
-    std::vector<char> mine;
-    if (ncclResult_t r = to_host(send, bytes, s, mine)) return r;
-    std::vector<std::vector<char>> all;
-    if (ncclResult_t r = publish_and_collect(c, mine, bytes, all)) return r;
-    for (int r = 0; r < c->nranks; r++)
-        if (bytes && hipMemcpy((char *)recv + (size_t)r * bytes, all[r].data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-    return ncclSuccess;
+    if (c->failed.load()) return ncclSystemError;
+    Batch *b = new Batch();
+    b->comm = c;
+    add_collective_ops(c, b, send, count * type_size(t), (char *)recv);
+    return submit(b, s);
 }
 
 ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t s)
 {
     if (!c || t != ncclFloat64 || (op != ncclMax && op != ncclSum)) return ncclInvalidArgument;       // what comm.hip uses
-    const size_t bytes = count * sizeof(double);
-    std::vector<char> mine;
-    if (ncclResult_t r = to_host(send, bytes, s, mine)) return r;
-    std::vector<std::vector<char>> all;
-    if (ncclResult_t r = publish_and_collect(c, mine, bytes, all)) return r;
-    std::vector<double> res(count ? count : 1);
-    for (size_t i = 0; i < count; i++) {
-        double v = reinterpret_cast<const double *>(all[0].data())[i];
-        for (int r = 1; r < c->nranks; r++) {
-            const double w = reinterpret_cast<const double *>(all[r].data())[i];
-            v = op == ncclMax ? (w > v ? w : v) : v + w;
-        }
-        res[i] = v;
-    }
-    if (bytes && hipMemcpy(recv, res.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-    return ncclSuccess;
+    if (c->failed.load()) return ncclSystemError;
+    Batch *b = new Batch();
+    b->comm = c;
+    add_collective_ops(c, b, send, count * sizeof(double), nullptr);
+    Op red;
+    red.kind = REDUCE;
+    red.bytes = count * sizeof(double);
+    red.dev_dst = recv;
+    red.red_op = (int)op;
+    red.red_count = (int)count;
+    b->ops.push_back(std::move(red));
+    return submit(b, s);
 }
 
 }  // extern "C"

@@ -1,6 +1,7 @@
 """Several ranks of the multi-GPU path on ONE GPU: the ranks share device 0 (KLT_RANKS_SHARE_DEVICE) and librccl is replaced by
 tests/stub_rccl (KLT_RCCL_LIB), a file-based stand-in with RCCL's entry points -- RCCL itself refuses two ranks of a communicator on
-one device.  Everything else is the real thing: bench.py's launcher and rendezvous, one process per rank, libkltgpu.so's comm.hip
+one device.  The stand-in is ASYNCHRONOUS (round 4): a call only enqueues, the exchange runs in stream order inside a host function, the
+operations of a group are carried out in random order with random delays, receives may be posted before their sends exist.  Everything else is the real thing: bench.py's launcher and rendezvous, one process per rank, libkltgpu.so's comm.hip
 (gather with per-rank counts, all-gather of the record tables, send / receive of the feature list, barrier and max over ranks), the
 per-rank seeds and shard arithmetic, the cross-rank checks against the oracle."""
 import json
@@ -24,7 +25,7 @@ def stub_rccl():
     src = os.path.join(STUB_DIR, "stub_rccl.cpp")
     if not os.path.exists(STUB) or os.path.getmtime(STUB) < os.path.getmtime(src):
         subprocess.run(["g++", "-shared", "-fPIC", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", STUB,
-                        "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+                        "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"], check=True)
     return STUB
 
 
@@ -69,7 +70,7 @@ def test_cfg4_shards_of_unequal_size_through_the_gather_with_counts(tmp_path, st
                           "--no-cpu-baseline", "--min-timed-s", "0"], tmp_path / str(world), stub_rccl)
         cfg = line["config"]
         assert cfg["pairs_per_rank"] == shards and cfg["rccl_ranks"] == world and cfg["gathered_table_ok"] is True
-        assert line["parity_checked"] is True and line["parity_cases"] == 3, line
+        assert line["parity_checked"] is True and line["parity_cases"] == shards[0] + 1, line      # every pair of rank 0 + the last pair as gathered
         assert "as gathered" in line["parity_what"]
 
 
@@ -148,3 +149,79 @@ def test_the_drivers_multi_gpu_launch_line(tmp_path, stub_rccl):
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["parity_checked"] is True and line["parity_cases"] == 5
+
+
+# ------------------------------------------------------------------------------------------------ ordering stress
+@pytest.mark.parametrize("world", [4, 8])
+def test_ordering_stress_with_four_and_eight_ranks(world, tmp_path, stub_rccl):
+    """Everything the multi-GPU path does between ranks, with `world` rank processes on the one GPU and the asynchronous stand-in shuffling
+    and delaying the operations of every group: (a) the default arrangement of the headline -- three contexts per rank, each with its own
+    communicator and record table, three all-gathers per step chained in issue order; (b) cfg-4 with 257 pairs (shards of 33 and 32), the
+    gather with a count per rank; (c) cfg-5's baton through all ranks.  50 steps of (a) and (b), 5 passes of the baton through every rank;
+    rank 0 checks its own records AND what the last rank contributed against the oracle every time."""
+    steps = ["--steps", "10", "--warmup", "1", "--repeats", "5", "--min-timed-s", "0", "--no-cpu-baseline"]
+    a = run_ranks(["--gpus", str(world), "--resident-pairs", "6", "--inflight", "3", "--batch", "2", "--no-extras"] + steps, tmp_path / "a", stub_rccl)
+    assert a["n_gpus"] == world and a["config"]["rccl_ranks"] == world and a["config"]["contexts"] == 3
+    assert a["config"]["pairs_per_step"] == 6 * world and a["parity_checked"] is True and a["parity_cases"] == 7 and a["max_abs_dx"] <= 1e-3
+    b = run_ranks(["--config", "cfg4", "--gpus", str(world), "--pairs", "257"] + steps, tmp_path / "b", stub_rccl)
+    shards = b["config"]["pairs_per_rank"]
+    assert sum(shards) == 257 and max(shards) - min(shards) == 1 and len(shards) == world
+    assert b["config"]["gathered_table_ok"] is True and b["parity_checked"] is True and b["parity_cases"] == shards[0] + 1
+    c = run_ranks(["--config", "cfg5", "--gpus", str(world), "--steps", "7", "--repeats", "5", "--min-timed-s", "0", "--no-cpu-baseline"],
+                  tmp_path / "c", stub_rccl)
+    cfg = c["config"]
+    assert c["n_gpus"] == world and cfg["rccl_ranks"] == world and cfg["live_after_each_block"] == [20000] * world
+    assert len(set(cfg["list_sha16_after_each_block"])) == world
+
+
+def test_a_timed_out_collective_does_not_hang_the_teardown(tmp_path, stub_rccl):
+    """after klt_comm_wait has given up (KLT_ERR_TIMEOUT: the peer is gone), the context must still close -- the communicator
+    is poisoned, nothing waits for its stream again, klt_destroy returns at once -- and the rank leaves non-zero.  Two ranks on the one
+    GPU; rank 1 joins the communicator and exits without taking part in the gather."""
+    import time
+    script = tmp_path / "rank.py"
+    script.write_text('''
+import os, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+from pyfeaturetrack_amd import parallel
+from pyfeaturetrack_amd._abi import KltCommTimeout, exit_on_comm_timeout
+from pyfeaturetrack_amd.backend import Context, FEAT_DTYPE
+rank, local, world = parallel.world_from_env()
+ctx = Context(0)
+parallel.init_communicators([ctx], rank, world)
+if rank == 1:
+    os._exit(0)                                            # gone before the collective
+ctx.comm_set_timeout(1500.0)
+ctx.featbuf_upload(1, np.zeros(100, FEAT_DTYPE))
+ctx.gather_featbuf_async(1, 2, 100, 0)
+t = time.monotonic()
+try:
+    ctx.comm_wait()
+    print("NO TIMEOUT")
+    os._exit(1)
+except KltCommTimeout as e:
+    waited = time.monotonic() - t
+    try:
+        ctx.comm_wait()                                    # poisoned: fails at once
+        os._exit(1)
+    except KltCommTimeout:
+        pass
+    t = time.monotonic()
+    ctx.close()                                            # must not wait for the dead collective
+    print("TIMEOUT after %%.1f s, close took %%.2f s" %% (waited, time.monotonic() - t), flush=True)
+    exit_on_comm_timeout(e)
+''' % REPO)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KLT_RDZV_FILE", "MASTER_PORT")}
+    env.update(KLT_RANKS_SHARE_DEVICE="0", KLT_RCCL_LIB=stub_rccl, KLT_STUB_RCCL_DIR=str(tmp_path / "mail"), WORLD_SIZE="2",
+               KLT_RDZV_FILE=str(tmp_path / "ids"))
+    os.makedirs(env["KLT_STUB_RCCL_DIR"], exist_ok=True)
+    t0 = time.monotonic()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    out0, err0 = procs[0].communicate(timeout=120)
+    procs[1].wait(timeout=60)
+    assert procs[0].returncode == 3, (procs[0].returncode, out0, err0[-2000:])
+    assert "TIMEOUT after" in out0 and "exiting with code 3" in err0
+    took = float(out0.split("close took")[1].split()[0])
+    assert took < 5.0 and time.monotonic() - t0 < 90
