@@ -5,7 +5,7 @@
 # texture-addresser / L1 (TCP) / L2 (TCC) activity, the L1's request latency towards the L2 and the address-translation misses.
 TAG=${1:-vX}
 export TMPDIR=/tmp
-export KLT_PROFILE_TAG=r03_$TAG
+export KLT_PROFILE_TAG=r04_$TAG
 export KLT_PROFILE_BATCH=8
 O=gpurun_out
 mkdir -p $O

@@ -8,7 +8,7 @@
 # refused counter set makes rocprofv3 abort and then hang.  tools/profile_collect.sh <tag> then copies the summaries into profiles/.
 TAG=${1:-vX}
 export TMPDIR=/tmp
-export KLT_PROFILE_TAG=r03_$TAG
+export KLT_PROFILE_TAG=r04_$TAG
 export KLT_PROFILE_BATCH=8       # pairs per launch of the cfg-2 passes below (bench.py --batch default)
 O=gpurun_out
 mkdir -p $O
@@ -50,6 +50,6 @@ python3 tools/api_probe.py > $O/api_probe_$TAG.json 2>> $O/bench_$TAG.err
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${TAG}_cfg4_fetch -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 10 --warmup 2 --min-timed-s 0 --repeats 3 --no-cpu-baseline > $O/pmc_${TAG}_cfg4_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${TAG}_cfg4_write -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 10 --warmup 2 --min-timed-s 0 --repeats 3 --no-cpu-baseline > $O/pmc_${TAG}_cfg4_write.log 2>&1
 python3 tools/pmc_traffic.py $O/pmc_${TAG}_cfg4_fetch $O/pmc_${TAG}_cfg4_write $O/traffic_${TAG}_cfg4.json > /dev/null 2>> $O/bench_$TAG.err
-bash tools/pmc_mem.sh $TAG > $O/pmc_mem_$TAG.log 2>&1
+# (memory-path counters of the tracker: bash tools/pmc_mem.sh $TAG -- eleven more passes, run separately when the tracker changes)
 find $O/prof_$TAG $O/prof_${TAG}_select -name "*kernel_stats.csv" | head
 tail -c 600 $O/bench_$TAG.json
