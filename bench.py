@@ -802,13 +802,29 @@ def run_cfg5(args, json_fd):
     ctx = Context(0)
     ctx.configure(tc)
     phases = synth.sequence_phases(w, h, 4, workers=usable_cores(10))
+    # the clip is resident in HBM as u8 (4.2 GB for 512 frames); a frame's slot ADOPTS its buffer (klt_slot_adopt_u8: read in place, no
+    # copy), the slots are a ring of three as in any sequence -- one slot per frame (59 GB of planes, each written once per pass) reads
+    # 0.336 ms per frame instead of 0.26: fresh pages for 115 MB of planes every frame
+    NPX = w * h
+    store = ctx.device_alloc(nframes * NPX)
     frames = []                                  # only the first frames stay on the host (parity check, CPU baseline)
     for k, f in enumerate(synth.periodic_sequence(w, h, 4, nframes, phases=phases)):
-        ctx.upload(10 + k, f)
+        ctx.device_write(store + k * NPX, f)
         if k < 8:
             frames.append(f)
-    ctx.build_pyramids(10)
-    fl, placed = ctx.select(10, n, use_pyramid=True)
+    RING = (10, 11, 12)
+
+    def slot(k):
+        return RING[k % 3]
+
+    def build(k, prepare_scores=False):
+        ctx.adopt_u8(slot(k), store + k * NPX, w, h)
+        ctx.build_pyramids(slot(k), sync=False)
+        if prepare_scores:
+            ctx.select_prepare(slot(k))
+
+    build(0)
+    fl, placed = ctx.select(slot(0), n, use_pyramid=True)
     ctx.featbuf_upload(0, fl)
     ctx.sync()
 
@@ -824,22 +840,19 @@ def run_cfg5(args, json_fd):
     def run_sequence(look=None):
         """one pass over the sequence; `look(k)` (instrumented passes) is called after frame k's replacement, synchronised"""
         def track(k):                                     # frame k - 1 -> k; the lists alternate between two buffers
-            ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)
+            ctx.track_async(slot(k - 1), slot(k), (k - 1) % 2, k % 2, n)
 
+        build(0)                                          # (a pass starts from frame 0 again: its slot holds a later frame by now)
         if prefetch:
-            ctx.build_pyramids(10 + 1, sync=False)
-            if prepare:
-                ctx.select_prepare(10 + 1)
+            build(1, prepare)
             track(1)
         for k in range(1, nframes):
             if not prefetch:
-                ctx.build_pyramids(10 + k, sync=False)
+                build(k)
                 track(k)
-            ctx.select_begin(10 + k, 2, True, k % 2, n)      # KLTReplaceLostFeatures on the resident level-0 images, up to the host's look
+            ctx.select_begin(slot(k), 2, True, k % 2, n)      # KLTReplaceLostFeatures on the resident level-0 images, up to the host's look
             if prefetch and k + 1 < nframes:
-                ctx.build_pyramids(10 + k + 1, sync=False)
-                if prepare:
-                    ctx.select_prepare(10 + k + 1)        # SAT + eigenvalues of the next frame, behind its build on the build stream
+                build(k + 1, prepare)                     # pyramids + SAT + eigenvalues of the next frame, on the build stream
                 # the NEXT frame's tracker goes out before the host looks at this frame's selection: it only reads the list, and the GPU
                 # has it queued while the host turns around (44 us of an idle main stream per frame in the round-3 kernel trace)
                 track(k + 1)
@@ -869,12 +882,13 @@ def run_cfg5(args, json_fd):
     same_end = bool(np.array_equal(lists[nframes - 1], out))
     t_sel, lost = 0.0, []
     ctx.featbuf_upload(0, fl)
+    build(0)
     for k in range(1, nframes):                              # (plain loop: tracker, look at the losses, replacement timed on its own)
-        ctx.build_pyramids(10 + k, sync=False)
-        ctx.track_async(10 + k - 1, 10 + k, (k - 1) % 2, k % 2, n)
+        build(k)
+        ctx.track_async(slot(k - 1), slot(k), (k - 1) % 2, k % 2, n)
         lost.append(int((ctx.featbuf_download(k % 2, n)["val"] < 0).sum()))
         t = time.perf_counter()
-        ctx.select_async(10 + k, 2, True, k % 2, n)
+        ctx.select_async(slot(k), 2, True, k % 2, n)
         ctx.sync()
         t_sel += time.perf_counter() - t
     ko = load_oracle()
@@ -923,7 +937,7 @@ def run_cfg5(args, json_fd):
         cpu = cpu_baseline_of(ko, one_frame, n, "pyramid of the new 3840x2160 frame + track 20000 features + replacement selection (one frame of cfg-5)", budget_s=8.0)
     ctx.close()
     line = base_line(n * frames_per_region / el, 1, frames_per_region, 0, ms_step, ms_step,
-                     "cfg-5 (one GPU): ONE 3840x2160 sequence of %d frames (resident in HBM as u8, one slot each), 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost " % nframes +
+                     "cfg-5 (one GPU): ONE 3840x2160 sequence of %d frames (the clip resident in HBM as u8; a ring of three frame slots adopts the frames in place), 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost " % nframes +
                      "features replaced after every frame; per step (frame): pyramid of the new frame + track + replacement"
                      + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else "")
                      + (", and so are its summed-area tables and eigenvalues (klt_select_prepare_async)" if prepare else ""),

@@ -126,6 +126,16 @@ int klt_host_alloc(klt_ctx *ctx, size_t bytes, void **out);     /* pinned host m
 int klt_host_free(klt_ctx *ctx, void *p);
 int klt_upload_u8_async(klt_ctx *ctx, int slot, const uint8_t *px, int ncols, int nrows, int pitch);
 int klt_upload_wait(klt_ctx *ctx);      /* host waits for the copies issued so far (only the copy stream; kernels keep running) */
+/* Frames that are ALREADY in device memory (a hardware decoder's output, a clip kept resident): the slot's frame becomes this caller-owned
+ * buffer -- read in place by the next build / selection of the slot, never copied, written or freed by the library (zero-copy
+ * ingest).  pitch must equal ncols.  Host-only call: nothing is enqueued; the buffer must hold the frame already and stay unchanged until
+ * the work that reads it has completed (klt_sync, or the download of what was computed from it).  The next upload into the slot ends the
+ * adoption.  klt_device_alloc / klt_device_write / klt_device_free give callers without a HIP binding of their own (Python) such memory:
+ * owned by the context, freed with it. */
+int klt_slot_adopt_u8(klt_ctx *ctx, int slot, const uint8_t *dev_px, int ncols, int nrows, int pitch);
+int klt_device_alloc(klt_ctx *ctx, size_t bytes, void **out);
+int klt_device_write(klt_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);   /* synchronous host-to-device copy */
+int klt_device_free(klt_ctx *ctx, void *dev);
 /* smooth -> pyramid -> gradients of every level: ComputeImagePyramids for one image,
  * trackFeatures.py:165-172 + pyramid.py:37-77 + convolve.py:208-264 */
 int klt_build_pyramids_async(klt_ctx *ctx, int slot);

@@ -69,6 +69,10 @@ SYMBOLS = {
     "klt_host_free": (_I, [_P, _P]),
     "klt_upload_u8_async": (_I, [_P, _I, _P, _I, _I, _I]),
     "klt_upload_wait": (_I, [_P]),
+    "klt_slot_adopt_u8": (_I, [_P, _I, _P, _I, _I, _I]),
+    "klt_device_alloc": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
+    "klt_device_write": (_I, [_P, _P, _P, C.c_size_t]),
+    "klt_device_free": (_I, [_P, _P]),
     "klt_build_pyramids_async": (_I, [_P, _I]),
     "klt_build_pyramids_batch_async": (_I, [_P, C.POINTER(C.c_int), _I]),
     "klt_set_option": (_I, [_P, _I, _I]),

@@ -185,6 +185,24 @@ class Context:
             raise ValueError("upload_async takes a C-contiguous 2-D uint8 array in pinned memory")
         self._check(self._lib.klt_upload_u8_async(self._h, slot, img.ctypes.data, img.shape[1], img.shape[0], img.shape[1]))
 
+    def device_alloc(self, nbytes):
+        """Device memory owned by the context (an address as int); freed by device_free or with the context."""
+        p = C.c_void_p()
+        self._check(self._lib.klt_device_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def device_write(self, dev, arr):
+        """Synchronous copy of a C-contiguous array to device address `dev`."""
+        a = np.ascontiguousarray(arr)
+        self._check(self._lib.klt_device_write(self._h, C.c_void_p(dev), a.ctypes.data, a.nbytes))
+
+    def device_free(self, dev):
+        self._check(self._lib.klt_device_free(self._h, C.c_void_p(dev)))
+
+    def adopt_u8(self, slot, dev, ncols, nrows):
+        """The slot's frame IS the u8 image at device address `dev` (contiguous rows): read in place, not copied (klt_slot_adopt_u8)."""
+        self._check(self._lib.klt_slot_adopt_u8(self._h, slot, C.c_void_p(dev), ncols, nrows, ncols))
+
     def upload_wait(self):
         """Host waits until every upload_async issued so far has left its pinned source buffer."""
         self._check(self._lib.klt_upload_wait(self._h))

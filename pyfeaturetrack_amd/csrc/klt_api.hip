@@ -53,9 +53,12 @@ struct Slot {
     // HOST for the duration of the queued work on this runtime (measured 150-800 us per step)
     uint8_t *u8_alt = nullptr;
     size_t u8_alt_cap = 0;
+    const uint8_t *u8_ext = nullptr;  // klt_slot_adopt_u8: the frame IS this caller-owned device buffer (read in place, never written or freed here)
     hipEvent_t ev_consumed_alt = nullptr;
     bool consumed_alt_valid = false;
 };
+
+inline const uint8_t *raw8(const Slot *s) { return s->u8_ext ? s->u8_ext : s->u8; }
 
 struct FeatBuf { klt_feat *d = nullptr; int cap = 0; bool view = false; hipEvent_t comm_done = nullptr; /* last collective that touched it */ };
 
@@ -112,6 +115,7 @@ struct klt_ctx {
     bool build_stream_on = false;
     KltComm *comm = nullptr;          // RCCL communicator + side stream (klt_comm_init_rank), comm.hip
     std::vector<void *> pinned;       // klt_host_alloc allocations
+    std::vector<void *> dev_allocs;   // klt_device_alloc allocations
     // Ordering events come from one ring and are never re-recorded while a waiter may still be queued on them
     // (re-recording a pending event makes hipEventRecord block the host until the device has caught up -- measured:
     // 400-800 us per step).  256 events ~ 25 steps of history.
@@ -488,6 +492,7 @@ int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int p
     }
     if (int rc = wait_built(c, s)) return rc;                 // a build on the build stream may still read the old frame
     const size_t px_count = (size_t)ncols * nrows;
+    s->u8_ext = nullptr;
     if (kind == 1) { if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc; }
     else { if (int rc = ensure(c, s->f32, s->f32_cap, px_count)) return rc; }
     const size_t esz = kind == 1 ? 1 : sizeof(float);
@@ -557,7 +562,7 @@ int enqueue_smooth_raw(klt_ctx *c, Slot *s, float *dst)
     const Taps &g = c->gauss[0];
     {
         TimerScope t(c, F_SMOOTH_H, N * ((s->raw_kind == 1 ? 1 : 4) + 4));
-        if (s->raw_kind == 1) launch_hconv_u8(c->work, s->u8, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+        if (s->raw_kind == 1) launch_hconv_u8(c->work, raw8(s), nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
         else launch_hconv_f32(c->work, s->f32, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
     }
     {
@@ -730,7 +735,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         bool h1_fused = false;              // level 1 comes from the H1 planes written by the level-0 kernel
         if (fused_smooth_ok(c)) {
             for (int b = 0; b < B; b++) {
-                raw[b] = g[b]->raw_kind == 1 ? (const void *)g[b]->u8 : (const void *)g[b]->f32;
+                raw[b] = g[b]->raw_kind == 1 ? (const void *)raw8(g[b]) : (const void *)g[b]->f32;
                 img[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy;
             }
             h1_fused = s0->nlev > 1 && fused_reduce_ok(c);
@@ -891,6 +896,7 @@ void klt_destroy(klt_ctx *c)
     if (c->bstream) { hipStreamSynchronize(c->bstream); hipStreamDestroy(c->bstream); }
     if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
     for (void *p : c->pinned) hipHostFree(p);
+    for (void *p : c->dev_allocs) hipFree(p);
     for (hipEvent_t e : c->ring) hipEventDestroy(e);
     if (c->ev_sel) hipEventDestroy(c->ev_sel);
     for (Slot &s : c->slots) { hipFree(s.u8); hipFree(s.u8_alt); hipFree(s.f32); hipFree(s.planes); }
@@ -1015,6 +1021,7 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
     if (int rc = get_slot(c, slot, &s, true)) return rc;
     const size_t px_count = (size_t)ncols * nrows;
     // write into the buffer the build before last read (normally long finished: poll, block only if it is not)
+    s->u8_ext = nullptr;
     std::swap(s->u8, s->u8_alt);
     std::swap(s->u8_cap, s->u8_alt_cap);
     std::swap(s->ev_consumed, s->ev_consumed_alt);
@@ -1057,6 +1064,67 @@ int klt_upload_wait(klt_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
     for (hipStream_t x : c->cextra) if (x) HIPCHK(c, hipStreamSynchronize(x));
+    return KLT_OK;
+}
+
+int klt_device_alloc(klt_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || !bytes) return fail(c, KLT_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(c, KLT_ERR_NOMEM, "klt_device_alloc: out of device memory"); }
+    c->dev_allocs.push_back(p);
+    *out = p;
+    return KLT_OK;
+}
+
+int klt_device_free(klt_ctx *c, void *p)
+{
+    if (!c) return KLT_ERR_ARG;
+    for (size_t i = 0; i < c->dev_allocs.size(); i++)
+        if (c->dev_allocs[i] == p) {
+            HIPCHK(c, hipSetDevice(c->device));
+            if (int rc = sync_all(c)) return rc;              // a build may still read a frame adopted from it
+            for (Slot &s : c->slots)
+                if (s.u8_ext) { s.u8_ext = nullptr; if (s.raw_kind == 1 && !s.u8) s.raw_kind = 0; }     // (whichever buffer they pointed into)
+            hipFree(p);
+            c->dev_allocs.erase(c->dev_allocs.begin() + (long)i);
+            return KLT_OK;
+        }
+    return fail(c, KLT_ERR_ARG, "not a klt_device_alloc allocation");
+}
+
+int klt_device_write(klt_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return fail(c, KLT_ERR_ARG, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KLT_OK;
+}
+
+int klt_slot_adopt_u8(klt_ctx *c, int slot, const uint8_t *dev_px, int ncols, int nrows, int pitch)
+{
+    if (!c || !dev_px) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535) return fail(c, KLT_ERR_ARG, "bad image geometry");
+    if (pitch != ncols) return fail(c, KLT_ERR_ARG, "an adopted frame must have contiguous rows (pitch == ncols): it is read in place");
+    if ((long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "frame too large (2^28 pixels or more: a plane must stay below 2 GB)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, dev_px) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(c, KLT_ERR_ARG, "klt_slot_adopt_u8 needs device memory");
+    }
+    Slot *s;
+    if (int rc = get_slot(c, slot, &s, true)) return rc;
+    // nothing is enqueued: the pointer is what the next build / selection of the slot reads.  Work already enqueued read the slot's
+    // previous frame through its own pointer and is unaffected; a pending asynchronous upload into the slot is abandoned
+    s->upload_pending = false;
+    s->u8_ext = dev_px;
+    s->nc = ncols;
+    s->nr = nrows;
+    s->raw_kind = 1;
+    s->pyr_valid = false;
     return KLT_OK;
 }
 
@@ -1481,7 +1549,7 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
         if (int rc = wait_built(c, s)) return rc;              // a build of this slot may still read the raw frame's buffers
         bool grads_done = false;
         if (p.smoothBeforeSelecting && fused_smooth_ok(c)) {
-            const void *raw = s->raw_kind == 1 ? (const void *)s->u8 : (const void *)s->f32;
+            const void *raw = s->raw_kind == 1 ? (const void *)raw8(s) : (const void *)s->f32;
             if (int rc = enqueue_fused_smooth_grad(c, 1, &raw, s->raw_kind, &c->sel_img, &c->sel_gx, &c->sel_gy, nc, nr)) return rc;
             img = c->sel_img;
             grads_done = true;
@@ -1495,7 +1563,7 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
             Taps one;
             std::memset(&one, 0, sizeof(one));
             one.n = 1; one.sym = 1; one.k[0] = 1.0;
-            launch_hconv_u8(c->stream, s->u8, nc, nr, c->sel_img, nullptr, nc, 1, 0, one, nullptr);
+            launch_hconv_u8(c->stream, raw8(s), nc, nr, c->sel_img, nullptr, nc, 1, 0, one, nullptr);
             img = c->sel_img;
         }
         if (!grads_done) {

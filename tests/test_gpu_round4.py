@@ -405,3 +405,48 @@ def test_dispatch_timestamps_never_drop_a_launch_silently():
                 assert mode == 2 or not any(k.endswith("!unstamped") for k in t)
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------------------------------------ frames already in device memory
+def test_a_slot_adopts_a_frame_that_is_already_on_the_device(img0, img1, cfg1):
+    """klt_slot_adopt_u8 (zero-copy ingest): a clip kept in device memory (klt_device_alloc / klt_device_write) is read in
+    place -- the slot that adopts a frame gives the reference's pyramid planes, selection and tracking, exactly as the slot that was
+    uploaded to; an upload into the slot ends the adoption, freeing the clip leaves no slot pointing into it, and the argument checks hold."""
+    from pyfeaturetrack_amd.backend import Context, KltBackendError
+    c = Context(0)
+    try:
+        c.configure(make_tc(max_residue=10.0))
+        n = img0.size
+        clip = c.device_alloc(2 * n)
+        c.device_write(clip, img0)
+        c.device_write(clip + n, img1)
+        c.adopt_u8(0, clip, 320, 240)
+        c.adopt_u8(1, clip + n, 320, 240)
+        assert c.frame_resident(0) and not c.pyramids_valid(0)
+        c.build_pyramids_batch([0, 1], sync=True)
+        for slot, name in ((0, "p0"), (1, "p1")):
+            for l in range(2):
+                for pi, w in enumerate(("img", "gx", "gy")):
+                    assert np.array_equal(c.download_level(slot, pi, l), cfg1["%s_%s_%d" % (name, w, l)]), (name, w, l)
+        fl, placed = c.select(0, 100)                              # from the raw (adopted) frame, not the pyramid
+        assert placed == 100 and np.array_equal(fl["x"].astype(np.float64), cfg1["sel100_x"]) and np.array_equal(fl["val"].astype(np.int64), cfg1["sel100_val"])
+        out, _ = c.track(0, 1, fl)
+        assert np.array_equal(out["val"].astype(np.int64), cfg1["trk100_r10_val"])
+        ok = out["val"] >= 0
+        assert np.array_equal(out["x"][ok].astype(np.float64), cfg1["trk100_r10_x"][ok])
+        c.upload(0, img1)                                          # an upload ends the adoption: the clip's first frame is untouched
+        c.adopt_u8(2, clip, 320, 240)
+        c.build_pyramids_batch([0, 2], sync=True)
+        assert np.array_equal(c.download_level(0, 0, 1), cfg1["p1_img_1"]) and np.array_equal(c.download_level(2, 0, 1), cfg1["p0_img_1"])
+        with pytest.raises(KltBackendError):
+            c.adopt_u8(3, clip, 320, 240 * 100000)
+        with pytest.raises(KltBackendError):
+            c._check(c._lib.klt_slot_adopt_u8(c._h, 3, img0.ctypes.data, 320, 240, 320))     # host memory is not adoptable
+        with pytest.raises(KltBackendError):
+            c._check(c._lib.klt_slot_adopt_u8(c._h, 3, clip, 300, 240, 320))                  # rows must be contiguous
+        c.device_free(clip)
+        assert not c.frame_resident(2) and not c.frame_resident(1)
+        with pytest.raises(KltBackendError):
+            c.device_free(clip)
+    finally:
+        c.close()
