@@ -450,3 +450,11 @@ def test_a_slot_adopts_a_frame_that_is_already_on_the_device(img0, img1, cfg1):
             c.device_free(clip)
     finally:
         c.close()
+
+
+def test_the_resident_clip_example_runs():
+    """examples/resident_clip.py: the cfg-5 loop on frames read in place from device memory, at a small size."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "examples", "resident_clip.py"), "--frames", "12", "--size", "640x480", "--features", "300"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "300 of 300 alive at the end" in r.stdout, r.stdout
