@@ -448,3 +448,34 @@ def test_product_taps_equal_the_reference_kernels(golden_dir):
         assert np.array_equal(np.array(g, np.float64), k["gauss_%s" % s]) and np.array_equal(np.array(d, np.float64), k["deriv_%s" % s])
     # (the smoothing sigma is 0.1 * 7 = 0.7000000000000001 as the reference computes it, klt_util.py:4-5: the taps of THAT value)
     assert len(taps[0][0]) == 5 and np.allclose(taps[0][0], k["gauss_0.7"], rtol=0, atol=1e-15) and taps[0] == tuple(_computeKernels(0.1 * 7))
+
+
+def test_periodic_sequence_is_the_texture_moved_by_k_steps():
+    """synth.periodic_sequence (the 512-frame clips of cfg-5's tests and bench): frames 0..9 are synth_frame's, frame k >= 10 is frame
+    k % 10 rolled by (k // 10) * (33, -21) whole pixels; `phases` and `start` only save work."""
+    from pyfeaturetrack_amd import synth
+    w, h = 96, 64
+    base = synth.synth_base(w, h, 9)
+    frames = list(synth.periodic_sequence(w, h, 9, 34, base=base))
+    assert len(frames) == 34 and frames[0].dtype == np.uint8 and frames[0].shape == (h, w)
+    for k in range(10):
+        assert np.array_equal(frames[k], synth.synth_frame(w, h, 9, k, base=base))
+    for k in (10, 17, 23, 33):
+        assert np.array_equal(frames[k], np.roll(frames[k % 10], ((k // 10) * -21, (k // 10) * 33), axis=(0, 1)))
+    phases = synth.sequence_phases(w, h, 9, base=base, workers=3)
+    again = list(synth.periodic_sequence(w, h, 9, 34, phases=phases, start=21))
+    assert len(again) == 13 and all(np.array_equal(a, b) for a, b in zip(again, frames[21:]))
+    with pytest.raises(ValueError):
+        next(synth.periodic_sequence(w, h, 9, 3, shift=(1.25, 0.5)))
+
+
+def test_selection_falls_back_when_the_pyramid_does_not_fit():
+    """selectGoodFeatures._pyramid_fits: int(n / ss) per level (pyramid.py:26-31) must leave at least one pixel at every level."""
+    from pyfeaturetrack_amd.selectGoodFeatures import _pyramid_fits
+
+    class TC:
+        nPyramidLevels, subsampling = 3, 4
+
+    assert _pyramid_fits(TC, 320, 240) and _pyramid_fits(TC, 16, 16) and not _pyramid_fits(TC, 15, 240) and not _pyramid_fits(TC, 320, 15)
+    TC.nPyramidLevels = 1
+    assert _pyramid_fits(TC, 1, 1)
