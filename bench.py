@@ -1383,9 +1383,10 @@ def run_cfg2(args, json_fd):
         if link:
             extra["pcie_link"] = link
             extra["pcie_pipelined_frac_of_link"] = extra["pcie_pipelined_GBps"] / link["1080p"]
-        if not args.no_api:
+        # (one-GPU secondary figures: with N > 1 the other ranks are done by now and must not be kept waiting for rank 0's extras)
+        if not args.no_api and not distributed:
             extra.update(api_figures(frames[0], tc))
-        if not args.no_sequences:
+        if not args.no_sequences and not distributed:
             extra["sequence_from_host"] = {"1080p": sequence_from_host(ranks.local_rank, 1920, 1080, 5000, 256, link.get("1080p")),
                                            "4k": sequence_from_host(ranks.local_rank, 3840, 2160, 20000, 128, link.get("4k")),
                                            "note": sequence_from_host.__doc__.split("  Secondary")[0].replace("\n    ", " ")}

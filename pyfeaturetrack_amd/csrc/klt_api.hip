@@ -2627,7 +2627,9 @@ int klt_pyramid_f32(klt_ctx *c, const float *src, int ncols, int nrows, int nlev
 }
 
 // ------------------------------------------------------------------------------------------ experiment: a frame as a HIP graph
-// Not part of include/klt_gpu.h.  op 0: every stream idle, the cross-stream bookkeeping forgotten (no event recorded before the capture
+#ifdef KLT_GRAPH_PROBE
+// Not part of include/klt_gpu.h and not in the product library: tools/graph_frame_probe.py compiles this file with -DKLT_GRAPH_PROBE into a
+// private copy (profiles/README.md, "HIP graphs").  op 0: every stream idle, the cross-stream bookkeeping forgotten (no event recorded before the capture
 // is waited for inside it), capture begins on the main stream; the caller then enqueues ONE frame's work through the ordinary *_async
 // entry points -- the build first, so that the build stream forks off the main stream at the graph's root.  op 1: the build stream joins,
 // the capture ends, the graph is instantiated; the selection the capture left pending is dropped (its launches are in the graph).
@@ -2685,6 +2687,7 @@ int klt_debug_graph(klt_ctx *c, int op)
     }
     return fail(c, KLT_ERR_ARG, "unknown op");
 }
+#endif  // KLT_GRAPH_PROBE
 
 // ------------------------------------------------------------------------------------------ timing
 int klt_timing_enable(klt_ctx *c, int on)
