@@ -11,6 +11,6 @@ cp $O/traffic_$TAG.json $P/traffic.json
 if [ -f $O/sq_counters_$TAG.json ]; then cp $O/sq_counters_$TAG.json $P/${R}_${TAG}_sq_counters.json; cp $O/sq_counters_$TAG.json $P/sq_counters.json; fi
 [ -s $O/api_probe_$TAG.json ] && cp $O/api_probe_$TAG.json $P/${R}_${TAG}_api_probe.json
 [ -s $O/traffic_${TAG}_cfg4.json ] && cp $O/traffic_${TAG}_cfg4.json $P/${R}_${TAG}_cfg4_pmc_traffic.json
-[ -s $O/mem_counters_$TAG.json ] && cp $O/mem_counters_$TAG.json $P/${R}_${TAG}_mem_counters.json
+[ -s $O/mem_counters_$TAG.json ] && [ $O/mem_counters_$TAG.json -nt $O/bench_$TAG.json ] && cp $O/mem_counters_$TAG.json $P/${R}_${TAG}_mem_counters.json
 for c in cfg3 cfg5; do [ -s $O/sq_counters_${TAG}_$c.json ] && cp $O/sq_counters_${TAG}_$c.json $P/${R}_${TAG}_${c}_sq_counters.json; done
 ls -la $P | grep ${R}_$TAG
