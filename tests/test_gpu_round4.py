@@ -458,3 +458,61 @@ def test_the_resident_clip_example_runs():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "300 of 300 alive at the end" in r.stdout, r.stdout
+
+
+# ------------------------------------------------------------------------------------------------ degenerate inputs
+def _degenerate_pairs(w, h):
+    rng = np.random.default_rng(123)
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    checker = (((xx // 8 + yy // 8) & 1) * 255).astype(np.uint8)
+    spike = np.zeros((h, w), np.uint8)
+    spike[h // 2, w // 2] = 255
+    ramp = (xx * 255 // (w - 1)).astype(np.uint8)
+    flat = np.full((h, w), 128, np.uint8)
+    return {
+        "constant -> constant": (flat, flat.copy()),
+        "black -> white": (np.zeros((h, w), np.uint8), np.full((h, w), 255, np.uint8)),
+        "white noise, uncorrelated": (noise, np.roll(noise[::-1], 7, axis=1).copy()),
+        "white noise, shifted by (2, -1)": (noise, np.roll(noise, (-1, 2), axis=(0, 1))),
+        "saturated checkerboard, shifted by half a period": (checker, np.roll(checker, 4, axis=1)),
+        "one bright pixel that vanishes": (spike, np.zeros((h, w), np.uint8)),
+        "horizontal ramp (no corner anywhere)": (ramp, np.roll(ramp, 3, axis=1)),
+        "texture -> constant": (noise, flat),
+    }
+
+
+@pytest.mark.parametrize("levels,ss,window", [(2, 4, 7), (3, 2, 5), (1, 2, 15)])
+def test_degenerate_frames_match_the_oracle(levels, ss, window):
+    """Inputs a synthetic texture never produces: constant frames (every determinant 0: KLT_SMALL_DET, no candidate above the
+    eigenvalue floor), saturated noise and checkerboards (ties, equal eigenvalues, aliasing), a single bright pixel, a ramp, and pairs
+    whose second frame has nothing in common with the first -- selection, tracking (with and without the residue test) and replacement
+    give the oracle's records, status codes included."""
+    from oracle import klt_oracle as ko
+    from helpers import params_from_tc
+    from pyfeaturetrack_amd.backend import Context, REPLACING_SOME
+    w, h, n = 200, 152, 120
+    c = Context(0)
+    try:
+        for mr in (None, 6.0):
+            tc = make_tc(levels=levels, ss=ss, window=window, max_residue=mr, mindist=6)
+            p = params_from_tc(tc)
+            c.configure(tc)
+            for name, (f0, f1) in _degenerate_pairs(w, h).items():
+                c.upload(0, f0)
+                c.upload(1, f1)
+                c.build_pyramids_batch([0, 1], sync=True)
+                fl, placed = c.select(0, n)
+                ofl = ko.select_good_features(p, f0.astype(np.float32), n)
+                for k in ("val", "x", "y"):
+                    assert np.array_equal(fl[k], ofl[k]), (name, "selection", k, mr)
+                out, _ = c.track(0, 1, fl)
+                ko.track_features(p, ko.Pyramids(p, f0.astype(np.float32)), ko.Pyramids(p, f1.astype(np.float32)), ofl)
+                for k in ("val", "x", "y"):
+                    assert np.array_equal(out[k], ofl[k]), (name, "tracking", k, mr, np.unique(ofl["val"]))
+                rep, _ = c.select(1, n, mode=REPLACING_SOME, fl=out)
+                orep = ko.select_good_features(p, f1.astype(np.float32), n, mode=2, fl=ofl)
+                for k in ("val", "x", "y"):
+                    assert np.array_equal(rep[k], orep[k]), (name, "replacement", k, mr)
+    finally:
+        c.close()
