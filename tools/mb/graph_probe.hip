@@ -53,7 +53,7 @@ int main()
     CHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
     unsigned *acc, *counter, *row, *src, *table, *scratch;
     CHK(hipMalloc(&acc, 4)); CHK(hipMalloc(&counter, 4)); CHK(hipMalloc(&row, 4));
-    const int N = 4096, ROWS = 1200;
+    const int N = 4096, ROWS = 2000;
     CHK(hipMalloc(&src, N * 4)); CHK(hipMalloc(&table, (size_t)N * ROWS * 4)); CHK(hipMalloc(&scratch, 1 << 20));
     CHK(hipMemset(acc, 0, 4)); CHK(hipMemset(counter, 0, 4)); CHK(hipMemset(row, 0, 4)); CHK(hipMemset(src, 0, N * 4));
     unsigned *host_word;
@@ -134,6 +134,31 @@ int main()
     bool ok = rows == (unsigned)(3 + F + 3 + F);
     for (unsigned r = 0; r < rows && ok; r++) ok = t[(size_t)r * N] == r && t[(size_t)r * N + N - 1] == r;
     printf("check : %u rows appended through the device-side row counter (%s), %u kernels counted, last published payload %u\n", rows, ok ? "every row holds its index" : "WRONG", accv, payload);
+    // the same graph instantiated FOUR times, launched in rotation (a sequence would rotate through one graph per ring phase): does the host
+    // cost of a launch come from re-launching an executable graph whose previous launch is still running?
+    {
+        hipGraphExec_t ex[4];
+        for (auto &e : ex) CHK(hipGraphInstantiate(&e, graph, nullptr, nullptr, 0));
+        for (int w = 0; w < 8; w++) CHK(hipGraphLaunch(ex[w % 4], s0));
+        CHK(hipStreamSynchronize(s0));
+        unsigned base2 = 0;
+        CHK(hipMemcpy(&base2, counter, 4, hipMemcpyDeviceToHost));
+        double host_rot = 0;
+        t0 = now_us();
+        for (int f = 0; f < F; f++) {
+            const double a = now_us();
+            CHK(hipGraphLaunch(ex[f % 4], s0));
+            host_rot += now_us() - a;
+            while (*(volatile unsigned *)host_word < base2 + f + 1) { }
+        }
+        CHK(hipStreamSynchronize(s0));
+        printf("graph : four executable graphs in rotation: %.1f us per frame wall (look per frame), %.1f us of host time per hipGraphLaunch\n", (now_us() - t0) / F, host_rot / F);
+        t0 = now_us();
+        host_rot = 0;
+        for (int f = 0; f < F; f++) { const double a = now_us(); CHK(hipGraphLaunch(ex[f % 4], s0)); host_rot += now_us() - a; }
+        CHK(hipStreamSynchronize(s0));
+        printf("graph : four executable graphs in rotation, back to back: %.1f us per frame, %.1f us of host time per launch\n", (now_us() - t0) / F, host_rot / F);
+    }
     // back-to-back graph launches without a look: the floor
     t0 = now_us();
     for (int f = 0; f < F; f++) CHK(hipGraphLaunch(exec, s0));
