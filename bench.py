@@ -1324,17 +1324,25 @@ def run_cfg2(args, json_fd):
         ms_pcie = (time.perf_counter() - t) / reps * 1e3
         # pipelined ingest: frames already sit in pinned host memory (as a decoder would leave them), uploads run on the
         # copy stream and overlap the previous pair's kernels; records go to a device table read back every 16 pairs
-        NPIN = min(PL, 4)
+        NPIN = min(PL, 8)
         pins = []
         for lp in range(NPIN):
             a, b = ctx.pinned_array((HEIGHT, WIDTH)), ctx.pinned_array((HEIGHT, WIDTH))
             a[:], b[:] = frames[pair_index(0, lp)]
             pins.append((a, b))
+        # records: a device table of 2 x 16 rows; the half a window filled goes to pinned host memory with klt_featbuf_download_async at the
+        # window's end and is waited for at the NEXT window's end -- a synchronous download there makes the host wait for every queued step
+        # and the link idles 0.3-0.9 ms per window meanwhile (tools/trace_copies.py)
         TAB, NT = FB_MISC + 1, 16
-        ctx.featbuf_alloc(TAB, NT * NFEAT)
-        for k in range(NT):
+        HALVES = (TAB + 1 + 2 * NT, TAB + 2 + 2 * NT)
+        ctx.featbuf_alloc(TAB, 2 * NT * NFEAT)
+        for k in range(2 * NT):
             ctx.featbuf_view(TAB + 1 + k, TAB, k * NFEAT, NFEAT)
-        npipe = 8 * NT
+        for hlf in range(2):
+            ctx.featbuf_view(HALVES[hlf], TAB, hlf * NT * NFEAT, NT * NFEAT)
+        from pyfeaturetrack_amd.backend import FEAT_DTYPE
+        host_tab = [ctx.pinned_array((NT * NFEAT,), FEAT_DTYPE) for _ in range(2)]
+        npipe = 16 * NT
 
         def send(i):                         # the two frames of pair i leave on the two copy streams
             lp = i % NPIN
@@ -1347,8 +1355,14 @@ def run_cfg2(args, json_fd):
             lp = i % NPIN
             send(i + 1)
             ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
-            ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, TAB + 1 + i % NT, NFEAT)
-            return ctx.featbuf_download(TAB, NT * NFEAT) if i % NT == NT - 1 else None
+            ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, TAB + 1 + i % (2 * NT), NFEAT)
+            if i % NT != NT - 1:
+                return None
+            win = i // NT
+            ctx.download_wait()                                   # the PREVIOUS window's records (long there)
+            got = host_tab[(win - 1) % 2] if win > 0 else None     # (valid until the window after next overwrites it)
+            ctx.featbuf_download_async(HALVES[win % 2], host_tab[win % 2])
+            return got
 
         send(0)
         for i in range(NT):                 # warm-up: the alternate raw buffers are allocated on first use
@@ -1358,6 +1372,8 @@ def run_cfg2(args, json_fd):
         for i in range(NT, NT + npipe):
             got = pipelined_step(i)
             table = got if got is not None else table
+        ctx.download_wait()
+        table = host_tab[((NT + npipe - 1) // NT) % 2].copy()     # the last window's records
         ctx.sync()
         ms_pipe = (time.perf_counter() - t) / npipe * 1e3
         last_lp = (NT + npipe - 1) % NPIN
@@ -1376,13 +1392,15 @@ def run_cfg2(args, json_fd):
                          "throughput with pairs_in_flight pairs overlapping).  cache_resident = round 2's headline arrangement: every "
                          "context rebuilds the same four frame slots, which then never leave the 256 MB Infinity Cache.  pcie_inclusive "
                          "= H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the records, synchronised per "
-                         "pair; pcie_pipelined = the same bytes with klt_upload_u8_async from pinned memory on a copy stream and the "
-                         "records read back every 16 pairs"}
+                         "pair; pcie_pipelined = the same bytes with klt_upload_u8_async from pinned memory on two copy streams, the next "
+                         "pair sent before this pair's kernels are enqueued, and the records read back every 16 pairs without draining the "
+                         "queue (klt_featbuf_download_async)"}
         link = link_rates()
         extra["pcie_pipelined_GBps"] = 2 * WIDTH * HEIGHT / (ms_pipe * 1e-3) / 1e9
         if link:
             extra["pcie_link"] = link
             extra["pcie_pipelined_frac_of_link"] = extra["pcie_pipelined_GBps"] / link["1080p"]
+            extra["pcie_pipelined_frac_of_link_next_to_a_kernel"] = min(1.0, extra["pcie_pipelined_GBps"] / link["1080p_next_to_a_kernel"])
         # (one-GPU secondary figures: with N > 1 the other ranks are done by now and must not be kept waiting for rank 0's extras)
         if not args.no_api and not distributed:
             extra.update(api_figures(frames[0], tc))
@@ -1470,6 +1488,8 @@ def sequence_from_host(device, w, h, n, nframes=256, link_gbps=None):
         for i in range(2):
             ctx.featbuf_view(HALF[i], TAB, i * NT * n, NT * n)
         row = lambda k: TAB + 1 + k % (2 * NT)                                # noqa: E731
+        from pyfeaturetrack_amd.backend import FEAT_DTYPE
+        host_tab = [ctx.pinned_array((NT * n,), FEAT_DTYPE) for _ in range(2)]
         ctx.set_option(15, 1)                                                 # KLT_OPT_BUILD_STREAM
 
         def send(k):                         # frame k leaves for its slot (the copy overlaps whatever the GPU is doing)
@@ -1504,10 +1524,13 @@ def sequence_from_host(device, w, h, n, nframes=256, link_gbps=None):
                 send(k + 3)
                 if k % NT == NT - 1:
                     # the half holding rows k-15 .. k is complete once frame k's selection is; the tracker of k+1 already writes into the
-                    # other half.  (The download waits for the main stream.)
-                    live = ctx.featbuf_download(HALF[(k // NT) % 2], NT * n)
+                    # other half.  The copy is enqueued in stream order and waited for one window later: the host never drains the queue.
+                    ctx.download_wait()
+                    ctx.featbuf_download_async(HALF[(k // NT) % 2], host_tab[(k // NT) % 2])
+                    live = host_tab[(k // NT) % 2]
+            ctx.download_wait()
             ctx.sync()
-            return live
+            return None if live is None else live.copy()
 
         run(2 * NT)                                                           # sizes every buffer
         t = time.perf_counter()
@@ -1530,7 +1553,10 @@ def link_rates():
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r04_h2d_probe.json")))
         return {"1080p": d["h2d_1080p_2.07MB"]["two_streams_GBps"], "4k": d["h2d_4k_8.29MB"]["two_streams_GBps"],
-                "source": "profiles/r04_h2d_probe.json (tools/h2d_probe.cpp, builder gpurun): pinned H2D on two copy streams"}
+                "1080p_next_to_a_kernel": d["h2d_1080p_2.07MB"]["two_streams_next_to_a_kernel_GBps"],
+                "4k_next_to_a_kernel": d["h2d_4k_8.29MB"]["two_streams_next_to_a_kernel_GBps"],
+                "source": "profiles/r04_h2d_probe.json (tools/h2d_probe.cpp, builder gpurun): pinned H2D on two copy streams, back to back, "
+                          "on an idle GPU / next to a running compute kernel"}
     except (OSError, KeyError, ValueError):
         return {}
 

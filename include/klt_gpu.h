@@ -165,6 +165,11 @@ int   klt_featbuf_upload(klt_ctx *ctx, int fb, const klt_feat *src, int n);
  * klt_featbuf_download, ...) */
 int   klt_featbuf_upload_async(klt_ctx *ctx, int fb, const klt_feat *src, int n);
 int   klt_featbuf_download(klt_ctx *ctx, int fb, klt_feat *dst, int n);
+/* the same without draining the pipeline: the copy is enqueued in stream order behind the kernels that wrote the records; `dst` must be
+ * pinned (klt_host_alloc) and holds the records once klt_download_wait (or any synchronising call) has returned.  A loop that reads a
+ * table back every N steps issues this at the window's end and waits for it at the NEXT window's end: the host never waits for queued work. */
+int   klt_featbuf_download_async(klt_ctx *ctx, int fb, klt_feat *dst, int n);
+int   klt_download_wait(klt_ctx *ctx);                        /* host waits for the latest klt_featbuf_download_async */
 int   klt_featbuf_alloc(klt_ctx *ctx, int fb, int n);         /* n records, all marked lost (val = -1) */
 /* fb_view becomes a window [offset, offset+n) of fb_parent (a device-side [frames x features] table, cf. the
  * KLT_FeatureTable stub at klt.py:278-283, can then be gathered with one collective).  The parent must outlive the

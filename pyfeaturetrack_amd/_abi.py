@@ -85,6 +85,8 @@ SYMBOLS = {
     "klt_featbuf_upload": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_upload_async": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_download": (_I, [_P, _I, _P, _I]),
+    "klt_featbuf_download_async": (_I, [_P, _I, _P, _I]),
+    "klt_download_wait": (_I, [_P]),
     "klt_featbuf_alloc": (_I, [_P, _I, _I]),
     "klt_featbuf_view": (_I, [_P, _I, _I, _I, _I]),
     "klt_featbuf_devptr": (_P, [_P, _I]),

@@ -276,6 +276,14 @@ class Context:
         self._check(self._lib.klt_featbuf_download(self._h, fb, out.ctypes.data, n))
         return out
 
+    def featbuf_download_async(self, fb, out):
+        """Enqueue the download of len(out) records of feature buffer `fb` into the PINNED record array `out` (pinned_array(..., FEAT_DTYPE));
+        the records are there after download_wait().  The host does not wait for queued work (klt_featbuf_download_async)."""
+        self._check(self._lib.klt_featbuf_download_async(self._h, fb, out.ctypes.data, len(out)))
+
+    def download_wait(self):
+        self._check(self._lib.klt_download_wait(self._h))
+
     def featbuf_alloc(self, fb, n):
         self._check(self._lib.klt_featbuf_alloc(self._h, fb, n))
 

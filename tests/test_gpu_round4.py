@@ -516,3 +516,31 @@ def test_degenerate_frames_match_the_oracle(levels, ss, window):
                     assert np.array_equal(rep[k], orep[k]), (name, "replacement", k, mr)
     finally:
         c.close()
+
+
+def test_records_come_back_without_draining_the_pipeline(img0, img1, cfg1):
+    """klt_featbuf_download_async / klt_download_wait: the copy is enqueued in stream order behind the tracker that wrote the records and
+    lands in pinned host memory; work enqueued behind it does not disturb it; a pageable destination is refused."""
+    from pyfeaturetrack_amd.backend import Context, FEAT_DTYPE, KltBackendError
+    c = Context(0)
+    try:
+        c.configure(make_tc(max_residue=10.0))
+        c.upload(0, img0)
+        c.upload(1, img1)
+        c.build_pyramids_batch([0, 1])
+        fl, _ = c.select(0, 100)
+        c.featbuf_upload(5, fl)
+        out = c.pinned_array((100,), FEAT_DTYPE)
+        out["val"] = 77
+        c.track_async(0, 1, 5, 6, 100)
+        c.featbuf_download_async(6, out)
+        c.track_async(1, 0, 6, 7, 100)                              # more work behind the copy: reads buffer 6, must not change what was copied
+        c.download_wait()
+        assert np.array_equal(out["val"].astype(np.int64), cfg1["trk100_r10_val"])
+        ok = out["val"] >= 0
+        assert np.array_equal(out["x"][ok].astype(np.float64), cfg1["trk100_r10_x"][ok])
+        c.download_wait()                                           # nothing pending: returns at once
+        with pytest.raises(KltBackendError):
+            c.featbuf_download_async(6, np.empty(100, FEAT_DTYPE))
+    finally:
+        c.close()

@@ -57,6 +57,7 @@ v = {
     "CFG5_MS": "%.3f" % c5["ms_per_step"], "CFG5_MF": "%.0f" % (c5["value"] / 1e6), "CFG5_STEPFRAC": "%.2f" % c5["roofline"]["step_frac"],
     "SEL_MS": "%.3f" % e["ms_per_select_5000"],
     "PIPE_MS": "%.3f" % e["pcie_pipelined_ms_per_pair"], "PIPE_GB": "%.1f" % e["pcie_pipelined_GBps"], "PIPE_FRAC": "%.2f" % e["pcie_pipelined_frac_of_link"],
+    "PIPE_FRACK": "%.2f" % e["pcie_pipelined_frac_of_link_next_to_a_kernel"],
     "SEQ1080": "%.3f" % e["sequence_from_host"]["1080p"]["ms_per_frame"], "SEQ4K": "%.3f" % e["sequence_from_host"]["4k"]["ms_per_frame"],
     "API_TRK": "%.2f" % e["api_ms_per_KLTTrackFeatures"], "API_SEL": "%.2f" % e["api_ms_per_KLTSelectGoodFeatures"],
     "API_TRK_T": "%.2f" % e["api_trusting_ms_per_KLTTrackFeatures"], "API_SEL_T": "%.2f" % e["api_trusting_ms_per_KLTSelectGoodFeatures"],

@@ -31,28 +31,34 @@ int main()
         memset(pin[i], i + 1, NMAX);
     }
     memset(page, 7, NMAX);
-    hipStream_t s[2], k;
-    hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking);
-    hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking);
+    hipStream_t s[4], k;
+    for (auto &x : s) hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
     hipStreamCreateWithFlags(&k, hipStreamNonBlocking);
     float *work;
     hipMalloc((void **)&work, 256 * 1024 * sizeof(float));
+    hipEvent_t ev[64];
+    for (auto &e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     std::string out = "{";
     char buf[256];
     for (int si = 0; si < 2; si++) {
         const size_t N = sizes[si];
         const int reps = si == 0 ? 400 : 150;
-        auto run = [&](int nstreams, bool with_kernel, bool pageable) {
+        double last_enqueue_us = 0;
+        auto run = [&](int nstreams, bool with_kernel, bool pageable, bool with_events = false) {
             double best = 1e9;
             for (int rep = 0; rep < 4; rep++) {
                 hipDeviceSynchronize();
                 if (with_kernel) hipLaunchKernelGGL(busy, dim3(1024), dim3(256), 0, k, work, 20000000);   // keeps the CUs busy for the whole pass
                 const double t = now();
                 for (int i = 0; i < reps; i++)
+                {
                     hipMemcpyAsync(d[i % NBUF], pageable ? page : pin[i % NBUF], N, hipMemcpyHostToDevice, s[i % nstreams]);
-                hipStreamSynchronize(s[0]);
-                hipStreamSynchronize(s[1]);
+                    if (with_events) hipEventRecord(ev[i % 64], s[i % nstreams]);      // what klt_upload_u8_async does behind every copy
+                }
+                const double enq = (now() - t) / reps;
+                for (auto &x : s) hipStreamSynchronize(x);
                 const double dt = (now() - t) / reps;
+                last_enqueue_us = enq * 1e6;
                 if (dt < best) best = dt;
                 hipDeviceSynchronize();
             }
@@ -63,6 +69,16 @@ int main()
                  "\"two_streams_next_to_a_kernel_GBps\": %.2f, \"pageable_GBps\": %.2f, \"us_per_frame_one_stream\": %.1f}",
                  si ? ", " : "", names[si], N / one / 1e9, N / two / 1e9, N / onek / 1e9, N / twok / 1e9, N / pg / 1e9, one * 1e6);
         out += buf;
+        // more streams, and an event recorded behind every copy
+        std::string more = std::string(", \"h2d_") + names[si] + "_streams\": {";
+        for (int ns = 1; ns <= 4; ns++) {
+            const double plain = run(ns, false, false, false); const double e1 = last_enqueue_us;
+            const double evd = run(ns, false, false, true); const double e2 = last_enqueue_us;
+            snprintf(buf, sizeof(buf), "%s\"%d\": {\"GBps\": %.2f, \"host_us_per_copy\": %.1f, \"with_an_event_per_copy_GBps\": %.2f, \"with_an_event_host_us\": %.1f}",
+                     ns > 1 ? ", " : "", ns, N / plain / 1e9, e1, N / evd / 1e9, e2);
+            more += buf;
+        }
+        out += more + "}";
     }
     // device-to-host: 16 rows of 5000 records (1.28 MB) and 16 rows of 20000 (5.12 MB)
     for (size_t bytes : {16ul * 5000 * 16, 16ul * 20000 * 16}) {

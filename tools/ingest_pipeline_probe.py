@@ -33,10 +33,16 @@ for lp in range(NPIN):
     ctx.upload(2 * lp + 1, f1)
     ctx.build_pyramids(2 * lp)
     ctx.select_async(2 * lp, 1, True, 500 + lp, NF)
+SYNC_DOWNLOAD = os.environ.get("KLT_PROBE_SYNC_DOWNLOAD") == "1"      # round 3's loop: a synchronous read-back every 16 pairs
 TAB = 100
-ctx.featbuf_alloc(TAB, NT * NF)
-for k in range(NT):
+ctx.featbuf_alloc(TAB, 2 * NT * NF)
+for k in range(2 * NT):
     ctx.featbuf_view(TAB + 1 + k, TAB, k * NF, NF)
+HALVES = (300, 301)
+for hlf in range(2):
+    ctx.featbuf_view(HALVES[hlf], TAB, hlf * NT * NF, NT * NF)
+from pyfeaturetrack_amd.backend import FEAT_DTYPE  # noqa: E402
+host_tab = [ctx.pinned_array((NT * NF,), FEAT_DTYPE) for _ in range(2)]
 
 
 def send(i):
@@ -52,11 +58,16 @@ def step(i, host):
     host[0] += time.perf_counter() - t
     t = time.perf_counter()
     ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
-    ctx.track_async(2 * lp, 2 * lp + 1, 500 + lp, TAB + 1 + i % NT, NF)
+    ctx.track_async(2 * lp, 2 * lp + 1, 500 + lp, TAB + 1 + i % (2 * NT), NF)
     host[1] += time.perf_counter() - t
     if i % NT == NT - 1:
         t = time.perf_counter()
-        ctx.featbuf_download(TAB, NT * NF)
+        win = i // NT
+        if SYNC_DOWNLOAD:
+            ctx.featbuf_download(HALVES[win % 2], NT * NF)
+        else:
+            ctx.download_wait()                                  # the previous window's records
+            ctx.featbuf_download_async(HALVES[win % 2], host_tab[win % 2])
         host[2] += time.perf_counter() - t
 
 
@@ -70,6 +81,7 @@ host = [0.0, 0.0, 0.0]
 t0 = time.perf_counter()
 for i in range(NT, NT + STEPS):
     step(i, host)
+ctx.download_wait()
 ctx.sync()
 el = (time.perf_counter() - t0) / STEPS
 print("%d pairs in rotation, uploads %d ahead: %.1f us per pair = %.1f GB/s; host per pair: uploads %.1f us, build + track %.1f us, table read-back %.1f us"
