@@ -276,6 +276,12 @@ class Context:
         self._check(self._lib.klt_featbuf_download(self._h, fb, out.ctypes.data, n))
         return out
 
+    def featbuf_download_into(self, fb, out):
+        """Download out.size records of feature buffer `fb` straight into the C-contiguous record array `out`."""
+        if out.dtype != FEAT_DTYPE or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("featbuf_download_into takes a C-contiguous array of klt_feat records")
+        self._check(self._lib.klt_featbuf_download(self._h, fb, out.ctypes.data, out.size))
+
     def featbuf_download_async(self, fb, out):
         """Enqueue the download of len(out) records of feature buffer `fb` into the PINNED record array `out` (pinned_array(..., FEAT_DTYPE));
         the records are there after download_wait().  The host does not wait for queued work (klt_featbuf_download_async)."""

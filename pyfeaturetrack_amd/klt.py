@@ -354,9 +354,11 @@ class KLT_FeatureTable:
     device-side table KLTTrackSequence fills, so a tracked sequence comes back with ONE download.  Upstream indexes
     feature-major (ft->feature[feat][frame]); `ft.feature(feat, frame)` mirrors that."""
 
-    def __init__(self, nFrames=0, nFeatures=0):
+    def __init__(self, nFrames=0, nFeatures=0, _fill=True):
         self.nFrames, self.nFeatures = nFrames, nFeatures
-        self.rec = _lost_records((nFrames, nFeatures))
+        # (_fill=False: the caller overwrites every row -- KLTTrackSequence's one download -- and marking 1.3 M records lost first would
+        # cost as much as tracking a dozen frames)
+        self.rec = _lost_records((nFrames, nFeatures)) if _fill else np.empty((nFrames, nFeatures), _REC_DTYPE)
 
     x = property(lambda self: self.rec["x"])
     y = property(lambda self: self.rec["y"])

@@ -265,11 +265,11 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
                         finally:
                             ctx.release_affine_state(state)
     nframes = k + 1
-    ft = KLT_FeatureTable(nframes, nFeatures)
+    ft = KLT_FeatureTable(nframes, nFeatures, _fill=False)
     for ci, base in enumerate(tables):
         lo = ci * chunk
         hi = min(nframes, lo + chunk)
-        ft.rec[lo:hi] = ctx.featbuf_download(base, (hi - lo) * nFeatures).reshape(hi - lo, nFeatures)
+        ctx.featbuf_download_into(base, ft.rec[lo:hi])          # rows lo .. hi-1 are contiguous in the table: no staging copy
     ft.rec["aux"] = 0
     if tc.sequentialMode:
         # leave the context as the per-frame API would: the last frame's pyramids are "frame 1" of the next call
