@@ -199,7 +199,8 @@ def ComputeImagePyramids(tc, img1, img2):
     at (:152-161).  The pyramids are built and stay on the device (one launch sequence for both images); the objects returned have the
     reference's KLTPyramid attributes, and `pyramid.img[level]` is the float32 plane, downloaded when first looked at."""
     ctx, s1, s2, ncols, nrows = _prepare_pair(tc, img1, img2)
-    settle_frames(ctx)
+    # (no settle_frames here: nothing has been waited for, the staged frames may still be on their way -- the next call that wants
+    # their pinned buffers waits for the copies)
     if tc.sequentialMode and tc.pyramid_last is not None and getattr(tc.pyramid_last, "_gen", None) == ctx.slot_generation(s1):
         first = (tc.pyramid_last, tc.pyramid_last_gradx, tc.pyramid_last_grady)
     else:
