@@ -4,7 +4,7 @@ pyramid depths, subsamplings, window sizes, minimum distances, skipped pixels, b
 per trial: pyramids of two frames, selection, tracking, replacement of the lost features on the second frame -- every record compared
 bit for bit.
 
-    python3 tools/fuzz_parity.py [--trials 40] [--seed 1] [--max-pixels 400000] [--max-n 700] [--max-side 900]
+    python3 tests/fuzz/fuzz_parity.py [--trials 40] [--seed 1] [--max-pixels 400000] [--max-n 700] [--max-side 900]
 --sequence: KLTTrackSequence against the per-frame host API loop on short random sequences (both are the HIP path; the per-frame
 API is the one pinned to the reference).
 Prints one line per trial and exits non-zero at the first difference (with the drawn parameters, so that it can be replayed by seed).
@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import make_tc, params_from_tc                      # noqa: E402

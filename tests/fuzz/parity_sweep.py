@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: random frame sizes / pyramid geometries / windows, HIP path against the CPU oracle
 (pyramids, eigenvalue map, selected list, tracked list, bit for bit).  Not part of the test suite: a longer soak of the kernels'
-tile-edge, alignment and fallback paths.   python tools/parity_sweep.py [cases] [seed] [max_width] [max_height]
+tile-edge, alignment and fallback paths.   python tests/fuzz/parity_sweep.py [cases] [seed] [max_width] [max_height]
 (frames of a megapixel and more take the tall-tile level-0 kernel with the fused first reduction)"""
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from pyfeaturetrack_amd import synth                       # noqa: E402

@@ -181,12 +181,12 @@ def test_gpu_affine_python_api_and_replacement(capsys):
 
 @pytest.mark.gpu
 def test_gpu_affine_matches_oracle_on_random_draws():
-    """tools/fuzz_parity.py --affine: frame sizes, pyramid shapes, tracker windows, affine windows 9-21, modes 0 / 1 / 2, residue and
+    """tests/fuzz/fuzz_parity.py --affine: frame sizes, pyramid shapes, tracker windows, affine windows 9-21, modes 0 / 1 / 2, residue and
     displacement limits, iteration counts and a random affine map per frame -- 20 draws (380 were run when the tool was written): every
     status, position, template offset and matrix entry equals the oracle's after each of three calls."""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     from pyfeaturetrack_amd.backend import Context

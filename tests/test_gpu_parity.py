@@ -669,11 +669,11 @@ def test_batched_pairs_in_alternating_sub_shards(ctx):
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_parameter_draws_vs_oracle(seed):
-    """tools/fuzz_parity.py: frame sizes of any parity, 1-4 levels, subsampling 2 / 4 / 8, windows 3-15, minimum distance 0-24, skipped
+    """tests/fuzz/fuzz_parity.py: frame sizes of any parity, 1-4 levels, subsampling 2 / 4 / 8, windows 3-15, minimum distance 0-24, skipped
     pixels, borders, residue limits, iteration counts and list lengths drawn at random -- selection, tracking and the replacement of the
     lost features identical to the oracle's in every record (900 draws were run when the tool was written; 2 x 25 stay in the suite)."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     from pyfeaturetrack_amd.backend import Context
@@ -715,10 +715,10 @@ def test_random_draws_the_reference_ran(ctx, golden_dir):
 
 
 def test_random_sequences_vs_per_frame_api():
-    """tools/fuzz_parity.py --sequence: KLTTrackSequence (device-resident table; build stream, prepared scores and frame stager switched on
+    """tests/fuzz/fuzz_parity.py --sequence: KLTTrackSequence (device-resident table; build stream, prepared scores and frame stager switched on
     and off by the draw) against the per-frame host API loop on 20 short random sequences with a wiped region -- identical tables."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     from pyfeaturetrack_amd import selectGoodFeatures as sgf, trackFeatures as tf
