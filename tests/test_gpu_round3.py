@@ -244,6 +244,7 @@ def _records(fl):
     return [(f.x, f.y, f.val) for f in fl]
 
 
+@pytest.mark.skipif(bool(os.environ.get("KLT_NO_FRAME_CACHE")), reason="the frame cache was switched off through the environment")
 def test_python_api_keeps_frames_resident_and_notices_changes():
     """The reference-shaped API with the frame cache (_frames.py): the ping-pong of example1 uploads and builds nothing after its
     first round trip, results are those of a cache-less run, an image edited in place is seen as new, KLTForgetFrames voids the
