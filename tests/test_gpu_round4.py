@@ -553,3 +553,52 @@ def test_records_come_back_without_draining_the_pipeline(img0, img1, cfg1):
             c.featbuf_download_async(6, np.empty(100, FEAT_DTYPE))
     finally:
         c.close()
+
+
+def test_one_context_per_host_thread():
+    """include/klt_gpu.h: "One context per host thread / device; no shared mutable globals" (ctypes releases the GIL during every call).
+    Six threads, a context each, run upload + pyramids + selection + tracking + replacement on their own frames at the same time, eight
+    rounds each with a different frame size per thread (so buffers are grown, LDS attributes set and kernels loaded concurrently); every
+    round gives exactly what the same calls give on one thread."""
+    import threading
+    from pyfeaturetrack_amd.backend import Context
+    sizes = [(320, 240, 150), (648, 486, 400), (500, 380, 300), (1280, 720, 1500), (402, 302, 200), (960, 540, 900)]
+    ROUNDS = 8
+    frames = [[synth.synth_pair(w, h, 100 * k + r) for r in range(ROUNDS)] for k, (w, h, _) in enumerate(sizes)]
+
+    def work(k, out, rounds):
+        n = sizes[k][2]
+        try:
+            c = Context(0)
+            try:
+                c.configure(make_tc(max_residue=10.0, levels=3 if k % 2 else 2, ss=2 if k % 2 else 4))
+                for r in range(rounds):
+                    f0, f1 = frames[k][r]
+                    c.upload(0, f0)
+                    c.upload(1, f1)
+                    c.build_pyramids_batch([0, 1], sync=False)
+                    fl, placed = c.select(0, n)
+                    trk, _ = c.track(0, 1, fl)
+                    rep, _ = c.select(1, n, mode=2, fl=trk)
+                    out.append((placed, fl.tobytes(), trk.tobytes(), rep.tobytes()))
+            finally:
+                c.close()
+        except BaseException as e:          # noqa: BLE001  (re-raised by the main thread)
+            out.append(e)
+
+    want = [[] for _ in sizes]
+    for k in range(len(sizes)):
+        work(k, want[k], 3)
+    got = [[] for _ in sizes]
+    threads = [threading.Thread(target=work, args=(k, got[k], ROUNDS)) for k in range(len(sizes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+        assert not t.is_alive()
+    for k in range(len(sizes)):
+        for e in got[k] + want[k]:
+            if isinstance(e, BaseException):
+                raise e
+        assert len(got[k]) == ROUNDS and got[k][:3] == want[k], "thread %d" % k
+        assert any(rec[0] > 0 for rec in got[k])
