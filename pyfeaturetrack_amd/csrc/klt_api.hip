@@ -1460,7 +1460,7 @@ int select_geometry(klt_ctx *c, int nc, int nr, SelGeom *g)
 
 // summed-area tables of the gradient products (goodFeaturesUtils.pyx:49-51): step-synchronous wavefront pipelines (sat_pipeline.hip)
 // where whole aligned quads can be moved, else the barrier-coupled kernels of select_kernels.hip
-int enqueue_sat(klt_ctx *c, hipStream_t st, const float *gx, const float *gy, float *sat, int nc, int nr)
+int enqueue_sat(klt_ctx *c, hipStream_t st, const float *gx, const float *gy, float *sat, int nc, int nr, bool rows_only = false)
 {
     const bool pipe = c->sat_variant == 1;
     const double N = (double)nc * nr;
@@ -1468,6 +1468,7 @@ int enqueue_sat(klt_ctx *c, hipStream_t st, const float *gx, const float *gy, fl
       const int e = pipe ? launch_sat_rows_pipe(st, gx, gy, sat, nc, nr) : -1;
       if (e > 0) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e));
       if (e < 0) launch_sat_rows(st, gx, gy, sat, nc, nr); }
+    if (rows_only) return 0;
     { TimerScope t(c, F_SAT_COLS, N * 24);
       const int e = pipe ? launch_sat_cols_pipe(st, sat, nc, nr) : -1;
       if (e > 0) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e));
@@ -1528,17 +1529,27 @@ int klt_select_prepare_async(klt_ctx *c, int slot)
         const ScoreCache *busy = c->sel_job ? c->sel_job->pre : nullptr;      // (a pending selection still reads its set)
         for (auto &x : c->pre) if (&x != busy && (!e || x.stamp < e->stamp)) e = &x;
     }
-    if (int rc = ensure(c, c->sat_pre, c->sat_pre_cap, 3 * N)) return rc;
+    if (int rc = ensure(c, c->sat_pre, c->sat_pre_cap, 3 * N + KLT_SAT_PAD)) return rc;
     if (int rc = ensure(c, e->keys, e->cap, (size_t)g.npow2)) return rc;
     e->gen = 0;
-    if (int rc = enqueue_sat(c, c->work, s->lv[0].gx, s->lv[0].gy, c->sat_pre, nc, nr)) return rc;
     SelectArgs sa;
     std::memset(&sa, 0, sizeof(sa));
     sa.sat = c->sat_pre; sa.keys = e->keys;
     sa.min_eig = c->p.min_eigenvalue < 1 ? 1.0 : c->p.min_eigenvalue;          // selectGoodFeatures.py:53
     sa.ncols = nc; sa.nrows = nr; sa.bx = g.bx; sa.by = g.by; sa.step = g.step; sa.nx = g.nx; sa.ny = g.ny;
     sa.hw = g.hw; sa.hh = g.hh; sa.npow2 = (int)g.npow2;
-    { TimerScope t(c, F_EIGEN, 12.0 * N + (double)g.ncand * 8); launch_eigen_hist(c->work, sa); }
+    // the tables' column pass and the eigenvalue keys in one launch where that applies (sat_pipeline.hip: the column-summed tables never
+    // reach HBM); KLT_FUSED_COLS_EIGEN=0: the two separate kernels
+    static const bool fused_cols_eigen = !(getenv("KLT_FUSED_COLS_EIGEN") && atoi(getenv("KLT_FUSED_COLS_EIGEN")) == 0);
+    if (fused_cols_eigen && c->sat_variant == 1 && sat_cols_eigen_ok(sa)) {
+        if (int rc = enqueue_sat(c, c->work, s->lv[0].gx, s->lv[0].gy, c->sat_pre, nc, nr, true)) return rc;
+        TimerScope t(c, F_EIGEN, 12.0 * N + (double)g.ncand * 8);
+        launch_sat_cols_eigen_pipe(c->work, c->sat_pre, sa);
+    } else {
+        if (int rc = enqueue_sat(c, c->work, s->lv[0].gx, s->lv[0].gy, c->sat_pre, nc, nr)) return rc;
+        TimerScope t(c, F_EIGEN, 12.0 * N + (double)g.ncand * 8);
+        launch_eigen_hist(c->work, sa);
+    }
     if (int rc = fresh_event(c, &e->ev, &e->ev_serial)) return rc;
     HIPCHK(c, hipEventRecord(e->ev, c->work));
     e->gen = s->gen; e->stamp = ++c->pre_stamp;

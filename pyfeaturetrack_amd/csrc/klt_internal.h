@@ -200,11 +200,51 @@ bool smooth_grad_hred_ok(const SmoothGradArgs &a, int batch, int kind, const Tap
 int launch_pyr_vreduce(hipStream_t s, const PyrReduceArgs &a, int batch);
 int launch_pyr_reduce(hipStream_t s, const PyrReduceArgs &a, int batch);
 
+// Eigenvalue and sort key of one candidate window from its three window sums (goodFeaturesUtils.pyx:17-19 as compiled: (gxx-gyy)^2 in f32,
+// 4*gxy*gxy and the sum in f64, pow(., 0.5) -> f32, (gxx+gyy-s) in f32, /2 exact); key 0 = not a candidate (val < max(min_eigenvalue, 1)).
+// One definition for every kernel that scores windows (select_kernels.hip, sat_pipeline.hip).
+__device__ __forceinline__ float klt_window_value(float gxx, float gxy, float gyy)
+{
+    const float dif = gxx - gyy;
+    const float sq = dif * dif;
+    const double t = (double)sq + (4.0 * (double)gxy) * (double)gxy;
+    const float s = (float)sqrt(t);
+    const float sum = gxx + gyy;
+    const float num = sum - s;
+    return (float)((double)num / 2.0);
+}
+
+__device__ __forceinline__ unsigned long long klt_pack_key(float val, int x, int y)
+{
+    return ((unsigned long long)__float_as_uint(val) << 32) | ((unsigned long long)x << 16) | (unsigned long long)y;
+}
+
+__device__ __forceinline__ unsigned long long klt_window_key(float gxx, float gxy, float gyy, double min_eig, int x, int y, float *val_out)
+{
+    const float val = klt_window_value(gxx, gxy, gyy);
+    *val_out = val;
+    return (double)val >= min_eig ? klt_pack_key(val, x, y) : 0ull;          // val >= max(min_eigenvalue, 1) > 0
+}
+
+// the smallest f32 that is >= m: for an f32 v, (double)v >= m exactly when v >= klt_threshold_f32(m) -- the test without the conversion
+// and the f64 compare (a kernel that scores windows waits for its CU's f64 pipes)
+inline float klt_threshold_f32(double m)
+{
+    float t = (float)m;
+    if ((double)t < m) t = nextafterf(t, INFINITY);
+    return t;
+}
+
 void launch_sat_rows(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows);
 void launch_sat_cols(hipStream_t s, float *sat, int ncols, int nrows);
 // step-synchronous wavefront pipelines (sat_pipeline.hip); return 0 or a hipError_t
 int  launch_sat_rows_pipe(hipStream_t s, const float *gx, const float *gy, float *sat, int ncols, int nrows);
 int  launch_sat_cols_pipe(hipStream_t s, float *sat, int ncols, int nrows);
+// column pass + eigenvalue keys in one launch (the column-summed tables never reach HBM); `sat` holds the ROW-summed planes, followed by
+// a pad of KLT_SAT_PAD floats (the last strip reads past a row's end), and is only read; keys only (no seed map, value map, histogram or given values); -1 = not applicable (the caller runs the two separate kernels)
+constexpr int KLT_SAT_PAD = 64;
+bool sat_cols_eigen_ok(const SelectArgs &a);
+int  launch_sat_cols_eigen_pipe(hipStream_t s, const float *sat, const SelectArgs &a);
 void launch_seed_fill(hipStream_t s, const klt_feat *fl, int nfeat, uint8_t *seedmap, int ncols, int nrows, int d, uint8_t stamp);
 void launch_eigen(hipStream_t s, const SelectArgs &a);
 void launch_sort_desc(hipStream_t s, unsigned long long *keys, int npow2);

@@ -20,8 +20,11 @@
 #ifdef SAT_PIPE_DEBUG
 __device__ long long g_sat_dbg[6 * 64 * 3];       // workgroup 0: per wavefront and step {step start, work done, barrier passed}
 #define SAT_MARK(w, s, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (s) >= 0 && (s) < 64) g_sat_dbg[((w) * 64 + (s)) * 3 + (i)] = wall_clock64(); } while (0)
+__device__ long long g_fused_dbg[16 * 96 * 3];   // cols_eigen_pipe, workgroup 0: per wavefront and step {step start, work done, barrier passed}
+#define FUSED_MARK(w, s, i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (s) >= 0 && (s) < 96) g_fused_dbg[((w) * 96 + (s)) * 3 + (i)] = wall_clock64(); } while (0)
 #else
 #define SAT_MARK(w, s, i) do { } while (0)
+#define FUSED_MARK(w, s, i) do { } while (0)
 #endif
 
 namespace {
@@ -235,6 +238,161 @@ __global__ __launch_bounds__(PIPE_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     }
 }
 
+
+// ------------------------------------------------------------------ column pass + eigenvalue keys (the column-summed tables stay in LDS)
+// The column pass above writes 12 bytes per pixel that the eigenvalue kernel reads straight back: at 4K 100 MB each way, 2 x ~20 us of a
+// selection whose tables nobody else reads (klt_select_prepare_async).  Here a workgroup owns a strip of FW table columns of all three
+// planes and walks down the frame in tiles of FT rows through a ring of four LDS slots:
+//   step s: loaders write tile s | chain wavefronts scan tile s - 1 in place | eigen wavefronts score the candidates whose window's
+//           BOTTOM row lies in tile s - 2 (its top row, 2 hh + 1 rows higher, lies in tile s - 2 or s - 3: 2 hh + 1 <= FT)
+// and the only things that reach HBM are the keys.  A strip of FW table columns serves FW - (2 hw + 1) candidate columns (a window
+// needs the columns x - hw - 1 and x + hw), so neighbouring strips overlap by 2 hw + 1 columns that both scan: FW = 32 with two rows
+// per wavefront keeps the overlap at 22 % (7x7) and gives a 4K frame 144 workgroups -- scoring a candidate is ~80 instructions (an f64
+// square root among them), a 64-column strip would leave the whole frame's scoring to 64 CUs.
+#ifndef KLT_F_LOAD
+#define KLT_F_LOAD 3
+#endif
+#ifndef KLT_F_EIGEN
+#define KLT_F_EIGEN 8
+#endif
+#ifndef KLT_F_FT
+#define KLT_F_FT 32
+#endif
+constexpr int FW = 32, FT = KLT_F_FT, FSLOTS = 4 /* a power of two */, FPLANE = FT * FW, FSLOT = 3 * FPLANE;
+constexpr int FN_CHAIN = 2, FN_LOAD = KLT_F_LOAD, FN_EIGEN = KLT_F_EIGEN;
+constexpr int FUSED_THREADS = 64 * (FN_CHAIN + FN_LOAD + FN_EIGEN);
+// (Bands of candidate rows per strip, each band a workgroup of its own whose chains start at the top of the frame -- 288 workgroups for a
+// 4K frame instead of 144 -- were measured: 80.7 us alone against 68.7.  A CU's f64 pipes are what a scoring step waits for
+// (tools/mb/cols_eigen_steps.hip: the eight eigen wavefronts work 0.5-0.9 us of a 1.0 us step), two workgroups on one CU halve each
+// other, and 144 strips do not spread evenly over 256 CUs.)
+
+struct ColsEigenArgs {
+    const float *sat;                 // row-summed planes
+    unsigned long long *keys;
+    float min_eig_f32;                // klt_threshold_f32(max(min_eigenvalue, 1))
+    int ncols, nrows, bx, by, nx, ny, hw, hh, per_strip, ntiles;
+};
+
+__global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(1, 4))) void cols_eigen_pipe(ColsEigenArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float pipe_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int c0 = a.bx - a.hw - 1 + a.per_strip * (int)blockIdx.x;       // first table column of the strip
+    const int ntiles = a.ntiles, nsteps = ntiles + 2;
+    const int first_scored = (a.by + a.hh) / FT;                               // the first tile that holds the bottom row of a candidate's window
+    const size_t plane = (size_t)a.ncols * a.nrows;
+
+    if (wave < FN_CHAIN) {                                       // ---- the chains: lane = (plane, column); wavefront 1 runs plane 2 on 32 lanes
+        const int pl = 2 * wave + half;
+        const bool mine = pl < 3;
+        float carry = 0.f;
+        for (int s = 0; s < nsteps; s++) {
+            FUSED_MARK(wave, s, 0);
+            if (s >= 1 && s <= ntiles && mine) {
+                float *tile = pipe_lds + ((s - 1) % FSLOTS) * FSLOT + pl * FPLANE + col;
+                float v[FT];
+#pragma unroll
+                for (int u = 0; u < FT; u++) v[u] = tile[u * FW];
+#pragma unroll
+                for (int u = 0; u < FT; u++) {
+                    carry = carry + v[u];
+                    tile[u * FW] = carry;
+                }
+            }
+            FUSED_MARK(wave, s, 1);
+            step_barrier();
+            FUSED_MARK(wave, s, 2);
+        }
+    } else if (wave < FN_CHAIN + FN_LOAD) {                       // ---- loaders: lane = (row of a group of eight, quad of the strip); every FN_LOAD-th tile, all planes
+        // 16-byte loads (a strip row is 128 bytes: eight lanes), 12 per tile -- with one dword per lane a tile was 48 load instructions, and
+        // the loader whose turn it was held every step's barrier for the time it takes to issue them.  The strip starts at any column, so
+        // the loads are only 4-byte aligned; the last strip reads up to 31 floats past a row's end (the next row, or the pad behind the
+        // planes): columns that no candidate's window uses.
+        const int j = wave - FN_CHAIN;
+        const int g = lane >> 3, q = lane & 7;
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        f32x4 v[3][FT / 8];
+        for (int s = -FN_LOAD; s < nsteps; s++) {
+            FUSED_MARK(wave, s, 0);
+            if (s >= 0 && s % FN_LOAD == j && s < ntiles) {
+                float *slot = pipe_lds + (s % FSLOTS) * FSLOT + g * FW + 4 * q;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                    for (int r8 = 0; r8 < FT / 8; r8++) *reinterpret_cast<f32x4 *>(slot + pl * FPLANE + 8 * r8 * FW) = v[pl][r8];
+            }
+            if ((s + FN_LOAD) % FN_LOAD == j && s + FN_LOAD < ntiles) {
+                const int t = s + FN_LOAD;
+#pragma unroll
+                for (int r8 = 0; r8 < FT / 8; r8++) {
+                    const size_t o = (size_t)min(t * FT + 8 * r8 + g, a.nrows - 1) * a.ncols + (c0 + 4 * q);
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) v[pl][r8] = *reinterpret_cast<const f32x4u *>(a.sat + pl * plane + o);
+                }
+            }
+            FUSED_MARK(wave, s, 1);
+            if (s >= 0) step_barrier();
+            FUSED_MARK(wave, s, 2);
+        }
+    } else {                                                    // ---- eigen wavefronts: lane = (row parity, strip column); two row pairs per step
+        const int e = wave - FN_CHAIN - FN_LOAD;
+        const int x = c0 + col;
+        const bool col_ok = col >= a.hw + 1 && col < a.hw + 1 + a.per_strip && x < a.bx + a.nx;
+        // (lanes that score nothing read the strip's own column: valid LDS addresses, results dropped -- the loop body is straight-line code)
+        const int cl = col_ok ? col - a.hw - 1 : col, cr = col_ok ? col + a.hw : col;          // left / right table column of the window
+        constexpr int NIT = FT / 2 / FN_EIGEN;
+        static_assert(NIT * 2 * FN_EIGEN == FT, "the eigen wavefronts share a tile's rows evenly");
+        // everything but the tile number is a constant of the lane: row of the window's bottom inside its tile, row of its top inside
+        // that tile or the one before, the candidate's row in tile 0, and where its key goes
+        int bot_off[NIT], top_off[NIT], y0[NIT];
+        bool top_before[NIT];
+        long long kidx[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int rl = 2 * (e + FN_EIGEN * it) + half, rtl = rl - (2 * a.hh + 1);
+            bot_off[it] = rl * FW;
+            top_before[it] = rtl < 0;
+            top_off[it] = (rtl < 0 ? rtl + FT : rtl) * FW;
+            y0[it] = rl - a.hh;
+            kidx[it] = (long long)(y0[it] - a.by) * a.nx + (x - a.bx);       // (negative for the rows above the first candidate row: not stored to)
+        }
+        const long long kstep = (long long)FT * a.nx;
+        for (int s = 0; s < nsteps; s++) {
+            const int t = s - 2;
+            FUSED_MARK(wave, s, 0);
+            if (t >= first_scored && t < ntiles) {
+                const float *sb = pipe_lds + (t & (FSLOTS - 1)) * FSLOT, *sp = pipe_lds + ((t - 1) & (FSLOTS - 1)) * FSLOT;
+                float sum[NIT][3];
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const float *top = (top_before[it] ? sp : sb) + top_off[it];
+                    const float *bot = sb + bot_off[it];
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) {
+                        const float wa = top[pl * FPLANE + cl], wb = top[pl * FPLANE + cr];
+                        const float wc = bot[pl * FPLANE + cr], wd = bot[pl * FPLANE + cl];
+                        sum[it][pl] = ((wc + wa) - wb) - wd;                    // SumGradientInWindow, goodFeaturesUtils.pyx:23-31
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int y = t * FT + y0[it];
+                    const float val = klt_window_value(sum[it][0], sum[it][1], sum[it][2]);
+                    const unsigned long long key = val >= a.min_eig_f32 ? klt_pack_key(val, x, y) : 0ull;
+                    if (col_ok && (unsigned)(y - a.by) < (unsigned)a.ny) a.keys[kidx[it]] = key;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; it++)
+                if (t >= 0) kidx[it] += kstep;
+            FUSED_MARK(wave, s, 1);
+            step_barrier();
+            FUSED_MARK(wave, s, 2);
+        }
+    }
+}
+
 }  // namespace
 
 // Both passes move whole aligned quads: they need ncols % 4 == 0 and 16-byte aligned planes; -1 = not applicable (the caller
@@ -269,5 +427,31 @@ int launch_sat_cols_pipe(hipStream_t s, float *sat, int ncols, int nrows)
         set = true;
     }
     klt_launch(sat_cols_pipe, dim3((ncols + 63) / 64, 3), dim3(PIPE_THREADS), (unsigned)lds, s, sat, ncols, nrows);
+    return 0;
+}
+
+bool sat_cols_eigen_ok(const SelectArgs &a)
+{
+    // keys only, every pixel a candidate column / row (step 1), a window whose rows fit one tile and whose columns leave a strip room
+    if (a.seedmap || a.valmap || a.val_in || a.hist || a.step != 1 || 2 * a.hh + 1 > FT || FW - (2 * a.hw + 1) < 8 || a.nx <= 0 || a.ny <= 0) return false;
+    return a.bx - a.hw - 1 >= 0 && a.by - a.hh - 1 >= 0 && a.by + a.ny + a.hh <= a.nrows;
+}
+
+int launch_sat_cols_eigen_pipe(hipStream_t s, const float *sat, const SelectArgs &a)
+{
+    if (!sat_cols_eigen_ok(a)) return -1;
+    ColsEigenArgs k;
+    k.sat = sat; k.keys = a.keys; k.min_eig_f32 = klt_threshold_f32(a.min_eig);
+    k.ncols = a.ncols; k.nrows = a.nrows; k.bx = a.bx; k.by = a.by; k.nx = a.nx; k.ny = a.ny; k.hw = a.hw; k.hh = a.hh;
+    k.per_strip = FW - (2 * a.hw + 1);
+    k.ntiles = (a.by + a.ny + a.hh + FT - 1) / FT;              // rows 0 .. by + ny - 1 + hh: the chains start at the top of the frame
+    constexpr size_t lds = sizeof(float) * FSLOTS * FSLOT;
+    static bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute((const void *)cols_eigen_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        set = true;
+    }
+    klt_launch(cols_eigen_pipe, dim3((a.nx + k.per_strip - 1) / k.per_strip), dim3(FUSED_THREADS), (unsigned)lds, s, k);
     return 0;
 }

@@ -239,18 +239,14 @@ __device__ __forceinline__ unsigned long long eigen_key(const SelectArgs &a, int
     const float gxx = window_sum(a.sat, a.ncols, x, y, a.hw, a.hh);
     const float gxy = window_sum(a.sat + plane, a.ncols, x, y, a.hw, a.hh);
     const float gyy = window_sum(a.sat + 2 * plane, a.ncols, x, y, a.hw, a.hh);
-    // goodFeaturesUtils.pyx:17-19 as compiled: (gxx-gyy)^2 in f32, 4*gxy*gxy and the sum in f64,
-    // pow(.,0.5) -> f32, (gxx+gyy-s) in f32, /2 exact
-    const float dif = gxx - gyy;
-    const float sq = dif * dif;
-    const double t = (double)sq + (4.0 * (double)gxy) * (double)gxy;
-    const float s = (float)sqrt(t);
-    const float sum = gxx + gyy;
-    const float num = sum - s;
-    const float val = a.val_in ? a.val_in[k] : (float)((double)num / 2.0);
+    float val;
+    unsigned long long key = klt_window_key(gxx, gxy, gyy, a.min_eig, x, y, &val);       // goodFeaturesUtils.pyx:17-19 (klt_internal.h)
+    if (a.val_in) {                                                                      // test hook: the eigenvalue is given
+        val = a.val_in[k];
+        key = (double)val >= a.min_eig ? (((unsigned long long)__float_as_uint(val) << 32) | ((unsigned long long)x << 16) | (unsigned long long)y) : 0ull;
+    }
     if (a.valmap) a.valmap[k] = val;
-    const bool ok = (double)val >= a.min_eig;          // val >= max(min_eigenvalue, 1) > 0
-    return ok ? (((unsigned long long)__float_as_uint(val) << 32) | ((unsigned long long)x << 16) | (unsigned long long)y) : 0ull;
+    return key;
 }
 
 __global__ __launch_bounds__(256) void eigen_kernel(SelectArgs a)

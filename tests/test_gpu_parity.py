@@ -1731,3 +1731,56 @@ def test_two_rank_launch_reaches_rccl_on_one_gpu():
     else:
         assert "ncclCommInitRank" in r.stderr, r.stderr[-2000:]
         assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("case", [
+    # (width, height, window, levels, ss, min_eigenvalue, mindist, skipped pixels) -- more than 262 144 candidates each: below that a
+    # replacement does not use prepared scores
+    (1022, 647, 7, 2, 2, 1, 6, 0),        # a last strip that ends inside the frame's right border zone, rows that are no multiple of a tile
+    (941, 701, 3, 2, 2, 1, 5, 0),         # the smallest window: 29 candidate columns per strip
+    (1000, 780, 11, 2, 2, 2.5, 8, 0),     # a fractional threshold: the f32 threshold of the fused kernel against the reference's f64 compare
+    (1003, 800, 15, 2, 2, 1, 10, 0),      # the reference's affine-size window: 17 candidate columns per strip, 15 rows between top and bottom
+    (1100, 820, 23, 2, 2, 1, 10, 0),      # 9 candidate columns per strip
+    (1100, 820, 25, 2, 2, 1, 10, 0),      # too wide for a strip: the separate column pass + eigenvalue kernels
+    (1920, 1080, 7, 2, 4, 1, 10, 1),      # skipped pixels: not every pixel is a candidate -- the separate kernels
+    (1920, 1080, 7, 3, 4, 1e3, 10, 0),    # a high threshold: most windows are no candidates
+])
+def test_prepared_scores_of_the_fused_column_and_eigenvalue_kernel(ko, case):
+    """klt_select_prepare_async runs the tables' column pass and the eigenvalue keys as ONE kernel where a window fits a strip
+    (sat_pipeline.hip, cols_eigen_pipe) and as the two separate kernels elsewhere; the replacement that consumes the scores gives the
+    reference walk's list either way -- window sizes 3 .. 25, frames whose sides are no multiples of the strip / tile sizes, thresholds
+    that are no f32 values."""
+    from pyfeaturetrack_amd import synth
+    from pyfeaturetrack_amd.backend import Context, REPLACING_SOME
+    w, h, window, levels, ss, min_eig, mindist, skip = case
+    n = max(40, w * h // 1500)       # (64 n < half the candidates: the cut that makes a replacement use prepared scores)
+    f0 = synth.synth_frame(w, h, 21, 0)
+    tc = make_tc(levels=levels, ss=ss, window=window, mindist=mindist, nSkippedPixels=skip)
+    tc.min_eigenvalue = min_eig
+    p = params_from_tc(tc)
+    c = Context(0)
+    try:
+        c.configure(tc)
+        c.set_option(15, 1)
+        c.upload(0, f0)
+        c.build_pyramids(0, sync=False)
+        first, placed = c.select(0, n, use_pyramid=True)
+        want0 = ko.select_good_features(p, f0.astype(np.float32), n)
+        assert_feats(first, *oracle_feats(want0), what="selection %r" % (case,))
+        if placed < 8:
+            pytest.skip("too few features at this threshold to lose some")
+        rng = np.random.default_rng(5)
+        gone = rng.choice(np.flatnonzero(first["val"] >= 0), max(4, placed // 10), replace=False)
+        fl = first.copy()
+        fl["val"][gone] = -1
+        fl["x"][gone] = -1.0
+        fl["y"][gone] = -1.0
+        want = ko.select_good_features(p, f0.astype(np.float32), n, mode=REPLACING_SOME, fl=fl.copy())
+        c.select_prepare(0)
+        got, _ = c.select(0, n, mode=REPLACING_SOME, fl=fl.copy(), use_pyramid=True)
+        assert_feats(got, *oracle_feats(want), what="prepared replacement %r" % (case,))
+        from pyfeaturetrack_amd.backend import KltBackendError
+        with pytest.raises(KltBackendError, match="prepared scores"):
+            c.select_intermediate(3)                    # the replacement did use the prepared scores (it wrote no eigenvalue map)
+    finally:
+        c.close()

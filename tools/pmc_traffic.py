@@ -23,7 +23,7 @@ import sys
 FAMILY = [("smooth_grad_rb<unsigned char, true", "smooth_grad_l0"), ("smooth_grad_rb<float, true", "smooth_grad_l0"),
           ("smooth_grad_rb<float, false", "gradients"), ("smooth_grad_kernel", "smooth_grad_l0"),
           ("pyr_reduce", "pyramid_reduce"), ("pyr_vreduce", "pyramid_reduce"), ("track_kernel", "track"), ("sat_rows", "sat_rows"), ("sat_cols", "sat_cols"),
-          ("eigen_kernel", "eigen_keys"), ("eigen_hist_kernel", "eigen_keys"), ("nms_kernel", "nms"), ("mis_init", "min_distance_init"),
+          ("eigen_kernel", "eigen_keys"), ("eigen_hist_kernel", "eigen_keys"), ("cols_eigen_pipe", "eigen_keys"), ("nms_kernel", "nms"), ("mis_init", "min_distance_init"),
           ("mis_round", "min_distance_pass"), ("mis_compact", "min_distance_compact"), ("mis_rank", "min_distance_rank"),
           ("mis_place", "min_distance_place"), ("mis_prepare", "min_distance_prepare"), ("mask_hist", "mask_hist"),
           ("seed_fill", "seed_fill"), ("affine_kernel", "affine_check")]
