@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_fuzz_long_e.txt
+: > $O
+t() { local name="$1"; shift; local s=$(date +%s); r=$(timeout 900 python tests/fuzz/fuzz_parity.py "$@" 2>&1 | tail -1); echo "fuzz $name: $r" | tee -a $O; }
+t "default (seed 31337)" --trials 6000 --seed 31337
+t "sequence (seed 31337)" --trials 8000 --seed 31337 --sequence
+t "sequence, frames up to 3 Mpx (seed 31338)" --trials 300 --seed 31338 --sequence --max-pixels 3000000 --max-n 6000 --max-side 2200
+t "batch (seed 31337)" --trials 2000 --seed 31337 --batch
+t "huge (seed 4243, frames up to 8.5 Mpx)" --trials 80 --seed 4243 --max-pixels 8500000 --max-n 20000 --max-side 3900
