@@ -1357,6 +1357,7 @@ int select_job_start(klt_ctx *c, SelectJob &j)
         }
     } else {
         launch_zero_words(c->stream, j.zero_from, j.zero_n);      // threshold bin 0: every candidate
+        j.ma.sparse = 0;
     }
     if (!j.by_rank) HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)j.np2 * sizeof(unsigned long long), c->stream));
     j.round = 0;
@@ -1768,6 +1769,7 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
         ma.remaining = c->mis_cnt + off_rem; ma.acc_cnt = c->mis_cnt + off_tacc; ma.acc_cap = tile_cap;
         ma.acc_keys = c->mis_tile_keys; ma.info = j.info_d;
         ma.nx = nx; ma.ny = ny; ma.R = R; ma.stage = 1; ma.bx = bx; ma.by = by; ma.step = step;
+        ma.sparse = mode == KLT_REPLACING_SOME && prefilter ? 1 : 0;
         j.pa = na;                                          // placement: the accepted candidates never exclude each other
         j.pa.d = -1; j.pa.cell = 1; j.pa.cell_magic = 0u; j.pa.gw = j.pa.gh = 1; j.pa.grid_in_lds = 1; j.pa.grid_global = nullptr;
         j.pa.keys = c->keys2; j.pa.nkeys = (int)j.np2;

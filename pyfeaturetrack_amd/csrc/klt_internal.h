@@ -125,6 +125,7 @@ struct MisArgs {
     const uint8_t *seed;              // optional: [nrows][ncols] squares of the live features (pixels holding seed_stamp); keys were scored WITHOUT it
     uint8_t seed_stamp;               // (klt_select_prepare_async)
     int ncols;
+    int sparse;                       // 1: few candidates per tile are expected (a replacement behind the cut): later passes take several tiles per workgroup
 };
 
 // ---- timing by the dispatch's own timestamps --------------------------------------------------------------------------------

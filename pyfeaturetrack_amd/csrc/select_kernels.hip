@@ -747,7 +747,7 @@ __global__ __launch_bounds__(MIS_T) void mis_init_kernel(MisArgs a)
 // RC > 0: the exclusion radius as a compile-time constant (the reference's default mindist 10 -> 9 cells: tile geometry, window
 // loops and the index arithmetic fold); RC = 0: any radius
 template <int RC>
-__global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
+__device__ __forceinline__ void mis_round_tile(const MisArgs &a, int round, unsigned tile, unsigned n)
 {
     // staged tiles: S = states of the tile + halo ((32 + 2R)^2 u32), H = per row of S and interior column the maximum
     // state over the horizontal window; a candidate then needs the 2R + 1 values of H above and below it.  The maximum
@@ -757,9 +757,6 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
     extern __shared__ uint32_t lds32[];
     __shared__ unsigned short top_local[MIS_CAP], wait_local[MIS_CAP];
     __shared__ unsigned s_cursor, s_acc, s_top, s_left;
-    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
-    const unsigned n = a.cnt[tile];
-    if (n == 0u) return;
     const unsigned have = a.acc_cnt[tile];             // accepted candidates of this tile so far
     const int tiles_x = (a.nx + MIS_TILE - 1) / MIS_TILE;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -988,6 +985,31 @@ __global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round)
         const unsigned long long key = ((unsigned long long)sp << 32) | ((unsigned long long)(a.bx + xi * a.step) << 16) |
                                        (unsigned long long)(a.by + yi * a.step);
         a.acc_keys[s_base + i] = key;
+    }
+}
+
+// One workgroup = TPW consecutive tiles of its XCD's eighth (see xcd_tile), one after the other.  After the first pass most tiles have
+// nothing left to decide, and a workgroup whose only act is to find that out costs a launch slot and a round trip to its counter: 6780
+// such workgroups (4K) were 5-8 us of every later pass.  Four tiles per workgroup, their counters requested together, make that a
+// quarter of the workgroups with one round trip each; the first pass, where almost every tile has work, keeps one tile per workgroup.
+constexpr int MIS_TPW_MAX = 4;
+template <int RC>
+__global__ __launch_bounds__(MIS_T) void mis_round_kernel(MisArgs a, int round, int tpw)
+{
+    const unsigned ntile = (unsigned)(((a.nx + MIS_TILE - 1) / MIS_TILE) * ((a.ny + MIS_TILE - 1) / MIS_TILE));
+    const unsigned k = blockIdx.x & 7u, i = blockIdx.x >> 3, base = ntile >> 3, rem = ntile & 7u;
+    const unsigned first = k * base + min(k, rem), len = base + (k < rem ? 1u : 0u);      // XCD k's tiles
+    unsigned cnt[MIS_TPW_MAX];
+#pragma unroll
+    for (int sub = 0; sub < MIS_TPW_MAX; sub++) {
+        const unsigned j = i * (unsigned)tpw + (unsigned)sub;
+        cnt[sub] = sub < tpw && j < len ? a.cnt[first + j] : 0u;
+    }
+#pragma unroll
+    for (int sub = 0; sub < MIS_TPW_MAX; sub++) {
+        if (cnt[sub] == 0u) continue;                                                     // (uniform: the whole workgroup skips the tile)
+        mis_round_tile<RC>(a, round, first + i * (unsigned)tpw + (unsigned)sub, cnt[sub]);
+        __syncthreads();
     }
 }
 
@@ -1271,7 +1293,12 @@ static int launch_mis_round_t(hipStream_t s, const MisArgs &a, int round, size_t
         hipError_t e = hipFuncSetAttribute((const void *)mis_round_kernel<RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(mis_round_kernel<RC>, dim3(mis_tiles(a.nx, a.ny)), dim3(MIS_T), lds, s, a, round);
+    static const int tpw_later = getenv("KLT_MIS_TPW") ? atoi(getenv("KLT_MIS_TPW")) : MIS_TPW_MAX;      // 1: every pass one tile per workgroup
+    // (a selection of all features has hundreds of candidates per tile for several passes: four tiles per workgroup one after the other
+    // took its 5000-feature selection at 1080p from 0.149 to 0.185 ms)
+    const int tpw = round == 0 || !a.sparse ? 1 : (tpw_later < 1 ? 1 : (tpw_later > MIS_TPW_MAX ? MIS_TPW_MAX : tpw_later));
+    const int tiles = mis_tiles(a.nx, a.ny), per_xcd = (tiles + 7) / 8;
+    hipLaunchKernelGGL(mis_round_kernel<RC>, dim3(8 * ((per_xcd + tpw - 1) / tpw)), dim3(MIS_T), lds, s, a, round, tpw);
     return 0;
 }
 
