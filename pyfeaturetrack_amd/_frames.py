@@ -150,19 +150,30 @@ class FrameCache:
         if hb is not None:
             self.held[a] = hb
 
+    def plausible(self, key, slot, ctx):
+        """the fast rejects only: `slot` holds a frame of the image's size and mode with the same 1024-pixel lattice (and, in the
+        trusting mode, filled from the very same object).  True is a candidate, not a match: `verify` decides (the trusting mode
+        stops here, that is what it trusts)."""
+        if _DISABLED:
+            return False
+        h = self.held.get(slot)
+        if h is None or h.size != key.size or h.kind != key.kind or not ctx.frame_resident(slot):
+            return False
+        if self.trusting():
+            return h.ref is not None and h.ref() is key.img and h.sig == key.sig()
+        return h.sig == key.sig()
+
+    def verify(self, key, slot):
+        """every byte of the image against the host copy the slot was filled from (the trusting mode does not look)"""
+        if self.trusting():
+            return True
+        h = self.held.get(slot)
+        return h is not None and same_pixels(key.array(), h.kept)
+
     def find(self, key, slots, ctx):
         """slot among `slots` whose resident frame has exactly the pixels of the image `key` names, or None"""
-        if _DISABLED:
-            return None
-        trusting = self.trusting()
         for s in slots:
-            h = self.held.get(s)
-            if h is None or h.size != key.size or h.kind != key.kind or not ctx.frame_resident(s):
-                continue
-            if trusting:
-                if h.ref is not None and h.ref() is key.img and h.sig == key.sig():
-                    return s
-            elif h.sig == key.sig() and same_pixels(key.array(), h.kept):
+            if self.plausible(key, s, ctx) and self.verify(key, s):
                 return s
         return None
 

@@ -4,7 +4,9 @@ Everything numeric happens behind the ABI in hand-written HIP kernels; this modu
 marshals numpy buffers and keeps the tracking-context parameters in sync.  There is no
 CPU fallback: creating a Context without a usable MI355X raises KltBackendError.
 """
+import collections
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -37,6 +39,11 @@ class Context:
         self._h = h
         self.device = int(device)
         self._params_key = None
+        # One context = one HIP stream set + one set of pinned record buffers: never two host threads inside it at a time
+        # (include/klt_gpu.h, "Threads").  The reference-shaped API holds this lock for the length of a KLT* call; callers that
+        # drive a Context directly from several threads take it themselves (`with ctx.lock:`) or give each thread its own.
+        self.lock = threading.RLock()
+        self._deferred = collections.deque()          # releases asked for by finalizers that could not get the lock at once
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -121,12 +128,37 @@ class Context:
         return base
 
     def release_slots(self, base, count=3):
+        """Finalizer of a tracking context (any thread, any moment -- the garbage collector runs it): never waits for the lock."""
+        self._when_free(self._release_slots, base, count)
+
+    def _release_slots(self, base, count):
         try:
             for k in range(count):
                 self.slot_free(base + k)
         except KltBackendError:
             return
         self.__dict__.setdefault("_free_slot_bases", []).append(base)
+
+    def _when_free(self, fn, *args):
+        """Run fn(*args) under the context's lock if nobody holds it (or this thread does); otherwise leave it for the next holder
+        (`settle_deferred`).  A finalizer that WAITED here could deadlock two threads whose collectors each free an object of the
+        other's context."""
+        if self.lock.acquire(blocking=False):
+            try:
+                fn(*args)
+            finally:
+                self.lock.release()
+        else:
+            self._deferred.append((fn, args))
+
+    def settle_deferred(self):
+        """(lock held) the releases finalizers left behind while another thread was inside the context"""
+        while self._deferred:
+            try:
+                fn, args = self._deferred.popleft()
+            except IndexError:
+                return
+            fn(*args)
 
     def take_affine_state(self):
         free = self.__dict__.setdefault("_free_affine_states", [])
@@ -137,6 +169,9 @@ class Context:
         return sid
 
     def release_affine_state(self, sid):
+        self._when_free(self._release_affine_state, sid)
+
+    def _release_affine_state(self, sid):
         try:
             self.affine_free(sid)
         except KltBackendError:
@@ -330,22 +365,42 @@ class Context:
         """klt_select for the host API without its spare round trips: SELECTING_ALL needs no list on the way in (every slot is
         written), REPLACING_SOME sends host_records(n)[0] (filled by the caller) without waiting for the copy; one download brings
         the records back into host_records(n)[1], which is returned."""
-        rin, rout = self.host_records(n)
+        self.select_enqueue(slot, n, mode, use_pyramid, fb)
+        return self.select_complete(n, fb)
+
+    def select_enqueue(self, slot, n, mode=SELECTING_ALL, use_pyramid=False, fb=65533):
+        """First half of select_records: the list goes up (REPLACING_SOME) and everything up to the host's look at the outcome is
+        enqueued (klt_select_begin_async); the caller does its own host work, then calls select_complete."""
         if mode == REPLACING_SOME:
-            self._check(self._lib.klt_featbuf_upload_async(self._h, fb, rin.ctypes.data, n))
-        self._check(self._lib.klt_select_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))
+            self._check(self._lib.klt_featbuf_upload_async(self._h, fb, self.host_records(n)[0].ctypes.data, n))
+        self._check(self._lib.klt_select_begin_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))
+
+    def select_complete(self, n, fb=65533):
+        """Second half: waits for the selection (klt_select_finish) and brings the records back into host_records(n)[1]."""
+        self._check(self._lib.klt_select_finish(self._h))
+        rout = self.host_records(n)[1]
         self._check(self._lib.klt_featbuf_download(self._h, fb, rout.ctypes.data, n))
         return rout
 
     def track_records(self, slot1, slot2, n, state=None, fb_in=65534, fb_out=65535):
         """klt_track / klt_track_affine on host_records(n): [0] (filled by the caller) goes up without waiting for the copy, the
         tracked records come back in [1], which is returned."""
-        rin, rout = self.host_records(n)
-        self._check(self._lib.klt_featbuf_upload_async(self._h, fb_in, rin.ctypes.data, n))
+        self.track_enqueue(slot1, slot2, n, state, True, fb_in, fb_out)
+        return self.track_complete(n, fb_out)
+
+    def track_enqueue(self, slot1, slot2, n, state=None, upload=True, fb_in=65534, fb_out=65535):
+        """The list in host_records(n)[0] goes up (`upload`; not again when the tracker is only repeated on other pyramids) and the
+        tracker is enqueued; nothing is waited for."""
+        if upload:
+            self._check(self._lib.klt_featbuf_upload_async(self._h, fb_in, self.host_records(n)[0].ctypes.data, n))
         if state is None:
             self._check(self._lib.klt_track_async(self._h, slot1, slot2, fb_in, fb_out, n))
         else:
             self._check(self._lib.klt_track_affine_async(self._h, slot1, slot2, fb_in, fb_out, n, state))
+
+    def track_complete(self, n, fb_out=65535):
+        """The records of the LAST tracker enqueued into fb_out, in host_records(n)[1] (one synchronous download)."""
+        rout = self.host_records(n)[1]
         self._check(self._lib.klt_featbuf_download(self._h, fb_out, rout.ctypes.data, n))
         return rout
 
@@ -506,22 +561,40 @@ class Context:
                  "bytes": float(buf[i].bytes)} for i in range(n)]
 
 
-_default = {}
+_tls = threading.local()
 
 
 def default_context(device=None):
-    """Process-wide context used by the reference-shaped Python API (one per device)."""
+    """The calling THREAD's context for `device` (created on first use): the one the reference-shaped Python API works on.
+
+    One context per host thread and device (include/klt_gpu.h, "Threads"; SURVEY section 8(b): no shared mutable globals): two
+    threads that each track their own video run on their own HIP streams, parameters and pinned record buffers, side by side.
+    A tracking context (`KLT_TrackingContext`) stays with the context of the thread that first used it (`context_of`), because its
+    frames and pyramids live in that context's slots; every KLT* call holds that context's lock, so a tracking context handed to
+    another thread -- or shared by two -- is served one call at a time."""
     import os
     if device is None:
         device = int(os.environ.get("KLT_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         n = load_library().klt_device_count()
         if n > 0:
             device %= n
-    ctx = _default.get(device)
-    if ctx is None:
-        ctx = _default[device] = Context(device)
+    table = _tls.__dict__.setdefault("contexts", {})
+    ctx = table.get(device)
+    if ctx is None or ctx._h is None:
+        ctx = table[device] = Context(device)
     return ctx
 
 
-__all__ = ["Context", "default_context", "FEAT_DTYPE", "SELECTING_ALL", "REPLACING_SOME", "KltBackendError", "KltCommTimeout",
+def context_of(tc, device=None):
+    """The context a tracking context is bound to: the calling thread's default context when `tc` is first used, the same one ever
+    after (whichever thread calls)."""
+    ctx = tc.__dict__.get("_klt_ctx")
+    if ctx is None or ctx._h is None:
+        ctx = tc.__dict__["_klt_ctx"] = default_context(device)
+        tc.__dict__.pop("_klt_slots", None)                 # (slots of a context that was closed under it)
+        tc.__dict__.pop("_klt_frames", None)
+    return ctx
+
+
+__all__ = ["Context", "default_context", "context_of", "FEAT_DTYPE", "SELECTING_ALL", "REPLACING_SOME", "KltBackendError", "KltCommTimeout",
            "KLT_MAX_LEVELS", "KltParams"]

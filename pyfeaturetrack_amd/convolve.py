@@ -85,11 +85,15 @@ def KLTComputeSmoothedImage(img, sigma):
     """f32 image -> f32 image smoothed with (gauss, gauss) -- convolve.py:254-264.  Runs on the GPU."""
     from .backend import default_context
     g, _ = _computeKernels(sigma)
-    return default_context().smooth(_as_f32(img), g)
+    ctx = default_context()
+    with ctx.lock:
+        return ctx.smooth(_as_f32(img), g)
 
 
 def KLTComputeGradients(img, sigma):
     """(gradx, grady) -- convolve.py:226-248.  Runs on the GPU."""
     from .backend import default_context
     g, d = _computeKernels(sigma)
-    return default_context().gradients(_as_f32(img), g, d)
+    ctx = default_context()
+    with ctx.lock:
+        return ctx.gradients(_as_f32(img), g, d)

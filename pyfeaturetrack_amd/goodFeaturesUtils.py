@@ -25,8 +25,9 @@ def ScanImageForGoodFeatures(gradxArr, gradyArr, borderx, bordery, window_hw, wi
     val = np.empty(max(1, len(xs) * len(ys)), np.float32)
     ctx = default_context()
     nx, ny = C.c_int(), C.c_int()
-    ctx._check(ctx._lib.klt_scan_good_features_f32(ctx._h, gx.ctypes.data, gy.ctypes.data, ncols, nrows, bx, by, hw, hh, skip,
-                                                  val.ctypes.data, val.size, C.byref(nx), C.byref(ny)))
+    with ctx.lock:
+        ctx._check(ctx._lib.klt_scan_good_features_f32(ctx._h, gx.ctypes.data, gy.ctypes.data, ncols, nrows, bx, by, hw, hh, skip,
+                                                      val.ctypes.data, val.size, C.byref(nx), C.byref(ny)))
     assert (nx.value, ny.value) == (len(xs), len(ys))
     n = nx.value * ny.value
     pointlistx = list(np.tile(xs, ny.value))                 # numpy int32 scalars, as `pointlistx.extend(xRow)` leaves them (:67-71)

@@ -7,10 +7,13 @@ numeric state lives in a `klt_params` POD (include/klt_gpu.h) pushed across the 
 """
 from __future__ import print_function
 
+import gc as _gc
 import math
 import os as _os
 import time
+import weakref as _weakref
 from itertools import repeat as _repeat
+from operator import itemgetter as _itemgetter
 
 import numpy as np
 
@@ -128,9 +131,11 @@ class _FeatureStore:
     shared numpy columns, so KLTSelectGoodFeatures / KLTTrackFeatures / KLTReplaceLostFeatures move whole columns to and from the
     16-byte device records instead of looping over features; a feature object reads its row when somebody looks at it.
     x / y are kept as float64 (exact for the reference's values: integers after selection, f32-valued after tracking) plus a flag
-    that remembers whether the reference would hold a Python int there (`print` shows 86, not 86.0)."""
+    that remembers whether the reference would hold a Python int there (`print` shows 86, not 86.0).
+    The store does not point at its feature objects (they point at it): a dropped list is freed by reference counting, not by the
+    cycle collector.  `owner` is a weak reference to the KLT_FeatureList that was made with the store."""
 
-    __slots__ = ("x", "y", "val", "xint", "yint", "aff", "aff_img", "features", "__weakref__")
+    __slots__ = ("x", "y", "val", "xint", "yint", "aff", "aff_img", "owner", "__weakref__")
     _AFF_DEFAULTS = (("aff_x", -1.0), ("aff_y", -1.0), ("aff_Axx", 1.0), ("aff_Ayx", 0.0), ("aff_Axy", 0.0), ("aff_Ayy", 1.0))
 
     def __init__(self, n):
@@ -141,10 +146,13 @@ class _FeatureStore:
         self.yint = np.ones(n, bool)
         self.aff = None               # {name: float64 column}, created when an affine field is first written
         self.aff_img = None           # {name: object column} for aff_img / aff_img_gradx / aff_img_grady
-        self.features = None          # the KLT_Feature objects of rows 0 .. n-1 (new_feature_list)
+        self.owner = None             # weakref to the KLT_FeatureList whose `_canon` lists the objects of rows 0 .. n-1
 
     def __len__(self):
         return self.x.shape[0]
+
+    def __reduce__(self):                   # pickles / deep-copies as its columns (the owner is a weak reference)
+        return (_restored_store, (self.x, self.y, self.val, self.xint, self.yint, self.aff, self.aff_img))
 
     def aff_columns(self):
         if self.aff is None:
@@ -163,14 +171,20 @@ class _FeatureStore:
             col[rows] = None
 
 
+def _restored_store(x, y, val, xint, yint, aff, aff_img):
+    s = _FeatureStore(0)
+    s.x, s.y, s.val, s.xint, s.yint, s.aff, s.aff_img = x, y, val, xint, yint, aff, aff_img
+    return s
+
+
 def _coord_property(col, flag):
     def get(self):
-        s, i = self._s, self._i
+        s, i = self
         v = getattr(s, col)[i]
         return int(v) if getattr(s, flag)[i] else float(v)
 
     def put(self, value):
-        s, i = self._s, self._i
+        s, i = self
         getattr(s, col)[i] = value
         getattr(s, flag)[i] = isinstance(value, (int, np.integer)) and not isinstance(value, bool)
     return property(get, put)
@@ -178,48 +192,64 @@ def _coord_property(col, flag):
 
 def _aff_property(name, dflt):
     def get(self):
-        s = self._s
-        return dflt if s.aff is None else float(s.aff[name][self._i])
+        s, i = self
+        return dflt if s.aff is None else float(s.aff[name][i])
 
     def put(self, value):
-        self._s.aff_columns()[name][self._i] = value
+        s, i = self
+        s.aff_columns()[name][i] = value
     return property(get, put)
 
 
 def _aff_img_property(name):
     def get(self):
-        s = self._s
-        return None if s.aff is None else s.aff_img[name][self._i]
+        s, i = self
+        return None if s.aff is None else s.aff_img[name][i]
 
     def put(self, value):
-        s = self._s
+        s, i = self
         s.aff_columns()
-        s.aff_img[name][self._i] = value
+        s.aff_img[name][i] = value
     return property(get, put)
 
 
-class KLT_Feature:
+_tuple_new = tuple.__new__
+
+
+class KLT_Feature(tuple):
     """klt.py:249-263.  The reference's __init__ assigns locals only; real attributes are set on first placement
     (selectGoodFeatures.py:117-128).  Here x, y, val and the affine-consistency fields always exist; the object is a view of
-    row `_i` of a _FeatureStore (its own one-row store when created on its own, the list's shared store when it comes from
-    KLTSelectGoodFeatures / KLTCreateFeatureList)."""
+    row `_i` of a _FeatureStore `_s` (its own one-row store when created on its own, the list's shared store when it comes from
+    KLTSelectGoodFeatures / KLTCreateFeatureList).
 
-    __slots__ = ("_s", "_i", "__weakref__")
+    It is implemented as the PAIR (store, row) -- a `tuple` subclass -- because that is the cheapest object CPython can make in
+    bulk: a 5000-feature list is `map(tuple.__new__, ...)` over a `zip`, all of it in C, 2.7x faster than 5000 calls of a Python
+    `__init__` (0.21 against 0.57 ms at cfg-2's list length, `profiles/README.md`), and the list KLTSelectGoodFeatures hands out is
+    a complete list of feature objects as the reference's is.  Like the reference's objects a feature accepts further attributes,
+    can be weakly referenced, and is equal only to itself in practice (two objects are equal when they view the same row of the
+    same store)."""
 
-    def __init__(self, _store=None, _index=0):
-        self._s = _FeatureStore(1) if _store is None else _store
-        self._i = _index
+    def __new__(cls, _store=None, _index=0):
+        return _tuple_new(cls, (_FeatureStore(1) if _store is None else _store, _index))
+
+    def __getnewargs__(self):
+        return tuple(self)
+
+    _s = property(_itemgetter(0))
+    _i = property(_itemgetter(1))
 
     x = _coord_property("x", "xint")
     y = _coord_property("y", "yint")
 
     @property
     def val(self):
-        return int(self._s.val[self._i])
+        s, i = self
+        return int(s.val[i])
 
     @val.setter
     def val(self, value):
-        self._s.val[self._i] = value
+        s, i = self
+        s.val[i] = value
 
     aff_x = _aff_property("aff_x", -1.0)
     aff_y = _aff_property("aff_y", -1.0)
@@ -233,36 +263,51 @@ class KLT_Feature:
 
     def _reset_affine(self):
         """Back to the state of a newly placed feature (selectGoodFeatures.py:120-128)."""
-        self._s.reset_affine(self._i)
+        s, i = self
+        s.reset_affine(i)
+
+    def __repr__(self):
+        return "<KLT_Feature x={0!r} y={1!r} val={2!r}>".format(self.x, self.y, self.val)
 
 
 class KLT_FeatureList(list):
     """The list KLTSelectGoodFeatures / KLTCreateFeatureList hand out (the reference builds `[KLT_Feature() for i in
     range(nFeatures)]`, selectGoodFeatures.py:143; its own KLT_FeatureList is commented out, klt.py:266-270).  It IS a list of
-    KLT_Feature objects -- but the 5000 Python objects of a cfg-2 list cost 1.1 ms to create, four times what the device needs to
-    select the features, and a tracking loop that only hands the list from one KLT* call to the next never looks at one of them.
+    KLT_Feature objects -- complete when it is handed out, as the reference's -- made in one C-level pass with the cycle collector
+    paused (`_fill`), which KLTSelectGoodFeatures runs while the device is still selecting.  A tracking loop that only hands the
+    list from one KLT* call to the next never looks at one of the objects: the calls work on the column store.
     In the LAZY mode (opt-in: `klt.LAZY_FEATURE_LISTS = True`, or KLT_LAZY_FEATURE_LISTS=1 in the environment) the objects are
-    therefore made when somebody first touches an element (indexing, iteration, any list method); `len()`, truth value and the KLT*
-    calls themselves work on the column store and do not.  The price of that mode: C code that reads the list's storage directly
-    (`PySequence_Fast` users such as slice assignment `a[0:0] = fl`, numpy's array constructor, Cython functions with list-typed
-    arguments) sees an empty list until something has touched it.  By DEFAULT the list is therefore filled when it is created -- a
-    plain, complete list of KLT_Feature objects as the reference hands out -- and only the column store behind the objects remains
-    (the KLT* calls still move whole columns)."""
+    made when somebody first touches an element (indexing, iteration, any list method); `len()`, truth value and the KLT* calls
+    themselves do not.  The price of that mode: C code that reads the list's storage directly (`PySequence_Fast` users such as
+    slice assignment `a[0:0] = fl`, numpy's array constructor, Cython functions with list-typed arguments) sees an empty list
+    until something has touched it."""
 
-    __slots__ = ("_store", "_pending")
+    __slots__ = ("_store", "_pending", "_canon", "__weakref__")
 
     def __init__(self, store):
         list.__init__(self)
         self._store = store
         self._pending = len(store)
+        self._canon = None            # private copy of the complete list: what `shared_store` compares a caller's list with
 
     def _fill(self):
         n = self._pending
         if n:
             self._pending = 0
             store = self._store
-            list.extend(self, map(KLT_Feature, _repeat(store, n), range(n)))
-            store.features = list(self)         # a private copy: the caller's list may be edited
+            # 5000 new container objects cross the collector's young-generation threshold seven times; the young objects are all
+            # reachable, so those passes find nothing and double the cost of the fill.  Paused for the length of one C call; a
+            # collector the caller has disabled stays disabled.
+            paused = _gc.isenabled()
+            if paused:
+                _gc.disable()
+            try:
+                list.extend(self, map(_tuple_new, _repeat(KLT_Feature, n), zip(_repeat(store, n), range(n))))
+            finally:
+                if paused:
+                    _gc.enable()
+            self._canon = list.copy(self)       # the caller's list may be edited
+            store.owner = _weakref.ref(self)
 
     def __len__(self):
         return self._pending or list.__len__(self)
@@ -299,27 +344,37 @@ KLT_FeatureList.__hash__ = None
 LAZY_FEATURE_LISTS = _os.environ.get("KLT_LAZY_FEATURE_LISTS") == "1"
 
 
-def new_feature_list(n):
-    """n lost features sharing one column store (what KLTSelectGoodFeatures / KLTCreateFeatureList hand out)."""
+def new_feature_list(n, fill=None):
+    """n lost features sharing one column store (what KLTSelectGoodFeatures / KLTCreateFeatureList hand out).  `fill=False`: the
+    caller fills the list itself (KLTSelectGoodFeatures: after the selection has been enqueued)."""
     fl = KLT_FeatureList(_FeatureStore(n))
-    if not LAZY_FEATURE_LISTS:
+    if (not LAZY_FEATURE_LISTS) if fill is None else fill:
         fl._fill()
     return fl
+
+
+_list_eq = list.__eq__
 
 
 def shared_store(featurelist):
     """The _FeatureStore whose rows 0 .. n-1 are exactly this list's features, in order -- or None (a list assembled by hand,
     re-ordered, or mixing features of several lists), in which case callers fall back to per-feature access.  The test is one
-    C-level list comparison (identity of every element)."""
-    if type(featurelist) is KLT_FeatureList and featurelist._pending:
-        return featurelist._store           # nobody has looked at an element yet: the list is the store's rows by construction
+    C-level list comparison (identity of every element) with the private copy made when the list was filled; a plain-list copy of
+    a list this package handed out is recognised for as long as the original is alive."""
+    if type(featurelist) is KLT_FeatureList:
+        if featurelist._pending:
+            return featurelist._store           # nobody has looked at an element yet: the list is the store's rows by construction
+        canon = featurelist._canon
+        if canon is not None and _list_eq(featurelist, canon) is True:
+            return featurelist._store
     try:
         s = featurelist[0]._s
-    except (IndexError, AttributeError):
+        owner = s.owner() if s.owner is not None else None
+    except (IndexError, AttributeError, TypeError):
         return None
-    if s.features is None or len(featurelist) != len(s.features):
+    if owner is None or owner._canon is None or len(featurelist) != len(owner._canon):
         return None
-    return s if featurelist == s.features else None
+    return s if _list_eq(list(featurelist) if type(featurelist) is not list else featurelist, owner._canon) is True else None
 
 
 _REC_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("val", np.int32), ("aux", np.int32)])   # == klt_feat

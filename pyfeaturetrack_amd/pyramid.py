@@ -36,4 +36,6 @@ class KLTPyramid:
         self.img[0] = img
         if self.nLevels > 1:
             gauss, _ = _computeKernels(self.subsampling * sigma_fact)
-            self.img[1:] = default_context().pyramid(img, self.subsampling, self.nLevels, gauss)
+            ctx = default_context()
+            with ctx.lock:
+                self.img[1:] = ctx.pyramid(img, self.subsampling, self.nLevels, gauss)

@@ -9,7 +9,8 @@ from __future__ import print_function
 
 import numpy as np
 
-from .backend import FEAT_DTYPE, REPLACING_SOME, SELECTING_ALL, default_context
+from .backend import FEAT_DTYPE, REPLACING_SOME, SELECTING_ALL, context_of, default_context  # noqa: F401
+from . import klt as klt_module
 from .klt import KLT_Feature, KLTCountRemainingFeatures, kltState, new_feature_list, shared_store
 from .error import KLTWarning
 
@@ -37,13 +38,18 @@ def _image_size(img):
     return img.size
 
 
-def features_to_array(featurelist, out=None):
+_UNKNOWN = object()
+
+
+def features_to_array(featurelist, out=None, store=_UNKNOWN):
     """KLT_Feature list -> record array (`out`, or a new one).  A list whose features share one column store (every list this
-    package hands out) is converted column by column; anything else feature by feature."""
+    package hands out) is converted column by column; anything else feature by feature.  `store`: what shared_store(featurelist)
+    gave, for a caller that has asked already."""
     fl = np.zeros(len(featurelist), FEAT_DTYPE) if out is None else out
     if out is not None:
         fl["aux"] = 0
-    store = shared_store(featurelist)
+    if store is _UNKNOWN:
+        store = shared_store(featurelist)
     if store is not None:
         fl["x"], fl["y"], fl["val"] = store.x, store.y, store.val
     elif len(featurelist):
@@ -55,10 +61,10 @@ def features_to_array(featurelist, out=None):
 
 def _slots_of(tc):
     """Two device slots per tracking context: [frame 1, frame 2]; a third for selection frames."""
-    s = getattr(tc, "_klt_slots", None)
+    s = tc.__dict__.get("_klt_slots")
     if s is None:
         import weakref
-        ctx = default_context()
+        ctx = context_of(tc)
         base = ctx.take_slots(3)
         s = tc._klt_slots = (base, base + 1, base + 2)
         weakref.finalize(tc, ctx.release_slots, base, 3)      # the device memory goes when the tracking context does
@@ -93,14 +99,18 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
     if tc.mindist < 0:
         KLTWarning("(_KLTSelectGoodFeatures) Tracking context field tc.mindist is negative ({0}); setting to zero".format(tc.mindist))
         tc.mindist = 0
+    ctx = context_of(tc)
+    with ctx.lock:                                      # one KLT* call at a time per device context (backend.default_context)
+        ctx.settle_deferred()
+        return _select_locked(ctx, tc, img, nFeatures, mode, featurelist)
+
+
+def _select_locked(ctx, tc, img, nFeatures, mode, featurelist):
     from ._frames import FrameKey, cache_of, settle_frames
-    ctx = default_context()
     if cache_of(tc).handles and not ctx.configured_for(tc):
         cache_of(tc).keep_all_handles()               # new parameters void every pyramid of the context: kept handles fetch theirs first
     ctx.configure(tc)
     slots = _slots_of(tc)
-    if featurelist is None:
-        featurelist = new_feature_list(nFeatures)
     reuse = (mode == selectionMode.REPLACING_SOME and tc.sequentialMode and tc.pyramid_last is not None
              and ctx.pyramids_valid(slots[0]))
     if reuse:
@@ -127,44 +137,58 @@ def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
         # and succeeds on such a frame, so the selection smooths and differentiates in its own slot
         slot = slots[2]
         ctx.upload(slot, image_to_array(img))
-    fl_in = features_to_array(featurelist, ctx.host_records(len(featurelist))[0]) if mode == selectionMode.REPLACING_SOME else None
-    from .trackFeatures import affine_state_lookup
-    aff = affine_state_lookup(ctx, featurelist)
-    if aff is not None and aff[1] == len(featurelist):
+    replacing = mode == selectionMode.REPLACING_SOME
+    n = int(nFeatures) if featurelist is None else len(featurelist)
+    store = fl_in = aff = None
+    if featurelist is not None:
+        store = shared_store(featurelist)
+        if replacing:
+            fl_in = features_to_array(featurelist, ctx.host_records(n)[0], store)
+        from .trackFeatures import affine_state_lookup
+        aff = affine_state_lookup(ctx, featurelist)
+    if aff is not None and aff[1] == n:
         ctx.set_option(4, aff[0])       # newly placed features lose their affine templates (:120-128)
     try:
-        fl = ctx.select_records(slot, len(featurelist), mode=mode, use_pyramid=reuse)
+        ctx.select_enqueue(slot, n, mode=mode, use_pyramid=reuse)
+        try:
+            if featurelist is None:
+                # the reference's `[KLT_Feature() for i in range(nFeatures)]` (:143), made while the device scores, sorts and picks
+                featurelist = new_feature_list(n, fill=False)
+                store = featurelist._store
+                if not klt_module.LAZY_FEATURE_LISTS:
+                    featurelist._fill()
+        finally:
+            fl = ctx.select_complete(n)
     finally:
         if aff is not None:
             ctx.set_option(4, -1)
     settle_frames(ctx)
     affine_used = aff is not None or tc.affineConsistencyCheck >= 0     # otherwise the affine fields were never assigned
     vals = fl["val"]
-    olds = fl_in["val"] if mode == selectionMode.REPLACING_SOME else None
-    store = shared_store(featurelist)
     if store is not None:
         # whole columns at once (selectGoodFeatures.py:109-128 touches every feature object in a Python loop)
-        free = np.ones(len(featurelist), bool) if olds is None else olds < 0      # live features are left untouched (:109-110)
-        placed = free & (vals >= 0)
-        store.x[placed] = fl["x"][placed]                                     # integer positions (:116-119)
-        store.y[placed] = fl["y"][placed]
-        store.val[placed] = vals[placed]
-        store.xint[placed] = True
-        store.yint[placed] = True
-        touched = placed
-        if mode == selectionMode.SELECTING_ALL:
-            missing = free & (vals < 0)
-            store.x[missing] = -1
-            store.y[missing] = -1
-            store.val[missing] = kltState.KLT_NOT_FOUND
-            store.xint[missing] = True
-            store.yint[missing] = True
-            touched = free
+        if replacing:
+            placed = fl_in["val"] < 0                                         # live features are left untouched (:109-110)
+            np.logical_and(placed, vals >= 0, out=placed)
+            touched = placed
+            np.copyto(store.x, fl["x"], where=placed)                         # integer positions (:116-119)
+            np.copyto(store.y, fl["y"], where=placed)
+            np.copyto(store.val, vals, where=placed)
+            np.logical_or(store.xint, placed, out=store.xint)
+            np.logical_or(store.yint, placed, out=store.yint)
+        else:
+            # every slot is written: the placed features, then (-1, -1, KLT_NOT_FOUND) where the candidates ran out
+            touched = slice(None)
+            store.x[:] = fl["x"]
+            store.y[:] = fl["y"]
+            store.val[:] = vals
+            store.xint[:] = True
+            store.yint[:] = True
         if affine_used:
             store.reset_affine(touched)
         return featurelist
     xs, ys, vals = fl["x"].tolist(), fl["y"].tolist(), vals.tolist()
-    olds = olds.tolist() if olds is not None else None
+    olds = fl_in["val"].tolist() if replacing else None
     for i, feat in enumerate(featurelist):
         if olds is not None and olds[i] >= 0:
             continue                # live features are left untouched (:109-110)

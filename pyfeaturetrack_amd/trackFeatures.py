@@ -8,7 +8,9 @@ frame-2 pyramids stay resident and become frame 1 of the next call (:152-161, :4
 from __future__ import print_function
 
 from . import selectGoodFeatures as _sgf
-from .backend import default_context
+import numpy as np
+
+from .backend import context_of, default_context  # noqa: F401
 from .klt import KLTCountRemainingFeatures, kltState, shared_store  # noqa: F401
 from ._frames import FrameKey, KLTForgetFrames, cache_of, settle_frames  # noqa: F401
 from .selectGoodFeatures import _fix_window, _image_size, _slots_of, features_to_array, image_to_array
@@ -90,16 +92,24 @@ def _pyramid_handles(tc, ctx, slot, ncols, nrows):
 _DEVICE_TEMPLATE = "<template on device>"      # what feat.aff_img* hold while the device keeps the templates
 
 
+def _anchor(featurelist):
+    """the object whose life stands for the list's features': the column store of the first feature (KLT_Feature objects are
+    (store, row) pairs and, like any tuple, cannot be weakly referenced; the store lives exactly as long as one of its features
+    does), or the first element itself for a list of foreign objects"""
+    first = featurelist[0]
+    return getattr(first, "_s", first)
+
+
 class _ListRef:
-    """Weak handle on a feature list (plain lists cannot be weakly referenced): the list's first feature object stands in for it.
+    """Weak handle on a feature list (plain lists cannot be weakly referenced): the first feature's column store stands in for it.
     The reference keeps the affine state in the KLT_Feature objects themselves, so the state dies with them."""
     def __init__(self, featurelist):
         import weakref
         self.ident = id(featurelist)
-        self.first = weakref.ref(featurelist[0]) if len(featurelist) else None
+        self.first = weakref.ref(_anchor(featurelist)) if len(featurelist) else None
 
     def matches(self, featurelist):
-        return (self.first is not None and len(featurelist) > 0 and self.first() is featurelist[0]
+        return (self.first is not None and len(featurelist) > 0 and self.first() is _anchor(featurelist)
                 and self.ident == id(featurelist))
 
 
@@ -131,7 +141,7 @@ def _affine_state_of(tc, ctx, featurelist):
                 if key in table and table[key][1] == sid:
                     del table[key]
                     ctx.release_affine_state(sid)
-            weakref.finalize(featurelist[0], _drop)
+            weakref.finalize(_anchor(featurelist), _drop)
     return entry[1]
 
 
@@ -140,18 +150,35 @@ def _outOfBounds(x, y, ncols, nrows, borderx, bordery):
     return x < borderx or x > ncols - 1 - borderx or y < bordery or y > nrows - 1 - bordery
 
 
-def _prepare_pair(tc, img1, img2):
-    """ComputeImagePyramids (trackFeatures.py:146-196) on the device: both frames in their slots with valid pyramids.
-    Returns (ctx, slot1, slot2, ncols, nrows)."""
+def _prepare_pair(tc, ctx, img1, img2, speculate=False):
+    """ComputeImagePyramids (trackFeatures.py:146-196) on the device: both frames in their slots, their pyramids built or being
+    built.  Returns (slot1, slot2, ncols, nrows, doubts).
+
+    `speculate`: a slot that passes the fast rejects (size, mode, 1024-pixel lattice) is TAKEN as holding the image, and listed in
+    `doubts` as (slot, key), frame 2 first: the caller enqueues its device work at once, compares every byte while the device
+    runs (`FrameCache.verify`), and for a frame that turns out to differ calls `_resend` and enqueues its work again.  Without it
+    every byte is compared before anything is enqueued and `doubts` is empty."""
     ncols, nrows = _image_size(img1)
     assert _image_size(img2) == (ncols, nrows)
     _fix_window(tc)
-    ctx = default_context()
     frames = cache_of(tc)
     if frames.handles and not ctx.configured_for(tc):
         frames.keep_all_handles()                     # new parameters void every pyramid of the context: kept handles fetch theirs first
     ctx.configure(tc)
     s1, s2, _ = _slots_of(tc)
+    doubts = []
+    sure = frames.trusting() or not speculate
+
+    def locate(key, slots):
+        """(slot that holds the image -- or, speculating, probably does --, True when that is still to be verified)"""
+        for s in slots:
+            if frames.plausible(key, s, ctx):
+                if not sure:
+                    return s, True
+                if frames.verify(key, s):
+                    return s, False
+        return None, False
+
     resident = tc.sequentialMode and tc.pyramid_last is not None
     if resident and not ctx.pyramids_valid(s1):
         # the pyramid geometry / taps changed since the last call (or another tracking context rebuilt the slot):
@@ -163,33 +190,46 @@ def _prepare_pair(tc, img1, img2):
             KLTError("(KLTTrackFeatures) Size of incoming image ({0} by {1}) is different from size of previous image "
                      "({2} by {3})".format(ncols, nrows, tc.pyramid_last.ncols[0], tc.pyramid_last.nrows[0]))
         k2 = FrameKey(img2)
-        if frames.find(k2, (s2,), ctx) is None:
+        at2, doubt2 = locate(k2, (s2,))
+        if at2 is None:
             frames.send(ctx, s2, k2)
             ctx.build_pyramids(s2, sync=False)
-        elif not ctx.pyramids_valid(s2):
-            frames.keep_handles(ctx, s2)
-            ctx.build_pyramids(s2, sync=False)
+        else:
+            if doubt2:
+                doubts.append((s2, k2))
+            if not ctx.pyramids_valid(s2):
+                frames.keep_handles(ctx, s2)
+                ctx.build_pyramids(s2, sync=False)
     else:
         # A slot that already holds exactly the pixels of one of the two images (every byte compared -- _frames.py) keeps it: the
         # reference converts and rebuilds both on every call, example1's ping-pong (example1.py:53-56) the same two 200 times.
         k1, k2 = FrameKey(img1), FrameKey(img2)
-        at1, at2 = frames.find(k1, (s1, s2), ctx), frames.find(k2, (s1, s2), ctx)
+        (at1, doubt1), (at2, doubt2) = locate(k1, (s1, s2)), locate(k2, (s1, s2))
         if at1 == s2 or at2 == s1:                    # the pair arrives the other way round (or shifted by one frame)
             ctx.swap_slots(s1, s2)
             frames.swap(s1, s2)
             at1 = {s1: s2, s2: s1}.get(at1)
             at2 = {s1: s2, s2: s1}.get(at2)
         build = []
-        for slot, key, at in ((s1, k1, at1), (s2, k2, at2)):
+        for slot, key, at, doubt in ((s2, k2, at2, doubt2), (s1, k1, at1, doubt1)):      # frame 2 first: in a video it is the new one
             if at != slot:
                 frames.send(ctx, slot, key)
                 build.append(slot)
-            elif not ctx.pyramids_valid(slot):        # the frame is there, the pyramid geometry / taps changed since
-                frames.keep_handles(ctx, slot)
-                build.append(slot)
+            else:
+                if doubt:
+                    doubts.append((slot, key))
+                if not ctx.pyramids_valid(slot):      # the frame is there, the pyramid geometry / taps changed since
+                    frames.keep_handles(ctx, slot)
+                    build.append(slot)
         if build:
             ctx.build_pyramids_batch(build)           # frames share every kernel launch
-    return ctx, s1, s2, ncols, nrows
+    return s1, s2, ncols, nrows, doubts
+
+
+def _resend(tc, ctx, slot, key):
+    """a frame taken as resident on the strength of its lattice differs from what the slot holds: send it and rebuild"""
+    cache_of(tc).send(ctx, slot, key)
+    ctx.build_pyramids(slot, sync=False)
 
 
 def ComputeImagePyramids(tc, img1, img2):
@@ -198,7 +238,14 @@ def ComputeImagePyramids(tc, img1, img2):
     sequential mode with pyramids kept from the last KLTTrackFeatures call the first three are tc.pyramid_last* and img1 is not looked
     at (:152-161).  The pyramids are built and stay on the device (one launch sequence for both images); the objects returned have the
     reference's KLTPyramid attributes, and `pyramid.img[level]` is the float32 plane, downloaded when first looked at."""
-    ctx, s1, s2, ncols, nrows = _prepare_pair(tc, img1, img2)
+    ctx = context_of(tc)
+    with ctx.lock:
+        ctx.settle_deferred()
+        return _compute_image_pyramids(tc, ctx, img1, img2)
+
+
+def _compute_image_pyramids(tc, ctx, img1, img2):
+    s1, s2, ncols, nrows, _ = _prepare_pair(tc, ctx, img1, img2)
     # (no settle_frames here: nothing has been waited for, the staged frames may still be on their way -- the next call that wants
     # their pinned buffers waits for the copies)
     if tc.sequentialMode and tc.pyramid_last is not None and getattr(tc.pyramid_last, "_gen", None) == ctx.slot_generation(s1):
@@ -224,35 +271,54 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
         ncols, nrows = _image_size(img1)
         print("(KLT) Tracking {0} features in a {1} by {2} image...  ".format(
             KLTCountRemainingFeatures(featurelist), ncols, nrows))
-    ctx, s1, s2, ncols, nrows = _prepare_pair(tc, img1, img2)
+    ctx = context_of(tc)
+    with ctx.lock:                                    # one KLT* call at a time per device context (backend.default_context)
+        ctx.settle_deferred()
+        _track_locked(ctx, tc, img1, img2, featurelist)
+    if KLT_verbose >= 1:
+        print("\n\t{0} features successfully tracked.".format(KLTCountRemainingFeatures(featurelist)))
+
+
+def _track_locked(ctx, tc, img1, img2, featurelist):
+    affine = tc.affineConsistencyCheck >= 0
+    # The affine check updates its per-feature state in place, so its launch cannot be repeated: nothing is taken on trust there.
+    s1, s2, ncols, nrows, doubts = _prepare_pair(tc, ctx, img1, img2, speculate=not affine)
 
     nfeat = len(featurelist)
-    fl_in = features_to_array(featurelist, ctx.host_records(nfeat)[0])      # pinned: goes up without a staging copy
-    affine = tc.affineConsistencyCheck >= 0
+    store = shared_store(featurelist)
+    fl_in = features_to_array(featurelist, ctx.host_records(nfeat)[0], store)      # pinned: goes up without a staging copy
+    state = None
     if affine:
         # The reference calls _am_trackFeatureAffine here but never defines it (trackFeatures.py:347-399); behaviour
         # follows upstream KLT 1.3.4.  The per-feature templates / A matrices live on the device, keyed
         # by the feature list object.
         state = _affine_state_of(tc, ctx, featurelist)
-        fl_out = ctx.track_records(s1, s2, nfeat, state)
+    ctx.track_enqueue(s1, s2, nfeat, state)
+    # The device is tracking; now every byte of the frames that were taken as resident is compared with what their slots were
+    # filled from.  One that differs (the same array edited in place off the lattice, ...) is sent and built now and the tracker
+    # runs again on the same input records: the records that come back are those of the last launch.
+    again = False
+    for slot, key in doubts:
+        if not cache_of(tc).verify(key, slot):
+            _resend(tc, ctx, slot, key)
+            again = True
+    if again:
+        ctx.track_enqueue(s1, s2, nfeat, state, upload=False)
+    fl_out = ctx.track_complete(nfeat)
+    if affine:
         rec = ctx.affine_download(state, nfeat)
-    else:
-        fl_out = ctx.track_records(s1, s2, nfeat)
-    store = shared_store(featurelist)
     if store is not None:
-        # whole columns at once (the reference walks the list: trackFeatures.py:288-399)
-        live = fl_in["val"] >= 0                          # only live features are tracked (:253)
-        ok = live & (fl_out["val"] == kltState.KLT_TRACKED)
-        lost = live & ~ok
-        store.x[ok] = fl_out["x"][ok]
-        store.y[ok] = fl_out["y"][ok]
-        store.val[ok] = kltState.KLT_TRACKED
-        store.x[lost] = -1.0
-        store.y[lost] = -1.0
-        store.val[lost] = fl_out["val"][lost]
-        store.xint[live] = False
-        store.yint[live] = False
+        # whole columns at once (the reference walks the list: trackFeatures.py:288-399).  The records are final for every row:
+        # the tracked position, (-1, -1, status) for a feature that was lost, the input record for one that was not live (:253).
+        dead = fl_in["val"] < 0
+        live = ~dead
+        np.copyto(store.x, fl_out["x"], where=live)
+        np.copyto(store.y, fl_out["y"], where=live)
+        np.copyto(store.val, fl_out["val"], where=live)
+        np.logical_and(store.xint, dead, out=store.xint)      # tracked or lost: Python floats from here on
+        np.logical_and(store.yint, dead, out=store.yint)
         if affine:
+            ok = live & (fl_out["val"] == kltState.KLT_TRACKED)
             cols = store.aff_columns()
             for name, key in (("aff_x", "aff_x"), ("aff_y", "aff_y"), ("aff_Axx", "Axx"), ("aff_Ayx", "Ayx"), ("aff_Axy", "Axy"),
                               ("aff_Ayy", "Ayy")):
@@ -262,6 +328,7 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
                 col[live] = None
                 col[has_tpl] = _DEVICE_TEMPLATE
         elif store.aff is not None:
+            lost = live & (fl_out["val"] != kltState.KLT_TRACKED)
             for col in store.aff_img.values():
                 col[lost] = None
     else:
@@ -291,6 +358,3 @@ def KLTTrackFeatures(tc, img1, img2, featurelist):
         ctx.swap_slots(s1, s2)                        # frame-2 pyramids become frame 1 (:401-404)
         cache_of(tc).swap(s1, s2)
         tc.pyramid_last, tc.pyramid_last_gradx, tc.pyramid_last_grady = _pyramid_handles(tc, ctx, s1, ncols, nrows)
-
-    if KLT_verbose >= 1:
-        print("\n\t{0} features successfully tracked.".format(KLTCountRemainingFeatures(featurelist)))

@@ -27,11 +27,12 @@ def extractImagePatchSlow(img, x, y, height, width):
     height, width = int(height), int(width)
     patch = np.empty((height, width), np.float32)
     ctx = default_context()
-    rc = ctx._lib.klt_extract_patch_f32(ctx._h, img.ctypes.data, img.shape[1], img.shape[0], float(np.float32(x)), float(np.float32(y)),
-                                        width, height, patch.ctypes.data)
-    if rc == -1 and b"leaves the image" in (ctx._lib.klt_last_error(ctx._h) or b""):
-        raise AssertionError("ix - hw >= 0 and iy - hh >= 0 and ix + hw + 2 <= ncols and iy + hh + 2 <= nrows")
-    ctx._check(rc)
+    with ctx.lock:
+        rc = ctx._lib.klt_extract_patch_f32(ctx._h, img.ctypes.data, img.shape[1], img.shape[0], float(np.float32(x)),
+                                            float(np.float32(y)), width, height, patch.ctypes.data)
+        if rc == -1 and b"leaves the image" in (ctx._lib.klt_last_error(ctx._h) or b""):
+            raise AssertionError("ix - hw >= 0 and iy - hh >= 0 and ix + hw + 2 <= ncols and iy + hh + 2 <= nrows")
+        ctx._check(rc)
     return patch
 
 
@@ -46,11 +47,12 @@ def trackFeatureIterateCKLT(x2, y2, img1GradxPatch, img1GradyPatch, img1Patch, i
         raise ValueError("patches must be window_height x window_width, and the three images of frame 2 equal in shape")
     ctx = default_context()
     xo, yo, st, it = C.c_float(), C.c_float(), C.c_int(), C.c_int()
-    ctx._check(ctx._lib.klt_track_iterate_f32(ctx._h, float(np.float32(x2)), float(np.float32(y2)), gxp.ctypes.data, gyp.ctypes.data,
-                                             ip.ctypes.data, width, height, i2.ctypes.data, gx2.ctypes.data, gy2.ctypes.data,
-                                             i2.shape[1], i2.shape[0], float(tc.step_factor), float(tc.min_determinant),
-                                             float(tc.min_displacement), int(tc.max_iterations),
-                                             C.byref(xo), C.byref(yo), C.byref(st), C.byref(it)))
+    with ctx.lock:
+        ctx._check(ctx._lib.klt_track_iterate_f32(ctx._h, float(np.float32(x2)), float(np.float32(y2)), gxp.ctypes.data, gyp.ctypes.data,
+                                                 ip.ctypes.data, width, height, i2.ctypes.data, gx2.ctypes.data, gy2.ctypes.data,
+                                                 i2.shape[1], i2.shape[0], float(tc.step_factor), float(tc.min_determinant),
+                                                 float(tc.min_displacement), int(tc.max_iterations),
+                                                 C.byref(xo), C.byref(yo), C.byref(st), C.byref(it)))
     return xo.value, yo.value, st.value, it.value
 
 

@@ -10,7 +10,7 @@ from __future__ import print_function
 
 import numpy as np
 
-from .backend import REPLACING_SOME, SELECTING_ALL, default_context
+from .backend import REPLACING_SOME, SELECTING_ALL, context_of
 from .klt import KLT_FeatureTable
 from .selectGoodFeatures import _fix_window, _slots_of, image_to_array
 
@@ -90,9 +90,15 @@ def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True
     KLTReplaceLostFeatures).  tc.affineConsistencyCheck >= 0 runs the affine check on every step.
     `prefetch`: the pyramids of frame k+1 are built on a second HIP stream (KLT_OPT_BUILD_STREAM) while frame k is tracked and its
     lost features are replaced -- same results, the frames then live in a ring of three slots."""
+    ctx = context_of(tc)
+    with ctx.lock:                       # one KLT* call at a time per device context (backend.default_context)
+        ctx.settle_deferred()
+        return _track_sequence_locked(ctx, tc, frames, nFeatures, replace_lost, async_ingest, prefetch)
+
+
+def _track_sequence_locked(ctx, tc, frames, nFeatures, replace_lost, async_ingest, prefetch):
     frames = iter(frames)
     _fix_window(tc)
-    ctx = default_context()
     from ._frames import cache_of
     cache_of(tc).keep_all_handles()     # pyramid handles somebody kept (ComputeImagePyramids, tc.pyramid_last) fetch their planes first
     ctx.configure(tc)

@@ -1,0 +1,248 @@
+"""Round-5 GPU checks: the reference-shaped Python API under threads (one device context per host thread, a lock per context), the
+calls' optimistic frame reuse (device work enqueued before every byte of a frame has been compared, repeated when the comparison
+fails) and the feature objects (KLT_Feature as a (store, row) pair)."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import make_tc
+from pyfeaturetrack_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _api_modules():
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import trackFeatures as trk
+    sgf.KLT_verbose = trk.KLT_verbose = 0
+    return sgf, trk
+
+
+def _records(fl):
+    return [(f.x, f.y, f.val) for f in fl]
+
+
+# four tracking contexts that differ in everything the device context caches: window, levels, subsampling, frame size; two of them
+# use the SAME feature count (the pinned record buffers are cached per length)
+_CASES = [
+    dict(size=(320, 240), n=120, tc=dict(levels=2, ss=4, window=7, max_residue=10.0)),
+    dict(size=(648, 486), n=300, tc=dict(levels=3, ss=2, window=9)),
+    dict(size=(500, 380), n=300, tc=dict(levels=2, ss=2, window=5, max_residue=12.0)),
+    dict(size=(960, 540), n=700, tc=dict(levels=3, ss=4, window=11)),
+]
+_ROUNDS = 50
+
+
+def _frames_of(k, rounds):
+    w, h = _CASES[k]["size"]
+    base = synth.synth_base(w, h, 40 + k)
+    return [synth.synth_frame(w, h, 40 + k, r, shift=(1.7, -1.1), base=base) for r in range(rounds + 1)]
+
+
+def _api_rounds(k, frames, rounds, tc=None, out=None):
+    """select on frame r, track r -> r+1, replace the lost ones on r+1: the three public calls, `rounds` times"""
+    sgf, trk = _api_modules()
+    tc = tc or make_tc(**_CASES[k]["tc"])
+    out = [] if out is None else out
+    for r in range(rounds):
+        fl = sgf.KLTSelectGoodFeatures(tc, frames[r], _CASES[k]["n"])
+        sel = _records(fl)
+        trk.KLTTrackFeatures(tc, frames[r], frames[r + 1], fl)
+        tracked = _records(fl)
+        sgf.KLTReplaceLostFeatures(tc, frames[r + 1], fl)
+        out.append((sel, tracked, _records(fl)))
+    return out
+
+
+def test_public_api_from_four_threads_at_once():
+    """KLTSelectGoodFeatures -> KLTTrackFeatures -> KLTReplaceLostFeatures from four threads, each with its own
+    KLT_TrackingContext (different window / levels / frame size; two with the same feature count), 50 rounds concurrently, give the
+    lists the same calls give on one thread.  The reference's state is per tracking context (klt.py:43-81); here every thread gets
+    its own device context (backend.default_context) and every call holds that context's lock."""
+    frames = [_frames_of(k, _ROUNDS) for k in range(len(_CASES))]
+    want = [_api_rounds(k, frames[k], 6) for k in range(len(_CASES))]           # single thread (the main thread's context)
+    got, errors = [[] for _ in _CASES], []
+    gate = threading.Barrier(len(_CASES))
+
+    def work(k):
+        try:
+            gate.wait(60)
+            _api_rounds(k, frames[k], _ROUNDS, out=got[k])
+        except BaseException as e:              # noqa: BLE001 -- re-raised by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(_CASES))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+        assert not t.is_alive()
+    if errors:
+        raise errors[0]
+    for k in range(len(_CASES)):
+        assert len(got[k]) == _ROUNDS
+        assert got[k][:6] == want[k], "thread %d differs from the single-thread run" % k
+        assert any(v >= 0 for _, _, v in got[k][-1][2])
+
+
+def test_threads_have_their_own_device_context_and_a_tc_stays_with_its_first():
+    from pyfeaturetrack_amd.backend import context_of, default_context
+    sgf, trk = _api_modules()
+    main_ctx = default_context()
+    assert default_context() is main_ctx
+    seen = {}
+
+    def other():
+        seen["ctx"] = default_context()
+        seen["again"] = default_context()
+        tc = make_tc(**_CASES[0]["tc"])
+        f = _frames_of(0, 1)
+        sgf.KLTSelectGoodFeatures(tc, f[0], 50)
+        seen["tc"], seen["tc_ctx"] = tc, context_of(tc)
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join(120)
+    assert seen["ctx"] is seen["again"] and seen["ctx"] is not main_ctx
+    assert seen["tc_ctx"] is seen["ctx"]
+    assert context_of(seen["tc"]) is seen["ctx"], "a tracking context stays with the device context it was first used on"
+    # ... and goes on working from this thread (its frames and pyramids live in that context's slots)
+    f = _frames_of(0, 1)
+    fl = sgf.KLTSelectGoodFeatures(seen["tc"], f[0], 50)
+    trk.KLTTrackFeatures(seen["tc"], f[0], f[1], fl)
+    ref_tc = make_tc(**_CASES[0]["tc"])
+    fl2 = sgf.KLTSelectGoodFeatures(ref_tc, f[0], 50)
+    trk.KLTTrackFeatures(ref_tc, f[0], f[1], fl2)
+    assert _records(fl) == _records(fl2)
+
+
+def test_two_threads_sharing_one_tracking_context():
+    """Two threads calling the public API on ONE KLT_TrackingContext are served one call at a time (the lock of the device context the
+    tracking context is bound to): every call's result is the single-thread result for its inputs."""
+    sgf, trk = _api_modules()
+    k = 1
+    frames = _frames_of(k, 8)
+    tc = make_tc(**_CASES[k]["tc"])
+    n = _CASES[k]["n"]
+    want = {}
+    for r in range(8):
+        fl = sgf.KLTSelectGoodFeatures(tc, frames[r], n)
+        sel = _records(fl)
+        trk.KLTTrackFeatures(tc, frames[r], frames[r + 1], fl)
+        want[r] = (sel, _records(fl))
+    got, errors = {}, []
+
+    def work(rs):
+        try:
+            for _ in range(5):
+                for r in rs:
+                    fl = sgf.KLTSelectGoodFeatures(tc, frames[r], n)
+                    sel = _records(fl)
+                    trk.KLTTrackFeatures(tc, frames[r], frames[r + 1], fl)
+                    got.setdefault(r, []).append((sel, _records(fl)))
+        except BaseException as e:              # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(rs,)) for rs in ((0, 2, 4, 6), (1, 3, 5, 7))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+        assert not t.is_alive()
+    if errors:
+        raise errors[0]
+    for r in range(8):
+        assert len(got[r]) == 5 and all(g == want[r] for g in got[r]), "round %d" % r
+
+
+def test_finalizers_never_wait_for_a_context_somebody_else_is_inside():
+    """A tracking context that dies while another thread holds its device context's lock leaves its release for the next holder
+    (Context._when_free / settle_deferred) instead of blocking the thread the collector happens to run on."""
+    import gc
+    from pyfeaturetrack_amd.backend import context_of
+    sgf, _ = _api_modules()
+    f = _frames_of(0, 1)
+    tc = make_tc(**_CASES[0]["tc"])
+    sgf.KLTSelectGoodFeatures(tc, f[0], 30)
+    ctx = context_of(tc)
+    base = tc._klt_slots[0]
+    held, release = threading.Event(), threading.Event()
+
+    def holder():
+        with ctx.lock:
+            held.set()
+            release.wait(60)
+
+    t = threading.Thread(target=holder)
+    t.start()
+    assert held.wait(60)
+    del tc
+    gc.collect()                                    # the finalizer runs here and must not block
+    assert len(ctx._deferred) == 1
+    release.set()
+    t.join(60)
+    tc2 = make_tc(**_CASES[0]["tc"])
+    sgf.KLTSelectGoodFeatures(tc2, f[0], 30)        # the next call settles the deferred release and reuses the slots
+    assert not ctx._deferred and tc2._klt_slots[0] == base
+
+
+# ------------------------------------------------------------------------------------- optimistic frame reuse
+def test_optimistic_reuse_repeats_the_tracker_when_a_frame_was_edited_in_place():
+    """KLTTrackFeatures enqueues the tracker on the strength of size + lattice and compares every byte while the device runs; a frame
+    that was edited in place OFF the lattice (frame 1, frame 2, or both) is sent, rebuilt and tracked again inside the same call: the
+    lists are those of a tracking context that has never seen the frames."""
+    sgf, trk = _api_modules()
+    w, h, n = 648, 486, 400
+    base = synth.synth_base(w, h, 5)
+    f0 = synth.synth_frame(w, h, 5, 0, shift=(2.2, -1.4), base=base)
+    f1 = synth.synth_frame(w, h, 5, 1, shift=(2.2, -1.4), base=base)
+    tc = make_tc(levels=2, ss=4, max_residue=10.0)
+    fl = sgf.KLTSelectGoodFeatures(tc, f0, n)
+    trk.KLTTrackFeatures(tc, f0, f1, fl)
+
+    def fresh(a, b):
+        t = make_tc(levels=2, ss=4, max_residue=10.0)
+        l = sgf.KLTSelectGoodFeatures(t, a, n)
+        trk.KLTTrackFeatures(t, a, b, l)
+        return _records(l)
+
+    rng = np.random.default_rng(3)
+    for edit in ("second", "first", "both", "none", "second"):
+        for img in {"second": (f1,), "first": (f0,), "both": (f0, f1), "none": ()}[edit]:
+            # a block of pixels off the 32 x 32 lattice (rows / columns that are no multiples of the lattice strides), strong enough to move features
+            y, x = int(rng.integers(40, h - 60)) | 1, int(rng.integers(40, w - 60)) | 1
+            img[y:y + 9:2, x:x + 9:2] ^= 0x5A
+        fl = sgf.KLTSelectGoodFeatures(tc, f0, n)
+        trk.KLTTrackFeatures(tc, f0, f1, fl)
+        assert _records(fl) == fresh(f0.copy(), f1.copy()), "after editing %s" % edit
+
+
+def test_feature_objects_are_store_row_pairs_with_the_reference_attributes():
+    """KLT_Feature: x / y / val and the affine fields read and written through the column store, Python types as the reference holds
+    them (ints after selection, floats after tracking), further attributes accepted, pickles and copies; lists handed out by the API
+    are complete plain-list-compatible lists."""
+    import copy
+    import pickle
+    from pyfeaturetrack_amd.klt import KLT_Feature, shared_store
+    sgf, trk = _api_modules()
+    f = _frames_of(0, 1)
+    tc = make_tc(**_CASES[0]["tc"])
+    fl = sgf.KLTSelectGoodFeatures(tc, f[0], 60)
+    assert type(fl[0]) is KLT_Feature and list.__len__(fl) == 60 and shared_store(fl) is fl._store
+    assert all(type(a.x) is int and type(a.y) is int and type(a.val) is int for a in fl if a.val >= 0)
+    plain = list(fl)
+    trk.KLTTrackFeatures(tc, f[0], f[1], plain)                   # a plain-list copy is recognised as the same rows
+    assert all(type(a.x) is float and type(a.y) is float for a in fl)
+    a = fl[7]
+    a.note = "mine"
+    a.x, a.y, a.val = 5, 2.5, 3
+    assert (a.x, a.y, a.val, a.note) == (5, 2.5, 3, "mine") and type(a.x) is int and fl._store.x[7] == 5.0
+    b = pickle.loads(pickle.dumps(a))
+    assert (b.x, b.y, b.val) == (5, 2.5, 3) and copy.deepcopy(a).y == 2.5
+    lone = KLT_Feature()
+    assert (lone.x, lone.y, lone.val) == (-1, -1, -1) and lone != KLT_Feature() and lone == lone
+    fl.append(lone)
+    assert shared_store(fl) is None                                # an edited list falls back to per-feature access
+    trk.KLTTrackFeatures(tc, f[0], f[1], fl)
+    assert lone.val == -1
