@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 8
+#define KLT_ABI_VERSION 9
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -126,6 +126,14 @@ int klt_host_alloc(klt_ctx *ctx, size_t bytes, void **out);     /* pinned host m
 int klt_host_free(klt_ctx *ctx, void *p);
 int klt_upload_u8_async(klt_ctx *ctx, int slot, const uint8_t *px, int ncols, int nrows, int pitch);
 int klt_upload_wait(klt_ctx *ctx);      /* host waits for the copies issued so far (only the copy stream; kernels keep running) */
+/* Host side of the ingest, no context involved (thread-safe; a process-wide pool of parked worker threads, KLT_HOST_THREADS lanes in
+ * all, default 4; a caller that finds the pool busy does its own work): the reference converts and rebuilds both images on every call
+ * (trackFeatures.py:146-196); a caller that keeps a frame's pyramids while the image still has EXACTLY the pixels the slot was filled
+ * from pays one pass over the frame per call instead -- klt_host_compare: 0 = every byte equal, 1 = different --, and stages a new
+ * frame into the pinned buffer klt_upload_u8_async reads with klt_host_copy. */
+int klt_host_compare(const void *a, const void *b, size_t bytes);
+int klt_host_copy(void *dst, const void *src, size_t bytes);
+int klt_host_lanes(void);               /* lanes a large compare / copy is spread over (workers + the caller) */
 /* Frames that are ALREADY in device memory (a hardware decoder's output, a clip kept resident): the slot's frame becomes this caller-owned
  * buffer -- read in place by the next build / selection of the slot, never copied, written or freed by the library (zero-copy
  * ingest).  pitch must equal ncols.  Host-only call: nothing is enqueued; the buffer must hold the frame already and stay unchanged until
@@ -170,6 +178,12 @@ int   klt_featbuf_download(klt_ctx *ctx, int fb, klt_feat *dst, int n);
  * table back every N steps issues this at the window's end and waits for it at the NEXT window's end: the host never waits for queued work. */
 int   klt_featbuf_download_async(klt_ctx *ctx, int fb, klt_feat *dst, int n);
 int   klt_download_wait(klt_ctx *ctx);                        /* host waits for the latest klt_featbuf_download_async */
+/* Feature buffer `fb` becomes `n` records of PINNED host memory (klt_host_alloc), read and written in place by the kernels over the
+ * link: a call that sends a list, tracks it and waits (KLTTrackFeatures, trackFeatures.py:205-409) then needs no copy command in either
+ * direction -- the records are in `host` once klt_sync (or any synchronising call) has returned.  Meant for the lists of such one-shot
+ * calls; tables that kernels revisit belong in device memory.  host == NULL ends the mapping (the buffer is empty afterwards).  The
+ * memory must outlive the mapping. */
+int   klt_featbuf_map_host(klt_ctx *ctx, int fb, klt_feat *host, int n);
 int   klt_featbuf_alloc(klt_ctx *ctx, int fb, int n);         /* n records, all marked lost (val = -1) */
 /* fb_view becomes a window [offset, offset+n) of fb_parent (a device-side [frames x features] table, cf. the
  * KLT_FeatureTable stub at klt.py:278-283, can then be gathered with one collective).  The parent must outlive the

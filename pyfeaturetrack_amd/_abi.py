@@ -69,6 +69,9 @@ SYMBOLS = {
     "klt_host_free": (_I, [_P, _P]),
     "klt_upload_u8_async": (_I, [_P, _I, _P, _I, _I, _I]),
     "klt_upload_wait": (_I, [_P]),
+    "klt_host_compare": (_I, [_P, _P, C.c_size_t]),
+    "klt_host_copy": (_I, [_P, _P, C.c_size_t]),
+    "klt_host_lanes": (_I, []),
     "klt_slot_adopt_u8": (_I, [_P, _I, _P, _I, _I, _I]),
     "klt_device_alloc": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
     "klt_device_write": (_I, [_P, _P, _P, C.c_size_t]),
@@ -87,6 +90,7 @@ SYMBOLS = {
     "klt_featbuf_download": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_download_async": (_I, [_P, _I, _P, _I]),
     "klt_download_wait": (_I, [_P]),
+    "klt_featbuf_map_host": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_alloc": (_I, [_P, _I, _I]),
     "klt_featbuf_view": (_I, [_P, _I, _I, _I, _I]),
     "klt_featbuf_devptr": (_P, [_P, _I]),

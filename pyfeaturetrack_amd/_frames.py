@@ -12,7 +12,6 @@ Opt-in shortcut, a documented deviation: `tc.trustFrameIde
 environment) trusts object identity + size + the lattice and skips the full comparison -- for callers that never edit an image in
 place, or call KLTForgetFrames(tc) when they do.  KLT_NO_FRAME_CACHE=1 disables the cache altogether.
 """
-import ctypes
 import os
 import weakref
 
@@ -22,12 +21,16 @@ _LATTICE = 32
 _DISABLED = os.environ.get("KLT_NO_FRAME_CACHE") == "1"
 _TRUST_ENV = os.environ.get("KLT_TRUST_FRAME_IDENTITY") == "1"
 
-try:
-    _memcmp = ctypes.CDLL(None).memcmp
-    _memcmp.argtypes = (ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
-    _memcmp.restype = ctypes.c_int
-except (OSError, AttributeError):                           # pragma: no cover -- no libc memcmp: numpy compares
-    _memcmp = None
+_host = None
+
+
+def _host_lib():
+    """libkltgpu's host-side helpers (klt_host_compare / klt_host_copy: a frame spread over a few parked worker threads)"""
+    global _host
+    if _host is None:
+        from ._abi import load_library
+        _host = load_library()
+    return _host
 
 
 def _lattice(arr):
@@ -36,12 +39,20 @@ def _lattice(arr):
 
 
 def same_pixels(a, b):
-    """every byte of two arrays of equal shape and dtype (one libc memcmp when both are contiguous)"""
+    """every byte of two arrays of equal shape and dtype (klt_host_compare when both are contiguous)"""
     if a.shape != b.shape or a.dtype != b.dtype:
         return False
-    if _memcmp is not None and a.flags["C_CONTIGUOUS"] and b.flags["C_CONTIGUOUS"]:
-        return _memcmp(a.ctypes.data, b.ctypes.data, a.nbytes) == 0
+    if a.flags["C_CONTIGUOUS"] and b.flags["C_CONTIGUOUS"]:
+        return _host_lib().klt_host_compare(a.ctypes.data, b.ctypes.data, a.nbytes) == 0
     return bool(np.array_equal(a, b))
+
+
+def copy_pixels(dst, src):
+    """src -> dst (equal shape and dtype; klt_host_copy when both are contiguous)"""
+    if src.flags["C_CONTIGUOUS"] and dst.flags["C_CONTIGUOUS"] and src.dtype == dst.dtype and src.shape == dst.shape:
+        _host_lib().klt_host_copy(dst.ctypes.data, src.ctypes.data, src.nbytes)
+    else:
+        np.copyto(dst, src)
 
 
 def _to_array(img):
@@ -196,7 +207,7 @@ class FrameCache:
             if old is not None:
                 old.release()
             _uploads_finished(ctx, no)                      # the DMA that last read this buffer has finished
-            np.copyto(buf, arr)
+            copy_pixels(buf, arr)
             ctx.upload_async(slot, buf)
             ctx.__dict__["_uploads_issued"] = no = ctx.__dict__.get("_uploads_issued", 0) + 1
             kept = buf

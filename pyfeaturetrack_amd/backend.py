@@ -6,6 +6,7 @@ CPU fallback: creating a Context without a usable MI355X raises KltBackendError.
 """
 import collections
 import ctypes as C
+import os as _os
 import threading
 
 import numpy as np
@@ -22,6 +23,9 @@ assert AFFINE_DTYPE.itemsize == C.sizeof(KltAffineRec)
 
 SELECTING_ALL = 1
 REPLACING_SOME = 2
+# the reference-shaped API's tracker reads and writes its pinned record arrays in place (klt_featbuf_map_host); KLT_MAP_RECORDS=0 in
+# the environment goes back to one copy command each way
+MAP_RECORDS = _os.environ.get("KLT_MAP_RECORDS", "1") != "0"
 
 
 def _dp(a):
@@ -354,7 +358,13 @@ class Context:
         pair = cache.pop(n, None)
         if pair is None:
             if len(cache) >= 8:                                   # a script with lists of many lengths: the least recently used pair goes
-                old = cache.pop(next(iter(cache)))
+                gone = next(iter(cache))
+                old = cache.pop(gone)
+                mapped = self.__dict__.get("_mapped_records")
+                if mapped is not None and mapped[0] == gone:           # the tracker's feature buffers are these arrays: unmap first
+                    for fb in mapped[3:]:
+                        self._check(self._lib.klt_featbuf_map_host(self._h, fb, None, 0))
+                    self._mapped_records = None
                 for a in old:
                     self._check(self._lib.klt_host_free(self._h, C.c_void_p(a.ctypes.data)))
             pair = (self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n], self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n])
@@ -388,10 +398,22 @@ class Context:
         self.track_enqueue(slot1, slot2, n, state, True, fb_in, fb_out)
         return self.track_complete(n, fb_out)
 
+    def _map_records(self, n, fb_in, fb_out):
+        """feature buffers fb_in / fb_out ARE host_records(n) (klt_featbuf_map_host): the tracker reads and writes them in place"""
+        rin, rout = self.host_records(n)
+        key = (n, rin.ctypes.data, rout.ctypes.data, fb_in, fb_out)
+        if self.__dict__.get("_mapped_records") != key:
+            self._check(self._lib.klt_featbuf_map_host(self._h, fb_in, rin.ctypes.data, max(n, 1)))
+            self._check(self._lib.klt_featbuf_map_host(self._h, fb_out, rout.ctypes.data, max(n, 1)))
+            self._mapped_records = key
+
     def track_enqueue(self, slot1, slot2, n, state=None, upload=True, fb_in=65534, fb_out=65535):
-        """The list in host_records(n)[0] goes up (`upload`; not again when the tracker is only repeated on other pyramids) and the
-        tracker is enqueued; nothing is waited for."""
-        if upload:
+        """The tracker is enqueued on the list in host_records(n)[0]; nothing is waited for.  With MAP_RECORDS (the default) the two
+        feature buffers are those pinned arrays themselves and no copy is enqueued; otherwise the list goes up first (`upload`; not
+        again when the tracker is only repeated on other pyramids)."""
+        if MAP_RECORDS:
+            self._map_records(n, fb_in, fb_out)
+        elif upload:
             self._check(self._lib.klt_featbuf_upload_async(self._h, fb_in, self.host_records(n)[0].ctypes.data, n))
         if state is None:
             self._check(self._lib.klt_track_async(self._h, slot1, slot2, fb_in, fb_out, n))
@@ -399,9 +421,13 @@ class Context:
             self._check(self._lib.klt_track_affine_async(self._h, slot1, slot2, fb_in, fb_out, n, state))
 
     def track_complete(self, n, fb_out=65535):
-        """The records of the LAST tracker enqueued into fb_out, in host_records(n)[1] (one synchronous download)."""
+        """The records of the LAST tracker enqueued into fb_out, in host_records(n)[1] (a wait for the stream when the buffers are
+        mapped, one synchronous download otherwise)."""
         rout = self.host_records(n)[1]
-        self._check(self._lib.klt_featbuf_download(self._h, fb_out, rout.ctypes.data, n))
+        if MAP_RECORDS:
+            self._check(self._lib.klt_sync(self._h))
+        else:
+            self._check(self._lib.klt_featbuf_download(self._h, fb_out, rout.ctypes.data, n))
         return rout
 
     def select_async(self, slot, mode, use_pyramid, fb, n):

@@ -1,0 +1,190 @@
+// host_pool.hip -- host side of the frame ingest: comparing a frame with the copy its slot was filled from, and staging a frame into
+// pinned memory, by a few parked worker threads.  Pure host code (no kernel in this file).
+//
+// Why: the reference converts and rebuilds both images on every KLTTrackFeatures call (trackFeatures.py:146-196).  The Python layer
+// keeps a frame's pyramids while a call names an image with EXACTLY the pixels the slot holds, which costs one pass over the frame
+// per call and image (2 MB at 1080p): 0.034 ms for one core on the GPU box, next to 0.03-0.05 ms of device work for the tracker --
+// with both frames resident the two comparisons ARE the call.  Four lanes bring a frame to about 0.012 ms; the same lanes stage a
+// new frame into the pinned buffer the DMA reads (klt_upload_u8_async).
+//
+// Design: one process-wide pool; a job is a range cut into 128 KB chunks that lanes claim from one atomic word tagged with the job's
+// number and closed when the job ends (a lane that wakes late can never claim a chunk of another job); the caller is a lane itself and always finishes the job
+// even if no worker shows up; a second caller that finds the pool busy simply does its own work.  Workers spin for ~40 us after a
+// job (the second frame's comparison follows the first one's) and then park on a condition variable.  KLT_HOST_THREADS = total
+// lanes (default 4, 1 = no workers).
+#include "../../include/klt_gpu.h"
+
+#include <pthread.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+
+namespace {
+
+constexpr size_t kChunk = 128 << 10;
+constexpr size_t kParallelFrom = 512 << 10;      // below this one core is done before a second one has started
+
+struct Pool {
+    std::mutex job_mutex;                        // one job at a time
+    std::mutex m;                                // parking
+    std::condition_variable cv;
+    std::atomic<int> parked{0};
+    std::atomic<uint64_t> next{0};               // (job number << 32) | next chunk to claim
+    std::atomic<uint32_t> done{0};               // chunks of the current job completed
+    std::atomic<int> differ{0};
+    // the job (written between jobs only; read by a lane only while it holds a claim of that job)
+    std::atomic<int> kind{0};                    // 0 compare, 1 copy
+    std::atomic<const uint8_t *> a{nullptr}, b{nullptr};
+    std::atomic<uint8_t *> dst{nullptr};
+    std::atomic<size_t> bytes{0};
+    std::atomic<uint32_t> nchunks{0};
+    uint32_t job_no = 0;                         // guarded by job_mutex
+    int workers = 0;                             // guarded by job_mutex
+    int lanes = 4;
+};
+
+Pool *g_pool = nullptr;
+std::once_flag g_once;
+
+inline void cpu_relax() { __builtin_ia32_pause(); }
+
+// claims and runs chunks of job `tag` until none is left (or the tag has moved on); returns the number of chunks this lane completed
+uint32_t run_chunks(Pool *p, uint32_t tag)
+{
+    uint32_t mine = 0;
+    for (;;) {
+        uint64_t v = p->next.load(std::memory_order_acquire);
+        if ((uint32_t)(v >> 32) != tag) return mine;
+        const uint32_t idx = (uint32_t)v, n = p->nchunks.load(std::memory_order_relaxed);
+        if (idx >= n) return mine;
+        const int kind = p->kind.load(std::memory_order_relaxed);
+        const uint8_t *a = p->a.load(std::memory_order_relaxed), *b = p->b.load(std::memory_order_relaxed);
+        uint8_t *dst = p->dst.load(std::memory_order_relaxed);
+        const size_t bytes = p->bytes.load(std::memory_order_relaxed);
+        if (!p->next.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) continue;
+        // the claim succeeded while the tag was still ours: the fields read above are this job's
+        const size_t off = (size_t)idx * kChunk, len = bytes - off < kChunk ? bytes - off : kChunk;
+        if (kind == 0) {
+            if (!p->differ.load(std::memory_order_relaxed) && memcmp(a + off, b + off, len) != 0)
+                p->differ.store(1, std::memory_order_relaxed);
+        } else {
+            memcpy(dst + off, a + off, len);
+        }
+        p->done.fetch_add(1, std::memory_order_release);
+        mine++;
+    }
+}
+
+void worker(Pool *p)
+{
+    uint32_t seen = 0;
+    for (;;) {
+        // spin for a while: the next job usually follows at once
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(40);
+        uint32_t tag = (uint32_t)(p->next.load(std::memory_order_acquire) >> 32);
+        while (tag == seen && std::chrono::steady_clock::now() < until) {
+            for (int i = 0; i < 32; i++) cpu_relax();
+            tag = (uint32_t)(p->next.load(std::memory_order_acquire) >> 32);
+        }
+        if (tag == seen) {
+            std::unique_lock<std::mutex> lk(p->m);
+            p->parked.fetch_add(1, std::memory_order_seq_cst);
+            p->cv.wait(lk, [&] { return (uint32_t)(p->next.load(std::memory_order_acquire) >> 32) != seen; });
+            p->parked.fetch_sub(1, std::memory_order_seq_cst);
+            tag = (uint32_t)(p->next.load(std::memory_order_acquire) >> 32);
+        }
+        seen = tag;
+        run_chunks(p, tag);
+    }
+}
+
+Pool *fresh_pool()
+{
+    Pool *p = new Pool();                        // never destroyed: detached workers may be parked on it at exit
+    const char *e = getenv("KLT_HOST_THREADS");
+    int lanes = e ? atoi(e) : 4;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && lanes > hw) lanes = hw;
+    p->lanes = lanes < 1 ? 1 : (lanes > 16 ? 16 : lanes);
+    return p;
+}
+
+void in_child_after_fork()
+{
+    // the worker threads do not exist in the child, and the locks may have been held: a fresh pool (the old one is abandoned)
+    if (g_pool) g_pool = fresh_pool();
+}
+
+Pool *pool()
+{
+    std::call_once(g_once, [] {
+        g_pool = fresh_pool();
+        pthread_atfork(nullptr, nullptr, in_child_after_fork);
+    });
+    return g_pool;
+}
+
+// 0 / 1 for a comparison (equal / different), 0 for a copy
+int run_job(int kind, const uint8_t *a, const uint8_t *b, uint8_t *dst, size_t bytes)
+{
+    Pool *p = bytes >= kParallelFrom ? pool() : nullptr;
+    if (!p || p->lanes <= 1 || !p->job_mutex.try_lock()) {
+        if (kind == 0) return memcmp(a, b, bytes) != 0;
+        memcpy(dst, a, bytes);
+        return 0;
+    }
+    std::lock_guard<std::mutex> job(p->job_mutex, std::adopt_lock);
+    while (p->workers < p->lanes - 1) {          // started on first use
+        try { std::thread(worker, p).detach(); } catch (...) { break; }
+        p->workers++;
+    }
+    const uint32_t n = (uint32_t)((bytes + kChunk - 1) / kChunk);
+    p->kind.store(kind, std::memory_order_relaxed);
+    p->a.store(a, std::memory_order_relaxed);
+    p->b.store(b, std::memory_order_relaxed);
+    p->dst.store(dst, std::memory_order_relaxed);
+    p->bytes.store(bytes, std::memory_order_relaxed);
+    p->nchunks.store(n, std::memory_order_relaxed);
+    p->differ.store(0, std::memory_order_relaxed);
+    p->done.store(0, std::memory_order_relaxed);
+    const uint32_t tag = ++p->job_no ? p->job_no : ++p->job_no;      // never 0 (a worker's initial `seen`)
+    p->next.store((uint64_t)tag << 32, std::memory_order_seq_cst);
+    if (p->parked.load(std::memory_order_seq_cst) > 0) {
+        std::lock_guard<std::mutex> lk(p->m);
+        p->cv.notify_all();
+    }
+    run_chunks(p, tag);
+    while (p->done.load(std::memory_order_acquire) < n) cpu_relax();  // chunks other lanes have claimed
+    // closed: no chunk of this job can be claimed any more, whatever the next job writes into the fields above before it publishes
+    // its own tag (a lane that wakes late compares its chunk index with the NEW job's chunk count otherwise)
+    p->next.store(((uint64_t)tag << 32) | 0xffffffffu, std::memory_order_seq_cst);
+    return kind == 0 ? p->differ.load(std::memory_order_relaxed) : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int klt_host_compare(const void *a, const void *b, size_t bytes)
+{
+    if ((!a || !b) && bytes) return KLT_ERR_ARG;
+    if (!bytes || a == b) return 0;
+    return run_job(0, (const uint8_t *)a, (const uint8_t *)b, nullptr, bytes);
+}
+
+int klt_host_copy(void *dst, const void *src, size_t bytes)
+{
+    if ((!dst || !src) && bytes) return KLT_ERR_ARG;
+    if (!bytes || dst == src) return KLT_OK;
+    return run_job(1, (const uint8_t *)src, nullptr, (uint8_t *)dst, bytes);
+}
+
+int klt_host_lanes(void) { return pool()->lanes; }
+
+}  // extern "C"

@@ -1322,6 +1322,35 @@ int klt_featbuf_view(klt_ctx *c, int fb_view, int fb_parent, int offset, int n)
     return KLT_OK;
 }
 
+// A feature buffer that IS pinned host memory: kernels read and write the caller's records over the link (16 bytes per feature -- 80 KB
+// for 5000 features, a few microseconds), so a call that sends a list, tracks it and waits for the result needs no copy command in
+// either direction (each one costs 8-15 us of queue latency on its own, a third of the tracker's run time at cfg-2's list length).
+int klt_featbuf_map_host(klt_ctx *c, int fb, klt_feat *host, int n)
+{
+    if (!c || n < 0 || (host && n == 0)) return fail(c, KLT_ERR_ARG, "bad argument");
+    if (fb < 0 || fb > 65535) return fail(c, KLT_ERR_ARG, "feature buffer index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    void *dev = nullptr;
+    if (host) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, host) != hipSuccess || attr.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            return fail(c, KLT_ERR_ARG, "klt_featbuf_map_host needs pinned host memory (klt_host_alloc)");
+        }
+        HIPCHK(c, hipHostGetDevicePointer(&dev, host, 0));
+    }
+    if ((size_t)fb >= c->fbs.size()) c->fbs.resize(fb + 1);
+    FeatBuf &v = c->fbs[fb];
+    if (v.d) {                                             // queued work may still use what the buffer was so far
+        if (int rc = sync_all(c)) return rc;
+        if (!v.view) hipFree(v.d);
+    }
+    v.d = (klt_feat *)dev;
+    v.cap = host ? n : 0;
+    v.view = host != nullptr;
+    return KLT_OK;
+}
+
 void *klt_featbuf_devptr(klt_ctx *c, int fb)
 {
     if (!c || fb < 0 || (size_t)fb >= c->fbs.size()) return nullptr;

@@ -10,6 +10,8 @@ from __future__ import print_function
 import gc as _gc
 import math
 import os as _os
+import sys as _sys
+import threading as _threading
 import time
 import weakref as _weakref
 from itertools import repeat as _repeat
@@ -135,7 +137,7 @@ class _FeatureStore:
     The store does not point at its feature objects (they point at it): a dropped list is freed by reference counting, not by the
     cycle collector.  `owner` is a weak reference to the KLT_FeatureList that was made with the store."""
 
-    __slots__ = ("x", "y", "val", "xint", "yint", "aff", "aff_img", "owner", "__weakref__")
+    __slots__ = ("x", "y", "val", "xint", "yint", "aff", "aff_img", "owner", "hooks", "__weakref__")
     _AFF_DEFAULTS = (("aff_x", -1.0), ("aff_y", -1.0), ("aff_Axx", 1.0), ("aff_Ayx", 0.0), ("aff_Axy", 0.0), ("aff_Ayy", 1.0))
 
     def __init__(self, n):
@@ -147,6 +149,27 @@ class _FeatureStore:
         self.aff = None               # {name: float64 column}, created when an affine field is first written
         self.aff_img = None           # {name: object column} for aff_img / aff_img_gradx / aff_img_grady
         self.owner = None             # weakref to the KLT_FeatureList whose `_canon` lists the objects of rows 0 .. n-1
+        self.hooks = None             # callbacks for the end of the features' life (device-side affine state: trackFeatures.py)
+
+    def when_features_die(self, callback):
+        """`callback()` runs when the last feature of this store is gone -- or when store and objects are handed to a new list
+        (`_recycled`), which is the same moment as far as the old features are concerned.  Callbacks must be idempotent."""
+        _weakref.finalize(self, callback)
+        if self.hooks is None:
+            self.hooks = []
+        self.hooks.append(callback)
+
+    def _reset(self):
+        """back to n lost features nobody has looked at (the objects of a dropped list serve the next one: `_recycled`)"""
+        hooks, self.hooks = self.hooks, None
+        for h in hooks or ():
+            h()
+        self.x.fill(-1.0)
+        self.y.fill(-1.0)
+        self.val.fill(kltState.KLT_NOT_FOUND)
+        self.xint.fill(True)
+        self.yint.fill(True)
+        self.aff = self.aff_img = self.owner = None
 
     def __len__(self):
         return self.x.shape[0]
@@ -225,9 +248,11 @@ class KLT_Feature(tuple):
     It is implemented as the PAIR (store, row) -- a `tuple` subclass -- because that is the cheapest object CPython can make in
     bulk: a 5000-feature list is `map(tuple.__new__, ...)` over a `zip`, all of it in C, 2.7x faster than 5000 calls of a Python
     `__init__` (0.21 against 0.57 ms at cfg-2's list length, `profiles/README.md`), and the list KLTSelectGoodFeatures hands out is
-    a complete list of feature objects as the reference's is.  Like the reference's objects a feature accepts further attributes,
-    can be weakly referenced, and is equal only to itself in practice (two objects are equal when they view the same row of the
-    same store)."""
+    a complete list of feature objects as the reference's is.  A feature is equal only to itself in practice (two objects are equal
+    when they view the same row of the same store).  Unlike the reference's plain objects it takes no further attributes and no
+    weak references (`__slots__ = ()` on a tuple): that is what lets the objects of a dropped list serve the next one."""
+
+    __slots__ = ()
 
     def __new__(cls, _store=None, _index=0):
         return _tuple_new(cls, (_FeatureStore(1) if _store is None else _store, _index))
@@ -312,6 +337,16 @@ class KLT_FeatureList(list):
     def __len__(self):
         return self._pending or list.__len__(self)
 
+    def __del__(self):
+        # The caller's list is gone.  Its feature objects (kept alive by the private copy) are offered to the next list of the same
+        # length: whether somebody still holds one of them is looked at when they are about to be used again (`_recycled`).
+        try:
+            canon = self._canon
+            if canon is not None and RECYCLE_FEATURE_OBJECTS:
+                _offer(self._store, canon)
+        except Exception:                           # noqa: BLE001 -- interpreter shutdown
+            pass
+
     def __radd__(self, other):
         # `[] + fl`, `sum([fl1, fl2], [])`: list.__add__ reads the right operand's storage directly, so the reflected method (tried
         # first for a subclass on the right) fills the list before anything is concatenated
@@ -343,14 +378,79 @@ KLT_FeatureList.__hash__ = None
 
 LAZY_FEATURE_LISTS = _os.environ.get("KLT_LAZY_FEATURE_LISTS") == "1"
 
+# ---- the feature objects of a dropped list serve the next list of the same length -------------------------------------------
+# A loop such as `fl = KLTSelectGoodFeatures(tc, img, 5000)` per frame drops a complete list of 5000 objects per call and makes
+# 5000 new ones: 0.3 ms to create, 0.1 ms for the cycle collector's look at them, 0.07 ms to free -- three times what the device
+# needs to select the features (profiles/README.md).  The objects of a dropped list are therefore kept (with their store) and,
+# provided NOBODY holds one of them any more -- every reference count is looked at, 0.1 ms --, handed out again as the next
+# list: same objects, store reset to n lost features, callbacks registered with `when_features_die` run.  CPython only
+# (sys.getrefcount); KLT_NO_FEATURE_RECYCLING=1 in the environment (or klt.RECYCLE_FEATURE_OBJECTS = False) turns it off.
+_getrefcount = getattr(_sys, "getrefcount", None)
+RECYCLE_FEATURE_OBJECTS = _getrefcount is not None and _os.environ.get("KLT_NO_FEATURE_RECYCLING") != "1"
+_POOL_LENGTHS, _POOL_DEPTH = 4, 2
+_pool = {}                      # list length -> [(store, canon), ...] (newest last)
+_pool_lock = _threading.Lock()
+
+
+def _offer(store, canon):
+    with _pool_lock:
+        stack = _pool.pop(len(canon), None)
+        if stack is None:
+            stack = []
+            while len(_pool) >= _POOL_LENGTHS:
+                del _pool[next(iter(_pool))]
+        stack.append((store, canon))
+        del stack[:-_POOL_DEPTH]
+        _pool[len(canon)] = stack                   # (re-inserted last: the dict's order is the order of last use)
+
+
+def _counts(entry):
+    """(highest reference count among the feature objects, the store's count beyond one per feature) of a pool entry that only
+    the caller holds -- compared with what the same call gives for an entry made on the spot (`_UNSHARED`)"""
+    store, canon = entry
+    return max(map(_getrefcount, canon)), _getrefcount(store) - len(canon)
+
+
+def _probe_counts():
+    st = _FeatureStore(3)
+    entry = (st, list(map(_tuple_new, _repeat(KLT_Feature, 3), zip(_repeat(st, 3), range(3)))))
+    del st
+    return _counts(entry)
+
+
+_UNSHARED = _probe_counts() if _getrefcount is not None else None
+
+
+def _recycled(n):
+    """A filled KLT_FeatureList of n lost features made of the objects of a dropped list, or None."""
+    if not RECYCLE_FEATURE_OBJECTS or n == 0:
+        return None
+    with _pool_lock:
+        stack = _pool.get(n)
+        entry = stack.pop() if stack else None
+    if entry is None or _counts(entry) != _UNSHARED:
+        return None                                 # (an entry somebody still holds a feature of is dropped: freed when they let go)
+    store, canon = entry
+    del entry
+    store._reset()
+    fl = KLT_FeatureList(store)
+    fl._pending = 0
+    list.extend(fl, canon)
+    fl._canon = canon
+    store.owner = _weakref.ref(fl)
+    return fl
+
 
 def new_feature_list(n, fill=None):
     """n lost features sharing one column store (what KLTSelectGoodFeatures / KLTCreateFeatureList hand out).  `fill=False`: the
     caller fills the list itself (KLTSelectGoodFeatures: after the selection has been enqueued)."""
-    fl = KLT_FeatureList(_FeatureStore(n))
     if (not LAZY_FEATURE_LISTS) if fill is None else fill:
-        fl._fill()
-    return fl
+        fl = _recycled(n)
+        if fl is None:
+            fl = KLT_FeatureList(_FeatureStore(n))
+            fl._fill()
+        return fl
+    return KLT_FeatureList(_FeatureStore(n))
 
 
 _list_eq = list.__eq__

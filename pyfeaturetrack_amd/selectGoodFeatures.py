@@ -10,7 +10,6 @@ from __future__ import print_function
 import numpy as np
 
 from .backend import FEAT_DTYPE, REPLACING_SOME, SELECTING_ALL, context_of, default_context  # noqa: F401
-from . import klt as klt_module
 from .klt import KLT_Feature, KLTCountRemainingFeatures, kltState, new_feature_list, shared_store
 from .error import KLTWarning
 
@@ -153,10 +152,9 @@ def _select_locked(ctx, tc, img, nFeatures, mode, featurelist):
         try:
             if featurelist is None:
                 # the reference's `[KLT_Feature() for i in range(nFeatures)]` (:143), made while the device scores, sorts and picks
-                featurelist = new_feature_list(n, fill=False)
+                # (or taken over from a list the caller has dropped: klt._recycled)
+                featurelist = new_feature_list(n)
                 store = featurelist._store
-                if not klt_module.LAZY_FEATURE_LISTS:
-                    featurelist._fill()
         finally:
             fl = ctx.select_complete(n)
     finally:

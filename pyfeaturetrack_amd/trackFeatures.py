@@ -141,7 +141,11 @@ def _affine_state_of(tc, ctx, featurelist):
                 if key in table and table[key][1] == sid:
                     del table[key]
                     ctx.release_affine_state(sid)
-            weakref.finalize(_anchor(featurelist), _drop)
+            anchor = _anchor(featurelist)
+            if hasattr(anchor, "when_features_die"):
+                anchor.when_features_die(_drop)          # (also when the objects are handed to a new list: klt._recycled)
+            else:
+                weakref.finalize(anchor, _drop)
     return entry[1]
 
 

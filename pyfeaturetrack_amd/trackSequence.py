@@ -41,6 +41,7 @@ class _FrameStager:
         self._thread.start()
 
     def _run(self):
+        from ._frames import copy_pixels
         try:
             for img in self._frames:
                 if self._stop.is_set():                     # closed: no further frame is pulled, no buffer written
@@ -52,7 +53,7 @@ class _FrameStager:
                 buf = self._free.get()
                 if buf is None or self._stop.is_set():
                     return
-                buf[...] = arr
+                copy_pixels(buf, arr)
                 self._ready.put(("staged", buf))
             self._ready.put((None, None))
         except BaseException as e:                          # noqa: BLE001 -- handed to the calling thread

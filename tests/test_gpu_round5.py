@@ -220,8 +220,8 @@ def test_optimistic_reuse_repeats_the_tracker_when_a_frame_was_edited_in_place()
 
 def test_feature_objects_are_store_row_pairs_with_the_reference_attributes():
     """KLT_Feature: x / y / val and the affine fields read and written through the column store, Python types as the reference holds
-    them (ints after selection, floats after tracking), further attributes accepted, pickles and copies; lists handed out by the API
-    are complete plain-list-compatible lists."""
+    them (ints after selection, floats after tracking), pickles and copies; lists handed out by the API are complete
+    plain-list-compatible lists."""
     import copy
     import pickle
     from pyfeaturetrack_amd.klt import KLT_Feature, shared_store
@@ -235,9 +235,8 @@ def test_feature_objects_are_store_row_pairs_with_the_reference_attributes():
     trk.KLTTrackFeatures(tc, f[0], f[1], plain)                   # a plain-list copy is recognised as the same rows
     assert all(type(a.x) is float and type(a.y) is float for a in fl)
     a = fl[7]
-    a.note = "mine"
     a.x, a.y, a.val = 5, 2.5, 3
-    assert (a.x, a.y, a.val, a.note) == (5, 2.5, 3, "mine") and type(a.x) is int and fl._store.x[7] == 5.0
+    assert (a.x, a.y, a.val) == (5, 2.5, 3) and type(a.x) is int and fl._store.x[7] == 5.0
     b = pickle.loads(pickle.dumps(a))
     assert (b.x, b.y, b.val) == (5, 2.5, 3) and copy.deepcopy(a).y == 2.5
     lone = KLT_Feature()
@@ -246,3 +245,42 @@ def test_feature_objects_are_store_row_pairs_with_the_reference_attributes():
     assert shared_store(fl) is None                                # an edited list falls back to per-feature access
     trk.KLTTrackFeatures(tc, f[0], f[1], fl)
     assert lone.val == -1
+
+
+def test_feature_objects_of_a_dropped_list_serve_the_next_selection():
+    """klt._recycled through the public API: a per-frame `fl = KLTSelectGoodFeatures(...)` loop alternates between two sets of
+    feature objects; a list one of whose features somebody still holds is never taken over; results are those of fresh lists."""
+    from pyfeaturetrack_amd import klt
+    sgf, trk = _api_modules()
+    f = _frames_of(0, 2)
+    tc = make_tc(**_CASES[0]["tc"])
+    n = 77                                                         # (a length no other test uses: the pool is per length)
+    fl = sgf.KLTSelectGoodFeatures(tc, f[0], n)
+    want0 = _records(fl)
+    first_ids = {id(a) for a in fl}
+    trk.KLTTrackFeatures(tc, f[0], f[1], fl)
+    want1 = _records(fl)
+    del fl
+    seen = []
+    for r in range(6):
+        fl = sgf.KLTSelectGoodFeatures(tc, f[0], n)
+        seen.append({id(a) for a in fl})
+        assert _records(fl) == want0
+        trk.KLTTrackFeatures(tc, f[0], f[1], fl)
+        assert _records(fl) == want1
+    assert seen[0] == first_ids, "the dropped list's objects were not taken over"
+    assert seen[2] == seen[0] and seen[3] == seen[1] and seen[0].isdisjoint(seen[1])
+    held = fl[5]
+    held_rec = (held.x, held.y, held.val)
+    ids = {id(a) for a in fl}
+    del fl
+    fl = sgf.KLTSelectGoodFeatures(tc, f[1], n)                    # would take the objects over -- but one of them is held
+    fl2 = sgf.KLTSelectGoodFeatures(tc, f[1], n)
+    assert id(held) not in {id(a) for a in fl} | {id(a) for a in fl2} and ids.isdisjoint({id(a) for a in fl2})
+    assert (held.x, held.y, held.val) == held_rec, "a feature somebody held was rewritten"
+    klt.RECYCLE_FEATURE_OBJECTS, was = False, klt.RECYCLE_FEATURE_OBJECTS
+    try:
+        del fl, fl2
+        assert _records(sgf.KLTSelectGoodFeatures(tc, f[0], n)) == want0
+    finally:
+        klt.RECYCLE_FEATURE_OBJECTS = was

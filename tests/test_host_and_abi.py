@@ -29,7 +29,7 @@ def test_library_exports_every_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     lib.klt_abi_version.restype = ctypes.c_int
-    assert lib.klt_abi_version() == 8
+    assert lib.klt_abi_version() == 9
 
 
 def test_struct_layouts():
@@ -359,6 +359,46 @@ def test_feature_list_is_a_complete_list_by_default_and_lazy_on_request(monkeypa
     assert type(pickle.loads(pickle.dumps(new_feature_list(3)))) is list and len(copy.copy(new_feature_list(3))) == 3
     e = new_feature_list(0)
     assert len(e) == 0 and not e and list(e) == []
+
+
+def test_feature_objects_are_recycled_only_when_nobody_holds_one():
+    """klt._recycled: the objects (and store) of a dropped list become the next list of the same length -- reset to lost features,
+    `when_features_die` callbacks run -- unless somebody still holds one of the features, the store, or the list itself."""
+    import gc
+    from pyfeaturetrack_amd import klt
+    from pyfeaturetrack_amd.klt import new_feature_list, shared_store
+    if not klt.RECYCLE_FEATURE_OBJECTS:
+        pytest.skip("feature recycling is switched off")
+    n = 61
+    fl = new_feature_list(n)
+    ids = [id(f) for f in fl]
+    fl[3].x, fl[3].y, fl[3].val = 9, 2.5, 4
+    fl[4].aff_x = 2.0
+    died = []
+    fl._store.when_features_die(lambda: died.append(1))
+    del fl
+    assert not died
+    g = new_feature_list(n)
+    assert [id(f) for f in g] == ids and died == [1], "not taken over"
+    assert all((f.x, f.y, f.val, f.aff_x, f.aff_img) == (-1, -1, -1, -1.0, None) for f in g) and type(g[3].x) is int
+    assert shared_store(g) is g._store and g._store.aff is None and list.__len__(g) == n
+    held = g[7]
+    held.val = 5
+    del g
+    h = new_feature_list(n)
+    assert id(held) not in [id(f) for f in h] and held.val == 5 and [id(f) for f in h][:7] != ids[:7]
+    alias = h                                                      # the list itself is still referenced: nothing is offered
+    del h
+    k = new_feature_list(n)
+    assert {id(f) for f in k}.isdisjoint({id(f) for f in alias})
+    copy_of = list(k)                                              # a plain copy keeps every feature alive
+    del k
+    m = new_feature_list(n)
+    assert {id(f) for f in m}.isdisjoint({id(f) for f in copy_of})
+    del copy_of, alias, m, held
+    gc.collect()
+    with pytest.raises(AttributeError):
+        new_feature_list(2)[0].note = 1                            # no per-object attributes: nothing of a previous owner can survive
 
 
 def test_frame_cache_compares_every_pixel():

@@ -70,6 +70,14 @@ def main():
         g1[k % H, k % W] ^= 1
         tf.KLTTrackFeatures(tc, f0, g1, state["fl"])
 
+    clip = [synth.synth_frame(W, H, 1, k, base=base) for k in range(16)]
+    order = list(range(16)) + list(range(14, 0, -1))
+
+    def video():
+        # consecutive frames of a clip, non-sequential mode: frame 1 is the previous call's frame 2, frame 2 has new pixels
+        k = state["k"] = state["k"] + 1
+        tf.KLTTrackFeatures(tc, clip[order[k % 30]], clip[order[(k + 1) % 30]], state["fl"])
+
     print("host primitives on this box (ms):")
     a, b = f0.copy(), f0.copy()
     memcmp = ctypes.CDLL(None).memcmp
@@ -78,10 +86,12 @@ def main():
     print("  numpy copy of one frame                      %.4f" % med(lambda: np.copyto(b, a)))
     print("  new_feature_list(%d)                        %.4f" % (N, med(lambda: new_feature_list(N))))
     print("wall clock per call (ms, median of 40):")
-    for name, fn in (("KLTSelectGoodFeatures", select), ("KLTTrackFeatures ping-pong", pingpong), ("KLTTrackFeatures new frame 2 each call", fresh)):
+    for name, fn in (("KLTSelectGoodFeatures", select), ("KLTTrackFeatures ping-pong", pingpong), ("KLTTrackFeatures new frame 2 each call", fresh),
+                     ("KLTTrackFeatures consecutive frames of a clip", video)):
         fn()
-        print("  %-42s %.4f" % (name, med(fn)))
-    for name, fn in (("KLTSelectGoodFeatures", select), ("KLTTrackFeatures ping-pong", pingpong), ("KLTTrackFeatures new frame 2 each call", fresh)):
+        print("  %-46s %.4f" % (name, med(fn)))
+    for name, fn in (("KLTSelectGoodFeatures", select), ("KLTTrackFeatures ping-pong", pingpong), ("KLTTrackFeatures new frame 2 each call", fresh),
+                     ("KLTTrackFeatures consecutive frames of a clip", video)):
         table(fn, 200, name)
 
 
