@@ -152,18 +152,22 @@ class _FeatureStore:
         self.hooks = None             # callbacks for the end of the features' life (device-side affine state: trackFeatures.py)
 
     def when_features_die(self, callback):
-        """`callback()` runs when the last feature of this store is gone -- or when store and objects are handed to a new list
-        (`_recycled`), which is the same moment as far as the old features are concerned.  Callbacks must be idempotent."""
+        """`callback()` runs when the KLT_FeatureList made with this store is dropped (what is keyed by that list -- the device-side
+        affine state -- is unreachable from then on, and the objects may be handed to a new list: `_recycled`), at the latest when
+        the last feature of the store is gone.  Callbacks must be idempotent."""
         _weakref.finalize(self, callback)
         if self.hooks is None:
             self.hooks = []
         self.hooks.append(callback)
 
-    def _reset(self):
-        """back to n lost features nobody has looked at (the objects of a dropped list serve the next one: `_recycled`)"""
+    def _run_hooks(self):
         hooks, self.hooks = self.hooks, None
         for h in hooks or ():
             h()
+
+    def _reset(self):
+        """back to n lost features nobody has looked at (the objects of a dropped list serve the next one: `_recycled`)"""
+        self._run_hooks()
         self.x.fill(-1.0)
         self.y.fill(-1.0)
         self.val.fill(kltState.KLT_NOT_FOUND)
@@ -342,6 +346,7 @@ class KLT_FeatureList(list):
         # length: whether somebody still holds one of them is looked at when they are about to be used again (`_recycled`).
         try:
             canon = self._canon
+            self._store._run_hooks()
             if canon is not None and RECYCLE_FEATURE_OBJECTS:
                 _offer(self._store, canon)
         except Exception:                           # noqa: BLE001 -- interpreter shutdown

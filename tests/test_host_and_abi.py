@@ -377,7 +377,7 @@ def test_feature_objects_are_recycled_only_when_nobody_holds_one():
     died = []
     fl._store.when_features_die(lambda: died.append(1))
     del fl
-    assert not died
+    assert died == [1]                                             # the list is gone: what was keyed by it is unreachable
     g = new_feature_list(n)
     assert [id(f) for f in g] == ids and died == [1], "not taken over"
     assert all((f.x, f.y, f.val, f.aff_x, f.aff_img) == (-1, -1, -1, -1.0, None) for f in g) and type(g[3].x) is int
