@@ -56,6 +56,11 @@ struct Slot {
     const uint8_t *u8_ext = nullptr;  // klt_slot_adopt_u8: the frame IS this caller-owned device buffer (read in place, never written or freed here)
     hipEvent_t ev_consumed_alt = nullptr;
     bool consumed_alt_valid = false;
+    // last asynchronous copy INTO each raw buffer (consecutive uploads go round-robin over the copy streams: the next copy into the
+    // same buffer may be issued on another stream and must wait for this one)
+    hipEvent_t ev_wr = nullptr, ev_wr_alt = nullptr;
+    uint64_t wr_serial = 0, wr_alt_serial = 0;
+    int wr_lane = -1, wr_alt_lane = -1;
 };
 
 inline const uint8_t *raw8(const Slot *s) { return s->u8_ext ? s->u8_ext : s->u8; }
@@ -116,6 +121,7 @@ struct klt_ctx {
     KltComm *comm = nullptr;          // RCCL communicator + side stream (klt_comm_init_rank), comm.hip
     std::vector<void *> pinned;       // klt_host_alloc allocations
     std::vector<void *> dev_allocs;   // klt_device_alloc allocations
+    std::vector<size_t> dev_alloc_bytes;
     // Ordering events come from one ring and are never re-recorded while a waiter may still be queued on them
     // (re-recording a pending event makes hipEventRecord block the host until the device has caught up -- measured:
     // 400-800 us per step).  256 events ~ 25 steps of history.
@@ -306,13 +312,16 @@ int drain_timers(klt_ctx *c)
 // before freeing anything a queued kernel or collective may still use
 int sync_all(klt_ctx *c)
 {
+    // A communicator whose collective timed out: the main stream may be fenced behind the dead collective (klt_comm_fence_async, a
+    // feature buffer's comm_done wait), so waiting for it here would hang the rank that is trying to report and leave.  Nothing is
+    // freed or re-laid-out in that state -- the rank exits non-zero and is never restarted in place (klt_comm_set_timeout).
+    if (c->comm && comm_poisoned(c->comm))
+        return fail(c, KLT_ERR_TIMEOUT, "the communicator timed out earlier: device memory is left to process exit (klt_destroy does not wait either)");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));
     for (hipStream_t x : c->cextra) if (x) HIPCHK(c, hipStreamSynchronize(x));
     if (c->bstream) HIPCHK(c, hipStreamSynchronize(c->bstream));
-    // (a communicator whose collective timed out is left alone: the wait that found out has reported it, and calls that only free
-    // host memory or lay out a pyramid must not fail because of it -- the main stream is idle at this point, which is what they need)
-    if (c->comm && !comm_poisoned(c->comm)) { std::string err; if (int rc = comm_wait(c->comm, err)) return fail(c, rc, err); }
+    if (c->comm) { std::string err; if (int rc = comm_wait(c->comm, err)) return fail(c, rc, err); }
     return 0;
 }
 
@@ -1030,7 +1039,16 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
     std::swap(s->ev_consumed, s->ev_consumed_alt);
     std::swap(s->consumed_serial, s->consumed_alt_serial);
     std::swap(s->consumed_valid, s->consumed_alt_valid);
+    std::swap(s->ev_wr, s->ev_wr_alt);
+    std::swap(s->wr_serial, s->wr_alt_serial);
+    std::swap(s->wr_lane, s->wr_alt_lane);
     if (int rc = ensure(c, s->u8, s->u8_cap, px_count)) return rc;
+    if (s->wr_lane >= 0 && s->wr_lane != lane) {
+        // an earlier copy into this very buffer went through another copy stream (a slot uploaded twice without a build in between, an
+        // upload abandoned by klt_slot_adopt_u8): this one is ordered behind it -- a copy-stream event, normally long complete
+        if (event_live(c, s->wr_serial)) HIPCHK(c, hipStreamWaitEvent(cs, s->ev_wr, 0));
+        else HIPCHK(c, hipStreamSynchronize(s->wr_lane == 0 ? c->cstream : c->cextra[s->wr_lane - 1]));
+    }
     if (s->consumed_valid) {
         if (!event_live(c, s->consumed_serial)) {
             // the event has been re-used since: wait for the reading streams themselves (a build on the build stream reads raw frames too)
@@ -1054,6 +1072,7 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
     if (int rc = fresh_event(c, &s->ev_upload, &s->upload_serial)) return rc;
     HIPCHK(c, hipEventRecord(s->ev_upload, cs));
     s->upload_pending = true;
+    s->ev_wr = s->ev_upload; s->wr_serial = s->upload_serial; s->wr_lane = lane;
     s->nc = ncols;
     s->nr = nrows;
     s->raw_kind = 1;
@@ -1077,6 +1096,7 @@ int klt_device_alloc(klt_ctx *c, size_t bytes, void **out)
     void *p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(c, KLT_ERR_NOMEM, "klt_device_alloc: out of device memory"); }
     c->dev_allocs.push_back(p);
+    c->dev_alloc_bytes.push_back(bytes);
     *out = p;
     return KLT_OK;
 }
@@ -1088,10 +1108,16 @@ int klt_device_free(klt_ctx *c, void *p)
         if (c->dev_allocs[i] == p) {
             HIPCHK(c, hipSetDevice(c->device));
             if (int rc = sync_all(c)) return rc;              // a build may still read a frame adopted from it
+            // slots that had adopted a frame INSIDE this allocation hold no frame any more (not the slot's own raw buffer, which may be
+            // smaller than the adopted frame and holds an older image); slots adopted from other memory keep theirs
+            const uint8_t *lo = (const uint8_t *)p, *hi = lo + c->dev_alloc_bytes[i];
             for (Slot &s : c->slots)
-                if (s.u8_ext) { s.u8_ext = nullptr; if (s.raw_kind == 1 && !s.u8) s.raw_kind = 0; }     // (whichever buffer they pointed into)
+                if (s.u8_ext && s.u8_ext >= lo && s.u8_ext < hi) {
+                    s.u8_ext = nullptr; s.raw_kind = 0; s.pyr_valid = false; s.gen = 0; s.nc = s.nr = 0;
+                }
             hipFree(p);
             c->dev_allocs.erase(c->dev_allocs.begin() + (long)i);
+            c->dev_alloc_bytes.erase(c->dev_alloc_bytes.begin() + (long)i);
             return KLT_OK;
         }
     return fail(c, KLT_ERR_ARG, "not a klt_device_alloc allocation");
@@ -1573,8 +1599,20 @@ int klt_select_prepare_async(klt_ctx *c, int slot)
     static const bool fused_cols_eigen = !(getenv("KLT_FUSED_COLS_EIGEN") && atoi(getenv("KLT_FUSED_COLS_EIGEN")) == 0);
     if (fused_cols_eigen && c->sat_variant == 1 && sat_cols_eigen_ok(sa)) {
         if (int rc = enqueue_sat(c, c->work, s->lv[0].gx, s->lv[0].gy, c->sat_pre, nc, nr, true)) return rc;
-        TimerScope t(c, F_EIGEN, 12.0 * N + (double)g.ncand * 8);
-        launch_sat_cols_eigen_pipe(c->work, c->sat_pre, sa);
+        int e2;
+        { TimerScope t(c, F_EIGEN, 12.0 * N + (double)g.ncand * 8);
+          e2 = launch_sat_cols_eigen_pipe(c->work, c->sat_pre, sa); }
+        if (e2 > 0) return fail(c, KLT_ERR_DEVICE, std::string("column pass + eigenvalue keys: ") + hipGetErrorString((hipError_t)e2));
+        if (e2 < 0) {
+            // the fused kernel does not take this geometry after all: the column pass and the keys as two launches (no keys were written,
+            // and the score set is only stamped below, after a launch that did write them)
+            { TimerScope t(c, F_SAT_COLS, N * 24);
+              const int e3 = launch_sat_cols_pipe(c->work, c->sat_pre, nc, nr);
+              if (e3 > 0) return fail(c, KLT_ERR_DEVICE, hipGetErrorString((hipError_t)e3));
+              if (e3 < 0) launch_sat_cols(c->work, c->sat_pre, nc, nr); }
+            TimerScope t(c, F_EIGEN, 12.0 * N + (double)g.ncand * 8);
+            launch_eigen_hist(c->work, sa);
+        }
     } else {
         if (int rc = enqueue_sat(c, c->work, s->lv[0].gx, s->lv[0].gy, c->sat_pre, nc, nr)) return rc;
         TimerScope t(c, F_EIGEN, 12.0 * N + (double)g.ncand * 8);

@@ -85,6 +85,50 @@ def run_trial(ctx, t):
     return None
 
 
+def run_prepared_trial(ctx, t):
+    """The replacement pass as a sequence runs it -- scores prepared ahead (klt_select_prepare_async: row pass + cols_eigen_pipe), then
+    klt_select_begin_async / klt_select_finish with REPLACING_SOME on the slot's pyramid -- against the oracle, on frames large enough for
+    the prefilter cut (more than 262144 candidates) so that the passes behind the cut (four tiles per workgroup) run as well.  A random
+    share of the tracked features is marked lost first, from a handful (a tight cut, sometimes its repeat) to most of the list."""
+    t = dict(t, smooth=True, skip=0)
+    tc = make_tc(levels=t["levels"], ss=t["ss"], window=t["window"], max_residue=t["mr"], mindist=t["mindist"],
+                 nSkippedPixels=0, smoothBeforeSelecting=True, min_eigenvalue=t["min_eig"], max_iterations=t["max_iter"])
+    if t["border"] is not None:
+        tc.borderx = tc.bordery = t["border"]
+    p = params_from_tc(tc)
+    ctx.configure(tc)
+    base = synth.synth_base(t["w"], t["h"], t["seed"])
+    f0 = synth.shift_frame(base, 0, 0)
+    f1 = synth.shift_frame(base, *t["shift"])
+    ctx.upload(0, f0)
+    ctx.upload(1, f1)
+    ctx.build_pyramids_batch([0, 1], sync=False)
+    fl, _ = ctx.select(0, t["n"], use_pyramid=True)
+    ofl = ko.select_good_features(p, f0.astype(np.float32), t["n"])
+    if not same(fl, ofl):
+        return "selection"
+    out, _ = ctx.track(0, 1, fl)
+    ko.track_features(p, ko.Pyramids(p, f0.astype(np.float32)), ko.Pyramids(p, f1.astype(np.float32)), ofl)
+    if not same(out, ofl):
+        return "tracking"
+    rng = np.random.default_rng(t["seed"])
+    lose = rng.random(t["n"]) < rng.choice([0.003, 0.02, 0.2, 0.9])
+    for rec in (out, ofl):
+        rec["x"][lose] = -1
+        rec["y"][lose] = -1
+        rec["val"][lose] = -1
+    ctx.select_prepare(1)
+    ctx.featbuf_upload(7, out)
+    ctx.select_begin(1, REPLACING_SOME, True, 7, t["n"])
+    repeated = ctx.select_finish()
+    rep = ctx.featbuf_download(7, t["n"])
+    orep = ko.select_good_features(p, f1.astype(np.float32), t["n"], mode=2, fl=ofl)
+    if not same(rep, orep):
+        return "prepared replacement"
+    t["_stat"] = "lost %d, replaced %d, look repeated %d" % (int(lose.sum()), int((rep["val"] > 0).sum()), int(repeated))
+    return None
+
+
 def run_sequence_trial(t):
     """KLTTrackSequence (device-resident table, build stream, prepared scores, frame stager) against the per-frame host API loop it
     replaces (track, replace, store) on 5-7 frames; one region of one frame is wiped so that features are lost and replaced."""
@@ -226,14 +270,18 @@ def main():
     ap.add_argument("--batch", action="store_true", help="batched build + one tracker launch for several pairs, against the oracle")
     ap.add_argument("--affine", action="store_true", help="the affine consistency check, HIP against the oracle")
     ap.add_argument("--sequence", action="store_true", help="KLTTrackSequence against the per-frame host API instead of HIP against the oracle")
+    ap.add_argument("--prepared", action="store_true", help="replacement on prepared scores (klt_select_prepare_async + begin / finish), HIP against the oracle")
+    ap.add_argument("--min-pixels", type=int, default=0)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     ctx = None if a.sequence else Context(0)
     t0 = time.time()
     for k in range(a.trials):
         t = draw(rng, a.max_pixels, a.max_n, a.max_side)
+        while t["w"] * t["h"] < a.min_pixels:
+            t = draw(rng, a.max_pixels, a.max_n, a.max_side)
         try:
-            bad = run_sequence_trial(t) if a.sequence else run_affine_trial(ctx, t) if a.affine else run_batch_trial(ctx, t) if a.batch else run_trial(ctx, t)
+            bad = run_prepared_trial(ctx, t) if a.prepared else run_sequence_trial(t) if a.sequence else run_affine_trial(ctx, t) if a.affine else run_batch_trial(ctx, t) if a.batch else run_trial(ctx, t)
         except SystemExit as e:            # KLTError of the host layer
             bad = "error: %s" % (e,)
         print("trial %3d %s  %s" % (k, "ok  " if not bad else "FAIL (%s)" % bad, t), flush=True)

@@ -284,3 +284,94 @@ def test_feature_objects_of_a_dropped_list_serve_the_next_selection():
         assert _records(sgf.KLTSelectGoodFeatures(tc, f[0], n)) == want0
     finally:
         klt.RECYCLE_FEATURE_OBJECTS = was
+
+
+# ------------------------------------------------------------------------------------- ADVICE r4
+def test_device_free_unadopts_only_frames_inside_the_freed_allocation():
+    """a slot that once held an uploaded SMALL frame, then adopted a LARGER one from a klt_device_alloc buffer, holds
+    no frame after klt_device_free of that buffer (its own raw buffer holds an older, smaller image: a rebuild must not read it with the
+    adopted frame's size); a slot adopted from ANOTHER allocation keeps its frame and still builds."""
+    from pyfeaturetrack_amd.backend import Context, KltBackendError
+    c = Context(0)
+    try:
+        c.configure(make_tc(levels=2, ss=4))
+        small = synth.synth_pair(160, 120, seed=1)[0]
+        big, other = synth.synth_pair(640, 480, seed=2)
+        a, b = c.device_alloc(big.nbytes), c.device_alloc(other.nbytes)
+        c.device_write(a, big)
+        c.device_write(b, other)
+        c.upload(0, small)                                     # slot 0 owns a 160 x 120 raw buffer
+        c.build_pyramids(0)
+        c.adopt_u8(0, a, 640, 480)
+        c.adopt_u8(1, b, 640, 480)
+        c.build_pyramids_batch([0, 1], sync=True)
+        want = c.download_level(1, 0, 0).copy()
+        c.device_free(a)
+        assert not c.frame_resident(0) and not c.pyramids_valid(0)
+        with pytest.raises(KltBackendError, match="no frame"):
+            c.build_pyramids(0)
+        assert c.frame_resident(1), "a slot adopted from other memory lost its frame"
+        c.build_pyramids(1)
+        assert np.array_equal(c.download_level(1, 0, 0), want)
+        c.upload(0, small)                                     # the slot is usable again
+        c.build_pyramids(0)
+        assert c.level_dims(0, 0) == (160, 120)
+    finally:
+        c.close()
+
+
+def test_uploads_into_one_slot_without_a_build_in_between_stay_ordered():
+    """consecutive klt_upload_u8_async calls go round-robin over the copy streams; a slot uploaded again and again
+    without a build in between (each copy then lands in a raw buffer an earlier copy -- on another stream -- was written to) always
+    ends up holding the LAST frame sent."""
+    from pyfeaturetrack_amd.backend import Context
+    c = Context(0)
+    try:
+        c.configure(make_tc(levels=2, ss=4))
+        w, h = 1920, 1080
+        frames = [np.full((h, w), 10 * k + 5, np.uint8) for k in range(7)]
+        pins = []
+        for f in frames:
+            p = c.pinned_array((h, w))
+            p[...] = f
+            pins.append(p)
+        ref = Context(0)
+        try:
+            ref.configure(make_tc(levels=2, ss=4))
+            for rounds in (2, 3, 4, 5, 7):
+                for k in range(rounds):
+                    c.upload_async(0, pins[k])
+                c.build_pyramids(0)
+                ref.upload(0, frames[rounds - 1])
+                ref.build_pyramids(0)
+                assert np.array_equal(c.download_level(0, 0, 0), ref.download_level(0, 0, 0)), "after %d uploads" % rounds
+        finally:
+            ref.close()
+    finally:
+        c.close()
+
+
+def test_prepared_replacement_vs_oracle_on_random_draws():
+    """tests/fuzz/fuzz_parity.py --prepared: klt_select_prepare_async (row pass + cols_eigen_pipe) followed by
+    klt_select_begin_async / klt_select_finish with REPLACING_SOME, on frames with more than 262144 candidates (the prefilter cut and
+    the four-tiles-per-workgroup passes behind it run) -- every record identical to the oracle's.  250 draws ran in
+    tests/fuzz/fuzz_long.sh; 6 stay in the suite."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from pyfeaturetrack_amd.backend import Context
+    rng = np.random.default_rng(5)
+    c = Context(0)
+    try:
+        done = 0
+        while done < 6:
+            t = fz.draw(rng, 600000, 2500, 1000)
+            if t["w"] * t["h"] < 330000:
+                continue
+            bad = fz.run_prepared_trial(c, t)
+            assert bad is None, "draw %d: %s differs from the oracle: %r" % (done, bad, t)
+            done += 1
+    finally:
+        c.close()
