@@ -349,6 +349,46 @@ def timed_pass(ctx, run, mode):
     return {k["name"]: k for k in res}
 
 
+KLT_OPT_TRACK_TREE_SUMS = 18
+# VGPRs of the two forms of the quad tracker kernels, from the compiler's metadata (tools/kernel_regs.py prints them from a fresh
+# compile of track_kernels.hip; a CPU test compares)
+TRACKER_VGPRS = {7: {"exact": 124, "tree": 94}, 15: {"exact": 96, "tree": 96}}
+
+
+def tree_sums_probe(ctx, launch, read, bytes_per_launch, window, reps=6):
+    """what bit-identity costs the tracker.  The same tracker launches (resident pyramids, the same input lists) with the
+    sums added in the reference's order (the default, LDS product arrays + five serial chains) and with KLT_OPT_TRACK_TREE_SUMS (butterfly
+    sums in registers: same precision, other order of the additions): duration per launch by the dispatches' timestamps, and how the
+    records differ -- per call on identical inputs, not chained."""
+    def one(opt):
+        ctx.set_option(KLT_OPT_TRACK_TREE_SUMS, opt)
+        launch()
+        ctx.sync()
+        r = timed_pass(ctx, lambda: [launch() for _ in range(reps)], 2).get("track")
+        if not r or not r["launches"]:
+            r = timed_pass(ctx, lambda: [launch() for _ in range(reps)], 1)["track"]
+        launch()
+        return 1e3 * r["total_ms"] / r["launches"], read().copy()
+    try:
+        us_exact, rec_exact = one(0)
+        us_tree, rec_tree = one(1)
+        us_exact2, _ = one(0)
+    finally:
+        ctx.set_option(KLT_OPT_TRACK_TREE_SUMS, 0)
+    us_exact = min(us_exact, us_exact2)
+    both = (rec_exact["val"] == 0) & (rec_tree["val"] == 0)
+    flips = int((rec_exact["val"] != rec_tree["val"]).sum())
+    dx = float(max(np.abs(rec_exact["x"][both] - rec_tree["x"][both]).max(), np.abs(rec_exact["y"][both] - rec_tree["y"][both]).max())) if both.any() else 0.0
+    out = {"us_per_launch": us_tree, "us_per_launch_exact": us_exact, "speedup": us_exact / us_tree,
+           "frac": bytes_per_launch / (us_tree * 1e-6) / 1e9 / HBM_PEAK_GBS, "frac_exact": bytes_per_launch / (us_exact * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "vgprs": TRACKER_VGPRS.get(window, {}).get("tree"), "vgprs_exact": TRACKER_VGPRS.get(window, {}).get("exact"),
+           "max_abs_dx": dx, "status_flips": flips, "features": int(rec_exact.size),
+           "differing_positions": int(((rec_exact["x"] != rec_tree["x"]) | (rec_exact["y"] != rec_tree["y"]))[both].sum()),
+           "note": "opt-in KLT_OPT_TRACK_TREE_SUMS (off in every other figure of this line): the five window sums and the residue by a DPP butterfly "
+                   "in registers instead of LDS product arrays added in the reference's sequential order"}
+    return out
+
+
 def kernel_table(stamped, paired, nsteps, bytes_override=None, peak=HBM_PEAK_GBS):
     """per-kernel figures of a config's step: duration per launch (dispatch timestamps where the family has them, else the event
     pair), launches per step, algorithmic bytes per launch (the library books SURVEY 8(d)'s figure per launch; the tracker's and the
@@ -761,6 +801,10 @@ def run_cfg3(args, json_fd):
     kt = kernel_table(stamped, paired, 2, {"track": track_bytes(p, st, 2 * n), "affine_check": abytes})
     roof = roofline_of(kt, 2, ms_step, extra={"affine_checked_features_per_step": checked / 2.0, "affine_iterations_per_checked_feature": its / max(1, checked),
                                               "newton_iterations_per_level": [v / 2.0 for v in st["iterations"][:p.nPyramidLevels]]})
+    # what bit-identity costs the 15x15 tracker: the translation tracker alone on frames 0 -> 1 with the selected list
+    ctx.featbuf_upload(50, fl)
+    tree = tree_sums_probe(ctx, lambda: ctx.track_async(0, 1, 50, 51, n), lambda: ctx.featbuf_download(51, n),
+                           kt["track"]["algorithmic_bytes_per_launch"], p.window_width)
     cpu = None
     if ko and not args.no_cpu_baseline:
         snap_rec, snap_fl = None, None
@@ -783,7 +827,8 @@ def run_cfg3(args, json_fd):
                      extra_cfg={"tracked_after_call_2": int((lists[0]["val"] >= 0).sum()), "tracked_after_call_3": int((lists[1]["val"] >= 0).sum())})
     line.update(par)
     line["roofline"], line["cpu_baseline"] = roof, cpu
-    line["extra"] = {"region_ms_per_step": region_stats(regions, nsteps, el), "host_enqueue_ms_per_step": enq / nsteps * 1e3}
+    line["extra"] = {"region_ms_per_step": region_stats(regions, nsteps, el), "host_enqueue_ms_per_step": enq / nsteps * 1e3,
+                     "tracker_tree_sums": tree}
     emit(json_fd, line)
     fail_on_parity(par)
 
@@ -1259,6 +1304,12 @@ def run_cfg2(args, json_fd):
             "step_unit": "one frame pair", "step_algorithmic_bytes_formula": 2 * pyr_b + trk_b,
             "newton_iterations_per_level": st_pair["iterations"][:p.nPyramidLevels]})
 
+    tree = None
+    if rank == 0 and roofline and not args.no_extras:
+        tree = tree_sums_probe(ctx, lambda: [group_track(ctx, j, 0) for j in range(NG)],
+                               lambda: ctx.featbuf_download(T_OUT0, PL * NFEAT),
+                               roofline["kernels"]["track"]["algorithmic_bytes_per_launch"], p.window_width)
+
     # secondary figures (never `value`): selection time, the one-stream figure, the cache-resident figure and the PCIe-inclusive pair time
     extra = None
     ms_single = None
@@ -1395,6 +1446,8 @@ def run_cfg2(args, json_fd):
                          "pair; pcie_pipelined = the same bytes with klt_upload_u8_async from pinned memory on two copy streams, the next "
                          "pair sent before this pair's kernels are enqueued, and the records read back every 16 pairs without draining the "
                          "queue (klt_featbuf_download_async)"}
+        if tree:
+            extra["tracker_tree_sums"] = tree
         link = link_rates()
         extra["pcie_pipelined_GBps"] = 2 * WIDTH * HEIGHT / (ms_pipe * 1e-3) / 1e9
         if link:

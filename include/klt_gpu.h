@@ -101,6 +101,7 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
  * them (one event each way per frame).  0 (default): one stream.  The caller must give frame t+1 a slot that no call still to be
  * enqueued reads (a ring of three slots for a sequence). */
 #define KLT_OPT_BUILD_STREAM 15
+#define KLT_OPT_TRACK_TREE_SUMS 18        /* 0 (default): the tracker adds its five window sums (and the residue) in the reference's order -- records identical to the reference's bit for bit; 1: butterfly sums in registers (7x7 / 15x15 quad kernels; same precision, other order of the additions): positions agree to 1e-3 px, a status word can differ where a feature sits on a threshold */
 #define KLT_OPT_SCORE_SETS 16            /* how many sets of prepared selection scores (klt_select_prepare_async) the context keeps: 2 (default) .. 256; a selection frees the set it uses */
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
@@ -217,6 +218,14 @@ int klt_select_finish(klt_ctx *ctx);
  * squares, cuts and runs the minimum-distance passes.  Same result with or without this call. */
 int klt_select_prepare_async(klt_ctx *ctx, int slot);
 int klt_select(klt_ctx *ctx, int slot, int mode, int use_pyramid, klt_feat *inout, int n, int *n_placed);
+/* replaces _enforceMinimumDistance(pointlist, featurelist, ncols, nrows, mindist, min_eigenvalue, overwriteAllFeatures) called on its own
+ * (selectGoodFeatures.py:45-135): the greedy walk over a GIVEN candidate list in the GIVEN order.  keys[i] = f32 bits of val << 32 |
+ * x << 16 | y (what klt_download_sorted_candidates returns, re-packed); the caller has dropped the candidates the walk skips without
+ * effect (val < min_eigenvalue; positions inside the (2 mindist - 1)-squares of live features when overwrite_all == 0).  Free slots of
+ * `inout` are filled in list order -- every slot by rank when overwrite_all, the lost ones (val < 0) otherwise; with overwrite_all the
+ * slots the candidates did not reach become (-1, -1, KLT_NOT_FOUND).  Synchronous; needs no parameters and no frame. */
+int klt_min_distance_walk(klt_ctx *ctx, const uint64_t *keys, int nkeys, int ncols, int nrows, int mindist, int overwrite_all,
+                          klt_feat *inout, int n, int *n_placed);
 
 /* ---- tracking: KLTTrackFeatures, trackFeatures.py:205-409 (translation model) -------------- */
 /* _trackFeature (:67-136) + trackFeatureIterateCKLT (trackFeaturesUtils.pyx:393-459) for every

@@ -99,6 +99,7 @@ SYMBOLS = {
     "klt_select_finish": (_I, [_P]),
     "klt_select_prepare_async": (_I, [_P, _I]),
     "klt_select": (_I, [_P, _I, _I, _I, _P, _I, _PI]),
+    "klt_min_distance_walk": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _PI]),
     "klt_track_async": (_I, [_P, _I, _I, _I, _I, _I]),
     "klt_track": (_I, [_P, _I, _I, _P, _I, _PI]),
     "klt_track_batch_async": (_I, [_P, _PI, _PI, _PI, _PI, _I, _I]),

@@ -26,6 +26,9 @@ REPLACING_SOME = 2
 # the reference-shaped API's tracker reads and writes its pinned record arrays in place (klt_featbuf_map_host); KLT_MAP_RECORDS=0 in
 # the environment goes back to one copy command each way
 MAP_RECORDS = _os.environ.get("KLT_MAP_RECORDS", "1") != "0"
+# feature buffers of the reference-shaped API (65534 / 65535 are the staging buffers of the synchronous klt_track / klt_select entry
+# points, 65533 the API's selection list, 60000 .. 65524 KLTTrackSequence's table rows)
+_FB_API_IN, _FB_API_OUT = 65526, 65527
 
 
 def _dp(a):
@@ -351,6 +354,17 @@ class Context:
         self._check(self._lib.klt_select(self._h, slot, mode, int(bool(use_pyramid)), fl.ctypes.data, len(fl), C.byref(placed)))
         return fl, placed.value
 
+    def min_distance_walk(self, keys, ncols, nrows, mindist, overwrite_all, fl):
+        """klt_min_distance_walk: the greedy minimum-distance walk over the candidate keys in the given order; returns (a copy of
+        `fl` with its free slots filled, number placed)."""
+        keys = np.ascontiguousarray(keys, np.uint64)
+        fl = np.array(fl, FEAT_DTYPE)
+        placed = C.c_int()
+        self._check(self._lib.klt_min_distance_walk(self._h, keys.ctypes.data if keys.size else None, int(keys.size), int(ncols),
+                                                    int(nrows), int(mindist), int(bool(overwrite_all)), fl.ctypes.data, len(fl),
+                                                    C.byref(placed)))
+        return fl, placed.value
+
     def host_records(self, n):
         """(in, out): two pinned arrays of n klt_feat records, cached per length -- the host side of the reference-shaped API's
         lists (no staging copy inside the runtime, and the copies can be asynchronous).  Valid until the next call that uses them."""
@@ -392,7 +406,7 @@ class Context:
         self._check(self._lib.klt_featbuf_download(self._h, fb, rout.ctypes.data, n))
         return rout
 
-    def track_records(self, slot1, slot2, n, state=None, fb_in=65534, fb_out=65535):
+    def track_records(self, slot1, slot2, n, state=None, fb_in=_FB_API_IN, fb_out=_FB_API_OUT):
         """klt_track / klt_track_affine on host_records(n): [0] (filled by the caller) goes up without waiting for the copy, the
         tracked records come back in [1], which is returned."""
         self.track_enqueue(slot1, slot2, n, state, True, fb_in, fb_out)
@@ -407,7 +421,7 @@ class Context:
             self._check(self._lib.klt_featbuf_map_host(self._h, fb_out, rout.ctypes.data, max(n, 1)))
             self._mapped_records = key
 
-    def track_enqueue(self, slot1, slot2, n, state=None, upload=True, fb_in=65534, fb_out=65535):
+    def track_enqueue(self, slot1, slot2, n, state=None, upload=True, fb_in=_FB_API_IN, fb_out=_FB_API_OUT):
         """The tracker is enqueued on the list in host_records(n)[0]; nothing is waited for.  With MAP_RECORDS (the default) the two
         feature buffers are those pinned arrays themselves and no copy is enqueued; otherwise the list goes up first (`upload`; not
         again when the tracker is only repeated on other pyramids)."""
@@ -420,7 +434,7 @@ class Context:
         else:
             self._check(self._lib.klt_track_affine_async(self._h, slot1, slot2, fb_in, fb_out, n, state))
 
-    def track_complete(self, n, fb_out=65535):
+    def track_complete(self, n, fb_out=_FB_API_OUT):
         """The records of the LAST tracker enqueued into fb_out, in host_records(n)[1] (a wait for the stream when the buffers are
         mapped, one synchronous download otherwise)."""
         rout = self.host_records(n)[1]

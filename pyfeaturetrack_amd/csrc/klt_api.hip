@@ -159,6 +159,7 @@ struct klt_ctx {
     unsigned *topk_hist = nullptr;            // 8192 bins + 4 words of info
     klt_feat *fl_snapshot = nullptr;
     size_t fl_snapshot_cap = 0;
+    bool track_tree_sums = false;     // KLT_OPT_TRACK_TREE_SUMS
     bool use_topk = true;
     bool use_mis = true;                      // parallel minimum-distance passes instead of the sorted serial walk
     int mis_rounds_hint = 6;
@@ -1183,6 +1184,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
         c->pre.resize((size_t)value);
         return KLT_OK;
     }
+    if (option == KLT_OPT_TRACK_TREE_SUMS) { c->track_tree_sums = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_PARALLEL_NMS) { c->use_mis = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_AFFINE_STATE) {
@@ -1915,6 +1917,48 @@ int klt_select(klt_ctx *c, int slot, int mode, int use_pyramid, klt_feat *inout,
     return KLT_OK;
 }
 
+// _enforceMinimumDistance (selectGoodFeatures.py:45-135) as the reference's callers may use it on its own: the greedy walk over a
+// GIVEN candidate list in the GIVEN order (keys as klt_download_sorted_candidates describes them: f32 bits of val << 32 | x << 16 | y;
+// the caller has dropped the candidates the walk would skip without effect -- val below min_eigenvalue, positions inside the squares of
+// live features when these are kept), filling the list's free slots: every slot in rank order when overwrite_all, the lost ones otherwise.
+int klt_min_distance_walk(klt_ctx *c, const uint64_t *keys, int nkeys, int ncols, int nrows, int mindist, int overwrite_all,
+                          klt_feat *inout, int n, int *n_placed)
+{
+    if (!c || !inout || (!keys && nkeys > 0)) return fail(c, KLT_ERR_ARG, "null argument");
+    if (nkeys < 0 || n <= 0 || ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535) return fail(c, KLT_ERR_ARG, "bad argument");
+    if (c->sel_job) return fail(c, KLT_ERR_STATE, "a selection is pending: klt_select_finish first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int fb = 65535;                                  // the synchronous entry points' staging buffer
+    if (int rc = klt_featbuf_upload(c, fb, inout, n)) return rc;
+    if (int rc = ensure(c, c->keys2, c->keys2_cap, (size_t)nkeys + 1)) return rc;
+    if (nkeys) HIPCHK(c, hipMemcpyAsync(c->keys2, keys, (size_t)nkeys * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->keys2 + nkeys, 0, sizeof(uint64_t), c->stream));            // a zero key ends the walk
+    NmsArgs na;
+    std::memset(&na, 0, sizeof(na));
+    const int d = (mindist < 0 ? 0 : mindist) - 1;        // :61 (and :241-243 for a negative minimum distance)
+    na.fl = c->fbs[fb].d; na.placed_out = c->placed_d;
+    na.nfeat = n; na.overwrite_all = overwrite_all != 0;
+    na.d = d; na.cell = d >= 0 ? d + 1 : 1;
+    na.cell_magic = na.cell == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)na.cell) + 1u;
+    if (int rc = ensure(c, c->nms_slots, c->nms_slots_cap, (size_t)n)) return rc;
+    na.slots = c->nms_slots;
+    na.gw = d >= 0 ? (ncols + na.cell - 1) / na.cell : 1;
+    na.gh = d >= 0 ? (nrows + na.cell - 1) / na.cell : 1;
+    const size_t grid_bytes = (size_t)na.gw * na.gh * sizeof(uint32_t);
+    na.grid_in_lds = grid_bytes <= 128 * 1024;
+    if (!na.grid_in_lds) {
+        if (int rc = ensure(c, c->grid, c->grid_cap, (size_t)na.gw * na.gh)) return rc;
+        na.grid_global = c->grid;
+        HIPCHK(c, hipMemsetAsync(c->grid, 0, grid_bytes, c->stream));
+    }
+    na.keys = c->keys2; na.nkeys = nkeys + 1;
+    if (const int e = launch_nms(c->stream, na)) return fail(c, KLT_ERR_DEVICE, std::string("nms launch: ") + hipGetErrorString((hipError_t)e));
+    c->sorted_keys = nullptr; c->sorted_count = 0;
+    if (int rc = klt_featbuf_download(c, fb, inout, n)) return rc;
+    if (n_placed) HIPCHK(c, hipMemcpy(n_placed, c->placed_d, sizeof(int), hipMemcpyDeviceToHost));
+    return KLT_OK;
+}
+
 // ----------------------------------------------------------------------------------------- tracking
 static void fill_track_params(const klt_ctx *c, const Slot *s1, TrackArgs &a, int n)
 {
@@ -1926,6 +1970,7 @@ static void fill_track_params(const klt_ctx *c, const Slot *s1, TrackArgs &a, in
     a.small = p.min_determinant; a.th = p.min_displacement; a.step = p.step_factor; a.max_residue = p.max_residue;
     a.ss = (float)s1->ss;
     a.inv_ss = 1.0f / (float)s1->ss;
+    a.tree_sums = c->track_tree_sums ? 1 : 0;
 }
 
 // XCD-aware feature order (KLT_OPT_TRACK_XCD_ORDER): one permutation of 0..n-1 per pair of the launch.  It is only a locality

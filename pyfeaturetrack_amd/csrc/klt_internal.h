@@ -71,6 +71,7 @@ struct TrackArgs {
     double borderx, bordery;
     int n, nlevels, window, max_iterations, use_max_residue, retain, ncols, nrows;
     float small, th, step, max_residue, ss, inv_ss;
+    int tree_sums;               // KLT_OPT_TRACK_TREE_SUMS: the quad kernels add the five sums (and the residue) by a butterfly in registers
 };
 
 struct AffineArgs {

@@ -413,7 +413,23 @@ __device__ __forceinline__ void sample_quad(const f32x4 a, const Bilinear &b, fl
     }
 }
 
-template <bool BATCH, int W, int WAVES = 1>
+// KLT_OPT_TRACK_TREE_SUMS: the sum of one value per lane over the LPF lanes of a feature, by a butterfly in registers -- within a
+// row of 16 lanes four v_add_f32 with DPP operands (quad_perm [1,0,3,2] and [2,3,0,1], row_half_mirror, row_mirror: after each step
+// the lanes that were combined hold the same partial sum, so mirroring pairs what xor would pair), across rows ds_bpermute.  Every
+// lane ends up with the total.  Same precision as the sequential f32 chain, other ORDER of the additions: not the reference's bits.
+template <int LPF>
+__device__ __forceinline__ float group_tree_sum(float v)
+{
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    if (LPF > 16) v = v + __shfl_xor(v, 16);
+    if (LPF > 32) v = v + __shfl_xor(v, 32);
+    return v;
+}
+
+template <bool BATCH, int W, int WAVES = 1, bool TREE = false>
 __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
 {
     static_assert(W == 7 || W == 15, "quad kernels exist for 7x7 and 15x15 windows");
@@ -515,6 +531,7 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
             sample_quad<QPR>(s_qi, b2, s_i);
             sample_quad<QPR>(s_qgx, b2, s_gx);
             sample_quad<QPR>(s_qgy, b2, s_gy);
+            float tree[5] = {0.f, 0.f, 0.f, 0.f, 0.f};     // TREE: this lane's share of the five sums (its samples inside the window)
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 if (qr < w && 4 * qh + m < w) {
@@ -522,16 +539,24 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
                     const float diff = t_i[m] - s_i[m];
                     const float sx = t_gx[m] + s_gx[m];
                     const float sy = t_gy[m] + s_gy[m];
-                    gl[k] = sx * sx;
-                    gl[npad + k] = sx * sy;
-                    gl[2 * npad + k] = sy * sy;
-                    gl[3 * npad + k] = diff * sx;
-                    gl[4 * npad + k] = diff * sy;
+                    if (TREE) {
+                        tree[0] = tree[0] + sx * sx;
+                        tree[1] = tree[1] + sx * sy;
+                        tree[2] = tree[2] + sy * sy;
+                        tree[3] = tree[3] + diff * sx;
+                        tree[4] = tree[4] + diff * sy;
+                    } else {
+                        gl[k] = sx * sx;
+                        gl[npad + k] = sx * sy;
+                        gl[2 * npad + k] = sy * sy;
+                        gl[3 * npad + k] = diff * sx;
+                        gl[4 * npad + k] = diff * sy;
+                    }
                 }
             }
-            wave_lds_sync();
+            if (!TREE) wave_lds_sync();
             float acc = 0.f;
-            if (s < 5) {
+            if (!TREE && s < 5) {
                 const float4 *T4 = reinterpret_cast<const float4 *>(gl + s * npad);
                 if (W > 8) {
                     // 15x15: whole quads without a test, the n % 4 tail on its own -- with the tests inside the partly unrolled loop every
@@ -562,9 +587,15 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
                     }
                 }
             }
-            wave_lds_sync();
-            const float gxx = __shfl(acc, glead), gxy = __shfl(acc, glead + 1), gyy = __shfl(acc, glead + 2);
-            const float ex = __shfl(acc, glead + 3) * a.step, ey = __shfl(acc, glead + 4) * a.step;
+            if (!TREE) wave_lds_sync();
+            float gxx, gxy, gyy, ex, ey;
+            if (TREE) {
+                gxx = group_tree_sum<LPF>(tree[0]); gxy = group_tree_sum<LPF>(tree[1]); gyy = group_tree_sum<LPF>(tree[2]);
+                ex = group_tree_sum<LPF>(tree[3]) * a.step; ey = group_tree_sum<LPF>(tree[4]) * a.step;
+            } else {
+                gxx = __shfl(acc, glead); gxy = __shfl(acc, glead + 1); gyy = __shfl(acc, glead + 2);
+                ex = __shfl(acc, glead + 3) * a.step; ey = __shfl(acc, glead + 4) * a.step;
+            }
             const float p1 = gxx * gyy, p2 = gxy * gxy;
             const float det = p1 - p2;
             const bool small_det = det < a.small;
@@ -603,13 +634,22 @@ __global__ __launch_bounds__(64, WAVES) void track_kernel_quad(TrackArgs a)
             }
             float s_i[4];
             sample_quad<QPR>(r_qi, br, s_i);
+            float sres;
+            if (TREE) {
+                float part = 0.f;
 #pragma unroll
-            for (int m = 0; m < 4; m++)
-                if (qr < w && 4 * qh + m < w) gl[k0 + m] = fabsf(t_i[m] - s_i[m]);
-            wave_lds_sync();
-            float sres = pairwise_group<3>(gl, n, s);
-            wave_lds_sync();
-            sres = __shfl(sres, glead);
+                for (int m = 0; m < 4; m++)
+                    if (qr < w && 4 * qh + m < w) part = part + fabsf(t_i[m] - s_i[m]);
+                sres = group_tree_sum<LPF>(part);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                    if (qr < w && 4 * qh + m < w) gl[k0 + m] = fabsf(t_i[m] - s_i[m]);
+                wave_lds_sync();
+                sres = pairwise_group<3>(gl, n, s);
+                wave_lds_sync();
+                sres = __shfl(sres, glead);
+            }
             if (need_res && sres / (float)n > a.max_residue) status = KLT_LARGE_RESIDUE;
         }
 
@@ -748,14 +788,16 @@ static int launch_track_t(hipStream_t s, const TrackArgs &a)
         // latency: 112 / 199 us per launch against 87.5, cfg-4's 32-pair shard 0.535 / 0.687 ms against 0.495.  A scratch reload is a
         // vector memory operation and those return in order: it waits behind the footprint loads in flight, i.e. for the round trip
         // the extra wavefront was meant to hide.)
-        klt_launch((track_kernel_quad<BATCH, 7>), gq, block, (unsigned)(4 * lds), s, a);
+        if (a.tree_sums) klt_launch((track_kernel_quad<BATCH, 7, 1, true>), gq, block, 0u, s, a);
+        else klt_launch((track_kernel_quad<BATCH, 7>), gq, block, (unsigned)(4 * lds), s, a);
         return 0;
     }
     if (g_track_variant != 0 && a.window == 15) {
         const dim3 gq(a.order ? 8 * a.order_chunk : a.n, ny);
         // occupancy target 5 (96 VGPRs, 40 bytes of scratch per lane instead of 107 VGPRs): the 5000 wavefronts of cfg-3 are then
         // resident at once instead of in two rounds -- 57.9 -> 49.3 us.  (The 7x7 kernel loses from the same cap, see above.)
-        klt_launch((track_kernel_quad<BATCH, 15, 5>), gq, block, (unsigned)lds, s, a);
+        if (a.tree_sums) klt_launch((track_kernel_quad<BATCH, 15, 5, true>), gq, block, 0u, s, a);
+        else klt_launch((track_kernel_quad<BATCH, 15, 5>), gq, block, (unsigned)lds, s, a);
         return 0;
     }
     const dim3 grid(a.order ? 8 * a.order_chunk : a.n, ny);

@@ -92,6 +92,77 @@ def _fix_window(tc):
         KLTWarning("Tracking context's window height must be at least three.  \nChanging to 3.\n")
 
 
+def _fillFeaturemap(x, y, featuremap, mindist, ncols, nrows):
+    """selectGoodFeatures.py:18-25: marks the (2 mindist + 1)-square around (x, y), clipped to the image, in the flat row-major
+    `featuremap` (a list of bools, or any flat sequence that takes item assignment) and returns it."""
+    x0, x1 = max(x - mindist, 0), min(x + mindist, ncols - 1)
+    if x0 <= x1:
+        for iy in range(max(y - mindist, 0), min(y + mindist, nrows - 1) + 1):
+            for k in range(iy * ncols + x0, iy * ncols + x1 + 1):
+                featuremap[k] = True
+    return featuremap
+
+
+def _enforceMinimumDistance(pointlist, featurelist, ncols, nrows, mindist, min_eigenvalue, overwriteAllFeatures):
+    """selectGoodFeatures.py:45-135 under the reference's own name: `pointlist` = [(val, x, y), ...] is walked IN THE ORDER GIVEN (the
+    reference's caller has sorted it, :234-236); a point is placed into the next free slot of `featurelist` -- every slot in turn when
+    `overwriteAllFeatures`, the lost ones (val < 0) otherwise -- unless it lies within mindist - 1 (Chebyshev) of a feature placed
+    before it or, when the old features are kept, of a live one, or its value is below max(min_eigenvalue, 1).  The walk itself runs
+    on the device (klt_min_distance_walk); the points it would skip without effect are dropped here first.  Returns the list.
+    Values are C floats as ScanImageForGoodFeatures produces them; a point outside the image is the reference's AssertionError."""
+    if min_eigenvalue < 1:
+        min_eigenvalue = 1
+    n = len(featurelist)
+    pts = np.asarray([(p[0], p[1], p[2]) for p in pointlist], np.float64).reshape(-1, 3)
+    val, px, py = pts[:, 0], pts[:, 1].astype(np.int64), pts[:, 2].astype(np.int64)
+    if n == 0:
+        return featurelist
+    d = mindist - 1
+    store = shared_store(featurelist)
+    rec = features_to_array(featurelist, None, store)
+    keep = val >= min_eigenvalue
+    if not overwriteAllFeatures and d >= 0:
+        seeded = np.zeros((nrows, ncols), bool)
+        for i in np.nonzero(rec["val"] >= 0)[0]:
+            x, y = int(rec["x"][i]), int(rec["y"][i])           # int(feat.x), int(feat.y): truncation (:66-67)
+            seeded[max(y - d, 0):max(min(y + d, nrows - 1) + 1, 0), max(x - d, 0):max(min(x + d, ncols - 1) + 1, 0)] = True
+    else:
+        seeded = None
+    # The reference asserts a point's bounds when the walk reaches it (:100-103) and stops looking once the list is full; a point
+    # list with an out-of-image entry behind that point is accepted there and refused here -- the stricter reading.
+    assert bool(np.all((px >= 0) & (px < ncols) & (py >= 0) & (py < nrows))), "point outside the image"
+    if seeded is not None and len(px):
+        keep &= ~seeded[py, px]
+    v32 = val[keep].astype(np.float32)
+    keys = (v32.view(np.uint32).astype(np.uint64) << np.uint64(32)) | (px[keep].astype(np.uint64) << np.uint64(16)) | py[keep].astype(np.uint64)
+    ctx = default_context()
+    with ctx.lock:
+        out, placed = ctx.min_distance_walk(keys, ncols, nrows, mindist, overwriteAllFeatures, rec)
+    old = rec["val"]
+    if overwriteAllFeatures:
+        # slots the walk reached are rewritten by rank; behind them only the lost ones become (-1, -1, KLT_NOT_FOUND) (:80-82)
+        touched = np.arange(n) < placed
+        touched |= old < 0
+    else:
+        touched = (old < 0) & (out["val"] >= 0)
+    if store is not None:
+        np.copyto(store.x, out["x"], where=touched)
+        np.copyto(store.y, out["y"], where=touched)
+        np.copyto(store.val, out["val"], where=touched)
+        np.logical_or(store.xint, touched, out=store.xint)
+        np.logical_or(store.yint, touched, out=store.yint)
+        store.reset_affine(touched)
+        return featurelist
+    xs, ys, vs = out["x"].tolist(), out["y"].tolist(), out["val"].tolist()
+    for i in np.nonzero(touched)[0]:
+        feat = featurelist[i]
+        feat.x, feat.y, feat.val = int(xs[i]), int(ys[i]), vs[i]
+        feat.aff_img = feat.aff_img_gradx = feat.aff_img_grady = None
+        feat.aff_x, feat.aff_y = -1.0, -1.0
+        feat.aff_Axx, feat.aff_Ayx, feat.aff_Axy, feat.aff_Ayy = 1.0, 0.0, 0.0, 1.0
+    return featurelist
+
+
 def _KLTSelectGoodFeatures(tc, img, nFeatures, mode, featurelist=None):
     """selectGoodFeatures.py:141-261.  With REPLACING_SOME the given list is updated in place."""
     _fix_window(tc)

@@ -149,6 +149,40 @@ def _affine_state_of(tc, ctx, featurelist):
     return entry[1]
 
 
+def _trackFeature(x1, y1, x2, y2, img1, gradx1, grady1, img2, gradx2, grady2, tc):
+    """trackFeatures.py:67-136 under the reference's own name: one feature at one pyramid level, from the planes the caller hands
+    over -- the three patches around (x1, y1), the Newton loop (klt_track_iterate_f32 through trackFeaturesUtils), the window's bounds
+    with the Python-3 float half-window (3.5 for 7x7, :88-89, :108), the residue test (:113-121: computeIntensityDifference, numpy's
+    f32 pairwise sum), retainTrackers and the status priority (:123-135).  Returns (status, x2, y2).
+    KLTTrackFeatures does not come through here: klt_track runs every feature and level in one launch."""
+    from . import trackFeaturesUtils as tfu
+    width, height = tc.window_width, tc.window_height
+    hw, hh = width / 2, height / 2
+    nc, nr = img1.shape[1], img1.shape[0]
+    one_plus_eps = 1.001
+    img1Patch = tfu.extractImagePatchSlow(img1, x1, y1, height, width)
+    img1GradxPatch = tfu.extractImagePatchSlow(gradx1, x1, y1, height, width)
+    img1GradyPatch = tfu.extractImagePatchSlow(grady1, x1, y1, height, width)
+    x2, y2, status, iteration = tfu.trackFeatureIterateCKLT(x2, y2, img1GradxPatch, img1GradyPatch, img1Patch, img2, gradx2, grady2, tc)
+    if x2 - hw < 0.0 or nc - (x2 + hw) < one_plus_eps or y2 - hh < 0.0 or nr - (y2 + hh) < one_plus_eps:
+        status = kltState.KLT_OOB
+    if status == kltState.KLT_TRACKED and tc.max_residue is not None:
+        if tc.lighting_insensitive:
+            raise Exception("Not implemented")
+        workingPatch = np.empty((height, width), np.float32)
+        imgdiff = np.zeros(workingPatch.size, np.float32)
+        tfu.computeIntensityDifference(img1Patch, img2, x2, y2, workingPatch, imgdiff)
+        if np.abs(imgdiff).sum() / (width * height) > tc.max_residue:
+            status = kltState.KLT_LARGE_RESIDUE
+    if tc.retainTrackers:
+        return kltState.KLT_TRACKED, x2, y2
+    if status in (kltState.KLT_SMALL_DET, kltState.KLT_OOB, kltState.KLT_LARGE_RESIDUE):
+        return status, x2, y2
+    if iteration >= tc.max_iterations:
+        return kltState.KLT_MAX_ITERATIONS, x2, y2
+    return kltState.KLT_TRACKED, x2, y2
+
+
 def _outOfBounds(x, y, ncols, nrows, borderx, bordery):
     """trackFeatures.py:140-141"""
     return x < borderx or x > ncols - 1 - borderx or y < bordery or y > nrows - 1 - bordery

@@ -2,9 +2,11 @@
 feature and level (trackFeatures.py:102-106), with the reference's names, arguments and results.
 
 KLTTrackFeatures does not come through here -- klt_track runs all features and levels in one launch.  This module is the reference's
-literal native boundary for callers (and parity checks) that use it directly; every call uploads the planes it is given.  The
-SciPy-optimiser helpers of the reference's module (computeIntensityDifference, computeGradientSum, minFunc, jacobian:
-trackFeaturesUtils.pyx:90-97, :130-142, :342-388) belong to an alternative path the tracker does not take and are not provided.
+literal native boundary for callers (and parity checks) that use it directly; every call uploads the planes it is given.
+computeIntensityDifference (the residue test of _trackFeature calls it, trackFeatures.py:120) and computeGradientSum
+(trackFeaturesUtils.pyx:90-97, :130-142) are here as well: the bilinear samples come from the device (klt_extract_patch_f32), the
+f32 subtraction behind them is numpy's.  The SciPy-optimiser helpers minFunc / jacobian (:342-388) belong to an alternative path the
+tracker does not take and are not provided.
 """
 import ctypes as C
 
@@ -36,6 +38,45 @@ def extractImagePatchSlow(img, x, y, height, width):
     return patch
 
 
+def _f32_2d(a, what):
+    if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.ndim != 2:
+        raise ValueError("Buffer dtype mismatch or wrong number of dimensions (expected a 2-D float32 array): {0}".format(what))
+    return a
+
+
+def computeIntensityDifference(img1Patch, img2, x2, y2, workingPatch, out):
+    """trackFeaturesUtils.pyx:61-97: `workingPatch` (its shape is the window) receives the bilinear samples of `img2` around (x2, y2),
+    `out` (flat float32, window size) the differences img1Patch - workingPatch in row-major order.  Returns None."""
+    work = _f32_2d(workingPatch, "workingPatch")
+    p1 = _f32_2d(img1Patch, "img1Patch")
+    if not isinstance(out, np.ndarray) or out.dtype != np.float32 or out.ndim != 1:
+        raise ValueError("Buffer dtype mismatch or wrong number of dimensions (expected a 1-D float32 array): out")
+    h, w = work.shape
+    work[...] = extractImagePatchSlow(img2, x2, y2, h, w)
+    hh, hw = h // 2, w // 2                                   # (the loops run over 2 * half + 1 rows / columns, :80-81)
+    rows, cols = 2 * hh + 1, 2 * hw + 1
+    out[:rows * cols] = (p1[:rows, :cols] - work[:rows, :cols]).ravel()
+    return None
+
+
+def computeGradientSum(img1GradxPatch, gradx2, x2, y2, workingPatch, out, row):
+    """trackFeaturesUtils.pyx:107-142: `workingPatch` receives the bilinear samples of `gradx2` around (x2, y2); column `row` of the
+    2-D float32 `out` receives -img1GradxPatch - workingPatch, entry (j, i) at index j * workingPatch.shape[0] + i (the reference's
+    indexing: row-major for the square windows the tracker uses)."""
+    work = _f32_2d(workingPatch, "workingPatch")
+    p1 = _f32_2d(img1GradxPatch, "img1GradxPatch")
+    out = _f32_2d(out, "out")
+    h, w = work.shape
+    work[...] = extractImagePatchSlow(gradx2, x2, y2, h, w)
+    s = -p1[:h, :w] - work
+    if h == w:
+        out[:h * w, row] = s.ravel()
+    else:
+        for j in range(h):
+            out[j * h:j * h + w, row] = s[j]
+    return None
+
+
 def trackFeatureIterateCKLT(x2, y2, img1GradxPatch, img1GradyPatch, img1Patch, img2, gradx2, grady2, tc):
     """trackFeaturesUtils.pyx:393-459: (x2, y2, status, iteration) after the Newton loop of one feature at one level."""
     if getattr(tc, "lighting_insensitive", False):
@@ -56,4 +97,4 @@ def trackFeatureIterateCKLT(x2, y2, img1GradxPatch, img1GradyPatch, img1Patch, i
     return xo.value, yo.value, st.value, it.value
 
 
-__all__ = ["extractImagePatchSlow", "trackFeatureIterateCKLT"]
+__all__ = ["extractImagePatchSlow", "trackFeatureIterateCKLT", "computeIntensityDifference", "computeGradientSum"]

@@ -375,3 +375,171 @@ def test_prepared_replacement_vs_oracle_on_random_draws():
             done += 1
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------------------------- the reference's helper functions by name
+@pytest.fixture(scope="module")
+def literal(golden_dir):
+    import os
+    return np.load(os.path.join(golden_dir, "literal_boundary.npz"))
+
+
+def test_compute_intensity_difference_and_gradient_sum(literal):
+    """compat/trackFeaturesUtils.computeIntensityDifference / computeGradientSum (trackFeaturesUtils.pyx:90-97, :130-142) against what the
+    reference's functions wrote into `out` and `workingPatch` for 40 + 20 windows of 7x7 / 15x15 (tests/golden/gen_literal_boundary.py)."""
+    from pyfeaturetrack_amd import trackFeaturesUtils as tfu
+    img = literal["cid_img"]
+    for w in (7, 15):
+        xs, ys, p1 = literal["cid_x_%d" % w], literal["cid_y_%d" % w], literal["cid_p1_%d" % w]
+        cnt = len(xs)
+        for k in range(cnt):
+            work = np.full((w, w), -7.0, np.float32)
+            d = np.zeros(w * w, np.float32)
+            assert tfu.computeIntensityDifference(p1[k], img, float(xs[k]), float(ys[k]), work, d) is None
+            assert np.array_equal(work, literal["cid_work_%d" % w][k]) and np.array_equal(d, literal["cid_diff_%d" % w][k])
+            g = np.zeros((w * w, 2), np.float32)
+            work2 = np.empty((w, w), np.float32)
+            tfu.computeGradientSum(p1[k], img, float(xs[k]), float(ys[k]), work2, g, 0)
+            tfu.computeGradientSum(p1[(k + 1) % cnt], img, float(ys[k]), float(xs[k]) * 0.5 + 8, work2, g, 1)
+            assert np.array_equal(g, literal["cgs_sum_%d" % w][k])
+    with pytest.raises(ValueError):
+        tfu.computeIntensityDifference(p1[0].astype(np.float64), img, 20.0, 20.0, np.empty((15, 15), np.float32), np.zeros(225, np.float32))
+
+
+@pytest.mark.parametrize("tag,mr,retain", [("r10", 10.0, False), ("rnone", None, False), ("retain", 10.0, True)])
+def test_track_feature_under_the_reference_name(literal, golden_dir, tag, mr, retain):
+    """trackFeatures._trackFeature (trackFeatures.py:67-136) on every call the reference made while tracking img0 -> img1 (100 features x
+    2 levels, three tracking contexts): same (status, x2, y2), Python floats equal bit for bit."""
+    import os
+    from conftest import read_pgm
+    sgf, trk = _api_modules()
+    img0, img1 = read_pgm(os.path.join(golden_dir, "img0.pgm")), read_pgm(os.path.join(golden_dir, "img1.pgm"))
+    tc = make_tc(max_residue=mr, retainTrackers=retain)
+    p1, p1x, p1y, p2, p2x, p2y = trk.ComputeImagePyramids(tc, img0, img1)
+    level = {320: 0, 80: 1}
+    rows = literal["tf_%s" % tag]
+    assert len(rows) == 200
+    statuses = set()
+    for x1, y1, x2, y2, nc, st, xo, yo in rows:
+        r = level[int(nc)]
+        got = trk._trackFeature(x1, y1, x2, y2, p1.img[r], p1x.img[r], p1y.img[r], p2.img[r], p2x.img[r], p2y.img[r], tc)
+        assert (got[0], float(got[1]), float(got[2])) == (int(st), xo, yo), (x1, y1, r)
+        statuses.add(int(st))
+    assert (statuses == {0}) if (retain or mr is None) else (len(statuses) >= 2)
+
+
+def test_enforce_minimum_distance_under_the_reference_name(literal):
+    """selectGoodFeatures._enforceMinimumDistance / _fillFeaturemap (selectGoodFeatures.py:18-25, :45-135) called directly, on point
+    lists nobody sorted (duplicates, values below the threshold), with and without live features to keep, mindist 0 .. 25, both
+    list kinds (a list this package made; plain objects): the reference's lists."""
+    from pyfeaturetrack_amd.klt import KLT_Feature, new_feature_list
+    sgf, _ = _api_modules()
+    for ci, (ncols, nrows, mindist, min_eig, overwrite) in enumerate(literal["emd_cases"]):
+        points = [(float(v), int(x), int(y)) for v, x, y in literal["emd_%d_points" % ci]]
+        fin, want = literal["emd_%d_in" % ci], literal["emd_%d_out" % ci]
+        for kind in ("package list", "plain objects"):
+            fl = new_feature_list(len(fin)) if kind == "package list" else [KLT_Feature() for _ in fin]
+            for f, (x, y, v) in zip(fl, fin):
+                if v >= 0:
+                    f.x, f.y, f.val = float(x), float(y), int(v)
+            got = sgf._enforceMinimumDistance(points, fl, int(ncols), int(nrows), int(mindist), float(min_eig) if min_eig != int(min_eig) else int(min_eig),
+                                              bool(overwrite))
+            assert got is fl
+            have = np.array([(f.x, f.y, f.val) for f in fl], np.float64)
+            assert np.array_equal(have, want), "case %d (%s)" % (ci, kind)
+            placed = [f for f, before, after in zip(fl, fin, want) if after[2] > 0 and tuple(before) != tuple(after)]
+            assert all(type(f.x) is int and type(f.y) is int for f in placed)     # newly placed: Python ints (:116-119)
+    for (x, y, md, nc_, nr_), want in zip(literal["ffm_cases"], literal["ffm_maps"]):
+        fm = [False] * int(nc_ * nr_)
+        assert sgf._fillFeaturemap(int(x), int(y), fm, int(md), int(nc_), int(nr_)) is fm
+        assert np.array_equal(np.array(fm, bool), want)
+
+
+def test_replacement_through_enforce_minimum_distance_by_name(cfg1, img1):
+    """SURVEY a-23's pin, literally: the reference's replacement = _enforceMinimumDistance(sorted pointlist, featurelist, ...,
+    overwriteAllFeatures=False) on img1's candidates -- here the candidates come from the compat ScanImageForGoodFeatures on the device's
+    gradients, are sorted as the reference sorts them (selectGoodFeatures.py:234-236) and go through the function under its own name;
+    the list equals the reference's `repl_out_*`."""
+    from pyfeaturetrack_amd import convolve, goodFeaturesUtils
+    from pyfeaturetrack_amd.klt import new_feature_list
+    from pyfeaturetrack_amd.klt_util import KLTComputeSmoothSigma
+    sgf, _ = _api_modules()
+    tc = make_tc(max_residue=10.0)
+    smooth = convolve.KLTComputeSmoothedImage(img1.astype(np.float32), KLTComputeSmoothSigma(tc))
+    gx, gy = convolve.KLTComputeGradients(smooth, tc.grad_sigma)
+    px, py, pv = goodFeaturesUtils.ScanImageForGoodFeatures(gx, gy, tc.borderx, tc.bordery, tc.window_width / 2, tc.window_height / 2,
+                                                            tc.nSkippedPixels)
+    pointlist = sorted(zip(pv, px, py), reverse=True)
+    fl = new_feature_list(100)
+    for f, x, y, v in zip(fl, cfg1["repl_in_x"], cfg1["repl_in_y"], cfg1["repl_in_val"]):
+        f.x, f.y, f.val = float(x), float(y), int(v)
+    sgf._enforceMinimumDistance(pointlist, fl, 320, 240, tc.mindist, tc.min_eigenvalue, False)
+    have = np.array([(f.x, f.y, f.val) for f in fl], np.float64)
+    assert np.array_equal(have[:, 0], cfg1["repl_out_x"]) and np.array_equal(have[:, 1], cfg1["repl_out_y"])
+    assert np.array_equal(have[:, 2], cfg1["repl_out_val"].astype(np.float64))
+
+
+# ------------------------------------------------------------------------------------- opt-in tree sums in the tracker
+def _tree_vs_golden(ctx, fl, want_x, want_y, want_val, what, s1=0, s2=1):
+    """tracker with KLT_OPT_TRACK_TREE_SUMS on the given list: identical status words, positions within the north star's 1e-3 px of the
+    reference's (the default kernel gives them bit for bit); returns (max |d|, positions that are not bit-identical)"""
+    ctx.set_option(18, 1)
+    try:
+        out, _ = ctx.track(s1, s2, fl)
+    finally:
+        ctx.set_option(18, 0)
+    assert np.array_equal(out["val"].astype(np.int64), np.asarray(want_val).astype(np.int64)), \
+        "%s: %d status words differ" % (what, int((out["val"] != want_val).sum()))
+    ok = out["val"] == 0
+    dx = np.abs(out["x"][ok].astype(np.float64) - want_x[ok])
+    dy = np.abs(out["y"][ok].astype(np.float64) - want_y[ok])
+    err = float(max(dx.max(), dy.max())) if ok.any() else 0.0
+    assert err <= 1e-3, "%s: %g px" % (what, err)
+    return err, int(((dx != 0) | (dy != 0)).sum())
+
+
+def test_tree_sums_tracker_vs_reference_goldens(golden_dir, cfg1, img0, img1):
+    """KLT_OPT_TRACK_TREE_SUMS (north_star: "gradient-sum / SSD reduction with wave-level shuffles", outputs within
+    1e-3 px): the five window sums and the residue reduced by a DPP butterfly in registers -- same precision as the reference
+    (trackFeaturesUtils.pyx:246-305), other order of the additions.  Per call on the reference's own inputs (its selected lists), not
+    chained: status words identical and |dx|, |dy| <= 1e-3 px against the reference's tracked lists at cfg-1 / 2 / 3 / 4 / 5 size and on the
+    220 random draws it ran.  The default stays the bit-exact kernel."""
+    import os
+    from helpers import baseline_case, random_draws
+    from pyfeaturetrack_amd.backend import Context, FEAT_DTYPE
+    big = np.load(os.path.join(golden_dir, "baseline_sizes.npz"))
+    c = Context(0)
+    worst, inexact, total = 0.0, 0, 0
+    try:
+        for tag, mr in (("r10", 10.0), ("rnone", None)):                      # cfg-1: img0 -> img1, 100 features (one feature per wavefront:
+            c.configure(make_tc(max_residue=mr))                            # the option does not apply, the records are the exact ones)
+            c.upload(0, img0)
+            c.upload(1, img1)
+            c.build_pyramids_batch([0, 1], sync=True)
+            fl, _ = c.select(0, 100)
+            e, k = _tree_vs_golden(c, fl, cfg1["trk100_%s_x" % tag], cfg1["trk100_%s_y" % tag], cfg1["trk100_%s_val" % tag], "cfg-1 " + tag)
+            assert (e, k) == (0.0, 0)
+        for tag in ("cfg2", "cfg4", "cfg3", "cfg5"):
+            frames, tc, n = baseline_case(tag)
+            c.configure(tc)
+            c.upload(0, frames[0])
+            c.upload(1, frames[1])
+            c.build_pyramids_batch([0, 1], sync=True)
+            fl = np.zeros(n, FEAT_DTYPE)
+            fl["x"], fl["y"], fl["val"] = big[tag + "_sel_x"], big[tag + "_sel_y"], big[tag + "_sel_val"]
+            e, k = _tree_vs_golden(c, fl, big[tag + "_trk_x"], big[tag + "_trk_y"], big[tag + "_trk_val"], tag)
+            worst, inexact, total = max(worst, e), inexact + k, total + n
+        assert inexact > 0, "the tree sums gave the reference's bits everywhere: is the option wired?"
+        for name in ("random_draws.npz", "random_draws_large.npz"):
+            for t, tc, f0, f1, want in random_draws(golden_dir, name):
+                c.configure(tc)
+                c.upload(0, f0)
+                c.upload(1, f1)
+                c.build_pyramids_batch([0, 1], sync=True)
+                fl = np.zeros(t["n"], FEAT_DTYPE)
+                fl["x"], fl["y"], fl["val"] = want["sel"]
+                e, k = _tree_vs_golden(c, fl, *want["trk"], what="draw %r" % (t["seed"],))
+                worst = max(worst, e)
+    finally:
+        c.close()
+    print("tree sums: worst |d| = %g px, %d of %d positions at the BASELINE sizes not bit-identical" % (worst, inexact, total))
