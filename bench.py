@@ -187,7 +187,7 @@ def cpu_time(fn, budget_s=10.0, max_reps=200):
     return (time.perf_counter() - t) / reps, reps
 
 
-def cpu_baseline_of(ko, one_step, nfeat, what, all_cores=True, budget_s=10.0):
+def cpu_baseline_of(ko, one_step, nfeat, what, all_cores=True, budget_s=10.0, reference_python_survey=None):
     """Oracle timed on the host: a bounded sample of the same workload (about 10-20 s of CPU work).  `one_step()` = one step of the
     config on the CPU; value = nfeat / seconds."""
     if ko is None:
@@ -196,6 +196,14 @@ def cpu_baseline_of(ko, one_step, nfeat, what, all_cores=True, budget_s=10.0):
     dt, reps = cpu_time(one_step, budget_s)
     out = {"value": nfeat / dt, "unit": "features/s", "cores": 1, "kind": "port", "ms_per_step": dt * 1e3,
            "sample": "%d x (%s), oracle/klt_oracle.c, 1 thread" % (reps, what)}
+    if reference_python_survey:
+        # the reference ITSELF (Python / Cython / SciPy; it cannot travel to the GPU box) as the survey timed
+        # it in its own container, next to the port -- context, not a measurement of this run
+        ref = dict(reference_python_survey)
+        ref["port_over_reference"] = (nfeat / dt) / ref["features_per_s"]
+        ref["note"] = ("TimSC/PyFeatureTrack itself on this workload, measured by the survey (BASELINE.md section 2: Intel Xeon @ 2.10 GHz, "
+                       "one thread; best of 3); port_over_reference = this run's one-thread oracle / that figure -- two different hosts")
+        out["reference_python_survey"] = ref
     if all_cores:
         # the same port on the host cores this process may actually use (OpenMP over image lines / features; bit-identical
         # results).  Time-bounded: a container with a CPU quota can make many threads slower than one.
@@ -1466,7 +1474,8 @@ def run_cfg2(args, json_fd):
     if rank == 0 and not distributed and not args.no_cpu_baseline and ko:
         a0, a1 = frames[0][0].astype(np.float32), frames[0][1].astype(np.float32)
         cpu = cpu_baseline_of(ko, lambda: ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), lists[0].copy()), NFEAT,
-                              "pyramids of both frames + track 5000 features of ONE pair of cfg-2 (1920x1080, seed %d)" % seeds[0])
+                              "pyramids of both frames + track 5000 features of ONE pair of cfg-2 (1920x1080, seed %d)" % seeds[0],
+                              reference_python_survey={"ms_per_pair": 603.0, "features_per_s": 8300.0, "where": "survey container, 1 thread"})
         if cpu:
             cpu["ms_per_pair"] = cpu["ms_per_step"]
 

@@ -21,16 +21,16 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-# the capture hook (klt_debug_graph) is not in the product library: a private copy of it, klt_api.hip compiled with -DKLT_GRAPH_PROBE
+# the capture hook (klt_debug_graph) is not in the product library: a private copy of it, api_compat.hip compiled with -DKLT_GRAPH_PROBE
 _src = os.path.join(ROOT, "pyfeaturetrack_amd", "csrc")
 _lib = os.path.join(ROOT, "gpurun_out", "libkltgpu_graph.so")
 os.makedirs(os.path.dirname(_lib), exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-                "-I" + os.path.join(ROOT, "include"), "-Wno-cuda-compat", "-Wno-unused-result", "-DKLT_GRAPH_PROBE", "-c", os.path.join(_src, "klt_api.hip"),
+                "-I" + os.path.join(ROOT, "include"), "-Wno-cuda-compat", "-Wno-unused-result", "-DKLT_GRAPH_PROBE", "-c", os.path.join(_src, "api_compat.hip"),
                 "-o", "/tmp/klt_api_graph.o"], check=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", _lib, "/tmp/klt_api_graph.o"] +
-               [os.path.join(_src, f) for f in ("conv_kernels.o", "pyramid_kernels.o", "select_kernels.o", "sat_pipeline.o", "track_kernels.o",
-                                                "affine_kernels.o", "comm.o")] + ["-ldl"], check=True)
+               [os.path.join(_src, f) for f in ("api_context.o", "api_frames.o", "api_featbuf.o", "api_select.o", "api_track.o", "api_comm.o", "host_pool.o", "conv_kernels.o", "pyramid_kernels.o", "select_kernels.o", "sat_pipeline.o", "track_kernels.o",
+                                                "affine_kernels.o", "comm.o")] + ["-ldl", "-lpthread"], check=True)
 os.environ["KLT_GPU_LIB"] = _lib
 from pyfeaturetrack_amd import synth                                     # noqa: E402
 from pyfeaturetrack_amd.backend import Context                           # noqa: E402

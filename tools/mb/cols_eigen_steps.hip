@@ -3,7 +3,7 @@
 // worked and waited in each step (ticks of 10 ns).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DSAT_PIPE_DEBUG -Iinclude -Ipyfeaturetrack_amd/csrc tools/mb/cols_eigen_steps.hip -o tools/mb/cols_eigen_steps
 #include "../../pyfeaturetrack_amd/csrc/sat_pipeline.hip"
-thread_local hipEvent_t g_klt_stamp_start = nullptr, g_klt_stamp_stop = nullptr;     // the timing hooks of klt_launch (klt_api.hip in the library)
+thread_local hipEvent_t g_klt_stamp_start = nullptr, g_klt_stamp_stop = nullptr;     // the timing hooks of klt_launch (api_context.hip in the library)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

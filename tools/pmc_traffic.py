@@ -48,10 +48,11 @@ def read(dirname, counter):
 
 
 # everything a per-launch counter depends on: the kernels, the shared load / store helpers (klt_internal.h) and the launch geometry
-# (klt_api.hip)
+# (the files of the C ABI that enqueue those kernels: pyramid build, selection, tracker)
 KERNEL_SOURCES = ["pyfeaturetrack_amd/csrc/pyramid_kernels.hip", "pyfeaturetrack_amd/csrc/track_kernels.hip",
                   "pyfeaturetrack_amd/csrc/select_kernels.hip", "pyfeaturetrack_amd/csrc/sat_pipeline.hip",
-                  "pyfeaturetrack_amd/csrc/klt_internal.h", "pyfeaturetrack_amd/csrc/klt_api.hip"]
+                  "pyfeaturetrack_amd/csrc/klt_internal.h", "pyfeaturetrack_amd/csrc/klt_context.h",
+                  "pyfeaturetrack_amd/csrc/api_frames.hip", "pyfeaturetrack_amd/csrc/api_select.hip", "pyfeaturetrack_amd/csrc/api_track.hip"]
 
 
 def provenance(what):

@@ -14,8 +14,8 @@ os.makedirs(os.path.dirname(dbg), exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
                 "-I" + os.path.join(ROOT, "include"), "-Wno-cuda-compat", "-DKLT_TRACK_CLOCKS", "-c", os.path.join(src, "track_kernels.hip"),
                 "-o", "/tmp/track_clk.o"], check=True)
-objs = [os.path.join(src, f) for f in ("klt_api.o", "conv_kernels.o", "pyramid_kernels.o", "select_kernels.o", "sat_pipeline.o", "affine_kernels.o")]
-subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", dbg, "/tmp/track_clk.o"] + objs, check=True)
+objs = [os.path.join(src, f) for f in ("api_context.o", "api_frames.o", "api_featbuf.o", "api_select.o", "api_track.o", "api_comm.o", "api_compat.o", "host_pool.o", "comm.o", "conv_kernels.o", "pyramid_kernels.o", "select_kernels.o", "sat_pipeline.o", "affine_kernels.o")]
+subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", dbg, "/tmp/track_clk.o"] + objs + ["-ldl", "-lpthread"], check=True)
 os.environ["KLT_GPU_LIB"] = dbg
 
 import numpy as np                                          # noqa: E402
