@@ -41,1682 +41,23 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 `roofline` with the per-kernel table, `cpu_baseline`.
 """
 import argparse
-import hashlib
-import json
-import math
 import os
-import statistics
 import sys
-import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# importing the package does not touch the GPU (the library is bound on first use)
-from pyfeaturetrack_amd import parallel, synth                          # noqa: E402
-from pyfeaturetrack_amd.backend import Context                          # noqa: E402
-from pyfeaturetrack_amd.klt import KLT_TrackingContext                  # noqa: E402
-from pyfeaturetrack_amd.params import affine_params_from_tc, params_from_tc   # noqa: E402
-
-WIDTH, HEIGHT, NFEAT = 1920, 1080, 5000
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TOL_PX = 1e-3             # north_star: sub-pixel x/y within 1e-3 (observed: 0)
-DTYPE = "f32 (convolutions accumulate in f64)"
-MIN_TIMED_S = 6.0         # the timed regions of a run add up to at least this much GPU work (the driver samples the GPU every 5 s:
-                          # r03 saw 0 of 4 samples busy with 2 s of timed work inside an 18 s run)
-HBM_ACHIEVABLE_GBS = 6300.0   # MI355X_MICROARCH.md: what a streaming kernel sustains of the 8 TB/s
-ORACLE_NOTE = "oracle/klt_oracle.c (pinned to reference-generated goldens)"
-
-
-def cfg2_context():
-    tc = KLT_TrackingContext()
-    tc.nPyramidLevels = 3
-    tc.subsampling = 4
-    tc.KLTUpdateTCBorder()          # border 120 (SURVEY.md 8(d))
-    return tc
-
-
-def level_pixels(p, ncols, nrows):
-    n, dims = [], (ncols, nrows)
-    for _ in range(p.nPyramidLevels):
-        n.append(dims[0] * dims[1])
-        dims = (dims[0] // p.subsampling, dims[1] // p.subsampling)
-    return n
-
-
-def pyramid_bytes(p, ncols, nrows, b_in=1):
-    """N0 (b_in + 4) + sum 4 (N_{l-1} + N_l) + sum 12 N_l -- one frame"""
-    n = level_pixels(p, ncols, nrows)
-    return n[0] * (b_in + 4) + sum(4 * (n[l - 1] + n[l]) for l in range(1, len(n))) + sum(12 * v for v in n)
-
-
-def track_bytes(p, stats, nfeat):
-    """sum over features and levels of 12 (w+1)(h+1) (1 + iterations) + 24 per record; `stats` = totals of the
-    device counters (klt_track_stats) over the launches they cover, nfeat = records those launches read and wrote"""
-    L = p.nPyramidLevels
-    foot = 12.0 * (p.window_width + 1) * (p.window_height + 1)
-    return foot * (sum(stats["level_visits"][:L]) + sum(stats["iterations"][:L])) + 24.0 * nfeat
-
-
-def algorithmic_bytes(p, ncols, nrows, stats, nfeat):
-    """per pair (pyramid bytes of one frame, tracker bytes); `stats` = per-pair averages"""
-    return pyramid_bytes(p, ncols, nrows), track_bytes(p, stats, nfeat)
-
-
-def usable_cores(cap=32):
-    """Cores this process can really run on: scheduler affinity, clipped by the cgroup CPU quota and by `cap`."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except (OSError, ValueError):
-            pass
-    return max(1, min(n, cap))
-
-
-# ============================================================================= the checker (oracle) and the CPU baseline
-def load_oracle():
-    """oracle/klt_oracle.py -- the checker and the cpu_baseline leg only; never the thing measured.  None if it is not built."""
-    try:
-        from oracle import klt_oracle as ko
-        ko.lib()
-        return ko
-    except (ImportError, OSError) as e:
-        print("oracle unavailable: %s" % e, file=sys.stderr)
-        return None
-
-
-def oracle_track(ko, p, f0, f1, fl, threads=1):
-    """The CPU oracle's records for one pair."""
-    a0, a1 = f0.astype(np.float32), f1.astype(np.float32)
-    ofl = fl.copy()
-    ko.set_threads(threads)
-    ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), ofl)
-    ko.set_threads(1)
-    return ofl
-
-
-def records_equal(out, ofl):
-    """(status codes equal, max |dx, dy|) of records `out` against the oracle's `ofl`"""
-    same_val = bool(np.array_equal(out["val"], ofl["val"]))
-    dx = float(max(np.abs(out["x"].astype(np.float64) - ofl["x"]).max(), np.abs(out["y"].astype(np.float64) - ofl["y"]).max())) if len(out) else 0.0
-    return same_val, dx
-
-
-def parity_summary(checks, what):
-    """{parity_checked, ...} from [(label, status codes equal, max |dx|)]; an empty list = unchecked"""
-    if not checks:
-        return {"parity_checked": False, "parity_note": "oracle library not built on this box"}
-    worst = max(c[2] for c in checks)
-    same = all(c[1] for c in checks)
-    bad = [c[0] for c in checks if not c[1] or c[2] > TOL_PX]
-    out = {"parity_checked": bool(same and worst <= TOL_PX), "max_abs_dx": worst, "status_codes_equal": same,
-           "parity_tolerance_px": TOL_PX, "parity_against": ORACLE_NOTE, "parity_cases": len(checks), "parity_what": what}
-    if bad:
-        out["parity_failed_cases"] = bad[:8]
-    return out
-
-
-def fail_on_parity(par):
-    if par and not par.get("parity_checked") and "max_abs_dx" in par:
-        raise SystemExit("timed records differ from the oracle: %r" % par)
-
-
-def cpu_time(fn, budget_s=10.0, max_reps=200):
-    """(seconds per call, calls): one call to size the sample, then about `budget_s` of them"""
-    t = time.perf_counter()
-    fn()
-    t1 = time.perf_counter() - t
-    reps = int(max(2, min(max_reps, budget_s / max(t1, 1e-4))))
-    t = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    return (time.perf_counter() - t) / reps, reps
-
-
-def cpu_baseline_of(ko, one_step, nfeat, what, all_cores=True, budget_s=10.0, reference_python_survey=None):
-    """Oracle timed on the host: a bounded sample of the same workload (about 10-20 s of CPU work).  `one_step()` = one step of the
-    config on the CPU; value = nfeat / seconds."""
-    if ko is None:
-        return None
-    ko.set_threads(1)
-    dt, reps = cpu_time(one_step, budget_s)
-    out = {"value": nfeat / dt, "unit": "features/s", "cores": 1, "kind": "port", "ms_per_step": dt * 1e3,
-           "sample": "%d x (%s), oracle/klt_oracle.c, 1 thread" % (reps, what)}
-    if reference_python_survey:
-        # BASELINE.md section 2 / 4: the reference ITSELF (Python / Cython / SciPy; it cannot travel to the GPU box) as the survey timed
-        # it in its own container, next to the port -- context, not a measurement of this run
-        ref = dict(reference_python_survey)
-        ref["port_over_reference"] = (nfeat / dt) / ref["features_per_s"]
-        ref["note"] = ("TimSC/PyFeatureTrack itself on this workload, measured by the survey (BASELINE.md section 2: Intel Xeon @ 2.10 GHz, "
-                       "one thread; best of 3); port_over_reference = this run's one-thread oracle / that figure -- two different hosts")
-        out["reference_python_survey"] = ref
-    if all_cores:
-        # the same port on the host cores this process may actually use (OpenMP over image lines / features; bit-identical
-        # results).  Time-bounded: a container with a CPU quota can make many threads slower than one.
-        ncores = ko.set_threads(usable_cores())
-        t = time.perf_counter()
-        reps_all = 0
-        while reps_all < 40 and (reps_all < 2 or time.perf_counter() - t < 4.0) and time.perf_counter() - t < 12.0:
-            one_step()
-            reps_all += 1
-        dt_all = (time.perf_counter() - t) / reps_all
-        ko.set_threads(1)
-        out["all_cores"] = {"value": nfeat / dt_all, "cores": ncores, "ms_per_step": dt_all * 1e3,
-                            "sample": "%d x the same step, OpenMP over image lines and features" % reps_all}
-    return out
-
-
-def list_digest(fl):
-    """sha256 (16 hex digits) of the (x, y, val) columns of a feature list"""
-    cols = np.stack([fl["x"].view(np.int32), fl["y"].view(np.int32), fl["val"].astype(np.int32)], axis=1)
-    return hashlib.sha256(np.ascontiguousarray(cols).tobytes()).hexdigest()[:16]
-
-
-def file_sha16(rel):
-    try:
-        return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
-    except OSError:
-        return None
-
-
-def committed_counters(name, kernel_family, pairs_per_launch=None):
-    """Per-launch PMC figures of `kernel_family` from profiles/<name> -- NOT measurements of this run: they come from the
-    builder's rocprofv3 --pmc passes (tools/pmc_traffic.py, tools/pmc_sq.py) and carry their provenance; they are dropped when
-    the kernel source they were collected for is no longer the one in the tree."""
-    path = os.path.join(ROOT, "profiles", name)
-    if not os.path.exists(path):
-        return None, None
-    data = json.load(open(path))
-    meta = data.get("_meta", {})
-    for rel, sha in (meta.get("kernel_source_sha16") or {}).items():
-        if file_sha16(rel) != sha:
-            return None, "profiles/%s is stale: %s changed since it was collected" % (name, rel)
-    if not meta:
-        return None, "profiles/%s carries no provenance record" % name
-    if pairs_per_launch is not None and meta.get("cfg2_pairs_per_launch", 1) != pairs_per_launch:
-        return None, "profiles/%s was collected for launches of %d pair(s), this run's hold %d" % (name, meta.get("cfg2_pairs_per_launch", 1), pairs_per_launch)
-    return data.get(kernel_family), "profiles/%s, %s" % (name, meta.get("source", "builder gpurun"))
-
-
-# ================================================================================== timing helpers
-class Ranks:
-    """Rank bookkeeping + the barrier / max-over-ranks of the timing contract, through libkltgpu's RCCL entry points."""
-
-    def __init__(self, args):
-        self.rank, self.local_rank, self.world = parallel.world_from_env()
-        if os.environ.get("KLT_RANKS_SHARE_DEVICE") is not None:      # test hook: several ranks on one GPU (a one-GPU box)
-            self.local_rank = int(os.environ["KLT_RANKS_SHARE_DEVICE"])
-        if self.world != args.gpus and self.world > 1:
-            print("warning: WORLD_SIZE=%d but --gpus %d" % (self.world, args.gpus), file=sys.stderr)
-        self.distributed = self.world > 1 or os.environ.get("KLT_FORCE_DIST") == "1"   # the env var exercises the RCCL path on one GPU
-        self.ctxs = []
-
-    def attach(self, ctxs):
-        """One communicator per context, same order on every rank."""
-        self.ctxs = list(ctxs)
-        if self.distributed:
-            parallel.init_communicators(self.ctxs, self.rank, self.world)
-            self.max_over_ranks(0.0)                      # first collective: RCCL's lazy set-up, and every rank has joined
-            parallel.cleanup_rendezvous(self.rank)
-
-    def sync_local(self):
-        for cx in self.ctxs:
-            cx.sync()                                      # stream + copy stream + this context's collectives
-
-    def max_over_ranks(self, v):
-        if not self.distributed:
-            return v
-        return self.ctxs[0].comm_allreduce_max([float(v)])[0]
-
-    def fence(self):
-        """everything enqueued so far has finished on every rank"""
-        self.sync_local()
-        self.max_over_ranks(0.0)
-
-    def timed(self, fn):
-        """fence; run fn(); synchronise; elapsed seconds = MAX over ranks"""
-        self.fence()
-        t0 = time.perf_counter()
-        fn()
-        enq = time.perf_counter() - t0
-        self.sync_local()
-        el = time.perf_counter() - t0
-        return self.max_over_ranks(el), enq
-
-
-class OneGpu:
-    """The same bracket for the single-GPU configs (no communicator)."""
-    distributed = False
-    rank, world = 0, 1
-
-    def __init__(self, ctxs):
-        self.ctxs = list(ctxs)
-
-    def max_over_ranks(self, v):
-        return v
-
-    def timed(self, fn):
-        for cx in self.ctxs:
-            cx.sync()
-        t0 = time.perf_counter()
-        fn()
-        enq = time.perf_counter() - t0
-        for cx in self.ctxs:
-            cx.sync()
-        return time.perf_counter() - t0, enq
-
-
-def timed_regions(ranks, run_region, repeats, min_total_s=None, budget_s=30.0):
-    """K-step regions, each bracketed as the contract says, until `repeats` regions AND `min_total_s` of timed work are in (so that
-    a sampler outside this process sees a busy GPU even when one region lasts a millisecond); fewer -- never below 5 -- when the
-    regions are long.  Returns (median seconds per region, all regions, host enqueue seconds of the median region)."""
-    min_total_s = MIN_TIMED_S if min_total_s is None else min_total_s
-    el, enq = ranks.timed(run_region)
-    regions = [(el, enq)]
-    n = max(repeats, int(math.ceil(min_total_s / max(el, 1e-9))))
-    if el * n > budget_s:
-        n = max(5, int(budget_s / max(el, 1e-9)))
-    n = int(ranks.max_over_ranks(n)) if ranks.distributed else n      # every rank runs the same number of regions
-    while len(regions) < n:
-        regions.append(ranks.timed(run_region))
-    regions.sort()
-    med = regions[len(regions) // 2]
-    return med[0], [r[0] for r in regions], med[1]
-
-
-def region_stats(regions, units, elapsed):
-    """spread of the timed regions in ms per unit (`units` per region)"""
-    return {"median": elapsed / units * 1e3, "min": min(regions) / units * 1e3, "max": max(regions) / units * 1e3,
-            "regions": len(regions), "timed_s_total": sum(regions)}
-
-
-# ------------------------------------------------------------------------------------------------- roofline bookkeeping
-def timed_pass(ctx, run, mode):
-    """`run()` with every launch timed: mode 1 = an event pair around each launch (it also holds the boundary to the launch before,
-    ~2.6 us); mode 2 = the kernels that are one launch per call by their dispatch's own start / stop timestamps -- what rocprofv3
-    reports as the kernel's duration.  {family: {launches, total_ms, bytes}}"""
-    ctx.sync()
-    ctx.timing_enable(mode)
-    run()
-    res = ctx.timing_read()
-    ctx.timing_enable(False)
-    return {k["name"]: k for k in res}
-
-
-KLT_OPT_TRACK_TREE_SUMS = 18
-# VGPRs of the two forms of the quad tracker kernels, from the compiler's metadata (tools/kernel_regs.py prints them from a fresh
-# compile of track_kernels.hip; a CPU test compares)
-TRACKER_VGPRS = {7: {"exact": 124, "tree": 94}, 15: {"exact": 96, "tree": 96}}
-
-
-def tree_sums_probe(ctx, launch, read, bytes_per_launch, window, reps=6):
-    """what bit-identity costs the tracker.  The same tracker launches (resident pyramids, the same input lists) with the
-    sums added in the reference's order (the default, LDS product arrays + five serial chains) and with KLT_OPT_TRACK_TREE_SUMS (butterfly
-    sums in registers: same precision, other order of the additions): duration per launch by the dispatches' timestamps, and how the
-    records differ -- per call on identical inputs, not chained."""
-    def one(opt):
-        ctx.set_option(KLT_OPT_TRACK_TREE_SUMS, opt)
-        launch()
-        ctx.sync()
-        r = timed_pass(ctx, lambda: [launch() for _ in range(reps)], 2).get("track")
-        if not r or not r["launches"]:
-            r = timed_pass(ctx, lambda: [launch() for _ in range(reps)], 1)["track"]
-        launch()
-        return 1e3 * r["total_ms"] / r["launches"], read().copy()
-    try:
-        us_exact, rec_exact = one(0)
-        us_tree, rec_tree = one(1)
-        us_exact2, _ = one(0)
-    finally:
-        ctx.set_option(KLT_OPT_TRACK_TREE_SUMS, 0)
-    us_exact = min(us_exact, us_exact2)
-    both = (rec_exact["val"] == 0) & (rec_tree["val"] == 0)
-    flips = int((rec_exact["val"] != rec_tree["val"]).sum())
-    dx = float(max(np.abs(rec_exact["x"][both] - rec_tree["x"][both]).max(), np.abs(rec_exact["y"][both] - rec_tree["y"][both]).max())) if both.any() else 0.0
-    out = {"us_per_launch": us_tree, "us_per_launch_exact": us_exact, "speedup": us_exact / us_tree,
-           "frac": bytes_per_launch / (us_tree * 1e-6) / 1e9 / HBM_PEAK_GBS, "frac_exact": bytes_per_launch / (us_exact * 1e-6) / 1e9 / HBM_PEAK_GBS,
-           "vgprs": TRACKER_VGPRS.get(window, {}).get("tree"), "vgprs_exact": TRACKER_VGPRS.get(window, {}).get("exact"),
-           "max_abs_dx": dx, "status_flips": flips, "features": int(rec_exact.size),
-           "differing_positions": int(((rec_exact["x"] != rec_tree["x"]) | (rec_exact["y"] != rec_tree["y"]))[both].sum()),
-           "note": "opt-in KLT_OPT_TRACK_TREE_SUMS (off in every other figure of this line): the five window sums and the residue by a DPP butterfly "
-                   "in registers instead of LDS product arrays added in the reference's sequential order"}
-    return out
-
-
-def kernel_table(stamped, paired, nsteps, bytes_override=None, peak=HBM_PEAK_GBS):
-    """per-kernel figures of a config's step: duration per launch (dispatch timestamps where the family has them, else the event
-    pair), launches per step, algorithmic bytes per launch (the library books SURVEY 8(d)'s figure per launch; the tracker's and the
-    affine check's come from the device counters: `bytes_override` = {family: total bytes over the pass}), GB/s and fraction of peak"""
-    out = {}
-    for name, k in sorted(paired.items(), key=lambda kv: -kv[1]["total_ms"]):
-        s = stamped.get(name) if stamped else None
-        src = s if s and s["launches"] == k["launches"] else k
-        total_bytes = (bytes_override or {}).get(name, k["bytes"])
-        us = 1e3 * src["total_ms"] / src["launches"]
-        gbps = total_bytes / max(src["total_ms"], 1e-9) / 1e6
-        out[name] = {"us_per_launch": us, "launches_per_step": k["launches"] / nsteps,
-                     "timed_by": "dispatch timestamps" if src is s else "event pair",
-                     "us_per_launch_event_pair": 1e3 * k["total_ms"] / k["launches"],
-                     "algorithmic_bytes_per_launch": total_bytes / k["launches"], "GBps": gbps, "frac": gbps / peak}
-    return out
-
-
-def roofline_of(table, nsteps, ms_per_step, peak=HBM_PEAK_GBS, dominant=None, extra=None):
-    """the `roofline` object: the dominant kernel (largest share of device time) against the HBM roof, the whole step next to it"""
-    dom = dominant or max(table, key=lambda n: table[n]["us_per_launch"] * table[n]["launches_per_step"])
-    d = table[dom]
-    step_bytes = sum(k["algorithmic_bytes_per_launch"] * k["launches_per_step"] for k in table.values())
-    dev_ms = sum(k["us_per_launch"] * k["launches_per_step"] for k in table.values()) * 1e-3
-    r = {"bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": peak, "unit": "GB/s", "frac": d["frac"],
-         "frac_vs_achievable": min(1.0, d["GBps"] / HBM_ACHIEVABLE_GBS), "achievable": HBM_ACHIEVABLE_GBS,
-         "achievable_note": "the guide's measured streaming ceiling (6.3 TB/s of the 8 TB/s specification); frac stays against the specification",
-         "traffic": None,
-         "launch_us": d["us_per_launch"], "launch_us_source": d["timed_by"], "launch_us_event_pair": d["us_per_launch_event_pair"],
-         "launches_per_step": d["launches_per_step"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-         "step_algorithmic_bytes": step_bytes, "step_kernel_ms": dev_ms,
-         "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / peak,
-         "step_frac_note": "step_algorithmic_bytes / ms_per_step / peak (the un-instrumented timed regions); step_kernel_ms = sum of the kernels' own durations",
-         "kernels": table}
-    r.update(extra or {})
-    return r
-
-
-def check_fractions(obj, path="line"):
-    """Every fraction of peak in the line must be <= 1 (and every GB/s <= the peak next to it): a figure above the roof is a
-    bookkeeping error (round 2 shipped step_frac 2.6 from counters that included warm-up launches), never a result."""
-    bad = []
-
-    def walk(o, p, peak):
-        if isinstance(o, dict):
-            peak = o.get("peak", peak) if isinstance(o.get("peak"), (int, float)) else peak
-            for k, v in o.items():
-                if isinstance(v, bool) or v is None:
-                    continue
-                if isinstance(v, (int, float)):
-                    if (k == "frac" or k.endswith("_frac") or k.startswith("frac_")) and not (0.0 <= v <= 1.0):
-                        bad.append("%s.%s = %r" % (p, k, v))
-                    if k == "GBps" and peak and v > peak:
-                        bad.append("%s.%s = %r > peak %r" % (p, k, v, peak))
-                else:
-                    walk(v, p + "." + k, peak)
-        elif isinstance(o, list):
-            for i, v in enumerate(o):
-                walk(v, "%s[%d]" % (p, i), peak)
-
-    walk(obj, path, HBM_PEAK_GBS)
-    return bad
-
-
-def emit(json_fd, line):
-    bad = check_fractions(line)
-    if bad:
-        raise SystemExit("refusing to print a line with figures above the roof: " + "; ".join(bad))
-    os.write(json_fd, (json.dumps(line) + "\n").encode())      # the ONE JSON line on the real stdout
-
-
-def base_line(value, n_gpus, steps, warmup, ms_step, ms_pair, workload, scaling="weak", extra_cfg=None):
-    cfg = {"workload": workload}
-    cfg.update(extra_cfg or {})
-    return {"metric": "features tracked/sec", "value": value, "unit": "features/s", "n_gpus": n_gpus, "steps": steps,
-            "warmup": warmup, "ms_per_step": ms_step, "ms_per_frame_pair": ms_pair, "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-            "config": cfg, "roofline": None, "cpu_baseline": None}
-
-
-def sane_iterations(stats, nfeat_total, levels, what):
-    """The Newton-iteration counters must describe exactly the launches they are divided by: per feature and level between 1 and
-    max_iterations (10) on average.  (Round 2 reset them before a warm-up loop.)"""
-    for l in range(levels):
-        per = stats["iterations"][l] / max(1, nfeat_total)
-        if not (0.5 <= per <= 10.0):
-            raise SystemExit("%s: %.2f Newton iterations per feature at level %d -- the counters cover other launches than the ones "
-                             "they are booked on" % (what, per, l))
-
-
-# ========================================================================================== cfg-4
-def run_cfg4(args, json_fd):
-    """BASELINE cfg-4: 256 independent 1280x720 pairs (seeds 0..255), 2000 features each, 7x7, 3 levels / ss 4, sharded
-    contiguously over the ranks (32 per GPU at N = 8; shards may differ by one pair), frames resident in HBM.  Per step every rank
-    builds the pyramids of its whole shard (frames share launches through blockIdx.z), tracks it with ONE launch into a device-side
-    [pairs x features] table and the table is gathered to rank 0 with one RCCL gather (a count per rank).  Total work is fixed:
-    strong scaling."""
-    ranks = Ranks(args)
-    total, w, h, nf = args.pairs, 1280, 720, 2000
-    mine = parallel.shard_range(total, ranks.world, ranks.rank)
-    pairs = len(mine)
-    tc = cfg2_context()
-    p = params_from_tc(tc)
-    ctx = Context(ranks.local_rank)
-    ctx.set_params(p)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=max(1, usable_cores(16) // max(1, min(ranks.world, 8)))) as ex:
-        frames = list(ex.map(lambda i: synth.synth_pair(w, h, seed=i), mine))
-    for k, (f0, f1) in enumerate(frames):
-        ctx.upload(2 * k, f0)
-        ctx.upload(2 * k + 1, f1)
-    slots = list(range(2 * pairs))
-    T_IN, T_OUT, T_ALL, V_IN, V_OUT = 0, 1, 2, 1000, 1000 + max(pairs, 1)
-    if pairs:
-        ctx.build_pyramids_batch(slots, sync=True)
-        ctx.featbuf_alloc(T_IN, pairs * nf)
-        ctx.featbuf_alloc(T_OUT, pairs * nf)
-    for k in range(pairs):
-        ctx.featbuf_view(V_IN + k, T_IN, k * nf, nf)
-        ctx.featbuf_view(V_OUT + k, T_OUT, k * nf, nf)
-        ctx.select_async(2 * k, 1, True, V_IN + k, nf)
-    ctx.sync()
-    table = [(2 * k, 2 * k + 1, V_IN + k, V_OUT + k) for k in range(pairs)]
-    ranks.attach([ctx])
-    gather = parallel.ShardGather(ctx, T_OUT, T_ALL, total, nf, root=0) if ranks.distributed else None
-
-    def step():
-        if pairs:
-            ctx.build_pyramids_batch(slots)
-        if gather and pairs:
-            ctx.comm_fence_featbuf(T_OUT)          # the gather of the previous step has read the table
-        if pairs:
-            ctx.track_batch_async(table, nf)
-        if gather:
-            gather.gather_async()
-
-    def region():
-        for _ in range(args.steps):
-            step()
-
-    for _ in range(max(1, args.warmup)):
-        step()
-    el, regions, enq = timed_regions(ranks, region, args.repeats)
-    # what was timed, against the oracle: the first and the last pair of rank 0's shard
-    out = ctx.featbuf_download(T_OUT, pairs * nf).reshape(pairs, nf) if pairs else np.zeros((0, nf), parallel.FEAT_DTYPE)
-    ko = load_oracle() if ranks.rank == 0 else None
-    par = {}
-    fl_in = ctx.featbuf_download(T_IN, pairs * nf).reshape(pairs, nf) if pairs else None
-    if ranks.rank == 0 and pairs:
-        checks = []
-        for k in range(pairs) if ko else []:
-            same, dx = records_equal(out[k], oracle_track(ko, p, frames[k][0], frames[k][1], fl_in[k], threads=usable_cores()))
-            checks.append(("pair %d" % mine[k], same, dx))
-        par = parity_summary(checks, "tracked records of ALL %d pairs of rank 0's shard, last timed step" % pairs)
-    gathered_ok = None
-    if gather:
-        full = gather.result()
-        if ranks.rank == 0:
-            gathered_ok = bool(full.shape == (total, nf) and np.array_equal(full[:pairs], out))
-            if ko and ranks.world > 1 and par.get("parity_checked") is not None:
-                # what another rank contributed, against the oracle: the last pair of the batch (the last rank's shard), selected and
-                # tracked on the CPU from its seed
-                g0, g1 = synth.synth_pair(w, h, seed=total - 1)
-                ko.set_threads(usable_cores())
-                osel = ko.select_good_features(p, g0.astype(np.float32), nf)
-                ko.set_threads(1)
-                same, dx = records_equal(full[total - 1], oracle_track(ko, p, g0, g1, osel, threads=usable_cores()))
-                checks.append(("pair %d as gathered from rank %d" % (total - 1, ranks.world - 1), same, dx))
-                par = parity_summary(checks, "tracked records of all %d pairs of rank 0's shard and of the batch's last pair as gathered" % pairs)
-    roof = cpu = None
-    if ranks.rank == 0 and pairs:
-        nst = min(args.steps, 10)
-
-        def plain_steps():
-            for _ in range(nst):
-                ctx.build_pyramids_batch(slots)
-                ctx.track_batch_async(table, nf)
-
-        plain_steps()                                   # (the parity check left the GPU idle)
-        ctx.sync()
-        ctx.track_stats_reset()
-        paired = timed_pass(ctx, plain_steps, 1)
-        st = ctx.track_stats()
-        sane_iterations(st, nst * pairs * nf, p.nPyramidLevels, "cfg-4")
-        stamped = timed_pass(ctx, plain_steps, 2)
-        kt = kernel_table(stamped, paired, nst, {"track": track_bytes(p, st, nst * pairs * nf)})
-        # the line's step is the whole batch on all ranks: rank 0's kernels describe its own shard
-        ms_step = el / args.steps * 1e3
-        roof = roofline_of(kt, nst, ms_step)
-        rank0_bytes = roof["step_algorithmic_bytes"]
-        step_bytes = rank0_bytes * total / pairs
-        roof.update({"peak": HBM_PEAK_GBS * ranks.world, "step_algorithmic_bytes": step_bytes, "rank0_shard_algorithmic_bytes": rank0_bytes,
-                     "step_frac": step_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * ranks.world),
-                     "kernels_note": "rank 0's shard (%d of %d pairs), per-GPU peak %g GB/s" % (pairs, total, HBM_PEAK_GBS)})
-        for k in roof["kernels"].values():
-            k["frac"] = k["GBps"] / HBM_PEAK_GBS
-        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-        roof["kernel_peak"] = HBM_PEAK_GBS
-        if ko and not ranks.distributed and not args.no_cpu_baseline:
-            a0, a1 = frames[0][0].astype(np.float32), frames[0][1].astype(np.float32)
-            cpu = cpu_baseline_of(ko, lambda: ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), fl_in[0].copy()), nf,
-                                  "pyramids of both frames + track 2000 features of ONE 1280x720 pair of cfg-4 (seed %d)" % mine[0])
-    ctx.close()
-    if ranks.rank == 0:
-        ms_step = el / args.steps * 1e3
-        tracked = int(np.count_nonzero(out["val"] >= 0))
-        line = base_line(total * nf * args.steps / el, ranks.world, args.steps, args.warmup, ms_step, ms_step / total,
-                         "cfg-4: %d independent 1280x720 pairs per step (%d on rank 0), 2000 features each, 7x7, 3 levels "
-                         "(subsampling 4); per rank: batched pyramid build + one tracker launch + one RCCL gather of the "
-                         "[pairs x 2000] record table to rank 0" % (total, pairs), scaling="strong",
-                         extra_cfg={"pairs_per_step": total, "pairs_per_rank": [len(parallel.shard_range(total, ranks.world, r)) for r in range(ranks.world)],
-                                    "tracked_rank0": tracked,
-                                    "rccl_ranks": ranks.world if ranks.distributed else 0, "gathered_table_ok": gathered_ok,
-                                    "parallelism": "pairs sharded contiguously (shards differ by at most one pair); no data-path collective, one gather with a count per rank"})
-        line.update(par)
-        line["roofline"], line["cpu_baseline"] = roof, cpu
-        line["extra"] = {"region_ms_per_step": region_stats(regions, args.steps, el), "host_enqueue_ms_per_step": enq / args.steps * 1e3}
-        emit(json_fd, line)
-        if gathered_ok is False:
-            raise SystemExit("the gathered table differs from the shards")
-        fail_on_parity(par)
-
-
-# ==================================================================================== cfg-1 / 3 / 5
-def run_cfg1(args, json_fd):
-    """BASELINE cfg-1: img0.pgm -> img1.pgm, 100 features, default context (7x7, 2 levels / ss 4), max_residue 10."""
-    from tests.conftest import read_pgm
-    g = os.path.join(ROOT, "tests", "golden")
-    i0, i1 = read_pgm(os.path.join(g, "img0.pgm")), read_pgm(os.path.join(g, "img1.pgm"))
-    n = 100
-    tc = KLT_TrackingContext()
-    tc.max_residue = 10.0
-    p = params_from_tc(tc)
-    ctx = Context(0)
-    ctx.configure(tc)
-    ctx.upload(0, i0)
-    ctx.upload(1, i1)
-    ctx.build_pyramids_batch([0, 1], sync=True)
-    ctx.select(0, n, use_pyramid=True)                 # first call allocates the selection scratch
-    t = time.perf_counter()
-    fl, _ = ctx.select(0, n, use_pyramid=True)
-    ms_select = (time.perf_counter() - t) * 1e3
-    ctx.featbuf_upload(0, fl)
-
-    def step():
-        ctx.build_pyramids_batch([0, 1])
-        ctx.track_async(0, 1, 0, 1, n)
-
-    def region():
-        for _ in range(args.steps):
-            step()
-
-    for _ in range(max(1, args.warmup)):
-        step()
-    el, regions, enq = timed_regions(OneGpu([ctx]), region, args.repeats)
-    out = ctx.featbuf_download(1, n)
-    ko = load_oracle()
-    checks = []
-    if ko:
-        ofl = ko.select_good_features(p, i0.astype(np.float32), n)
-        same_sel = bool(np.array_equal(fl["x"], ofl["x"]) and np.array_equal(fl["y"], ofl["y"]) and np.array_equal(fl["val"], ofl["val"]))
-        checks.append(("selection of 100 on img0", same_sel, 0.0))
-        same, dx = records_equal(out, oracle_track(ko, p, i0, i1, fl))
-        checks.append(("100 features tracked img0 -> img1", same, dx))
-    par = parity_summary(checks, "selected list and the tracked records of the last timed step")
-    nst = min(args.steps, 50)
-
-    def plain():
-        for _ in range(nst):
-            step()
-
-    plain()
-    ctx.sync()
-    ctx.track_stats_reset()
-    paired = timed_pass(ctx, plain, 1)
-    st = ctx.track_stats()
-    sane_iterations(st, nst * int((fl["val"] >= 0).sum()), p.nPyramidLevels, "cfg-1")
-    stamped = timed_pass(ctx, plain, 2)
-    ms_step = el / args.steps * 1e3
-    roof = roofline_of(kernel_table(stamped, paired, nst, {"track": track_bytes(p, st, nst * n)}), nst, ms_step)
-    cpu = None
-    if ko and not args.no_cpu_baseline:
-        a0, a1 = i0.astype(np.float32), i1.astype(np.float32)
-        cpu = cpu_baseline_of(ko, lambda: ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), fl.copy()), n,
-                              "pyramids of img0 and img1 + track 100 features (cfg-1)", budget_s=5.0)
-    ctx.close()
-    line = base_line(n * args.steps / el, 1, args.steps, args.warmup, ms_step, ms_step,
-                     "cfg-1: img0.pgm -> img1.pgm (320x240), 100 features, 7x7, 2 levels (ss 4), max_residue 10; per step: pyramids of "
-                     "both frames + track",
-                     extra_cfg={"tracked": int((out["val"] >= 0).sum()), "ms_select_100": ms_select})
-    line.update(par)
-    line["roofline"], line["cpu_baseline"] = roof, cpu
-    line["extra"] = {"region_ms_per_step": region_stats(regions, args.steps, el), "host_enqueue_ms_per_step": enq / args.steps * 1e3}
-    emit(json_fd, line)
-    fail_on_parity(par)
-
-
-def cfg3_context():
-    tc = KLT_TrackingContext()
-    tc.window_width = tc.window_height = 15
-    tc.nPyramidLevels, tc.subsampling = 4, 2
-    tc.KLTUpdateTCBorder()
-    tc.affineConsistencyCheck = 2
-    return tc
-
-
-def cfg3_frames(count=4):
-    base = synth.synth_base(WIDTH, HEIGHT, 1)
-    return [synth.synth_frame(WIDTH, HEIGHT, 1, k, shift=(1.1, -0.7), base=base) for k in range(count)]
-
-
-def affine_bytes(ap, recs, live_in):
-    """algorithmic bytes of one affine-check launch: per checked feature the three (w+2)(h+2) templates once, the frame-2 footprint
-    of image / gradx / grady per Newton iteration (klt_affine_rec.pad holds the count), the image footprint of the residue pass, and
-    the records (16 B in, 16 out, 32 state in / out)"""
-    w, h = ap.window_width, ap.window_height
-    it = recs["pad"][live_in].astype(np.int64)
-    checked = int((it > 0).sum())
-    return checked * (12.0 * (w + 2) * (h + 2) + 4.0 * (w + 1) * (h + 1) + 96.0) + 12.0 * (w + 1) * (h + 1) * float(it.sum()), checked, int(it.sum())
-
-
-def run_cfg3(args, json_fd):
-    """BASELINE cfg-3: 1920x1080, 15x15 window, 4 levels / ss 2 (border 108), 5000 features, affine consistency check (mode 2,
-    15x15 affine window) -- a four-frame sequence = three KLTTrackFeatures calls; the first only stores the templates, the steps
-    time the second and the third (state restored to what the first call left before every repetition)."""
-    tc = cfg3_context()
-    p, ap = params_from_tc(tc), affine_params_from_tc(tc)
-    n = NFEAT
-    ctx = Context(0)
-    ctx.configure(tc)
-    frames = cfg3_frames(4)
-    for k, f in enumerate(frames):
-        ctx.upload(k, f)
-    ctx.build_pyramids_batch([0, 1, 2, 3], sync=True)
-    fl, placed = ctx.select(0, n, use_pyramid=True)
-    ST, SNAP = 0, 1
-    ctx.affine_alloc(ST, n)
-    ctx.featbuf_upload(0, fl)
-    ctx.track_affine_async(0, 1, 0, 1, n, ST)            # call 1: stores the templates
-    ctx.affine_copy(SNAP, ST, n)                          # the state every repetition starts from (records; templates never change while valid)
-    ctx.sync()
-    list1 = ctx.featbuf_download(1, n)
-    live1 = int((list1["val"] >= 0).sum())
-
-    def step(k):                                          # call k + 2: frame k+1 -> k+2 with the affine check active
-        ctx.build_pyramids_batch([k + 1, k + 2])
-        ctx.track_affine_async(k + 1, k + 2, k + 1, k + 2, n, ST)
-
-    def rep():
-        ctx.affine_copy(ST, SNAP, n)
-        step(0)
-        step(1)
-
-    def region():
-        for _ in range(max(1, args.steps // 2)):
-            rep()
-
-    nsteps = 2 * max(1, args.steps // 2)
-    for _ in range(max(1, args.warmup // 2)):
-        rep()
-    el, regions, enq = timed_regions(OneGpu([ctx]), region, args.repeats)
-    lists = [ctx.featbuf_download(k, n) for k in (2, 3)]
-    recs_end = ctx.affine_download(ST, n)
-    ko = load_oracle()
-    checks = []
-    if ko:
-        ko.set_threads(usable_cores())
-        pyr = [ko.Pyramids(p, f.astype(np.float32)) for f in frames]
-        ofl = ko.select_good_features(p, frames[0].astype(np.float32), n)
-        checks.append(("selection of 5000", bool(np.array_equal(ofl["x"], fl["x"]) and np.array_equal(ofl["y"], fl["y"]) and np.array_equal(ofl["val"], fl["val"])), 0.0))
-        ost = ko.AffineState(ap, n)
-        for call in range(3):
-            ko.track_features_affine(p, pyr[call], pyr[call + 1], ofl, ost)
-            got = list1 if call == 0 else lists[call - 1]
-            same, dx = records_equal(got, ofl)
-            checks.append(("records after call %d" % (call + 1), same, dx))
-        ko.set_threads(1)
-        same_state = all(np.array_equal(recs_end[f], ost.rec[f]) for f in ("valid", "aff_x", "aff_y", "Axx", "Ayx", "Axy", "Ayy"))
-        checks.append(("affine state (valid, aff_x, aff_y, A) after call 3", bool(same_state), 0.0))
-    par = parity_summary(checks, "selection, the records after each of the three calls and the per-feature affine state at the end (parity "
-                         "of the affine check is UNPINNED: the reference does not define it; the oracle restates upstream KLT 1.3.4)")
-    # roofline pass: the two timed calls once more, each launch timed; tracker / affine bytes from the device counters
-    ctx.affine_copy(ST, SNAP, n)
-    rep()
-    ctx.sync()
-
-    def counted(mode):
-        res = {}
-        abytes = checked = its = 0
-        for k in (0, 1):
-            if k == 0:
-                ctx.affine_copy(ST, SNAP, n)
-            ctx.sync()
-            before = ctx.featbuf_download(k + 1, n)
-            r = timed_pass(ctx, lambda: step(k), mode)
-            b, c, i = affine_bytes(ap, ctx.affine_download(ST, n), before["val"] >= 0)
-            abytes, checked, its = abytes + b, checked + c, its + i
-            for name, v in r.items():
-                e = res.setdefault(name, {"name": name, "launches": 0, "total_ms": 0.0, "bytes": 0.0})
-                for f in ("launches", "total_ms", "bytes"):
-                    e[f] += v[f]
-        return res, abytes, checked, its
-
-    ctx.track_stats_reset()
-    paired, abytes, checked, its = counted(1)
-    st = ctx.track_stats()
-    sane_iterations(st, st["features"], p.nPyramidLevels, "cfg-3")
-    stamped, _, _, _ = counted(2)
-    ms_step = el / nsteps * 1e3
-    kt = kernel_table(stamped, paired, 2, {"track": track_bytes(p, st, 2 * n), "affine_check": abytes})
-    roof = roofline_of(kt, 2, ms_step, extra={"affine_checked_features_per_step": checked / 2.0, "affine_iterations_per_checked_feature": its / max(1, checked),
-                                              "newton_iterations_per_level": [v / 2.0 for v in st["iterations"][:p.nPyramidLevels]]})
-    # what bit-identity costs the 15x15 tracker: the translation tracker alone on frames 0 -> 1 with the selected list
-    ctx.featbuf_upload(50, fl)
-    tree = tree_sums_probe(ctx, lambda: ctx.track_async(0, 1, 50, 51, n), lambda: ctx.featbuf_download(51, n),
-                           kt["track"]["algorithmic_bytes_per_launch"], p.window_width)
-    cpu = None
-    if ko and not args.no_cpu_baseline:
-        snap_rec, snap_fl = None, None
-        ost = ko.AffineState(ap, n)
-        ofl = fl.copy()
-        ko.track_features_affine(p, pyr[0], pyr[1], ofl, ost)
-        snap_rec, snap_fl = ost.rec.copy(), ofl.copy()
-        a1, a2 = frames[1].astype(np.float32), frames[2].astype(np.float32)
-
-        def one_step():
-            ost.rec[:] = snap_rec
-            ko.track_features_affine(p, ko.Pyramids(p, a1), ko.Pyramids(p, a2), snap_fl.copy(), ost)
-
-        cpu = cpu_baseline_of(ko, one_step, live1, "pyramids of both frames + track + affine check of the second call of cfg-3 (%d live features)" % live1)
-    ctx.close()
-    line = base_line(live1 * nsteps / el, 1, nsteps, args.warmup, ms_step, ms_step,
-                     "cfg-3: 1920x1080 four-frame sequence, %d features placed (%d live after call 1), 15x15 window, 4 levels (ss 2), affine "
-                     "consistency check mode 2; a step = one KLTTrackFeatures call with the check active (calls 2 and 3 alternate): "
-                     "pyramids of both frames + translation tracker + affine check" % (placed, live1),
-                     extra_cfg={"tracked_after_call_2": int((lists[0]["val"] >= 0).sum()), "tracked_after_call_3": int((lists[1]["val"] >= 0).sum())})
-    line.update(par)
-    line["roofline"], line["cpu_baseline"] = roof, cpu
-    line["extra"] = {"region_ms_per_step": region_stats(regions, nsteps, el), "host_enqueue_ms_per_step": enq / nsteps * 1e3,
-                     "tracker_tree_sums": tree}
-    emit(json_fd, line)
-    fail_on_parity(par)
-
-
-def run_cfg5(args, json_fd):
-    """BASELINE cfg-5 (single GPU): 3840x2160 sequence, 20000 features, sequential mode, lost features replaced after every
-    frame.  Per step (= frame): upload is excluded (frames resident), pyramid of the new frame, track, REPLACING_SOME selection."""
-    ranks = Ranks(args)
-    if ranks.distributed:
-        return run_cfg5_blocks(args, json_fd, ranks)
-    w, h, n = 3840, 2160, 20000
-    nframes = max(2, args.frames)                # BASELINE cfg-5: a 512-frame sequence; every frame resident in its own slot (115 MB of
-    tc = cfg2_context()                          # raw frame + pyramid planes each: 59 GB of the 288 GB for 512 frames)
-    tc.max_residue = 10.0
-    p = params_from_tc(tc)
-    ctx = Context(0)
-    ctx.configure(tc)
-    phases = synth.sequence_phases(w, h, 4, workers=usable_cores(10))
-    # the clip is resident in HBM as u8 (4.2 GB for 512 frames); a frame's slot ADOPTS its buffer (klt_slot_adopt_u8: read in place, no
-    # copy), the slots are a ring of three as in any sequence -- one slot per frame (59 GB of planes, each written once per pass) reads
-    # 0.336 ms per frame instead of 0.26: fresh pages for 115 MB of planes every frame
-    NPX = w * h
-    store = ctx.device_alloc(nframes * NPX)
-    frames = []                                  # only the first frames stay on the host (parity check, CPU baseline)
-    for k, f in enumerate(synth.periodic_sequence(w, h, 4, nframes, phases=phases)):
-        ctx.device_write(store + k * NPX, f)
-        if k < 8:
-            frames.append(f)
-    RING = (10, 11, 12)
-
-    def slot(k):
-        return RING[k % 3]
-
-    def build(k, prepare_scores=False):
-        ctx.adopt_u8(slot(k), store + k * NPX, w, h)
-        ctx.build_pyramids(slot(k), sync=False)
-        if prepare_scores:
-            ctx.select_prepare(slot(k))
-
-    build(0)
-    fl, placed = ctx.select(slot(0), n, use_pyramid=True)
-    ctx.featbuf_upload(0, fl)
-    ctx.sync()
-
-    # the pyramids of frame k+1 are built on the context's build stream while frame k is tracked and its lost features are replaced
-    # (KLT_OPT_BUILD_STREAM; same results -- every frame has its own slot here)
-    prefetch = os.environ.get("KLT_BENCH_NO_PREFETCH") != "1"
-    prepare = prefetch and os.environ.get("KLT_BENCH_NO_PREPARE") != "1"
-    if prefetch:
-        ctx.set_option(15, 1)
-
-    redone = [0]
-
-    def run_sequence(look=None):
-        """one pass over the sequence; `look(k)` (instrumented passes) is called after frame k's replacement, synchronised"""
-        def track(k):                                     # frame k - 1 -> k; the lists alternate between two buffers
-            ctx.track_async(slot(k - 1), slot(k), (k - 1) % 2, k % 2, n)
-
-        build(0)                                          # (a pass starts from frame 0 again: its slot holds a later frame by now)
-        if prefetch:
-            build(1, prepare)
-            track(1)
-        for k in range(1, nframes):
-            if not prefetch:
-                build(k)
-                track(k)
-            ctx.select_begin(slot(k), 2, True, k % 2, n)      # KLTReplaceLostFeatures on the resident level-0 images, up to the host's look
-            if prefetch and k + 1 < nframes:
-                build(k + 1, prepare)                     # pyramids + SAT + eigenvalues of the next frame, on the build stream
-                # the NEXT frame's tracker goes out before the host looks at this frame's selection: it only reads the list, and the GPU
-                # has it queued while the host turns around (44 us of an idle main stream per frame in the round-3 kernel trace)
-                track(k + 1)
-            if ctx.select_finish() and prefetch and k + 1 < nframes:
-                redone[0] += 1
-                track(k + 1)                              # (rare) the selection rewrote the list after the tracker had read it
-            if look:
-                ctx.sync()
-                look(k)
-        ctx.sync()
-
-    def region():
-        for _ in range(max(1, args.steps // (nframes - 1))):
-            ctx.featbuf_upload(0, fl)
-            run_sequence()
-
-    frames_per_region = max(1, args.steps // (nframes - 1)) * (nframes - 1)
-    ctx.featbuf_upload(0, fl)
-    run_sequence()
-    el, regions, enq = timed_regions(OneGpu([ctx]), region, max(5, min(args.repeats, 10)))
-    out = ctx.featbuf_download((nframes - 1) % 2, n)
-
-    # instrumented pass 1: the list after every frame (parity) and how long the replacement alone takes
-    lists = {}
-    ctx.featbuf_upload(0, fl)
-    run_sequence(look=lambda k: lists.__setitem__(k, ctx.featbuf_download(k % 2, n)))
-    same_end = bool(np.array_equal(lists[nframes - 1], out))
-    t_sel, lost = 0.0, []
-    ctx.featbuf_upload(0, fl)
-    build(0)
-    for k in range(1, nframes):                              # (plain loop: tracker, look at the losses, replacement timed on its own)
-        build(k)
-        ctx.track_async(slot(k - 1), slot(k), (k - 1) % 2, k % 2, n)
-        lost.append(int((ctx.featbuf_download(k % 2, n)["val"] < 0).sum()))
-        t = time.perf_counter()
-        ctx.select_async(slot(k), 2, True, k % 2, n)
-        ctx.sync()
-        t_sel += time.perf_counter() - t
-    ko = load_oracle()
-    checks = [("the timed passes end with the list of the instrumented pass", same_end, 0.0)]
-    PAR_FRAMES = 3
-    if ko:
-        ko.set_threads(usable_cores())
-        ofl = ko.select_good_features(p, frames[0].astype(np.float32), n)
-        checks.append(("selection of 20000 on frame 0", bool(np.array_equal(ofl["x"], fl["x"]) and np.array_equal(ofl["y"], fl["y"]) and np.array_equal(ofl["val"], fl["val"])), 0.0))
-        P_prev = ko.Pyramids(p, frames[0].astype(np.float32))
-        for k in range(1, PAR_FRAMES + 1):
-            P_cur = ko.Pyramids(p, frames[k].astype(np.float32))
-            ko.track_features(p, P_prev, P_cur, ofl)
-            ofl = ko.select_good_features(p, frames[k].astype(np.float32), n, mode=2, fl=ofl)
-            same, dx = records_equal(lists[k], ofl)
-            checks.append(("list after tracking into frame %d and replacing the lost features" % k, same, dx))
-            P_prev = P_cur
-        ko.set_threads(1)
-    par = parity_summary(checks, "initial selection and the whole feature list (tracked and replaced records) after each of the first %d frames; "
-                         "the wrapper KLTReplaceLostFeatures is absent from the reference (pinned at the level of _enforceMinimumDistance)" % PAR_FRAMES)
-
-    # instrumented pass 2: every launch timed (one stream order per stream; the build stream's launches carry their own timestamps)
-    def seq():
-        ctx.featbuf_upload(0, fl)
-        run_sequence()
-
-    seq()
-    ctx.track_stats_reset()
-    paired = timed_pass(ctx, seq, 1)
-    st = ctx.track_stats()
-    sane_iterations(st, st["features"], p.nPyramidLevels, "cfg-5")
-    stamped = timed_pass(ctx, seq, 2)
-    ms_step = el / frames_per_region * 1e3
-    kt = kernel_table(stamped, paired, nframes - 1, {"track": track_bytes(p, st, (nframes - 1) * n)})
-    roof = roofline_of(kt, nframes - 1, ms_step, extra={"newton_iterations_per_level": [v / (nframes - 1.0) for v in st["iterations"][:p.nPyramidLevels]]})
-    cpu = None
-    if ko and not args.no_cpu_baseline:
-        a0, a1 = frames[0].astype(np.float32), frames[1].astype(np.float32)
-        P0 = ko.Pyramids(p, a0)
-
-        def one_frame():
-            o = fl.copy()
-            ko.track_features(p, P0, ko.Pyramids(p, a1), o)
-            ko.select_good_features(p, a1, n, mode=2, fl=o)
-
-        cpu = cpu_baseline_of(ko, one_frame, n, "pyramid of the new 3840x2160 frame + track 20000 features + replacement selection (one frame of cfg-5)", budget_s=8.0)
-    ctx.close()
-    line = base_line(n * frames_per_region / el, 1, frames_per_region, 0, ms_step, ms_step,
-                     "cfg-5 (one GPU): ONE 3840x2160 sequence of %d frames (the clip resident in HBM as u8; a ring of three frame slots adopts the frames in place), 20000 features, 7x7, 3 levels (ss 4), sequential mode, lost " % nframes +
-                     "features replaced after every frame; per step (frame): pyramid of the new frame + track + replacement"
-                     + ("; the next frame's pyramids are built on a second stream meanwhile" if prefetch else "")
-                     + (", and so are its summed-area tables and eigenvalues (klt_select_prepare_async)" if prepare else ""),
-                     extra_cfg={"frames": nframes, "live_at_end": int((out["val"] >= 0).sum()), "ms_replace_per_frame": t_sel / (nframes - 1) * 1e3,
-                                "lost_per_frame": {"first": lost[:8], "min": min(lost), "median": float(statistics.median(lost)), "max": max(lost)},
-                                "build_stream": bool(prefetch), "scores_prepared": bool(prepare),
-                                "tracker_enqueued_ahead": bool(prefetch), "trackers_repeated": redone[0]})
-    line.update(par)
-    line["roofline"], line["cpu_baseline"] = roof, cpu
-    line["extra"] = {"region_ms_per_step": region_stats(regions, frames_per_region, el), "host_enqueue_ms_per_step": enq / frames_per_region * 1e3}
-    emit(json_fd, line)
-    fail_on_parity(par)
-
-
-def run_cfg5_blocks(args, json_fd, ranks):
-    """cfg-5 on N GPUs: ONE 3840x2160 sequence cut into blocks of 7 tracking steps, block r on rank r.  The tracker and
-    the replacement pass are a serial chain, so the feature list travels from rank to rank as a baton (klt_sendrecv_featbuf_async,
-    320 KB); what depends on the pixels only -- the pyramids and the selection scores of the block's frames -- is enqueued on the
-    owner's build stream at once and is ready (ranks > 0) long before the baton arrives.  Per-GPU work is fixed: weak scaling; the
-    serial chain bounds it.  With one rank (KLT_FORCE_DIST=1) this is the single-GPU sequence with all pixel
-    work enqueued ahead, and the baton a device copy."""
-    w, h, n, B = 3840, 2160, 20000, 7
-    rank, world = ranks.rank, ranks.world
-    tc = cfg2_context()
-    tc.max_residue = 10.0
-    ctx = Context(ranks.local_rank)
-    ctx.configure(tc)
-    base = synth.synth_base(w, h, 4)
-    first = rank * B                                       # global index of the block's frame 0 (= the previous block's last frame)
-    for j in range(B + 1):
-        ctx.upload(10 + j, synth.synth_frame(w, h, 4, first + j, base=base))
-    fl = None
-    if rank == 0:
-        ctx.build_pyramids(10)
-        fl, placed = ctx.select(10, n, use_pyramid=True)
-    ctx.set_option(15, 1)                                  # KLT_OPT_BUILD_STREAM
-    ctx.set_option(16, B + 1)                              # KLT_OPT_SCORE_SETS: one per frame of the block
-    ranks.attach([ctx])
-    FB_A, FB_B, FB_BATON, FB_ALL = 0, 1, 2, 3
-
-    def block():
-        ctx.comm_fence_featbuf(FB_B if B % 2 else FB_A)    # the baton sent at the end of the previous block has left its buffer
-        for j in range(B + 1):                             # the block's pixel work: build stream, nothing to wait for
-            ctx.build_pyramids(10 + j, sync=False)
-            if j:
-                ctx.select_prepare(10 + j)
-        if rank == 0:
-            ctx.featbuf_upload(FB_A, fl)
-        else:
-            ctx.sendrecv_featbuf(-1, -1, FB_A, rank - 1, n)             # the baton: the list after the previous block's last frame
-        for j in range(1, B + 1):
-            ctx.track_async(10 + j - 1, 10 + j, (FB_A, FB_B)[(j - 1) % 2], (FB_A, FB_B)[j % 2], n)
-            ctx.select_async(10 + j, 2, True, (FB_A, FB_B)[j % 2], n)        # (nothing to enqueue in between: the pixel work is ahead)
-        last = (FB_A, FB_B)[B % 2]
-        if world > 1 and rank + 1 < world:
-            ctx.sendrecv_featbuf(last, rank + 1, -1, -1, n)
-        elif world == 1:
-            ctx.sendrecv_featbuf(last, 0, FB_BATON, 0, n)                # one rank: the baton path as a device copy
-        return last
-
-    last = block()                                         # warm-up (allocations, RCCL's lazy connections)
-    ranks.fence()
-    # a timed region is ONE pass of the sequence over the ranks (a second pass inside the region would let rank 0 start it while the
-    # others still work on the first: N pipelined replicas, not one sequence)
-    reps = 1
-    el, regions, enq = timed_regions(ranks, block, max(5, min(args.repeats, 15)))
-    # the list after the last frame of every block, gathered on rank 0 (rank order = frame order)
-    ctx.gather_featbuf_async(last, FB_ALL, n, 0)
-    ctx.comm_wait()
-    ctx.sync()
-    if rank == 0:
-        table = ctx.featbuf_download(FB_ALL, n * world).reshape(world, n)
-        baton_ok = None
-        if world == 1:
-            baton_ok = bool(np.array_equal(ctx.featbuf_download(FB_BATON, n), table[0]))
-        frames_done = reps * B * world
-        emit(json_fd, base_line(n * frames_done / el, world, frames_done, 0, el / frames_done * 1e3, el / (reps * B) * 1e3,
-                                "cfg-5 on %d GPU(s): ONE 3840x2160 sequence in blocks of %d frames per GPU, 20000 features, sequential "
-                                "mode, lost features replaced after every frame; the feature list is the baton between the blocks (RCCL "
-                                "send / receive), the blocks' pyramids and selection scores are prepared on the owners' build streams" % (world, B),
-                                extra_cfg={"rccl_ranks": world, "live_after_each_block": [int((t["val"] >= 0).sum()) for t in table],
-                                           "list_sha16_after_each_block": [list_digest(t) for t in table],
-                                           "ms_per_frame_of_the_chain": el / (reps * B * world) * 1e3, "baton_copy_ok": baton_ok,
-                                           "region_ms": {"median": el * 1e3, "min": min(regions) * 1e3, "max": max(regions) * 1e3}}))
-    ctx.close()
-
-
-# ================================================================================= launcher dry run
-def dry_run(args, json_fd):
-    """KLT_BENCH_DRYRUN=1: launcher + rendezvous + shard arithmetic without a GPU (the collective is stubbed by files).
-    Exercised by the CPU tests with 2 processes."""
-    rank, local_rank, world = parallel.world_from_env()
-    path = parallel.rendezvous_file()
-    ids = parallel.exchange_ids(rank, world, 3, lambda: os.urandom(parallel.KLT_COMM_ID_BYTES), path=path, timeout=60)
-    digest = hashlib.sha256(b"".join(ids)).hexdigest()
-    mine = list(parallel.shard_range(args.pairs, world, rank))
-    if os.environ.get("KLT_DRYRUN_FAIL_RANK") == str(rank):
-        raise SystemExit(3)
-    with open("%s.rank%d" % (path, rank), "w") as f:
-        json.dump({"digest": digest, "pairs": mine, "local_rank": local_rank}, f)
-    if rank != 0:
-        return
-    seen = []
-    t0 = time.monotonic()
-    for r in range(world):
-        while True:
-            try:
-                seen.append(json.load(open("%s.rank%d" % (path, r))))
-                break
-            except (OSError, ValueError):
-                if time.monotonic() - t0 > 60:
-                    raise SystemExit("rank %d never reported" % r)
-                time.sleep(0.01)
-    emit(json_fd, {"dryrun": True, "n_gpus": world, "ids_agree": all(s["digest"] == digest for s in seen),
-                   "pairs_covered": sorted(i for s in seen for i in s["pairs"]) == list(range(args.pairs)),
-                   "gatherv_counts": [len(s["pairs"]) for s in seen],
-                   "local_ranks": [s["local_rank"] for s in seen], "spawned": os.environ.get("KLT_SPAWNED") == "1"})
-
-
-# ================================================================================= cfg-2 (headline)
-T_OUT0, T_OUT1, T_GATH0, T_GATH1, FB_IN0, V_OUT0, FB_MISC = 10, 11, 20, 21, 1000, 3000, 90
-
-
-def run_cfg2(args, json_fd):
-    ranks = Ranks(args)
-    rank, world, distributed = ranks.rank, ranks.world, ranks.distributed
-    tc = cfg2_context()
-    p = params_from_tc(tc)
-    nctx, B, NP = max(1, args.inflight), max(1, args.batch), args.resident_pairs
-    if NP < nctx * B or NP % (nctx * B):
-        raise SystemExit("--resident-pairs must be a positive multiple of --inflight x --batch")
-    PL = NP // nctx                              # pairs per context
-    NG = PL // B                                 # groups (launch sets) per context and step
-    seeds = [rank * NP + i + 1 for i in range(NP)]
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=max(1, usable_cores(16) // max(1, min(world, 8)))) as ex:
-        frames = list(ex.map(lambda s: synth.synth_pair(WIDTH, HEIGHT, seed=s), seeds))
-
-    # pair i: group i // B of the step; groups go round-robin to the contexts.  Context c, its j-th group, pair b of the group:
-    # local pair index lp = j B + b, frame slots 2 lp and 2 lp + 1, input list FB_IN0 + lp, output row lp of the step's table
-    def pair_index(c, lp):
-        j, b = divmod(lp, B)
-        return (j * nctx + c) * B + b
-
-    ctxs, lists = [], {}
-    for c in range(nctx):
-        cx = Context(ranks.local_rank)
-        cx.set_params(p)
-        for lp in range(PL):
-            f0, f1 = frames[pair_index(c, lp)]
-            cx.upload(2 * lp, f0)
-            cx.upload(2 * lp + 1, f1)
-        for t in (T_OUT0, T_OUT1):
-            cx.featbuf_alloc(t, PL * NFEAT)
-        for t in (0, 1):
-            for lp in range(PL):
-                cx.featbuf_view(V_OUT0 + t * PL + lp, (T_OUT0, T_OUT1)[t], lp * NFEAT, NFEAT)
-        for j in range(PL // B):                 # (launches of the same shape as the timed ones: a profiler's per-kernel averages stay clean)
-            cx.build_pyramids_batch([2 * (j * B + b) + f for b in range(B) for f in (0, 1)])
-        for lp in range(PL):
-            fl_c, placed = cx.select(2 * lp, NFEAT, use_pyramid=True)
-            assert placed == NFEAT, "only %d of %d features could be placed" % (placed, NFEAT)
-            lists[pair_index(c, lp)] = fl_c
-            cx.featbuf_upload(FB_IN0 + lp, fl_c)
-        ctxs.append(cx)
-    ctx = ctxs[0]
-    ranks.attach(ctxs)
-
-    def group_slots(j, nb=B):
-        return [2 * (j * B + b) + f for b in range(nb) for f in (0, 1)]
-
-    def group_build(cx, j):
-        cx.build_pyramids_batch(group_slots(j))                  # all frames of the group share every launch
-
-    def group_track(cx, j, t):
-        if B == 1:
-            cx.track_async(2 * j, 2 * j + 1, FB_IN0 + j, V_OUT0 + t * PL + j, NFEAT)
-        else:
-            cx.track_batch_async([(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + t * PL + lp) for lp in range(j * B, j * B + B)], NFEAT)
-
-    step_no = [0]
-
-    def one_step(collect=True):
-        """one pass over the resident pairs (collect = False: without the collectives -- the untimed prewarm runs for a TIME, i.e. a
-        different number of steps on every rank, and a collective must be issued by all ranks or by none).  The groups go out in rounds of one group per context, the builds of a round before its
-        tracker launches: every stream has work a few microseconds after the step starts (enqueueing a group takes the host ~25 us);
-        the order inside each stream, and the work, are the same either way.  N > 1: the step's record table of every context is
-        all-gathered with ONE collective behind its last tracker launch; two tables alternate, a table is reused once its collective
-        of two steps ago has read it."""
-        t = step_no[0] % 2
-        step_no[0] += 1
-        gather = distributed and collect
-        if distributed:
-            for cx in ctxs:
-                cx.comm_fence_featbuf((T_OUT0, T_OUT1)[t])
-        for j in range(NG):
-            for cx in ctxs:
-                group_build(cx, j)
-            for cx in ctxs:
-                group_track(cx, j, t)
-        if gather:
-            for cx in ctxs:
-                cx.allgather_featbuf_async((T_OUT0, T_OUT1)[t], (T_GATH0, T_GATH1)[t], PL * NFEAT)
-        return t
-
-    # bring the GPU to its steady state first (the same work as the steps)
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        one_step(collect=False)
-        for cx in ctxs:
-            cx.sync()
-    for _ in range(args.warmup):
-        one_step()
-    if os.environ.get("KLT_BENCH_DIE_RANK") == str(rank):      # test hook: a rank that vanishes with collectives in flight
-        os._exit(7)
-
-    def region():
-        for _ in range(args.steps):
-            one_step()
-
-    elapsed, regions, enqueue_s = timed_regions(ranks, region, args.repeats)
-    t_last = (step_no[0] - 1) % 2
-
-    # correctness of what was timed: the last step's records of EVERY resident pair (and, N > 1, what the gather delivered of them)
-    outs = {}
-    for c, cx in enumerate(ctxs):
-        tab = cx.featbuf_download((T_OUT0, T_OUT1)[t_last], PL * NFEAT).reshape(PL, NFEAT)
-        for lp in range(PL):
-            outs[pair_index(c, lp)] = tab[lp]
-        if distributed:                 # what this rank received from itself equals what it produced
-            got = cx.featbuf_download((T_GATH0, T_GATH1)[t_last], world * PL * NFEAT).reshape(world, PL, NFEAT)
-            assert np.array_equal(got[rank], tab), "gathered records differ"
-    out, fl = outs[0], lists[0]
-    tracked = int(np.count_nonzero(out["val"] >= 0))
-    live = out["val"] == 0
-    shift = (float(np.median(out["x"][live] - fl["x"][live])), float(np.median(out["y"][live] - fl["y"][live])))
-    ko = load_oracle() if rank == 0 else None
-    parity = {}
-    if rank == 0:
-        checks = []
-        if ko:
-            nthreads = usable_cores()
-            for i in range(NP):
-                same, dx = records_equal(outs[i], oracle_track(ko, p, frames[i][0], frames[i][1], lists[i], threads=nthreads))
-                checks.append(("pair %d (seed %d)" % (i, seeds[i]), same, dx))
-        what = "tracked records of all %d resident pairs, last timed step" % NP
-        if ko and world > 1:
-            # ... and what another rank contributed: pair 0 of the last rank (context 0, row 0 of its table) as this rank received it,
-            # against the oracle's selection + tracking of that pair from its seed
-            g0, g1 = synth.synth_pair(WIDTH, HEIGHT, seed=(world - 1) * NP + 1)
-            ko.set_threads(usable_cores())
-            osel = ko.select_good_features(p, g0.astype(np.float32), NFEAT)
-            ko.set_threads(1)
-            got0 = ctxs[0].featbuf_download((T_GATH0, T_GATH1)[t_last], world * PL * NFEAT).reshape(world, PL, NFEAT)
-            same, dx = records_equal(got0[world - 1][0], oracle_track(ko, p, g0, g1, osel, threads=usable_cores()))
-            checks.append(("pair 0 of rank %d as gathered" % (world - 1), same, dx))
-            what += " + pair 0 of the last rank as received through the all-gather"
-        parity = parity_summary(checks, what)
-
-    # second pass: per-kernel timing + iteration counters for the roofline, on context 0 over its own pairs
-    roofline = None
-    ms_per_pair = elapsed / (args.steps * NP) * 1e3
-    if rank == 0:
-        passes = max(1, min(args.steps, 4))
-
-        def ctx0_passes(n=passes):
-            for _ in range(n):
-                for j in range(NG):
-                    group_build(ctx, j)
-                    group_track(ctx, j, 0)
-
-        def warm():
-            """at the clocks the timed regions ran at: the parity check and the downloads above left the GPU idle"""
-            t_warm = time.perf_counter()
-            while (time.perf_counter() - t_warm) * 1e3 < min(args.prewarm_ms, 30.0):
-                ctx0_passes(1)
-                ctx.sync()
-
-        warm()
-        ctx.track_stats_reset()                        # AFTER the warm-up: the counters cover exactly the launches they are divided by
-        paired = timed_pass(ctx, ctx0_passes, 1)
-        st = ctx.track_stats()
-        npairs_roof = passes * PL
-        sane_iterations(st, npairs_roof * NFEAT, p.nPyramidLevels, "cfg-2")
-        warm()
-        stamped = timed_pass(ctx, ctx0_passes, 2)
-        kt = kernel_table(stamped, paired, npairs_roof, {"track": track_bytes(p, st, npairs_roof * NFEAT)})
-        st_pair = {k: ([x / npairs_roof for x in v] if isinstance(v, list) else v / npairs_roof) for k, v in st.items()}
-        pyr_b, trk_b = algorithmic_bytes(p, WIDTH, HEIGHT, st_pair, NFEAT)
-        dom = "smooth_grad_l0"
-        # PMC-derived figures are NOT measured by this run: committed results of the builder's rocprofv3 --pmc passes, with their
-        # provenance, dropped when the kernel source changed since (committed_counters)
-        traffic, traffic_source = committed_counters("traffic.json", dom, B)
-        # the same kernel against the roof that actually bounds it: VALU issue.  Wavefront-instructions per launch come from a
-        # rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/sq_counters.json, tools/pmc_sq.py); 4.5 clocks per instruction and SIMD
-        # is what the FP64-rate instruction mix of the convolutions sustains on gfx950 (tools/mb/valu_rate.hip, fp64_mix.hip).
-        issue = None
-        sq, sq_source = committed_counters("sq_counters.json", dom, B)
-        if sq and sq.get("SQ_INSTS_VALU"):
-            simds, cpi, mhz = 256 * 4, 4.5, 2400.0
-            ideal_us = sq["SQ_INSTS_VALU"] / simds * cpi / mhz
-            issue = {"valu_wavefront_instructions_per_launch": sq["SQ_INSTS_VALU"], "simds": simds, "clocks_per_instruction": cpi,
-                     "clock_mhz": mhz, "ideal_us": ideal_us, "frac": ideal_us / kt[dom]["us_per_launch"], "source": sq_source}
-            if issue["frac"] > 1.0:
-                # a MODEL (calibrated clocks per instruction x a committed instruction count), not a measurement of this run: when the
-                # kernel beats it, the model is what is wrong -- say so instead of printing a fraction above 1
-                issue["model_exceeded"] = issue.pop("frac")
-        elif sq_source:
-            issue = {"source": sq_source}
-        npx = WIDTH * HEIGHT * 2 * B
-        moved = npx * (1 + 4 + 12) + npx // p.subsampling * 4      # what crosses L2: u8 in, image + two gradients + the H1 plane out
-        roofline = roofline_of(kt, npairs_roof, ms_per_pair, dominant=dom, extra={
-            "traffic": traffic, "traffic_source": traffic_source, "issue_bound": issue, "pairs_per_launch": B,
-            "frac_note": "frac books SURVEY 8(d)'s 21 B per pixel (17 for smoothing + gradients, 4 for the first reduction's input, which this "
-                         "kernel consumes from LDS); frac_moved books the 18 B per pixel that actually cross the L2 (4 of the 21 never leave LDS, "
-                         "the H1 plane adds 1)",
-            "moved_bytes_per_launch": moved, "achieved_moved": moved / (kt[dom]["us_per_launch"] * 1e-6) / 1e9,
-            "frac_moved": moved / (kt[dom]["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-            "step_unit": "one frame pair", "step_algorithmic_bytes_formula": 2 * pyr_b + trk_b,
-            "newton_iterations_per_level": st_pair["iterations"][:p.nPyramidLevels]})
-
-    tree = None
-    if rank == 0 and roofline and not args.no_extras:
-        tree = tree_sums_probe(ctx, lambda: [group_track(ctx, j, 0) for j in range(NG)],
-                               lambda: ctx.featbuf_download(T_OUT0, PL * NFEAT),
-                               roofline["kernels"]["track"]["algorithmic_bytes_per_launch"], p.window_width)
-
-    # secondary figures (never `value`): selection time, the one-stream figure, the cache-resident figure and the PCIe-inclusive pair time
-    extra = None
-    ms_single = None
-    reg = region_stats(regions, args.steps, elapsed)
-    if rank == 0 and args.no_extras:
-        extra = {"region_ms_per_step": reg, "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "note": "--no-extras: secondary figures skipped"}
-    elif rank == 0:
-        reps = 10
-        ctx.sync()
-        t = time.perf_counter()
-        for k in range(reps):
-            ctx.select_async(2 * (k % PL), 1, True, FB_MISC, NFEAT)      # SELECTING_ALL on a resident level-0 pyramid
-        ctx.sync()
-        ms_select = (time.perf_counter() - t) / reps * 1e3
-        def one_pair_at_a_time():
-            runs = []
-            for _ in range(5):
-                t = time.perf_counter()
-                for i in range(4 * PL):                          # one pair per build / tracker call, rotating through the context's pairs
-                    lp = i % PL
-                    ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
-                    ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp, NFEAT)
-                ctx.sync()
-                runs.append((time.perf_counter() - t) / (4 * PL) * 1e3)
-            return runs
-
-        singles = one_pair_at_a_time()
-        ms_single = statistics.median(singles)
-        # round 2's headline arrangement: every context rebuilds the SAME two pairs (four slots) over and over, so the pyramid planes
-        # the tracker reads are still in the Infinity Cache
-        nrep, HB = 64, min(2, PL)                  # (two pairs per launch: 4 x 27 MB of planes per context stay below the cache's 256 MB)
-        hot_pairs = [(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp) for lp in range(HB)]
-        hots = []
-        for _ in range(5):
-            for cx in ctxs:
-                cx.sync()
-            t = time.perf_counter()
-            for _ in range(nrep):
-                for cx in ctxs:
-                    cx.build_pyramids_batch(list(range(2 * HB)))
-                for cx in ctxs:
-                    cx.track_batch_async(hot_pairs, NFEAT) if HB > 1 else cx.track_async(0, 1, FB_IN0, V_OUT0, NFEAT)
-            for cx in ctxs:
-                cx.sync()
-            hots.append((time.perf_counter() - t) / (nrep * nctx * HB) * 1e3)
-        ms_hot = statistics.median(hots)
-        t = time.perf_counter()
-        for k in range(reps):                                  # un-pipelined latency of one pair
-            lp = k % PL
-            ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
-            ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp, NFEAT)
-            ctx.sync()
-        ms_latency = (time.perf_counter() - t) / reps * 1e3
-        t = time.perf_counter()
-        for k in range(reps):
-            lp = k % PL
-            f0, f1 = frames[pair_index(0, lp)]
-            ctx.upload(2 * lp, f0)
-            ctx.upload(2 * lp + 1, f1)
-            ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
-            ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, V_OUT0 + lp, NFEAT)
-            ctx.featbuf_download(V_OUT0 + lp, NFEAT)
-        ms_pcie = (time.perf_counter() - t) / reps * 1e3
-        # pipelined ingest: frames already sit in pinned host memory (as a decoder would leave them), uploads run on the
-        # copy stream and overlap the previous pair's kernels; records go to a device table read back every 16 pairs
-        NPIN = min(PL, 8)
-        pins = []
-        for lp in range(NPIN):
-            a, b = ctx.pinned_array((HEIGHT, WIDTH)), ctx.pinned_array((HEIGHT, WIDTH))
-            a[:], b[:] = frames[pair_index(0, lp)]
-            pins.append((a, b))
-        # records: a device table of 2 x 16 rows; the half a window filled goes to pinned host memory with klt_featbuf_download_async at the
-        # window's end and is waited for at the NEXT window's end -- a synchronous download there makes the host wait for every queued step
-        # and the link idles 0.3-0.9 ms per window meanwhile (tools/trace_copies.py)
-        TAB, NT = FB_MISC + 1, 16
-        HALVES = (TAB + 1 + 2 * NT, TAB + 2 + 2 * NT)
-        ctx.featbuf_alloc(TAB, 2 * NT * NFEAT)
-        for k in range(2 * NT):
-            ctx.featbuf_view(TAB + 1 + k, TAB, k * NFEAT, NFEAT)
-        for hlf in range(2):
-            ctx.featbuf_view(HALVES[hlf], TAB, hlf * NT * NFEAT, NT * NFEAT)
-        from pyfeaturetrack_amd.backend import FEAT_DTYPE
-        host_tab = [ctx.pinned_array((NT * NFEAT,), FEAT_DTYPE) for _ in range(2)]
-        npipe = 16 * NT
-
-        def send(i):                         # the two frames of pair i leave on the two copy streams
-            lp = i % NPIN
-            ctx.upload_async(2 * lp, pins[lp][0])
-            ctx.upload_async(2 * lp + 1, pins[lp][1])
-
-        def pipelined_step(i):
-            # the NEXT pair's frames are sent before this pair's kernels are enqueued: the link works on pair i + 1 while the GPU works on
-            # pair i (four pairs of slots in rotation; a slot's raw buffers alternate, so the copy never waits for the build before last)
-            lp = i % NPIN
-            send(i + 1)
-            ctx.build_pyramids_batch([2 * lp, 2 * lp + 1])
-            ctx.track_async(2 * lp, 2 * lp + 1, FB_IN0 + lp, TAB + 1 + i % (2 * NT), NFEAT)
-            if i % NT != NT - 1:
-                return None
-            win = i // NT
-            ctx.download_wait()                                   # the PREVIOUS window's records (long there)
-            got = host_tab[(win - 1) % 2] if win > 0 else None     # (valid until the window after next overwrites it)
-            ctx.featbuf_download_async(HALVES[win % 2], host_tab[win % 2])
-            return got
-
-        send(0)
-        for i in range(NT):                 # warm-up: the alternate raw buffers are allocated on first use
-            table = pipelined_step(i)
-        ctx.sync()
-        t = time.perf_counter()
-        for i in range(NT, NT + npipe):
-            got = pipelined_step(i)
-            table = got if got is not None else table
-        ctx.download_wait()
-        table = host_tab[((NT + npipe - 1) // NT) % 2].copy()     # the last window's records
-        ctx.sync()
-        ms_pipe = (time.perf_counter() - t) / npipe * 1e3
-        last_lp = (NT + npipe - 1) % NPIN
-        assert np.array_equal(table[-NFEAT:]["x"], outs[pair_index(0, last_lp)]["x"]), "pipelined ingest changed the result"
-        extra = {"region_ms_per_step": reg,
-                 "overlapped_ms_per_pair": ms_per_pair,
-                 "cache_resident_ms_per_pair": ms_hot, "cache_resident_features_per_s": NFEAT / (ms_hot * 1e-3),
-                 "pcie_pipelined_ms_per_pair": ms_pipe, "pcie_pipelined_features_per_s": NFEAT / (ms_pipe * 1e-3),
-                 "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3, "latency_ms_per_pair_synchronised": ms_latency,
-                 "single_stream_ms_per_pair": ms_single, "single_stream_features_per_s": NFEAT / (ms_single * 1e-3),
-                 "single_stream_runs_ms": singles,
-                 "ms_per_select_5000": ms_select,
-                 "pcie_inclusive_ms_per_pair": ms_pcie, "pcie_inclusive_features_per_s": NFEAT / (ms_pcie * 1e-3),
-                 "note": "ms_per_frame_pair = single_stream_ms_per_pair: one pair at a time on ONE stream, rotating through the resident "
-                         "pairs, no overlap with other pairs (ms_per_step / pairs_per_step = overlapped_ms_per_pair is the inverse "
-                         "throughput with pairs_in_flight pairs overlapping).  cache_resident = round 2's headline arrangement: every "
-                         "context rebuilds the same four frame slots, which then never leave the 256 MB Infinity Cache.  pcie_inclusive "
-                         "= H2D of two u8 frames from pageable host memory + pyramids + track + D2H of the records, synchronised per "
-                         "pair; pcie_pipelined = the same bytes with klt_upload_u8_async from pinned memory on two copy streams, the next "
-                         "pair sent before this pair's kernels are enqueued, and the records read back every 16 pairs without draining the "
-                         "queue (klt_featbuf_download_async)"}
-        if tree:
-            extra["tracker_tree_sums"] = tree
-        link = link_rates()
-        extra["pcie_pipelined_GBps"] = 2 * WIDTH * HEIGHT / (ms_pipe * 1e-3) / 1e9
-        if link:
-            extra["pcie_link"] = link
-            extra["pcie_pipelined_frac_of_link"] = extra["pcie_pipelined_GBps"] / link["1080p"]
-            extra["pcie_pipelined_frac_of_link_next_to_a_kernel"] = min(1.0, extra["pcie_pipelined_GBps"] / link["1080p_next_to_a_kernel"])
-        # (one-GPU secondary figures: with N > 1 the other ranks are done by now and must not be kept waiting for rank 0's extras)
-        if not args.no_api and not distributed:
-            extra.update(api_figures(frames[0], tc))
-        if not args.no_sequences and not distributed:
-            extra["sequence_from_host"] = {"1080p": sequence_from_host(ranks.local_rank, 1920, 1080, 5000, 256, link.get("1080p")),
-                                           "4k": sequence_from_host(ranks.local_rank, 3840, 2160, 20000, 128, link.get("4k")),
-                                           "note": sequence_from_host.__doc__.split("  Secondary")[0].replace("\n    ", " ")}
-
-    cpu = None
-    if rank == 0 and not distributed and not args.no_cpu_baseline and ko:
-        a0, a1 = frames[0][0].astype(np.float32), frames[0][1].astype(np.float32)
-        cpu = cpu_baseline_of(ko, lambda: ko.track_features(p, ko.Pyramids(p, a0), ko.Pyramids(p, a1), lists[0].copy()), NFEAT,
-                              "pyramids of both frames + track 5000 features of ONE pair of cfg-2 (1920x1080, seed %d)" % seeds[0],
-                              reference_python_survey={"ms_per_pair": 603.0, "features_per_s": 8300.0, "where": "survey container, 1 thread"})
-        if cpu:
-            cpu["ms_per_pair"] = cpu["ms_per_step"]
-
-    line = None
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        line = base_line(world * NP * NFEAT * args.steps / elapsed, world, args.steps, args.warmup, ms_per_step,
-                         ms_single if ms_single is not None else ms_per_pair,
-                         ("THROUGHPUT over %d independent pairs in flight (%d contexts x %d pairs per launch); the literal single-pair figure is "
-                          "`single_pair`.  " % (nctx * B, nctx, B) if nctx * B > 1 else "ONE pair at a time on one stream.  ") +
-                         "cfg-2: %d DISTINCT 1920x1080 synthetic pairs resident per GPU (seeds %d..%d; own frame slots, pyramids and "
-                         "feature lists: %.1f GB), 5000 features each, 7x7 window, 3 pyramid levels (subsampling 4), translation only; "
-                         "a step = one pass of pyramid build + tracking over all of them (%d KLTTrackFeatures-equivalents); inputs "
-                         "resident in HBM, no frame or pyramid is touched twice within a step"
-                         % (NP, seeds[0], seeds[-1], NP * 2 * (WIDTH * HEIGHT + 4 * 3 * sum(level_pixels(p, WIDTH, HEIGHT))) / 1e9, NP),
-                         extra_cfg={
-                             "pipelining": (("none (one HIP stream)" if nctx == 1 else
-                                             "groups of pairs go round-robin to %d contexts, one HIP stream each, no ordering between them "
-                                             "(pairs are independent)" % nctx) +
-                                            ("; every pair has its own launches" if B == 1 else
-                                             "; the %d pairs of a group share every launch of their context: one batched pyramid "
-                                             "build for their %d frames, one tracker launch for their %d feature lists -- every pair still "
-                                             "gets the full work of one KLTTrackFeatures call" % (B, 2 * B, B))),
-                             "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "resident_pairs": NP,
-                             "features_per_pair": NFEAT, "pairs_per_step": NP * world, "ms_per_pair": ms_per_pair, "tracked": tracked,
-                             "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
-                             "rccl_ranks": world if distributed else 0,
-                             "parallelism": "%d pairs per GPU" % NP + (", one RCCL all-gather (libkltgpu side stream) of each context's [%d pairs x "
-                                                                      "5000] record table per step" % PL if distributed else "")})
-        line.update(parity)
-        # BASELINE cfg-2 read literally -- "single 1920x1080 pair": one pair at a time on ONE stream, nothing overlapping it
-        if ms_single is not None:
-            step_b = roofline["step_algorithmic_bytes_formula"] if roofline else None
-            line["single_pair"] = {"ms": ms_single, "features_per_s": NFEAT / (ms_single * 1e-3),
-                                   "step_frac": (step_b / (ms_single * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_b else None,
-                                   "note": "pyramids of both frames + tracker of ONE pair per build / tracker call on one HIP stream, rotating "
-                                           "through the resident pairs (median of 5 runs of %d pairs); `value` is the throughput with %d "
-                                           "independent pairs in flight" % (4 * PL, nctx * B)}
-        line["roofline"], line["cpu_baseline"], line["extra"] = roofline, cpu, extra
-    for cx in ctxs:
-        cx.close()
-    if line is not None:
-        emit(json_fd, line)
-        fail_on_parity(parity)
-
-
-def sequence_from_host(device, w, h, n, nframes=256, link_gbps=None):
-    """What a video pipeline pays per frame when the frames come from the host: sequential mode, ONE new u8 frame per
-    step from pinned host memory (klt_upload_u8_async on the copy streams, overlapping the previous frame's kernels), pyramid of the new
-    frame + score preparation on the build stream, track + replacement of the lost features on the main stream, the next tracker enqueued
-    ahead of the host's look -- the loop of `--config cfg5` with an upload per frame -- and the records written into a device table of 16
-    rows that is downloaded every 16 frames.  16 distinct frames of the periodic texture sit in pinned memory and are visited up and down
-    (0, 1, ... 15, 14, ... 0, ...), so consecutive frames always differ by one step of (3.3, -2.1) pixels.  Secondary figure, never `value`."""
-    tc = cfg2_context()
-    tc.max_residue = 10.0
-    ctx = Context(device)
-    ctx.configure(tc)
-    try:
-        NPIN, NT = 16, 16
-        phases = synth.sequence_phases(w, h, 4, workers=usable_cores(10))
-        pins = []
-        for f in synth.periodic_sequence(w, h, 4, NPIN, phases=phases):
-            a = ctx.pinned_array((h, w))
-            a[:] = f
-            pins.append(a)
-        order = list(range(NPIN)) + list(range(NPIN - 2, 0, -1))              # 0..15..1: period 30
-        S = [0, 1, 2]
-        TAB, HALF = 100, (200, 201)                                           # 2 x 16 rows: one half fills while the other is read back
-        ctx.featbuf_alloc(TAB, 2 * NT * n)
-        for k in range(2 * NT):
-            ctx.featbuf_view(TAB + 1 + k, TAB, k * n, n)
-        for i in range(2):
-            ctx.featbuf_view(HALF[i], TAB, i * NT * n, NT * n)
-        row = lambda k: TAB + 1 + k % (2 * NT)                                # noqa: E731
-        from pyfeaturetrack_amd.backend import FEAT_DTYPE
-        host_tab = [ctx.pinned_array((NT * n,), FEAT_DTYPE) for _ in range(2)]
-        ctx.set_option(15, 1)                                                 # KLT_OPT_BUILD_STREAM
-
-        def send(k):                         # frame k leaves for its slot (the copy overlaps whatever the GPU is doing)
-            ctx.upload_async(S[k % 3], pins[order[k % len(order)]])
-
-        def stage(k):
-            ctx.build_pyramids(S[k % 3], sync=False)
-            ctx.select_prepare(S[k % 3])
-
-        def track(k):
-            ctx.track_async(S[(k - 1) % 3], S[k % 3], row(k - 1), row(k), n)
-
-        def run(count):
-            live = None
-            send(0)
-            ctx.build_pyramids(S[0], sync=False)
-            ctx.select_async(S[0], 1, True, row(0), n)
-            send(1)
-            send(2)
-            stage(1)
-            track(1)
-            send(3)
-            for k in range(1, count):
-                ctx.select_begin(S[k % 3], 2, True, row(k), n)
-                stage(k + 1)
-                track(k + 1)
-                if ctx.select_finish():
-                    track(k + 1)
-                # frame k + 3 goes into the slot of frame k, whose pyramids only the tracker just enqueued (k -> k + 1) still reads: the copy fills
-                # the slot's other raw buffer, two frame times before its build needs it (a frame sent one step ahead is not there
-                # in time: 155 us of copy + the build = the whole frame time at 4K).  After the look: a repeated tracker needs slot k valid.
-                send(k + 3)
-                if k % NT == NT - 1:
-                    # the half holding rows k-15 .. k is complete once frame k's selection is; the tracker of k+1 already writes into the
-                    # other half.  The copy is enqueued in stream order and waited for one window later: the host never drains the queue.
-                    ctx.download_wait()
-                    ctx.featbuf_download_async(HALF[(k // NT) % 2], host_tab[(k // NT) % 2])
-                    live = host_tab[(k // NT) % 2]
-            ctx.download_wait()
-            ctx.sync()
-            return None if live is None else live.copy()
-
-        run(2 * NT)                                                           # sizes every buffer
-        t = time.perf_counter()
-        table = run(nframes)
-        ms = (time.perf_counter() - t) / (nframes - 1) * 1e3
-        alive = int((table.reshape(NT, n)[NT - 2]["val"] >= 0).sum())
-        gbps = w * h / (ms * 1e-3) / 1e9
-        out = {"ms_per_frame": ms, "features_per_s": n / (ms * 1e-3), "frames": nframes, "ingest_GBps": gbps,
-               "alive_after_replacement": alive, "frame": "%dx%d" % (w, h), "features": n}
-        if link_gbps:
-            out["link_GBps"] = link_gbps
-            out["ingest_frac_of_link"] = gbps / link_gbps
-        return out
-    finally:
-        ctx.close()
-
-
-def link_rates():
-    """profiles/r04_h2d_probe.json (tools/h2d_probe.cpp on the builder's GPU box): what pinned host-to-device copies of one frame sustain"""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r04_h2d_probe.json")))
-        return {"1080p": d["h2d_1080p_2.07MB"]["two_streams_GBps"], "4k": d["h2d_4k_8.29MB"]["two_streams_GBps"],
-                "1080p_next_to_a_kernel": d["h2d_1080p_2.07MB"]["two_streams_next_to_a_kernel_GBps"],
-                "4k_next_to_a_kernel": d["h2d_4k_8.29MB"]["two_streams_next_to_a_kernel_GBps"],
-                "source": "profiles/r04_h2d_probe.json (tools/h2d_probe.cpp, builder gpurun): pinned H2D on two copy streams, back to back, "
-                          "on an idle GPU / next to a running compute kernel"}
-    except (OSError, KeyError, ValueError):
-        return {}
-
-
-def api_figures(pair, tc):
-    """What a caller of the reference-shaped Python API sees (KLTSelectGoodFeatures / KLTTrackFeatures on PIL-like arrays, uploads
-    and the download of the list included): ms per call at cfg-2's size, on the package's default context."""
-    from pyfeaturetrack_amd import selectGoodFeatures as sgf
-    from pyfeaturetrack_amd import trackFeatures as trk
-    v0 = sgf.KLT_verbose
-    sgf.KLT_verbose = trk.KLT_verbose = 0
-    try:
-        f0, f1 = pair
-
-        def measure(trusting, new_frame_per_call=False):
-            tc.trustFrameIdentity = trusting
-            trk.KLTForgetFrames(tc)
-            t_sel, t_trk, t_pp = [], [], []
-            fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
-            trk.KLTTrackFeatures(tc, f0, f1, fl)
-            g1 = f1.copy()
-            for k in range(10):
-                t = time.perf_counter()
-                fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
-                t_sel.append(time.perf_counter() - t)
-                if new_frame_per_call:
-                    g1[k, k] ^= 1                              # one pixel: frame 2 is a new image every call
-                t = time.perf_counter()
-                trk.KLTTrackFeatures(tc, f0, g1 if new_frame_per_call else f1, fl)
-                t_trk.append(time.perf_counter() - t)
-            # example1's ping-pong (example1.py:53-56): the same two images, back and forth
-            fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
-            for k in range(20):
-                a, b = (f0, f1) if k % 2 == 0 else (f1, f0)
-                t = time.perf_counter()
-                trk.KLTTrackFeatures(tc, a, b, fl)
-                t_pp.append(time.perf_counter() - t)
-            return statistics.median(t_sel) * 1e3, statistics.median(t_trk) * 1e3, statistics.median(t_pp) * 1e3
-
-        def clip_loop():
-            # consecutive frames of a clip in non-sequential mode: frame 1 of a call is frame 2 of the call before, frame 2 has new
-            # pixels (16 distinct frames visited up and down) -- the call a video loop written against the reference makes
-            base = synth.synth_base(f0.shape[1], f0.shape[0], 1)
-            clip = [synth.synth_frame(f0.shape[1], f0.shape[0], 1, k, base=base) for k in range(16)]
-            order = list(range(16)) + list(range(14, 0, -1))
-            tc.trustFrameIdentity = False
-            trk.KLTForgetFrames(tc)
-            fl = sgf.KLTSelectGoodFeatures(tc, clip[0], NFEAT)
-            ts = []
-            for k in range(36):
-                a, b = clip[order[k % 30]], clip[order[(k + 1) % 30]]
-                t = time.perf_counter()
-                trk.KLTTrackFeatures(tc, a, b, fl)
-                ts.append(time.perf_counter() - t)
-                if k % 8 == 7:
-                    fl = sgf.KLTSelectGoodFeatures(tc, b, NFEAT)
-            return statistics.median(ts[4:]) * 1e3
-
-        def sequence(w, h, n, seed, nframes=256):
-            # KLTTrackSequence itself (the product's sequence function; VERDICT r4 missing-4): numpy frames in, feature table out
-            from pyfeaturetrack_amd.klt import KLT_TrackingContext
-            from pyfeaturetrack_amd.trackSequence import KLTTrackSequence
-            tcs = KLT_TrackingContext()
-            tcs.nPyramidLevels, tcs.subsampling = 3, 4
-            tcs.KLTUpdateTCBorder()
-            tcs.max_residue = 10.0
-            base = synth.synth_base(w, h, seed)
-            distinct = [synth.synth_frame(w, h, seed, k, base=base) for k in range(16)]
-            order = list(range(16)) + list(range(14, 0, -1))
-            frames = [distinct[order[k % 30]] for k in range(nframes)]
-            best = None
-            for _ in range(3):
-                t = time.perf_counter()
-                KLTTrackSequence(tcs, frames, n)
-                ms = (time.perf_counter() - t) * 1e3 / (nframes - 1)
-                best = ms if best is None else min(best, ms)
-            return best
-
-        exact, trusting, fresh = measure(False), measure(True), measure(False, True)
-        tc.trustFrameIdentity = False
-        return {"api_ms_per_KLTSelectGoodFeatures": exact[0], "api_ms_per_KLTTrackFeatures": exact[1],
-                "api_ms_per_KLTTrackFeatures_pingpong": exact[2],
-                "api_ms_per_KLTTrackFeatures_new_frame_each_call": fresh[1],
-                "api_ms_per_KLTTrackFeatures_consecutive_frames": clip_loop(),
-                "api_ms_per_frame_KLTTrackSequence": {"1080p_5000_features_256_frames": sequence(1920, 1080, 5000, 1),
-                                                      "4k_20000_features_256_frames": sequence(3840, 2160, 20000, 4),
-                                                      "note": "the whole call (first selection, helper thread, table download) / 255; "
-                                                              "replacement after every frame; best of 3"},
-                "api_trusting_ms_per_KLTSelectGoodFeatures": trusting[0], "api_trusting_ms_per_KLTTrackFeatures": trusting[1],
-                "api_trusting_ms_per_KLTTrackFeatures_pingpong": trusting[2],
-                "api_note": "reference-shaped Python API on numpy u8 frames of cfg-2's size, 5000 features; host-to-device copies and the "
-                            "download of the list are inside the figures.  api_* = the default: a frame is reused only after EVERY byte "
-                            "was compared with the copy the slot was filled from (results identical to the reference's for any call "
-                            "sequence); api_trusting_* = the opt-in tc.trustFrameIdentity shortcut (object identity + 1024 sampled pixels); "
-                            "new_frame_each_call = frame 2 differs by one pixel in every call (compare, copy to pinned memory, DMA, pyramid, track); "
-                            "consecutive_frames = a clip walked pair by pair in non-sequential mode (frame 1 resident from the call before, frame 2 new)"}
-    finally:
-        sgf.KLT_verbose = trk.KLT_verbose = v0
+# the parts (benchlib/): shared timing / roofline / oracle helpers and one module per BASELINE config.  Importing them does not touch
+# the GPU (the library is bound on first use).  The helpers stay importable as `bench.<name>` (tests use a few of them).
+from benchlib import common                                              # noqa: E402
+from benchlib.common import *                                            # noqa: E402,F401,F403
+from benchlib.cfg1 import run_cfg1                                       # noqa: E402
+from benchlib.cfg2 import run_cfg2                                       # noqa: E402
+from benchlib.cfg3 import run_cfg3                                       # noqa: E402
+from benchlib.cfg4 import run_cfg4                                       # noqa: E402
+from benchlib.cfg5 import run_cfg5                                       # noqa: E402
+from benchlib.dryrun import dry_run                                      # noqa: E402
 
 
 # ============================================================================================ main
@@ -1758,7 +99,7 @@ def main():
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S,
                     help="the timed regions of a run add up to at least this many seconds (0 for profiler passes, which replay every kernel)")
     args = ap.parse_args()
-    globals()["MIN_TIMED_S"] = args.min_timed_s
+    common.MIN_TIMED_S = args.min_timed_s
 
     # N > 1 without a launcher: start the ranks ourselves.  Nothing above or below this point has touched the GPU yet
     # (no HIP call, no library load): the children are fresh processes, this one only waits for them.

@@ -8,7 +8,7 @@
 # refused counter set makes rocprofv3 abort and then hang.  tools/profile_collect.sh <tag> then copies the summaries into profiles/.
 TAG=${1:-vX}
 export TMPDIR=/tmp
-export KLT_PROFILE_TAG=r04_$TAG
+export KLT_PROFILE_TAG=r05_$TAG
 export KLT_PROFILE_BATCH=8       # pairs per launch of the cfg-2 passes below (bench.py --batch default)
 O=gpurun_out
 mkdir -p $O
@@ -46,7 +46,9 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TA
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_cfg3 -o run -- python3 bench.py --config cfg3 --steps 100 --warmup 10 --min-timed-s 0 --repeats 5 --no-cpu-baseline > $O/prof_${TAG}_cfg3.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_cfg4 -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 30 --warmup 3 --min-timed-s 0 --repeats 5 --no-cpu-baseline > $O/prof_${TAG}_cfg4.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_cfg5 -o run -- python3 bench.py --config cfg5 --frames 32 --steps 31 --min-timed-s 0 --repeats 5 --no-cpu-baseline > $O/prof_${TAG}_cfg5.log 2>&1
-python3 tools/api_probe.py > $O/api_probe_$TAG.json 2>> $O/bench_$TAG.err
+python3 tools/api_probe.py --4k > $O/api_probe_$TAG.json 2>> $O/bench_$TAG.err
+python3 tools/api_profile.py > $O/api_profile_$TAG.txt 2>> $O/bench_$TAG.err
+python3 tools/api_timeline.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" > $O/api_timeline_$TAG.txt
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${TAG}_cfg4_fetch -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 10 --warmup 2 --min-timed-s 0 --repeats 3 --no-cpu-baseline > $O/pmc_${TAG}_cfg4_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${TAG}_cfg4_write -o run -- python3 bench.py --config cfg4 --pairs 32 --steps 10 --warmup 2 --min-timed-s 0 --repeats 3 --no-cpu-baseline > $O/pmc_${TAG}_cfg4_write.log 2>&1
 python3 tools/pmc_traffic.py $O/pmc_${TAG}_cfg4_fetch $O/pmc_${TAG}_cfg4_write $O/traffic_${TAG}_cfg4.json > /dev/null 2>> $O/bench_$TAG.err
