@@ -20,10 +20,16 @@ from .selectGoodFeatures import KLT_verbose  # noqa: E402
 
 
 class _Levels:
-    """`pyramid.img` of a device-resident pyramid: a sequence of the levels' float32 planes, each downloaded when first looked at."""
+    """`pyramid.img` of a device-resident pyramid: a sequence of the levels' float32 planes, each downloaded when first looked at.
+    It carries everything a download needs (context, the tracking context's slots, the generation of the build it stands for) and
+    no reference back to the pyramid object: a pyramid handle that is dropped -- `tc.pyramid_last*` are replaced on every
+    sequential-mode call -- is freed at once and never fetches its planes (with a cycle here the dropped handles of the last call
+    were still alive when their slot was overwritten, and every call downloaded nine planes nobody would look at: 4.7 instead of
+    0.5 ms per 1080p frame).  These objects are what the frame cache watches (`FrameCache.watch`)."""
 
-    def __init__(self, owner):
-        self._owner, self._planes = owner, [None] * owner.nLevels
+    def __init__(self, ctx, slots, gen, plane, nlevels):
+        self._ctx, self._slots, self._gen, self._plane = ctx, tuple(slots), gen, plane
+        self._planes = [None] * nlevels
 
     def __len__(self):
         return len(self._planes)
@@ -32,7 +38,7 @@ class _Levels:
         if isinstance(i, slice):
             return [self[k] for k in range(*i.indices(len(self._planes)))]
         if self._planes[i] is None:
-            self._owner._fetch(range(len(self._planes))[i])
+            self._fetch(range(len(self._planes))[i])
         return self._planes[i]
 
     def __setitem__(self, i, plane):
@@ -40,25 +46,6 @@ class _Levels:
 
     def __iter__(self):
         return (self[i] for i in range(len(self._planes)))
-
-
-class _ResidentPyramids:
-    """A KLTPyramid (pyramid.py:15-35: subsampling, nLevels, ncols[], nrows[], img[]) whose planes live in a device slot -- what
-    ComputeImagePyramids returns and what tc.pyramid_last* point at in sequential mode.  `img[i]` downloads level i on first access;
-    before the API layer overwrites the slot (a new frame, a rebuild) it fetches the levels of every handle that is still alive, so
-    a handle somebody kept stays valid as the reference's pyramid objects do."""
-
-    def __init__(self, ctx, slots, gen, which, ncols, nrows, subsampling, nlevels):
-        self._ctx, self._slots, self._gen = ctx, tuple(slots), gen
-        self.which = which
-        self._plane = ("img", "gradx", "grady").index(which)
-        self.subsampling, self.nLevels = subsampling, nlevels
-        self.ncols, self.nrows = [], []
-        for _ in range(nlevels):                  # true division, as in the reference (pyramid.py:26-31: levels >= 1 hold floats)
-            self.ncols.append(ncols)
-            self.nrows.append(nrows)
-            ncols, nrows = ncols / subsampling, nrows / subsampling
-        self.img = _Levels(self)
 
     def _slot(self):
         for s in self._slots:
@@ -69,12 +56,34 @@ class _ResidentPyramids:
                               "KLT* functions of this package (klt_build_pyramids on the tracking context's slot)")
 
     def _fetch(self, level):
-        self.img[level] = self._ctx.download_level(self._slot(), self._plane, level)
+        self._planes[level] = self._ctx.download_level(self._slot(), self._plane, level)
 
     def _materialise(self):
-        for level in range(self.nLevels):
-            if self.img._planes[level] is None:
+        for level in range(len(self._planes)):
+            if self._planes[level] is None:
                 self._fetch(level)
+
+
+class _ResidentPyramids:
+    """A KLTPyramid (pyramid.py:15-35: subsampling, nLevels, ncols[], nrows[], img[]) whose planes live in a device slot -- what
+    ComputeImagePyramids returns and what tc.pyramid_last* point at in sequential mode.  `img[i]` downloads level i on first access;
+    before the API layer overwrites the slot (a new frame, a rebuild) it fetches the levels of every handle that is still alive, so
+    a handle somebody kept stays valid as the reference's pyramid objects do."""
+
+    def __init__(self, ctx, slots, gen, which, ncols, nrows, subsampling, nlevels):
+        self.which = which
+        self.subsampling, self.nLevels = subsampling, nlevels
+        self.ncols, self.nrows = [], []
+        for _ in range(nlevels):                  # true division, as in the reference (pyramid.py:26-31: levels >= 1 hold floats)
+            self.ncols.append(ncols)
+            self.nrows.append(nrows)
+            ncols, nrows = ncols / subsampling, nrows / subsampling
+        self.img = _Levels(ctx, slots, gen, ("img", "gradx", "grady").index(which), nlevels)
+
+    _gen = property(lambda self: self.img._gen)
+
+    def _materialise(self):
+        self.img._materialise()
 
     def __repr__(self):
         return "<device pyramid %s, %dx%d, %d levels>" % (self.which, self.ncols[0], self.nrows[0], self.nLevels)
@@ -85,7 +94,7 @@ def _pyramid_handles(tc, ctx, slot, ncols, nrows):
     gen = ctx.slot_generation(slot)
     hs = tuple(_ResidentPyramids(ctx, _slots_of(tc), gen, which, ncols, nrows, int(tc.subsampling), tc.nPyramidLevels)
                for which in ("img", "gradx", "grady"))
-    cache_of(tc).watch(hs)
+    cache_of(tc).watch(h.img for h in hs)           # (the plane holders: they live as long as somebody holds the pyramid or its img)
     return hs
 
 

@@ -543,3 +543,36 @@ def test_tree_sums_tracker_vs_reference_goldens(golden_dir, cfg1, img0, img1):
     finally:
         c.close()
     print("tree sums: worst |d| = %g px, %d of %d positions at the BASELINE sizes not bit-identical" % (worst, inexact, total))
+
+
+def test_sequential_mode_downloads_no_plane_nobody_looks_at(monkeypatch):
+    """tc.pyramid_last* are replaced on every sequential-mode KLTTrackFeatures call (trackFeatures.py:401-404).  The handles dropped that
+    way must be gone before their slot is overwritten: with a reference cycle inside them they lingered until the cycle collector ran,
+    and every call downloaded the nine planes of the call before (4.7 instead of 0.45 ms per 1080p frame through the per-frame API).
+    A handle somebody KEEPS still gets its planes before the slot is reused."""
+    import gc
+    from pyfeaturetrack_amd.backend import Context
+    sgf, trk = _api_modules()
+    k = 3
+    frames = _frames_of(k, 9)
+    tc = make_tc(**_CASES[k]["tc"])
+    tc.sequentialMode = True
+    fl = sgf.KLTSelectGoodFeatures(tc, frames[0], _CASES[k]["n"])
+    calls = []
+    real = Context.download_level
+    monkeypatch.setattr(Context, "download_level", lambda self, *a: (calls.append(a), real(self, *a))[1])
+    gc.disable()                                                   # nothing but reference counting may free the dropped handles
+    try:
+        for r in range(1, 7):
+            trk.KLTTrackFeatures(tc, frames[r - 1], frames[r], fl)
+            sgf.KLTReplaceLostFeatures(tc, frames[r], fl)
+        assert calls == [], "%d planes were downloaded although nobody kept a pyramid handle" % len(calls)
+        kept = tc.pyramid_last                                     # ... but a kept handle survives the next two frames with its planes
+        trk.KLTTrackFeatures(tc, frames[6], frames[7], fl)
+        trk.KLTTrackFeatures(tc, frames[7], frames[8], fl)
+        assert len(calls) == tc.nPyramidLevels and kept.img[0].shape == frames[0].shape
+    finally:
+        gc.enable()
+    tc2 = make_tc(**_CASES[k]["tc"])
+    want = trk.ComputeImagePyramids(tc2, frames[5], frames[6])[3]
+    assert np.array_equal(kept.img[0], want.img[0]) and np.array_equal(kept.img[tc.nPyramidLevels - 1], want.img[tc.nPyramidLevels - 1])

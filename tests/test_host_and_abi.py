@@ -519,3 +519,59 @@ def test_selection_falls_back_when_the_pyramid_does_not_fit():
     assert _pyramid_fits(TC, 320, 240) and _pyramid_fits(TC, 16, 16) and not _pyramid_fits(TC, 15, 240) and not _pyramid_fits(TC, 320, 15)
     TC.nPyramidLevels = 1
     assert _pyramid_fits(TC, 1, 1)
+
+
+def test_host_pool_compare_and_copy_from_several_threads():
+    """klt_host_compare / klt_host_copy (csrc/host_pool.hip; no context, no GPU): random ranges, single differing bytes anywhere, from
+    four threads at once -- the pool serves one job at a time and a caller that finds it busy does its own work; results are memcmp's /
+    memcpy's."""
+    import threading
+    from pyfeaturetrack_amd._abi import load_library
+    lib = load_library()
+    assert 1 <= lib.klt_host_lanes() <= 16
+    errors = []
+
+    def fuzz(seed):
+        r = np.random.default_rng(seed)
+        x = r.integers(0, 255, 2_500_000, dtype=np.uint8)
+        y = x.copy()
+        z = np.zeros_like(x)
+        for it in range(120):
+            n = int(r.integers(1, x.size))
+            off = int(r.integers(0, x.size - n + 1))
+            if lib.klt_host_compare(x[off:].ctypes.data, y[off:].ctypes.data, n) != 0:
+                errors.append(("equal ranges reported different", seed, it))
+            k = off + int(r.integers(0, n))
+            y[k] ^= 1
+            if lib.klt_host_compare(x[off:].ctypes.data, y[off:].ctypes.data, n) != 1:
+                errors.append(("a differing byte was missed", seed, it))
+            y[k] ^= 1
+            z[:] = 0
+            lib.klt_host_copy(z[off:].ctypes.data, x[off:].ctypes.data, n)
+            if not (np.array_equal(z[off:off + n], x[off:off + n]) and not z[:off].any() and not z[off + n:].any()):
+                errors.append(("copy wrote the wrong bytes", seed, it))
+
+    threads = [threading.Thread(target=fuzz, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+        assert not t.is_alive()
+    assert not errors, errors[:3]
+    assert lib.klt_host_compare(None, None, 0) == 0 and lib.klt_host_copy(None, None, 0) == 0
+
+
+def test_tracker_register_counts_quoted_by_the_bench():
+    """benchlib.common.TRACKER_VGPRS (quoted in extra.tracker_tree_sums) = what the compiler reports for the quad tracker kernels of the
+    tree (tools/kernel_regs.py: a fresh device-only compile of track_kernels.hip)."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    sys.path.insert(0, REPO)
+    import kernel_regs
+    from benchlib.common import TRACKER_VGPRS
+    regs = kernel_regs.kernel_regs("track_kernels.hip", "track_kernel_quad")
+    for window, waves in ((7, 1), (15, 5)):
+        for form, flag in (("exact", 0), ("tree", 1)):
+            names = [n for n in regs if "ILb1ELi%dELi%dELb%dE" % (window, waves, flag) in n]
+            assert len(names) == 1, (window, form, sorted(regs))
+            assert regs[names[0]]["vgpr"] == TRACKER_VGPRS[window][form], (window, form, regs[names[0]])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fill the @PLACEHOLDER@ figures of a DESIGN.md template from a profile set:  python tools/fill_design.py <tag> [template] [out]
-(the template is DESIGN.md itself as long as it still holds placeholders; figures come from profiles/r04_<tag>_*)."""
+(figures come from profiles/r05_<tag>_*; INTEGRATION.md's @API_*@ figures are filled from the same set)."""
 import csv
 import json
 import os
@@ -15,12 +15,12 @@ P = os.path.join(ROOT, "profiles")
 
 
 def L(name):
-    return json.load(open(os.path.join(P, "r04_%s_bench%s.json" % (tag, name))))
+    return json.load(open(os.path.join(P, "r05_%s_bench%s.json" % (tag, name))))
 
 
 def stats(name, kernel):
     """mean duration (us) of the first kernel whose name contains `kernel` in a rocprofv3 kernel_stats csv"""
-    path = os.path.join(P, "r04_%s_%skernel_stats.csv" % (tag, name))
+    path = os.path.join(P, "r05_%s_%skernel_stats.csv" % (tag, name))
     for r in csv.DictReader(open(path)):
         if kernel in r["Name"]:
             return float(r["AverageNs"]) / 1e3
@@ -32,7 +32,8 @@ k = d["roofline"]["kernels"]
 e = d["extra"]
 c1, c3, c4s, c4, c5 = L("_cfg1"), L("_cfg3"), L("_cfg4_shard32"), L("_cfg4_256_rccl_1rank"), L("_cfg5")
 k3 = c3["roofline"]["kernels"]
-traffic = json.load(open(os.path.join(P, "r04_%s_pmc_traffic.json" % tag)))
+traffic = json.load(open(os.path.join(P, "r05_%s_pmc_traffic.json" % tag)))
+t7, t15 = e["tracker_tree_sums"], c3["extra"]["tracker_tree_sums"]
 gpu_tests = os.environ.get("KLT_NGPU", "189")
 cpu_tests = os.environ.get("KLT_NCPU", "56")
 v = {
@@ -59,8 +60,14 @@ v = {
     "PIPE_MS": "%.3f" % e["pcie_pipelined_ms_per_pair"], "PIPE_GB": "%.1f" % e["pcie_pipelined_GBps"], "PIPE_FRAC": "%.2f" % e["pcie_pipelined_frac_of_link"],
     "PIPE_FRACK": "%.2f" % e["pcie_pipelined_frac_of_link_next_to_a_kernel"],
     "SEQ1080": "%.3f" % e["sequence_from_host"]["1080p"]["ms_per_frame"], "SEQ4K": "%.3f" % e["sequence_from_host"]["4k"]["ms_per_frame"],
-    "API_TRK": "%.2f" % e["api_ms_per_KLTTrackFeatures"], "API_SEL": "%.2f" % e["api_ms_per_KLTSelectGoodFeatures"],
-    "API_TRK_T": "%.2f" % e["api_trusting_ms_per_KLTTrackFeatures"], "API_SEL_T": "%.2f" % e["api_trusting_ms_per_KLTSelectGoodFeatures"],
+    "API_PP": "%.3f" % e["api_ms_per_KLTTrackFeatures_pingpong"], "API_SEL": "%.3f" % e["api_ms_per_KLTSelectGoodFeatures"],
+    "API_CLIP": "%.3f" % e["api_ms_per_KLTTrackFeatures_consecutive_frames"], "API_FRESH": "%.3f" % e["api_ms_per_KLTTrackFeatures_new_frame_each_call"],
+    "API_SEQ1080": "%.3f" % e["api_ms_per_frame_KLTTrackSequence"]["1080p_5000_features_256_frames"],
+    "API_SEQ4K": "%.3f" % e["api_ms_per_frame_KLTTrackSequence"]["4k_20000_features_256_frames"],
+    "TREE7_US": "%.1f" % t7["us_per_launch"], "TREE7_EX": "%.1f" % t7["us_per_launch_exact"], "TREE7_X": "%.2f" % t7["speedup"],
+    "TREE7_FRAC": "%.2f" % t7["frac"], "TREE7_DIFF": "%d" % t7["differing_positions"], "TREE7_DX": "%.3f" % t7["max_abs_dx"],
+    "TREE15_US": "%.1f" % t15["us_per_launch"], "TREE15_EX": "%.1f" % t15["us_per_launch_exact"], "TREE15_X": "%.2f" % t15["speedup"],
+    "TREE15_FRAC": "%.2f" % t15["frac"],
     "CPU_MS": "%.0f" % d["cpu_baseline"]["ms_per_pair"], "CPU_KF": "%.1f" % (d["cpu_baseline"]["value"] / 1e3),
     "NGPU": gpu_tests, "NCPU": cpu_tests,
 }
@@ -71,4 +78,10 @@ if missing:
 for name, val in v.items():
     text = text.replace("@%s@" % name, val)
 open(dst, "w").write(text)
+# INTEGRATION.md carries a few of the same figures
+ipath = os.path.join(ROOT, "INTEGRATION.md")
+itext = open(ipath).read()
+for name, val in v.items():
+    itext = itext.replace("@%s@" % name, val)
+open(ipath, "w").write(itext)
 print("filled %d figures into %s (%d bytes)" % (len(v), dst, len(text.encode())))
