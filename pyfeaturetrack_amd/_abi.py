@@ -90,6 +90,7 @@ SYMBOLS = {
     "klt_featbuf_download": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_download_async": (_I, [_P, _I, _P, _I]),
     "klt_download_wait": (_I, [_P]),
+    "klt_download_mark_async": (_I, [_P]),
     "klt_featbuf_map_host": (_I, [_P, _I, _P, _I]),
     "klt_featbuf_alloc": (_I, [_P, _I, _I]),
     "klt_featbuf_view": (_I, [_P, _I, _I, _I, _I]),

@@ -434,11 +434,21 @@ class Context:
         else:
             self._check(self._lib.klt_track_affine_async(self._h, slot1, slot2, fb_in, fb_out, n, state))
 
-    def track_complete(self, n, fb_out=_FB_API_OUT):
-        """The records of the LAST tracker enqueued into fb_out, in host_records(n)[1] (a wait for the stream when the buffers are
-        mapped, one synchronous download otherwise)."""
-        rout = self.host_records(n)[1]
+    def track_mark(self):
+        """Marks the main stream behind the tracker just enqueued: track_complete(marked=True) then waits for THAT point, and work
+        enqueued after the mark (the scores of the replacement that follows) keeps running while the host moves the columns."""
         if MAP_RECORDS:
+            self._check(self._lib.klt_download_mark_async(self._h))
+            return True
+        return False
+
+    def track_complete(self, n, fb_out=_FB_API_OUT, marked=False):
+        """The records of the LAST tracker enqueued into fb_out, in host_records(n)[1] (a wait for the stream -- or for the mark --
+        when the buffers are mapped, one synchronous download otherwise)."""
+        rout = self.host_records(n)[1]
+        if MAP_RECORDS and marked:
+            self._check(self._lib.klt_download_wait(self._h))
+        elif MAP_RECORDS:
             self._check(self._lib.klt_sync(self._h))
         else:
             self._check(self._lib.klt_featbuf_download(self._h, fb_out, rout.ctypes.data, n))

@@ -61,6 +61,19 @@ int klt_featbuf_download_async(klt_ctx *c, int fb, klt_feat *dst, int n)
     return KLT_OK;
 }
 
+// The same event without a copy in front of it: "the host wants to wait for THIS point of the main stream" (klt_download_wait), not for
+// the stream -- a caller whose records are written straight into pinned memory (klt_featbuf_map_host) marks the stream behind the
+// kernel that writes them and may enqueue more work (the next selection's scores) before it waits.
+int klt_download_mark_async(klt_ctx *c)
+{
+    if (!c) return KLT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = fresh_event(c, &c->ev_download, &c->download_serial)) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_download, c->stream));
+    c->download_pending = true;
+    return KLT_OK;
+}
+
 int klt_download_wait(klt_ctx *c)
 {
     if (!c) return KLT_ERR_ARG;

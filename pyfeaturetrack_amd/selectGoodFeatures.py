@@ -295,6 +295,7 @@ def KLTReplaceLostFeatures(tc, img, featurelist):
     nLost = len(featurelist) - KLTCountRemainingFeatures(featurelist)
     if KLT_verbose >= 1:
         print("(KLT) Attempting to replace {0} features in a {1} by {2} image...  ".format(nLost, ncols, nrows))
+    tc.__dict__["_klt_replaced_after_track"] = True        # (KLTTrackFeatures then prepares the next replacement's scores ahead)
     if nLost > 0:
         _KLTSelectGoodFeatures(tc, img, len(featurelist), selectionMode.REPLACING_SOME, featurelist)
     if KLT_verbose >= 1:

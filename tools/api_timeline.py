@@ -32,7 +32,8 @@ def wrap(obj, name, label=None):
 
 def main():
     sgf.KLT_verbose = tf.KLT_verbose = 0
-    for n in ("upload_async", "build_pyramids_batch", "build_pyramids", "track_enqueue", "track_complete", "configure", "swap_slots"):
+    for n in ("upload_async", "build_pyramids_batch", "build_pyramids", "track_enqueue", "track_complete", "configure", "swap_slots",
+              "select_enqueue", "select_complete"):
         wrap(backend.Context, n)
     wrap(_frames, "same_pixels")
     wrap(_frames, "copy_pixels")
@@ -59,7 +60,21 @@ def main():
     def video(k):
         tf.KLTTrackFeatures(tc, clip[order[k % 30]], clip[order[(k + 1) % 30]], fl)
 
-    for name, fn in (("ping-pong", pingpong), ("new frame 2 each call (one pixel)", fresh), ("consecutive frames of a clip", video)):
+    tcs = KLT_TrackingContext()
+    tcs.nPyramidLevels, tcs.subsampling = 3, 4
+    tcs.KLTUpdateTCBorder()
+    tcs.sequentialMode = True
+    tcs.max_residue = 10.0
+    fls = sgf.KLTSelectGoodFeatures(tcs, clip[0], N)
+    wrap(sgf, "KLTCountRemainingFeatures")
+
+    def sequential(k):
+        cur = clip[order[(k + 1) % 30]]
+        tf.KLTTrackFeatures(tcs, clip[order[k % 30]], cur, fls)
+        sgf.KLTReplaceLostFeatures(tcs, cur, fls)
+
+    for name, fn in (("ping-pong", pingpong), ("new frame 2 each call (one pixel)", fresh), ("consecutive frames of a clip", video),
+                     ("sequential mode: KLTTrackFeatures + KLTReplaceLostFeatures", sequential)):
         for k in range(5):
             fn(k)
         runs, totals = [], []

@@ -62,6 +62,7 @@ v = {
     "SEQ1080": "%.3f" % e["sequence_from_host"]["1080p"]["ms_per_frame"], "SEQ4K": "%.3f" % e["sequence_from_host"]["4k"]["ms_per_frame"],
     "API_PP": "%.3f" % e["api_ms_per_KLTTrackFeatures_pingpong"], "API_SEL": "%.3f" % e["api_ms_per_KLTSelectGoodFeatures"],
     "API_CLIP": "%.3f" % e["api_ms_per_KLTTrackFeatures_consecutive_frames"], "API_FRESH": "%.3f" % e["api_ms_per_KLTTrackFeatures_new_frame_each_call"],
+    "API_SEQLOOP": "%.3f" % e["api_ms_per_frame_sequential_mode_loop"], "TAG": tag,
     "API_SEQ1080": "%.3f" % e["api_ms_per_frame_KLTTrackSequence"]["1080p_5000_features_256_frames"],
     "API_SEQ4K": "%.3f" % e["api_ms_per_frame_KLTTrackSequence"]["4k_20000_features_256_frames"],
     "TREE7_US": "%.1f" % t7["us_per_launch"], "TREE7_EX": "%.1f" % t7["us_per_launch_exact"], "TREE7_X": "%.2f" % t7["speedup"],
