@@ -53,10 +53,11 @@ if ROOT not in sys.path:
 from benchlib import common                                              # noqa: E402
 from benchlib.common import *                                            # noqa: E402,F401,F403
 from benchlib.cfg1 import run_cfg1                                       # noqa: E402
-from benchlib.cfg2 import run_cfg2                                       # noqa: E402
-from benchlib.cfg3 import run_cfg3                                       # noqa: E402
+from benchlib.cfg2 import link_rates, run_cfg2, sequence_from_host      # noqa: E402,F401
+from benchlib.api_figures import api_figures                            # noqa: E402,F401
+from benchlib.cfg3 import affine_bytes, cfg3_context, cfg3_frames, run_cfg3        # noqa: E402,F401
 from benchlib.cfg4 import run_cfg4                                       # noqa: E402
-from benchlib.cfg5 import run_cfg5                                       # noqa: E402
+from benchlib.cfg5 import run_cfg5, run_cfg5_blocks                      # noqa: E402,F401
 from benchlib.dryrun import dry_run                                      # noqa: E402
 
 
