@@ -4,6 +4,12 @@
 
 extern "C" int klt_comm_fence_async(klt_ctx *c);        // api_comm.hip: a gathered table is complete before it is read back
 
+namespace {
+// a view may be pinned host memory (klt_featbuf_map_host): the copy's direction is then left to the runtime, which knows both pointers
+inline hipMemcpyKind up(const FeatBuf &b) { return b.view ? hipMemcpyDefault : hipMemcpyHostToDevice; }
+inline hipMemcpyKind down(const FeatBuf &b) { return b.view ? hipMemcpyDefault : hipMemcpyDeviceToHost; }
+}  // namespace
+
 extern "C" {
 
 int klt_featbuf_upload(klt_ctx *c, int fb, const klt_feat *src, int n)
@@ -12,7 +18,7 @@ int klt_featbuf_upload(klt_ctx *c, int fb, const klt_feat *src, int n)
     HIPCHK(c, hipSetDevice(c->device));
     FeatBuf *b;
     if (int rc = get_fb(c, fb, n > 0 ? n : 1, &b)) return rc;
-    HIPCHK(c, hipMemcpyAsync(b->d, src, (size_t)n * sizeof(klt_feat), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b->d, src, (size_t)n * sizeof(klt_feat), up(*b), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return KLT_OK;
 }
@@ -23,7 +29,7 @@ int klt_featbuf_upload_async(klt_ctx *c, int fb, const klt_feat *src, int n)
     HIPCHK(c, hipSetDevice(c->device));
     FeatBuf *b;
     if (int rc = get_fb(c, fb, n > 0 ? n : 1, &b)) return rc;
-    HIPCHK(c, hipMemcpyAsync(b->d, src, (size_t)n * sizeof(klt_feat), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b->d, src, (size_t)n * sizeof(klt_feat), up(*b), c->stream));
     return KLT_OK;
 }
 
@@ -33,7 +39,7 @@ int klt_featbuf_download(klt_ctx *c, int fb, klt_feat *dst, int n)
     if (fb < 0 || (size_t)fb >= c->fbs.size() || c->fbs[fb].cap < n) return fail(c, KLT_ERR_STATE, "feature buffer not that large");
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = klt_comm_fence_async(c)) return rc;        // a gathered table is complete before it is read back
-    HIPCHK(c, hipMemcpyAsync(dst, c->fbs[fb].d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dst, c->fbs[fb].d, (size_t)n * sizeof(klt_feat), down(c->fbs[fb]), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return KLT_OK;
 }
@@ -54,7 +60,7 @@ int klt_featbuf_download_async(klt_ctx *c, int fb, klt_feat *dst, int n)
         return fail(c, KLT_ERR_ARG, "klt_featbuf_download_async needs pinned host memory (klt_host_alloc)");
     }
     if (int rc = klt_comm_fence_async(c)) return rc;        // a gathered table is complete before it is read back
-    HIPCHK(c, hipMemcpyAsync(dst, c->fbs[fb].d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dst, c->fbs[fb].d, (size_t)n * sizeof(klt_feat), down(c->fbs[fb]), c->stream));
     if (int rc = fresh_event(c, &c->ev_download, &c->download_serial)) return rc;
     HIPCHK(c, hipEventRecord(c->ev_download, c->stream));
     c->download_pending = true;

@@ -10,6 +10,7 @@ from __future__ import print_function
 from . import selectGoodFeatures as _sgf
 import numpy as np
 
+from ._abi import KltBackendError
 from .backend import context_of, default_context  # noqa: F401
 from .klt import KLTCountRemainingFeatures, kltState, shared_store  # noqa: F401
 from ._frames import FrameKey, KLTForgetFrames, cache_of, settle_frames  # noqa: F401
@@ -368,7 +369,10 @@ def _track_locked(ctx, tc, img1, img2, featurelist):
     if tc.sequentialMode and not affine and tc.__dict__.pop("_klt_replaced_after_track", False) and _prepared_scores_pay(tc, ncols, nrows):
         marked = ctx.track_mark()
         if marked:
-            ctx.select_prepare(s2)
+            try:
+                ctx.select_prepare(s2)
+            except KltBackendError:                         # (an optimisation only: the replacement scores the frame itself then)
+                pass
     fl_out = ctx.track_complete(nfeat, marked=marked)
     if affine:
         rec = ctx.affine_download(state, nfeat)

@@ -576,3 +576,47 @@ def test_sequential_mode_downloads_no_plane_nobody_looks_at(monkeypatch):
     tc2 = make_tc(**_CASES[k]["tc"])
     want = trk.ComputeImagePyramids(tc2, frames[5], frames[6])[3]
     assert np.array_equal(kept.img[0], want.img[0]) and np.array_equal(kept.img[tc.nPyramidLevels - 1], want.img[tc.nPyramidLevels - 1])
+
+
+def test_feature_buffers_mapped_into_pinned_host_memory():
+    """klt_featbuf_map_host: the tracker reads and writes pinned host records in place -- same records as through device buffers and two
+    copies; the ordinary copies still work on a mapped buffer; pageable memory is refused; unmapping empties the buffer; the Python
+    layer unmaps before it frees the pinned arrays of a list length it evicts."""
+    from pyfeaturetrack_amd.backend import Context, FEAT_DTYPE, KltBackendError
+    c = Context(0)
+    try:
+        c.configure(make_tc(levels=2, ss=4, max_residue=10.0))
+        f0, f1 = synth.synth_pair(640, 480, seed=9)
+        c.upload(0, f0)
+        c.upload(1, f1)
+        c.build_pyramids_batch([0, 1], sync=True)
+        n = 300
+        fl, _ = c.select(0, n)
+        want, _ = c.track(0, 1, fl)                                   # device buffers, synchronous copies
+        rin, rout = c.pinned_array((n,), FEAT_DTYPE), c.pinned_array((n,), FEAT_DTYPE)
+        rin[...] = fl
+        rout["val"] = 77
+        c._check(c._lib.klt_featbuf_map_host(c._h, 40, rin.ctypes.data, n))
+        c._check(c._lib.klt_featbuf_map_host(c._h, 41, rout.ctypes.data, n))
+        c.track_async(0, 1, 40, 41, n)
+        c.sync()
+        assert rout.tobytes() == want.tobytes(), "records written in place differ from the copied ones"
+        assert c.featbuf_download(41, n).tobytes() == want.tobytes()            # an ordinary download of a mapped buffer
+        c.featbuf_upload(40, want)                                              # ... and an upload into one: lands in the host array
+        assert rin.tobytes() == want.tobytes()
+        with pytest.raises(KltBackendError, match="pinned"):
+            c._check(c._lib.klt_featbuf_map_host(c._h, 42, np.zeros(n, FEAT_DTYPE).ctypes.data, n))
+        c._check(c._lib.klt_featbuf_map_host(c._h, 41, None, 0))                # unmapped: empty
+        with pytest.raises(KltBackendError):
+            c.featbuf_download(41, n)
+        c.track_async(0, 1, 40, 41, n)                                          # ... and usable as an ordinary device buffer again
+        assert c.featbuf_download(41, n)["val"].tolist() == c.track(0, 1, want)[0]["val"].tolist()
+        # the API's own mapping follows its pinned arrays: nine list lengths evict the first pair of arrays while it is mapped
+        for k in range(9):
+            m = 50 + k
+            c.host_records(m)[0][...] = fl[:m]
+            c.track_enqueue(0, 1, m)
+            got = c.track_complete(m)
+            assert got.tobytes() == want[:m].tobytes(), m
+    finally:
+        c.close()
