@@ -394,7 +394,7 @@ _getrefcount = getattr(_sys, "getrefcount", None)
 RECYCLE_FEATURE_OBJECTS = _getrefcount is not None and _os.environ.get("KLT_NO_FEATURE_RECYCLING") != "1"
 _POOL_LENGTHS, _POOL_DEPTH = 4, 2
 _pool = {}                      # list length -> [(store, canon), ...] (newest last)
-_pool_lock = _threading.Lock()
+_pool_lock = _threading.RLock()         # re-entrant: the collector may finalize another dropped list while `_offer` holds it
 
 
 def _offer(store, canon):
