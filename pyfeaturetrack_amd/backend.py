@@ -385,23 +385,34 @@ class Context:
         cache[n] = pair                                            # (re-inserted last: dicts keep insertion order)
         return pair
 
-    def select_records(self, slot, n, mode=SELECTING_ALL, use_pyramid=False, fb=65533):
+    def select_records(self, slot, n, mode=SELECTING_ALL, use_pyramid=False, fb=None):
         """klt_select for the host API without its spare round trips: SELECTING_ALL needs no list on the way in (every slot is
         written), REPLACING_SOME sends host_records(n)[0] (filled by the caller) without waiting for the copy; one download brings
         the records back into host_records(n)[1], which is returned."""
         self.select_enqueue(slot, n, mode, use_pyramid, fb)
         return self.select_complete(n, fb)
 
-    def select_enqueue(self, slot, n, mode=SELECTING_ALL, use_pyramid=False, fb=65533):
-        """First half of select_records: the list goes up (REPLACING_SOME) and everything up to the host's look at the outcome is
-        enqueued (klt_select_begin_async); the caller does its own host work, then calls select_complete."""
-        if mode == REPLACING_SOME:
+    def select_enqueue(self, slot, n, mode=SELECTING_ALL, use_pyramid=False, fb=None):
+        """First half of select_records: everything up to the host's look at the outcome is enqueued (klt_select_begin_async) on the
+        list in host_records(n)[0] (filled by the caller for REPLACING_SOME); the caller does its own host work, then calls
+        select_complete.  With MAP_RECORDS (the default) the feature buffer IS that pinned array -- the kernels update it in place, no
+        copy either way; otherwise the list goes up first."""
+        if fb is None:
+            fb = _FB_API_IN if MAP_RECORDS else 65533
+        if MAP_RECORDS and fb == _FB_API_IN:
+            self._map_records(n, _FB_API_IN, _FB_API_OUT)
+        elif mode == REPLACING_SOME:
             self._check(self._lib.klt_featbuf_upload_async(self._h, fb, self.host_records(n)[0].ctypes.data, n))
         self._check(self._lib.klt_select_begin_async(self._h, slot, mode, int(bool(use_pyramid)), fb, n))
 
-    def select_complete(self, n, fb=65533):
-        """Second half: waits for the selection (klt_select_finish) and brings the records back into host_records(n)[1]."""
+    def select_complete(self, n, fb=None):
+        """Second half: waits for the selection (klt_select_finish); the records are host_records(n)[0] itself when the buffer is
+        mapped, else they come back into host_records(n)[1] with one download."""
+        if fb is None:
+            fb = _FB_API_IN if MAP_RECORDS else 65533
         self._check(self._lib.klt_select_finish(self._h))
+        if MAP_RECORDS and fb == _FB_API_IN:
+            return self.host_records(n)[0]
         rout = self.host_records(n)[1]
         self._check(self._lib.klt_featbuf_download(self._h, fb, rout.ctypes.data, n))
         return rout

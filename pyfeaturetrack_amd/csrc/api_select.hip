@@ -100,7 +100,7 @@ int select_job_finish(klt_ctx *c, SelectJob &j)
         if (rem[j.look - 1] != 0u) {
             // a dependency chain longer than the passes run so far: put the list back and keep going
             if (j.round + j.rounds_per_look > SelectJob::kMaxRounds) return fail(c, KLT_ERR_DEVICE, "minimum-distance passes did not settle");
-            HIPCHK(c, hipMemcpyAsync(j.fl, c->fl_snapshot, (size_t)j.n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(j.fl, c->fl_snapshot, (size_t)j.n * sizeof(klt_feat), hipMemcpyDefault /* the list may be pinned host memory (klt_featbuf_map_host) */, c->stream));
             if (j.by_rank) launch_zero_words(c->stream, j.rank_d, (size_t)j.bound);
             else HIPCHK(c, hipMemsetAsync(c->keys2, 0, (size_t)j.np2 * sizeof(unsigned long long), c->stream));
             if (int rc = select_job_rounds(c, j)) return rc;
@@ -116,7 +116,7 @@ int select_job_finish(klt_ctx *c, SelectJob &j)
         c->sorted_keys = j.by_rank ? nullptr : c->keys2; c->sorted_count = j.by_rank ? 0 : (int)j.np2;
         // ran out of accepted candidates although the prefilter dropped some: repeat with every candidate
         if (j.filtered && res[1] && info[1] < info[2]) {
-            HIPCHK(c, hipMemcpyAsync(j.fl, c->fl_snapshot, (size_t)j.n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(j.fl, c->fl_snapshot, (size_t)j.n * sizeof(klt_feat), hipMemcpyDefault, c->stream));
             j.attempt = 1;
             if (int rc = select_job_start(c, j)) return rc;
             if (int rc = select_job_rounds(c, j)) return rc;
@@ -496,7 +496,7 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
         while (np2 < kept) np2 <<= 1;
         if (kept < np2) HIPCHK(c, hipMemsetAsync(c->keys2 + kept, 0, (size_t)(np2 - kept) * sizeof(unsigned long long), c->stream));
         { TimerScope t(c, F_SORT, (double)np2 * 16); launch_sort_desc(c->stream, c->keys2, (int)np2); }
-        HIPCHK(c, hipMemcpyAsync(c->fl_snapshot, b->d, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->fl_snapshot, b->d, (size_t)n * sizeof(klt_feat), hipMemcpyDefault, c->stream));
         if (int rc = run_nms(c->keys2, (int)kept)) return rc;
         c->sorted_keys = c->keys2; c->sorted_count = (int)kept;
         int res[2] = {0, 0};
@@ -504,7 +504,7 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (!(res[1] && kept < valid)) { HIPCHK(c, hipGetLastError()); return KLT_OK; }
         // the kept candidates ran out before the list was full: restore the list and take the full sort
-        HIPCHK(c, hipMemcpyAsync(b->d, c->fl_snapshot, (size_t)n * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b->d, c->fl_snapshot, (size_t)n * sizeof(klt_feat), hipMemcpyDefault, c->stream));
     }
     { TimerScope t(c, F_SORT, (double)npow2 * 16); launch_sort_desc(c->stream, c->keys, (int)npow2); }
     if (int rc = run_nms(c->keys, (int)(ncand < npow2 ? ncand : npow2))) return rc;

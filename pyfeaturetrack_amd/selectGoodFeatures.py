@@ -209,11 +209,12 @@ def _select_locked(ctx, tc, img, nFeatures, mode, featurelist):
         ctx.upload(slot, image_to_array(img))
     replacing = mode == selectionMode.REPLACING_SOME
     n = int(nFeatures) if featurelist is None else len(featurelist)
-    store = fl_in = aff = None
+    store = fl_in = aff = was_lost = None
     if featurelist is not None:
         store = shared_store(featurelist)
         if replacing:
             fl_in = features_to_array(featurelist, ctx.host_records(n)[0], store)
+            was_lost = fl_in["val"] < 0                 # (before the device updates that array in place)
         from .trackFeatures import affine_state_lookup
         aff = affine_state_lookup(ctx, featurelist)
     if aff is not None and aff[1] == n:
@@ -237,7 +238,7 @@ def _select_locked(ctx, tc, img, nFeatures, mode, featurelist):
     if store is not None:
         # whole columns at once (selectGoodFeatures.py:109-128 touches every feature object in a Python loop)
         if replacing:
-            placed = fl_in["val"] < 0                                         # live features are left untouched (:109-110)
+            placed = was_lost                                                 # live features are left untouched (:109-110)
             np.logical_and(placed, vals >= 0, out=placed)
             touched = placed
             np.copyto(store.x, fl["x"], where=placed)                         # integer positions (:116-119)
@@ -257,9 +258,9 @@ def _select_locked(ctx, tc, img, nFeatures, mode, featurelist):
             store.reset_affine(touched)
         return featurelist
     xs, ys, vals = fl["x"].tolist(), fl["y"].tolist(), vals.tolist()
-    olds = fl_in["val"].tolist() if replacing else None
+    lost = was_lost.tolist() if replacing else None
     for i, feat in enumerate(featurelist):
-        if olds is not None and olds[i] >= 0:
+        if lost is not None and not lost[i]:
             continue                # live features are left untouched (:109-110)
         if vals[i] >= 0:
             feat.x = int(xs[i])
