@@ -22,7 +22,7 @@ def api_figures(pair, tc):
             fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
             trk.KLTTrackFeatures(tc, f0, f1, fl)
             g1 = f1.copy()
-            for k in range(10):
+            for k in range(30):
                 t = time.perf_counter()
                 fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
                 t_sel.append(time.perf_counter() - t)
@@ -33,7 +33,7 @@ def api_figures(pair, tc):
                 t_trk.append(time.perf_counter() - t)
             # example1's ping-pong (example1.py:53-56): the same two images, back and forth
             fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
-            for k in range(20):
+            for k in range(40):
                 a, b = (f0, f1) if k % 2 == 0 else (f1, f0)
                 t = time.perf_counter()
                 trk.KLTTrackFeatures(tc, a, b, fl)
@@ -50,7 +50,7 @@ def api_figures(pair, tc):
             trk.KLTForgetFrames(tc)
             fl = sgf.KLTSelectGoodFeatures(tc, clip[0], NFEAT)
             ts = []
-            for k in range(36):
+            for k in range(64):
                 a, b = clip[order[k % 30]], clip[order[(k + 1) % 30]]
                 t = time.perf_counter()
                 trk.KLTTrackFeatures(tc, a, b, fl)
@@ -92,14 +92,14 @@ def api_figures(pair, tc):
             order = list(range(16)) + list(range(14, 0, -1))
             fl = sgf.KLTSelectGoodFeatures(tcs, clip[0], NFEAT)
             best = None
-            for rep in range(3):
+            for rep in range(6):                                   # (the first pass is the warm-up: slots, pinned buffers, score sets)
                 t = time.perf_counter()
                 for k in range(1, nframes):
                     prev, cur = clip[order[(k - 1) % 30]], clip[order[k % 30]]
                     trk.KLTTrackFeatures(tcs, prev, cur, fl)
                     sgf.KLTReplaceLostFeatures(tcs, cur, fl)
                 ms = (time.perf_counter() - t) * 1e3 / (nframes - 1)
-                best = ms if best is None else min(best, ms)
+                best = ms if best is None or rep == 1 else min(best, ms)
             return best
 
         exact, trusting, fresh = measure(False), measure(True), measure(False, True)
@@ -121,7 +121,8 @@ def api_figures(pair, tc):
                             "sequence); api_trusting_* = the opt-in tc.trustFrameIdentity shortcut (object identity + 1024 sampled pixels); "
                             "new_frame_each_call = frame 2 differs by one pixel in every call (compare, copy to pinned memory, DMA, pyramid, track); "
                             "consecutive_frames = a clip walked pair by pair in non-sequential mode (frame 1 resident from the call before, frame 2 new); "
-                            "sequential_mode_loop = tc.sequentialMode, per frame KLTTrackFeatures + KLTReplaceLostFeatures (63 frames, best of 3)"}
+                            "sequential_mode_loop = tc.sequentialMode, per frame KLTTrackFeatures + KLTReplaceLostFeatures (63 frames, best of 5 after a warm-up pass); "
+                            "per-call figures are medians of 30-64 calls"}
     finally:
         sgf.KLT_verbose = trk.KLT_verbose = v0
 

@@ -408,6 +408,14 @@ def run_cfg2(args, json_fd):
     if line is not None and isinstance(extra, dict) and not args.no_extras and not distributed:
         if not args.no_api:
             extra.update(api_figures_in_a_child_process())
+            # ... and once more with the child confined to eight CPUs of the GPU's NUMA node, as a deployment would pin it: the host part of a
+            # call (frame comparison on the pool's lanes, column moves) stops migrating between the box's 256 CPUs -- the same figures with a
+            # third of the run-to-run spread.  The unpinned ones above stay the headline of the API.
+            cpus = gpu_numa_cpus(ranks.local_rank)
+            if cpus and "api_error" not in extra:
+                pinned = api_figures_in_a_child_process(cpus=cpus)
+                extra["api_pinned_to_the_gpus_numa_node"] = dict({k: v for k, v in pinned.items() if k.startswith("api_ms") or k == "api_error"},
+                                                                 cpus=cpus)
         if not args.no_sequences:
             link = extra.get("pcie_link") or {}
             extra["sequence_from_host"] = {"1080p": sequence_from_host(ranks.local_rank, 1920, 1080, 5000, 256, link.get("1080p")),
@@ -519,14 +527,34 @@ def link_rates():
         return {}
 
 
-def api_figures_in_a_child_process(timeout=600):
+def gpu_numa_cpus(device=0, count=8):
+    """the first `count` CPUs of the NUMA node the GPU hangs off (sysfs), or None"""
+    try:
+        import glob
+        nodes = sorted(glob.glob("/sys/class/drm/card*/device/numa_node"))
+        node = int(open(nodes[min(device, len(nodes) - 1)]).read())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.extend(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0)
+        cpus = [c for c in cpus if c in allowed][:count]
+        return cpus if len(cpus) >= 4 else None
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def api_figures_in_a_child_process(timeout=600, cpus=None):
     """`python -m benchlib.api_figures` as a child process: what a caller of the reference-shaped API sees in a process of its OWN -- this
     one has run the headline, the parity checks (32 OpenMP threads of the oracle) and a dozen probes, and the same calls read 5-30 % slower
     inside it than in a fresh interpreter (KLTTrackSequence 0.166-0.214 against 0.147 ms per 1080p frame).  The child opens the GPU itself;
-    this process only waits for it."""
+    this process only waits for it.  `cpus`: the child is confined to these CPUs before it starts (sched_setaffinity)."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, "-m", "benchlib.api_figures"], cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run([sys.executable, "-m", "benchlib.api_figures"], cwd=ROOT, capture_output=True, text=True, timeout=timeout,
+                           preexec_fn=(lambda: os.sched_setaffinity(0, cpus)) if cpus else None)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"api_error": "benchlib.api_figures exited with %d: %s" % (r.returncode, r.stderr[-400:])}
