@@ -34,6 +34,7 @@ c1, c3, c4s, c4, c5 = L("_cfg1"), L("_cfg3"), L("_cfg4_shard32"), L("_cfg4_256_r
 k3 = c3["roofline"]["kernels"]
 traffic = json.load(open(os.path.join(P, "r05_%s_pmc_traffic.json" % tag)))
 t7, t15 = e["tracker_tree_sums"], c3["extra"]["tracker_tree_sums"]
+pin = e["api_pinned_to_the_gpus_numa_node"]
 gpu_tests = os.environ.get("KLT_NGPU", "189")
 cpu_tests = os.environ.get("KLT_NCPU", "56")
 v = {
@@ -63,6 +64,11 @@ v = {
     "API_PP": "%.3f" % e["api_ms_per_KLTTrackFeatures_pingpong"], "API_SEL": "%.3f" % e["api_ms_per_KLTSelectGoodFeatures"],
     "API_CLIP": "%.3f" % e["api_ms_per_KLTTrackFeatures_consecutive_frames"], "API_FRESH": "%.3f" % e["api_ms_per_KLTTrackFeatures_new_frame_each_call"],
     "API_SEQLOOP": "%.3f" % e["api_ms_per_frame_sequential_mode_loop"], "TAG": tag,
+    "API_PP_P": "%.3f" % pin["api_ms_per_KLTTrackFeatures_pingpong"], "API_SEL_P": "%.3f" % pin["api_ms_per_KLTSelectGoodFeatures"],
+    "API_CLIP_P": "%.3f" % pin["api_ms_per_KLTTrackFeatures_consecutive_frames"], "API_FRESH_P": "%.3f" % pin["api_ms_per_KLTTrackFeatures_new_frame_each_call"],
+    "API_SEQLOOP_P": "%.3f" % pin["api_ms_per_frame_sequential_mode_loop"],
+    "API_SEQ1080_P": "%.3f" % pin["api_ms_per_frame_KLTTrackSequence"]["1080p_5000_features_256_frames"],
+    "API_SEQ4K_P": "%.3f" % pin["api_ms_per_frame_KLTTrackSequence"]["4k_20000_features_256_frames"],
     "API_SEQ1080": "%.3f" % e["api_ms_per_frame_KLTTrackSequence"]["1080p_5000_features_256_frames"],
     "API_SEQ4K": "%.3f" % e["api_ms_per_frame_KLTTrackSequence"]["4k_20000_features_256_frames"],
     "TREE7_US": "%.1f" % t7["us_per_launch"], "TREE7_EX": "%.1f" % t7["us_per_launch_exact"], "TREE7_X": "%.2f" % t7["speedup"],
@@ -79,10 +85,3 @@ if missing:
 for name, val in v.items():
     text = text.replace("@%s@" % name, val)
 open(dst, "w").write(text)
-# INTEGRATION.md carries a few of the same figures
-ipath = os.path.join(ROOT, "INTEGRATION.md")
-itext = open(ipath).read()
-for name, val in v.items():
-    itext = itext.replace("@%s@" % name, val)
-open(ipath, "w").write(itext)
-print("filled %d figures into %s (%d bytes)" % (len(v), dst, len(text.encode())))
