@@ -130,6 +130,8 @@ def api_figures(pair, tc):
 
 if __name__ == "__main__":
     from .common import cfg2_context
+    if os.environ.get("KLT_API_FIGURES_CPUS"):
+        os.sched_setaffinity(0, {int(c) for c in os.environ["KLT_API_FIGURES_CPUS"].split(",")})
     _fd = os.dup(1)                      # the HIP runtime / RCCL print to fd 1: the JSON goes to the saved descriptor
     os.dup2(2, 1)
     _tc = cfg2_context()

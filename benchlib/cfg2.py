@@ -550,11 +550,13 @@ def api_figures_in_a_child_process(timeout=600, cpus=None):
     """`python -m benchlib.api_figures` as a child process: what a caller of the reference-shaped API sees in a process of its OWN -- this
     one has run the headline, the parity checks (32 OpenMP threads of the oracle) and a dozen probes, and the same calls read 5-30 % slower
     inside it than in a fresh interpreter (KLTTrackSequence 0.166-0.214 against 0.147 ms per 1080p frame).  The child opens the GPU itself;
-    this process only waits for it.  `cpus`: the child is confined to these CPUs before it starts (sched_setaffinity)."""
+    this process only waits for it.  `cpus`: the child confines itself to these CPUs before it touches the GPU (sched_setaffinity)."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, "-m", "benchlib.api_figures"], cwd=ROOT, capture_output=True, text=True, timeout=timeout,
-                           preexec_fn=(lambda: os.sched_setaffinity(0, cpus)) if cpus else None)
+        env = dict(os.environ)
+        if cpus:                                            # (the child confines itself first thing: no code between fork and exec here)
+            env["KLT_API_FIGURES_CPUS"] = ",".join(str(c) for c in cpus)
+        r = subprocess.run([sys.executable, "-m", "benchlib.api_figures"], cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"api_error": "benchlib.api_figures exited with %d: %s" % (r.returncode, r.stderr[-400:])}
