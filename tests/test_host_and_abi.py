@@ -575,3 +575,108 @@ def test_tracker_register_counts_quoted_by_the_bench():
             names = [n for n in regs if "ILb1ELi%dELi%dELb%dE" % (window, waves, flag) in n]
             assert len(names) == 1, (window, form, sorted(regs))
             assert regs[names[0]]["vgpr"] == TRACKER_VGPRS[window][form], (window, form, regs[names[0]])
+
+
+def test_pair_arrangement_of_the_api_with_and_without_speculation():
+    """trackFeatures._prepare_pair (host logic only, against a recording stand-in for the device context): which frames are sent,
+    when the two slots are swapped, which frames are only TAKEN as resident (`doubts`, frame 2 first) for the caller to verify while
+    the device works -- for a first call, the same pair again, the pair reversed, a video step (frame 1 = the last frame 2), an
+    in-place edit off the lattice, the same image twice, and the mode without speculation (every byte compared first)."""
+    import threading
+    from pyfeaturetrack_amd import trackFeatures as trk
+    from pyfeaturetrack_amd._frames import cache_of
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+
+    class FakeCtx:
+        _h = object()
+
+        def __init__(self):
+            self.lock = threading.RLock()
+            self.log = []
+            self.has, self.valid = set(), set()
+            self._next = 0
+
+        def take_slots(self, n):
+            base, self._next = self._next, self._next + n
+            return base
+
+        def release_slots(self, base, n):
+            pass
+
+        def configured_for(self, tc):
+            return True
+
+        def configure(self, tc):
+            pass
+
+        def frame_resident(self, s):
+            return s in self.has
+
+        def pyramids_valid(self, s):
+            return s in self.valid
+
+        def slot_generation(self, s):
+            return 1
+
+        def upload(self, s, arr):                      # (no upload_async attribute: FrameCache.send takes the synchronous path)
+            self.log.append(("send", s))
+            self.has.add(s)
+            self.valid.discard(s)
+
+        def build_pyramids(self, s, sync=True):
+            self.build_pyramids_batch([s])
+
+        def build_pyramids_batch(self, slots, sync=False):
+            self.log.append(("build", tuple(slots)))
+            self.valid.update(slots)
+
+        def swap_slots(self, a, b):
+            self.log.append(("swap", a, b))
+            for group in (self.has, self.valid):
+                ia, ib = a in group, b in group
+                group.discard(a), group.discard(b)
+                if ia:
+                    group.add(b)
+                if ib:
+                    group.add(a)
+
+    def frame(seed):
+        return np.random.default_rng(seed).integers(0, 255, (480, 640), dtype=np.uint8)
+
+    def run(tc, ctx, a, b, speculate):
+        del ctx.log[:]
+        s1, s2, ncols, nrows, doubts = trk._prepare_pair(tc, ctx, a, b, speculate=speculate)
+        assert (ncols, nrows) == (640, 480)
+        return (s1, s2), [(s, k.img) for s, k in doubts], list(ctx.log)
+
+    for speculate in (True, False):
+        tc, ctx = KLT_TrackingContext(), FakeCtx()
+        tc.__dict__["_klt_ctx"] = ctx
+        f0, f1, f2 = frame(0), frame(1), frame(2)
+        (s1, s2), doubts, log = run(tc, ctx, f0, f1, speculate)
+        assert (s1, s2) == (0, 1) and doubts == [] and log == [("send", 1), ("send", 0), ("build", (1, 0))], "first call"
+        (_, _), doubts, log = run(tc, ctx, f0, f1, speculate)
+        assert log == [] and [s for s, _ in doubts] == ([1, 0] if speculate else []), "the same pair again"
+        assert all(cache_of(tc).verify(trk.FrameKey(img), s) for s, img in doubts)
+        (_, _), doubts, log = run(tc, ctx, f1, f0, speculate)
+        assert log == [("swap", 0, 1)] and [(s, img is f0) for s, img in doubts] == ([(1, True), (0, False)] if speculate else []), "reversed"
+        (_, _), doubts, log = run(tc, ctx, f0, f2, speculate)                       # video step: f0 sits in slot 2 now
+        assert log == [("swap", 0, 1), ("send", 1), ("build", (1,))], log
+        assert [(s, img is f0) for s, img in doubts] == ([(0, True)] if speculate else [])
+        f2[101, 7] ^= 1                                                            # off the lattice (rows % 15, columns % 20)
+        (_, _), doubts, log = run(tc, ctx, f0, f2, speculate)
+        if speculate:
+            assert log == [] and [s for s, _ in doubts] == [1, 0]
+            assert not cache_of(tc).verify(trk.FrameKey(f2), 1) and cache_of(tc).verify(trk.FrameKey(f0), 0)
+            trk._resend(tc, ctx, 1, trk.FrameKey(f2))
+            assert ctx.log == [("send", 1), ("build", (1,))] and cache_of(tc).verify(trk.FrameKey(f2), 1)
+        else:
+            assert log == [("send", 1), ("build", (1,))] and doubts == []
+        (_, _), doubts, log = run(tc, ctx, f2, f2, speculate)                       # the same image as both frames
+        assert log == [("swap", 0, 1), ("send", 1), ("build", (1,))], log          # one copy stays (as frame 1 now), the other slot gets the image too
+        tc.sequentialMode = True                                                   # sequential mode: only frame 2 is looked at
+        tc.pyramid_last = type("P", (), {"ncols": [640], "nrows": [480], "_gen": 1})()
+        (_, _), doubts, log = run(tc, ctx, f0, f1, speculate)
+        assert log == [("send", 1), ("build", (1,))] and doubts == []
+        (_, _), doubts, log = run(tc, ctx, f0, f1, speculate)
+        assert log == [] and [s for s, _ in doubts] == ([1] if speculate else [])
