@@ -180,7 +180,8 @@ int   klt_featbuf_download(klt_ctx *ctx, int fb, klt_feat *dst, int n);
 int   klt_featbuf_download_async(klt_ctx *ctx, int fb, klt_feat *dst, int n);
 int   klt_download_wait(klt_ctx *ctx);                        /* host waits for the latest klt_featbuf_download_async / klt_download_mark_async */
 /* marks this point of the main stream for klt_download_wait without copying anything: for records the kernels write straight into pinned
- * memory (klt_featbuf_map_host) when more work is enqueued behind the kernel that writes them */
+ * memory (klt_featbuf_map_host) when more work is enqueued behind the kernel that writes them -- KLTTrackFeatures (trackFeatures.py:205-409)
+ * waits for its tracker only while the scores of the KLTReplaceLostFeatures call that follows are already being computed */
 int   klt_download_mark_async(klt_ctx *ctx);
 /* Feature buffer `fb` becomes `n` records of PINNED host memory (klt_host_alloc), read and written in place by the kernels over the
  * link: a call that sends a list, tracks it and waits (KLTTrackFeatures, trackFeatures.py:205-409) then needs no copy command in either
