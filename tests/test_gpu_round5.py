@@ -631,3 +631,45 @@ def test_feature_buffers_mapped_into_pinned_host_memory():
             assert got.tobytes() == want[:m].tobytes(), m
     finally:
         c.close()
+
+
+def test_enforce_minimum_distance_on_random_point_lists_vs_the_checker():
+    """selectGoodFeatures._enforceMinimumDistance (klt_min_distance_walk) against oracle/min_distance_walk.py -- the plain-Python
+    restatement pinned to the reference's own outputs -- on 60 random cases: frames from 64 x 48 to 2400 x 1800 (with a small
+    minimum distance the walk's occupancy grid no longer fits in LDS: the global-memory grid), 0 .. 6000 points in any order with
+    duplicates and sub-threshold values, lists of 1 .. 900 features with any share alive, minimum distances 0 .. 40, both modes."""
+    from oracle.min_distance_walk import enforce_minimum_distance
+    from pyfeaturetrack_amd.klt import new_feature_list
+    sgf, _ = _api_modules()
+    rng = np.random.default_rng(2026)
+    big = 0
+    for case in range(60):
+        ncols, nrows = (int(rng.integers(64, 400)), int(rng.integers(48, 300))) if case % 3 else (int(rng.integers(1500, 2400)), int(rng.integers(1200, 1800)))
+        mindist = int(rng.choice([0, 1, 2, 3, 5, 10, 17, 40]))
+        npts = int(rng.integers(0, 6000 if case % 3 == 0 else 1500))
+        nfeat = int(rng.integers(1, 900 if case % 3 == 0 else 200))
+        overwrite = bool(rng.integers(0, 2))
+        min_eig = float(rng.choice([0.2, 1, 1, 30, 400]))
+        px, py = rng.integers(0, ncols, npts), rng.integers(0, nrows, npts)
+        pv = (rng.random(npts) * 1000).astype(np.float32)
+        pv[rng.random(npts) < 0.1] = 0.5
+        if npts > 8:
+            px[3:6], py[3:6] = px[2], py[2]
+        if rng.integers(0, 2):
+            o = np.argsort(-pv, kind="stable")
+            px, py, pv = px[o], py[o], pv[o]
+        points = [(float(v), int(x), int(y)) for v, x, y in zip(pv, px, py)]
+        fl = new_feature_list(nfeat)
+        feats = []
+        alive = rng.random(nfeat) < rng.choice([0.0, 0.3, 0.9])
+        for f, a in zip(fl, alive):
+            if a:
+                f.x, f.y, f.val = float(np.float32(rng.uniform(0, ncols - 1))), float(np.float32(rng.uniform(0, nrows - 1))), int(rng.integers(0, 900))
+            feats.append([f.x, f.y, f.val])
+        big += ((ncols + max(mindist - 1, 0)) // max(mindist, 1)) * ((nrows + max(mindist - 1, 0)) // max(mindist, 1)) * 4 > 128 * 1024
+        sgf._enforceMinimumDistance(points, fl, ncols, nrows, mindist, min_eig, overwrite)
+        enforce_minimum_distance(points, feats, ncols, nrows, mindist, min_eig, overwrite)
+        have = np.array([(f.x, f.y, f.val) for f in fl], np.float64)
+        assert np.array_equal(have, np.array(feats, np.float64)), \
+            "case %d: %dx%d, %d points, %d features, mindist %d, min_eig %g, overwrite %d" % (case, ncols, nrows, npts, nfeat, mindist, min_eig, overwrite)
+    assert big >= 5, "no case with the occupancy grid in global memory"

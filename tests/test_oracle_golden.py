@@ -267,3 +267,16 @@ def test_random_draws_the_reference_ran(golden_dir):
         # the second call (tracked, replaced and lost features in one list; in sequential mode the reference reused frame 1's pyramids)
         ko.track_features(p, ko.Pyramids(p, f1.astype(np.float32)), ko.Pyramids(p, t["frame2"].astype(np.float32)), fl)
         assert draw_equal(fl, want["trk2"]), "second tracking call differs from the reference: %r" % ({k: v for k, v in t.items() if k != "frame2"},)
+
+
+def test_min_distance_walk_restatement_vs_reference(golden_dir):
+    """oracle/min_distance_walk.py (the plain-Python checker of the literal _enforceMinimumDistance) against what the reference's
+    function returned for eight unsorted point lists (tests/golden/literal_boundary.npz, generated by running the reference)."""
+    import os
+    from oracle.min_distance_walk import enforce_minimum_distance
+    g = np.load(os.path.join(golden_dir, "literal_boundary.npz"))
+    for ci, (ncols, nrows, mindist, min_eig, overwrite) in enumerate(g["emd_cases"]):
+        points = [(float(v), int(x), int(y)) for v, x, y in g["emd_%d_points" % ci]]
+        feats = [list(r) for r in g["emd_%d_in" % ci]]
+        enforce_minimum_distance(points, feats, int(ncols), int(nrows), int(mindist), float(min_eig), bool(overwrite))
+        assert np.array_equal(np.array(feats, np.float64), g["emd_%d_out" % ci]), ci
