@@ -125,6 +125,18 @@ class KLT_TrackingContext:
         self.bordery = border
 
 
+class _StaleColumn:
+    """What a store's lx / ly / lv are while the plain-list form of the columns is out of date: indexing it rebuilds the three lists
+    (which replace the stand-ins on the store) and answers from the new one."""
+    __slots__ = ("_store", "_k")
+
+    def __init__(self, store_ref, k):
+        self._store, self._k = store_ref, k
+
+    def __getitem__(self, i):
+        return self._store()._lists()[self._k][i]
+
+
 class _FeatureStore:
     """Column storage behind the KLT_Feature objects of one feature list.
 
@@ -137,7 +149,7 @@ class _FeatureStore:
     The store does not point at its feature objects (they point at it): a dropped list is freed by reference counting, not by the
     cycle collector.  `owner` is a weak reference to the KLT_FeatureList that was made with the store."""
 
-    __slots__ = ("x", "y", "val", "xint", "yint", "aff", "aff_img", "owner", "hooks", "__weakref__")
+    __slots__ = ("x", "y", "val", "xint", "yint", "aff", "aff_img", "owner", "hooks", "lx", "ly", "lv", "_stale", "__weakref__")
     _AFF_DEFAULTS = (("aff_x", -1.0), ("aff_y", -1.0), ("aff_Axx", 1.0), ("aff_Ayx", 0.0), ("aff_Axy", 0.0), ("aff_Ayy", 1.0))
 
     def __init__(self, n):
@@ -150,6 +162,13 @@ class _FeatureStore:
         self.aff_img = None           # {name: object column} for aff_img / aff_img_gradx / aff_img_grady
         self.owner = None             # weakref to the KLT_FeatureList whose `_canon` lists the objects of rows 0 .. n-1
         self.hooks = None             # callbacks for the end of the features' life (device-side affine state: trackFeatures.py)
+        # lx / ly / lv: the columns as plain lists of the Python values the features show (ints where the reference holds ints) -- what a
+        # feature's x / y / val read, one C-level list index per attribute.  After the columns were written (`changed()`) they are
+        # stand-ins (`_StaleColumn`) that rebuild all three lists when first indexed: a loop over every feature of a list pays one
+        # conversion per column instead of two numpy scalar reads per attribute, a loop that never looks at a feature pays nothing.
+        ref = _weakref.ref(self)
+        self._stale = (_StaleColumn(ref, 0), _StaleColumn(ref, 1), _StaleColumn(ref, 2))
+        self.lx, self.ly, self.lv = self._stale
 
     def when_features_die(self, callback):
         """`callback()` runs when the KLT_FeatureList made with this store is dropped (what is keyed by that list -- the device-side
@@ -159,6 +178,19 @@ class _FeatureStore:
         if self.hooks is None:
             self.hooks = []
         self.hooks.append(callback)
+
+    def changed(self):
+        """the columns were written (a KLT* call, a feature's setter): the lists the features read from are stale"""
+        self.lx, self.ly, self.lv = self._stale
+
+    def _lists(self):
+        def column(values, ints):
+            o = values.astype(object)                              # Python floats ...
+            if ints.any():
+                o[ints] = values[ints].astype(np.int64).astype(object)      # ... and Python ints where the reference holds ints
+            return o.tolist()
+        self.lx, self.ly, self.lv = ls = (column(self.x, self.xint), column(self.y, self.yint), self.val.tolist())
+        return ls
 
     def _run_hooks(self):
         hooks, self.hooks = self.hooks, None
@@ -174,6 +206,7 @@ class _FeatureStore:
         self.xint.fill(True)
         self.yint.fill(True)
         self.aff = self.aff_img = self.owner = None
+        self.changed()
 
     def __len__(self):
         return self.x.shape[0]
@@ -201,20 +234,17 @@ class _FeatureStore:
 def _restored_store(x, y, val, xint, yint, aff, aff_img):
     s = _FeatureStore(0)
     s.x, s.y, s.val, s.xint, s.yint, s.aff, s.aff_img = x, y, val, xint, yint, aff, aff_img
+    s.changed()
     return s
 
 
-def _coord_property(col, flag):
-    def get(self):
-        s, i = self
-        v = getattr(s, col)[i]
-        return int(v) if getattr(s, flag)[i] else float(v)
-
+def _coord_setter(col, flag):
     def put(self, value):
         s, i = self
         getattr(s, col)[i] = value
         getattr(s, flag)[i] = isinstance(value, (int, np.integer)) and not isinstance(value, bool)
-    return property(get, put)
+        s.changed()
+    return put
 
 
 def _aff_property(name, dflt):
@@ -267,18 +297,18 @@ class KLT_Feature(tuple):
     _s = property(_itemgetter(0))
     _i = property(_itemgetter(1))
 
-    x = _coord_property("x", "xint")
-    y = _coord_property("y", "yint")
+    x = property(lambda self: self[0].lx[self[1]], _coord_setter("x", "xint"))       # (one attribute load + two C-level indexings)
+    y = property(lambda self: self[0].ly[self[1]], _coord_setter("y", "yint"))
 
     @property
     def val(self):
-        s, i = self
-        return int(s.val[i])
+        return self[0].lv[self[1]]
 
     @val.setter
     def val(self, value):
         s, i = self
         s.val[i] = value
+        s.changed()
 
     aff_x = _aff_property("aff_x", -1.0)
     aff_y = _aff_property("aff_y", -1.0)

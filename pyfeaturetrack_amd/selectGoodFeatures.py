@@ -152,6 +152,7 @@ def _enforceMinimumDistance(pointlist, featurelist, ncols, nrows, mindist, min_e
         np.logical_or(store.xint, touched, out=store.xint)
         np.logical_or(store.yint, touched, out=store.yint)
         store.reset_affine(touched)
+        store.changed()
         return featurelist
     xs, ys, vs = out["x"].tolist(), out["y"].tolist(), out["val"].tolist()
     for i in np.nonzero(touched)[0]:
@@ -256,6 +257,7 @@ def _select_locked(ctx, tc, img, nFeatures, mode, featurelist):
             store.yint[:] = True
         if affine_used:
             store.reset_affine(touched)
+        store.changed()
         return featurelist
     xs, ys, vals = fl["x"].tolist(), fl["y"].tolist(), vals.tolist()
     lost = was_lost.tolist() if replacing else None

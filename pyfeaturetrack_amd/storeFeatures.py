@@ -51,6 +51,7 @@ def KLTExtractFeatureList(fl, ft, frame):
         store.x[:], store.y[:], store.val[:] = row["x"], row["y"], row["val"]
         store.xint[:] = False
         store.yint[:] = False
+        store.changed()
         return
     for feat, x, y, v in zip(fl, row["x"].tolist(), row["y"].tolist(), row["val"].tolist()):
         feat.x, feat.y, feat.val = x, y, v

@@ -386,6 +386,7 @@ def _track_locked(ctx, tc, img1, img2, featurelist):
         np.copyto(store.val, fl_out["val"], where=live)
         np.logical_and(store.xint, dead, out=store.xint)      # tracked or lost: Python floats from here on
         np.logical_and(store.yint, dead, out=store.yint)
+        store.changed()
         if affine:
             ok = live & (fl_out["val"] == kltState.KLT_TRACKED)
             cols = store.aff_columns()

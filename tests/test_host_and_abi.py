@@ -680,3 +680,36 @@ def test_pair_arrangement_of_the_api_with_and_without_speculation():
         assert log == [("send", 1), ("build", (1,))] and doubts == []
         (_, _), doubts, log = run(tc, ctx, f0, f1, speculate)
         assert log == [] and [s for s, _ in doubts] == ([1] if speculate else [])
+
+
+def test_features_read_through_plain_lists_that_follow_the_columns():
+    """A feature's x / y / val come out of plain lists of Python values kept per store (one C-level index per read: a loop over 5000
+    features costs 1.5 instead of 4 ms); the lists are rebuilt on the first read after the columns were written (`changed()`), hold
+    Python ints where the reference holds ints, follow a feature's own setters, and add no reference cycle to the store."""
+    import gc
+    import weakref
+    from pyfeaturetrack_amd.klt import _StaleColumn, new_feature_list
+    fl = new_feature_list(6)
+    st = fl._store
+    assert all(type(c) is _StaleColumn for c in (st.lx, st.ly, st.lv))
+    assert [(f.x, f.y, f.val) for f in fl] == [(-1, -1, -1)] * 6 and type(st.lx) is list and type(fl[0].x) is int
+    st.x[:3] = [1.5, 2.25, 7.0]                                    # what a KLT* call does: whole columns, then changed()
+    st.xint[:3] = [False, False, True]
+    st.val[:3] = [0, -4, 12]
+    assert fl[0].x == -1, "the lists are only as fresh as the last changed()"
+    st.changed()
+    assert [(f.x, type(f.x)) for f in fl[:3]] == [(1.5, float), (2.25, float), (7, int)] and [f.val for f in fl[:3]] == [0, -4, 12]
+    fl[4].y = 3
+    fl[4].val = 5
+    assert (fl[4].x, fl[4].y, fl[4].val) == (-1, 3, 5) and type(fl[4].y) is int and st.y[4] == 3.0
+    fl[4].y = 3.5
+    assert fl[4].y == 3.5 and type(fl[4].y) is float and fl[3].y == -1
+    ref = weakref.ref(st)
+    gc.disable()
+    try:
+        del fl, st
+        from pyfeaturetrack_amd import klt
+        klt._pool.clear()                                          # (the dropped list's objects were offered for reuse)
+        assert ref() is None, "the store is kept alive by a cycle"
+    finally:
+        gc.enable()
