@@ -412,6 +412,12 @@ class Context:
             fb = _FB_API_IN if MAP_RECORDS else 65533
         self._check(self._lib.klt_select_finish(self._h))
         if MAP_RECORDS and fb == _FB_API_IN:
+            # klt_select_finish has waited for the parallel passes' last launch -- but the sorted serial walk (no candidates at all, an
+            # exclusion square too large for the passes' LDS tile, KLT_OPT_SELECT_PARALLEL_NMS = 0) completes inside
+            # klt_select_begin_async WITHOUT a host wait: the download that used to follow was that wait.  The records are only in the
+            # mapped array once the stream is idle (found by tests/fuzz/fuzz_seeds_r05.sh: 1 of 15 000 sequence trials; the regression
+            # test fails three times out of three without this line).
+            self._check(self._lib.klt_sync(self._h))
             return self.host_records(n)[0]
         rout = self.host_records(n)[1]
         self._check(self._lib.klt_featbuf_download(self._h, fb, rout.ctypes.data, n))

@@ -166,6 +166,10 @@ def run_sequence_trial(t):
     t["_stat"] = "frames %d, replace %d, ingest %d, prefetch %d, lost entries %d, replaced %d" % (
         nf, replace, ingest, prefetch, int((want.val[1:] < 0).sum()), int((want.val[1:] > 0).sum()))
     if not (np.array_equal(got.val, want.val) and np.array_equal(got.x, want.x) and np.array_equal(got.y, want.y)):
+        bad = np.argwhere((got.val != want.val) | (got.x != want.x) | (got.y != want.y))
+        t["_diff"] = "%d entries differ, first (frame, feature) %s: per-frame API (%g, %g, %d), KLTTrackSequence (%g, %g, %d)" % (
+            len(bad), tuple(bad[0]), want.x[tuple(bad[0])], want.y[tuple(bad[0])], want.val[tuple(bad[0])],
+            got.x[tuple(bad[0])], got.y[tuple(bad[0])], got.val[tuple(bad[0])])
         return "sequence table"
     return None
 

@@ -673,3 +673,53 @@ def test_enforce_minimum_distance_on_random_point_lists_vs_the_checker():
         assert np.array_equal(have, np.array(feats, np.float64)), \
             "case %d: %dx%d, %d points, %d features, mindist %d, min_eig %g, overwrite %d" % (case, ncols, nrows, npts, nfeat, mindist, min_eig, overwrite)
     assert big >= 5, "no case with the occupancy grid in global memory"
+
+
+def test_api_selection_is_complete_when_it_returns_on_every_selection_path():
+    """The API's selection lists are pinned host memory the kernels write in place (klt_featbuf_map_host); the call must not return before
+    the LAST kernel has written them on ANY path of the selection: the parallel passes (klt_select_finish waits), the sorted serial walk
+    (KLT_OPT_SELECT_PARALLEL_NMS = 0, or an exclusion square too large for the passes' tile: completes inside klt_select_begin_async
+    without a host wait), and a frame without a single candidate.  Found by tests/fuzz/fuzz_seeds_r05.sh (1 of 15 000 sequence trials
+    differed, not reproducibly).  Every call is compared with the synchronous ABI call on a context of its own; stale records of the
+    call before (another frame, the same list length) sit in the mapped array each time."""
+    from pyfeaturetrack_amd.backend import Context, context_of
+    from pyfeaturetrack_amd.params import params_from_tc
+    sgf, trk = _api_modules()
+    ref = Context(0)
+    try:
+        cases = [dict(size=(640, 480), tc=dict(levels=2, ss=4, mindist=10), serial=False),
+                 dict(size=(640, 480), tc=dict(levels=2, ss=4, mindist=10), serial=True),
+                 dict(size=(900, 700), tc=dict(levels=2, ss=2, mindist=130), serial=False),         # the passes' tile would not fit: serial walk
+                 dict(size=(168, 553), tc=dict(levels=4, ss=2, window=9, mindist=10), serial=False)]   # border 84: no candidate column
+        for case in cases:
+            w, h = case["size"]
+            tc = make_tc(**case["tc"])
+            frames = [synth.synth_frame(w, h, 77, k, shift=(2.0, 1.0)) for k in range(4)]
+            ctx = None
+            for rep in range(12):
+                f = frames[rep % 4]
+                if ctx is not None:
+                    ctx.set_option(8, 0 if case["serial"] else 1)
+                fl = sgf.KLTSelectGoodFeatures(tc, f, 150)
+                ctx = context_of(tc)
+                ref.configure(tc)
+                ref.set_option(8, 0 if case["serial"] else 1)
+                ref.upload(0, f)
+                ref.build_pyramids(0)
+                want, _ = ref.select(0, 150, use_pyramid=True)
+                have = np.array([(a.x, a.y, a.val) for a in fl], np.float64)
+                assert (np.array_equal(have[:, 2], want["val"].astype(np.float64)) and np.array_equal(have[:, 0], want["x"].astype(np.float64))
+                        and np.array_equal(have[:, 1], want["y"].astype(np.float64))), (case, rep)
+                # ... and a replacement on the next frame through the same mapped array
+                g = frames[(rep + 1) % 4]
+                trk.KLTTrackFeatures(tc, f, g, fl)
+                sgf.KLTReplaceLostFeatures(tc, g, fl)
+                ref.upload(1, g)
+                ref.build_pyramids(1)
+                out, _ = ref.track(0, 1, want)
+                rep_want, _ = ref.select(1, 150, mode=2, fl=out, use_pyramid=True)
+                have = np.array([(a.x, a.y, a.val) for a in fl], np.float64)
+                assert np.array_equal(have[:, 2], rep_want["val"].astype(np.float64)) and np.array_equal(have[:, 0], rep_want["x"].astype(np.float64)), (case, rep, "replacement")
+            ctx.set_option(8, 1)
+    finally:
+        ref.close()
