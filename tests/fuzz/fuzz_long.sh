@@ -8,3 +8,4 @@ t "sequence, frames up to 3 Mpx (seed 31338)" --trials 300 --seed 31338 --sequen
 t "batch (seed 31337)" --trials 2000 --seed 31337 --batch
 t "huge (seed 4243, frames up to 8.5 Mpx)" --trials 80 --seed 4243 --max-pixels 8500000 --max-n 20000 --max-side 3900
 t "prepared replacement vs oracle, frames of 0.3-0.7 Mpx (seed 777)" --trials 250 --seed 777 --prepared --min-pixels 300000 --max-pixels 700000 --max-n 3000 --max-side 1100
+t "Python API over random call sequences vs oracle (seed 8088)" --trials 3000 --seed 8088 --api

@@ -129,6 +129,76 @@ def run_prepared_trial(ctx, t):
     return None
 
 
+def run_api_trial(t):
+    """The reference-shaped Python API against the ORACLE over a random call sequence on one tracking context: KLTSelectGoodFeatures,
+    KLTTrackFeatures (any two of four frames, in any order; in sequential mode frame 1 is whatever frame 2 was last time),
+    KLTReplaceLostFeatures, frames edited in place between calls (a block anywhere: on or off the frame cache's lattice), a new list
+    now and then -- everything the Python layer does on the way (exact frame cache with its optimistic device work, lists mapped into
+    pinned memory, recycled feature objects, scores prepared ahead) must leave the reference's results."""
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf, trackFeatures as tf
+    sgf.KLT_verbose = tf.KLT_verbose = 0
+    rng = np.random.default_rng(t["seed"])
+    tc = make_tc(levels=t["levels"], ss=t["ss"], window=t["window"], max_residue=t["mr"], mindist=t["mindist"],
+                 nSkippedPixels=t["skip"], smoothBeforeSelecting=t["smooth"], min_eigenvalue=t["min_eig"], max_iterations=t["max_iter"])
+    if t["border"] is not None:
+        tc.borderx = tc.bordery = t["border"]
+    tc.sequentialMode = bool(rng.integers(0, 3) == 0)
+    p = params_from_tc(tc)
+    base = synth.synth_base(t["w"], t["h"], t["seed"])
+    frames = [synth.synth_frame(t["w"], t["h"], t["seed"], k, shift=t["shift"], base=base) for k in range(4)]
+    n = t["n"]
+
+    def same_list(fl, ofl, what):
+        have = np.array([(f.x, f.y, f.val) for f in fl], np.float64).reshape(-1, 3)
+        ok = (np.array_equal(have[:, 0], ofl["x"].astype(np.float64)) and np.array_equal(have[:, 1], ofl["y"].astype(np.float64))
+              and np.array_equal(have[:, 2], ofl["val"].astype(np.float64)))
+        return None if ok else what
+
+    cur = int(rng.integers(0, 4))
+    fl = sgf.KLTSelectGoodFeatures(tc, frames[cur], n)
+    ofl = ko.select_good_features(p, frames[cur].astype(np.float32), n)
+    bad = same_list(fl, ofl, "op 0: select")
+    last2 = None                                 # pixels of the last call's frame 2 (what sequential mode tracks from)
+    ops = []
+    for step in range(1, 9):
+        if bad:
+            break
+        op = rng.choice(["track", "track", "track", "replace", "edit", "select"])
+        ops.append(op)
+        if op == "edit":
+            k = int(rng.integers(0, 4))
+            y, x = int(rng.integers(0, t["h"] - 8)), int(rng.integers(0, t["w"] - 8))
+            frames[k][y:y + int(rng.integers(1, 8)), x:x + int(rng.integers(1, 8))] ^= int(rng.integers(1, 255))
+        elif op == "select":
+            cur = int(rng.integers(0, 4))
+            fl = sgf.KLTSelectGoodFeatures(tc, frames[cur], n)
+            ofl = ko.select_good_features(p, frames[cur].astype(np.float32), n)
+            bad = same_list(fl, ofl, "op %d: select" % step)
+        elif op == "replace":
+            sgf.KLTReplaceLostFeatures(tc, frames[cur], fl)
+            if int((ofl["val"] < 0).sum()) > 0:
+                if tc.sequentialMode and last2 is not None:
+                    # selectGoodFeatures.py:176-181: level 0 of the pyramids kept from the last track -- the SMOOTHED frame 2 and its
+                    # gradients, whatever smoothBeforeSelecting says
+                    import copy
+                    q = copy.copy(p)
+                    q.smoothBeforeSelecting = 1
+                    ofl = ko.select_good_features(q, last2.astype(np.float32), n, mode=2, fl=ofl)
+                else:
+                    ofl = ko.select_good_features(p, frames[cur].astype(np.float32), n, mode=2, fl=ofl)
+            bad = same_list(fl, ofl, "op %d: replace" % step)
+        else:
+            nxt = int(rng.integers(0, 4))
+            tf.KLTTrackFeatures(tc, frames[cur], frames[nxt], fl)
+            first = last2 if (tc.sequentialMode and last2 is not None) else frames[cur]          # trackFeatures.py:152-161
+            ko.track_features(p, ko.Pyramids(p, first.astype(np.float32)), ko.Pyramids(p, frames[nxt].astype(np.float32)), ofl)
+            last2 = frames[nxt].copy()
+            cur = nxt
+            bad = same_list(fl, ofl, "op %d: track" % step)
+    t["_stat"] = "sequential %d, ops %s, alive at the end %d" % (tc.sequentialMode, "".join(o[0] for o in ops), int((ofl["val"] >= 0).sum()))
+    return bad
+
+
 def run_sequence_trial(t):
     """KLTTrackSequence (device-resident table, build stream, prepared scores, frame stager) against the per-frame host API loop it
     replaces (track, replace, store) on 5-7 frames; one region of one frame is wiped so that features are lost and replaced."""
@@ -275,17 +345,18 @@ def main():
     ap.add_argument("--affine", action="store_true", help="the affine consistency check, HIP against the oracle")
     ap.add_argument("--sequence", action="store_true", help="KLTTrackSequence against the per-frame host API instead of HIP against the oracle")
     ap.add_argument("--prepared", action="store_true", help="replacement on prepared scores (klt_select_prepare_async + begin / finish), HIP against the oracle")
+    ap.add_argument("--api", action="store_true", help="the reference-shaped Python API over random call sequences, against the oracle")
     ap.add_argument("--min-pixels", type=int, default=0)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
-    ctx = None if a.sequence else Context(0)
+    ctx = None if (a.sequence or a.api) else Context(0)
     t0 = time.time()
     for k in range(a.trials):
         t = draw(rng, a.max_pixels, a.max_n, a.max_side)
         while t["w"] * t["h"] < a.min_pixels:
             t = draw(rng, a.max_pixels, a.max_n, a.max_side)
         try:
-            bad = run_prepared_trial(ctx, t) if a.prepared else run_sequence_trial(t) if a.sequence else run_affine_trial(ctx, t) if a.affine else run_batch_trial(ctx, t) if a.batch else run_trial(ctx, t)
+            bad = run_api_trial(t) if a.api else run_prepared_trial(ctx, t) if a.prepared else run_sequence_trial(t) if a.sequence else run_affine_trial(ctx, t) if a.affine else run_batch_trial(ctx, t) if a.batch else run_trial(ctx, t)
         except SystemExit as e:            # KLTError of the host layer
             bad = "error: %s" % (e,)
         print("trial %3d %s  %s" % (k, "ok  " if not bad else "FAIL (%s)" % bad, t), flush=True)

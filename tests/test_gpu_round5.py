@@ -723,3 +723,20 @@ def test_api_selection_is_complete_when_it_returns_on_every_selection_path():
             ctx.set_option(8, 1)
     finally:
         ref.close()
+
+
+def test_python_api_over_random_call_sequences_vs_oracle():
+    """tests/fuzz/fuzz_parity.py --api: KLTSelectGoodFeatures / KLTTrackFeatures / KLTReplaceLostFeatures on one tracking context in random
+    order over four frames that are edited in place between calls, a third of the draws in sequential mode -- every list equals the
+    ORACLE's after every call (the exact frame cache with its optimistic device work, lists mapped into pinned memory, recycled feature
+    objects, scores prepared ahead: none of it may show).  8400 draws ran when the mode was written (profiles/r05_fuzz_seeds.txt); 25
+    stay in the suite."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(99)
+    for k in range(25):
+        t = fz.draw(rng, 250000, 500, 700)
+        bad = fz.run_api_trial(t)
+        assert bad is None, "draw %d: %s differs from the oracle: %r" % (k, bad, t)
