@@ -209,7 +209,7 @@ def _track_sequence_locked(ctx, tc, frames, nFeatures, replace_lost, async_inges
 
             have = 0                                 # frames sent so far beyond frame 0: 1 .. have
             for j in (1, 2):
-                if send(j):
+                if have == j - 1 and send(j):        # (a source that has ended is not asked again: the helper thread says so only once)
                     have = j
             if have >= 1:
                 build(1)

@@ -1,10 +1,13 @@
-# More seeds on the final tree of round 5 (run through gpurun from the repo root): bash tests/fuzz/fuzz_seeds_r05.sh
+# More seeds on the final tree of round 5 (run through gpurun from the repo root): bash tests/fuzz/fuzz_seeds_r05.sh [base seed] [tag]
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
-O=gpurun_out/r05_fuzz_seeds.txt
+B=${1:-50500}
+O=gpurun_out/r05_fuzz_seeds${2:+_$2}.txt
 : > $O
 t() { local name="$1"; shift; r=$(timeout 1200 python tests/fuzz/fuzz_parity.py "$@" 2>&1 | tail -1); echo "fuzz $name: $r" | tee -a $O; }
-t "default (seed 50501)" --trials 15000 --seed 50501
-t "sequence (seed 50502)" --trials 15000 --seed 50502 --sequence
-t "affine (seed 50503)" --trials 4000 --seed 50503 --affine
-t "batch (seed 50504)" --trials 4000 --seed 50504 --batch
-t "prepared replacement vs oracle (seed 50505)" --trials 1500 --seed 50505 --prepared --min-pixels 300000 --max-pixels 900000 --max-n 4000 --max-side 1300
+t "default (seed $((B+1)))" --trials ${FUZZ_DEFAULT:-15000} --seed $((B+1))
+t "sequence (seed $((B+2)))" --trials ${FUZZ_SEQUENCE:-15000} --seed $((B+2)) --sequence
+t "affine (seed $((B+3)))" --trials ${FUZZ_AFFINE:-4000} --seed $((B+3)) --affine
+t "batch (seed $((B+4)))" --trials ${FUZZ_BATCH:-4000} --seed $((B+4)) --batch
+t "prepared replacement vs oracle (seed $((B+5)))" --trials ${FUZZ_PREPARED:-1500} --seed $((B+5)) --prepared --min-pixels 300000 --max-pixels 900000 --max-n 4000 --max-side 1300
+[ -n "$FUZZ_API" ] && t "random call sequences through the Python API (seed $((B+6)))" --trials $FUZZ_API --seed $((B+6)) --api
+true

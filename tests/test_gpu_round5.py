@@ -740,3 +740,57 @@ def test_python_api_over_random_call_sequences_vs_oracle():
         t = fz.draw(rng, 250000, 500, 700)
         bad = fz.run_api_trial(t)
         assert bad is None, "draw %d: %s differs from the oracle: %r" % (k, bad, t)
+
+
+@pytest.mark.timeout(300)
+def test_track_sequence_of_any_length_and_a_slow_frame_source():
+    """KLTTrackSequence keeps frames on their way two steps ahead of the tracker: sequences of 1 .. 7 frames (the frame source ends
+    during the start-up sends -- a ONE-frame sequence used to ask the helper thread for a frame after it had said "no more", and waited
+    for ever), with frames that arrive late (a generator that sleeps) and early, with and without the helper thread, equal the per-frame
+    API loop row by row; so does every further call on the same tracking context and the per-frame call that continues the sequence."""
+    import time
+    from test_gpu_parity import _host_api_sequence
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    from pyfeaturetrack_amd.trackSequence import KLTTrackSequence
+    w, h, n = 360, 280, 250
+    base = synth.synth_base(w, h, 23)
+    frames = [synth.synth_frame(w, h, 23, k, shift=(2.1, -1.7), base=base) for k in range(7)]
+    frames[3] = frames[3].copy()
+    frames[3][60:150, 100:240] = 128                      # features there are lost and replaced elsewhere
+
+    def make():
+        tc = KLT_TrackingContext()
+        tc.sequentialMode = True
+        tc.max_residue = 10.0
+        return tc
+
+    def slow(seq, every):
+        for k, f in enumerate(seq):
+            if every and k % every == every - 1:
+                time.sleep(0.02)                          # the look comes long before this frame is staged
+            yield f
+
+    sgf.KLT_verbose = 0
+    try:
+        tc = make()
+        for nf in (1, 2, 3, 4, 5, 7):
+            want = _host_api_sequence(make(), frames[:nf], n, True)
+            for ingest, every in ((True, 0), (True, 2), (True, 1), (False, 0)):
+                got = KLTTrackSequence(tc, slow(frames[:nf], every), n, replace_lost=True, async_ingest=ingest)
+                assert got.nFrames == nf, (nf, ingest, every)
+                assert np.array_equal(got.val, want.val) and np.array_equal(got.x, want.x) and np.array_equal(got.y, want.y), (nf, ingest, every)
+        if True:
+            from pyfeaturetrack_amd import storeFeatures as sf
+            from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures
+            nxt = synth.synth_frame(w, h, 23, 7, shift=(2.1, -1.7), base=base)
+            fl, fl2 = sf.KLTCreateFeatureList(n), sf.KLTCreateFeatureList(n)
+            sf.KLTExtractFeatureList(fl, got, 6)
+            sf.KLTExtractFeatureList(fl2, got, 6)
+            KLTTrackFeatures(tc, frames[6], nxt, fl)
+            other = make()
+            other.sequentialMode = False
+            KLTTrackFeatures(other, frames[6], nxt, fl2)
+            assert [(f.x, f.y, f.val) for f in fl] == [(f.x, f.y, f.val) for f in fl2]
+    finally:
+        sgf.KLT_verbose = 1
