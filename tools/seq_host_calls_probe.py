@@ -5,7 +5,7 @@ over the frames and the mean over even and odd frames (the per-queue timeline sh
   after   select_finish (the product's order: the copy gets its head start while the re-run tracker is on the device), and
   early   right behind select_begin (a ring of four slots: an upload un-validates its slot's pyramids, and before the look the slot of
           frame k is still wanted by a repeated tracker); `after, ring of four` separates the ring's size from the order.
-Prints one JSON line."""
+`--periodic`: bench.py's frames; `--table`: bench.py's read-back of 16 rows every 16 frames.  Prints one JSON line."""
 import json
 import os
 import sys
@@ -37,11 +37,15 @@ def run(order_of_send, w, h, n, nframes):
 
     try:
         NPIN = 16
-        base = synth.synth_base(w, h, 4)
         pins = []
-        for k in range(NPIN):
+        if "--periodic" in sys.argv:                                       # bench.py's frames (replacement passes are heavier on them)
+            source = synth.periodic_sequence(w, h, 4, NPIN, phases=synth.sequence_phases(w, h, 4, workers=6))
+        else:
+            base = synth.synth_base(w, h, 4)
+            source = (synth.synth_frame(w, h, 4, k, base=base) for k in range(NPIN))
+        for f in source:
             a = ctx.pinned_array((h, w))
-            a[:] = synth.synth_frame(w, h, 4, k, base=base)
+            a[:] = f
             pins.append(a)
         order = list(range(NPIN)) + list(range(NPIN - 2, 0, -1))
         # an upload un-validates its slot's pyramids: sent BEFORE the look it must not go into the slot of frame k, which a repeated tracker
@@ -52,6 +56,13 @@ def run(order_of_send, w, h, n, nframes):
         for k in range(2 * NT):
             ctx.featbuf_view(TAB + 1 + k, TAB, k * n, n)
         row = lambda k: TAB + 1 + k % (2 * NT)                         # noqa: E731
+        table = "--table" in sys.argv                                      # bench.py's read-back of 16 rows every 16 frames
+        if table:
+            from pyfeaturetrack_amd.backend import FEAT_DTYPE
+            HALF = (200, 201)
+            for i in range(2):
+                ctx.featbuf_view(HALF[i], TAB, i * NT * n, NT * n)
+            host_tab = [ctx.pinned_array((NT * n,), FEAT_DTYPE) for _ in range(2)]
         ctx.set_option(15, 1)                                          # KLT_OPT_BUILD_STREAM
 
         def send(k):
@@ -83,6 +94,11 @@ def run(order_of_send, w, h, n, nframes):
                     track(k + 1, "track_async (again)")
                 if order_of_send != "early":
                     send(k + ahead + 1)
+                if table and k % NT == NT - 1:
+                    ctx.download_wait()
+                    ctx.featbuf_download_async(HALF[(k // NT) % 2], host_tab[(k // NT) % 2])
+            if table:
+                ctx.download_wait()
             ctx.sync()
 
         loop(32)
@@ -106,7 +122,7 @@ def run(order_of_send, w, h, n, nframes):
 
 def main():
     w, h, n, nframes = (3840, 2160, 20000, 128) if "--1080p" not in sys.argv else (1920, 1080, 5000, 256)
-    out = {"frame": "%dx%d" % (w, h), "features": n, "frames": nframes}
+    out = {"frame": "%dx%d" % (w, h), "features": n, "frames": nframes, "flags": [a for a in sys.argv[1:]]}
     for rep in range(int(os.environ.get("KLT_PROBE_REPS", "4"))):
         for mode in ("after", "after, ring of four", "early"):
             out.setdefault("upload " + mode, []).append(run(mode, w, h, n, nframes))
