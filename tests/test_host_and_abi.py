@@ -386,7 +386,8 @@ def test_feature_objects_are_recycled_only_when_nobody_holds_one():
     held.val = 5
     del g
     h = new_feature_list(n)
-    assert id(held) not in [id(f) for f in h] and held.val == 5 and [id(f) for f in h][:7] != ids[:7]
+    # (the other sixty objects of `g` were freed, so their addresses may well come back: only what is still alive can be told apart)
+    assert id(held) not in [id(f) for f in h] and held.val == 5 and held[0] is not h._store and h[7].val == -1
     alias = h                                                      # the list itself is still referenced: nothing is offered
     del h
     k = new_feature_list(n)
@@ -713,3 +714,105 @@ def test_features_read_through_plain_lists_that_follow_the_columns():
         assert ref() is None, "the store is kept alive by a cycle"
     finally:
         gc.enable()
+
+
+@pytest.mark.timeout(60)
+@pytest.mark.parametrize("nframes", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("ingest", [True, False])
+def test_track_sequence_call_order_on_a_recording_context(nframes, ingest):
+    """KLTTrackSequence's host logic without a device (the calls are recorded): for every sequence length -- the ONE-frame sequence
+    included, which used to ask the helper thread for a frame after it had said "no more" and waited for ever -- the call returns, every
+    frame is sent exactly once and before its pyramid is built, built exactly once and before the first tracker that reads it, every
+    frame but the first gets a replacement pass, nothing is sent into a slot whose pyramids a tracker still to be enqueued needs, and
+    the options set for the call are reset."""
+    import threading
+    from pyfeaturetrack_amd import trackSequence as ts
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+
+    class Recorder:
+        def __init__(self):
+            self.lock = threading.RLock()
+            self.log = []
+            self._next = 0
+            self.frame_in_slot = {}
+            self.sent = -1
+
+        def take_slots(self, n=3):
+            base, self._next = self._next, self._next + n
+            return base
+
+        def release_slots(self, base, n=3):
+            pass
+
+        def staging(self, shape, count=2):
+            return [np.empty(shape, np.uint8) for _ in range(count)]
+
+        def _send(self, slot, arr):
+            self.sent += 1
+            assert int(arr[0, 0]) == self.sent, "frames leave in order"
+            self.frame_in_slot[slot] = self.sent
+            self.log.append(("send", self.sent, slot))
+
+        def upload(self, slot, arr):
+            self._send(slot, arr)
+
+        def upload_async(self, slot, arr):
+            self._send(slot, arr)
+
+        def build_pyramids(self, slot, sync=True):
+            self.log.append(("build", self.frame_in_slot[slot], slot))
+
+        def select_async(self, slot, mode, use_pyramid, fb, n):
+            self.log.append(("select", self.frame_in_slot[slot], slot))
+
+        def select_prepare(self, slot):
+            self.log.append(("prepare", self.frame_in_slot[slot], slot))
+
+        def select_begin(self, slot, mode, use_pyramid, fb, n):
+            self.log.append(("replace", self.frame_in_slot[slot], slot))
+
+        def select_finish(self):
+            self.log.append(("look",))
+            return len(self.log) % 3 == 0                    # now and then the list was rewritten: the tracker is enqueued again
+
+        def track_async(self, s1, s2, fb1, fb2, n):
+            self.log.append(("track", self.frame_in_slot[s1], self.frame_in_slot[s2], fb1, fb2))
+
+        def set_option(self, opt, value):
+            self.log.append(("option", opt, value))
+
+        def featbuf_download_into(self, fb, out):
+            out["val"] = -1
+
+        def __getattr__(self, name):                         # everything else: accepted, not recorded
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return lambda *a, **k: None
+
+    h, w, n = 48, 64, 10
+    frames = [np.full((h, w), k, np.uint8) for k in range(nframes)]
+    tc = KLT_TrackingContext()
+    tc.sequentialMode = False
+    ctx = Recorder()
+    tc.__dict__["_klt_ctx"] = ctx                            # (backend.context_of: a tracking context stays with its device context)
+    ft = ts._track_sequence_locked(ctx, tc, iter(frames), n, True, ingest, True)
+    assert ft.nFrames == nframes
+    log = ctx.log
+    at = lambda what, k: [i for i, e in enumerate(log) if e[0] == what and e[1] == k]      # noqa: E731
+    for k in range(nframes):
+        assert len(at("send", k)) == 1 and len(at("build", k)) == 1, (k, log)
+        assert at("send", k)[0] < at("build", k)[0]
+        if k:
+            tracked = [i for i, e in enumerate(log) if e[0] == "track" and e[2] == k]
+            assert tracked and all(log[i][1] == k - 1 for i in tracked), (k, log)            # frame k - 1 -> k, from the slots that hold them
+            assert at("build", k)[0] < tracked[0] and at("build", k - 1)[0] < tracked[0]
+            assert len(at("replace", k)) == 1 and all(i < at("replace", k)[0] for i in tracked)      # (a repeated tracker included)
+            assert len(at("prepare", k)) == 1 and at("build", k)[0] < at("prepare", k)[0] < at("replace", k)[0]
+            # row k - 1 in, row k out
+            assert all(log[i][4] == log[i][3] + 1 for i in tracked)
+    assert len(at("select", 0)) == 1 and not [e for e in log if e[0] == "replace" and e[1] == 0]
+    assert len([e for e in log if e[0] == "look"]) == nframes          # one per replacement pass + the one that closes the call
+    # a frame is never sent into a slot that a LATER tracker reads as it was: every tracker's two slots hold the frames it names
+    # (checked when it is recorded: frame_in_slot), and the build stream option is switched on and off again
+    opts = [e for e in log if e[0] == "option" and e[1] == ts._OPT_BUILD_STREAM]
+    assert [e[2] for e in opts] == [1, 0]
