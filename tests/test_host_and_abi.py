@@ -716,18 +716,8 @@ def test_features_read_through_plain_lists_that_follow_the_columns():
         gc.enable()
 
 
-@pytest.mark.timeout(60)
-@pytest.mark.parametrize("nframes", [1, 2, 3, 4, 6])
-@pytest.mark.parametrize("ingest", [True, False])
-def test_track_sequence_call_order_on_a_recording_context(nframes, ingest):
-    """KLTTrackSequence's host logic without a device (the calls are recorded): for every sequence length -- the ONE-frame sequence
-    included, which used to ask the helper thread for a frame after it had said "no more" and waited for ever -- the call returns, every
-    frame is sent exactly once and before its pyramid is built, built exactly once and before the first tracker that reads it, every
-    frame but the first gets a replacement pass, nothing is sent into a slot whose pyramids a tracker still to be enqueued needs, and
-    the options set for the call are reset."""
+def _recording_context():
     import threading
-    from pyfeaturetrack_amd import trackSequence as ts
-    from pyfeaturetrack_amd.klt import KLT_TrackingContext
 
     class Recorder:
         def __init__(self):
@@ -789,11 +779,27 @@ def test_track_sequence_call_order_on_a_recording_context(nframes, ingest):
                 raise AttributeError(name)
             return lambda *a, **k: None
 
+    return Recorder()
+
+
+@pytest.mark.timeout(60)
+@pytest.mark.parametrize("nframes", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("ingest", [True, False])
+def test_track_sequence_call_order_on_a_recording_context(nframes, ingest):
+    """KLTTrackSequence's host logic without a device (the calls are recorded): for every sequence length -- the ONE-frame sequence
+    included, which used to ask the helper thread for a frame after it had said "no more" and waited for ever -- the call returns, every
+    frame is sent exactly once and before its pyramid is built, built exactly once and before the first tracker that reads it, every
+    frame but the first gets a replacement pass, nothing is sent into a slot whose pyramids a tracker still to be enqueued needs, and
+    the options set for the call are reset."""
+    import threading
+    from pyfeaturetrack_amd import trackSequence as ts
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+
     h, w, n = 48, 64, 10
     frames = [np.full((h, w), k, np.uint8) for k in range(nframes)]
     tc = KLT_TrackingContext()
     tc.sequentialMode = False
-    ctx = Recorder()
+    ctx = _recording_context()
     tc.__dict__["_klt_ctx"] = ctx                            # (backend.context_of: a tracking context stays with its device context)
     ft = ts._track_sequence_locked(ctx, tc, iter(frames), n, True, ingest, True)
     assert ft.nFrames == nframes
@@ -816,3 +822,34 @@ def test_track_sequence_call_order_on_a_recording_context(nframes, ingest):
     # (checked when it is recorded: frame_in_slot), and the build stream option is switched on and off again
     opts = [e for e in log if e[0] == "option" and e[1] == ts._OPT_BUILD_STREAM]
     assert [e[2] for e in opts] == [1, 0]
+
+
+@pytest.mark.timeout(60)
+@pytest.mark.parametrize("nframes", [1, 2, 3, 5])
+@pytest.mark.parametrize("replace,prefetch", [(False, True), (True, False), (False, False)])
+def test_track_sequence_call_order_without_replacement_or_prefetch(nframes, replace, prefetch):
+    """The other arrangements of KLTTrackSequence on the recording context: no replacement of lost features (nothing to look at, so
+    nothing is sent ahead), no build stream (frames in a ring of two slots) -- the call returns for every length, every frame is sent and
+    built once, in that order, and tracked once from the frame before it."""
+    from pyfeaturetrack_amd import trackSequence as ts
+    from pyfeaturetrack_amd.klt import KLT_TrackingContext
+    h, w, n = 48, 64, 10
+    frames = [np.full((h, w), k, np.uint8) for k in range(nframes)]
+    tc = KLT_TrackingContext()
+    tc.sequentialMode = False
+    ctx = _recording_context()
+    tc.__dict__["_klt_ctx"] = ctx
+    ft = ts._track_sequence_locked(ctx, tc, iter(frames), n, replace, True, prefetch)
+    assert ft.nFrames == nframes
+    log = ctx.log
+    at = lambda what, k: [i for i, e in enumerate(log) if e[0] == what and e[1] == k]      # noqa: E731
+    for k in range(nframes):
+        assert len(at("send", k)) == 1 and len(at("build", k)) == 1 and at("send", k)[0] < at("build", k)[0], (k, log)
+        if k:
+            tracked = [i for i, e in enumerate(log) if e[0] == "track" and e[2] == k]
+            assert len(tracked) == 1 and log[tracked[0]][1] == k - 1 and at("build", k)[0] < tracked[0], (k, log)
+            assert len(at("replace", k)) == (1 if replace else 0)
+            if replace:
+                assert tracked[0] < at("replace", k)[0]
+    slots = {e[2] for e in log if e[0] == "send"}
+    assert len(slots) <= (3 if prefetch else 2)
