@@ -38,7 +38,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline -- the CPU oracle (oracle/klt_oracle.c, a bit-exact port of the reference's Python/Cython/SciPy path) on the same
                   workload, 1 thread, rank 0, N = 1 only.
 `--config cfg1|cfg3|cfg4|cfg5` run the other BASELINE configs the same way: timed regions, records checked against the oracle,
-`roofline` with the per-kernel table, `cpu_baseline`.
+`roofline` with the per-kernel table, `cpu_baseline`.  The default run (cfg-2, one GPU) runs all four at their BASELINE counts as child
+processes of its own after the headline and keeps a compact record of each in `extra.configs` (benchlib/sweep.py); a config whose
+records differ from the oracle's makes the whole run exit non-zero.
 """
 import argparse
 import os
@@ -78,6 +80,9 @@ def main():
                     help="skip the secondary figures (selection, one pair at a time, PCIe-inclusive, Python API): a profiler then sees only "
                          "the launches of the timed regions and of the roofline pass, all of the headline's size")
     ap.add_argument("--no-api", action="store_true", help="skip the reference-shaped Python API figures in `extra`")
+    ap.add_argument("--no-config-sweep", action="store_true",
+                    help="skip extra.configs (the default cfg-2 run otherwise runs --config cfg1, cfg3, cfg4 --pairs 256 and cfg5 --frames 512, each in a "
+                         "child process of its own, after the headline, and folds a compact record of each into its line); --no-extras implies it")
     ap.add_argument("--no-sequences", action="store_true", help="skip extra.sequence_from_host (a 1080p and a 4K sequence fed from pinned host memory)")
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 (default, the headline line); cfg4 = the 256-pair batch sharded over --gpus ranks; the others are "

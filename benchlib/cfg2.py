@@ -421,9 +421,16 @@ def run_cfg2(args, json_fd):
             extra["sequence_from_host"] = {"1080p": sequence_from_host(ranks.local_rank, 1920, 1080, 5000, 256, link.get("1080p")),
                                            "4k": sequence_from_host(ranks.local_rank, 3840, 2160, 20000, 128, link.get("4k")),
                                            "note": sequence_from_host.__doc__.split("  Secondary")[0].replace("\n    ", " ")}
+    sweep_failed = []
+    if line is not None and isinstance(extra, dict) and not args.no_extras and not distributed and not args.no_config_sweep:
+        # the other four BASELINE configs, each in a child process of its own (benchlib/sweep.py): compact records in extra.configs
+        from .sweep import config_sweep
+        extra["configs"], sweep_failed = config_sweep(["--no-cpu-baseline"] if args.no_cpu_baseline else [])
     if line is not None:
         emit(json_fd, line)
         fail_on_parity(parity)
+        if sweep_failed:
+            raise SystemExit("config sweep: %s failed: %s" % (", ".join(sweep_failed), "; ".join(extra["configs"][c]["error"] for c in sweep_failed)))
 
 
 def sequence_from_host(device, w, h, n, nframes=256, link_gbps=None):

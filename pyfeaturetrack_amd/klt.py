@@ -15,7 +15,6 @@ import threading as _threading
 import time
 import weakref as _weakref
 from itertools import repeat as _repeat
-from operator import itemgetter as _itemgetter
 
 import numpy as np
 
@@ -149,7 +148,7 @@ class _FeatureStore:
     The store does not point at its feature objects (they point at it): a dropped list is freed by reference counting, not by the
     cycle collector.  `owner` is a weak reference to the KLT_FeatureList that was made with the store."""
 
-    __slots__ = ("x", "y", "val", "xint", "yint", "aff", "aff_img", "owner", "hooks", "lx", "ly", "lv", "_stale", "__weakref__")
+    __slots__ = ("x", "y", "val", "xint", "yint", "aff", "aff_img", "owner", "hooks", "lx", "ly", "lv", "_stale", "tagged", "kept", "__weakref__")
     _AFF_DEFAULTS = (("aff_x", -1.0), ("aff_y", -1.0), ("aff_Axx", 1.0), ("aff_Ayx", 0.0), ("aff_Axy", 0.0), ("aff_Ayy", 1.0))
 
     def __init__(self, n):
@@ -162,6 +161,8 @@ class _FeatureStore:
         self.aff_img = None           # {name: object column} for aff_img / aff_img_gradx / aff_img_grady
         self.owner = None             # weakref to the KLT_FeatureList whose `_canon` lists the objects of rows 0 .. n-1
         self.hooks = None             # callbacks for the end of the features' life (device-side affine state: trackFeatures.py)
+        self.tagged = False           # somebody gave a feature of this store an attribute of their own (or looked at its __dict__)
+        self.kept = None              # a private copy of a caller's plain list found to be exactly this store's rows (`shared_store`)
         # lx / ly / lv: the columns as plain lists of the Python values the features show (ints where the reference holds ints) -- what a
         # feature's x / y / val read, one C-level list index per attribute.  After the columns were written (`changed()`) they are
         # stand-ins (`_StaleColumn`) that rebuild all three lists when first indexed: a loop over every feature of a list pays one
@@ -173,10 +174,12 @@ class _FeatureStore:
     def when_features_die(self, callback):
         """`callback()` runs when the KLT_FeatureList made with this store is dropped (what is keyed by that list -- the device-side
         affine state -- is unreachable from then on, and the objects may be handed to a new list: `_recycled`), at the latest when
-        the last feature of the store is gone.  Callbacks must be idempotent."""
-        _weakref.finalize(self, callback)
+        the last feature of the store is gone.  Callbacks must be idempotent.  ONE finalizer per store runs whatever the list
+        holds at the end (a finalizer per call would pile up in weakref.finalize's registry for as long as a recycled store
+        lives -- one per select + register round, each pinning its callback's closure: ADVICE r5)."""
         if self.hooks is None:
             self.hooks = []
+            _weakref.finalize(self, _run_hook_list, self.hooks)      # (holds the LIST, never the store)
         self.hooks.append(callback)
 
     def changed(self):
@@ -193,9 +196,8 @@ class _FeatureStore:
         return ls
 
     def _run_hooks(self):
-        hooks, self.hooks = self.hooks, None
-        for h in hooks or ():
-            h()
+        if self.hooks:
+            _run_hook_list(self.hooks)
 
     def _reset(self):
         """back to n lost features nobody has looked at (the objects of a dropped list serve the next one: `_recycled`)"""
@@ -205,7 +207,7 @@ class _FeatureStore:
         self.val.fill(kltState.KLT_NOT_FOUND)
         self.xint.fill(True)
         self.yint.fill(True)
-        self.aff = self.aff_img = self.owner = None
+        self.aff = self.aff_img = self.owner = self.kept = None
         self.changed()
 
     def __len__(self):
@@ -231,6 +233,14 @@ class _FeatureStore:
             col[rows] = None
 
 
+def _run_hook_list(hooks):
+    """run and forget the callbacks registered so far (the list object stays the one the store's finalizer holds)"""
+    pending = hooks[:]
+    del hooks[:]
+    for h in pending:
+        h()
+
+
 def _restored_store(x, y, val, xint, yint, aff, aff_img):
     s = _FeatureStore(0)
     s.x, s.y, s.val, s.xint, s.yint, s.aff, s.aff_img = x, y, val, xint, yint, aff, aff_img
@@ -238,9 +248,13 @@ def _restored_store(x, y, val, xint, yint, aff, aff_img):
     return s
 
 
+_tuple_new = tuple.__new__
+_item = tuple.__getitem__           # the (store, row) pair of a feature: `feat[0]` itself is hidden from callers
+
+
 def _coord_setter(col, flag):
     def put(self, value):
-        s, i = self
+        s, i = _item(self, 0), _item(self, 1)
         getattr(s, col)[i] = value
         getattr(s, flag)[i] = isinstance(value, (int, np.integer)) and not isinstance(value, bool)
         s.changed()
@@ -249,65 +263,76 @@ def _coord_setter(col, flag):
 
 def _aff_property(name, dflt):
     def get(self):
-        s, i = self
-        return dflt if s.aff is None else float(s.aff[name][i])
+        s = _item(self, 0)
+        return dflt if s.aff is None else float(s.aff[name][_item(self, 1)])
 
     def put(self, value):
-        s, i = self
-        s.aff_columns()[name][i] = value
+        _item(self, 0).aff_columns()[name][_item(self, 1)] = value
     return property(get, put)
 
 
 def _aff_img_property(name):
     def get(self):
-        s, i = self
-        return None if s.aff is None else s.aff_img[name][i]
+        s = _item(self, 0)
+        return None if s.aff is None else s.aff_img[name][_item(self, 1)]
 
     def put(self, value):
-        s, i = self
+        s = _item(self, 0)
         s.aff_columns()
-        s.aff_img[name][i] = value
+        s.aff_img[name][_item(self, 1)] = value
     return property(get, put)
 
 
-_tuple_new = tuple.__new__
+class _FeatureObject(tuple):
+    """A tuple subclass WITHOUT __slots__: its instances carry a lazily created __dict__ (nothing is allocated until somebody sets an
+    attribute).  A class of its own so that KLT_Feature can put a property in front of the instance dictionary (`_instance_dict`)."""
 
 
-class KLT_Feature(tuple):
+_instance_dict = _FeatureObject.__dict__["__dict__"]        # the getset descriptor that hands out / replaces an instance's dictionary
+_FIELDS = frozenset(("x", "y", "val", "aff_x", "aff_y", "aff_Axx", "aff_Ayx", "aff_Axy", "aff_Ayy", "aff_img", "aff_img_gradx", "aff_img_grady"))
+_generic_setattr = object.__setattr__
+
+
+def _no_sequence(what):
+    def refuse(self, *args):
+        raise TypeError("'KLT_Feature' object %s" % what)
+    return refuse
+
+
+class KLT_Feature(_FeatureObject):
     """klt.py:249-263.  The reference's __init__ assigns locals only; real attributes are set on first placement
-    (selectGoodFeatures.py:117-128).  Here x, y, val and the affine-consistency fields always exist; the object is a view of
-    row `_i` of a _FeatureStore `_s` (its own one-row store when created on its own, the list's shared store when it comes from
-    KLTSelectGoodFeatures / KLTCreateFeatureList).
+    (selectGoodFeatures.py:117-128) -- a KLT_Feature there is an attribute bag.  Here x, y, val and the affine-consistency fields
+    always exist and read row `_i` of a _FeatureStore `_s` (its own one-row store when created on its own, the list's shared store
+    when it comes from KLTSelectGoodFeatures / KLTCreateFeatureList); ANY OTHER attribute is the caller's (`feat.track_id = 7`) and
+    lives in the object's own dictionary, as on the reference's plain objects.
 
     It is implemented as the PAIR (store, row) -- a `tuple` subclass -- because that is the cheapest object CPython can make in
     bulk: a 5000-feature list is `map(tuple.__new__, ...)` over a `zip`, all of it in C, 2.7x faster than 5000 calls of a Python
     `__init__` (0.21 against 0.57 ms at cfg-2's list length, `profiles/README.md`), and the list KLTSelectGoodFeatures hands out is
-    a complete list of feature objects as the reference's is.  A feature is equal only to itself in practice (two objects are equal
-    when they view the same row of the same store).  Unlike the reference's plain objects it takes no further attributes and no
-    weak references (`__slots__ = ()` on a tuple): that is what lets the objects of a dropped list serve the next one."""
-
-    __slots__ = ()
+    a complete list of feature objects as the reference's is.  Nothing of the tuple shows: a feature has no length, is not iterable
+    or subscriptable, is always true, equals and hashes by identity (numpy's array constructor makes a 1-D object array of a list
+    of features; `feat in some_list` asks for this very object), pickles and deep-copies as a feature of its own (values, affine
+    fields, own attributes -- not the list's column store).  One deviation from the reference's plain objects remains: no weak
+    references (CPython does not support them on tuple subclasses).  The objects of a dropped list serve the next one
+    (`_recycled`) only when no feature of the list was ever given an attribute of its own."""
 
     def __new__(cls, _store=None, _index=0):
         return _tuple_new(cls, (_FeatureStore(1) if _store is None else _store, _index))
 
-    def __getnewargs__(self):
-        return tuple(self)
+    _s = property(lambda self: _item(self, 0))
+    _i = property(lambda self: _item(self, 1))
 
-    _s = property(_itemgetter(0))
-    _i = property(_itemgetter(1))
-
-    x = property(lambda self: self[0].lx[self[1]], _coord_setter("x", "xint"))       # (one attribute load + two C-level indexings)
-    y = property(lambda self: self[0].ly[self[1]], _coord_setter("y", "yint"))
+    x = property(lambda self: _item(self, 0).lx[_item(self, 1)], _coord_setter("x", "xint"))
+    y = property(lambda self: _item(self, 0).ly[_item(self, 1)], _coord_setter("y", "yint"))
 
     @property
     def val(self):
-        return self[0].lv[self[1]]
+        return _item(self, 0).lv[_item(self, 1)]
 
     @val.setter
     def val(self, value):
-        s, i = self
-        s.val[i] = value
+        s = _item(self, 0)
+        s.val[_item(self, 1)] = value
         s.changed()
 
     aff_x = _aff_property("aff_x", -1.0)
@@ -320,13 +345,67 @@ class KLT_Feature(tuple):
     aff_img_gradx = _aff_img_property("aff_img_gradx")
     aff_img_grady = _aff_img_property("aff_img_grady")
 
+    # ---- the attribute bag.  Own attributes go to the instance dictionary as on any object; the store remembers that one of its
+    # features carries something of the caller's (a store like that is never recycled: a recycled object starts clean).
+    def __setattr__(self, name, value):
+        if name not in _FIELDS:
+            _item(self, 0).tagged = True
+        _generic_setattr(self, name, value)
+
+    @property
+    def __dict__(self):
+        _item(self, 0).tagged = True            # (vars(feat)[...] = ... writes without __setattr__)
+        return _instance_dict.__get__(self)
+
+    @__dict__.setter
+    def __dict__(self, value):
+        _item(self, 0).tagged = True
+        _instance_dict.__set__(self, value)
+
+    # ---- nothing of the pair shows
+    __len__ = _no_sequence("has no len()")
+    __iter__ = _no_sequence("is not iterable")
+    __getitem__ = _no_sequence("is not subscriptable")
+    __contains__ = _no_sequence("is not a container")
+    __add__ = __mul__ = __rmul__ = _no_sequence("is not a sequence")
+    __lt__ = __le__ = __gt__ = __ge__ = lambda self, other: NotImplemented
+    __eq__ = object.__eq__
+    __ne__ = object.__ne__
+    __hash__ = object.__hash__
+
+    def _no_tuple_method(self):
+        raise AttributeError("'KLT_Feature' object has no attribute 'index' / 'count'")
+    index = count = property(_no_tuple_method)
+    del _no_tuple_method
+
+    def __bool__(self):
+        return True
+
+    def __reduce_ex__(self, protocol):
+        # a feature of its own: the values it shows (ints where it shows ints), the affine fields if any were written, own attributes
+        s, i = _item(self, 0), _item(self, 1)
+        aff = None if s.aff is None else ({k: float(v[i]) for k, v in s.aff.items()}, {k: v[i] for k, v in s.aff_img.items()})
+        return (_restored_feature, (self.x, self.y, self.val, aff, dict(_instance_dict.__get__(self)) if s.tagged else None))
+
     def _reset_affine(self):
         """Back to the state of a newly placed feature (selectGoodFeatures.py:120-128)."""
-        s, i = self
-        s.reset_affine(i)
+        _item(self, 0).reset_affine(_item(self, 1))
 
     def __repr__(self):
         return "<KLT_Feature x={0!r} y={1!r} val={2!r}>".format(self.x, self.y, self.val)
+
+
+def _restored_feature(x, y, val, aff, own):
+    f = KLT_Feature()
+    f.x, f.y, f.val = x, y, val
+    if aff is not None:
+        for k, v in aff[0].items():
+            setattr(f, k, v)
+        for k, v in aff[1].items():
+            setattr(f, k, v)
+    if own:
+        f.__dict__.update(own)
+    return f
 
 
 class KLT_FeatureList(list):
@@ -418,16 +497,22 @@ LAZY_FEATURE_LISTS = _os.environ.get("KLT_LAZY_FEATURE_LISTS") == "1"
 # 5000 new ones: 0.3 ms to create, 0.1 ms for the cycle collector's look at them, 0.07 ms to free -- three times what the device
 # needs to select the features (profiles/README.md).  The objects of a dropped list are therefore kept (with their store) and,
 # provided NOBODY holds one of them any more -- every reference count is looked at, 0.1 ms --, handed out again as the next
-# list: same objects, store reset to n lost features, callbacks registered with `when_features_die` run.  CPython only
-# (sys.getrefcount); KLT_NO_FEATURE_RECYCLING=1 in the environment (or klt.RECYCLE_FEATURE_OBJECTS = False) turns it off.
+# list: same objects, store reset to n lost features, callbacks registered with `when_features_die` run.  A list one of whose
+# features was given an attribute of the caller's own (`store.tagged`) is never handed out again: a recycled object starts clean.
+# CPython with the GIL only (sys.getrefcount is exact there; a free-threaded build defers and biases reference counts, so a feature
+# still in use could look unheld: off when sys._is_gil_enabled() says so); KLT_NO_FEATURE_RECYCLING=1 in the environment (or
+# klt.RECYCLE_FEATURE_OBJECTS = False) turns it off.
 _getrefcount = getattr(_sys, "getrefcount", None)
-RECYCLE_FEATURE_OBJECTS = _getrefcount is not None and _os.environ.get("KLT_NO_FEATURE_RECYCLING") != "1"
+RECYCLE_FEATURE_OBJECTS = (_getrefcount is not None and getattr(_sys, "_is_gil_enabled", lambda: True)()
+                           and _os.environ.get("KLT_NO_FEATURE_RECYCLING") != "1")
 _POOL_LENGTHS, _POOL_DEPTH = 4, 2
 _pool = {}                      # list length -> [(store, canon), ...] (newest last)
 _pool_lock = _threading.RLock()         # re-entrant: the collector may finalize another dropped list while `_offer` holds it
 
 
 def _offer(store, canon):
+    if store.tagged:
+        return
     with _pool_lock:
         stack = _pool.pop(len(canon), None)
         if stack is None:
@@ -463,7 +548,7 @@ def _recycled(n):
     with _pool_lock:
         stack = _pool.get(n)
         entry = stack.pop() if stack else None
-    if entry is None or _counts(entry) != _UNSHARED:
+    if entry is None or entry[0].tagged or _counts(entry) != _UNSHARED:
         return None                                 # (an entry somebody still holds a feature of is dropped: freed when they let go)
     store, canon = entry
     del entry
@@ -489,13 +574,17 @@ def new_feature_list(n, fill=None):
 
 
 _list_eq = list.__eq__
+_tuple_eq = tuple.__eq__
 
 
 def shared_store(featurelist):
     """The _FeatureStore whose rows 0 .. n-1 are exactly this list's features, in order -- or None (a list assembled by hand,
     re-ordered, or mixing features of several lists), in which case callers fall back to per-feature access.  The test is one
-    C-level list comparison (identity of every element) with the private copy made when the list was filled; a plain-list copy of
-    a list this package handed out is recognised for as long as the original is alive."""
+    C-level list comparison (identity of every element) with the private copy made when the list was filled.  A plain-list copy
+    (`fl[:]`, `list(fl)`) of a list this package handed out is recognised while the original is alive by the same comparison, and
+    after the original was dropped by looking at every element once (it is row i of the store of element 0: one C-level pass,
+    ~0.1 ms at 5000) -- the store then keeps a private copy of that list to compare with on the next call (a reference cycle the
+    collector frees with the features; the price of this rare path, not of the usual one)."""
     if type(featurelist) is KLT_FeatureList:
         if featurelist._pending:
             return featurelist._store           # nobody has looked at an element yet: the list is the store's rows by construction
@@ -507,9 +596,18 @@ def shared_store(featurelist):
         owner = s.owner() if s.owner is not None else None
     except (IndexError, AttributeError, TypeError):
         return None
-    if owner is None or owner._canon is None or len(featurelist) != len(owner._canon):
+    plain = list(featurelist) if type(featurelist) is not list else featurelist
+    if owner is not None and owner._canon is not None:
+        return s if len(plain) == len(owner._canon) and _list_eq(plain, owner._canon) is True else None
+    if len(plain) != len(s):
         return None
-    return s if _list_eq(list(featurelist) if type(featurelist) is not list else featurelist, owner._canon) is True else None
+    if s.kept is not None and _list_eq(plain, s.kept) is True:
+        return s
+    # the list the store was made with is gone: is this list its rows 0 .. n-1, in order, all of them KLT_Feature objects?
+    if set(map(type, plain)) != {KLT_Feature} or not all(map(_tuple_eq, plain, zip(_repeat(s), range(len(plain))))):
+        return None
+    s.kept = plain[:]
+    return s
 
 
 _REC_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("val", np.int32), ("aux", np.int32)])   # == klt_feat

@@ -288,7 +288,7 @@ def test_feature_objects_of_a_dropped_list_serve_the_next_selection():
     fl = sgf.KLTSelectGoodFeatures(tc, f[1], n)                    # would take the objects over -- but one of them is held
     fl2 = sgf.KLTSelectGoodFeatures(tc, f[1], n)
     # (the other objects of the dropped list were freed, so their addresses may come back: only what is alive can be told apart by id)
-    assert id(held) not in {id(a) for a in fl} | {id(a) for a in fl2} and held[0] is not fl._store and held[0] is not fl2._store
+    assert id(held) not in {id(a) for a in fl} | {id(a) for a in fl2} and held._s is not fl._store and held._s is not fl2._store
     assert len(ids) == n
     assert (held.x, held.y, held.val) == held_rec, "a feature somebody held was rewritten"
     klt.RECYCLE_FEATURE_OBJECTS, was = False, klt.RECYCLE_FEATURE_OBJECTS

@@ -387,7 +387,7 @@ def test_feature_objects_are_recycled_only_when_nobody_holds_one():
     del g
     h = new_feature_list(n)
     # (the other sixty objects of `g` were freed, so their addresses may well come back: only what is still alive can be told apart)
-    assert id(held) not in [id(f) for f in h] and held.val == 5 and held[0] is not h._store and h[7].val == -1
+    assert id(held) not in [id(f) for f in h] and held.val == 5 and held._s is not h._store and h[7].val == -1
     alias = h                                                      # the list itself is still referenced: nothing is offered
     del h
     k = new_feature_list(n)
@@ -398,8 +398,119 @@ def test_feature_objects_are_recycled_only_when_nobody_holds_one():
     assert {id(f) for f in m}.isdisjoint({id(f) for f in copy_of})
     del copy_of, alias, m, held
     gc.collect()
-    with pytest.raises(AttributeError):
-        new_feature_list(2)[0].note = 1                            # no per-object attributes: nothing of a previous owner can survive
+    # a list one of whose features carries an attribute of the caller's own is never handed out again: a recycled object starts clean
+    n = 62
+    t = new_feature_list(n)
+    t[5].track_id = 7
+    tagged_ids = {id(f) for f in t}
+    keep = t[5]
+    del t
+    u = new_feature_list(n)
+    assert keep.track_id == 7 and id(keep) not in {id(f) for f in u} and keep._s is not u._store
+    assert all(vars(f) == {} for f in u[:3])
+    for writer in (lambda f: vars(f).update(note=1), lambda f: setattr(f, "__dict__", {"note": 1}), lambda f: setattr(f, "note", 1)):
+        v = new_feature_list(n)
+        ids = [id(f) for f in v]
+        writer(v[0])
+        assert v[0].note == 1
+        del v
+        w = new_feature_list(n)
+        assert not hasattr(w[0], "note") and all(vars(f) == {} for f in w)
+        del w
+        assert not any(hasattr(f, "note") for f in new_feature_list(n))
+    del tagged_ids, ids
+
+
+def test_feature_objects_are_attribute_bags_and_nothing_of_the_pair_shows():
+    """klt.py:249-263: the reference's KLT_Feature is a plain object -- any attribute can be set on it, it has no length, is not
+    iterable, equals only itself.  Here it is a (store, row) pair underneath (bulk construction in C); none of that shows
+    (numpy made an (n, 2) array of a list of features, two views of a row compared equal, pickling one feature pickled the
+    whole column store)."""
+    import copy
+    import pickle
+    from pyfeaturetrack_amd.klt import KLT_Feature, new_feature_list, shared_store
+    fl = new_feature_list(40)
+    a = fl[3]
+    a.track_id, a.colour = 7, "red"
+    assert (a.track_id, a.colour) == (7, "red") and vars(a) == {"track_id": 7, "colour": "red"} and not hasattr(fl[4], "track_id")
+    del a.colour
+    assert not hasattr(a, "colour")
+    a.x, a.y, a.val = 12, 3.5, 2                                   # the reference's fields still go to the column store
+    assert fl._store.x[3] == 12 and "x" not in vars(a) and (a.x, a.y, a.val) == (12, 3.5, 2)
+    assert shared_store(fl) is fl._store                           # own attributes do not cost a list its column path
+    # not a sequence
+    for op in (len, iter, list, tuple, lambda f: f[0], lambda f: 1 in f, lambda f: f + (1,), lambda f: f * 2, lambda f: f < f, sorted):
+        with pytest.raises(TypeError):
+            op(a)
+    with pytest.raises(TypeError):
+        s, i = a
+    assert not hasattr(a, "index") and not hasattr(a, "count") and bool(a) is True
+    arr = np.array(fl, dtype=object)
+    assert arr.shape == (40,) and arr[3] is a and np.array(list(fl)).shape == (40,) and np.asarray(fl[:5], dtype=object).shape == (5,)
+    # identity
+    twin = KLT_Feature(fl._store, 3)                               # another object viewing the same row
+    assert twin.x == 12 and twin != a and not (twin == a) and a == a and hash(a) != hash(twin) and len({a, twin, a}) == 2
+    other = new_feature_list(40)
+    assert a in fl and a not in other and twin not in fl and fl.index(a) == 3 and other.count(a) == 0
+    assert {a: 1}[a] == 1
+    # pickles and deep-copies as a feature of its own: values, int-ness, affine fields, own attributes -- not the store
+    a.aff_Axx, a.aff_img = 0.5, "template"
+    blob = pickle.dumps(a)
+    assert len(blob) < 600, "pickling one feature dragged %d bytes along" % len(blob)
+    for b in (pickle.loads(blob), copy.deepcopy(a), copy.copy(a)):
+        assert type(b) is KLT_Feature and b is not a and b._s is not fl._store and len(b._s) == 1
+        assert (b.x, b.y, b.val, b.aff_Axx, b.aff_img, b.aff_x, b.track_id) == (12, 3.5, 2, 0.5, "template", -1.0, 7) and type(b.x) is int
+    plain = pickle.loads(pickle.dumps(fl[2]))
+    assert (plain.x, plain.y, plain.val, plain.aff_Axx, plain.aff_img) == (-1, -1, -1, 1.0, None) and vars(plain) == {}
+    whole = pickle.loads(pickle.dumps(fl))
+    assert type(whole) is list and len(whole) == 40 and whole[3].track_id == 7 and whole[3].x == 12 and whole[3]._s is not whole[4]._s
+    deep = copy.deepcopy(fl)
+    assert deep[3].track_id == 7 and deep[3] is not a and copy.copy(fl)[3] is a
+
+
+def test_a_plain_copy_keeps_the_column_path_after_the_original_list_is_gone():
+    """`fl2 = fl[:]; del fl` left every later KLT* call on fl2 on the per-feature path.  shared_store now recognises a list
+    that is exactly the rows of its first element's store, in order, and keeps a private copy to compare with from then on."""
+    from pyfeaturetrack_amd.klt import KLT_Feature, new_feature_list, shared_store
+    fl = new_feature_list(33)
+    store = fl._store
+    copy_of = fl[:]
+    assert type(copy_of) is list and shared_store(copy_of) is store and store.kept is None        # (the original is alive: its private copy serves)
+    del fl
+    assert store.owner() is None
+    assert shared_store(copy_of) is store and store.kept == copy_of and store.kept is not copy_of
+    assert shared_store(copy_of) is store                                                        # (second call: one list comparison)
+    assert shared_store(copy_of[::-1]) is None and shared_store(copy_of[:-1]) is None
+    swapped = copy_of[:]
+    swapped[4], swapped[5] = swapped[5], swapped[4]
+    assert shared_store(swapped) is None
+    stranger = copy_of[:]
+    stranger[7] = KLT_Feature()
+    assert shared_store(stranger) is None
+    stranger[7] = KLT_Feature(store, 7)                                                          # the right row, but not THE object of a kept list
+    assert shared_store(stranger) is store                                                       # rows 0 .. n-1 of the store all the same: columns apply
+    stranger[7] = object()
+    assert shared_store(stranger) is None
+    copy_of.append(KLT_Feature())
+    assert shared_store(copy_of) is None
+
+
+def test_one_finalizer_per_store_however_often_hooks_are_registered():
+    """when_features_die registered a weakref.finalize per call; a recycled store never dies, so a per-frame select + register
+    loop grew weakref.finalize's registry without bound."""
+    import weakref
+    from pyfeaturetrack_amd.klt import _FeatureStore
+    st = _FeatureStore(4)
+    before = len(weakref.finalize._registry)
+    ran = []
+    for k in range(200):
+        st.when_features_die(lambda k=k: ran.append(k))
+        if k % 2:
+            st._reset()                                            # what recycling does: the hooks registered so far run, the store lives on
+    assert len(weakref.finalize._registry) - before == 1 and ran == list(range(200)) and st.hooks == []
+    st.when_features_die(lambda: ran.append("end"))
+    del st
+    assert ran[-1] == "end" and len(weakref.finalize._registry) == before
 
 
 def test_frame_cache_compares_every_pixel():
