@@ -13,21 +13,31 @@ def api_figures(pair, tc):
     v0 = sgf.KLT_verbose
     sgf.KLT_verbose = trk.KLT_verbose = 0
     try:
-        f0, f1 = pair
+        a0, a1 = pair
 
-        def measure(trusting, new_frame_per_call=False):
+        def as_pil(arr):
+            """a mode-"L" Pillow image with storage of its own, as Image.open(...) of a PGM / PNG file gives (Image.fromarray would
+            share the array's memory) -- what a script written against the reference passes (trackFeatures.py:165,176)"""
+            from PIL import Image
+            return Image.frombytes("L", (arr.shape[1], arr.shape[0]), arr.tobytes())
+
+        def measure(trusting, new_frame_per_call=False, pil=False):
             tc.trustFrameIdentity = trusting
             trk.KLTForgetFrames(tc)
             t_sel, t_trk, t_pp = [], [], []
+            f0, f1 = (as_pil(a0), as_pil(a1)) if pil else (a0, a1)
             fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
             trk.KLTTrackFeatures(tc, f0, f1, fl)
-            g1 = f1.copy()
+            g1 = as_pil(a1) if pil else f1.copy()
             for k in range(30):
                 t = time.perf_counter()
                 fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
                 t_sel.append(time.perf_counter() - t)
-                if new_frame_per_call:
-                    g1[k, k] ^= 1                              # one pixel: frame 2 is a new image every call
+                if new_frame_per_call:                         # one pixel: frame 2 is a new image every call
+                    if pil:
+                        g1.putpixel((k, k), g1.getpixel((k, k)) ^ 1)
+                    else:
+                        g1[k, k] ^= 1
                 t = time.perf_counter()
                 trk.KLTTrackFeatures(tc, f0, g1 if new_frame_per_call else f1, fl)
                 t_trk.append(time.perf_counter() - t)
@@ -40,11 +50,15 @@ def api_figures(pair, tc):
                 t_pp.append(time.perf_counter() - t)
             return statistics.median(t_sel) * 1e3, statistics.median(t_trk) * 1e3, statistics.median(t_pp) * 1e3
 
-        def clip_loop():
+        f0, f1 = a0, a1
+
+        def clip_loop(pil=False):
             # consecutive frames of a clip in non-sequential mode: frame 1 of a call is frame 2 of the call before, frame 2 has new
             # pixels (16 distinct frames visited up and down) -- the call a video loop written against the reference makes
             base = synth.synth_base(f0.shape[1], f0.shape[0], 1)
             clip = [synth.synth_frame(f0.shape[1], f0.shape[0], 1, k, base=base) for k in range(16)]
+            if pil:
+                clip = [as_pil(c) for c in clip]
             order = list(range(16)) + list(range(14, 0, -1))
             tc.trustFrameIdentity = False
             trk.KLTForgetFrames(tc)
@@ -103,8 +117,30 @@ def api_figures(pair, tc):
             return best
 
         exact, trusting, fresh = measure(False), measure(True), measure(False, True)
+        pil_exact, pil_fresh = measure(False, pil=True), measure(False, True, pil=True)
         tc.trustFrameIdentity = False
-        return {"api_ms_per_KLTSelectGoodFeatures": exact[0], "api_ms_per_KLTTrackFeatures": exact[1],
+        from pyfeaturetrack_amd import _pil
+        # ... and what the same calls cost when every image is first made into an array (np.asarray(img), the path of rounds 1-5 and the
+        # fallback when the self-check of the row tables fails)
+        was, _pil._layout = _pil.layout(), False
+        try:
+            conv_exact, conv_fresh = measure(False, pil=True), measure(False, True, pil=True)
+        finally:
+            _pil._layout = was
+        return {"api_pil_converted_to_arrays": {"api_ms_per_KLTSelectGoodFeatures_pil": conv_exact[0], "api_ms_per_KLTTrackFeatures_pil": conv_exact[1],
+                                                "api_ms_per_KLTTrackFeatures_pingpong_pil": conv_exact[2],
+                                                "api_ms_per_KLTTrackFeatures_new_frame_each_call_pil": conv_fresh[1],
+                                                "note": "row tables switched off (as KLT_NO_PIL_ROWS=1): np.asarray(img) per image and call"},
+                "api_ms_per_KLTSelectGoodFeatures_pil": pil_exact[0], "api_ms_per_KLTTrackFeatures_pil": pil_exact[1],
+                "api_ms_per_KLTTrackFeatures_pingpong_pil": pil_exact[2],
+                "api_ms_per_KLTTrackFeatures_new_frame_each_call_pil": pil_fresh[1],
+                "api_ms_per_KLTTrackFeatures_consecutive_frames_pil": clip_loop(pil=True),
+                "api_pil_note": "the same scenarios with mode-\"L\" Pillow images that own their storage (the reference's image type: "
+                                "trackFeatures.py:165,176 `img.convert(\"F\")`); the images are read through Pillow's row table (Image.getim(), "
+                                "pyfeaturetrack_amd/_pil.py: %s) -- no array is made of them; new_frame_each_call edits frame 2 with putpixel"
+                                % ("active, struct layout found by the start-up self-check" if _pil.status()["active"] else
+                                   "INACTIVE (%s): np.asarray(img) per image and call" % _pil.status()["why_not"]),
+                "api_ms_per_KLTSelectGoodFeatures": exact[0], "api_ms_per_KLTTrackFeatures": exact[1],
                 "api_ms_per_KLTTrackFeatures_pingpong": exact[2],
                 "api_ms_per_KLTTrackFeatures_new_frame_each_call": fresh[1],
                 "api_ms_per_KLTTrackFeatures_consecutive_frames": clip_loop(),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 9
+#define KLT_ABI_VERSION 10
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -40,7 +40,8 @@ typedef enum {
     KLT_ERR_ARG = -1,        /* bad argument / unsupported parameter combination */
     KLT_ERR_DEVICE = -2,     /* HIP runtime error */
     KLT_ERR_STATE = -3,      /* call order (e.g. tracking a slot whose pyramids were never built) */
-    KLT_ERR_NOMEM = -4,
+    KLT_ERR_NOMEM = -4,      /* a device or pinned-host allocation could not be had (klt_last_error names the size asked for); nothing is left
+                              * half-allocated and no stale error is left with the HIP runtime: free something and repeat the call */
     KLT_ERR_TIMEOUT = -5     /* a host-side wait for a collective gave up (klt_comm_set_timeout): a peer is gone or stuck */
 } klt_status;
 
@@ -103,6 +104,9 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
 #define KLT_OPT_BUILD_STREAM 15
 #define KLT_OPT_TRACK_TREE_SUMS 18        /* 0 (default): the tracker adds its five window sums (and the residue) in the reference's order -- records identical to the reference's bit for bit; 1: butterfly sums in registers (7x7 / 15x15 quad kernels; same precision, other order of the additions): positions agree to 1e-3 px, a status word can differ where a feature sits on a threshold */
 #define KLT_OPT_SCORE_SETS 16            /* how many sets of prepared selection scores (klt_select_prepare_async) the context keeps: 2 (default) .. 256; a selection frees the set it uses */
+/* test hook: >= 0: the library's (value + 1)-th device / pinned-host allocation from now is refused as if memory had run out (KLT_ERR_NOMEM; the
+ * context stays usable, the call can be repeated); -1 (default): off.  Lets the tests walk every allocation site of a call sequence. */
+#define KLT_OPT_FAIL_ALLOC_AFTER 19
 int klt_set_option(klt_ctx *ctx, int option, int value);
 
 /* ---- parameters and taps ------------------------------------------------------------------- */
@@ -135,6 +139,18 @@ int klt_upload_wait(klt_ctx *ctx);      /* host waits for the copies issued so f
 int klt_host_compare(const void *a, const void *b, size_t bytes);
 int klt_host_copy(void *dst, const void *src, size_t bytes);
 int klt_host_lanes(void);               /* lanes a large compare / copy is spread over (workers + the caller) */
+/* The same two for a frame that is NOT one contiguous array but a table of row addresses -- Pillow's ImagingMemoryInstance.image8, which the
+ * reference's callers hand in (trackFeatures.py:165,176 / selectGoodFeatures.py:190: `img.convert("F")` of a PIL image; the Python layer
+ * takes the table from Image.getim(), pyfeaturetrack_amd/_pil.py): rows[r] = address of row r, row_bytes bytes each; `b` / `dst` a contiguous
+ * [nrows x row_bytes] buffer (the pinned copy a slot was filled from).  Rows that follow each other in memory are treated as one range.
+ * klt_host_sample_rows: rows[y][x] for y = 0, ystep, ... and x = 0, xstep, ... (row-major) into out; returns the count (the 1024-pixel
+ * lattice of the frame cache without making an array of the image). */
+int klt_host_compare_rows(const uint8_t *const *rows, int nrows, size_t row_bytes, const void *b);
+int klt_host_copy_rows(void *dst, const uint8_t *const *rows, int nrows, size_t row_bytes);
+/* on != 0: compares / copies issued by the CALLING THREAD from now on stay on that thread (a background thread that stages frames while
+ * the main thread enqueues must not take the pool's lanes away from it: measured slower, profiles/README.md); returns the previous setting */
+int klt_host_thread_serial(int on);
+int klt_host_sample_rows(const uint8_t *const *rows, int nrows, int ncols, int ystep, int xstep, uint8_t *out, size_t cap);
 /* Frames that are ALREADY in device memory (a hardware decoder's output, a clip kept resident): the slot's frame becomes this caller-owned
  * buffer -- read in place by the next build / selection of the slot, never copied, written or freed by the library (zero-copy
  * ingest).  pitch must equal ncols.  Host-only call: nothing is enqueued; the buffer must hold the frame already and stay unchanged until
@@ -337,6 +353,12 @@ int klt_set_score_override(klt_ctx *ctx, const float *val, int count);
 int klt_download_sorted_candidates(klt_ctx *ctx, float *val, int32_t *x, int32_t *y, int n, int *n_valid);
 
 /* ---- standalone convolutions (host buffers in / out, synchronous) ---------------------------- */
+/* _convolveSeparate(imgin, horiz_kernel, vert_kernel), convolve.py:208-219 (SciPy branch: scipy.ndimage.convolve1d along axis 1, then
+ * along axis 0; FP64 accumulation in correlate1d's operation order, f32 after each pass, `reflect` borders): the reference's one general
+ * separable convolution -- ANY two tap lists of 1 .. 71 taps, odd or even (an even count shifts the window as convolve1d does), symmetric,
+ * antisymmetric or neither.  f32 image in, f32 image out. */
+int klt_convolve_separate_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, const double *horiz, int nh, const double *vert, int nv,
+                              float *dst);
 /* KLTComputeSmoothedImage, convolve.py:254-264: _convolveSeparate(img, gauss, gauss) */
 int klt_smooth_f32(klt_ctx *ctx, const float *src, int ncols, int nrows, const double *gauss, int ng, float *dst);
 /* KLTComputeGradients, convolve.py:226-248: gradx = (deriv, gauss), grady = (gauss, deriv) */

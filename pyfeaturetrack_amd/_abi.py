@@ -72,6 +72,10 @@ SYMBOLS = {
     "klt_host_compare": (_I, [_P, _P, C.c_size_t]),
     "klt_host_copy": (_I, [_P, _P, C.c_size_t]),
     "klt_host_lanes": (_I, []),
+    "klt_host_thread_serial": (_I, [_I]),
+    "klt_host_compare_rows": (_I, [_P, _I, C.c_size_t, _P]),
+    "klt_host_copy_rows": (_I, [_P, _P, _I, C.c_size_t]),
+    "klt_host_sample_rows": (_I, [_P, _I, _I, _I, _I, _P, C.c_size_t]),
     "klt_slot_adopt_u8": (_I, [_P, _I, _P, _I, _I, _I]),
     "klt_device_alloc": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
     "klt_device_write": (_I, [_P, _P, _P, C.c_size_t]),
@@ -120,6 +124,7 @@ SYMBOLS = {
     "klt_set_score_override": (_I, [_P, _P, _I]),
     "klt_download_sorted_candidates": (_I, [_P, _P, _P, _P, _I, _PI]),
     "klt_smooth_f32": (_I, [_P, _P, _I, _I, C.POINTER(C.c_double), _I, _P]),
+    "klt_convolve_separate_f32": (_I, [_P, _P, _I, _I, C.POINTER(C.c_double), _I, C.POINTER(C.c_double), _I, _P]),
     "klt_pyramid_f32": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_double), _I, _P]),
     "klt_gradients_f32": (_I, [_P, _P, _I, _I, C.POINTER(C.c_double), _I, C.POINTER(C.c_double), _I, _P, _P]),
     "klt_scan_good_features_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _PI, _PI]),
@@ -148,6 +153,11 @@ _lib = None
 
 class KltBackendError(RuntimeError):
     pass
+
+
+class KltOutOfMemory(KltBackendError, MemoryError):
+    """KLT_ERR_NOMEM: a device or pinned-host allocation could not be had (the message names the size asked for).  Nothing is left
+    half-allocated and the context stays usable: free something (`Context.device_free`, `slot_free`, drop frames) and repeat the call."""
 
 
 class KltCommTimeout(KltBackendError):

@@ -12,10 +12,13 @@ Opt-in shortcut, a documented deviation: `tc.trustFrameIde
 environment) trusts object identity + size + the lattice and skips the full comparison -- for callers that never edit an image in
 place, or call KLTForgetFrames(tc) when they do.  KLT_NO_FRAME_CACHE=1 disables the cache altogether.
 """
+import ctypes
 import os
 import weakref
 
 import numpy as np
+
+from ._pil import rows_of
 
 _LATTICE = 32
 _DISABLED = os.environ.get("KLT_NO_FRAME_CACHE") == "1"
@@ -63,15 +66,20 @@ def _to_array(img):
 
 class FrameKey:
     """One image as a call names it: the object, its size and mode; the pixel array and its lattice are made when first asked for
-    (a Pillow image is converted once per call, and not at all in the trusting mode when identity or size already differ)."""
-    __slots__ = ("img", "size", "kind", "_arr", "_sig")
+    (a Pillow image is converted once per call, and not at all in the trusting mode when identity or size already differ).
+    An 8-bit Pillow image -- what the reference's callers pass (trackFeatures.py:165,176) -- is never converted at all: `rows` is the
+    row table of Pillow's own storage (_pil.py), which the lattice, the comparison and the staging copy read in place."""
+    __slots__ = ("img", "size", "kind", "rows", "_arr", "_sig")
 
     def __init__(self, img):
         self.img = img
+        self.rows = None
         if isinstance(img, np.ndarray):
             self.size, self.kind = (img.shape[1], img.shape[0]), img.dtype.char
         else:
             self.size, self.kind = tuple(img.size), getattr(img, "mode", "?")
+            if self.kind == "L":
+                self.rows = rows_of(img)
         self._arr = self._sig = None
 
     def array(self):
@@ -81,8 +89,37 @@ class FrameKey:
 
     def sig(self):
         if self._sig is None:
-            self._sig = _lattice(self.array())
+            r = self.rows
+            if r is not None:
+                ys, xs = max(1, r.nrows // _LATTICE), max(1, r.ncols // _LATTICE)
+                out = (ctypes.c_ubyte * (((r.nrows + ys - 1) // ys) * ((r.ncols + xs - 1) // xs)))()
+                n = _host_lib().klt_host_sample_rows(r.table, r.nrows, r.ncols, ys, xs, out, len(out))
+                self._sig = bytes(out) if n == len(out) else _lattice(self.array())
+            else:
+                self._sig = _lattice(self.array())
         return self._sig
+
+    def same_as(self, kept):
+        """every byte of the image against `kept`, the host copy a slot was filled from"""
+        r = self.rows
+        if r is not None and kept.dtype == np.uint8 and kept.shape == (r.nrows, r.ncols) and kept.flags["C_CONTIGUOUS"]:
+            return _host_lib().klt_host_compare_rows(r.table, r.nrows, r.ncols, kept.ctypes.data) == 0
+        return same_pixels(self.array(), kept)
+
+    def stage_u8(self):
+        """(nrows, ncols) when the image can be staged as an 8-bit frame (`copy_into`), else None"""
+        if self.rows is not None:
+            return self.rows.nrows, self.rows.ncols
+        arr = self.array()
+        return arr.shape if arr.dtype == np.uint8 and arr.ndim == 2 else None
+
+    def copy_into(self, buf):
+        """the image's pixels -> the contiguous 8-bit buffer `buf` (pinned memory the DMA reads)"""
+        r = self.rows
+        if r is not None and buf.flags["C_CONTIGUOUS"] and buf.shape == (r.nrows, r.ncols):
+            _host_lib().klt_host_copy_rows(buf.ctypes.data, r.table, r.nrows, r.ncols)
+        else:
+            copy_pixels(buf, self.array())
 
 
 class _Held:
@@ -161,6 +198,11 @@ class FrameCache:
         if hb is not None:
             self.held[a] = hb
 
+    def filled_from(self, key, slot):
+        """the slot was last filled from this very image object (says nothing about its pixels now)"""
+        h = self.held.get(slot)
+        return h is not None and h.ref is not None and h.ref() is key.img
+
     def plausible(self, key, slot, ctx):
         """the fast rejects only: `slot` holds a frame of the image's size and mode with the same 1024-pixel lattice (and, in the
         trusting mode, filled from the very same object).  True is a candidate, not a match: `verify` decides (the trusting mode
@@ -179,7 +221,7 @@ class FrameCache:
         if self.trusting():
             return True
         h = self.held.get(slot)
-        return h is not None and same_pixels(key.array(), h.kept)
+        return h is not None and key.same_as(h.kept)
 
     def find(self, key, slots, ctx):
         """slot among `slots` whose resident frame has exactly the pixels of the image `key` names, or None"""
@@ -192,28 +234,29 @@ class FrameCache:
         """frame -> slot, remembered: 8-bit frames are copied into the slot's pinned buffer and leave with klt_upload_u8_async on
         the context's copy stream (the host copy of the second frame of a pair runs while the first one's DMA is in flight, the
         build waits for both on the device); anything else goes with the synchronous upload and an ordinary copy is kept."""
-        arr = key.array()
+        shape8 = key.stage_u8()
         self.keep_handles(ctx, slot)
         old = self.held.pop(slot, None)
-        if arr.dtype == np.uint8 and arr.ndim == 2 and hasattr(ctx, "upload_async"):
-            pool = _pool_of(ctx, arr.shape)
+        if shape8 is not None and hasattr(ctx, "upload_async"):
+            pool = _pool_of(ctx, shape8)
             if old is not None and old.pool is pool and old.kept is not None:
                 buf, no = old.kept, old.upload_no
                 old.kept = old.pool = None
             elif pool:
                 buf, no = pool.pop()
             else:
-                buf, no = ctx.pinned_array(arr.shape), 0
+                buf, no = ctx.pinned_array(shape8), 0
             if old is not None:
                 old.release()
             _uploads_finished(ctx, no)                      # the DMA that last read this buffer has finished
-            copy_pixels(buf, arr)
+            key.copy_into(buf)
             ctx.upload_async(slot, buf)
             ctx.__dict__["_uploads_issued"] = no = ctx.__dict__.get("_uploads_issued", 0) + 1
             kept = buf
         else:
             if old is not None:
                 old.release()
+            arr = key.array()
             if hasattr(ctx, "upload"):
                 ctx.upload(slot, arr)
             kept, no, pool = (arr if arr is not key.img else arr.copy()), 0, None

@@ -11,7 +11,7 @@ import threading
 
 import numpy as np
 
-from ._abi import (KLT_MAX_LEVELS, KltAffineRec, KltBackendError, KltCommTimeout, KltFeat, KltKernelTime, KltParams,
+from ._abi import (KLT_MAX_LEVELS, KltAffineRec, KltBackendError, KltCommTimeout, KltOutOfMemory, KltFeat, KltKernelTime, KltParams,
                    KltTrackStats, load_library)
 from .params import affine_params_from_tc, params_from_tc, taps_from_params
 
@@ -67,7 +67,7 @@ class Context:
     def _check(self, rc):
         if rc < 0:
             msg = self._lib.klt_last_error(self._h)
-            kind = KltCommTimeout if rc == -5 else KltBackendError          # KLT_ERR_TIMEOUT
+            kind = KltCommTimeout if rc == -5 else (KltOutOfMemory if rc == -4 else KltBackendError)      # KLT_ERR_TIMEOUT, KLT_ERR_NOMEM
             raise kind("libkltgpu error %d: %s" % (rc, (msg or b"").decode()))
         return rc
 
@@ -585,6 +585,14 @@ class Context:
         return list(a)
 
     # -------------------------------------------------- standalone convolutions
+    def convolve_separate(self, img, horiz, vert):
+        """_convolveSeparate (klt_convolve_separate_f32): any two tap lists"""
+        img = np.ascontiguousarray(img, np.float32)
+        out = np.empty_like(img)
+        self._check(self._lib.klt_convolve_separate_f32(self._h, img.ctypes.data, img.shape[1], img.shape[0], _dp(horiz), len(horiz),
+                                                        _dp(vert), len(vert), out.ctypes.data))
+        return out
+
     def smooth(self, img, gauss):
         img = np.ascontiguousarray(img, np.float32)
         out = np.empty_like(img)
@@ -663,5 +671,5 @@ def context_of(tc, device=None):
     return ctx
 
 
-__all__ = ["Context", "default_context", "context_of", "FEAT_DTYPE", "SELECTING_ALL", "REPLACING_SOME", "KltBackendError", "KltCommTimeout",
+__all__ = ["Context", "default_context", "context_of", "FEAT_DTYPE", "SELECTING_ALL", "REPLACING_SOME", "KltBackendError", "KltCommTimeout", "KltOutOfMemory",
            "KLT_MAX_LEVELS", "KltParams"]

@@ -81,6 +81,22 @@ def _as_f32(img):
     return a
 
 
+def _convolveSeparate(imgin, horiz_kernel, vert_kernel):
+    """convolve.py:208-219: the image convolved along its rows with `horiz_kernel`, then along its columns with `vert_kernel` -- the
+    reference's one general separable convolution (SciPy branch: scipy.ndimage.convolve1d, axis 1 then axis 0, `reflect` borders, FP64
+    accumulation, the image's f32 after each pass).  Any two tap sequences of 1 to 71 numbers (the reference's `_computeKernels` never
+    makes more), odd or even counts, symmetric or not.  f32 image in and out (what the reference passes: `img.convert("F")` arrays;
+    another dtype is converted first -- scipy would keep it).  Runs on the GPU (klt_convolve_separate_f32)."""
+    from .backend import default_context
+    h = [float(v) for v in np.asarray(horiz_kernel, dtype=np.float64).ravel()]
+    v = [float(x) for x in np.asarray(vert_kernel, dtype=np.float64).ravel()]
+    if not (1 <= len(h) <= MAX_KERNEL_WIDTH and 1 <= len(v) <= MAX_KERNEL_WIDTH):
+        raise ValueError("(_convolveSeparate) 1 to {0} taps per direction".format(MAX_KERNEL_WIDTH))
+    ctx = default_context()
+    with ctx.lock:
+        return ctx.convolve_separate(_as_f32(imgin), h, v)
+
+
 def KLTComputeSmoothedImage(img, sigma):
     """f32 image -> f32 image smoothed with (gauss, gauss) -- convolve.py:254-264.  Runs on the GPU."""
     from .backend import default_context

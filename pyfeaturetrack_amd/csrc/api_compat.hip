@@ -32,8 +32,9 @@ int klt_scan_good_features_f32(klt_ctx *c, const float *gradx, const float *grad
     for (size_t i = 0; i < N; i++) { inter[2 * i] = gradx[i]; inter[2 * i + 1] = grady[i]; }
     float *d = nullptr;                         // [2N] gradients | [3N] tables | [ncand] eigenvalues
     unsigned long long *keys = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d, (5 * N + (size_t)ncand) * sizeof(float)));
-    hipError_t e = hipMalloc((void **)&keys, (size_t)npow2 * sizeof(unsigned long long));
+    DEVALLOC(c, d, (5 * N + (size_t)ncand) * sizeof(float));
+    if (int rc_keys = dev_alloc(c, (void **)&keys, (size_t)npow2 * sizeof(unsigned long long), "candidate keys")) { hipFree(d); return rc_keys; }
+    hipError_t e = hipSuccess;
     int rc = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(d, inter.data(), 2 * N * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
@@ -67,7 +68,7 @@ int klt_extract_patch_f32(klt_ctx *c, const float *img, int ncols, int nrows, fl
     HIPCHK(c, hipSetDevice(c->device));
     const size_t N = (size_t)ncols * nrows, n = (size_t)width * width;
     float *d = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d, (N + n + 1) * sizeof(float)));
+    DEVALLOC(c, d, (N + n + 1) * sizeof(float));
     int bad = 0;
     hipError_t e = hipMemcpyAsync(d, img, N * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
@@ -94,7 +95,7 @@ int klt_track_iterate_f32(klt_ctx *c, float x2, float y2, const float *gradx_pat
     HIPCHK(c, hipSetDevice(c->device));
     const size_t N = (size_t)ncols * nrows, n = (size_t)width * width;
     float *d = nullptr;                         // three planes | three patches | result
-    HIPCHK(c, hipMalloc((void **)&d, (3 * N + 3 * n + 4) * sizeof(float)));
+    DEVALLOC(c, d, (3 * N + 3 * n + 4) * sizeof(float));
     float res[4] = {0, 0, 0, 0};
     const float *src[6] = {img2, gradx2, grady2, gradx_patch, grady_patch, img_patch};
     const size_t off[6] = {0, N, 2 * N, 3 * N, 3 * N + n, 3 * N + 2 * n}, len[6] = {N, N, N, n, n, n};

@@ -48,12 +48,48 @@ int sync_all(klt_ctx *c)
     if (c->comm) { std::string err; if (int rc = comm_wait(c->comm, err)) return fail(c, rc, err); }
     return 0;
 }
+int dev_alloc(klt_ctx *c, void **p, size_t bytes, const char *what)
+{
+    *p = nullptr;
+    hipError_t e = hipErrorOutOfMemory;
+    if (c->fail_alloc_in == 0) c->fail_alloc_in = -1;                 // the test hook: this allocation is refused as if memory had run out
+    else {
+        if (c->fail_alloc_in > 0) c->fail_alloc_in--;
+        e = hipMalloc(p, bytes ? bytes : 1);
+    }
+    if (e == hipSuccess) return 0;
+    *p = nullptr;
+    (void)hipGetLastError();                                          // out of memory has been answered: nothing stale for the next launch check
+    char msg[160];
+    snprintf(msg, sizeof msg, "out of device memory: %zu bytes asked for (%s)%s%s", bytes, what, e == hipErrorOutOfMemory ? "" : ": ",
+             e == hipErrorOutOfMemory ? "" : hipGetErrorString(e));
+    return fail(c, e == hipErrorOutOfMemory ? KLT_ERR_NOMEM : KLT_ERR_DEVICE, msg);
+}
+
+int host_alloc(klt_ctx *c, void **p, size_t bytes, const char *what)
+{
+    *p = nullptr;
+    hipError_t e = hipErrorOutOfMemory;
+    if (c->fail_alloc_in == 0) c->fail_alloc_in = -1;
+    else {
+        if (c->fail_alloc_in > 0) c->fail_alloc_in--;
+        e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+    }
+    if (e == hipSuccess) return 0;
+    *p = nullptr;
+    (void)hipGetLastError();
+    char msg[160];
+    snprintf(msg, sizeof msg, "out of pinned host memory: %zu bytes asked for (%s)%s%s", bytes, what, e == hipErrorOutOfMemory ? "" : ": ",
+             e == hipErrorOutOfMemory ? "" : hipGetErrorString(e));
+    return fail(c, e == hipErrorOutOfMemory ? KLT_ERR_NOMEM : KLT_ERR_DEVICE, msg);
+}
+
 int ensure_tmp(klt_ctx *c, size_t pixels)
 {
     if (pixels <= c->tmp_cap && c->tmpA) return 0;
     if (c->tmpA) { if (int rc = sync_all(c)) return rc; hipFree(c->tmpA); hipFree(c->tmpB); c->tmpA = c->tmpB = nullptr; c->tmp_cap = 0; }
-    HIPCHK(c, hipMalloc((void **)&c->tmpA, pixels * sizeof(float)));
-    HIPCHK(c, hipMalloc((void **)&c->tmpB, pixels * sizeof(float)));
+    DEVALLOC(c, c->tmpA, pixels * sizeof(float));
+    DEVALLOC(c, c->tmpB, pixels * sizeof(float));       // (tmpA alone with tmp_cap 0 is freed by the next call)
     c->tmp_cap = pixels;
     return 0;
 }
@@ -62,7 +98,7 @@ int ensure_h1(klt_ctx *c, size_t floats)
 {
     if (floats <= c->h1_cap && c->h1) return 0;
     if (c->h1) { if (int rc = sync_all(c)) return rc; hipFree(c->h1); c->h1 = nullptr; c->h1_cap = 0; }
-    HIPCHK(c, hipMalloc((void **)&c->h1, floats * sizeof(float)));
+    DEVALLOC(c, c->h1, floats * sizeof(float));
     c->h1_cap = floats;
     return 0;
 }
@@ -86,7 +122,7 @@ int get_fb(klt_ctx *c, int fb, int n, FeatBuf **out)
     if (n > b.cap && b.view) return fail(c, KLT_ERR_ARG, "feature buffer is a view and too small");
     if (n > b.cap) {
         klt_feat *nd = nullptr;
-        HIPCHK(c, hipMalloc((void **)&nd, (size_t)n * sizeof(klt_feat)));
+        DEVALLOC(c, nd, (size_t)n * sizeof(klt_feat));
         if (b.d) {
             HIPCHK(c, hipMemcpyAsync(nd, b.d, (size_t)b.cap * sizeof(klt_feat), hipMemcpyDeviceToDevice, c->stream));
             if (int rc = sync_all(c)) return rc;
@@ -323,6 +359,7 @@ int klt_set_option(klt_ctx *c, int option, int value)
         c->pre.resize((size_t)value);
         return KLT_OK;
     }
+    if (option == KLT_OPT_FAIL_ALLOC_AFTER) { c->fail_alloc_in = value; return KLT_OK; }
     if (option == KLT_OPT_TRACK_TREE_SUMS) { c->track_tree_sums = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }
     if (option == KLT_OPT_SELECT_PARALLEL_NMS) { c->use_mis = value != 0; return KLT_OK; }

@@ -74,7 +74,8 @@ int layout_pyramid(klt_ctx *c, Slot *s)
     }
     if (3 * total > s->planes_cap) {
         if (s->planes) { if (int rc = sync_all(c)) return rc; hipFree(s->planes); s->planes = nullptr; s->planes_cap = 0; }
-        HIPCHK(c, hipMalloc((void **)&s->planes, 3 * total * sizeof(float)));
+        s->pyr_valid = false;                              // (the old planes are gone whether or not the new ones can be had)
+        DEVALLOC(c, s->planes, 3 * total * sizeof(float));
         s->planes_cap = 3 * total;
     }
     size_t off = 0;
@@ -374,7 +375,7 @@ int download_plane(klt_ctx *c, const float *src, int stride, size_t cnt, float *
 {
     float *tmp = nullptr;
     if (stride != 1) {
-        HIPCHK(c, hipMalloc((void **)&tmp, cnt * sizeof(float)));
+        DEVALLOC(c, tmp, cnt * sizeof(float));
         launch_take_strided(c->stream, src, tmp, cnt, stride);
         src = tmp;
     }
@@ -425,7 +426,7 @@ int klt_host_alloc(klt_ctx *c, size_t bytes, void **out)
     if (!c || !out || bytes == 0) return fail(c, KLT_ERR_ARG, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     void *p = nullptr;
-    HIPCHK(c, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    if (int rc = host_alloc(c, &p, bytes, "klt_host_alloc")) return rc;
     c->pinned.push_back(p);
     *out = p;
     return KLT_OK;
@@ -524,7 +525,7 @@ int klt_device_alloc(klt_ctx *c, size_t bytes, void **out)
     if (!c || !out || !bytes) return fail(c, KLT_ERR_ARG, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(c, KLT_ERR_NOMEM, "klt_device_alloc: out of device memory"); }
+    if (int rc = dev_alloc(c, &p, bytes, "klt_device_alloc")) return rc;
     c->dev_allocs.push_back(p);
     c->dev_alloc_bytes.push_back(bytes);
     *out = p;
@@ -628,29 +629,39 @@ int klt_download_f32(klt_ctx *c, int slot, int pyramid, int level, float *dst)
 
 
 // ------------------------------------------------------------------------- standalone convolutions
-int klt_smooth_f32(klt_ctx *c, const float *src, int ncols, int nrows, const double *gauss, int ng, float *dst)
+// _convolveSeparate, convolve.py:208-219 (SciPy branch): convolve1d along axis 1 with the horizontal taps, f32, then along axis 0 with the
+// vertical taps -- ANY two tap lists (1 .. 71 taps each, odd or even, no symmetry assumed: make_taps classifies them as correlate1d does).
+int klt_convolve_separate_f32(klt_ctx *c, const float *src, int ncols, int nrows, const double *horiz, int nh, const double *vert, int nv, float *dst)
 {
-    if (!c || !src || !dst || !gauss) return fail(c, KLT_ERR_ARG, "null argument");
-    if (ng < 1 || ng > KLT_MAX_KERNEL_WIDTH || !(ng & 1)) return fail(c, KLT_ERR_ARG, "tap count must be odd and at most 71");
+    if (!c || !src || !dst || !horiz || !vert) return fail(c, KLT_ERR_ARG, "null argument");
+    if (nh < 1 || nv < 1 || nh > KLT_MAX_KERNEL_WIDTH || nv > KLT_MAX_KERNEL_WIDTH) return fail(c, KLT_ERR_ARG, "1 to 71 taps per direction");
     if (ncols <= 0 || nrows <= 0 || (long long)ncols * nrows > kMaxFramePixels) return fail(c, KLT_ERR_ARG, "bad image geometry");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t N = (size_t)ncols * nrows;
     if (int rc = ensure_tmp(c, N)) return rc;
     float *d_in = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_in, 2 * N * sizeof(float)));
+    DEVALLOC(c, d_in, 2 * N * sizeof(float));
     float *d_out = d_in + N;
-    Taps g;
-    make_taps(gauss, ng, g);
+    Taps th, tv;
+    make_taps(horiz, nh, th);
+    make_taps(vert, nv, tv);
     hipError_t e = hipMemcpyAsync(d_in, src, N * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        launch_hconv_f32(c->stream, d_in, ncols, nrows, c->tmpA, nullptr, ncols, 1, 0, g, nullptr);
-        launch_vconv(c->stream, c->tmpA, nullptr, ncols, nrows, d_out, nullptr, nrows, 1, 0, g, nullptr);
+        launch_hconv_f32(c->stream, d_in, ncols, nrows, c->tmpA, nullptr, ncols, 1, 0, th, nullptr);
+        launch_vconv(c->stream, c->tmpA, nullptr, ncols, nrows, d_out, nullptr, nrows, 1, 0, tv, nullptr);
         e = hipMemcpyAsync(dst, d_out, N * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_in);
     if (e != hipSuccess) return fail(c, KLT_ERR_DEVICE, hipGetErrorString(e));
     return KLT_OK;
+}
+
+int klt_smooth_f32(klt_ctx *c, const float *src, int ncols, int nrows, const double *gauss, int ng, float *dst)
+{
+    if (!c || !src || !dst || !gauss) return fail(c, KLT_ERR_ARG, "null argument");
+    if (ng < 1 || ng > KLT_MAX_KERNEL_WIDTH || !(ng & 1)) return fail(c, KLT_ERR_ARG, "tap count must be odd and at most 71");
+    return klt_convolve_separate_f32(c, src, ncols, nrows, gauss, ng, gauss, ng, dst);      // KLTComputeSmoothedImage, convolve.py:263
 }
 
 int klt_gradients_f32(klt_ctx *c, const float *src, int ncols, int nrows, const double *gauss, int ng,
@@ -664,7 +675,7 @@ int klt_gradients_f32(klt_ctx *c, const float *src, int ncols, int nrows, const 
     const size_t N = (size_t)ncols * nrows;
     if (int rc = ensure_tmp(c, N)) return rc;
     float *d_in = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_in, 3 * N * sizeof(float)));
+    DEVALLOC(c, d_in, 3 * N * sizeof(float));
     float *d_gx = d_in + N, *d_gy = d_in + 2 * N;
     Taps g, d;
     make_taps(gauss, ng, g);
@@ -706,7 +717,7 @@ int klt_pyramid_f32(klt_ctx *c, const float *src, int ncols, int nrows, int nlev
     }
     if (int rc = ensure_tmp(c, N)) return rc;
     float *d_in = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_in, (N + total) * sizeof(float)));
+    DEVALLOC(c, d_in, (N + total) * sizeof(float));
     float *d_lv = d_in + N;
     Taps g;
     make_taps(gauss, ng, g);

@@ -278,11 +278,17 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
     if (N > c->sel_cap) {
         if (c->sel_img) { if (int rc = sync_all(c)) return rc; hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sat); hipFree(c->valmap); }
         c->sel_img = c->sel_gx = c->sel_gy = c->sat = c->valmap = nullptr;
-        HIPCHK(c, hipMalloc((void **)&c->sel_img, N * sizeof(float)));
-        HIPCHK(c, hipMalloc((void **)&c->sel_gx, KLT_GRAD_STRIDE * N * sizeof(float)));      // gradx / grady interleaved, like a slot's planes
+        c->sel_cap = 0;                                       // (nothing is held until all four planes are: a failure below frees what it got)
+        int rc_alloc = dev_alloc(c, (void **)&c->sel_img, N * sizeof(float), "selection scratch: image");
+        if (!rc_alloc) rc_alloc = dev_alloc(c, (void **)&c->sel_gx, KLT_GRAD_STRIDE * N * sizeof(float), "selection scratch: gradients");      // gradx / grady interleaved, like a slot's planes
+        if (!rc_alloc) rc_alloc = dev_alloc(c, (void **)&c->sat, 3 * N * sizeof(float), "selection scratch: summed-area tables");
+        if (!rc_alloc) rc_alloc = dev_alloc(c, (void **)&c->valmap, N * sizeof(float), "selection scratch: eigenvalue map");
+        if (rc_alloc) {
+            hipFree(c->sel_img); hipFree(c->sel_gx); hipFree(c->sat); hipFree(c->valmap);
+            c->sel_img = c->sel_gx = c->sel_gy = c->sat = c->valmap = nullptr;
+            return rc_alloc;
+        }
         c->sel_gy = c->sel_gx + 1;
-        HIPCHK(c, hipMalloc((void **)&c->sat, 3 * N * sizeof(float)));
-        HIPCHK(c, hipMalloc((void **)&c->valmap, N * sizeof(float)));
         c->sel_cap = N;
     }
     if (int rc = ensure(c, c->keys, c->keys_cap, (size_t)npow2)) return rc;
@@ -448,7 +454,7 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
         // results come back through pinned host memory the kernels write to directly
         if (!c->readback) {
             void *hp = nullptr;
-            HIPCHK(c, hipHostMalloc(&hp, 128 * sizeof(unsigned), hipHostMallocDefault));
+            if (int rc = host_alloc(c, &hp, 128 * sizeof(unsigned), "selection read-back words")) return rc;
             c->readback = (unsigned *)hp;
             c->pinned.push_back(hp);
         }

@@ -232,8 +232,12 @@ int klt_affine_alloc(klt_ctx *c, int state, int n)
     const int tn = (c->ap.window_width + 2) * (c->ap.window_height + 2);
     if (a.n < n || a.tn != tn) {
         if (a.rec) { if (int rc = sync_all(c)) return rc; hipFree(a.rec); hipFree(a.tpl); a.rec = nullptr; a.tpl = nullptr; a.n = 0; }
-        HIPCHK(c, hipMalloc((void **)&a.rec, (size_t)n * sizeof(klt_affine_rec)));
-        HIPCHK(c, hipMalloc((void **)&a.tpl, (size_t)n * 3 * tn * sizeof(float)));
+        DEVALLOC(c, a.rec, (size_t)n * sizeof(klt_affine_rec));
+        if (int rc = dev_alloc(c, (void **)&a.tpl, (size_t)n * 3 * tn * sizeof(float), "affine templates")) {
+            hipFree(a.rec);                                   // a state is its records AND its templates, or nothing
+            a.rec = nullptr;
+            return rc;
+        }
         a.n = n;
         a.tn = tn;
     }

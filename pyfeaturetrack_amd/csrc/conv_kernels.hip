@@ -32,6 +32,10 @@ __device__ __forceinline__ float correlate_at(const TIn *line, size_t stride, in
     const int size1 = t.n / 2;
     const int size2 = t.n - size1 - 1;
     const double *fw = t.k + size1;
+    // scipy.ndimage.convolve1d hands correlate1d origin -1 for an EVEN tap count ("if not weights.shape[0] & 1: origin -= 1"): the window of
+    // output `pos` then sits one sample to the right.  The reference's own taps are always odd (convolve.py:27-93); only
+    // klt_convolve_separate_f32 (_convolveSeparate with a caller's tap lists) can bring an even count, which is never symmetric-classed.
+    pos += (t.n & 1) ^ 1;
     double acc;
     if (pos - size1 >= 0 && pos + size2 < n) {          // interior: no index folding
         const TIn *c = line + (size_t)pos * stride;

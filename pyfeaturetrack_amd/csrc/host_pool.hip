@@ -44,12 +44,18 @@ struct Pool {
     std::atomic<uint8_t *> dst{nullptr};
     std::atomic<size_t> bytes{0};
     std::atomic<uint32_t> nchunks{0};
+    // a frame given as a table of row addresses (klt_host_compare_rows / klt_host_copy_rows): rows != nullptr, a chunk = rows_per_chunk rows,
+    // `b` / `dst` the contiguous side
+    std::atomic<const uint8_t *const *> rows{nullptr};
+    std::atomic<size_t> row_bytes{0};
+    std::atomic<uint32_t> nrows{0}, rows_per_chunk{0};
     uint32_t job_no = 0;                         // guarded by job_mutex
     int workers = 0;                             // guarded by job_mutex
     int lanes = 4;
 };
 
 Pool *g_pool = nullptr;
+thread_local bool tl_serial = false;            // klt_host_thread_serial: this thread's compares / copies stay on this thread
 std::once_flag g_once;
 
 inline void cpu_relax() { __builtin_ia32_pause(); }
@@ -67,8 +73,25 @@ uint32_t run_chunks(Pool *p, uint32_t tag)
         const uint8_t *a = p->a.load(std::memory_order_relaxed), *b = p->b.load(std::memory_order_relaxed);
         uint8_t *dst = p->dst.load(std::memory_order_relaxed);
         const size_t bytes = p->bytes.load(std::memory_order_relaxed);
+        const uint8_t *const *rows = p->rows.load(std::memory_order_relaxed);
+        const size_t row_bytes = p->row_bytes.load(std::memory_order_relaxed);
+        const uint32_t nrows = p->nrows.load(std::memory_order_relaxed), rpc = p->rows_per_chunk.load(std::memory_order_relaxed);
         if (!p->next.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) continue;
         // the claim succeeded while the tag was still ours: the fields read above are this job's
+        if (rows) {
+            const uint32_t r0 = idx * rpc, r1 = r0 + rpc < nrows ? r0 + rpc : nrows;
+            for (uint32_t r = r0; r < r1; r++) {
+                if (kind == 0) {
+                    if (p->differ.load(std::memory_order_relaxed)) break;
+                    if (memcmp(rows[r], b + (size_t)r * row_bytes, row_bytes) != 0) p->differ.store(1, std::memory_order_relaxed);
+                } else {
+                    memcpy(dst + (size_t)r * row_bytes, rows[r], row_bytes);
+                }
+            }
+            p->done.fetch_add(1, std::memory_order_release);
+            mine++;
+            continue;
+        }
         const size_t off = (size_t)idx * kChunk, len = bytes - off < kChunk ? bytes - off : kChunk;
         if (kind == 0) {
             if (!p->differ.load(std::memory_order_relaxed) && memcmp(a + off, b + off, len) != 0)
@@ -130,11 +153,20 @@ Pool *pool()
     return g_pool;
 }
 
-// 0 / 1 for a comparison (equal / different), 0 for a copy
-int run_job(int kind, const uint8_t *a, const uint8_t *b, uint8_t *dst, size_t bytes)
+// 0 / 1 for a comparison (equal / different), 0 for a copy.  rows != nullptr: side `a` is nrows rows of row_bytes bytes at rows[0 .. nrows-1]
+// (bytes = nrows * row_bytes), `b` / `dst` the contiguous side
+int run_job(int kind, const uint8_t *a, const uint8_t *b, uint8_t *dst, size_t bytes, const uint8_t *const *rows = nullptr, uint32_t nrows = 0,
+            size_t row_bytes = 0)
 {
-    Pool *p = bytes >= kParallelFrom ? pool() : nullptr;
+    Pool *p = bytes >= kParallelFrom && !tl_serial ? pool() : nullptr;
     if (!p || p->lanes <= 1 || !p->job_mutex.try_lock()) {
+        if (rows) {
+            for (uint32_t r = 0; r < nrows; r++) {
+                if (kind == 0) { if (memcmp(rows[r], b + (size_t)r * row_bytes, row_bytes) != 0) return 1; }
+                else memcpy(dst + (size_t)r * row_bytes, rows[r], row_bytes);
+            }
+            return 0;
+        }
         if (kind == 0) return memcmp(a, b, bytes) != 0;
         memcpy(dst, a, bytes);
         return 0;
@@ -144,7 +176,13 @@ int run_job(int kind, const uint8_t *a, const uint8_t *b, uint8_t *dst, size_t b
         try { std::thread(worker, p).detach(); } catch (...) { break; }
         p->workers++;
     }
-    const uint32_t n = (uint32_t)((bytes + kChunk - 1) / kChunk);
+    uint32_t rpc = 0;
+    if (rows) { rpc = (uint32_t)(kChunk / (row_bytes ? row_bytes : 1)); if (!rpc) rpc = 1; }
+    const uint32_t n = rows ? (nrows + rpc - 1) / rpc : (uint32_t)((bytes + kChunk - 1) / kChunk);
+    p->rows.store(rows, std::memory_order_relaxed);
+    p->row_bytes.store(row_bytes, std::memory_order_relaxed);
+    p->nrows.store(nrows, std::memory_order_relaxed);
+    p->rows_per_chunk.store(rpc, std::memory_order_relaxed);
     p->kind.store(kind, std::memory_order_relaxed);
     p->a.store(a, std::memory_order_relaxed);
     p->b.store(b, std::memory_order_relaxed);
@@ -185,6 +223,48 @@ int klt_host_copy(void *dst, const void *src, size_t bytes)
     return run_job(1, (const uint8_t *)src, nullptr, (uint8_t *)dst, bytes);
 }
 
+// rows that follow each other in memory (an image allocated in one block; an image mapped onto a contiguous array) are one range
+static bool rows_contiguous(const uint8_t *const *rows, int nrows, size_t row_bytes)
+{
+    for (int r = 1; r < nrows; r++)
+        if (rows[r] != rows[r - 1] + row_bytes) return false;
+    return true;
+}
+
+int klt_host_compare_rows(const uint8_t *const *rows, int nrows, size_t row_bytes, const void *b)
+{
+    if (nrows < 0 || ((!rows || !b) && nrows && row_bytes)) return KLT_ERR_ARG;
+    if (!nrows || !row_bytes) return 0;
+    for (int r = 0; r < nrows; r++) if (!rows[r]) return KLT_ERR_ARG;
+    if (rows_contiguous(rows, nrows, row_bytes)) return klt_host_compare(rows[0], b, (size_t)nrows * row_bytes);
+    return run_job(0, nullptr, (const uint8_t *)b, nullptr, (size_t)nrows * row_bytes, rows, (uint32_t)nrows, row_bytes);
+}
+
+int klt_host_copy_rows(void *dst, const uint8_t *const *rows, int nrows, size_t row_bytes)
+{
+    if (nrows < 0 || ((!rows || !dst) && nrows && row_bytes)) return KLT_ERR_ARG;
+    if (!nrows || !row_bytes) return KLT_OK;
+    for (int r = 0; r < nrows; r++) if (!rows[r]) return KLT_ERR_ARG;
+    if (rows_contiguous(rows, nrows, row_bytes)) return klt_host_copy(dst, rows[0], (size_t)nrows * row_bytes);
+    return run_job(1, nullptr, nullptr, (uint8_t *)dst, (size_t)nrows * row_bytes, rows, (uint32_t)nrows, row_bytes);
+}
+
+int klt_host_sample_rows(const uint8_t *const *rows, int nrows, int ncols, int ystep, int xstep, uint8_t *out, size_t cap)
+{
+    if (!rows || !out || nrows <= 0 || ncols <= 0 || ystep <= 0 || xstep <= 0) return KLT_ERR_ARG;
+    const size_t per_row = ((size_t)ncols + xstep - 1) / xstep, nr = ((size_t)nrows + ystep - 1) / ystep;
+    if (per_row * nr > cap) return KLT_ERR_ARG;
+    size_t k = 0;
+    for (int y = 0; y < nrows; y += ystep) {
+        const uint8_t *row = rows[y];
+        if (!row) return KLT_ERR_ARG;
+        for (int x = 0; x < ncols; x += xstep) out[k++] = row[x];
+    }
+    return (int)k;
+}
+
 int klt_host_lanes(void) { return pool()->lanes; }
+
+int klt_host_thread_serial(int on) { const int was = tl_serial; tl_serial = on != 0; return was; }
 
 }  // extern "C"

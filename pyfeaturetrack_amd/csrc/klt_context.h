@@ -249,6 +249,7 @@ struct klt_ctx {
     // experiment (tools/graph_frame_probe.py, profiles/README.md "HIP graphs"): one frame's launch set captured into a HIP graph and replayed
     bool capturing = false;                   // the streams are being captured: nothing may synchronise or allocate
     hipGraphExec_t probe_graph = nullptr;
+    int fail_alloc_in = -1;                   // KLT_OPT_FAIL_ALLOC_AFTER (test hook): >= 0 counts allocations down, the one that finds 0 fails
 };
 
 namespace kltapi {
@@ -260,6 +261,16 @@ int fail(klt_ctx *c, int code, const std::string &msg);      // sets the context
         hipError_t e_ = (call);                                                                      \
         if (e_ != hipSuccess)                                                                        \
             return fail((c), KLT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+// Every device / pinned-host allocation of the library goes through these two (api_context.hip).  Out of memory is an ANSWER, not a device
+// error: KLT_ERR_NOMEM with the size that was asked for, the pointer left null, and the runtime's sticky last-error cleared -- otherwise
+// the next HIPCHK(c, hipGetLastError()) behind a launch would report a stale out-of-memory after the caller has already dealt with it.
+int dev_alloc(klt_ctx *c, void **p, size_t bytes, const char *what);
+int host_alloc(klt_ctx *c, void **p, size_t bytes, const char *what);
+#define DEVALLOC(c, ptr, bytes)                                                                       \
+    do {                                                                                             \
+        if (int rc_ = kltapi::dev_alloc((c), (void **)&(ptr), (bytes), #ptr)) return rc_;            \
     } while (0)
 
 struct TimerScope {
@@ -322,7 +333,7 @@ int ensure(klt_ctx *c, T *&ptr, size_t &cap, size_t want)
     if (want <= cap && ptr) return 0;
     if (c->capturing) return fail(c, KLT_ERR_STATE, "a buffer would have to grow during a stream capture");
     if (ptr) { if (int rc = sync_all(c)) return rc; HIPCHK(c, hipFree(ptr)); ptr = nullptr; cap = 0; }
-    HIPCHK(c, hipMalloc((void **)&ptr, want * sizeof(T)));
+    DEVALLOC(c, ptr, want * sizeof(T));
     cap = want;
     return 0;
 }

@@ -219,6 +219,11 @@ def _prepare_pair(tc, ctx, img1, img2, speculate=False):
 
     def locate(key, slots):
         """(slot that holds the image -- or, speculating, probably does --, True when that is still to be verified)"""
+        if not sure and len(slots) > 1:
+            # speculating: the slot that was filled from this very object goes first (an image edited in place matches NEITHER slot's
+            # pixels, but two different frames of a static scene can share a lattice: taking the other one's slot costs a wasted
+            # tracker launch and a resend when the slot filled from this object holds the exact image -- ADVICE r5)
+            slots = sorted(slots, key=lambda s: not frames.filled_from(key, s))
         for s in slots:
             if frames.plausible(key, s, ctx):
                 if not sure:

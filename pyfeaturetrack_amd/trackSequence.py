@@ -42,17 +42,20 @@ class _FrameStager:
 
     def _run(self):
         try:
+            from ._abi import load_library
+            from ._frames import FrameKey
+            load_library().klt_host_thread_serial(1)        # (one core: spread over the pool's lanes this background copy slowed the loop, profiles/README.md)
             for img in self._frames:
                 if self._stop.is_set():                     # closed: no further frame is pulled, no buffer written
                     return
-                arr = image_to_array(img)
-                if arr.shape != self._shape or arr.dtype != np.uint8:
-                    self._ready.put(("raw", arr))          # the calling thread deals with it (size error, or a synchronous upload)
+                key = FrameKey(img)                         # (an 8-bit Pillow image is read through its row table: no array is made of it)
+                if key.stage_u8() != self._shape:
+                    self._ready.put(("raw", key.array()))  # the calling thread deals with it (size error, or a synchronous upload)
                     continue
                 buf = self._free.get()
                 if buf is None or self._stop.is_set():
                     return
-                buf[...] = arr                              # (one core: spread over the pool's lanes this background copy slowed the loop, profiles/README.md)
+                key.copy_into(buf)
                 self._ready.put(("staged", buf))
             self._ready.put((None, None))
         except BaseException as e:                          # noqa: BLE001 -- handed to the calling thread

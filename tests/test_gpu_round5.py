@@ -257,6 +257,39 @@ def test_feature_objects_are_store_row_pairs_with_the_reference_attributes():
     assert lone.val == -1
 
 
+def test_own_attributes_of_features_survive_the_klt_calls():
+    """klt.py:249-263 / selectGoodFeatures.py:117-128: a KLT_Feature of the reference is an attribute bag; a script that tags its features
+    (`feat.track_id = k`) finds the tags after KLTTrackFeatures / KLTReplaceLostFeatures, the calls stay on the column path, and the objects
+    of a tagged list are never handed to another list."""
+    import numpy as np
+    from pyfeaturetrack_amd.klt import shared_store
+    sgf, trk = _api_modules()
+    f = _frames_of(0, 2)
+    tc = make_tc(**_CASES[0]["tc"])
+    n = 83                                                         # (a length no other test uses: the recycling pool is per length)
+    ref = sgf.KLTSelectGoodFeatures(tc, f[0], n)
+    trk.KLTTrackFeatures(tc, f[0], f[1], ref)
+    want = _records(ref)
+    del ref                                                        # (its objects wait in the pool)
+    fl = sgf.KLTSelectGoodFeatures(tc, f[0], n)                    # ... and are taken over here
+    for k, feat in enumerate(fl):
+        feat.track_id = k
+    fl[4].history = [(fl[4].x, fl[4].y)]
+    trk.KLTTrackFeatures(tc, f[0], f[1], fl)
+    assert shared_store(fl) is fl._store and _records(fl) == want
+    assert [feat.track_id for feat in fl] == list(range(n)) and fl[4].history[0] == (int(fl[4].history[0][0]), int(fl[4].history[0][1]))
+    sgf.KLTReplaceLostFeatures(tc, f[1], fl)
+    assert [feat.track_id for feat in fl] == list(range(n))
+    assert np.array(fl, dtype=object).shape == (n,)
+    ids = {id(a) for a in fl}
+    keep = fl[4]
+    del fl, feat
+    again = sgf.KLTSelectGoodFeatures(tc, f[0], n)
+    assert keep.track_id == 4 and not any(hasattr(a, "track_id") for a in again) and id(keep) not in {id(a) for a in again}
+    trk.KLTTrackFeatures(tc, f[0], f[1], again)
+    assert _records(again) == want and len(ids) == n
+
+
 @default_lists
 def test_feature_objects_of_a_dropped_list_serve_the_next_selection():
     """klt._recycled through the public API: a per-frame `fl = KLTSelectGoodFeatures(...)` loop alternates between two sets of

@@ -29,7 +29,7 @@ def test_library_exports_every_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     lib.klt_abi_version.restype = ctypes.c_int
-    assert lib.klt_abi_version() == 9
+    assert lib.klt_abi_version() == 10
 
 
 def test_struct_layouts():
@@ -964,3 +964,106 @@ def test_track_sequence_call_order_without_replacement_or_prefetch(nframes, repl
                 assert tracked[0] < at("replace", k)[0]
     slots = {e[2] for e in log if e[0] == "send"}
     assert len(slots) <= (3 if prefetch else 2)
+
+
+def test_pillow_row_tables_pass_their_self_check_and_read_images_in_place():
+    """_pil.py: the layout of Pillow's image struct is found by a self-check, never assumed; the row table then serves the lattice, the
+    comparison and the staging copy of an 8-bit image without `np.asarray(img)` (0.43 ms per 1080p image: VERDICT r5 next-2) -- for images
+    Pillow allocated itself, images mapped onto a numpy array, images of several blocks, and images edited in place with putpixel."""
+    from PIL import Image
+    from pyfeaturetrack_amd import _pil
+    from pyfeaturetrack_amd._abi import load_library
+    from pyfeaturetrack_amd._frames import FrameKey, _lattice
+    st = _pil.status()
+    assert st["active"], "self-check failed: %s" % st["why_not"]
+    lib = load_library()
+    rng = np.random.default_rng(3)
+    for (h, w) in ((5, 23), (240, 320), (1080, 1920), (33, 1), (1, 40)):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        for img in (Image.fromarray(a), Image.frombytes("L", (w, h), a.tobytes()), Image.fromarray(a).copy()):
+            r = _pil.rows_of(img)
+            assert r is not None and (r.nrows, r.ncols) == (h, w)
+            key = FrameKey(img)
+            assert key.rows is not None and key.size == (w, h) and key.kind == "L"
+            assert key.sig() == _lattice(a)                                   # the same lattice an array of these pixels gives
+            assert key.same_as(a.copy()) and key.stage_u8() == (h, w)
+            other = a.copy()
+            other[h // 2, w // 3] ^= 1
+            assert not key.same_as(other)
+            buf = np.zeros((h, w), np.uint8)
+            key.copy_into(buf)
+            assert np.array_equal(buf, a)
+            assert key._arr is None, "the image was converted to an array after all"
+    # rows that do NOT follow each other in memory (two images' rows interleaved by hand): the general path of the C helpers
+    a = rng.integers(0, 256, (700, 1200), dtype=np.uint8)
+    padded = np.zeros((700, 1216), np.uint8)
+    padded[:, :1200] = a
+    table = (ctypes.c_void_p * 700)(*[padded.ctypes.data + 1216 * y for y in range(700)])
+    flat = a.copy()
+    assert lib.klt_host_compare_rows(table, 700, 1200, flat.ctypes.data) == 0
+    flat[699, 1199] ^= 1
+    assert lib.klt_host_compare_rows(table, 700, 1200, flat.ctypes.data) == 1
+    out = np.zeros_like(a)
+    assert lib.klt_host_copy_rows(out.ctypes.data, table, 700, 1200) == 0 and np.array_equal(out, a)
+    table[5] = None
+    assert lib.klt_host_compare_rows(table, 700, 1200, flat.ctypes.data) == -1          # KLT_ERR_ARG, not a fault
+    # an image edited in place: the rows are live storage
+    img = Image.frombytes("L", (320, 240), bytes(320 * 240))
+    key = FrameKey(img)
+    kept = np.zeros((240, 320), np.uint8)
+    assert key.same_as(kept)
+    img.putpixel((17, 31), 9)
+    assert not FrameKey(img).same_as(kept) and not key.same_as(kept)
+    # what it is not for: other modes and other objects take the array path
+    for other in (Image.new("F", (8, 8)), Image.new("RGB", (8, 8)), np.zeros((8, 8), np.uint8)):
+        assert _pil.rows_of(other) is None and FrameKey(other).rows is None
+
+
+def test_frame_cache_with_pillow_images_compares_every_pixel_without_converting():
+    """the frame cache on PIL images (what the reference's callers pass): same pixels in another image object = the same frame; putpixel
+    on or off the lattice = a new frame; none of it makes an array of the image"""
+    from PIL import Image
+    from pyfeaturetrack_amd._frames import FrameCache, FrameKey
+
+    class FakeCtx:
+        def __init__(self):
+            self.has, self.sent, self.pinned = {}, [], 0
+
+        def frame_resident(self, slot):
+            return self.has.get(slot, False)
+
+        def pinned_array(self, shape, dtype=np.uint8):
+            self.pinned += 1
+            return np.zeros(shape, dtype)
+
+        def upload_async(self, slot, buf):
+            self.has[slot] = True
+            self.sent.append((slot, buf.copy()))
+
+        def upload_wait(self):
+            pass
+
+    class TC:
+        trustFrameIdentity = False
+
+    ctx, cache = FakeCtx(), FrameCache(TC())
+    a = (np.arange(1080 * 1920) % 251).astype(np.uint8).reshape(1080, 1920)
+    img = Image.frombytes("L", (1920, 1080), a.tobytes())
+    twin = Image.fromarray(a)
+    k = FrameKey(img)
+    cache.send(ctx, 0, k)
+    assert k._arr is None and np.array_equal(ctx.sent[0][1], a)
+    for im in (img, twin):
+        k = FrameKey(im)
+        assert cache.find(k, (0, 1), ctx) == 0 and k._arr is None
+    img.putpixel((0, 0), (int(a[0, 0]) + 1) % 256)                                 # a lattice pixel
+    assert cache.find(FrameKey(img), (0, 1), ctx) is None and cache.find(FrameKey(twin), (0, 1), ctx) == 0
+    img.putpixel((0, 0), int(a[0, 0]))
+    assert cache.find(FrameKey(img), (0, 1), ctx) == 0
+    img.putpixel((31, 17), (int(a[17, 31]) + 1) % 256)                             # off the lattice: only the full comparison sees it
+    k = FrameKey(img)
+    assert cache.find(k, (0, 1), ctx) is None and k._arr is None
+    cache.send(ctx, 1, k)
+    assert ctx.sent[-1][0] == 1 and ctx.sent[-1][1][17, 31] == (int(a[17, 31]) + 1) % 256
+    assert cache.find(FrameKey(img), (0, 1), ctx) == 1 and cache.find(FrameKey(twin), (0, 1), ctx) == 0
+    assert cache.filled_from(FrameKey(img), 1) and cache.filled_from(FrameKey(img), 0) and not cache.filled_from(FrameKey(twin), 0)

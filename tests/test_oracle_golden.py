@@ -280,3 +280,23 @@ def test_min_distance_walk_restatement_vs_reference(golden_dir):
         feats = [list(r) for r in g["emd_%d_in" % ci]]
         enforce_minimum_distance(points, feats, int(ncols), int(nrows), int(mindist), float(min_eig), bool(overwrite))
         assert np.array_equal(np.array(feats, np.float64), g["emd_%d_out" % ci]), ci
+
+
+def test_convolve_separate_vs_reference(golden_dir, img0):
+    """ko_convolve_separate against `_convolveSeparate` of the reference itself (convolve.py:208-219; tests/golden/gen_convolve_separate.py):
+    the reference's own tap pairs at three sigmas and tap lists it never makes -- neither symmetric nor antisymmetric, even counts,
+    one tap, more taps than the image is wide, a pair just inside / outside correlate1d's symmetry tolerance."""
+    import hashlib
+    g = np.load(os.path.join(golden_dir, "convolve_separate.npz"))
+    names = [str(n) for n in g["names"]]
+    assert len(names) == 16 and {"asym_5_7", "even_4_6", "one_one", "wide_13_11", "almost_sym"} <= set(names)
+    f0 = img0.astype(np.float32)
+    rows, cols = g["img0_rows"], g["img0_cols"]
+    for name in names:
+        hk, vk = g[name + "_h"], g[name + "_v"]
+        for tag in ("small", "tiny"):
+            assert np.array_equal(ko.convolve_separate(g[tag], hk, vk), g["%s_%s" % (name, tag)]), (name, tag)
+        out = ko.convolve_separate(f0, hk, vk)
+        assert np.array_equal(out[rows], g[name + "_img0_rows"]) and np.array_equal(out[:, cols], g[name + "_img0_cols"]), name
+        assert hashlib.sha256(out.tobytes()).digest() == g[name + "_img0_sha256"].tobytes(), name
+    assert np.array_equal(ko.convolve_separate(g["small"], [1.0], [1.0]), g["small"])
