@@ -104,6 +104,7 @@ def run_cfg2(args, json_fd):
 
     elapsed, regions, enqueue_s = timed_regions(ranks, region, args.repeats)
     t_last = (step_no[0] - 1) % 2
+    rccl = ranks.validation(args.steps)                 # (collective: every rank, right behind the timed regions)
 
     # correctness of what was timed: the last step's records of EVERY resident pair (and, N > 1, what the gather delivered of them)
     outs = {}
@@ -386,7 +387,7 @@ def run_cfg2(args, json_fd):
                              "pairs_in_flight": nctx * B, "contexts": nctx, "pairs_per_launch": B, "resident_pairs": NP,
                              "features_per_pair": NFEAT, "pairs_per_step": NP * world, "ms_per_pair": ms_per_pair, "tracked": tracked,
                              "recovered_shift_px": shift, "imposed_shift_px": list(synth.DEFAULT_SHIFT),
-                             "rccl_ranks": world if distributed else 0,
+                             "rccl_ranks": rccl.get("rccl_ranks", 0),
                              "parallelism": "%d pairs per GPU" % NP + (", one RCCL all-gather (libkltgpu side stream) of each context's [%d pairs x "
                                                                       "5000] record table per step" % PL if distributed else "")})
         line.update(parity)
@@ -399,6 +400,8 @@ def run_cfg2(args, json_fd):
                                            "through the resident pairs (median of 5 runs of %d pairs); `value` is the throughput with %d "
                                            "independent pairs in flight" % (4 * PL, nctx * B)}
         line["roofline"], line["cpu_baseline"], line["extra"] = roofline, cpu, extra
+        if rccl and isinstance(extra, dict):
+            extra["rccl_validation"] = rccl
     for cx in ctxs:
         cx.close()
     # The figures a caller of the API / of a sequence loop sees are taken in a process that holds nothing else: the headline's contexts
@@ -426,9 +429,12 @@ def run_cfg2(args, json_fd):
         # the other four BASELINE configs, each in a child process of its own (benchlib/sweep.py): compact records in extra.configs
         from .sweep import config_sweep
         extra["configs"], sweep_failed = config_sweep(["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    if line is None:
+        Ranks.fail_on_validation(rccl)                  # (the other ranks leave non-zero as well: the launcher then reports the run as failed)
     if line is not None:
         emit(json_fd, line)
         fail_on_parity(parity)
+        Ranks.fail_on_validation(rccl)
         if sweep_failed:
             raise SystemExit("config sweep: %s failed: %s" % (", ".join(sweep_failed), "; ".join(extra["configs"][c]["error"] for c in sweep_failed)))
 

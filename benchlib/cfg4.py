@@ -54,6 +54,7 @@ def run_cfg4(args, json_fd):
     for _ in range(max(1, args.warmup)):
         step()
     el, regions, enq = timed_regions(ranks, region, args.repeats)
+    rccl = ranks.validation(args.steps)
     # what was timed, against the oracle: the first and the last pair of rank 0's shard
     out = ctx.featbuf_download(T_OUT, pairs * nf).reshape(pairs, nf) if pairs else np.zeros((0, nf), parallel.FEAT_DTYPE)
     ko = load_oracle() if ranks.rank == 0 else None
@@ -123,13 +124,16 @@ def run_cfg4(args, json_fd):
                          "[pairs x 2000] record table to rank 0" % (total, pairs), scaling="strong",
                          extra_cfg={"pairs_per_step": total, "pairs_per_rank": [len(parallel.shard_range(total, ranks.world, r)) for r in range(ranks.world)],
                                     "tracked_rank0": tracked,
-                                    "rccl_ranks": ranks.world if ranks.distributed else 0, "gathered_table_ok": gathered_ok,
+                                    "rccl_ranks": rccl.get("rccl_ranks", 0), "gathered_table_ok": gathered_ok,
                                     "parallelism": "pairs sharded contiguously (shards differ by at most one pair); no data-path collective, one gather with a count per rank"})
         line.update(par)
         line["roofline"], line["cpu_baseline"] = roof, cpu
         line["extra"] = {"region_ms_per_step": region_stats(regions, args.steps, el), "host_enqueue_ms_per_step": enq / args.steps * 1e3}
+        if rccl:
+            line["extra"]["rccl_validation"] = rccl
         emit(json_fd, line)
         if gathered_ok is False:
             raise SystemExit("the gathered table differs from the shards")
         fail_on_parity(par)
+    Ranks.fail_on_validation(rccl)
 

@@ -218,6 +218,7 @@ def run_cfg5_blocks(args, json_fd, ranks):
     # others still work on the first: N pipelined replicas, not one sequence)
     reps = 1
     el, regions, enq = timed_regions(ranks, block, max(5, min(args.repeats, 15)))
+    rccl = ranks.validation(1)
     # the list after the last frame of every block, gathered on rank 0 (rank order = frame order)
     ctx.gather_featbuf_async(last, FB_ALL, n, 0)
     ctx.comm_wait()
@@ -232,9 +233,10 @@ def run_cfg5_blocks(args, json_fd, ranks):
                                 "cfg-5 on %d GPU(s): ONE 3840x2160 sequence in blocks of %d frames per GPU, 20000 features, sequential "
                                 "mode, lost features replaced after every frame; the feature list is the baton between the blocks (RCCL "
                                 "send / receive), the blocks' pyramids and selection scores are prepared on the owners' build streams" % (world, B),
-                                extra_cfg={"rccl_ranks": world, "live_after_each_block": [int((t["val"] >= 0).sum()) for t in table],
+                                extra_cfg={"rccl_ranks": rccl.get("rccl_ranks", 0), "rccl_validation": rccl, "live_after_each_block": [int((t["val"] >= 0).sum()) for t in table],
                                            "list_sha16_after_each_block": [list_digest(t) for t in table],
                                            "ms_per_frame_of_the_chain": el / (reps * B * world) * 1e3, "baton_copy_ok": baton_ok,
                                            "region_ms": {"median": el * 1e3, "min": min(regions) * 1e3, "max": max(regions) * 1e3}}))
     ctx.close()
+    Ranks.fail_on_validation(rccl)
 

@@ -224,6 +224,8 @@ class Ranks:
             print("warning: WORLD_SIZE=%d but --gpus %d" % (self.world, args.gpus), file=sys.stderr)
         self.distributed = self.world > 1 or os.environ.get("KLT_FORCE_DIST") == "1"   # the env var exercises the RCCL path on one GPU
         self.ctxs = []
+        self.gpus_asked = args.gpus
+        self.local_s = []                                  # this rank's own elapsed time of every timed region (the line's is the MAX over ranks)
 
     def attach(self, ctxs):
         """One communicator per context, same order on every rank."""
@@ -255,7 +257,38 @@ class Ranks:
         enq = time.perf_counter() - t0
         self.sync_local()
         el = time.perf_counter() - t0
+        self.local_s.append(el)
         return self.max_over_ranks(el), enq
+
+    def validation(self, steps_per_region):
+        """The N > 1 line validates itself.  What RCCL reports -- klt_comm_info of every context of every rank, all-reduced:
+        `rccl_ranks` = the SMALLEST communicator any rank is in, `rccl_rank_ids_seen` = how many different rank numbers answered -- and every
+        rank's own median region time, min / max over the ranks (the line's ms_per_step is the max by contract).  Collective: every rank
+        calls it at the same point.  {} without communicators."""
+        if not self.distributed:
+            return {}
+        info = [cx.comm_info() for cx in self.ctxs]
+        sizes, ids = [i[0] for i in info], {i[1] for i in info}
+        onehot = [1.0 if r in ids else 0.0 for r in range(12)]
+        loc = sorted(self.local_s)[len(self.local_s) // 2] / max(1, steps_per_region) * 1e3 if self.local_s else 0.0
+        v = self.ctxs[0].comm_allreduce_max([-float(min(sizes)), float(max(sizes)), loc, -loc] + onehot)
+        out = {"rccl_ranks": int(-v[0]), "rccl_ranks_largest_communicator": int(v[1]), "rccl_rank_ids_seen": int(sum(v[4:])) if self.world <= 12 else None,
+               "gpus_asked": self.gpus_asked, "world_size": self.world,
+               "per_rank_ms_per_step": {"max": v[2], "min": -v[3], "note": "every rank's own median timed region / steps; the line's ms_per_step is the MAX over ranks of each region"}}
+        bad = []
+        if out["rccl_ranks"] < self.gpus_asked or out["rccl_ranks"] != self.world or out["rccl_ranks_largest_communicator"] != self.world:
+            bad.append("communicators of %d..%d ranks, WORLD_SIZE %d, --gpus %d" % (out["rccl_ranks"], out["rccl_ranks_largest_communicator"], self.world, self.gpus_asked))
+        if out["rccl_rank_ids_seen"] is not None and out["rccl_rank_ids_seen"] != self.world:
+            bad.append("%d different rank numbers answered, %d expected" % (out["rccl_rank_ids_seen"], self.world))
+        if bad:
+            out["rccl_validation_failed"] = "; ".join(bad)
+        return out
+
+    @staticmethod
+    def fail_on_validation(val):
+        """after the line is out: a run in which some rank saw fewer peers than --gpus is not a measurement of --gpus GPUs"""
+        if val.get("rccl_validation_failed"):
+            raise SystemExit("the ranks of this run do not add up: " + val["rccl_validation_failed"])
 
 
 class OneGpu:

@@ -122,6 +122,16 @@ class FrameKey:
             copy_pixels(buf, self.array())
 
 
+def pixels_of(img):
+    """the image as a uint8 / float32 array of its own (`image_to_array`; an 8-bit Pillow image is copied out of its row table)"""
+    key = FrameKey(img)
+    if key.rows is None:
+        return key.array()
+    out = np.empty((key.rows.nrows, key.rows.ncols), np.uint8)
+    key.copy_into(out)
+    return out
+
+
 class _Held:
     """what a slot holds: the host copy it was uploaded from (`kept`; pinned for 8-bit frames), the lattice of that copy, a weak
     reference to the image object, and the number of the last asynchronous upload made from `kept`"""

@@ -207,7 +207,8 @@ def _select_locked(ctx, tc, img, nFeatures, mode, featurelist):
         # KLTChangeTCPyramid with a large search range: the reference's selection never builds a pyramid (selectGoodFeatures.py:183-197)
         # and succeeds on such a frame, so the selection smooths and differentiates in its own slot
         slot = slots[2]
-        ctx.upload(slot, image_to_array(img))
+        from ._frames import pixels_of
+        ctx.upload(slot, pixels_of(img))
     replacing = mode == selectionMode.REPLACING_SOME
     n = int(nFeatures) if featurelist is None else len(featurelist)
     store = fl_in = aff = was_lost = None

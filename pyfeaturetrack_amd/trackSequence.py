@@ -12,7 +12,7 @@ import numpy as np
 
 from .backend import REPLACING_SOME, SELECTING_ALL, context_of
 from .klt import KLT_FeatureTable
-from .selectGoodFeatures import _fix_window, _slots_of, image_to_array
+from .selectGoodFeatures import _fix_window, _slots_of
 
 _FB_TABLE = 60000            # feature-buffer ids used by this module: the table, then one view per frame
 _FB_ROW0 = 60001
@@ -108,7 +108,8 @@ def _track_sequence_locked(ctx, tc, frames, nFeatures, replace_lost, async_inges
     s = list(_slots_of(tc))              # ring of three frame slots (the third is otherwise the per-frame API's selection slot)
     cache_of(tc).forget()               # this call fills the slots itself: what the per-frame API remembers of them is void
     ring = 3 if prefetch else 2
-    first = image_to_array(next(frames))
+    from ._frames import pixels_of
+    first = pixels_of(next(frames))
     rows = [first]
     nrows, ncols = first.shape
     affine = tc.affineConsistencyCheck >= 0
@@ -182,7 +183,7 @@ def _track_sequence_locked(ctx, tc, frames, nFeatures, replace_lost, async_inges
                 item = stager.next()
                 return item if item[0] is not None else None
             img = next(frames, None)
-            return None if img is None else ("raw", image_to_array(img))
+            return None if img is None else ("raw", pixels_of(img))
 
         def track(j):                                # frame j - 1 -> j: row j - 1 of the table in, row j out
                 cur, prev = s[j % ring], s[(j - 1) % ring]

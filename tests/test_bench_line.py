@@ -65,3 +65,67 @@ def test_sweep_timeout_is_a_failure(monkeypatch):
     monkeypatch.setattr(sweep.subprocess, "run", run)
     out, failed = sweep.config_sweep()
     assert len(failed) == 4 and "timed out" in out["cfg5"]["error"]
+
+
+# ---------------------------------------------------------------------------------------------- the N > 1 line validates itself
+class _FakeCtx:
+    """a context whose communicator has `size` ranks and whose all-reduce sees the vectors of `peers` (other ranks' contributions)"""
+
+    def __init__(self, size, rank, peers=()):
+        self.size, self.rank, self.peers = size, rank, list(peers)
+
+    def comm_info(self):
+        return self.size, self.rank
+
+    def comm_allreduce_max(self, values):
+        out = list(values)
+        for p in self.peers:
+            out = [max(a, b) for a, b in zip(out, p)]
+        return out
+
+
+def _ranks(monkeypatch, world, gpus, rank=0):
+    from benchlib.common import Ranks
+    monkeypatch.setenv("RANK", str(rank))
+    monkeypatch.setenv("WORLD_SIZE", str(world))
+    monkeypatch.delenv("KLT_FORCE_DIST", raising=False)
+    monkeypatch.delenv("KLT_RANKS_SHARE_DEVICE", raising=False)
+    return Ranks(types.SimpleNamespace(gpus=gpus))
+
+
+def _peer(size, rank, ms):
+    return [-float(size), float(size), ms, -ms] + [1.0 if r == rank else 0.0 for r in range(12)]
+
+
+def test_rank_validation_reports_what_rccl_says_and_every_ranks_own_time(monkeypatch):
+    from benchlib.common import Ranks
+    r = _ranks(monkeypatch, 4, 4)
+    r.ctxs = [_FakeCtx(4, 0, [_peer(4, 1, 2.5), _peer(4, 2, 2.0), _peer(4, 3, 2.2)]), _FakeCtx(4, 0), _FakeCtx(4, 0)]
+    r.local_s = [0.040, 0.042, 0.041]                    # this rank's regions of 20 steps: median 2.05 ms per step
+    v = r.validation(20)
+    assert v["rccl_ranks"] == 4 and v["rccl_ranks_largest_communicator"] == 4 and v["rccl_rank_ids_seen"] == 4 and v["gpus_asked"] == 4
+    assert abs(v["per_rank_ms_per_step"]["max"] - 2.5) < 1e-9 and abs(v["per_rank_ms_per_step"]["min"] - 2.0) < 1e-9
+    assert "rccl_validation_failed" not in v
+    Ranks.fail_on_validation(v)
+    Ranks.fail_on_validation({})                         # one GPU, no communicator: nothing to validate
+
+
+def test_rank_validation_fails_the_run_when_a_rank_saw_fewer_peers_than_asked(monkeypatch):
+    from benchlib.common import Ranks
+    # --gpus 8 under a launcher that started 4 ranks
+    r = _ranks(monkeypatch, 4, 8)
+    r.ctxs = [_FakeCtx(4, 0, [_peer(4, k, 2.0) for k in (1, 2, 3)])]
+    v = r.validation(1)
+    assert v["rccl_ranks"] == 4 and "--gpus 8" in v["rccl_validation_failed"]
+    with pytest.raises(SystemExit):
+        Ranks.fail_on_validation(v)
+    # one rank's communicator is smaller than the others' (two launches sharing a rendezvous file)
+    r = _ranks(monkeypatch, 4, 4)
+    r.ctxs = [_FakeCtx(4, 0, [_peer(4, 1, 2.0), _peer(2, 1, 2.0), _peer(4, 3, 2.0)])]
+    v = r.validation(1)
+    assert v["rccl_ranks"] == 2 and v["rccl_ranks_largest_communicator"] == 4 and "rccl_validation_failed" in v
+    # two processes answered as the same rank
+    r = _ranks(monkeypatch, 4, 4)
+    r.ctxs = [_FakeCtx(4, 0, [_peer(4, 1, 2.0), _peer(4, 1, 2.0), _peer(4, 3, 2.0)])]
+    v = r.validation(1)
+    assert v["rccl_rank_ids_seen"] == 3 and "different rank numbers" in v["rccl_validation_failed"]

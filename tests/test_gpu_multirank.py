@@ -50,6 +50,10 @@ def test_cfg2_ranks_with_their_own_pairs_and_the_all_gather(world, tmp_path, stu
     assert line["parity_checked"] is True and line["parity_cases"] == 5 and line["max_abs_dx"] <= 1e-3
     assert "as received through the all-gather" in line["parity_what"]
     assert line["value"] > 0 and line["scaling"] == "weak"
+    val = line["extra"]["rccl_validation"]               # what the communicators themselves report, all-reduced
+    assert val["rccl_ranks"] == val["rccl_ranks_largest_communicator"] == val["rccl_rank_ids_seen"] == val["world_size"] == world
+    assert 0 < val["per_rank_ms_per_step"]["min"] <= val["per_rank_ms_per_step"]["max"] <= line["ms_per_step"] * 1.0001
+    assert "rccl_validation_failed" not in val
 
 
 def test_cfg2_three_contexts_per_rank_as_in_the_default_arrangement(tmp_path, stub_rccl):
@@ -70,6 +74,7 @@ def test_cfg4_shards_of_unequal_size_through_the_gather_with_counts(tmp_path, st
                           "--no-cpu-baseline", "--min-timed-s", "0"], tmp_path / str(world), stub_rccl)
         cfg = line["config"]
         assert cfg["pairs_per_rank"] == shards and cfg["rccl_ranks"] == world and cfg["gathered_table_ok"] is True
+        assert line["extra"]["rccl_validation"]["rccl_rank_ids_seen"] == world and "rccl_validation_failed" not in line["extra"]["rccl_validation"]
         assert line["parity_checked"] is True and line["parity_cases"] == shards[0] + 1, line      # every pair of rank 0 + the last pair as gathered
         assert "as gathered" in line["parity_what"]
 
