@@ -439,13 +439,21 @@ def run_cfg2(args, json_fd):
             raise SystemExit("config sweep: %s failed: %s" % (", ".join(sweep_failed), "; ".join(extra["configs"][c]["error"] for c in sweep_failed)))
 
 
-def sequence_from_host(device, w, h, n, nframes=256, link_gbps=None):
+SEQ_ARRANGEMENTS = {"two_copy_streams": 2, "one_copy_stream": 1}      # name -> KLT_OPT_COPY_STREAMS
+SEQ_KEPT = "one_copy_stream"                                           # what KLTTrackSequence uses (profiles/README.md, round 6)
+
+
+def sequence_from_host(device, w, h, n, nframes=256, link_gbps=None, alternations=5, only=None):
     """What a video pipeline pays per frame when the frames come from the host: sequential mode, ONE new u8 frame per
     step from pinned host memory (klt_upload_u8_async on the copy streams, overlapping the previous frame's kernels), pyramid of the new
     frame + score preparation on the build stream, track + replacement of the lost features on the main stream, the next tracker enqueued
     ahead of the host's look -- the loop of `--config cfg5` with an upload per frame -- and the records written into a device table of 16
     rows that is downloaded every 16 frames.  16 distinct frames of the periodic texture sit in pinned memory and are visited up and down
-    (0, 1, ... 15, 14, ... 0, ...), so consecutive frames always differ by one step of (3.3, -2.1) pixels.  Secondary figure, never `value`."""
+    (0, 1, ... 15, 14, ... 0, ...), so consecutive frames always differ by one step of (3.3, -2.1) pixels.  Secondary figure, never `value`.
+    The loop is run in two arrangements alternately, `alternations` times each after a discarded first call: consecutive
+    uploads alternating between two copy streams (rounds 3-5, still the default for pairs) and all on ONE copy stream; `ms_per_frame` is the
+    median of the arrangement the product's loop (KLTTrackSequence) uses, SEQ_KEPT.  (Sending frame k + 3 earlier -- right behind
+    klt_select_begin_async -- was the other half of the experiment: no gain on one stream, a loss on two; profiles/README.md.)"""
     tc = cfg2_context()
     tc.max_residue = 10.0
     ctx = Context(device)
@@ -511,14 +519,36 @@ def sequence_from_host(device, w, h, n, nframes=256, link_gbps=None):
             ctx.sync()
             return None if live is None else live.copy()
 
+        def timed(name):
+            ctx.sync()
+            ctx.set_option(20, SEQ_ARRANGEMENTS[name])                        # KLT_OPT_COPY_STREAMS
+            t = time.perf_counter()
+            tab = run(nframes)
+            return (time.perf_counter() - t) / (nframes - 1) * 1e3, tab
+
         run(2 * NT)                                                           # sizes every buffer
-        t = time.perf_counter()
-        table = run(nframes)
-        ms = (time.perf_counter() - t) / (nframes - 1) * 1e3
+        timed(only or SEQ_KEPT)                                               # (the first full call of a process reads 10-20 % high whatever its order: discarded)
+        names = [only] if only else list(SEQ_ARRANGEMENTS)            # (`only`: a profiler's pass over one arrangement)
+        runs = {name: [] for name in names}
+        tables = {}
+        for _ in range(max(1, alternations)):
+            for name in names:
+                ms_one, tables[name] = timed(name)
+                runs[name].append(ms_one)
+        ctx.set_option(20, 2)
+        kept = only or SEQ_KEPT
+        assert all(np.array_equal(tables[kept], tab) for tab in tables.values()), "the two arrangements of the loop gave different records"
+        table = tables[kept]
+        med = {name: statistics.median(v) for name, v in runs.items()}
+        ms = med[kept]
         alive = int((table.reshape(NT, n)[NT - 2]["val"] >= 0).sum())
         gbps = w * h / (ms * 1e-3) / 1e9
         out = {"ms_per_frame": ms, "features_per_s": n / (ms * 1e-3), "frames": nframes, "ingest_GBps": gbps,
-               "alive_after_replacement": alive, "frame": "%dx%d" % (w, h), "features": n}
+               "alive_after_replacement": alive, "frame": "%dx%d" % (w, h), "features": n,
+               "arrangement": kept,
+               "arrangements_ms_per_frame": {name: {"median": med[name], "runs": runs[name]} for name in runs}}
+        if "two_copy_streams" in med and kept != "two_copy_streams":
+            out["kept_over_two_copy_streams"] = med[kept] / med["two_copy_streams"]
         if link_gbps:
             out["link_GBps"] = link_gbps
             out["ingest_frac_of_link"] = gbps / link_gbps

@@ -104,6 +104,11 @@ void       *klt_stream_handle(klt_ctx *ctx);                /* the context's hip
 #define KLT_OPT_BUILD_STREAM 15
 #define KLT_OPT_TRACK_TREE_SUMS 18        /* 0 (default): the tracker adds its five window sums (and the residue) in the reference's order -- records identical to the reference's bit for bit; 1: butterfly sums in registers (7x7 / 15x15 quad kernels; same precision, other order of the additions): positions agree to 1e-3 px, a status word can differ where a feature sits on a threshold */
 #define KLT_OPT_SCORE_SETS 16            /* how many sets of prepared selection scores (klt_select_prepare_async) the context keeps: 2 (default) .. 256; a selection frees the set it uses */
+/* 1 .. 8 (default 2; KLT_COPY_STREAMS in the environment sets the initial value): the copy streams consecutive klt_upload_u8_async calls
+ * alternate between.  Two let the frames of a PAIR travel side by side (45 GB/s against 28-39 on one or three); a SEQUENCE loop -- one new
+ * frame per step -- is faster on ONE (0.280 against 0.307 ms per 4K frame, 0.141-0.152 against 0.148-0.155 at 1080p: with two, the host's look
+ * at every other frame's selection waits 211 instead of 102 us, profiles/README.md): KLTTrackSequence and bench.py's sequence loops set 1. */
+#define KLT_OPT_COPY_STREAMS 20
 /* test hook: >= 0: the library's (value + 1)-th device / pinned-host allocation from now is refused as if memory had run out (KLT_ERR_NOMEM; the
  * context stays usable, the call can be repeated); -1 (default): off.  Lets the tests walk every allocation site of a call sequence. */
 #define KLT_OPT_FAIL_ALLOC_AFTER 19

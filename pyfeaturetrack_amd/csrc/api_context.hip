@@ -359,6 +359,13 @@ int klt_set_option(klt_ctx *c, int option, int value)
         c->pre.resize((size_t)value);
         return KLT_OK;
     }
+    if (option == KLT_OPT_COPY_STREAMS) {
+        if (value < 1 || value > klt_ctx::kMaxCopyStreams) return fail(c, KLT_ERR_ARG, "KLT_OPT_COPY_STREAMS takes 1..8");
+        if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));          // uploads in flight finish on the streams they were given
+        for (hipStream_t x : c->cextra) if (x) HIPCHK(c, hipStreamSynchronize(x));
+        c->ncopy = value;
+        return KLT_OK;
+    }
     if (option == KLT_OPT_FAIL_ALLOC_AFTER) { c->fail_alloc_in = value; return KLT_OK; }
     if (option == KLT_OPT_TRACK_TREE_SUMS) { c->track_tree_sums = value != 0; return KLT_OK; }
     if (option == KLT_OPT_TOPK_PREFILTER) { c->use_topk = value != 0; return KLT_OK; }

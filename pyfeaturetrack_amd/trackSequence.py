@@ -21,48 +21,84 @@ _OPT_SELECT_AFFINE_STATE = 4
 
 
 _OPT_BUILD_STREAM = 15
+_OPT_COPY_STREAMS = 20
+SEQUENCE_COPY_STREAMS = 1        # copy streams a sequence call's uploads use (the default of a context, two, is for the two frames of a pair)
+
+
+STAGER_WORKERS = 0                       # 0: by frame size (below); 1 / 2 / ...: that many helper threads
+STAGER_THREADS_FROM_BYTES = 4 << 20      # frames of this size and above are staged by two helper threads (one core copies a 4K frame in
+                                         # 0.26 ms -- longer than the GPU needs for it; tools/stage_copy_probe.py)
 
 
 class _FrameStager:
-    """Reads the frames and copies them into pinned staging buffers on a helper thread (numpy's copy and the frame source's decoding
+    """Reads the frames and copies them into pinned staging buffers on helper threads (the copy and the frame source's decoding
     release the GIL), so that the host copy of frame k+2 -- 2 MB at 1080p, as long as the tracker of a frame runs -- is made while the
-    calling thread waits for the GPU in frame k's replacement pass.  Only the helper thread advances the iterator; every call
-    into the library stays on the calling thread."""
+    calling thread waits for the GPU in frame k's replacement pass.  Every call into the library's device side stays on the calling
+    thread.  With `workers` > 1 several frames are copied at the same time, each by one core: the iterator is advanced and the
+    staging buffer taken under one lock, in frame order (so the buffers are handed out exactly as a single helper would), the copies
+    run side by side, and `next()` delivers the frames in order."""
 
-    def __init__(self, frames, buffers, shape):
+    def __init__(self, frames, buffers, shape, workers=1):
         import queue
         import threading
         self._frames, self._shape = frames, shape
-        self._free, self._ready = queue.Queue(), queue.Queue()
+        self._free = queue.Queue()
         self._stop = threading.Event()
+        self._pull = threading.Lock()               # advancing the iterator + taking a buffer: one frame at a time, in order
+        self._cv = threading.Condition()            # results by frame index
+        self._results, self._next_in, self._next_out, self._ended = {}, 0, 0, False
         for b in buffers:
             self._free.put(b)
-        self._thread = threading.Thread(target=self._run, name="klt-frame-stager", daemon=True)
-        self._thread.start()
+        self._threads = [threading.Thread(target=self._run, name="klt-frame-stager-%d" % i, daemon=True) for i in range(max(1, workers))]
+        for t in self._threads:
+            t.start()
+
+    def _publish(self, idx, kind, item):
+        with self._cv:
+            self._results[idx] = (kind, item)
+            self._cv.notify_all()
 
     def _run(self):
-        try:
-            from ._abi import load_library
-            from ._frames import FrameKey
-            load_library().klt_host_thread_serial(1)        # (one core: spread over the pool's lanes this background copy slowed the loop, profiles/README.md)
-            for img in self._frames:
-                if self._stop.is_set():                     # closed: no further frame is pulled, no buffer written
-                    return
-                key = FrameKey(img)                         # (an 8-bit Pillow image is read through its row table: no array is made of it)
-                if key.stage_u8() != self._shape:
-                    self._ready.put(("raw", key.array()))  # the calling thread deals with it (size error, or a synchronous upload)
-                    continue
-                buf = self._free.get()
-                if buf is None or self._stop.is_set():
-                    return
+        from ._abi import load_library
+        from ._frames import FrameKey
+        load_library().klt_host_thread_serial(1)            # (one core per frame: spread over the pool's lanes this background copy slowed the loop, profiles/README.md)
+        while True:
+            idx = None
+            try:
+                with self._pull:
+                    if self._stop.is_set() or self._ended:  # closed (no further frame is pulled, no buffer written) / the source has ended
+                        return
+                    idx = self._next_in
+                    try:
+                        img = next(self._frames)
+                    except StopIteration:
+                        self._ended = True
+                        self._publish(idx, None, None)
+                        return
+                    self._next_in = idx + 1
+                    key = FrameKey(img)                     # (an 8-bit Pillow image is read through its row table: no array is made of it)
+                    if key.stage_u8() != self._shape:
+                        self._publish(idx, "raw", key.array())      # the calling thread deals with it (size error, or a synchronous upload)
+                        continue
+                    buf = self._free.get()
+                    if buf is None or self._stop.is_set():
+                        return
                 key.copy_into(buf)
-                self._ready.put(("staged", buf))
-            self._ready.put((None, None))
-        except BaseException as e:                          # noqa: BLE001 -- handed to the calling thread
-            self._ready.put(("error", e))
+                self._publish(idx, "staged", buf)
+            except BaseException as e:                      # noqa: BLE001 -- handed to the calling thread
+                self._ended = True
+                self._publish(self._next_in if idx is None else idx, "error", e)
+                return
 
     def next(self):
-        kind, item = self._ready.get()
+        with self._cv:
+            while self._next_out not in self._results:
+                self._cv.wait()
+            kind, item = self._results.pop(self._next_out)
+            if kind is not None and kind != "error":
+                self._next_out += 1                         # (the end and an error are final: asked again, they answer again)
+            else:
+                self._results[self._next_out] = (kind, item)
         if kind == "error":
             raise item
         return kind, item
@@ -71,9 +107,9 @@ class _FrameStager:
         self._free.put(buf)
 
     def close(self):
-        """Stops the helper thread: the stop flag is looked at before every frame and before every copy, the free queue is drained
-        (so that the thread cannot pick up a buffer any more) and the sentinel wakes a thread waiting for one.  Returns True when
-        the thread has ended -- only then may the staging buffers be handed to somebody else."""
+        """Stops the helper threads: the stop flag is looked at before every frame and before every copy, the free queue is drained
+        (so that no thread can pick up a buffer any more) and a sentinel per thread wakes one waiting for a buffer.  Returns True
+        when every thread has ended -- only then may the staging buffers be handed to somebody else."""
         import queue
         self._stop.set()
         try:
@@ -81,9 +117,11 @@ class _FrameStager:
                 self._free.get_nowait()
         except queue.Empty:
             pass
-        self._free.put(None)
-        self._thread.join(timeout=2.0)       # (a frame source that blocks keeps its daemon thread; it touches no buffer any more)
-        return not self._thread.is_alive()
+        for _ in self._threads:
+            self._free.put(None)
+        for t in self._threads:
+            t.join(timeout=2.0)               # (a frame source that blocks keeps its daemon thread; it touches no buffer any more)
+        return not any(t.is_alive() for t in self._threads)
 
 
 def KLTTrackSequence(tc, frames, nFeatures, replace_lost=True, async_ingest=True, prefetch=True):
@@ -130,7 +168,8 @@ def _track_sequence_locked(ctx, tc, frames, nFeatures, replace_lost, async_inges
             tables.append(base)
         return tables[ci] + 1 + off
 
-    stage_key = ((nrows, ncols), ring + 3)      # frames k+1 .. k+3 on their way, one being filled by the helper thread, one spare
+    workers = STAGER_WORKERS or (2 if nrows * ncols >= STAGER_THREADS_FROM_BYTES else 1)
+    stage_key = ((nrows, ncols), ring + 2 + workers)      # frames k+1 .. k+3 on their way, one being filled by each helper thread, one spare
     stage = ctx.staging(*stage_key) if async_ingest and first.dtype == np.uint8 else None
     in_flight = []                          # staging buffer whose host-to-device copy may still be running
 
@@ -165,12 +204,15 @@ def _track_sequence_locked(ctx, tc, frames, nFeatures, replace_lost, async_inges
         state = ctx.take_affine_state()
         ctx.affine_alloc(state, nFeatures)
     k = 0
-    stager = _FrameStager(frames, stage, (nrows, ncols)) if stage is not None else None
+    stager = _FrameStager(frames, stage, (nrows, ncols), workers=workers) if stage is not None else None
     try:
         if affine:
             ctx.set_option(_OPT_SELECT_AFFINE_STATE, state)
         if prefetch:
             ctx.set_option(_OPT_BUILD_STREAM, 1)
+        # one new frame per step: all uploads on ONE copy stream (the default, two, is for the two frames of a pair; with two, the look at
+        # every other frame's selection waits twice as long -- 0.280 against 0.307 ms per 4K frame, profiles/README.md round 6)
+        ctx.set_option(_OPT_COPY_STREAMS, SEQUENCE_COPY_STREAMS)
 
         def stage_frame(k, item):                    # upload + pyramid build of frame k (enqueued only)
             ingest(s[k % ring], item[1], k, staged=item[0] == "staged")
@@ -269,6 +311,7 @@ def _track_sequence_locked(ctx, tc, frames, nFeatures, replace_lost, async_inges
                     ctx.staging_forget(*stage_key)
             finally:
                 try:
+                    ctx.set_option(_OPT_COPY_STREAMS, 2)
                     if prefetch:
                         ctx.set_option(_OPT_BUILD_STREAM, 0)
                 finally:
