@@ -366,24 +366,25 @@ class Context:
         return fl, placed.value
 
     def host_records(self, n):
-        """(in, out): two pinned arrays of n klt_feat records, cached per length -- the host side of the reference-shaped API's
-        lists (no staging copy inside the runtime, and the copies can be asynchronous).  Valid until the next call that uses them."""
-        cache = self.__dict__.setdefault("_host_records", {})
-        pair = cache.pop(n, None)
-        if pair is None:
-            if len(cache) >= 8:                                   # a script with lists of many lengths: the least recently used pair goes
-                gone = next(iter(cache))
-                old = cache.pop(gone)
+        """(in, out): two pinned arrays of n klt_feat records -- the host side of the reference-shaped API's lists (no staging copy
+        inside the runtime, and the copies can be asynchronous).  Valid until the next call that uses them.  Views of ONE pair of
+        pinned arrays that only ever grows (to twice what was asked for): a script that alternates between lists of two lengths keeps
+        one mapping of the tracker's feature buffers (`_map_records`; a pair per length was remapped -- with a device-wide wait each
+        time -- whenever the length changed: ADVICE r5)."""
+        pair = self.__dict__.get("_host_records")
+        if pair is None or len(pair[0]) < n:
+            if pair is not None:
                 mapped = self.__dict__.get("_mapped_records")
-                if mapped is not None and mapped[0] == gone:           # the tracker's feature buffers are these arrays: unmap first
-                    for fb in mapped[3:]:
+                if mapped is not None:                                 # the tracker's feature buffers are these arrays: unmap first
+                    for fb in mapped[2:]:
                         self._check(self._lib.klt_featbuf_map_host(self._h, fb, None, 0))
                     self._mapped_records = None
-                for a in old:
+                for a in pair:
                     self._check(self._lib.klt_host_free(self._h, C.c_void_p(a.ctypes.data)))
-            pair = (self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n], self.pinned_array((max(n, 1),), FEAT_DTYPE)[:n])
-        cache[n] = pair                                            # (re-inserted last: dicts keep insertion order)
-        return pair
+                self._host_records = None
+            cap = max(256, n if pair is None else 2 * n)
+            pair = self._host_records = (self.pinned_array((cap,), FEAT_DTYPE), self.pinned_array((cap,), FEAT_DTYPE))
+        return pair[0][:n], pair[1][:n]
 
     def select_records(self, slot, n, mode=SELECTING_ALL, use_pyramid=False, fb=None):
         """klt_select for the host API without its spare round trips: SELECTING_ALL needs no list on the way in (every slot is
@@ -431,11 +432,12 @@ class Context:
 
     def _map_records(self, n, fb_in, fb_out):
         """feature buffers fb_in / fb_out ARE host_records(n) (klt_featbuf_map_host): the tracker reads and writes them in place"""
-        rin, rout = self.host_records(n)
-        key = (n, rin.ctypes.data, rout.ctypes.data, fb_in, fb_out)
+        self.host_records(n)                                       # (grows the pair if it has to -- and unmaps it first)
+        rin, rout = self._host_records
+        key = (rin.ctypes.data, rout.ctypes.data, fb_in, fb_out)
         if self.__dict__.get("_mapped_records") != key:
-            self._check(self._lib.klt_featbuf_map_host(self._h, fb_in, rin.ctypes.data, max(n, 1)))
-            self._check(self._lib.klt_featbuf_map_host(self._h, fb_out, rout.ctypes.data, max(n, 1)))
+            self._check(self._lib.klt_featbuf_map_host(self._h, fb_in, rin.ctypes.data, len(rin)))
+            self._check(self._lib.klt_featbuf_map_host(self._h, fb_out, rout.ctypes.data, len(rout)))
             self._mapped_records = key
 
     def track_enqueue(self, slot1, slot2, n, state=None, upload=True, fb_in=_FB_API_IN, fb_out=_FB_API_OUT):

@@ -558,6 +558,16 @@ int klt_min_distance_walk(klt_ctx *c, const uint64_t *keys, int nkeys, int ncols
     if (!c || !inout || (!keys && nkeys > 0)) return fail(c, KLT_ERR_ARG, "null argument");
     if (nkeys < 0 || n <= 0 || ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535) return fail(c, KLT_ERR_ARG, "bad argument");
     if (c->sel_job) return fail(c, KLT_ERR_STATE, "a selection is pending: klt_select_finish first");
+    // every candidate inside the image (the reference asserts the same when the walk reaches the point, selectGoodFeatures.py:90-91): the
+    // kernel marks accepted candidates in a grid of ncols x nrows cells and checks nothing, a position outside would be a write outside it
+    for (int i = 0; i < nkeys && keys[i] != 0ull; i++) {          // (a zero key ends the list: the walk never looks behind it)
+        const int x = (int)((keys[i] >> 16) & 0xffffull), y = (int)(keys[i] & 0xffffull);
+        if (x >= ncols || y >= nrows) {
+            char msg[128];
+            snprintf(msg, sizeof msg, "candidate %d at (%d, %d) lies outside the %d x %d image", i, x, y, ncols, nrows);
+            return fail(c, KLT_ERR_ARG, msg);
+        }
+    }
     HIPCHK(c, hipSetDevice(c->device));
     const int fb = 65535;                                  // the synchronous entry points' staging buffer
     if (int rc = klt_featbuf_upload(c, fb, inout, n)) return rc;

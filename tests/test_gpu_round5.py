@@ -657,13 +657,29 @@ def test_feature_buffers_mapped_into_pinned_host_memory():
             c.featbuf_download(41, n)
         c.track_async(0, 1, 40, 41, n)                                          # ... and usable as an ordinary device buffer again
         assert c.featbuf_download(41, n)["val"].tolist() == c.track(0, 1, want)[0]["val"].tolist()
-        # the API's own mapping follows its pinned arrays: nine list lengths evict the first pair of arrays while it is mapped
+        # the API's own mapping: ONE pair of pinned arrays serves every list length (views), so changing the length does not remap
         for k in range(9):
             m = 50 + k
             c.host_records(m)[0][...] = fl[:m]
             c.track_enqueue(0, 1, m)
             got = c.track_complete(m)
             assert got.tobytes() == want[:m].tobytes(), m
+        first_map = c._mapped_records
+        assert first_map is not None and len(c._host_records[0]) >= 58
+        # ... it grows with the longest list (unmapped, freed, allocated anew, mapped again) ...
+        assert n > len(c._host_records[0])
+        c.host_records(n)[0][...] = fl
+        c.track_enqueue(0, 1, n)
+        assert c.track_complete(n).tobytes() == want.tobytes()
+        grown = c._mapped_records
+        assert grown != first_map and len(c._host_records[0]) >= n
+        # ... and a script that alternates between two list lengths keeps that one mapping (two device-wide waits per call)
+        for k in range(6):
+            m = (57, n)[k % 2]
+            c.host_records(m)[0][...] = fl[:m]
+            c.track_enqueue(0, 1, m)
+            assert c.track_complete(m).tobytes() == want[:m].tobytes(), m
+            assert c._mapped_records is grown
     finally:
         c.close()
 
@@ -708,6 +724,34 @@ def test_enforce_minimum_distance_on_random_point_lists_vs_the_checker():
         assert np.array_equal(have, np.array(feats, np.float64)), \
             "case %d: %dx%d, %d points, %d features, mindist %d, min_eig %g, overwrite %d" % (case, ncols, nrows, npts, nfeat, mindist, min_eig, overwrite)
     assert big >= 5, "no case with the occupancy grid in global memory"
+
+
+def test_min_distance_walk_refuses_candidates_outside_the_image():
+    """klt_min_distance_walk marked accepted candidates in a grid of ncols x nrows cells without looking at their coordinates -- a
+    key outside the image was a write outside the grid (LDS or device memory).  The ABI checks every key now (the reference asserts when
+    its walk reaches the point, selectGoodFeatures.py:90-91); a zero key still ends the list; the context is usable afterwards."""
+    from pyfeaturetrack_amd.backend import Context, FEAT_DTYPE, KltBackendError
+
+    def key(val, x, y):
+        return (int(np.float32(val).view(np.uint32)) << 32) | (x << 16) | y
+
+    c = Context(0)
+    try:
+        fl = np.zeros(6, FEAT_DTYPE)
+        fl["x"], fl["y"], fl["val"] = -1, -1, -1
+        good = [key(9.0, 10, 10), key(8.0, 50, 40), key(7.0, 99, 79)]
+        for mindist, (ncols, nrows) in ((5, (100, 80)), (1, (3000, 2500))):          # the grid in LDS / in device memory
+            out, placed = c.min_distance_walk(good, ncols, nrows, mindist, True, fl)
+            assert placed == 3 and out["x"][:3].tolist() == [10, 50, 99]
+            for bad in (key(6.0, ncols, 5), key(6.0, 5, nrows), key(6.0, 65535, 65535)):
+                with pytest.raises(KltBackendError, match="outside the %d x %d image" % (ncols, nrows)):
+                    c.min_distance_walk(good + [bad], ncols, nrows, mindist, True, fl)
+            out, placed = c.min_distance_walk(good[:2] + [0, key(6.0, 1, 1)], ncols, nrows, mindist, True, fl)      # a zero key ends the list
+            assert placed == 2
+            out, placed = c.min_distance_walk(good, ncols, nrows, mindist, True, fl)
+            assert placed == 3
+    finally:
+        c.close()
 
 
 def test_api_selection_is_complete_when_it_returns_on_every_selection_path():
