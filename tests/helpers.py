@@ -91,3 +91,27 @@ def draw_equal(fl, want):
 
 
 __all__ += ["random_draws", "draw_equal"]
+
+
+# ---- shared by the GPU tests of the reference-shaped Python API ----
+import os as _os                      # noqa: E402
+
+import pytest as _pytest              # noqa: E402
+
+
+def _api_modules():
+    from pyfeaturetrack_amd import selectGoodFeatures as sgf
+    from pyfeaturetrack_amd import trackFeatures as trk
+    sgf.KLT_verbose = trk.KLT_verbose = 0
+    return sgf, trk
+
+
+def _records(fl):
+    return [(f.x, f.y, f.val) for f in fl]
+
+
+# tests of DEFAULT behaviours that an environment switch changes for the whole process are meaningless under that switch, not wrong
+default_cache = _pytest.mark.skipif(bool(_os.environ.get("KLT_NO_FRAME_CACHE") or _os.environ.get("KLT_TRUST_FRAME_IDENTITY")),
+                                    reason="the frame cache's default was changed through the environment")
+default_lists = _pytest.mark.skipif(bool(_os.environ.get("KLT_NO_FEATURE_RECYCLING") == "1" or _os.environ.get("KLT_LAZY_FEATURE_LISTS") == "1"),
+                                    reason="feature lists are lazy / not recycled through the environment")
