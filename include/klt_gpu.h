@@ -249,8 +249,8 @@ int klt_select(klt_ctx *ctx, int slot, int mode, int use_pyramid, klt_feat *inou
  * effect (val < min_eigenvalue; positions inside the (2 mindist - 1)-squares of live features when overwrite_all == 0).  Free slots of
  * `inout` are filled in list order -- every slot by rank when overwrite_all, the lost ones (val < 0) otherwise; with overwrite_all the
  * slots the candidates did not reach become (-1, -1, KLT_NOT_FOUND).  Every candidate must lie inside the image (x < ncols, y < nrows;
- * KLT_ERR_ARG otherwise, checked here: the reference asserts the same, :90-91); a zero key ends the list.  Synchronous; needs no
- * parameters and no frame. */
+ * KLT_ERR_ARG otherwise, checked here: the reference asserts the same, :90-91) and no key may be zero (value 0.0 at (0, 0): the walk's own
+ * end mark; the reference never accepts a value below 1, :95).  Synchronous; needs no parameters and no frame. */
 int klt_min_distance_walk(klt_ctx *ctx, const uint64_t *keys, int nkeys, int ncols, int nrows, int mindist, int overwrite_all,
                           klt_feat *inout, int n, int *n_placed);
 

@@ -560,7 +560,8 @@ int klt_min_distance_walk(klt_ctx *c, const uint64_t *keys, int nkeys, int ncols
     if (c->sel_job) return fail(c, KLT_ERR_STATE, "a selection is pending: klt_select_finish first");
     // every candidate inside the image (the reference asserts the same when the walk reaches the point, selectGoodFeatures.py:90-91): the
     // kernel marks accepted candidates in a grid of ncols x nrows cells and checks nothing, a position outside would be a write outside it
-    for (int i = 0; i < nkeys && keys[i] != 0ull; i++) {          // (a zero key ends the list: the walk never looks behind it)
+    for (int i = 0; i < nkeys; i++) {
+        if (keys[i] == 0ull) return fail(c, KLT_ERR_ARG, "a zero key (value 0.0 at (0, 0)) is the walk's end mark, not a candidate");
         const int x = (int)((keys[i] >> 16) & 0xffffull), y = (int)(keys[i] & 0xffffull);
         if (x >= ncols || y >= nrows) {
             char msg[128];

@@ -287,7 +287,7 @@ def test_enforce_minimum_distance_on_random_point_lists_vs_the_checker():
 def test_min_distance_walk_refuses_candidates_outside_the_image():
     """klt_min_distance_walk marked accepted candidates in a grid of ncols x nrows cells without looking at their coordinates -- a
     key outside the image was a write outside the grid (LDS or device memory).  The ABI checks every key now (the reference asserts when
-    its walk reaches the point, selectGoodFeatures.py:90-91); a zero key still ends the list; the context is usable afterwards."""
+    its walk reaches the point, selectGoodFeatures.py:90-91), and refuses a zero key (the kernel's end mark); the context is usable afterwards."""
     from pyfeaturetrack_amd.backend import Context, FEAT_DTYPE, KltBackendError
 
     def key(val, x, y):
@@ -304,8 +304,8 @@ def test_min_distance_walk_refuses_candidates_outside_the_image():
             for bad in (key(6.0, ncols, 5), key(6.0, 5, nrows), key(6.0, 65535, 65535)):
                 with pytest.raises(KltBackendError, match="outside the %d x %d image" % (ncols, nrows)):
                     c.min_distance_walk(good + [bad], ncols, nrows, mindist, True, fl)
-            out, placed = c.min_distance_walk(good[:2] + [0, key(6.0, 1, 1)], ncols, nrows, mindist, True, fl)      # a zero key ends the list
-            assert placed == 2
+            with pytest.raises(KltBackendError, match="zero key"):
+                c.min_distance_walk(good[:2] + [0, key(6.0, 1, 1)], ncols, nrows, mindist, True, fl)      # the walk's own end mark
             out, placed = c.min_distance_walk(good, ncols, nrows, mindist, True, fl)
             assert placed == 3
     finally:

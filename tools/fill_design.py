@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fill the @PLACEHOLDER@ figures of a DESIGN.md template from a profile set:  python tools/fill_design.py <tag> [template] [out]
-(figures come from profiles/r05_<tag>_*; INTEGRATION.md's @API_*@ figures are filled from the same set)."""
+(figures come from profiles/r06_<tag>_*; INTEGRATION.md's @API_*@ figures are filled from the same set)."""
 import csv
 import json
 import os
@@ -15,12 +15,12 @@ P = os.path.join(ROOT, "profiles")
 
 
 def L(name):
-    return json.load(open(os.path.join(P, "r05_%s_bench%s.json" % (tag, name))))
+    return json.load(open(os.path.join(P, "r06_%s_bench%s.json" % (tag, name))))
 
 
 def stats(name, kernel):
     """mean duration (us) of the first kernel whose name contains `kernel` in a rocprofv3 kernel_stats csv"""
-    path = os.path.join(P, "r05_%s_%skernel_stats.csv" % (tag, name))
+    path = os.path.join(P, "r06_%s_%skernel_stats.csv" % (tag, name))
     for r in csv.DictReader(open(path)):
         if kernel in r["Name"]:
             return float(r["AverageNs"]) / 1e3
@@ -32,7 +32,7 @@ k = d["roofline"]["kernels"]
 e = d["extra"]
 c1, c3, c4s, c4, c5 = L("_cfg1"), L("_cfg3"), L("_cfg4_shard32"), L("_cfg4_256_rccl_1rank"), L("_cfg5")
 k3 = c3["roofline"]["kernels"]
-traffic = json.load(open(os.path.join(P, "r05_%s_pmc_traffic.json" % tag)))
+traffic = json.load(open(os.path.join(P, "r06_%s_pmc_traffic.json" % tag)))
 t7, t15 = e["tracker_tree_sums"], c3["extra"]["tracker_tree_sums"]
 pin = e["api_pinned_to_the_gpus_numa_node"]
 gpu_tests = os.environ.get("KLT_NGPU", "189")
@@ -64,6 +64,8 @@ v = {
     "API_PP": "%.3f" % e["api_ms_per_KLTTrackFeatures_pingpong"], "API_SEL": "%.3f" % e["api_ms_per_KLTSelectGoodFeatures"],
     "API_CLIP": "%.3f" % e["api_ms_per_KLTTrackFeatures_consecutive_frames"], "API_FRESH": "%.3f" % e["api_ms_per_KLTTrackFeatures_new_frame_each_call"],
     "API_SEQLOOP": "%.3f" % e["api_ms_per_frame_sequential_mode_loop"], "TAG": tag,
+    "PIL_PP": "%.3f" % e["api_ms_per_KLTTrackFeatures_pingpong_pil"], "PIL_SEL": "%.3f" % e["api_ms_per_KLTSelectGoodFeatures_pil"],
+    "PIL_CLIP": "%.3f" % e["api_ms_per_KLTTrackFeatures_consecutive_frames_pil"], "PIL_FRESH": "%.3f" % e["api_ms_per_KLTTrackFeatures_new_frame_each_call_pil"],
     "API_PP_P": "%.3f" % pin["api_ms_per_KLTTrackFeatures_pingpong"], "API_SEL_P": "%.3f" % pin["api_ms_per_KLTSelectGoodFeatures"],
     "API_CLIP_P": "%.3f" % pin["api_ms_per_KLTTrackFeatures_consecutive_frames"], "API_FRESH_P": "%.3f" % pin["api_ms_per_KLTTrackFeatures_new_frame_each_call"],
     "API_SEQLOOP_P": "%.3f" % pin["api_ms_per_frame_sequential_mode_loop"],

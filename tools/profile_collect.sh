@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of tools/profile_round.sh <tag> from gpurun_out/ into profiles/ (tracked).
 TAG=${1:-vX}
-O=gpurun_out; P=profiles; R=r05
+O=gpurun_out; P=profiles; R=r06
 cp $O/bench_$TAG.json $P/${R}_${TAG}_bench.json
 for v in steps20 steps200 single_stream 2x2 2x8 3x1 rccl_1rank cfg1 cfg3 cfg5 cfg4_shard32 cfg4_256_rccl_1rank cfg4_257_rccl_1rank; do [ -s $O/bench_${TAG}_$v.json ] && cp $O/bench_${TAG}_$v.json $P/${R}_${TAG}_bench_$v.json; done
 cp "$(find $O/prof_$TAG -name '*kernel_stats.csv' | head -1)" $P/${R}_${TAG}_kernel_stats.csv

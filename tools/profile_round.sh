@@ -8,7 +8,7 @@
 # refused counter set makes rocprofv3 abort and then hang.  tools/profile_collect.sh <tag> then copies the summaries into profiles/.
 TAG=${1:-vX}
 export TMPDIR=/tmp
-export KLT_PROFILE_TAG=r05_$TAG
+export KLT_PROFILE_TAG=r06_$TAG
 export KLT_PROFILE_BATCH=8       # pairs per launch of the cfg-2 passes below (bench.py --batch default)
 O=gpurun_out
 mkdir -p $O
@@ -30,13 +30,13 @@ python3 tools/pmc_sq.py $O/sq_counters_$TAG.json $O/pmc_${TAG}_sq1 $O/pmc_${TAG}
 cp $O/traffic_$TAG.json profiles/traffic.json
 [ -s $O/sq_counters_$TAG.json ] && cp $O/sq_counters_$TAG.json profiles/sq_counters.json
 python3 bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
-python3 bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_steps20.json 2>> $O/bench_$TAG.err
+python3 bench.py --steps 20 --warmup 5 --no-config-sweep > $O/bench_${TAG}_steps20.json 2>> $O/bench_$TAG.err
 python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_${TAG}_steps200.json 2>> $O/bench_$TAG.err
-python3 bench.py --inflight 1 --batch 1 --no-cpu-baseline --no-api > $O/bench_${TAG}_single_stream.json 2>> $O/bench_$TAG.err
-python3 bench.py --inflight 2 --batch 2 --no-cpu-baseline --no-api > $O/bench_${TAG}_2x2.json 2>> $O/bench_$TAG.err
-python3 bench.py --inflight 2 --batch 8 --resident-pairs 64 --no-cpu-baseline --no-api > $O/bench_${TAG}_2x8.json 2>> $O/bench_$TAG.err
-python3 bench.py --inflight 3 --batch 1 --resident-pairs 66 --no-cpu-baseline --no-api > $O/bench_${TAG}_3x1.json 2>> $O/bench_$TAG.err
-KLT_FORCE_DIST=1 python3 bench.py --gpus 1 --no-cpu-baseline --no-api > $O/bench_${TAG}_rccl_1rank.json 2>> $O/bench_$TAG.err
+python3 bench.py --inflight 1 --batch 1 --no-cpu-baseline --no-api --no-config-sweep > $O/bench_${TAG}_single_stream.json 2>> $O/bench_$TAG.err
+python3 bench.py --inflight 2 --batch 2 --no-cpu-baseline --no-api --no-config-sweep > $O/bench_${TAG}_2x2.json 2>> $O/bench_$TAG.err
+python3 bench.py --inflight 2 --batch 8 --resident-pairs 64 --no-cpu-baseline --no-api --no-config-sweep > $O/bench_${TAG}_2x8.json 2>> $O/bench_$TAG.err
+python3 bench.py --inflight 3 --batch 1 --resident-pairs 66 --no-cpu-baseline --no-api --no-config-sweep > $O/bench_${TAG}_3x1.json 2>> $O/bench_$TAG.err
+KLT_FORCE_DIST=1 python3 bench.py --gpus 1 --no-cpu-baseline --no-api --no-config-sweep > $O/bench_${TAG}_rccl_1rank.json 2>> $O/bench_$TAG.err
 for c in cfg1 cfg3 cfg5; do python3 bench.py --config $c > $O/bench_${TAG}_$c.json 2>> $O/bench_$TAG.err; done
 python3 bench.py --config cfg4 --pairs 32 --steps 50 --warmup 5 > $O/bench_${TAG}_cfg4_shard32.json 2>> $O/bench_$TAG.err
 KLT_FORCE_DIST=1 python3 bench.py --config cfg4 --gpus 1 --pairs 256 --steps 10 --warmup 2 > $O/bench_${TAG}_cfg4_256_rccl_1rank.json 2>> $O/bench_$TAG.err
