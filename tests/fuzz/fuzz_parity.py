@@ -129,12 +129,15 @@ def run_prepared_trial(ctx, t):
     return None
 
 
-def run_api_trial(t):
+def run_api_trial(t, pil=False):
     """The reference-shaped Python API against the ORACLE over a random call sequence on one tracking context: KLTSelectGoodFeatures,
     KLTTrackFeatures (any two of four frames, in any order; in sequential mode frame 1 is whatever frame 2 was last time),
     KLTReplaceLostFeatures, frames edited in place between calls (a block anywhere: on or off the frame cache's lattice), a new list
     now and then -- everything the Python layer does on the way (exact frame cache with its optimistic device work, lists mapped into
-    pinned memory, recycled feature objects, scores prepared ahead) must leave the reference's results."""
+    pinned memory, recycled feature objects, scores prepared ahead) must leave the reference's results.
+    `pil`: the API is handed mode-"L" Pillow images (the reference's image type) -- frames 0 and 2 own their storage and are edited in place
+    through Pillow (`paste`), frames 1 and 3 are mapped onto the numpy arrays the oracle reads and change with them -- all read through
+    Pillow's row tables (pyfeaturetrack_amd/_pil.py)."""
     from pyfeaturetrack_amd import selectGoodFeatures as sgf, trackFeatures as tf
     sgf.KLT_verbose = tf.KLT_verbose = 0
     rng = np.random.default_rng(t["seed"])
@@ -147,6 +150,11 @@ def run_api_trial(t):
     base = synth.synth_base(t["w"], t["h"], t["seed"])
     frames = [synth.synth_frame(t["w"], t["h"], t["seed"], k, shift=t["shift"], base=base) for k in range(4)]
     n = t["n"]
+    if pil:
+        from PIL import Image
+        imgs = [Image.frombytes("L", (t["w"], t["h"]), f.tobytes()) if k % 2 == 0 else Image.fromarray(f) for k, f in enumerate(frames)]
+    else:
+        imgs = frames
 
     def same_list(fl, ofl, what):
         have = np.array([(f.x, f.y, f.val) for f in fl], np.float64).reshape(-1, 3)
@@ -155,7 +163,7 @@ def run_api_trial(t):
         return None if ok else what
 
     cur = int(rng.integers(0, 4))
-    fl = sgf.KLTSelectGoodFeatures(tc, frames[cur], n)
+    fl = sgf.KLTSelectGoodFeatures(tc, imgs[cur], n)
     ofl = ko.select_good_features(p, frames[cur].astype(np.float32), n)
     bad = same_list(fl, ofl, "op 0: select")
     last2 = None                                 # pixels of the last call's frame 2 (what sequential mode tracks from)
@@ -168,14 +176,17 @@ def run_api_trial(t):
         if op == "edit":
             k = int(rng.integers(0, 4))
             y, x = int(rng.integers(0, t["h"] - 8)), int(rng.integers(0, t["w"] - 8))
-            frames[k][y:y + int(rng.integers(1, 8)), x:x + int(rng.integers(1, 8))] ^= int(rng.integers(1, 255))
+            hh, ww = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+            frames[k][y:y + hh, x:x + ww] ^= int(rng.integers(1, 255))
+            if pil and k % 2 == 0:                  # an image with storage of its own: the same edit through Pillow, on the same object
+                imgs[k].paste(Image.fromarray(frames[k][y:y + hh, x:x + ww].copy()), (x, y))
         elif op == "select":
             cur = int(rng.integers(0, 4))
-            fl = sgf.KLTSelectGoodFeatures(tc, frames[cur], n)
+            fl = sgf.KLTSelectGoodFeatures(tc, imgs[cur], n)
             ofl = ko.select_good_features(p, frames[cur].astype(np.float32), n)
             bad = same_list(fl, ofl, "op %d: select" % step)
         elif op == "replace":
-            sgf.KLTReplaceLostFeatures(tc, frames[cur], fl)
+            sgf.KLTReplaceLostFeatures(tc, imgs[cur], fl)
             if int((ofl["val"] < 0).sum()) > 0:
                 if tc.sequentialMode and last2 is not None:
                     # selectGoodFeatures.py:176-181: level 0 of the pyramids kept from the last track -- the SMOOTHED frame 2 and its
@@ -189,7 +200,7 @@ def run_api_trial(t):
             bad = same_list(fl, ofl, "op %d: replace" % step)
         else:
             nxt = int(rng.integers(0, 4))
-            tf.KLTTrackFeatures(tc, frames[cur], frames[nxt], fl)
+            tf.KLTTrackFeatures(tc, imgs[cur], imgs[nxt], fl)
             first = last2 if (tc.sequentialMode and last2 is not None) else frames[cur]          # trackFeatures.py:152-161
             ko.track_features(p, ko.Pyramids(p, first.astype(np.float32)), ko.Pyramids(p, frames[nxt].astype(np.float32)), ofl)
             last2 = frames[nxt].copy()
@@ -346,6 +357,7 @@ def main():
     ap.add_argument("--sequence", action="store_true", help="KLTTrackSequence against the per-frame host API instead of HIP against the oracle")
     ap.add_argument("--prepared", action="store_true", help="replacement on prepared scores (klt_select_prepare_async + begin / finish), HIP against the oracle")
     ap.add_argument("--api", action="store_true", help="the reference-shaped Python API over random call sequences, against the oracle")
+    ap.add_argument("--pil", action="store_true", help="with --api: the calls are handed Pillow images (owned storage and array-mapped ones), edited in place")
     ap.add_argument("--min-pixels", type=int, default=0)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
@@ -356,7 +368,7 @@ def main():
         while t["w"] * t["h"] < a.min_pixels:
             t = draw(rng, a.max_pixels, a.max_n, a.max_side)
         try:
-            bad = run_api_trial(t) if a.api else run_prepared_trial(ctx, t) if a.prepared else run_sequence_trial(t) if a.sequence else run_affine_trial(ctx, t) if a.affine else run_batch_trial(ctx, t) if a.batch else run_trial(ctx, t)
+            bad = run_api_trial(t, a.pil) if a.api else run_prepared_trial(ctx, t) if a.prepared else run_sequence_trial(t) if a.sequence else run_affine_trial(ctx, t) if a.affine else run_batch_trial(ctx, t) if a.batch else run_trial(ctx, t)
         except SystemExit as e:            # KLTError of the host layer
             bad = "error: %s" % (e,)
         print("trial %3d %s  %s" % (k, "ok  " if not bad else "FAIL (%s)" % bad, t), flush=True)

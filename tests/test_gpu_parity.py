@@ -1238,9 +1238,13 @@ def test_feature_table_views(ctx, cfg1, img0, img1):
 
 
 # ------------------------------------------------------------------------------- Python API
-def test_python_api_example1_flow(cfg1, golden_dir, tmp_path, capsys):
+def test_python_api_example1_flow(cfg1, golden_dir, tmp_path, capsys, monkeypatch):
     """The reference's example1.py call sequence through the reference-shaped API (PIL images)."""
     PIL = pytest.importorskip("PIL.Image")
+    from pyfeaturetrack_amd import selectGoodFeatures as _sgf, trackFeatures as _trk, writeFeatures as _wf
+    for mod in (_sgf, _trk, _wf):                  # the reference's default (selectGoodFeatures.py:14); other tests switch the prints off
+        if hasattr(mod, "KLT_verbose"):
+            monkeypatch.setattr(mod, "KLT_verbose", 1)
     from pyfeaturetrack_amd.klt import KLT_TrackingContext, KLTCountRemainingFeatures
     from pyfeaturetrack_amd.selectGoodFeatures import KLTSelectGoodFeatures, KLTReplaceLostFeatures
     from pyfeaturetrack_amd.trackFeatures import KLTTrackFeatures
