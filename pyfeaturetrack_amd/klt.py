@@ -248,13 +248,21 @@ def _restored_store(x, y, val, xint, yint, aff, aff_img):
     return s
 
 
-_tuple_new = tuple.__new__
-_item = tuple.__getitem__           # the (store, row) pair of a feature: `feat[0]` itself is hidden from callers
+_item = list.__getitem__            # the [store, row] pair of a feature: `feat[0]` itself is hidden from callers
+_pair_len = list.__len__
+
+
+def _own(feat):
+    """the store of a feature; one made on its own (`KLT_Feature()`, as the reference's scripts write) gets its one-row store here, when
+    it is first looked at (a Python-level __new__ / __init__ would make every object of a 5000-feature list pay for a Python call)"""
+    if not _pair_len(feat):
+        list.extend(feat, (_FeatureStore(1), 0))
+    return _item(feat, 0)
 
 
 def _coord_setter(col, flag):
     def put(self, value):
-        s, i = _item(self, 0), _item(self, 1)
+        s, i = _own(self), _item(self, 1)
         getattr(s, col)[i] = value
         getattr(s, flag)[i] = isinstance(value, (int, np.integer)) and not isinstance(value, bool)
         s.changed()
@@ -263,29 +271,30 @@ def _coord_setter(col, flag):
 
 def _aff_property(name, dflt):
     def get(self):
-        s = _item(self, 0)
+        s = _own(self)
         return dflt if s.aff is None else float(s.aff[name][_item(self, 1)])
 
     def put(self, value):
-        _item(self, 0).aff_columns()[name][_item(self, 1)] = value
+        _own(self).aff_columns()[name][_item(self, 1)] = value
     return property(get, put)
 
 
 def _aff_img_property(name):
     def get(self):
-        s = _item(self, 0)
+        s = _own(self)
         return None if s.aff is None else s.aff_img[name][_item(self, 1)]
 
     def put(self, value):
-        s = _item(self, 0)
+        s = _own(self)
         s.aff_columns()
         s.aff_img[name][_item(self, 1)] = value
     return property(get, put)
 
 
-class _FeatureObject(tuple):
-    """A tuple subclass WITHOUT __slots__: its instances carry a lazily created __dict__ (nothing is allocated until somebody sets an
-    attribute).  A class of its own so that KLT_Feature can put a property in front of the instance dictionary (`_instance_dict`)."""
+class _FeatureObject(list):
+    """A list subclass WITHOUT __slots__: its instances carry a lazily created __dict__ (nothing is allocated until somebody sets an
+    attribute) and can be weakly referenced.  A class of its own so that KLT_Feature can put a property in front of the instance
+    dictionary (`_instance_dict`)."""
 
 
 _instance_dict = _FeatureObject.__dict__["__dict__"]        # the getset descriptor that hands out / replaces an instance's dictionary
@@ -294,7 +303,7 @@ _generic_setattr = object.__setattr__
 
 
 def _no_sequence(what):
-    def refuse(self, *args):
+    def refuse(self, *args, **kw):
         raise TypeError("'KLT_Feature' object %s" % what)
     return refuse
 
@@ -304,34 +313,48 @@ class KLT_Feature(_FeatureObject):
     (selectGoodFeatures.py:117-128) -- a KLT_Feature there is an attribute bag.  Here x, y, val and the affine-consistency fields
     always exist and read row `_i` of a _FeatureStore `_s` (its own one-row store when created on its own, the list's shared store
     when it comes from KLTSelectGoodFeatures / KLTCreateFeatureList); ANY OTHER attribute is the caller's (`feat.track_id = 7`) and
-    lives in the object's own dictionary, as on the reference's plain objects.
+    lives in the object's own dictionary, as on the reference's plain objects; a feature can be weakly referenced as they can.
 
-    It is implemented as the PAIR (store, row) -- a `tuple` subclass -- because that is the cheapest object CPython can make in
-    bulk: a 5000-feature list is `map(tuple.__new__, ...)` over a `zip`, all of it in C, 2.7x faster than 5000 calls of a Python
-    `__init__` (0.21 against 0.57 ms at cfg-2's list length, `profiles/README.md`), and the list KLTSelectGoodFeatures hands out is
-    a complete list of feature objects as the reference's is.  Nothing of the tuple shows: a feature has no length, is not iterable
-    or subscriptable, is always true, equals and hashes by identity (numpy's array constructor makes a 1-D object array of a list
-    of features; `feat in some_list` asks for this very object), pickles and deep-copies as a feature of its own (values, affine
-    fields, own attributes -- not the list's column store).  One deviation from the reference's plain objects remains: no weak
-    references (CPython does not support them on tuple subclasses).  The objects of a dropped list serve the next one
-    (`_recycled`) only when no feature of the list was ever given an attribute of its own."""
+    Underneath it is the PAIR [store, row] -- a `list` subclass with neither __new__ nor __init__ of its own -- because that is the
+    cheapest object with a dictionary and weak references that CPython can make in bulk: a 5000-feature list is
+    `map(KLT_Feature, zip(...))`, the type call all in C (0.22 ms here; a tuple subclass, rounds 5 / 6a: 0.27 ms and no weak references;
+    5000 calls of a Python `__init__`: 0.57 ms), and the list KLTSelectGoodFeatures hands out is a complete list of feature objects
+    as the reference's is.  Nothing of the pair shows: a feature has no length, is not iterable or subscriptable, has none of a list's
+    methods, is always true, equals and hashes by identity (numpy's array constructor makes a 1-D object array of a list of features;
+    `feat in some_list` asks for this very object), pickles and deep-copies as a feature of its own (values, affine fields, own
+    attributes -- not the list's column store).  The objects of a dropped list serve the next one (`_recycled`) only when no
+    feature of the list was ever given an attribute of its own and none is weakly referenced."""
 
-    def __new__(cls, _store=None, _index=0):
-        return _tuple_new(cls, (_FeatureStore(1) if _store is None else _store, _index))
+    _s = property(_own)
+    _i = property(lambda self: _item(self, 1) if _own(self) is not None else 0)
 
-    _s = property(lambda self: _item(self, 0))
-    _i = property(lambda self: _item(self, 1))
+    @property
+    def x(self):
+        try:
+            return _item(self, 0).lx[_item(self, 1)]
+        except IndexError:                      # a feature made on its own, looked at for the first time
+            return _own(self).lx[0]
 
-    x = property(lambda self: _item(self, 0).lx[_item(self, 1)], _coord_setter("x", "xint"))
-    y = property(lambda self: _item(self, 0).ly[_item(self, 1)], _coord_setter("y", "yint"))
+    @property
+    def y(self):
+        try:
+            return _item(self, 0).ly[_item(self, 1)]
+        except IndexError:
+            return _own(self).ly[0]
 
     @property
     def val(self):
-        return _item(self, 0).lv[_item(self, 1)]
+        try:
+            return _item(self, 0).lv[_item(self, 1)]
+        except IndexError:
+            return _own(self).lv[0]
+
+    x = x.setter(_coord_setter("x", "xint"))
+    y = y.setter(_coord_setter("y", "yint"))
 
     @val.setter
     def val(self, value):
-        s = _item(self, 0)
+        s = _own(self)
         s.val[_item(self, 1)] = value
         s.changed()
 
@@ -349,47 +372,48 @@ class KLT_Feature(_FeatureObject):
     # features carries something of the caller's (a store like that is never recycled: a recycled object starts clean).
     def __setattr__(self, name, value):
         if name not in _FIELDS:
-            _item(self, 0).tagged = True
+            _own(self).tagged = True
         _generic_setattr(self, name, value)
 
     @property
     def __dict__(self):
-        _item(self, 0).tagged = True            # (vars(feat)[...] = ... writes without __setattr__)
+        _own(self).tagged = True                # (vars(feat)[...] = ... writes without __setattr__)
         return _instance_dict.__get__(self)
 
     @__dict__.setter
     def __dict__(self, value):
-        _item(self, 0).tagged = True
+        _own(self).tagged = True
         _instance_dict.__set__(self, value)
 
     # ---- nothing of the pair shows
     __len__ = _no_sequence("has no len()")
-    __iter__ = _no_sequence("is not iterable")
-    __getitem__ = _no_sequence("is not subscriptable")
+    __iter__ = __reversed__ = _no_sequence("is not iterable")
+    __getitem__ = __setitem__ = __delitem__ = _no_sequence("is not subscriptable")
     __contains__ = _no_sequence("is not a container")
-    __add__ = __mul__ = __rmul__ = _no_sequence("is not a sequence")
+    __add__ = __iadd__ = __mul__ = __imul__ = __rmul__ = _no_sequence("is not a sequence")
     __lt__ = __le__ = __gt__ = __ge__ = lambda self, other: NotImplemented
     __eq__ = object.__eq__
     __ne__ = object.__ne__
     __hash__ = object.__hash__
+    __class_getitem__ = None
 
-    def _no_tuple_method(self):
-        raise AttributeError("'KLT_Feature' object has no attribute 'index' / 'count'")
-    index = count = property(_no_tuple_method)
-    del _no_tuple_method
+    def _no_list_method(self):
+        raise AttributeError("'KLT_Feature' object has no such attribute (it is not a list)")
+    append = extend = insert = pop = remove = clear = index = count = sort = reverse = copy = property(_no_list_method)
+    del _no_list_method
 
     def __bool__(self):
         return True
 
     def __reduce_ex__(self, protocol):
         # a feature of its own: the values it shows (ints where it shows ints), the affine fields if any were written, own attributes
-        s, i = _item(self, 0), _item(self, 1)
+        s, i = _own(self), _item(self, 1)
         aff = None if s.aff is None else ({k: float(v[i]) for k, v in s.aff.items()}, {k: v[i] for k, v in s.aff_img.items()})
         return (_restored_feature, (self.x, self.y, self.val, aff, dict(_instance_dict.__get__(self)) if s.tagged else None))
 
     def _reset_affine(self):
         """Back to the state of a newly placed feature (selectGoodFeatures.py:120-128)."""
-        _item(self, 0).reset_affine(_item(self, 1))
+        _own(self).reset_affine(_item(self, 1))
 
     def __repr__(self):
         return "<KLT_Feature x={0!r} y={1!r} val={2!r}>".format(self.x, self.y, self.val)
@@ -406,6 +430,12 @@ def _restored_feature(x, y, val, aff, own):
     if own:
         f.__dict__.update(own)
     return f
+
+
+def _row_features(store, rows):
+    """the feature objects of rows `rows` of `store`, made in one C-level pass (the type call of a list subclass without __new__ /
+    __init__ of its own: list's constructor fills the object from the (store, row) pair)"""
+    return map(KLT_Feature, zip(_repeat(store), rows))
 
 
 class KLT_FeatureList(list):
@@ -440,7 +470,7 @@ class KLT_FeatureList(list):
             if paused:
                 _gc.disable()
             try:
-                list.extend(self, map(_tuple_new, _repeat(KLT_Feature, n), zip(_repeat(store, n), range(n))))
+                list.extend(self, _row_features(store, range(n)))
             finally:
                 if paused:
                     _gc.enable()
@@ -528,12 +558,12 @@ def _counts(entry):
     """(highest reference count among the feature objects, the store's count beyond one per feature) of a pool entry that only
     the caller holds -- compared with what the same call gives for an entry made on the spot (`_UNSHARED`)"""
     store, canon = entry
-    return max(map(_getrefcount, canon)), _getrefcount(store) - len(canon)
+    return max(map(_getrefcount, canon)), _getrefcount(store) - len(canon), max(map(_weakref.getweakrefcount, canon))
 
 
 def _probe_counts():
     st = _FeatureStore(3)
-    entry = (st, list(map(_tuple_new, _repeat(KLT_Feature, 3), zip(_repeat(st, 3), range(3)))))
+    entry = (st, list(_row_features(st, range(3))))
     del st
     return _counts(entry)
 
@@ -574,7 +604,6 @@ def new_feature_list(n, fill=None):
 
 
 _list_eq = list.__eq__
-_tuple_eq = tuple.__eq__
 
 
 def shared_store(featurelist):
@@ -604,7 +633,7 @@ def shared_store(featurelist):
     if s.kept is not None and _list_eq(plain, s.kept) is True:
         return s
     # the list the store was made with is gone: is this list its rows 0 .. n-1, in order, all of them KLT_Feature objects?
-    if set(map(type, plain)) != {KLT_Feature} or not all(map(_tuple_eq, plain, zip(_repeat(s), range(len(plain))))):
+    if set(map(type, plain)) != {KLT_Feature} or not all(map(_list_eq, plain, map(list, zip(_repeat(s), range(len(plain)))))):
         return None
     s.kept = plain[:]
     return s

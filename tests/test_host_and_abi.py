@@ -398,6 +398,20 @@ def test_feature_objects_are_recycled_only_when_nobody_holds_one():
     assert {id(f) for f in m}.isdisjoint({id(f) for f in copy_of})
     del copy_of, alias, m, held
     gc.collect()
+    # a WEAK reference to a feature of a dropped list does not keep it alive -- and does not end up pointing at a feature of the next list:
+    # a list one of whose objects is weakly referenced is not taken over
+    import weakref
+    n = 63
+    w = new_feature_list(n)
+    ids = {id(f) for f in w}
+    ref = weakref.ref(w[9])
+    del w
+    assert ref() is not None                                       # (the dropped list's objects wait in the pool)
+    w2 = new_feature_list(n)
+    assert ref() is None or all(ref() is not f for f in w2)
+    gc.collect()
+    assert ref() is None, "a weakly referenced feature of a dropped list was kept alive or handed out again"
+    del w2, ids
     # a list one of whose features carries an attribute of the caller's own is never handed out again: a recycled object starts clean
     n = 62
     t = new_feature_list(n)
@@ -445,10 +459,27 @@ def test_feature_objects_are_attribute_bags_and_nothing_of_the_pair_shows():
     with pytest.raises(TypeError):
         s, i = a
     assert not hasattr(a, "index") and not hasattr(a, "count") and bool(a) is True
+    for name in ("append", "extend", "insert", "pop", "remove", "clear", "sort", "reverse", "copy"):      # (underneath it is a list: none of that shows)
+        assert not hasattr(a, name), name
+    for op in (lambda f: f.__setitem__(0, 1), lambda f: f.__delitem__(0), lambda f: reversed(f), lambda f: f.__iadd__([1]), lambda f: f.__imul__(2)):
+        with pytest.raises(TypeError):
+            op(a)
+    assert (a.x, a.y, a.val) == (12, 3.5, 2) and a._s is fl._store and a._i == 3
+    # weak references, as to the reference's plain objects
+    import gc
+    import weakref
+    r = weakref.ref(a)
+    assert r() is a and weakref.getweakrefcount(a) == 1
+    lone = KLT_Feature()
+    rl = weakref.ref(lone)
+    assert (lone.x, lone.y, lone.val) == (-1, -1, -1) and len(lone._s) == 1
+    del lone
+    gc.collect()
+    assert rl() is None
     arr = np.array(fl, dtype=object)
     assert arr.shape == (40,) and arr[3] is a and np.array(list(fl)).shape == (40,) and np.asarray(fl[:5], dtype=object).shape == (5,)
     # identity
-    twin = KLT_Feature(fl._store, 3)                               # another object viewing the same row
+    twin = KLT_Feature((fl._store, 3))                               # another object viewing the same row
     assert twin.x == 12 and twin != a and not (twin == a) and a == a and hash(a) != hash(twin) and len({a, twin, a}) == 2
     other = new_feature_list(40)
     assert a in fl and a not in other and twin not in fl and fl.index(a) == 3 and other.count(a) == 0
@@ -487,7 +518,7 @@ def test_a_plain_copy_keeps_the_column_path_after_the_original_list_is_gone():
     stranger = copy_of[:]
     stranger[7] = KLT_Feature()
     assert shared_store(stranger) is None
-    stranger[7] = KLT_Feature(store, 7)                                                          # the right row, but not THE object of a kept list
+    stranger[7] = KLT_Feature((store, 7))                                                          # the right row, but not THE object of a kept list
     assert shared_store(stranger) is store                                                       # rows 0 .. n-1 of the store all the same: columns apply
     stranger[7] = object()
     assert shared_store(stranger) is None
