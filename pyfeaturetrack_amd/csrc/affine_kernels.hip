@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void affine_kernel(AffineArgs a)
     extern __shared__ float tsamp[];                      // [n] image (+ [n] gradx, [n] grady for the translation model), then the offsets
     // window offsets (i, j) of every sample as floats, once per feature: `k % width` and `k / width` with a run-time width are ~25
     // integer instructions each, and the sample loops below ran them for every sample of every Newton iteration -- 28 % of this kernel's
-    // 29.9 M wavefront-instructions were integer arithmetic (profiles/r02_g_cfg3_sq_counters.json), and the kernel sits on its issue roof
+    // 29.9 M wavefront-instructions were integer arithmetic (profiles/history/r02_g_cfg3_sq_counters.json), and the kernel sits on its issue roof
     float *const offx = tsamp + (MODE == 0 ? 3 * n : n), *const offy = offx + n;
     for (int k = lane; k < n; k += 64) {
         const float fi = (float)(k % width - hw), fj = (float)(k / width - hh);

@@ -619,7 +619,7 @@ def test_python_api_over_random_call_sequences_vs_oracle():
     """tests/fuzz/fuzz_parity.py --api: KLTSelectGoodFeatures / KLTTrackFeatures / KLTReplaceLostFeatures on one tracking context in random
     order over four frames that are edited in place between calls, a third of the draws in sequential mode -- every list equals the
     ORACLE's after every call (the exact frame cache with its optimistic device work, lists mapped into pinned memory, recycled feature
-    objects, scores prepared ahead: none of it may show).  8400 draws ran when the mode was written (profiles/r05_fuzz_seeds.txt); 25
+    objects, scores prepared ahead: none of it may show).  8400 draws ran when the mode was written (profiles/history/r05_fuzz_seeds.txt); 25
     stay in the suite."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz", "fuzz_parity.py"))
