@@ -75,6 +75,10 @@ class _FrameStager:
                         self._ended = True
                         self._publish(idx, None, None)
                         return
+                    except BaseException as e:              # noqa: BLE001 -- the source failed: said at this frame's place, under the lock
+                        self._ended = True                  # (another helper must not pull from the dead iterator and report the END here)
+                        self._publish(idx, "error", e)
+                        return
                     self._next_in = idx + 1
                     key = FrameKey(img)                     # (an 8-bit Pillow image is read through its row table: no array is made of it)
                     if key.stage_u8() != self._shape:

@@ -684,3 +684,53 @@ def test_track_sequence_of_any_length_and_a_slow_frame_source():
             assert [(f.x, f.y, f.val) for f in fl] == [(f.x, f.y, f.val) for f in fl2]
     finally:
         sgf.KLT_verbose = 1
+
+
+def test_track_sequence_stages_frames_of_4_mb_and_more_on_two_helper_threads(monkeypatch):
+    """KLTTrackSequence on 2400 x 1800 frames (4.3 MB: `trackSequence.STAGER_THREADS_FROM_BYTES`): two helper threads copy whole frames side
+    by side and deliver them in order; the table is the one ONE helper gives, the one the synchronous ingest gives, and -- frame by frame --
+    the per-frame API's; a generator of uneven speed and a Pillow image in the clip change nothing (round 6)."""
+    import time
+    from PIL import Image
+    from pyfeaturetrack_amd import storeFeatures as sf, trackSequence
+    sgf, trk = _api_modules()
+    w, h, n, nf = 2400, 1800, 1500, 11
+    assert w * h >= trackSequence.STAGER_THREADS_FROM_BYTES
+    base = synth.synth_base(w, h, 5)
+    frames = [synth.synth_frame(w, h, 5, k, shift=(2.3, -1.4), base=base) for k in range(nf)]
+
+    def tc_of():
+        tc = make_tc(levels=3, ss=4, max_residue=10.0)
+        tc.sequentialMode = True
+        return tc
+
+    seen = []
+    real = trackSequence._FrameStager
+
+    class Watched(real):
+        def __init__(self, frames_, buffers, shape, workers=1):
+            seen.append((workers, len(buffers)))
+            real.__init__(self, frames_, buffers, shape, workers=workers)
+    monkeypatch.setattr(trackSequence, "_FrameStager", Watched)
+
+    def uneven():
+        for k, f in enumerate(frames):
+            time.sleep(0.004 if k % 3 == 1 else 0.0)
+            yield Image.fromarray(f) if k == 4 else f
+
+    two = trackSequence.KLTTrackSequence(tc_of(), uneven(), n)
+    assert seen[-1][0] == 2 and seen[-1][1] >= 6
+    monkeypatch.setattr(trackSequence, "STAGER_WORKERS", 1)
+    one = trackSequence.KLTTrackSequence(tc_of(), iter(frames), n)
+    assert seen[-1][0] == 1
+    sync = trackSequence.KLTTrackSequence(tc_of(), iter(frames), n, async_ingest=False)
+    assert np.array_equal(two.rec, one.rec) and np.array_equal(two.rec, sync.rec)
+    tc = tc_of()
+    want = sf.KLTCreateFeatureTable(nf, n)
+    fl = sgf.KLTSelectGoodFeatures(tc, frames[0], n)
+    sf.KLTStoreFeatureList(fl, want, 0)
+    for k in range(1, nf):
+        trk.KLTTrackFeatures(tc, frames[k - 1], frames[k], fl)
+        sgf.KLTReplaceLostFeatures(tc, frames[k], fl)
+        sf.KLTStoreFeatureList(fl, want, k)
+    assert np.array_equal(two.val, want.val) and np.array_equal(two.x, want.x) and np.array_equal(two.y, want.y)

@@ -302,6 +302,64 @@ def test_frame_stager_stops_when_closed():
     assert all(np.array_equal(a, b) for a, b in zip(snapshot, bufs)), "a staging buffer was written after close()"
 
 
+@pytest.mark.parametrize("workers", [1, 2, 3])
+def test_frame_stager_with_several_helpers_delivers_in_order(workers):
+    """_FrameStager(workers = 2: frames of 4 MB and more): the helpers take frame AND buffer under one lock in frame order and copy side by
+    side; `next()` hands the frames out in order whatever the copies' durations, an odd-sized frame travels as "raw" in its place, the end
+    is reported once every frame before it has been delivered (and again when asked again), a source that raises surfaces at its place,
+    and close() with frames still wanted ends every helper."""
+    import threading
+    import time
+    from PIL import Image
+    from pyfeaturetrack_amd.trackSequence import _FrameStager
+    shape = (40, 60)
+    rng = np.random.default_rng(workers)
+    n = 37
+
+    def frame(k):
+        return np.full(shape, k % 251, np.uint8)
+
+    def source(fail_at=None):
+        for k in range(n):
+            if fail_at == k:
+                raise ValueError("decoder failed at frame %d" % k)
+            time.sleep(float(rng.random()) * 0.002)                  # a decoder of uneven speed
+            if k == 11:
+                yield np.full((10, 10), 11, np.uint8)                # another size: the calling thread deals with it
+            elif k % 5 == 0:
+                yield Image.fromarray(frame(k))                      # Pillow images travel through their row tables
+            else:
+                yield frame(k)
+
+    bufs = [np.zeros(shape, np.uint8) for _ in range(3 + workers)]
+    st = _FrameStager(source(), bufs, shape, workers=workers)
+    held = []
+    for k in range(n):
+        kind, item = st.next()
+        if k == 11:
+            assert kind == "raw" and item.shape == (10, 10)
+            continue
+        assert kind == "staged" and int(item[0, 0]) == k % 251 and int(item[-1, -1]) == k % 251, (k, kind)
+        held.append(item)
+        if len(held) > 2:                                            # the consumer keeps up to three frames in flight
+            time.sleep(float(rng.random()) * 0.001)
+            st.release(held.pop(0))
+    assert st.next() == (None, None) and st.next() == (None, None)
+    assert st.close()
+    # an error in the frame source arrives where the frame would have
+    st = _FrameStager(source(fail_at=7), [np.zeros(shape, np.uint8) for _ in range(12)], shape, workers=workers)
+    for k in range(7):
+        kind, item = st.next()
+        assert kind == "staged" and int(item[0, 0]) == k
+    with pytest.raises(ValueError, match="frame 7"):
+        st.next()
+    assert st.close()
+    # closed early: every helper ends although frames and buffers are still wanted
+    st = _FrameStager(source(), [np.zeros(shape, np.uint8) for _ in range(2)], shape, workers=workers)
+    assert st.next()[0] == "staged"
+    assert st.close() and not any(t.is_alive() for t in st._threads)
+
+
 def test_shard_gather_counts():
     """ShardGather's per-rank counts (klt_gatherv_featbuf_async) for shards of unequal size: 7 and 257 pairs over 2 / 8 ranks."""
     from pyfeaturetrack_amd.parallel import shard_range
