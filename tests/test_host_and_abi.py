@@ -1067,7 +1067,7 @@ def test_pillow_row_tables_pass_their_self_check_and_read_images_in_place():
     assert st["active"], "self-check failed: %s" % st["why_not"]
     lib = load_library()
     rng = np.random.default_rng(3)
-    for (h, w) in ((5, 23), (240, 320), (1080, 1920), (33, 1), (1, 40)):
+    for (h, w) in ((5, 23), (240, 320), (1080, 1920), (33, 1), (1, 40), (4320, 7680)):      # (8K: Pillow allocates such an image in two blocks -- rows that do not follow each other)
         a = rng.integers(0, 256, (h, w), dtype=np.uint8)
         for img in (Image.fromarray(a), Image.frombytes("L", (w, h), a.tobytes()), Image.fromarray(a).copy()):
             r = _pil.rows_of(img)
