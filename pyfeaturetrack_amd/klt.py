@@ -332,7 +332,9 @@ class KLT_Feature(_FeatureObject):
     def x(self):
         try:
             return _item(self, 0).lx[_item(self, 1)]
-        except IndexError:                      # a feature made on its own, looked at for the first time
+        except IndexError:                      # a feature made on its own, looked at for the first time (anything else is an error)
+            if _pair_len(self):
+                raise
             return _own(self).lx[0]
 
     @property
@@ -340,6 +342,8 @@ class KLT_Feature(_FeatureObject):
         try:
             return _item(self, 0).ly[_item(self, 1)]
         except IndexError:
+            if _pair_len(self):
+                raise
             return _own(self).ly[0]
 
     @property
@@ -347,6 +351,8 @@ class KLT_Feature(_FeatureObject):
         try:
             return _item(self, 0).lv[_item(self, 1)]
         except IndexError:
+            if _pair_len(self):
+                raise
             return _own(self).lv[0]
 
     x = x.setter(_coord_setter("x", "xint"))
