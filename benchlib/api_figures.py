@@ -21,20 +21,31 @@ def api_figures(pair, tc):
             from PIL import Image
             return Image.frombytes("L", (arr.shape[1], arr.shape[0]), arr.tobytes())
 
+        def as_rgb(arr):
+            """a colour frame (what a camera or a video decoder hands a script: the reference's GUI example feeds such frames): three
+            different functions of the grey frame, storage of its own"""
+            from PIL import Image
+            rgb = np.dstack([arr, np.roll(arr, 3, axis=1), 255 - arr // 2]).astype(np.uint8)
+            return Image.frombytes("RGB", (arr.shape[1], arr.shape[0]), rgb.tobytes())
+
         def measure(trusting, new_frame_per_call=False, pil=False):
             tc.trustFrameIdentity = trusting
             trk.KLTForgetFrames(tc)
             t_sel, t_trk, t_pp = [], [], []
-            f0, f1 = (as_pil(a0), as_pil(a1)) if pil else (a0, a1)
+            wrap = as_rgb if pil == "rgb" else as_pil
+            f0, f1 = (wrap(a0), wrap(a1)) if pil else (a0, a1)
             fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
             trk.KLTTrackFeatures(tc, f0, f1, fl)
-            g1 = as_pil(a1) if pil else f1.copy()
+            g1 = wrap(a1) if pil else f1.copy()
             for k in range(30):
                 t = time.perf_counter()
                 fl = sgf.KLTSelectGoodFeatures(tc, f0, NFEAT)
                 t_sel.append(time.perf_counter() - t)
                 if new_frame_per_call:                         # one pixel: frame 2 is a new image every call
-                    if pil:
+                    if pil == "rgb":
+                        r, g, b = g1.getpixel((k, k))
+                        g1.putpixel((k, k), (r ^ 1, g, b))
+                    elif pil:
                         g1.putpixel((k, k), g1.getpixel((k, k)) ^ 1)
                     else:
                         g1[k, k] ^= 1
@@ -122,12 +133,30 @@ def api_figures(pair, tc):
         from pyfeaturetrack_amd import _pil
         # ... and what the same calls cost when every image is first made into an array (np.asarray(img), the path of rounds 1-5 and the
         # fallback when the self-check of the row tables fails)
+        rgb_exact, rgb_fresh = measure(False, pil="rgb"), measure(False, True, pil="rgb")
         was, _pil._layout = _pil.layout(), False
         try:
             conv_exact, conv_fresh = measure(False, pil=True), measure(False, True, pil=True)
+            tc.trustFrameIdentity = False
+            trk.KLTForgetFrames(tc)
+            c0, c1 = as_rgb(a0), as_rgb(a1)
+            fl_c = sgf.KLTSelectGoodFeatures(tc, c0, NFEAT)
+            t_c = []
+            for k in range(6):                                 # (a few calls are enough: Pillow's own conversion takes milliseconds)
+                x, y = (c0, c1) if k % 2 == 0 else (c1, c0)
+                t = time.perf_counter()
+                trk.KLTTrackFeatures(tc, x, y, fl_c)
+                t_c.append(time.perf_counter() - t)
+            conv_rgb_pp = statistics.median(t_c) * 1e3
         finally:
             _pil._layout = was
-        return {"api_pil_converted_to_arrays": {"api_ms_per_KLTSelectGoodFeatures_pil": conv_exact[0], "api_ms_per_KLTTrackFeatures_pil": conv_exact[1],
+        return {"api_ms_per_KLTSelectGoodFeatures_pil_rgb": rgb_exact[0], "api_ms_per_KLTTrackFeatures_pingpong_pil_rgb": rgb_exact[2],
+                "api_ms_per_KLTTrackFeatures_new_frame_each_call_pil_rgb": rgb_fresh[1],
+                "api_pil_rgb_note": "the same on COLOUR Pillow images (\"RGB\", 1920x1080): the reference converts them with img.convert(\"F\") -- Pillow's luma -- on every "
+                                    "call; here the 4-byte pixels are compared as stored and the float frame is made from the image's rows by klt_host_luma_rows "
+                                    "and sent with klt_upload_f32_async (8 MB per frame on the link instead of 2); with np.array(img.convert(\"F\")) per image and "
+                                    "call (rounds 1-5) the ping-pong call reads %.2f ms" % conv_rgb_pp,
+                "api_pil_converted_to_arrays": {"api_ms_per_KLTSelectGoodFeatures_pil": conv_exact[0], "api_ms_per_KLTTrackFeatures_pil": conv_exact[1],
                                                 "api_ms_per_KLTTrackFeatures_pingpong_pil": conv_exact[2],
                                                 "api_ms_per_KLTTrackFeatures_new_frame_each_call_pil": conv_fresh[1],
                                                 "note": "row tables switched off (as KLT_NO_PIL_ROWS=1): np.asarray(img) per image and call"},

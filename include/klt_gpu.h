@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KLT_ABI_VERSION 10
+#define KLT_ABI_VERSION 11
 #define KLT_MAX_KERNEL_WIDTH 71   /* convolve.py:28 */
 #define KLT_MAX_LEVELS 8
 
@@ -135,6 +135,9 @@ int klt_upload_f32(klt_ctx *ctx, int slot, const float *px, int ncols, int nrows
 int klt_host_alloc(klt_ctx *ctx, size_t bytes, void **out);     /* pinned host memory, freed by klt_host_free / klt_destroy */
 int klt_host_free(klt_ctx *ctx, void *p);
 int klt_upload_u8_async(klt_ctx *ctx, int slot, const uint8_t *px, int ncols, int nrows, int pitch);
+/* the same for a float32 frame (what `img.convert("F")` of a colour or float image gives, trackFeatures.py:165,176): pinned host memory,
+ * copy streams, the slot's two alternating raw buffers -- 4 bytes per pixel on the link */
+int klt_upload_f32_async(klt_ctx *ctx, int slot, const float *px, int ncols, int nrows, int pitch);
 int klt_upload_wait(klt_ctx *ctx);      /* host waits for the copies issued so far (only the copy stream; kernels keep running) */
 /* Host side of the ingest, no context involved (thread-safe; a process-wide pool of parked worker threads, KLT_HOST_THREADS lanes in
  * all, default 4; a caller that finds the pool busy does its own work): the reference converts and rebuilds both images on every call
@@ -156,6 +159,10 @@ int klt_host_copy_rows(void *dst, const uint8_t *const *rows, int nrows, size_t 
  * the main thread enqueues must not take the pool's lanes away from it: measured slower, profiles/README.md); returns the previous setting */
 int klt_host_thread_serial(int on);
 int klt_host_sample_rows(const uint8_t *const *rows, int nrows, int ncols, int ystep, int xstep, uint8_t *out, size_t cap);
+/* `img.convert("F")` of a colour image without Pillow's intermediate image and numpy's copy of it: rows of 4-byte pixels (R, G, B, X --
+ * Pillow's storage of "RGB" / "RGBA" / "RGBX" images, ImagingMemoryInstance.image32) -> dst[nrows][ncols] float32 =
+ * (float)(299 R + 587 G + 114 B) / 1000.0f, Pillow's own expression (libImaging/Convert.c, rgb2f), spread over the pool's lanes */
+int klt_host_luma_rows(float *dst, const uint8_t *const *rows, int nrows, int ncols);
 /* Frames that are ALREADY in device memory (a hardware decoder's output, a clip kept resident): the slot's frame becomes this caller-owned
  * buffer -- read in place by the next build / selection of the slot, never copied, written or freed by the library (zero-copy
  * ingest).  pitch must equal ncols.  Host-only call: nothing is enqueued; the buffer must hold the frame already and stay unchanged until

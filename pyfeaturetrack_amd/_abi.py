@@ -68,6 +68,7 @@ SYMBOLS = {
     "klt_host_alloc": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
     "klt_host_free": (_I, [_P, _P]),
     "klt_upload_u8_async": (_I, [_P, _I, _P, _I, _I, _I]),
+    "klt_upload_f32_async": (_I, [_P, _I, _P, _I, _I, _I]),
     "klt_upload_wait": (_I, [_P]),
     "klt_host_compare": (_I, [_P, _P, C.c_size_t]),
     "klt_host_copy": (_I, [_P, _P, C.c_size_t]),
@@ -76,6 +77,7 @@ SYMBOLS = {
     "klt_host_compare_rows": (_I, [_P, _I, C.c_size_t, _P]),
     "klt_host_copy_rows": (_I, [_P, _P, _I, C.c_size_t]),
     "klt_host_sample_rows": (_I, [_P, _I, _I, _I, _I, _P, C.c_size_t]),
+    "klt_host_luma_rows": (_I, [_P, _P, _I, _I]),
     "klt_slot_adopt_u8": (_I, [_P, _I, _P, _I, _I, _I]),
     "klt_device_alloc": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
     "klt_device_write": (_I, [_P, _P, _P, C.c_size_t]),

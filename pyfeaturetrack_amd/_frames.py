@@ -67,8 +67,10 @@ def _to_array(img):
 class FrameKey:
     """One image as a call names it: the object, its size and mode; the pixel array and its lattice are made when first asked for
     (a Pillow image is converted once per call, and not at all in the trusting mode when identity or size already differ).
-    An 8-bit Pillow image -- what the reference's callers pass (trackFeatures.py:165,176) -- is never converted at all: `rows` is the
-    row table of Pillow's own storage (_pil.py), which the lattice, the comparison and the staging copy read in place."""
+    A Pillow image -- what the reference's callers pass (trackFeatures.py:165,176) -- is not converted by Pillow at all: `rows` is the
+    row table of its own storage (_pil.py), which the lattice, the comparison and the staging copy read in place: 8-bit images ("L") as
+    they are, colour images ("RGB" / "RGBA" / "RGBX") compared and kept as 4-byte pixels and turned into the float frame
+    `img.convert("F")` would be by klt_host_luma_rows, float images ("F") as float rows."""
     __slots__ = ("img", "size", "kind", "rows", "_arr", "_sig")
 
     def __init__(self, img):
@@ -78,54 +80,78 @@ class FrameKey:
             self.size, self.kind = (img.shape[1], img.shape[0]), img.dtype.char
         else:
             self.size, self.kind = tuple(img.size), getattr(img, "mode", "?")
-            if self.kind == "L":
-                self.rows = rows_of(img)
+            self.rows = rows_of(img)
         self._arr = self._sig = None
 
     def array(self):
+        """uint8 or float32 2-D array holding exactly `np.array(img.convert("F"))`"""
         if self._arr is None:
-            self._arr = _to_array(self.img)
+            r = self.rows
+            if r is None or r.kind == "u8":
+                self._arr = _to_array(self.img)
+            else:                                           # colour / float rows: Pillow's conversion without Pillow's intermediate image
+                self._arr = np.empty((r.nrows, r.ncols), np.float32)
+                self.float_into(self._arr)
         return self._arr
 
     def sig(self):
         if self._sig is None:
             r = self.rows
             if r is not None:
+                # (4-byte pixels: the first byte of every sampled pixel -- R, or the float's low byte: a fast reject, nothing more)
+                bpp = r.row_bytes // max(1, r.ncols)
                 ys, xs = max(1, r.nrows // _LATTICE), max(1, r.ncols // _LATTICE)
                 out = (ctypes.c_ubyte * (((r.nrows + ys - 1) // ys) * ((r.ncols + xs - 1) // xs)))()
-                n = _host_lib().klt_host_sample_rows(r.table, r.nrows, r.ncols, ys, xs, out, len(out))
+                n = _host_lib().klt_host_sample_rows(r.table, r.nrows, r.row_bytes, ys, xs * bpp, out, len(out))
                 self._sig = bytes(out) if n == len(out) else _lattice(self.array())
             else:
                 self._sig = _lattice(self.array())
         return self._sig
 
     def same_as(self, kept):
-        """every byte of the image against `kept`, the host copy a slot was filled from"""
+        """every byte of the image against `kept`, the host copy a slot was filled from (8-bit pixels, 4-byte colour pixels or floats,
+        as the image stores them)"""
         r = self.rows
-        if r is not None and kept.dtype == np.uint8 and kept.shape == (r.nrows, r.ncols) and kept.flags["C_CONTIGUOUS"]:
-            return _host_lib().klt_host_compare_rows(r.table, r.nrows, r.ncols, kept.ctypes.data) == 0
+        if r is not None and kept.flags["C_CONTIGUOUS"] and kept.shape[0] == r.nrows and kept.nbytes == r.nrows * r.row_bytes \
+                and kept.dtype == (np.float32 if r.kind == "f32" else np.uint8):
+            return _host_lib().klt_host_compare_rows(r.table, r.nrows, r.row_bytes, kept.ctypes.data) == 0
         return same_pixels(self.array(), kept)
+
+    def stage_kind(self):
+        """("u8" | "rgbx" | "f32", (nrows, ncols)) when the image can be staged into pinned memory and sent asynchronously, else None"""
+        if self.rows is not None:
+            return self.rows.kind, (self.rows.nrows, self.rows.ncols)
+        arr = self.array()
+        return ("u8", arr.shape) if arr.dtype == np.uint8 and arr.ndim == 2 else None
 
     def stage_u8(self):
         """(nrows, ncols) when the image can be staged as an 8-bit frame (`copy_into`), else None"""
-        if self.rows is not None:
-            return self.rows.nrows, self.rows.ncols
-        arr = self.array()
-        return arr.shape if arr.dtype == np.uint8 and arr.ndim == 2 else None
+        k = self.stage_kind()
+        return k[1] if k is not None and k[0] == "u8" else None
 
     def copy_into(self, buf):
-        """the image's pixels -> the contiguous 8-bit buffer `buf` (pinned memory the DMA reads)"""
+        """the image's pixels AS IT STORES THEM -> the contiguous buffer `buf` (pinned memory: the DMA's source for 8-bit and float
+        images, the copy later calls are compared with for colour images)"""
         r = self.rows
-        if r is not None and buf.flags["C_CONTIGUOUS"] and buf.shape == (r.nrows, r.ncols):
-            _host_lib().klt_host_copy_rows(buf.ctypes.data, r.table, r.nrows, r.ncols)
+        if r is not None and buf.flags["C_CONTIGUOUS"] and buf.nbytes == r.nrows * r.row_bytes:
+            _host_lib().klt_host_copy_rows(buf.ctypes.data, r.table, r.nrows, r.row_bytes)
         else:
             copy_pixels(buf, self.array())
 
+    def float_into(self, buf):
+        """`img.convert("F")` of a colour or float Pillow image -> the contiguous float32 buffer `buf` [nrows][ncols]"""
+        r = self.rows
+        assert r is not None and r.kind != "u8" and buf.dtype == np.float32 and buf.flags["C_CONTIGUOUS"] and buf.shape == (r.nrows, r.ncols)
+        if r.kind == "rgbx":
+            _host_lib().klt_host_luma_rows(buf.ctypes.data, r.table, r.nrows, r.ncols)
+        else:
+            _host_lib().klt_host_copy_rows(buf.ctypes.data, r.table, r.nrows, r.row_bytes)
+
 
 def pixels_of(img):
-    """the image as a uint8 / float32 array of its own (`image_to_array`; an 8-bit Pillow image is copied out of its row table)"""
+    """the image as a uint8 / float32 array of its own (`image_to_array`; a Pillow image is copied / converted out of its row table)"""
     key = FrameKey(img)
-    if key.rows is None:
+    if key.rows is None or key.rows.kind != "u8":
         return key.array()
     out = np.empty((key.rows.nrows, key.rows.ncols), np.uint8)
     key.copy_into(out)
@@ -244,24 +270,39 @@ class FrameCache:
         """frame -> slot, remembered: 8-bit frames are copied into the slot's pinned buffer and leave with klt_upload_u8_async on
         the context's copy stream (the host copy of the second frame of a pair runs while the first one's DMA is in flight, the
         build waits for both on the device); anything else goes with the synchronous upload and an ordinary copy is kept."""
-        shape8 = key.stage_u8()
+        staged = key.stage_kind()
         self.keep_handles(ctx, slot)
         old = self.held.pop(slot, None)
-        if shape8 is not None and hasattr(ctx, "upload_async"):
-            pool = _pool_of(ctx, shape8)
+        if staged is not None and hasattr(ctx, "upload_async"):
+            kind, shape = staged
+            # the copy later calls are compared with: the pixels as the image stores them (for 8-bit and float images also the DMA's source)
+            kshape, kdtype = ((shape[0], 4 * shape[1]), np.uint8) if kind == "rgbx" else (shape, np.float32 if kind == "f32" else np.uint8)
+            pool = _pool_of(ctx, kshape, kdtype)
             if old is not None and old.pool is pool and old.kept is not None:
                 buf, no = old.kept, old.upload_no
                 old.kept = old.pool = None
             elif pool:
                 buf, no = pool.pop()
             else:
-                buf, no = ctx.pinned_array(shape8), 0
+                buf, no = ctx.pinned_array(kshape, kdtype), 0
             if old is not None:
                 old.release()
             _uploads_finished(ctx, no)                      # the DMA that last read this buffer has finished
             key.copy_into(buf)
-            ctx.upload_async(slot, buf)
-            ctx.__dict__["_uploads_issued"] = no = ctx.__dict__.get("_uploads_issued", 0) + 1
+            if kind == "rgbx":
+                # a colour image: what travels is the float frame `img.convert("F")` would be, made in a pinned buffer of its own that goes
+                # back to its pool at once (with the number of the upload that reads it: the next user waits for that copy)
+                fpool = _pool_of(ctx, shape, np.float32)
+                fbuf, fno = fpool.pop() if fpool else (ctx.pinned_array(shape, np.float32), 0)
+                _uploads_finished(ctx, fno)
+                key.float_into(fbuf)
+                ctx.upload_async(slot, fbuf)
+                ctx.__dict__["_uploads_issued"] = issued = ctx.__dict__.get("_uploads_issued", 0) + 1
+                fpool.append((fbuf, issued))
+                no = 0                                      # (`buf` itself is never a DMA's source)
+            else:
+                ctx.upload_async(slot, buf)
+                ctx.__dict__["_uploads_issued"] = no = ctx.__dict__.get("_uploads_issued", 0) + 1
             kept = buf
         else:
             if old is not None:
@@ -276,9 +317,9 @@ class FrameCache:
             pool.append((kept, no))
 
 
-def _pool_of(ctx, shape):
-    """pinned frame buffers of this shape nobody holds at the moment: [(buffer, number of its last upload)]"""
-    return ctx.__dict__.setdefault("_frame_pool", {}).setdefault(tuple(shape), [])
+def _pool_of(ctx, shape, dtype=np.uint8):
+    """pinned frame buffers of this shape and type nobody holds at the moment: [(buffer, number of its last upload)]"""
+    return ctx.__dict__.setdefault("_frame_pool", {}).setdefault((tuple(shape), np.dtype(dtype).char), [])
 
 
 def _uploads_finished(ctx, upload_no):

@@ -1,4 +1,4 @@
-"""Pillow images without a conversion: the row table of an 8-bit image, straight from Pillow's own storage.
+"""Pillow images without a conversion: the row table of an 8-bit, colour or float image, straight from Pillow's own storage.
 
 The reference's callers hand PIL images to KLTSelectGoodFeatures / KLTTrackFeatures (selectGoodFeatures.py:190, trackFeatures.py:165,176:
 `img.convert("F")`).  Making a numpy array of a mode-"L" image (`np.asarray(img)`: Pillow encodes the image into a bytes object, numpy
@@ -6,7 +6,9 @@ wraps it) costs 0.43 ms per 1080p image -- several times what a whole call costs
 `ImagingMemoryInstance` whose `image8` member is a table of row addresses; `Image.getim()` (Pillow >= 11) hands out a capsule named
 "Pillow Imaging" with that struct's address.  `rows_of(img)` reads the table's address out of it; libkltgpu's klt_host_compare_rows /
 klt_host_copy_rows / klt_host_sample_rows then compare the image with the copy a slot was filled from, stage it into pinned memory and
-take the frame cache's 1024-pixel lattice from the rows directly.
+take the frame cache's 1024-pixel lattice from the rows directly.  Colour images ("RGB" / "RGBA" / "RGBX": 4-byte pixels behind `image32`) are
+compared and kept as they are and turned into the float image `img.convert("F")` would give by klt_host_luma_rows (Pillow's own expression,
+(float)(299 R + 587 G + 114 B) / 1000.0f); "F" images are float rows already.
 
 The struct is Pillow's private layout, so nothing is assumed about it: the first use runs a SELF-CHECK on a small known image -- the
 first 160 bytes of its struct are searched for the two consecutive ints that are its width and height and for a word that is the address
@@ -20,7 +22,7 @@ import struct
 import threading
 
 _lock = threading.Lock()
-_layout = None          # None: not probed yet; False: probe failed; else (offset of xsize, offset of ysize, offset of the row table pointer)
+_layout = None          # None: not probed yet; False: probe failed; else (offset of xsize, of ysize, of image8, of image32: the two row-table pointers)
 _why = None             # why the probe failed (for `status()`)
 _SCAN = 160
 _CAPSULE = b"Pillow Imaging"
@@ -51,8 +53,9 @@ def _struct_address(img):
     return _get_pointer(cap, _CAPSULE), cap
 
 
-def _probe_one(img, data, w, h, ranges):
-    """(offset of xsize, offset of ysize, offset of the row-table pointer) in img's struct, or a string saying what went wrong"""
+def _probe_one(img, data, w, h, ranges, bpp=1):
+    """(offset of xsize, offset of ysize, offset of the row-table pointer) in img's struct, or a string saying what went wrong; bpp = bytes
+    per pixel of the storage (1: image8, 4: image32)"""
     def readable(addr, n):
         return addr and any(lo <= addr and addr + n <= hi for lo, hi in ranges)
 
@@ -71,7 +74,7 @@ def _probe_one(img, data, w, h, ranges):
         if not readable(table, 8 * h):
             continue
         rows = struct.unpack("<%dQ" % h, C.string_at(table, 8 * h))
-        if all(readable(r, w) for r in rows) and b"".join(C.string_at(r, w) for r in rows) == data:
+        if all(readable(r, w * bpp) for r in rows) and b"".join(C.string_at(r, w * bpp) for r in rows) == data:
             return size_at[0], size_at[0] + 4, off
     return "no row table in the first %d bytes of the struct" % _SCAN
 
@@ -101,6 +104,17 @@ def _probe():
         if found[0] != found[1]:
             _why = "two images disagree about the layout: %r / %r" % tuple(found)
             return False
+        # 4-byte pixels live behind the other row table (image32): a colour image and a float image must agree about it
+        rgb = Image.frombytes("RGB", (w, h), bytes((11 * i + 5) % 253 for i in range(3 * w * h)))
+        flt = Image.frombytes("F", (w, h), np.linspace(-3.0, 900.0, w * h).astype(np.float32).tobytes())
+        found32 = [_probe_one(rgb, rgb.tobytes("raw", "RGBX"), w, h, ranges, 4), _probe_one(flt, flt.tobytes(), w, h, ranges, 4)]
+        for f in found32:
+            if isinstance(f, str):
+                _why = "4-byte pixels: " + f
+                return False
+        if found32[0] != found32[1] or found32[0][:2] != found[0][:2] or found32[0][2] == found[0][2]:
+            _why = "the 8-bit and the 32-bit images disagree about the layout: %r / %r / %r" % (found[0], found32[0], found32[1])
+            return False
         # ... and the table is live storage, not a snapshot: a pixel written through Pillow shows in the rows
         own.putpixel((3, 2), 200)
         p, cap = _struct_address(own)
@@ -109,14 +123,14 @@ def _probe():
         if C.string_at(row2 + 3, 1) != b"\xc8":
             _why = "a pixel written with putpixel does not show in the rows"
             return False
-        return found[0]
+        return found[0] + (found32[0][2],)
     except Exception as e:                                             # noqa: BLE001 -- whatever it is, the array path still works
         _why = "%s: %s" % (type(e).__name__, e)
         return False
 
 
 def layout():
-    """(offset of xsize, offset of ysize, offset of the row-table pointer) once the self-check has passed, else False"""
+    """(offset of xsize, of ysize, of the 8-bit row table, of the 32-bit row table) once the self-check has passed, else False"""
     global _layout
     if _layout is None:
         with _lock:
@@ -132,17 +146,24 @@ def status():
 
 
 class Rows:
-    """the row table of one 8-bit image: `table` = address of nrows row addresses, each row `ncols` bytes; `keep` holds what keeps the
-    storage alive for as long as this object lives (the image and its capsule)"""
-    __slots__ = ("table", "nrows", "ncols", "keep")
+    """the row table of one image: `table` = address of nrows row addresses, each row `ncols` pixels of `kind` "u8" (1 byte), "rgbx"
+    (4 bytes: R, G, B, pad / alpha) or "f32" (4 bytes); `keep` holds what keeps the storage alive for as long as this object lives
+    (the image and its capsule)"""
+    __slots__ = ("table", "nrows", "ncols", "keep", "kind", "row_bytes")
 
-    def __init__(self, table, nrows, ncols, keep):
-        self.table, self.nrows, self.ncols, self.keep = table, nrows, ncols, keep
+    def __init__(self, table, nrows, ncols, keep, kind="u8"):
+        self.table, self.nrows, self.ncols, self.keep, self.kind = table, nrows, ncols, keep, kind
+        self.row_bytes = ncols * (1 if kind == "u8" else 4)
+
+
+KINDS = {"L": "u8", "RGB": "rgbx", "RGBA": "rgbx", "RGBX": "rgbx", "F": "f32"}
 
 
 def rows_of(img):
-    """Rows of a mode-"L" Pillow image, or None (not such an image, self-check failed, the struct does not say what the image says)."""
-    if getattr(img, "mode", None) != "L":
+    """Rows of a mode-"L" / "RGB" / "RGBA" / "RGBX" / "F" Pillow image, or None (not such an image, self-check failed, the struct does
+    not say what the image says)."""
+    kind = KINDS.get(getattr(img, "mode", None))
+    if kind is None:
         return None
     lay = _layout if _layout is not None else layout()
     if not lay:
@@ -154,7 +175,7 @@ def rows_of(img):
         w, h = img.size
         if C.c_int.from_address(p + lay[0]).value != w or C.c_int.from_address(p + lay[1]).value != h or w <= 0 or h <= 0:
             return None
-        table = C.c_void_p.from_address(p + lay[2]).value
-        return Rows(table, h, w, (img, cap)) if table else None
+        table = C.c_void_p.from_address(p + lay[2 if kind == "u8" else 3]).value
+        return Rows(table, h, w, (img, cap), kind) if table else None
     except Exception:                                       # noqa: BLE001
         return None

@@ -222,10 +222,11 @@ class Context:
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def upload_async(self, slot, img):
-        """img: 2-D uint8 array from pinned_array(); enqueued on the copy stream, no host synchronisation."""
-        if img.dtype != np.uint8 or img.ndim != 2 or not img.flags["C_CONTIGUOUS"]:
-            raise ValueError("upload_async takes a C-contiguous 2-D uint8 array in pinned memory")
-        self._check(self._lib.klt_upload_u8_async(self._h, slot, img.ctypes.data, img.shape[1], img.shape[0], img.shape[1]))
+        """img: 2-D uint8 or float32 array from pinned_array(); enqueued on the copy stream, no host synchronisation."""
+        if img.dtype not in (np.uint8, np.float32) or img.ndim != 2 or not img.flags["C_CONTIGUOUS"]:
+            raise ValueError("upload_async takes a C-contiguous 2-D uint8 or float32 array in pinned memory")
+        fn = self._lib.klt_upload_u8_async if img.dtype == np.uint8 else self._lib.klt_upload_f32_async
+        self._check(fn(self._h, slot, img.ctypes.data, img.shape[1], img.shape[0], img.shape[1]))
 
     def device_alloc(self, nbytes):
         """Device memory owned by the context (an address as int); freed by device_free or with the context."""

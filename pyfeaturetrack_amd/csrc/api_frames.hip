@@ -55,6 +55,7 @@ int upload_raw(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int p
     s->nc = ncols;
     s->nr = nrows;
     s->raw_kind = kind;
+    s->f32_in_raw = false;
     s->pyr_valid = false;
     return 0;
 }
@@ -104,7 +105,7 @@ int enqueue_smooth_raw(klt_ctx *c, Slot *s, float *dst)
     {
         TimerScope t(c, F_SMOOTH_H, N * ((s->raw_kind == 1 ? 1 : 4) + 4));
         if (s->raw_kind == 1) launch_hconv_u8(c->work, raw8(s), nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
-        else launch_hconv_f32(c->work, s->f32, nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
+        else launch_hconv_f32(c->work, rawf(s), nc, nr, c->tmpA, nullptr, nc, 1, 0, g, nullptr);
     }
     {
         TimerScope t(c, F_SMOOTH_V, N * 8);
@@ -276,7 +277,7 @@ int build_pyramids_batch(klt_ctx *c, const int *slot_ids, int n)
         bool h1_fused = false;              // level 1 comes from the H1 planes written by the level-0 kernel
         if (fused_smooth_ok(c)) {
             for (int b = 0; b < B; b++) {
-                raw[b] = g[b]->raw_kind == 1 ? (const void *)raw8(g[b]) : (const void *)g[b]->f32;
+                raw[b] = g[b]->raw_kind == 1 ? (const void *)raw8(g[b]) : (const void *)rawf(g[b]);
                 img[b] = g[b]->lv[0].img; gx[b] = g[b]->lv[0].gx; gy[b] = g[b]->lv[0].gy;
             }
             h1_fused = s0->nlev > 1 && fused_reduce_ok(c);
@@ -445,7 +446,9 @@ int klt_host_free(klt_ctx *c, void *p)
     return fail(c, KLT_ERR_ARG, "pointer was not allocated with klt_host_alloc");
 }
 
-int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int nrows, int pitch)
+// one frame from pinned host memory into the slot's other raw buffer, on one of the copy streams; esz = bytes per pixel (1: u8, 4: f32;
+// pitch in pixels)
+static int upload_async(klt_ctx *c, int slot, const void *px, int ncols, int nrows, int pitch, size_t esz)
 {
     if (!c || !px) return fail(c, KLT_ERR_ARG, "null argument");
     if (ncols <= 0 || nrows <= 0 || ncols > 65535 || nrows > 65535 || pitch < ncols) return fail(c, KLT_ERR_ARG, "bad image geometry");
@@ -454,7 +457,7 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
     hipPointerAttribute_t attr;                           // the source must be pinned: a pageable copy would be staged synchronously
     if (hipPointerGetAttributes(&attr, px) != hipSuccess || attr.type != hipMemoryTypeHost) {
         (void)hipGetLastError();
-        return fail(c, KLT_ERR_ARG, "klt_upload_u8_async needs pinned host memory (klt_host_alloc)");
+        return fail(c, KLT_ERR_ARG, "klt_upload_u8_async / klt_upload_f32_async need pinned host memory (klt_host_alloc)");
     }
     if (!c->cstream) HIPCHK(c, hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
     const int lane = (int)(c->upload_count++ % (unsigned)c->ncopy);                 // the two frames of a pair travel side by side
@@ -462,7 +465,7 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
     const hipStream_t cs = lane == 0 ? c->cstream : c->cextra[lane - 1];
     Slot *s;
     if (int rc = get_slot(c, slot, &s, true)) return rc;
-    const size_t px_count = (size_t)ncols * nrows;
+    const size_t px_count = (size_t)ncols * nrows * esz;      // bytes: the raw buffers are byte buffers (`u8_cap` counts bytes)
     // write into the buffer the build before last read (normally long finished: poll, block only if it is not)
     s->u8_ext = nullptr;
     std::swap(s->u8, s->u8_alt);
@@ -499,16 +502,27 @@ int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int 
         s->consumed_valid = false;
     }
     if (pitch == ncols) HIPCHK(c, hipMemcpyAsync(s->u8, px, px_count, hipMemcpyHostToDevice, cs));
-    else HIPCHK(c, hipMemcpy2DAsync(s->u8, (size_t)ncols, px, (size_t)pitch, (size_t)ncols, nrows, hipMemcpyHostToDevice, cs));
+    else HIPCHK(c, hipMemcpy2DAsync(s->u8, (size_t)ncols * esz, px, (size_t)pitch * esz, (size_t)ncols * esz, nrows, hipMemcpyHostToDevice, cs));
     if (int rc = fresh_event(c, &s->ev_upload, &s->upload_serial)) return rc;
     HIPCHK(c, hipEventRecord(s->ev_upload, cs));
     s->upload_pending = true;
     s->ev_wr = s->ev_upload; s->wr_serial = s->upload_serial; s->wr_lane = lane;
     s->nc = ncols;
     s->nr = nrows;
-    s->raw_kind = 1;
+    s->raw_kind = esz == 1 ? 1 : 2;
+    s->f32_in_raw = esz != 1;
     s->pyr_valid = false;
     return KLT_OK;
+}
+
+int klt_upload_u8_async(klt_ctx *c, int slot, const uint8_t *px, int ncols, int nrows, int pitch)
+{
+    return upload_async(c, slot, px, ncols, nrows, pitch, 1);
+}
+
+int klt_upload_f32_async(klt_ctx *c, int slot, const float *px, int ncols, int nrows, int pitch)
+{
+    return upload_async(c, slot, px, ncols, nrows, pitch, sizeof(float));
 }
 
 int klt_upload_wait(klt_ctx *c)
@@ -584,6 +598,7 @@ int klt_slot_adopt_u8(klt_ctx *c, int slot, const uint8_t *dev_px, int ncols, in
     s->nc = ncols;
     s->nr = nrows;
     s->raw_kind = 1;
+    s->f32_in_raw = false;
     s->pyr_valid = false;
     return KLT_OK;
 }

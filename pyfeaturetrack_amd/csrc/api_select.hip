@@ -306,7 +306,7 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
         if (int rc = wait_built(c, s)) return rc;              // a build of this slot may still read the raw frame's buffers
         bool grads_done = false;
         if (p.smoothBeforeSelecting && fused_smooth_ok(c)) {
-            const void *raw = s->raw_kind == 1 ? (const void *)raw8(s) : (const void *)s->f32;
+            const void *raw = s->raw_kind == 1 ? (const void *)raw8(s) : (const void *)rawf(s);
             if (int rc = enqueue_fused_smooth_grad(c, 1, &raw, s->raw_kind, &c->sel_img, &c->sel_gx, &c->sel_gy, nc, nr)) return rc;
             img = c->sel_img;
             grads_done = true;
@@ -314,7 +314,7 @@ int klt_select_begin_async(klt_ctx *c, int slot, int mode, int use_pyramid, int 
             enqueue_smooth_raw(c, s, c->sel_img);
             img = c->sel_img;
         } else if (s->raw_kind == 2) {
-            img = s->f32;
+            img = rawf(s);
         } else {
             // u8 -> f32 with a 1-tap identity kernel is overkill; widen with a 1-tap correlate (exact)
             Taps one;

@@ -39,7 +39,7 @@ struct Pool {
     std::atomic<uint32_t> done{0};               // chunks of the current job completed
     std::atomic<int> differ{0};
     // the job (written between jobs only; read by a lane only while it holds a claim of that job)
-    std::atomic<int> kind{0};                    // 0 compare, 1 copy
+    std::atomic<int> kind{0};                    // 0 compare, 1 copy, 2 luma (rows of R, G, B, X bytes -> f32: klt_host_luma_rows)
     std::atomic<const uint8_t *> a{nullptr}, b{nullptr};
     std::atomic<uint8_t *> dst{nullptr};
     std::atomic<size_t> bytes{0};
@@ -59,6 +59,13 @@ thread_local bool tl_serial = false;            // klt_host_thread_serial: this 
 std::once_flag g_once;
 
 inline void cpu_relax() { __builtin_ia32_pause(); }
+
+// Pillow's rgb2f (libImaging/Convert.c: `(float)L(in) / 1000.0F`, L = 299 R + 587 G + 114 B in integers) for one row of 4-byte pixels
+inline void luma_row(float *dst, const uint8_t *px, size_t npx)
+{
+    for (size_t i = 0; i < npx; i++, px += 4)
+        dst[i] = (float)((int)px[0] * 299 + (int)px[1] * 587 + (int)px[2] * 114) / 1000.0f;
+}
 
 // claims and runs chunks of job `tag` until none is left (or the tag has moved on); returns the number of chunks this lane completed
 uint32_t run_chunks(Pool *p, uint32_t tag)
@@ -84,8 +91,10 @@ uint32_t run_chunks(Pool *p, uint32_t tag)
                 if (kind == 0) {
                     if (p->differ.load(std::memory_order_relaxed)) break;
                     if (memcmp(rows[r], b + (size_t)r * row_bytes, row_bytes) != 0) p->differ.store(1, std::memory_order_relaxed);
-                } else {
+                } else if (kind == 1) {
                     memcpy(dst + (size_t)r * row_bytes, rows[r], row_bytes);
+                } else {
+                    luma_row(reinterpret_cast<float *>(dst + (size_t)r * row_bytes), rows[r], row_bytes / 4);      // (4 bytes in, 4 bytes out per pixel)
                 }
             }
             p->done.fetch_add(1, std::memory_order_release);
@@ -163,7 +172,8 @@ int run_job(int kind, const uint8_t *a, const uint8_t *b, uint8_t *dst, size_t b
         if (rows) {
             for (uint32_t r = 0; r < nrows; r++) {
                 if (kind == 0) { if (memcmp(rows[r], b + (size_t)r * row_bytes, row_bytes) != 0) return 1; }
-                else memcpy(dst + (size_t)r * row_bytes, rows[r], row_bytes);
+                else if (kind == 1) memcpy(dst + (size_t)r * row_bytes, rows[r], row_bytes);
+                else luma_row(reinterpret_cast<float *>(dst + (size_t)r * row_bytes), rows[r], row_bytes / 4);
             }
             return 0;
         }
@@ -247,6 +257,14 @@ int klt_host_copy_rows(void *dst, const uint8_t *const *rows, int nrows, size_t 
     for (int r = 0; r < nrows; r++) if (!rows[r]) return KLT_ERR_ARG;
     if (rows_contiguous(rows, nrows, row_bytes)) return klt_host_copy(dst, rows[0], (size_t)nrows * row_bytes);
     return run_job(1, nullptr, nullptr, (uint8_t *)dst, (size_t)nrows * row_bytes, rows, (uint32_t)nrows, row_bytes);
+}
+
+int klt_host_luma_rows(float *dst, const uint8_t *const *rows, int nrows, int ncols)
+{
+    if (nrows < 0 || ncols < 0 || ((!rows || !dst) && nrows && ncols)) return KLT_ERR_ARG;
+    if (!nrows || !ncols) return KLT_OK;
+    for (int r = 0; r < nrows; r++) if (!rows[r]) return KLT_ERR_ARG;
+    return run_job(2, nullptr, nullptr, reinterpret_cast<uint8_t *>(dst), (size_t)nrows * ncols * 4, rows, (uint32_t)nrows, (size_t)ncols * 4);
 }
 
 int klt_host_sample_rows(const uint8_t *const *rows, int nrows, int ncols, int ystep, int xstep, uint8_t *out, size_t cap)

@@ -72,9 +72,11 @@ struct Slot {
     hipEvent_t ev_wr = nullptr, ev_wr_alt = nullptr;
     uint64_t wr_serial = 0, wr_alt_serial = 0;
     int wr_lane = -1, wr_alt_lane = -1;
+    bool f32_in_raw = false;          // klt_upload_f32_async: the f32 frame lives in the alternating raw buffers (`u8`, 4 bytes per pixel), not in `f32`
 };
 
 inline const uint8_t *raw8(const Slot *s) { return s->u8_ext ? s->u8_ext : s->u8; }
+inline const float *rawf(const Slot *s) { return s->f32_in_raw ? reinterpret_cast<const float *>(s->u8) : s->f32; }
 
 struct FeatBuf { klt_feat *d = nullptr; int cap = 0; bool view = false; hipEvent_t comm_done = nullptr; /* last collective that touched it */ };
 

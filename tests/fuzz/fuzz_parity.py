@@ -150,7 +150,13 @@ def run_api_trial(t, pil=False):
     base = synth.synth_base(t["w"], t["h"], t["seed"])
     frames = [synth.synth_frame(t["w"], t["h"], t["seed"], k, shift=t["shift"], base=base) for k in range(4)]
     n = t["n"]
-    if pil:
+    colour = pil and t["seed"] % 3 == 0          # every third --pil trial: "RGB" images (the reference converts them with Pillow's luma)
+    if colour:
+        from PIL import Image
+        rgbs = [np.dstack([f, np.roll(f, 2, axis=1), 255 - f]).astype(np.uint8) for f in frames]
+        imgs = [Image.frombytes("RGB", (t["w"], t["h"]), c.tobytes()) if k % 2 == 0 else Image.fromarray(c, "RGB") for k, c in enumerate(rgbs)]
+        frames = [np.array(im.convert("F")) for im in imgs]      # what the oracle is given: the reference's own conversion of these images
+    elif pil:
         from PIL import Image
         imgs = [Image.frombytes("L", (t["w"], t["h"]), f.tobytes()) if k % 2 == 0 else Image.fromarray(f) for k, f in enumerate(frames)]
     else:
@@ -177,6 +183,12 @@ def run_api_trial(t, pil=False):
             k = int(rng.integers(0, 4))
             y, x = int(rng.integers(0, t["h"] - 8)), int(rng.integers(0, t["w"] - 8))
             hh, ww = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+            if colour:                              # one channel of a block: the array-mapped image changes with its array, the other through Pillow
+                rgbs[k][y:y + hh, x:x + ww, int(rng.integers(0, 3))] ^= int(rng.integers(1, 255))
+                if k % 2 == 0:
+                    imgs[k].paste(Image.fromarray(rgbs[k][y:y + hh, x:x + ww].copy(), "RGB"), (x, y))
+                frames[k] = np.array(imgs[k].convert("F"))
+                continue
             frames[k][y:y + hh, x:x + ww] ^= int(rng.integers(1, 255))
             if pil and k % 2 == 0:                  # an image with storage of its own: the same edit through Pillow, on the same object
                 imgs[k].paste(Image.fromarray(frames[k][y:y + hh, x:x + ww].copy()), (x, y))
@@ -206,7 +218,7 @@ def run_api_trial(t, pil=False):
             last2 = frames[nxt].copy()
             cur = nxt
             bad = same_list(fl, ofl, "op %d: track" % step)
-    t["_stat"] = "sequential %d, ops %s, alive at the end %d" % (tc.sequentialMode, "".join(o[0] for o in ops), int((ofl["val"] >= 0).sum()))
+    t["_stat"] = "%ssequential %d, ops %s, alive at the end %d" % ("RGB images, " if colour else "", tc.sequentialMode, "".join(o[0] for o in ops), int((ofl["val"] >= 0).sum()))
     return bad
 
 

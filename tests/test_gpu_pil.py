@@ -1,7 +1,9 @@
 """The reference's own image type on the API path: KLTSelectGoodFeatures / KLTTrackFeatures / KLTReplaceLostFeatures /
 KLTTrackSequence on mode-"L" Pillow images (selectGoodFeatures.py:190, trackFeatures.py:165,176: `img.convert("F")`) give what the same
 calls give on arrays of the same pixels -- with the images read through Pillow's row table (pyfeaturetrack_amd/_pil.py) and with that
-switched off --, an image edited in place with putpixel between two calls is a new frame, and none of it makes an array of an image."""
+switched off --, an image edited in place with putpixel between two calls is a new frame, and none of it makes an array of an image.
+Colour ("RGB" / "RGBA") and float ("F") images: against what the reference gave on them (tests/golden/colour_images.npz), without Pillow's
+conversion on the way."""
 import os
 
 import numpy as np
@@ -138,8 +140,9 @@ def test_track_sequence_on_pillow_images(no_array_of_a_pil_image):
     assert np.array_equal(want.rec, got.rec)
 
 
-def test_other_pillow_modes_still_take_the_conversion_path(cfg1):
-    """mode "F" (what the reference converts to) and "RGB" images are converted with img.convert("F") as before"""
+def test_float_grey_colour_and_other_pillow_modes_agree(cfg1):
+    """a mode-"F" copy of img0 and a grey "RGB" image give img0's lists (float and colour rows: section below); modes without a row-table
+    path ("I", "P") are converted with img.convert("F") as the reference does"""
     sgf, trk = _api()
     img0 = Image.open(os.path.join(GOLDEN, "img0.pgm"))
     tc = make_tc(max_residue=10.0)
@@ -150,3 +153,89 @@ def test_other_pillow_modes_still_take_the_conversion_path(cfg1):
     fl2 = sgf.KLTSelectGoodFeatures(make_tc(max_residue=10.0), grey_rgb, 100)
     fl3 = sgf.KLTSelectGoodFeatures(make_tc(max_residue=10.0), want, 100)
     assert _records(fl2) == _records(fl3)
+    for other in (img0.convert("I"), img0.convert("P")):
+        fl4 = sgf.KLTSelectGoodFeatures(make_tc(max_residue=10.0), other, 100)
+        fl5 = sgf.KLTSelectGoodFeatures(make_tc(max_residue=10.0), np.array(other.convert("F")), 100)
+        assert _records(fl4) == _records(fl5), other.mode
+
+
+# ------------------------------------------------------------------------------------------------ colour and float images
+def _colour_cases(img0, img1):
+    from gen_colour_images_formula import colour_of
+    c0, c1 = colour_of(img0), colour_of(img1)
+    alpha = (np.arange(img0.size, dtype=np.uint32).reshape(img0.shape) * 7 % 256).astype(np.uint8)
+    return {"rgb": (Image.fromarray(c0, "RGB"), Image.fromarray(c1, "RGB")),
+            "rgba": (Image.fromarray(np.dstack([c0, alpha]), "RGBA"), Image.fromarray(np.dstack([c1, alpha]), "RGBA")),
+            "f": (Image.fromarray(c0, "RGB").convert("F"), Image.fromarray(c1, "RGB").convert("F"))}
+
+
+@pytest.mark.parametrize("mode", ["rgb", "rgba", "f"])
+def test_colour_and_float_images_give_the_reference_lists(mode, img0, img1, golden_dir):
+    """KLTSelectGoodFeatures / KLTTrackFeatures on "RGB", "RGBA" and "F" Pillow images against what the REFERENCE gave on the same images
+    (tests/golden/gen_colour_images.py): selection, track, track back -- with Pillow's own conversion out of the way (the float frame is
+    made from the image's rows by klt_host_luma_rows and sent with klt_upload_f32_async)."""
+    g = np.load(os.path.join(golden_dir, "colour_images.npz"))
+    sgf, trk = _api()
+    i0, i1 = _colour_cases(img0, img1)[mode]
+    tc = make_tc(max_residue=10.0)
+
+    def rec(fl):
+        return np.array([(f.x, f.y, f.val) for f in fl], np.float64)
+
+    undo = pytest.MonkeyPatch()
+    undo.setattr(Image.Image, "convert", lambda self, *a, **k: (_ for _ in ()).throw(AssertionError("img.convert%r of a %s image" % (a, self.mode))))
+    try:
+        fl = sgf.KLTSelectGoodFeatures(tc, i0, 100)
+        assert np.array_equal(rec(fl), g[mode + "_sel"])
+        trk.KLTTrackFeatures(tc, i0, i1, fl)
+        assert np.array_equal(rec(fl), g[mode + "_trk"])
+        trk.KLTTrackFeatures(tc, i1, i0, fl)                                   # both frames resident: compared as stored, nothing converted or sent
+        assert np.array_equal(rec(fl), g[mode + "_back"])
+    finally:
+        undo.undo()
+
+
+def test_colour_images_over_a_clip_equal_their_float_frames(monkeypatch):
+    """a colour clip through the three public calls (sequential mode too), a frame edited with putpixel between two calls, KLTTrackSequence
+    on colour frames: everything equals the same calls on `np.array(img.convert("F"))` of the same images -- the path of rounds 1-5, which
+    the switch KLT_NO_PIL_ROWS still selects"""
+    from pyfeaturetrack_amd.trackSequence import KLTTrackSequence
+    sgf, trk = _api()
+    w, h, n = 648, 486, 300
+    base = synth.synth_base(w, h, 51)
+    grey = [synth.synth_frame(w, h, 51, r, shift=(1.7, -1.1), base=base) for r in range(6)]
+    colour = [Image.fromarray(np.dstack([g, np.roll(g, 2, axis=0), 255 - g]), "RGB") for g in grey]
+    floats = [np.array(c.convert("F")) for c in colour]
+
+    def run(imgs, sequential, edit=None):
+        tc = make_tc(levels=3, ss=2, window=9, max_residue=10.0)
+        tc.sequentialMode = sequential
+        out = []
+        fl = sgf.KLTSelectGoodFeatures(tc, imgs[0], n)
+        out.append(_records(fl))
+        for k in range(1, len(imgs)):
+            if edit and k == 3:
+                edit(imgs[k])
+            trk.KLTTrackFeatures(tc, imgs[k - 1], imgs[k], fl)
+            out.append(_records(fl))
+            sgf.KLTReplaceLostFeatures(tc, imgs[k], fl)
+            out.append(_records(fl))
+        return out
+
+    for sequential in (False, True):
+        assert run(colour, sequential) == run(floats, sequential), "sequential mode %s" % sequential
+    # an edit in place: the image object is the one frame 3 was ... the call before compared; its float frame is made anew
+    edited = [c.copy() for c in colour]
+    want = [f.copy() for f in floats]
+    patch = Image.new("RGB", (40, 30), (250, 10, 90))
+
+    def edit_pil(im):
+        im.paste(patch, (300, 200))
+    ref_img = colour[3].copy()
+    ref_img.paste(patch, (300, 200))
+    want[3] = np.array(ref_img.convert("F"))
+    got = run(edited, False, edit=edit_pil)
+    assert got == run(want, False)
+    a = KLTTrackSequence(make_tc(levels=3, ss=2, window=9, max_residue=10.0), colour, n)
+    b = KLTTrackSequence(make_tc(levels=3, ss=2, window=9, max_residue=10.0), floats, n)
+    assert np.array_equal(a.rec, b.rec)

@@ -29,7 +29,7 @@ def test_library_exports_every_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     lib.klt_abi_version.restype = ctypes.c_int
-    assert lib.klt_abi_version() == 10
+    assert lib.klt_abi_version() == 11
 
 
 def test_struct_layouts():
@@ -1104,8 +1104,94 @@ def test_pillow_row_tables_pass_their_self_check_and_read_images_in_place():
     img.putpixel((17, 31), 9)
     assert not FrameKey(img).same_as(kept) and not key.same_as(kept)
     # what it is not for: other modes and other objects take the array path
-    for other in (Image.new("F", (8, 8)), Image.new("RGB", (8, 8)), np.zeros((8, 8), np.uint8)):
+    for other in (Image.new("I", (8, 8)), Image.new("P", (8, 8)), Image.new("1", (8, 8)), np.zeros((8, 8), np.uint8)):
         assert _pil.rows_of(other) is None and FrameKey(other).rows is None
+
+
+def test_colour_and_float_pillow_images_become_the_float_frame_pillow_would_make():
+    """`img.convert("F")` (trackFeatures.py:165,176) of "RGB" / "RGBA" / "RGBX" and "F" images without Pillow's conversion: the 4-byte pixels
+    are read through the image's 32-bit row table; klt_host_luma_rows is Pillow's own expression, (float)(299 R + 587 G + 114 B) / 1000.0f,
+    bit for bit; the frame cache compares and keeps such an image as it is stored (a colour image is new when ANY of its channels
+    changed, alpha included -- a spurious resend at worst) and sends the float frame."""
+    from PIL import Image
+    from pyfeaturetrack_amd import _pil
+    from pyfeaturetrack_amd._abi import load_library
+    from pyfeaturetrack_amd._frames import FrameCache, FrameKey, pixels_of
+    assert _pil.status()["active"] and len(_pil.status()["layout"]) == 4
+    lib = load_library()
+    rng = np.random.default_rng(5)
+    for (h, w) in ((7, 9), (240, 320), (1080, 1920)):
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        rgb[0, 0] = (255, 255, 255)
+        rgb[-1, -1] = (0, 0, 0)
+        alpha = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        images = [Image.fromarray(rgb, "RGB"), Image.fromarray(np.dstack([rgb, alpha]), "RGBA"), Image.fromarray(rgb, "RGB").convert("RGBX"),
+                  Image.fromarray(rng.normal(100, 60, (h, w)).astype(np.float32)), Image.fromarray(rgb, "RGB").convert("F")]
+        for img in images:
+            want = np.array(img.convert("F"))                                 # what the reference computes
+            key = FrameKey(img)
+            assert key.rows is not None and key.rows.kind == ("f32" if img.mode == "F" else "rgbx") and key.rows.row_bytes == 4 * w
+            got = key.array()
+            assert got.dtype == np.float32 and np.array_equal(got, want), img.mode
+            assert np.array_equal(pixels_of(img), want) and key.stage_kind() == (key.rows.kind, (h, w)) and key.stage_u8() is None
+            buf = np.zeros((h, w), np.float32)
+            key.float_into(buf)
+            assert np.array_equal(buf, want)
+            kept = np.zeros((h, 4 * w), np.uint8) if key.rows.kind == "rgbx" else np.zeros((h, w), np.float32)
+            key.copy_into(kept)
+            assert key.same_as(kept) and FrameKey(img.copy()).same_as(kept)
+            x, y = w // 2, h // 2
+            px = img.getpixel((x, y))
+            img.putpixel((x, y), (px + 1.5) if img.mode == "F" else tuple((c + 1) % 256 for c in px))
+            assert not FrameKey(img).same_as(kept)                    # (a fresh key: putpixel on an array-mapped image gives it storage of its own)
+    # the luma conversion over rows that do not follow each other in memory, and its argument checks
+    rgbx = rng.integers(0, 256, (300, 500, 4), dtype=np.uint8)
+    padded = np.zeros((300, 2016), np.uint8)
+    padded[:, :2000] = rgbx.reshape(300, 2000)
+    table = (ctypes.c_void_p * 300)(*[padded.ctypes.data + 2016 * y for y in range(300)])
+    out = np.zeros((300, 500), np.float32)
+    assert lib.klt_host_luma_rows(out.ctypes.data, table, 300, 500) == 0
+    assert np.array_equal(out, np.array(Image.fromarray(rgbx, "RGBX").convert("F")))
+    table[3] = None
+    assert lib.klt_host_luma_rows(out.ctypes.data, table, 300, 500) == -1
+
+    # the frame cache: a colour image goes out as its float frame, is recognised again without a conversion, and is new after putpixel
+    class FakeCtx:
+        def __init__(self):
+            self.has, self.sent = {}, []
+
+        def frame_resident(self, slot):
+            return self.has.get(slot, False)
+
+        def pinned_array(self, shape, dtype=np.uint8):
+            return np.zeros(shape, dtype)
+
+        def upload_async(self, slot, buf):
+            self.has[slot] = True
+            self.sent.append((slot, buf.copy()))
+
+        def upload_wait(self):
+            pass
+
+    class TC:
+        trustFrameIdentity = False
+
+    ctx, cache = FakeCtx(), FrameCache(TC())
+    rgb = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    img, twin = Image.fromarray(rgb, "RGB"), Image.fromarray(rgb.copy(), "RGB")
+    cache.send(ctx, 0, FrameKey(img))
+    assert ctx.sent[0][1].dtype == np.float32 and np.array_equal(ctx.sent[0][1], np.array(img.convert("F")))
+    for im in (img, twin):
+        k = FrameKey(im)
+        assert cache.find(k, (0, 1), ctx) == 0 and k._arr is None             # (no float image was made to find that out)
+    img.putpixel((333, 222), (1, 2, 3))
+    k = FrameKey(img)
+    assert cache.find(k, (0, 1), ctx) is None and cache.find(FrameKey(twin), (0, 1), ctx) == 0
+    cache.send(ctx, 1, k)
+    assert np.array_equal(ctx.sent[-1][1], np.array(img.convert("F"))) and cache.find(FrameKey(img), (0, 1), ctx) == 1
+    flt = Image.fromarray(rng.normal(90, 40, (480, 640)).astype(np.float32))
+    cache.send(ctx, 0, FrameKey(flt))
+    assert ctx.sent[-1][1].dtype == np.float32 and np.array_equal(ctx.sent[-1][1], np.array(flt)) and cache.find(FrameKey(flt.copy()), (0, 1), ctx) == 0
 
 
 def test_frame_cache_with_pillow_images_compares_every_pixel_without_converting():

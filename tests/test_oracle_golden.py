@@ -300,3 +300,22 @@ def test_convolve_separate_vs_reference(golden_dir, img0):
         assert np.array_equal(out[rows], g[name + "_img0_rows"]) and np.array_equal(out[:, cols], g[name + "_img0_cols"]), name
         assert hashlib.sha256(out.tobytes()).digest() == g[name + "_img0_sha256"].tobytes(), name
     assert np.array_equal(ko.convolve_separate(g["small"], [1.0], [1.0]), g["small"])
+
+
+def test_colour_images_vs_reference(golden_dir, img0, img1):
+    """What the reference gives on "RGB" / "RGBA" / "F" images (tests/golden/gen_colour_images.py: it converts whatever it is handed with
+    img.convert("F"), selectGoodFeatures.py:190,194, trackFeatures.py:165,176): the oracle on Pillow's float frame of the same images."""
+    from PIL import Image
+    from gen_colour_images_formula import colour_of
+    g = np.load(os.path.join(golden_dir, "colour_images.npz"))
+    c0, c1 = colour_of(img0), colour_of(img1)
+    f0, f1 = np.array(Image.fromarray(c0, "RGB").convert("F")), np.array(Image.fromarray(c1, "RGB").convert("F"))
+    assert np.array_equal(f0[[0, 119, 239]], g["luma0_rows"])
+    p = params_from_tc(make_tc(max_residue=10.0))
+    fl = ko.select_good_features(p, f0, 100)
+    for name in ("rgb", "rgba", "f"):
+        assert feats_equal(fl, g[name + "_sel"][:, 0], g[name + "_sel"][:, 1], g[name + "_sel"][:, 2].astype(np.int64)), name
+    ko.track_features(p, ko.Pyramids(p, f0), ko.Pyramids(p, f1), fl)
+    assert feats_equal(fl, g["rgb_trk"][:, 0], g["rgb_trk"][:, 1], g["rgb_trk"][:, 2].astype(np.int64))
+    ko.track_features(p, ko.Pyramids(p, f1), ko.Pyramids(p, f0), fl)
+    assert feats_equal(fl, g["rgb_back"][:, 0], g["rgb_back"][:, 1], g["rgb_back"][:, 2].astype(np.int64))

@@ -64,6 +64,8 @@ v = {
     "API_PP": "%.3f" % e["api_ms_per_KLTTrackFeatures_pingpong"], "API_SEL": "%.3f" % e["api_ms_per_KLTSelectGoodFeatures"],
     "API_CLIP": "%.3f" % e["api_ms_per_KLTTrackFeatures_consecutive_frames"], "API_FRESH": "%.3f" % e["api_ms_per_KLTTrackFeatures_new_frame_each_call"],
     "API_SEQLOOP": "%.3f" % e["api_ms_per_frame_sequential_mode_loop"], "TAG": tag,
+    "RGB_PP": "%.3f" % e["api_ms_per_KLTTrackFeatures_pingpong_pil_rgb"], "RGB_FRESH": "%.3f" % e["api_ms_per_KLTTrackFeatures_new_frame_each_call_pil_rgb"],
+    "RGB_SEL": "%.3f" % e["api_ms_per_KLTSelectGoodFeatures_pil_rgb"],
     "PIL_PP": "%.3f" % e["api_ms_per_KLTTrackFeatures_pingpong_pil"], "PIL_SEL": "%.3f" % e["api_ms_per_KLTSelectGoodFeatures_pil"],
     "PIL_CLIP": "%.3f" % e["api_ms_per_KLTTrackFeatures_consecutive_frames_pil"], "PIL_FRESH": "%.3f" % e["api_ms_per_KLTTrackFeatures_new_frame_each_call_pil"],
     "API_PP_P": "%.3f" % pin["api_ms_per_KLTTrackFeatures_pingpong"], "API_SEL_P": "%.3f" % pin["api_ms_per_KLTSelectGoodFeatures"],
