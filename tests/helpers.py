@@ -115,3 +115,10 @@ default_cache = _pytest.mark.skipif(bool(_os.environ.get("KLT_NO_FRAME_CACHE") o
                                     reason="the frame cache's default was changed through the environment")
 default_lists = _pytest.mark.skipif(bool(_os.environ.get("KLT_NO_FEATURE_RECYCLING") == "1" or _os.environ.get("KLT_LAZY_FEATURE_LISTS") == "1"),
                                     reason="feature lists are lazy / not recycled through the environment")
+
+
+def colour_of(grey):
+    """uint8 [h, w] -> uint8 [h, w, 3]: how the colour test images are made from tests/golden/img0.pgm / img1.pgm -- the same three lines as
+    in tests/golden/gen_colour_images.py (three different functions of the frame, so that the luma is not the frame itself)"""
+    g = np.asarray(grey, np.uint8)
+    return np.dstack([g, np.roll(g, 3, axis=1), (255 - g // 2).astype(np.uint8)])

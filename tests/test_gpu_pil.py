@@ -161,7 +161,7 @@ def test_float_grey_colour_and_other_pillow_modes_agree(cfg1):
 
 # ------------------------------------------------------------------------------------------------ colour and float images
 def _colour_cases(img0, img1):
-    from gen_colour_images_formula import colour_of
+    from helpers import colour_of
     c0, c1 = colour_of(img0), colour_of(img1)
     alpha = (np.arange(img0.size, dtype=np.uint32).reshape(img0.shape) * 7 % 256).astype(np.uint8)
     return {"rgb": (Image.fromarray(c0, "RGB"), Image.fromarray(c1, "RGB")),

@@ -306,7 +306,7 @@ def test_colour_images_vs_reference(golden_dir, img0, img1):
     """What the reference gives on "RGB" / "RGBA" / "F" images (tests/golden/gen_colour_images.py: it converts whatever it is handed with
     img.convert("F"), selectGoodFeatures.py:190,194, trackFeatures.py:165,176): the oracle on Pillow's float frame of the same images."""
     from PIL import Image
-    from gen_colour_images_formula import colour_of
+    from helpers import colour_of
     g = np.load(os.path.join(golden_dir, "colour_images.npz"))
     c0, c1 = colour_of(img0), colour_of(img1)
     f0, f1 = np.array(Image.fromarray(c0, "RGB").convert("F")), np.array(Image.fromarray(c1, "RGB").convert("F"))
