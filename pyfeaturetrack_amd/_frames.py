@@ -288,10 +288,10 @@ class FrameCache:
             if old is not None:
                 old.release()
             _uploads_finished(ctx, no)                      # the DMA that last read this buffer has finished
-            key.copy_into(buf)
             if kind == "rgbx":
                 # a colour image: what travels is the float frame `img.convert("F")` would be, made in a pinned buffer of its own that goes
-                # back to its pool at once (with the number of the upload that reads it: the next user waits for that copy)
+                # back to its pool at once (with the number of the upload that reads it: the next user waits for that copy); the copy of
+                # the pixels as stored -- what later calls are compared with -- is made while that DMA runs
                 fpool = _pool_of(ctx, shape, np.float32)
                 fbuf, fno = fpool.pop() if fpool else (ctx.pinned_array(shape, np.float32), 0)
                 _uploads_finished(ctx, fno)
@@ -299,8 +299,10 @@ class FrameCache:
                 ctx.upload_async(slot, fbuf)
                 ctx.__dict__["_uploads_issued"] = issued = ctx.__dict__.get("_uploads_issued", 0) + 1
                 fpool.append((fbuf, issued))
+                key.copy_into(buf)
                 no = 0                                      # (`buf` itself is never a DMA's source)
             else:
+                key.copy_into(buf)
                 ctx.upload_async(slot, buf)
                 ctx.__dict__["_uploads_issued"] = no = ctx.__dict__.get("_uploads_issued", 0) + 1
             kept = buf
