@@ -250,17 +250,18 @@ class Context:
         """Host waits until every upload_async issued so far has left its pinned source buffer."""
         self._check(self._lib.klt_upload_wait(self._h))
 
-    def staging(self, shape, count=2):
-        """`count` pinned uint8 staging buffers of `shape`, cached per context (pinned memory is never handed out twice)."""
+    def staging(self, shape, count=2, dtype=np.uint8):
+        """`count` pinned staging buffers of `shape` (uint8, or float32 for colour / float frames), cached per context (pinned memory is
+        never handed out twice)."""
         cache = self.__dict__.setdefault("_staging", {})
-        key = (tuple(shape), count)
+        key = (tuple(shape), count, np.dtype(dtype).char)
         if key not in cache:
-            cache[key] = [self.pinned_array(shape) for _ in range(count)]
+            cache[key] = [self.pinned_array(shape, dtype) for _ in range(count)]
         return cache[key]
 
-    def staging_forget(self, shape, count=2):
+    def staging_forget(self, shape, count=2, dtype=np.uint8):
         """Drops a cached staging set without freeing it (somebody may still write to it); the next staging() allocates anew."""
-        self.__dict__.setdefault("_staging", {}).pop((tuple(shape), count), None)
+        self.__dict__.setdefault("_staging", {}).pop((tuple(shape), count, np.dtype(dtype).char), None)
 
     def build_pyramids(self, slot, sync=True):
         fn = self._lib.klt_build_pyramids if sync else self._lib.klt_build_pyramids_async

@@ -42,6 +42,7 @@ class _FrameStager:
         import queue
         import threading
         self._frames, self._shape = frames, shape
+        self._float = bool(buffers) and buffers[0].dtype == np.float32     # the staging buffers take float frames (colour / float images)
         self._free = queue.Queue()
         self._stop = threading.Event()
         self._pull = threading.Lock()               # advancing the iterator + taking a buffer: one frame at a time, in order
@@ -80,14 +81,20 @@ class _FrameStager:
                         self._publish(idx, "error", e)
                         return
                     self._next_in = idx + 1
-                    key = FrameKey(img)                     # (an 8-bit Pillow image is read through its row table: no array is made of it)
-                    if key.stage_u8() != self._shape:
+                    key = FrameKey(img)                     # (a Pillow image is read through its row table: no array is made of it)
+                    kind = key.stage_kind()                 # ("u8" | "rgbx" | "f32", shape) of what can be written straight into a buffer
+                    if kind is None and self._float and isinstance(img, np.ndarray) and img.dtype == np.float32 and img.ndim == 2:
+                        kind = ("array", img.shape)
+                    if kind is None or tuple(kind[1]) != tuple(self._shape) or (kind[0] == "u8") == self._float:
                         self._publish(idx, "raw", key.array())      # the calling thread deals with it (size error, or a synchronous upload)
                         continue
                     buf = self._free.get()
                     if buf is None or self._stop.is_set():
                         return
-                key.copy_into(buf)
+                if kind[0] == "rgbx":
+                    key.float_into(buf)                     # Pillow's luma of a colour frame, straight into the pinned float buffer
+                else:
+                    key.copy_into(buf)
                 self._publish(idx, "staged", buf)
             except BaseException as e:                      # noqa: BLE001 -- handed to the calling thread
                 self._ended = True
@@ -172,9 +179,11 @@ def _track_sequence_locked(ctx, tc, frames, nFeatures, replace_lost, async_inges
             tables.append(base)
         return tables[ci] + 1 + off
 
-    workers = STAGER_WORKERS or (2 if nrows * ncols >= STAGER_THREADS_FROM_BYTES else 1)
-    stage_key = ((nrows, ncols), ring + 2 + workers)      # frames k+1 .. k+3 on their way, one being filled by each helper thread, one spare
-    stage = ctx.staging(*stage_key) if async_ingest and first.dtype == np.uint8 else None
+    workers = STAGER_WORKERS or (2 if first.nbytes >= STAGER_THREADS_FROM_BYTES else 1)
+    # frames k+1 .. k+3 on their way, one being filled by each helper thread, one spare; uint8 buffers for 8-bit frames, float32 ones for
+    # colour / float frames (the frame `img.convert("F")` would be, made by the helper threads: klt_upload_f32_async takes it from there)
+    stage_key = ((nrows, ncols), ring + 2 + workers, first.dtype)
+    stage = ctx.staging(*stage_key) if async_ingest and first.dtype in (np.uint8, np.float32) else None
     in_flight = []                          # staging buffer whose host-to-device copy may still be running
 
     def ingest(slot, img, k, staged=False, wait=True):

@@ -236,6 +236,9 @@ def test_colour_images_over_a_clip_equal_their_float_frames(monkeypatch):
     want[3] = np.array(ref_img.convert("F"))
     got = run(edited, False, edit=edit_pil)
     assert got == run(want, False)
-    a = KLTTrackSequence(make_tc(levels=3, ss=2, window=9, max_residue=10.0), colour, n)
+    a = KLTTrackSequence(make_tc(levels=3, ss=2, window=9, max_residue=10.0), colour, n)       # float staging buffers, filled by the helper thread
     b = KLTTrackSequence(make_tc(levels=3, ss=2, window=9, max_residue=10.0), floats, n)
-    assert np.array_equal(a.rec, b.rec)
+    c = KLTTrackSequence(make_tc(levels=3, ss=2, window=9, max_residue=10.0), colour, n, async_ingest=False)
+    mixed = [colour[0], floats[1], colour[2].convert("F"), colour[3], floats[4], colour[5]]
+    d = KLTTrackSequence(make_tc(levels=3, ss=2, window=9, max_residue=10.0), mixed, n)
+    assert np.array_equal(a.rec, b.rec) and np.array_equal(a.rec, c.rec) and np.array_equal(a.rec, d.rec)

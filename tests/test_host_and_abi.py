@@ -360,6 +360,30 @@ def test_frame_stager_with_several_helpers_delivers_in_order(workers):
     assert st.close() and not any(t.is_alive() for t in st._threads)
 
 
+def test_frame_stager_fills_float_buffers_with_colour_and_float_frames():
+    """KLTTrackSequence on colour frames: the staging buffers are float32 and the helper threads write the frame `img.convert("F")` would
+    be straight into them (Pillow's luma from the image's rows, float rows copied, float arrays copied); an 8-bit frame in such a clip
+    travels as "raw" (the calling thread converts and sends it synchronously)."""
+    from PIL import Image
+    from pyfeaturetrack_amd.trackSequence import _FrameStager
+    shape = (48, 64)
+    rng = np.random.default_rng(8)
+    rgb = [rng.integers(0, 256, shape + (3,), dtype=np.uint8) for _ in range(5)]
+    clip = [Image.fromarray(rgb[0], "RGB"), Image.fromarray(rgb[1], "RGB").convert("F"), np.array(Image.fromarray(rgb[2], "RGB").convert("F")),
+            Image.fromarray(rgb[3][..., 0]), Image.fromarray(np.dstack([rgb[4], rgb[4][..., 0]]), "RGBA")]
+    want = [np.array(im.convert("F")) if not isinstance(im, np.ndarray) else im for im in clip]
+    for workers in (1, 2):
+        st = _FrameStager(iter(clip), [np.zeros(shape, np.float32) for _ in range(4)], shape, workers=workers)
+        kinds = []
+        for k in range(5):
+            kind, item = st.next()
+            kinds.append(kind)
+            assert item.dtype == (np.uint8 if k == 3 else np.float32) and np.array_equal(item, want[k] if k != 3 else rgb[3][..., 0]), (workers, k)
+            if kind == "staged":
+                st.release(item)
+        assert kinds == ["staged", "staged", "staged", "raw", "staged"] and st.next() == (None, None) and st.close()
+
+
 def test_shard_gather_counts():
     """ShardGather's per-rank counts (klt_gatherv_featbuf_async) for shards of unequal size: 7 and 257 pairs over 2 / 8 ranks."""
     from pyfeaturetrack_amd.parallel import shard_range
@@ -934,8 +958,8 @@ def _recording_context():
         def release_slots(self, base, n=3):
             pass
 
-        def staging(self, shape, count=2):
-            return [np.empty(shape, np.uint8) for _ in range(count)]
+        def staging(self, shape, count=2, dtype=np.uint8):
+            return [np.empty(shape, dtype) for _ in range(count)]
 
         def _send(self, slot, arr):
             self.sent += 1
