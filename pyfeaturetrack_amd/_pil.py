@@ -148,7 +148,7 @@ def status():
 class Rows:
     """the row table of one image: `table` = address of nrows row addresses, each row `ncols` pixels of `kind` "u8" (1 byte), "rgbx"
     (4 bytes: R, G, B, pad / alpha) or "f32" (4 bytes); `keep` holds what keeps the storage alive for as long as this object lives
-    (the image and its capsule)"""
+    (the image, its core object -- the owner of the rows -- and the capsule)"""
     __slots__ = ("table", "nrows", "ncols", "keep", "kind", "row_bytes")
 
     def __init__(self, table, nrows, ncols, keep, kind="u8"):
@@ -176,6 +176,8 @@ def rows_of(img):
         if C.c_int.from_address(p + lay[0]).value != w or C.c_int.from_address(p + lay[1]).value != h or w <= 0 or h <= 0:
             return None
         table = C.c_void_p.from_address(p + lay[2 if kind == "u8" else 3]).value
-        return Rows(table, h, w, (img, cap), kind) if table else None
+        # (the capsule does not own the storage: the core object does.  Holding IT keeps the rows valid even if the image is given another
+        # core meanwhile -- paste / putpixel on an array-mapped image copy the storage first)
+        return Rows(table, h, w, (img, getattr(img, "im", None), cap), kind) if table else None
     except Exception:                                       # noqa: BLE001
         return None
