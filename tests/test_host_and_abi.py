@@ -1266,3 +1266,19 @@ def test_frame_cache_with_pillow_images_compares_every_pixel_without_converting(
     assert ctx.sent[-1][0] == 1 and ctx.sent[-1][1][17, 31] == (int(a[17, 31]) + 1) % 256
     assert cache.find(FrameKey(img), (0, 1), ctx) == 1 and cache.find(FrameKey(twin), (0, 1), ctx) == 0
     assert cache.filled_from(FrameKey(img), 1) and cache.filled_from(FrameKey(img), 0) and not cache.filled_from(FrameKey(twin), 0)
+
+
+def test_option_numbers_used_from_python_are_the_headers():
+    """the KLT_OPT_* numbers the Python layer, the bench and the tests pass to klt_set_option are the ones include/klt_gpu.h defines"""
+    hdr = open(os.path.join(REPO, "include", "klt_gpu.h")).read()
+    opts = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(KLT_OPT_[A-Z_]+)\s+(\d+)", hdr)}
+    assert len(set(opts.values())) == len(opts), "two options share a number"
+    from benchlib import common
+    from pyfeaturetrack_amd import trackSequence
+    assert trackSequence._OPT_BUILD_STREAM == opts["KLT_OPT_BUILD_STREAM"] and trackSequence._OPT_COPY_STREAMS == opts["KLT_OPT_COPY_STREAMS"]
+    assert trackSequence._OPT_SELECT_AFFINE_STATE == opts["KLT_OPT_SELECT_AFFINE_STATE"]
+    assert common.KLT_OPT_TRACK_TREE_SUMS == opts["KLT_OPT_TRACK_TREE_SUMS"]
+    assert opts["KLT_OPT_FAIL_ALLOC_AFTER"] == 19 and opts["KLT_OPT_SELECT_PARALLEL_NMS"] == 8 and opts["KLT_OPT_SCORE_SETS"] == 16      # (literals in tests / benchlib)
+    src = open(os.path.join(REPO, "pyfeaturetrack_amd", "csrc", "api_context.hip")).read()
+    for name in opts:
+        assert name in src, "%s is defined in the header but klt_set_option does not know it" % name
